@@ -1,0 +1,226 @@
+"""Drop-in for the reference's `model.backbone.CLIPViTFM` (model/backbone.py:12-309).
+
+Same constructor, attributes and methods; the arithmetic runs in libhybridgl.so
+(hand-written HIP for gfx950) through the C ABI of include/hybridgl.h.  Weights live in
+torch CUDA tensors owned by this object (torch = device memory + streams only).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, ops, weights
+from ._lib import HglClipTextW, HglClipVisionW, HglResBlockW, check
+
+FUSION = {"G2L": 0, "L2G": 1, "G2L&L2G": 2, "token_masking": 3, "attn_masking": 4, "crop": 5}
+
+
+def load_clip_state_dict(path):
+    """OpenAI CLIP checkpoint (JIT archive or plain state_dict), as clip/clip.py:119-142 does."""
+    try:
+        sd = torch.jit.load(path, map_location="cpu").state_dict()
+    except RuntimeError:
+        sd = torch.load(path, map_location="cpu")
+        if "state_dict" in sd:
+            sd = sd["state_dict"]
+    return {k: v.float().numpy() for k, v in sd.items()
+            if k not in ("input_resolution", "context_length", "vocab_size")}
+
+
+def _infer_config(sd):
+    """clip/model.py:474-503 build_model geometry inference (ViT only)."""
+    vw = sd["visual.conv1.weight"].shape[0]
+    vl = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    vp = sd["visual.conv1.weight"].shape[-1]
+    grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    tw = sd["ln_final.weight"].shape[0]
+    tl = len(set(k.split(".")[2] for k in sd if k.startswith("transformer.resblocks")))
+    return dict(embed_dim=sd["text_projection"].shape[1], image_resolution=vp * grid, vision_layers=vl,
+                vision_width=vw, vision_patch_size=vp, context_length=sd["positional_embedding"].shape[0],
+                vocab_size=sd["token_embedding.weight"].shape[0], transformer_width=tw,
+                transformer_heads=tw // 64, transformer_layers=tl)
+
+
+class _Blocks:
+    """Device tensors + the C array of HglResBlockW for one transformer."""
+
+    def __init__(self, sd, prefix, layers, device):
+        self.t = []  # keep tensors alive
+        self.arr = (HglResBlockW * layers)()
+        names = [("ln1_w", "ln_1.weight"), ("ln1_b", "ln_1.bias"),
+                 ("in_proj_w", "attn.in_proj_weight"), ("in_proj_b", "attn.in_proj_bias"),
+                 ("out_proj_w", "attn.out_proj.weight"), ("out_proj_b", "attn.out_proj.bias"),
+                 ("ln2_w", "ln_2.weight"), ("ln2_b", "ln_2.bias"),
+                 ("fc_w", "mlp.c_fc.weight"), ("fc_b", "mlp.c_fc.bias"),
+                 ("proj_w", "mlp.c_proj.weight"), ("proj_b", "mlp.c_proj.bias")]
+        for i in range(layers):
+            for field, key in names:
+                t = _to_dev(sd[f"{prefix}.resblocks.{i}.{key}"], device)
+                self.t.append(t)
+                setattr(self.arr[i], field, t.data_ptr())
+
+
+def _to_dev(a, device):
+    if isinstance(a, torch.Tensor):
+        t = a.detach().to(torch.float32)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return t.contiguous().to(device)
+
+
+class _ClipModel:
+    """The `.model` attribute: what the reference reaches as Model.model.* (clip/model.py:340-431)."""
+
+    def __init__(self, sd, cfg, device):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dtype = torch.float32  # convert_weights is disabled in the reference (clip/model.py:509)
+        vw, vl = cfg["vision_width"], cfg["vision_layers"]
+        p = cfg["vision_patch_size"]
+        grid = cfg["image_resolution"] // p
+        self._vb = _Blocks(sd, "visual.transformer", vl, device)
+        self._vt = {
+            "conv1": _to_dev(np.asarray(sd["visual.conv1.weight"]).reshape(vw, -1), device),
+            "cls": _to_dev(sd["visual.class_embedding"], device),
+            "pos": _to_dev(sd["visual.positional_embedding"], device),
+            "ln_pre_w": _to_dev(sd["visual.ln_pre.weight"], device),
+            "ln_pre_b": _to_dev(sd["visual.ln_pre.bias"], device),
+            "ln_post_w": _to_dev(sd["visual.ln_post.weight"], device),
+            "ln_post_b": _to_dev(sd["visual.ln_post.bias"], device),
+            "proj_t": _to_dev(np.ascontiguousarray(np.asarray(sd["visual.proj"]).T), device),
+        }
+        v = HglClipVisionW()
+        v.width, v.layers, v.heads, v.patch, v.grid, v.embed = vw, vl, vw // 64, p, grid, cfg["embed_dim"]
+        v.conv1_w = self._vt["conv1"].data_ptr()
+        v.class_embedding = self._vt["cls"].data_ptr()
+        v.positional_embedding = self._vt["pos"].data_ptr()
+        v.ln_pre_w, v.ln_pre_b = self._vt["ln_pre_w"].data_ptr(), self._vt["ln_pre_b"].data_ptr()
+        v.blocks = C.cast(self._vb.arr, C.POINTER(HglResBlockW))
+        v.ln_post_w, v.ln_post_b = self._vt["ln_post_w"].data_ptr(), self._vt["ln_post_b"].data_ptr()
+        v.proj_t = self._vt["proj_t"].data_ptr()
+        self.visual_w = v
+
+        tw, tl = cfg["transformer_width"], cfg["transformer_layers"]
+        self._tb = _Blocks(sd, "transformer", tl, device)
+        self._tt = {
+            "emb": _to_dev(sd["token_embedding.weight"], device),
+            "pos": _to_dev(sd["positional_embedding"], device),
+            "ln_w": _to_dev(sd["ln_final.weight"], device),
+            "ln_b": _to_dev(sd["ln_final.bias"], device),
+            "proj_t": _to_dev(np.ascontiguousarray(np.asarray(sd["text_projection"]).T), device),
+        }
+        t = HglClipTextW()
+        t.width, t.layers, t.heads = tw, tl, cfg["transformer_heads"]
+        t.context, t.vocab, t.embed = cfg["context_length"], cfg["vocab_size"], cfg["embed_dim"]
+        t.token_embedding = self._tt["emb"].data_ptr()
+        t.positional_embedding = self._tt["pos"].data_ptr()
+        t.blocks = C.cast(self._tb.arr, C.POINTER(HglResBlockW))
+        t.ln_final_w, t.ln_final_b = self._tt["ln_w"].data_ptr(), self._tt["ln_b"].data_ptr()
+        t.text_projection_t = self._tt["proj_t"].data_ptr()
+        self.text_w = t
+        self.logit_scale = _to_dev(np.asarray(sd["logit_scale"], dtype=np.float32).reshape(()), device)
+        self._logit_scale_exp = float(np.exp(np.float32(np.asarray(sd["logit_scale"]))))
+        self.context_length = cfg["context_length"]
+
+    def encode_text(self, text, target_noun_index=None):
+        """CLIP.encode_text (clip/model.py:414-431). text: [B, context] integer tokens."""
+        if target_noun_index:
+            raise NotImplementedError("target_noun_index pooling is not on the Hybridgl_main path")
+        lib = _lib.load()
+        if not text.is_cuda:
+            raise _lib.HybridGLError("encode_text: tokens must be on the GPU (no CPU path exists)")
+        tok = text.to(torch.int32).contiguous()
+        B = tok.shape[0]
+        assert tok.shape[1] == self.context_length
+        need = lib.hgl_clip_text_workspace_bytes(C.byref(self.text_w), B)
+        ws = ops.workspace(need, tok.device, "clip_text")
+        out = torch.empty((B, self.cfg["embed_dim"]), dtype=torch.float32, device=tok.device)
+        check(lib.hgl_clip_encode_text(C.byref(self.text_w), tok.data_ptr(), B, out.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), ops._stream()), "hgl_clip_encode_text")
+        return out
+
+
+class CLIPViTFM:
+    """model/backbone.py:12 -- `CLIPViTFM(model_name='ViT-B/16', size=224)`.
+
+    Extra keyword arguments (not in the reference): `state_dict` / `checkpoint` to supply
+    weights (the reference downloads them, clip/clip.py:94-142; there is no network here),
+    `seed` for the synthetic weights used when neither is given, `device`.
+    """
+
+    def __init__(self, model_name="ViT-B/16", size=224, state_dict=None, checkpoint=None, seed=0,
+                 device="cuda"):
+        _lib.load()
+        # model/backbone.py:16-21 (+ the ViT-L/14 extension of SURVEY.md note 2)
+        if model_name in ("ViT-B/32", "ViT-B/16", "tiny"):
+            self.last_layer, self.num_heads = 10, 12
+        elif model_name == "ViT-L/14":
+            self.last_layer, self.num_heads = 22, 16
+        else:
+            raise ValueError(f"unsupported model_name {model_name!r}")
+        checkpoint = checkpoint or os.environ.get("HYBRIDGL_CLIP_CHECKPOINT")
+        if state_dict is None and checkpoint:
+            state_dict = load_clip_state_dict(checkpoint)
+        if state_dict is None:
+            state_dict = weights.clip_state_dict(model_name, seed)
+        cfg = _infer_config(state_dict)
+        self.model_name = model_name
+        self.model = _ClipModel(state_dict, cfg, device)
+
+    # nn.Module-compatible no-ops used by Hybridgl_main.py:47-48
+    def to(self, device):
+        if torch.device(device).type != "cuda":
+            raise _lib.HybridGLError("CLIPViTFM runs on the GPU only (no CPU path exists)")
+        return self
+
+    def eval(self):
+        return self
+
+    @property
+    def device(self):
+        return self.model.device
+
+    @property
+    def dtype(self):
+        return self.model.dtype
+
+    def calculate_score(self, image_features, text_features, visual_norm_dim=1):
+        """model/backbone.py:74-87 -> [N, T] logits."""
+        assert visual_norm_dim == 1
+        return ops.calculate_score(image_features.contiguous(), text_features.contiguous(),
+                                   self.model._logit_scale_exp)
+
+    def forward(self, local_imgs, global_imgs, pred_masks, masking_block=None, fusion_mode="G2L"):
+        """model/backbone.py:117 -> [N, embed_dim]."""
+        lib = _lib.load()
+        if fusion_mode not in FUSION:
+            raise ValueError(f"unknown fusion_mode {fusion_mode!r}")
+        mode = FUSION[fusion_mode]
+        N = local_imgs.shape[0]
+        res = self.model.cfg["image_resolution"]
+        assert tuple(local_imgs.shape[1:]) == (3, res, res), "local_imgs must be [N,3,res,res]"
+        local_imgs = local_imgs.contiguous()
+        lp = ops._dev(local_imgs, torch.float32, "local_imgs")
+        gp = None
+        if global_imgs is not None:
+            assert global_imgs.shape == local_imgs.shape
+            global_imgs = global_imgs.contiguous()
+            gp = ops._dev(global_imgs, torch.float32, "global_imgs")
+        mp, Hm, Wm = None, 0, 0
+        if pred_masks is not None:
+            assert pred_masks.shape[0] == N
+            Hm, Wm = pred_masks.shape[1:]
+            pm = pred_masks if pred_masks.dtype in (torch.bool, torch.uint8) else (pred_masks != 0)
+            mp, pm = ops._u8(pm.contiguous(), "pred_masks")
+        v = self.model.visual_w
+        need = lib.hgl_clip_hybrid_workspace_bytes(C.byref(v), N, Hm, Wm, mode)
+        ws = ops.workspace(need, local_imgs.device, "clip_hybrid")
+        out = torch.empty((N, self.model.cfg["embed_dim"]), dtype=torch.float32, device=local_imgs.device)
+        check(lib.hgl_clip_hybrid_forward(C.byref(v), lp, gp, mp, N, Hm, Wm, mode,
+                                          -1 if masking_block is None else int(masking_block),
+                                          self.last_layer, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          ops._stream()), "hgl_clip_hybrid_forward")
+        return out
+
+    __call__ = forward

@@ -1,0 +1,83 @@
+// Error plumbing, device probing and the extern "C" wrappers of the primitive operators.
+#include "hgl_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void hgl_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hgl_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    hgl_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return HGL_ELAUNCH;
+  }
+  return HGL_OK;
+}
+
+int hgl_require_device() {
+  static int cached = -1;
+  if (cached < 0) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    cached = (e == hipSuccess && n > 0) ? 1 : 0;
+    if (e != hipSuccess) (void)hipGetLastError();
+  }
+  if (!cached) {
+    hgl_set_error("no HIP device visible: libhybridgl has no CPU path");
+    return HGL_ENODEVICE;
+  }
+  return HGL_OK;
+}
+
+extern "C" {
+
+int hgl_abi_version(void) { return HGL_ABI_VERSION; }
+const char* hgl_last_error(void) { return g_err; }
+
+int hgl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int hgl_gemm_f32(const float* A, const float* W, const float* bias, const float* R, float* C, int M,
+                 int N, int K, int lda, int ldw, int ldr, int ldc, int batch, long long sA,
+                 long long sW, long long sR, long long sC, int act, void* stream) {
+  HGL_TRY(hgl_require_device());
+  return hgl_launch_gemm(A, W, bias, R, C, M, N, K, lda, ldw, ldr, ldc, batch, sA, sW, sR, sC, act,
+                         (hipStream_t)stream);
+}
+
+int hgl_layernorm_f32(const float* x, const float* w, const float* b, float* y, int rows, int D,
+                      float eps, void* stream) {
+  HGL_TRY(hgl_require_device());
+  return hgl_launch_layernorm(x, w, b, y, rows, D, eps, (hipStream_t)stream);
+}
+
+int hgl_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int H, int Sq,
+                      int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
+                      long long skb, long long svb, long long sob, float scale, int mask_kind,
+                      const uint8_t* keep, int keep_b0, int keep_n, const float* rel_h,
+                      const float* rel_w, int kh, int kw, void* stream) {
+  HGL_TRY(hgl_require_device());
+  return hgl_launch_attention(q, k, v, out, B, H, Sq, Sk, hd, ldq, ldk, ldv, ldo, sqb, skb, svb, sob,
+                              scale, mask_kind, keep, keep_b0, keep_n, rel_h, rel_w, kh, kw,
+                              (hipStream_t)stream);
+}
+
+int hgl_mask_resize(const uint8_t* masks, int N, int Hm, int Wm, int g, float* pm, void* stream) {
+  HGL_TRY(hgl_require_device());
+  return hgl_launch_mask_resize(masks, N, Hm, Wm, g, pm, nullptr, (hipStream_t)stream);
+}
+
+}  // extern "C"

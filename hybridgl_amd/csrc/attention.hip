@@ -1,0 +1,232 @@
+// Fused fp32 attention on the CDNA4 matrix cores (flash-style, online softmax).
+//
+// Replaces nn.MultiheadAttention inside ResidualAttentionBlock (clip/model.py:209,
+// 220-229) including the per-call CLS-row mask built by make_attn_mask
+// (model/backbone.py:108-115, never materialised here: [N,196] keep bytes instead of
+// a [N*12,197,197] tensor), the causal text mask (clip/model.py:396-402), SAM's
+// Attention with decomposed relative position bias (image_encoder.py:224-240,
+// 325-361) and the decoder's Attention (transformer.py:185-240).
+//
+// Structure (one workgroup = 4 waves = 128 queries of one (batch, head)):
+//   * "swapped" QK^T: S^T[key][query] = K Q^T with v_mfma_f32_32x32x2_f32, so each
+//     lane owns ONE query column: row-max / row-sum are in-register reductions plus a
+//     single cross-half exchange (lanes l and l+32 hold the other 16 keys of the tile).
+//   * the P^T accumulator registers are directly the B operand of the PV product
+//     O^T[d][query] += V^T[d][key] P^T[key][query]: no LDS round trip for P.
+//   * K and V tiles of 64 keys are staged in LDS (K rows padded by one float4 so the
+//     ds_read_b128 fragment reads are conflict free; V read as ds_read_b32 rows).
+//   * everything fp32: exact products, fp32 accumulation -> matches the fp32 reference.
+#include "hgl_common.h"
+
+namespace {
+
+constexpr int KV_CHUNK = 64;
+constexpr int NEG_BIG_BITS = 0xff800000;  // -inf
+
+struct AttnArgs {
+  const float *q, *k, *v;
+  float* out;
+  int B, H, Sq, Sk;
+  int ldq, ldk, ldv, ldo;
+  long long sqb, skb, svb, sob;
+  float scale;
+  int mask_kind;
+  const uint8_t* keep;
+  int keep_b0, keep_n;
+  const float *rel_h, *rel_w;
+  int kh, kw;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_f32_kernel(AttnArgs a) {
+  constexpr int HDP = HD + 4;              // padded K row (floats)
+  constexpr int DT = (HD + 31) / 32;       // 32-wide d tiles of the output
+  constexpr int VLD = DT * 32;             // V row in LDS (zero padded to a multiple of 32)
+  constexpr int QC = HD / 8;               // 8-wide d chunks (HD % 8 == 0)
+  __shared__ __attribute__((aligned(16))) float Ks[KV_CHUNK * HDP];
+  __shared__ __attribute__((aligned(16))) float Vs[KV_CHUNK * VLD];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y;
+  const int b = bh / a.H, hh = bh - b * a.H;
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int qi = q0 + r;  // this lane's query
+  const bool qvalid = qi < a.Sq;
+
+  const float* qp = a.q + b * a.sqb + (long long)(qvalid ? qi : 0) * a.ldq + hh * HD;
+  const float* kp = a.k + b * a.skb + hh * HD;
+  const float* vp = a.v + b * a.svb + hh * HD;
+
+  // Q fragment: lane (r,h) holds Q[q][8c+4h+j] (pre-scaled)
+  f32x4 qf[QC];
+#pragma unroll
+  for (int c = 0; c < QC; ++c) {
+    f32x4 v = qvalid ? *(const f32x4*)(qp + 8 * c + 4 * h) : f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= a.scale;
+    qf[c] = v;
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  const float NEG_INF = __int_as_float(NEG_BIG_BITS);
+  float m_run = NEG_INF, l_run = 0.f;
+
+  const uint8_t* keep_row = nullptr;
+  if (a.mask_kind == HGL_MASK_CLS_KEEP && b >= a.keep_b0)
+    keep_row = a.keep + (long long)((b - a.keep_b0) % a.keep_n) * (a.Sk - 1);
+  const float* relh = a.rel_h ? a.rel_h + ((long long)bh * a.Sq + (qvalid ? qi : 0)) * a.kh : nullptr;
+  const float* relw = a.rel_w ? a.rel_w + ((long long)bh * a.Sq + (qvalid ? qi : 0)) * a.kw : nullptr;
+
+  // causal: keys beyond the last query of this workgroup are never needed
+  int sk_eff = a.Sk;
+  if (a.mask_kind == HGL_MASK_CAUSAL) sk_eff = min(a.Sk, (int)(blockIdx.x * 4 + 4) * 32);
+
+  for (int kc = 0; kc < sk_eff; kc += KV_CHUNK) {
+    __syncthreads();  // previous chunk fully consumed
+    // ---- stage K,V chunk (rows beyond Sk are zero) ----
+    for (int i = t; i < KV_CHUNK * (HD / 4); i += 256) {
+      const int row = i / (HD / 4), c4 = i - row * (HD / 4);
+      const int kg = kc + row;
+      f32x4 kvv = f32x4{0, 0, 0, 0}, vvv = f32x4{0, 0, 0, 0};
+      if (kg < a.Sk) {
+        kvv = *(const f32x4*)(kp + (long long)kg * a.ldk + c4 * 4);
+        vvv = *(const f32x4*)(vp + (long long)kg * a.ldv + c4 * 4);
+      }
+      *(f32x4*)(Ks + row * HDP + c4 * 4) = kvv;
+      *(f32x4*)(Vs + row * VLD + c4 * 4) = vvv;
+    }
+    if (VLD > HD) {  // zero the d padding of V once per chunk
+      constexpr int PADW = (VLD - HD) > 0 ? (VLD - HD) : 1;
+      for (int i = t; i < KV_CHUNK * PADW; i += 256) {
+        const int row = i / PADW, c = i - row * PADW;
+        Vs[row * VLD + HD + c] = 0.f;
+      }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int kt = 0; kt < KV_CHUNK / 32; ++kt) {
+      const int kbase = kc + kt * 32;
+      if (kbase >= sk_eff) break;  // uniform
+      // ---- S^T tile: [32 keys x 32 queries] ----
+      f32x16 s;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+      const float* krow = Ks + (kt * 32 + r) * HDP + 4 * h;
+#pragma unroll
+      for (int c = 0; c < QC; ++c) {
+        const f32x4 kf = *(const f32x4*)(krow + 8 * c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[c][j], s, 0, 0, 0);
+      }
+      // s[e] = S^T[key = kbase + (e&3) + 8*(e>>2) + 4*h][query qi]
+      float mx = NEG_INF;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float sv = s[e];
+        if (relh && kg < a.Sk) sv += relh[kg / a.kw] + relw[kg % a.kw];
+        bool masked = kg >= a.Sk;
+        if (a.mask_kind == HGL_MASK_CAUSAL) masked |= kg > qi;
+        if (keep_row && qi == 0 && kg >= 1 && kg < a.Sk) masked |= keep_row[kg - 1] == 0;
+        sv = masked ? NEG_INF : sv;
+        s[e] = sv;
+        mx = fmaxf(mx, sv);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      // all keys so far masked -> keep everything at zero
+      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+      const float alpha = expf(m_run - m_use);  // m_run=-inf -> 0
+      float rs = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = expf(s[e] - m_use);
+        s[e] = p;
+        rs += p;
+      }
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+      // ---- O^T += V^T P^T : A = V^T (lane (d=r,h): V[key(e,h)][d]), B = P^T = s[e] ----
+      const float* vbase = Vs + (kt * 32 + 4 * h) * VLD + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float* vr = vbase + ((e & 3) + 8 * (e >> 2)) * VLD;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[d * 32], s[e], o[d], 0, 0, 0);
+      }
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (qvalid) {
+    float* op = a.out + b * a.sob + (long long)qi * a.ldo + hh * HD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * h;  // o[d][4g..4g+3] = O^T[dd..dd+3][qi]
+        if (dd < HD) {
+          f32x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = o[d][4 * g + e] * inv;
+          *(f32x4*)(op + dd) = w;
+        }
+      }
+    }
+  }
+}
+
+template <int HD>
+int launch_hd(const AttnArgs& a, hipStream_t st) {
+  dim3 grid((a.Sq + 127) / 128, a.B * a.H);
+  hipLaunchKernelGGL(attn_f32_kernel<HD>, grid, dim3(256), 0, st, a);
+  return hgl_check_launch("attention_f32");
+}
+
+}  // namespace
+
+int hgl_launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H,
+                         int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
+                         long long skb, long long svb, long long sob, float scale, int mask_kind,
+                         const uint8_t* keep, int keep_b0, int keep_n, const float* rel_h,
+                         const float* rel_w, int kh, int kw, hipStream_t st) {
+  HGL_REQUIRE(q && k && v && out, "attention: null operand");
+  HGL_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0, "attention: bad shape");
+  HGL_REQUIRE((ldq & 3) == 0 && (ldk & 3) == 0 && (ldv & 3) == 0 && (ldo & 3) == 0, "attention: leading dims must be multiples of 4");
+  HGL_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "attention: operands must be 16-byte aligned");
+  HGL_REQUIRE(((sqb | skb | svb | sob) & 3) == 0, "attention: batch strides must be multiples of 4");
+  HGL_REQUIRE(mask_kind >= 0 && mask_kind <= 2, "attention: bad mask kind %d", mask_kind);
+  HGL_REQUIRE(mask_kind != HGL_MASK_CLS_KEEP || keep, "attention: HGL_MASK_CLS_KEEP needs keep bytes");
+  HGL_REQUIRE((rel_h == nullptr) == (rel_w == nullptr), "attention: rel_h and rel_w go together");
+  HGL_REQUIRE(!rel_h || (kh > 0 && kw > 0 && kh * kw == Sk), "attention: kh*kw must equal Sk");
+  HGL_REQUIRE((long long)B * H <= 65535, "attention: B*H too large for grid.y");
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.out = out;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.sqb = sqb; a.skb = skb; a.svb = svb; a.sob = sob;
+  a.scale = scale; a.mask_kind = mask_kind; a.keep = keep; a.keep_b0 = keep_b0; a.keep_n = keep_n > 0 ? keep_n : B;
+  a.rel_h = rel_h; a.rel_w = rel_w; a.kh = kh; a.kw = kw;
+  switch (hd) {
+    case 16: return launch_hd<16>(a, st);
+    case 32: return launch_hd<32>(a, st);
+    case 64: return launch_hd<64>(a, st);
+    case 80: return launch_hd<80>(a, st);
+    default:
+      hgl_set_error("attention: unsupported head dim %d (16,32,64,80)", hd);
+      return HGL_EINVAL;
+  }
+}

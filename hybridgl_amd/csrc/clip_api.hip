@@ -1,0 +1,296 @@
+// Host orchestration of the CLIP hybrid encoder and text encoder behind the C ABI.
+//
+//   hgl_clip_hybrid_forward  == CLIPViTFM.forward          (model/backbone.py:117-309)
+//   hgl_clip_encode_text     == CLIP.encode_text           (clip/model.py:414-431)
+//
+// Activations are kept batch-major [B, S, D] (the reference uses [S, B, D]; the math is
+// identical).  The local and global streams (and the two hybrid streams of G2L&L2G) are
+// stacked along B so every transformer block is ONE sequence of large GEMMs.  Streams whose
+// final-block output is never consumed (SURVEY.md section 3.3 "dead work") are not computed.
+#include "hgl_common.h"
+#include <math.h>
+
+namespace {
+
+struct BlockBufs {
+  float* H;    // [M, D]   LN output / attention output
+  float* QKV;  // [M, 3D]
+  float* F;    // [M, 4D]
+};
+
+// x <- x + attn(ln_1 x) ; x <- x + mlp(ln_2 x)      (clip/model.py:244-257)
+int run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, const BlockBufs& bf,
+              int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st) {
+  const int M = B * S;
+  const int hd = D / heads;
+  HGL_TRY(hgl_launch_layernorm(X, w.ln1_w, w.ln1_b, bf.H, M, D, 1e-5f, st));
+  HGL_TRY(hgl_launch_gemm(bf.H, w.in_proj_w, w.in_proj_b, nullptr, bf.QKV, M, 3 * D, D, D, D, 0,
+                          3 * D, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_attention(bf.QKV, bf.QKV + D, bf.QKV + 2 * D, bf.H, B, heads, S, S, hd, 3 * D,
+                               3 * D, 3 * D, D, (long long)S * 3 * D, (long long)S * 3 * D,
+                               (long long)S * 3 * D, (long long)S * D, 1.0f / sqrtf((float)hd),
+                               mask_kind, keep, keep_b0, keep_n, nullptr, nullptr, 0, 0, st));
+  HGL_TRY(hgl_launch_gemm(bf.H, w.out_proj_w, w.out_proj_b, X, X, M, D, D, D, D, D, D, 1, 0, 0, 0, 0,
+                          HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_layernorm(X, w.ln2_w, w.ln2_b, bf.H, M, D, 1e-5f, st));
+  HGL_TRY(hgl_launch_gemm(bf.H, w.fc_w, w.fc_b, nullptr, bf.F, M, 4 * D, D, D, D, 0, 4 * D, 1, 0, 0,
+                          0, 0, HGL_ACT_QUICKGELU, st));
+  HGL_TRY(hgl_launch_gemm(bf.F, w.proj_w, w.proj_b, X, X, M, D, 4 * D, 4 * D, 4 * D, D, D, 1, 0, 0,
+                          0, 0, HGL_ACT_NONE, st));
+  return HGL_OK;
+}
+
+int n_streams(int mode) {
+  switch (mode) {
+    case HGL_FUSION_G2L:
+    case HGL_FUSION_L2G: return 2;
+    case HGL_FUSION_G2L_L2G: return 4;
+    default: return 1;
+  }
+}
+
+struct ClipPlan {
+  float *X, *Y, *H, *QKV, *F, *pm, *cls_rows, *cls_ln;
+  uint8_t* keep;
+};
+
+// identical carve for the size query (dry) and the real run
+bool carve(HglArena& ar, const HglClipVisionW* w, int N, int mode, ClipPlan& p) {
+  const int D = w->width, S = w->grid * w->grid + 1;
+  const size_t ns = n_streams(mode);
+  const size_t act = ns * N * S * (size_t)D;
+  p.X = ar.take<float>(act);
+  p.Y = ar.take<float>(act);
+  p.H = ar.take<float>(act);
+  p.QKV = ar.take<float>(3 * act);
+  // F also holds the im2col matrix of one stream (N*P*3p^2 floats)
+  const size_t cols = (size_t)N * (S - 1) * 3 * w->patch * w->patch;
+  p.F = ar.take<float>(4 * act > cols ? 4 * act : cols);
+  p.pm = ar.take<float>((size_t)N * (S - 1));
+  p.keep = ar.take<uint8_t>((size_t)N * (S - 1));
+  p.cls_rows = ar.take<float>((size_t)2 * N * D);
+  p.cls_ln = ar.take<float>((size_t)2 * N * D);
+  return ar.ok();
+}
+
+// patch embedding + cls + pos + ln_pre for `n_img` images -> X [n_img, S, D]
+int embed_images(const HglClipVisionW* w, const float* imgs, int n_img, float* X, const ClipPlan& p,
+                 hipStream_t st) {
+  const int D = w->width, g = w->grid, P = g * g, S = P + 1, kd = 3 * w->patch * w->patch;
+  float* cols = p.F;
+  float* tok = p.QKV;
+  HGL_TRY(hgl_launch_im2col_patch(imgs, n_img, g * w->patch, w->patch, cols, st));
+  HGL_TRY(hgl_launch_gemm(cols, w->conv1_w, nullptr, nullptr, tok, n_img * P, D, kd, kd, kd, 0, D, 1,
+                          0, 0, 0, 0, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_assemble_lnpre(tok, w->class_embedding, w->positional_embedding, w->ln_pre_w,
+                                    w->ln_pre_b, X, n_img, S, D, st));
+  return HGL_OK;
+}
+
+// ln_post(x[:,0]) @ proj  (+ R)   (model/backbone.py:254-260)
+int head(const HglClipVisionW* w, const float* X, int N, float* out, const float* R,
+         const ClipPlan& p, hipStream_t st) {
+  const int D = w->width, S = w->grid * w->grid + 1, E = w->embed;
+  HGL_TRY(hgl_launch_gather_rows(X, (long long)S * D, N, D, p.cls_rows, st));
+  HGL_TRY(hgl_launch_layernorm(p.cls_rows, w->ln_post_w, w->ln_post_b, p.cls_ln, N, D, 1e-5f, st));
+  HGL_TRY(hgl_launch_gemm(p.cls_ln, w->proj_t, nullptr, R, out, N, E, D, D, D, E, E, 1, 0, 0, 0, 0,
+                          HGL_ACT_NONE, st));
+  return HGL_OK;
+}
+
+bool valid_vision(const HglClipVisionW* w) {
+  return w && w->width > 0 && w->layers > 0 && w->heads > 0 && w->patch > 0 && w->grid > 0 &&
+         w->embed > 0 && w->width % w->heads == 0 && (w->width & 3) == 0 && (w->embed & 3) == 0 &&
+         w->conv1_w && w->class_embedding && w->positional_embedding && w->ln_pre_w && w->ln_pre_b &&
+         w->blocks && w->ln_post_w && w->ln_post_b && w->proj_t;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hgl_clip_hybrid_workspace_bytes(const HglClipVisionW* w, int N, int Hm, int Wm, int fusion_mode) {
+  (void)Hm; (void)Wm;
+  if (!valid_vision(w) || N <= 0) return 0;
+  HglArena ar(nullptr, 0);
+  ClipPlan p;
+  carve(ar, w, N, fusion_mode, p);
+  return ar.off;
+}
+
+int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, const float* global_imgs,
+                            const uint8_t* masks, int N, int Hm, int Wm, int fusion_mode,
+                            int masking_block, int last_layer, float* out, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(valid_vision(w), "clip_hybrid_forward: invalid weight struct");
+  HGL_REQUIRE(local_imgs && out && N > 0, "clip_hybrid_forward: null input");
+  HGL_REQUIRE(fusion_mode >= 0 && fusion_mode <= 5, "clip_hybrid_forward: bad fusion mode %d", fusion_mode);
+  const bool two_stream = n_streams(fusion_mode) >= 2;
+  HGL_REQUIRE(!two_stream || global_imgs, "clip_hybrid_forward: global_imgs required for this fusion mode");
+  const bool need_masks = fusion_mode != HGL_FUSION_CROP;
+  HGL_REQUIRE(!need_masks || (masks && Hm > 0 && Wm > 0), "clip_hybrid_forward: masks required");
+  if (masking_block < 0) masking_block = last_layer;
+  HGL_REQUIRE(last_layer >= 0 && last_layer + 1 < w->layers + 1, "clip_hybrid_forward: bad last_layer %d", last_layer);
+  // the reference's return sits inside the per-block loop: the returning block must exist and be
+  // at or after masking_block (model/backbone.py:178,197,220,254,294)
+  const int ret_block = fusion_mode == HGL_FUSION_ATTN_MASKING ? last_layer : last_layer + 1;
+  HGL_REQUIRE(fusion_mode == HGL_FUSION_CROP || (ret_block < w->layers && masking_block <= ret_block && masking_block >= 0),
+              "clip_hybrid_forward: masking_block %d / return block %d outside the %d-layer transformer", masking_block, ret_block, w->layers);
+
+  HglArena ar(workspace, workspace_bytes);
+  ClipPlan p;
+  if (!workspace || !carve(ar, w, N, fusion_mode, p)) {
+    hgl_set_error("clip_hybrid_forward: workspace too small (%zu bytes given)", workspace_bytes);
+    return HGL_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int D = w->width, g = w->grid, S = g * g + 1, heads = w->heads;
+  const long long sN = (long long)N * S * D;  // elements per stream
+  BlockBufs bf{p.H, p.QKV, p.F};
+
+  // ---- patch embedding of the streams ----
+  HGL_TRY(embed_images(w, local_imgs, N, p.X, p, st));
+  if (two_stream) HGL_TRY(embed_images(w, global_imgs, N, p.X + sN, p, st));
+  if (need_masks) HGL_TRY(hgl_launch_mask_resize(masks, N, Hm, Wm, g, p.pm, p.keep, st));
+
+  if (fusion_mode == HGL_FUSION_CROP) {
+    for (int l = 0; l < w->layers; ++l)
+      HGL_TRY(run_block(w->blocks[l], p.X, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
+    return head(w, p.X, N, out, nullptr, p, st);
+  }
+
+  const int nb0 = two_stream ? 2 * N : N;
+  for (int l = 0; l < masking_block; ++l)
+    HGL_TRY(run_block(w->blocks[l], p.X, nb0, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
+
+  float* X = p.X;
+  float* Y = p.Y;
+  switch (fusion_mode) {
+    case HGL_FUSION_TOKEN_MASKING: {
+      for (int l = masking_block; l <= ret_block; ++l) {
+        // x = cat(cls, x*pm)  (model/backbone.py:163-176)
+        HGL_TRY(hgl_launch_mix(X, nullptr, 0.f, X, 1.f, p.pm, N, S, D, st));
+        HGL_TRY(run_block(w->blocks[l], X, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
+      }
+      return head(w, X, N, out, nullptr, p, st);
+    }
+    case HGL_FUSION_ATTN_MASKING: {
+      for (int l = masking_block; l <= ret_block; ++l)
+        HGL_TRY(run_block(w->blocks[l], X, N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 0, N, st));
+      return head(w, X, N, out, nullptr, p, st);
+    }
+    case HGL_FUSION_G2L: {
+      // streams: [local | global].  local' = blk(local + 2*tokmask(global)); global' = blk(global, keep)
+      for (int l = masking_block; l <= ret_block; ++l) {
+        HGL_TRY(hgl_launch_mix(Y, X, 1.f, X + sN, 2.f, p.pm, N, S, D, st));
+        if (l < ret_block) {
+          hipMemcpyAsync(Y + sN, X + sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+          HGL_TRY(run_block(w->blocks[l], Y, 2 * N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, N, N, st));
+        } else {  // the global stream of the returning block is dead
+          HGL_TRY(run_block(w->blocks[l], Y, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
+        }
+        float* t = X; X = Y; Y = t;
+      }
+      return head(w, X, N, out, nullptr, p, st);
+    }
+    case HGL_FUSION_L2G: {
+      // local' = blk(local); global' = blk(local + 2*global, keep)
+      for (int l = masking_block; l <= ret_block; ++l) {
+        HGL_TRY(hgl_launch_mix(Y + sN, X, 1.f, X + sN, 2.f, nullptr, N, S, D, st));
+        if (l < ret_block) {
+          hipMemcpyAsync(Y, X, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+          HGL_TRY(run_block(w->blocks[l], Y, 2 * N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, N, N, st));
+        } else {  // the local stream of the returning block is dead
+          HGL_TRY(run_block(w->blocks[l], Y + sN, N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 0, N, st));
+        }
+        float* t = X; X = Y; Y = t;
+      }
+      return head(w, X + sN, N, out, nullptr, p, st);
+    }
+    case HGL_FUSION_G2L_L2G: {
+      // stream order here: [xl | hl | xg | hg]  (keep applies to the last two)
+      // init: xg currently at X+sN -> move to slot 2; hl = xl, hg = xg (model/backbone.py:272-276)
+      hipMemcpyAsync(X + 2 * sN, X + sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+      hipMemcpyAsync(X + sN, X, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+      hipMemcpyAsync(X + 3 * sN, X + 2 * sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+      for (int l = masking_block; l <= ret_block; ++l) {
+        // hl_in = hl + 2*tokmask(xg) ; hg_in = xl + 2*hg   (pre-block values of xl, xg)
+        HGL_TRY(hgl_launch_mix(Y + sN, X + sN, 1.f, X + 2 * sN, 2.f, p.pm, N, S, D, st));
+        HGL_TRY(hgl_launch_mix(Y + 3 * sN, X, 1.f, X + 3 * sN, 2.f, nullptr, N, S, D, st));
+        if (l < ret_block) {
+          hipMemcpyAsync(Y, X, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+          hipMemcpyAsync(Y + 2 * sN, X + 2 * sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+          HGL_TRY(run_block(w->blocks[l], Y, 4 * N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 2 * N, N, st));
+        } else {  // plain xl / xg streams of the returning block are dead
+          HGL_TRY(run_block(w->blocks[l], Y + sN, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
+          HGL_TRY(run_block(w->blocks[l], Y + 3 * sN, N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 0, N, st));
+        }
+        float* t = X; X = Y; Y = t;
+      }
+      HGL_TRY(head(w, X + sN, N, out, nullptr, p, st));
+      // out = head(hl) + head(hg): the second projection accumulates onto the first
+      return head(w, X + 3 * sN, N, out, out, p, st);
+    }
+  }
+  hgl_set_error("clip_hybrid_forward: unreachable");
+  return HGL_EINVAL;
+}
+
+static bool valid_text(const HglClipTextW* w) {
+  return w && w->width > 0 && w->layers > 0 && w->heads > 0 && w->context > 0 && w->vocab > 0 &&
+         w->embed > 0 && w->width % w->heads == 0 && (w->width & 3) == 0 && w->token_embedding &&
+         w->positional_embedding && w->blocks && w->ln_final_w && w->ln_final_b && w->text_projection_t;
+}
+
+struct TextPlan {
+  float *X, *H, *QKV, *F, *rows, *rows_ln;
+  int32_t* eot;
+};
+static bool carve_text(HglArena& ar, const HglClipTextW* w, int B, TextPlan& p) {
+  const size_t act = (size_t)B * w->context * w->width;
+  p.X = ar.take<float>(act);
+  p.H = ar.take<float>(act);
+  p.QKV = ar.take<float>(3 * act);
+  p.F = ar.take<float>(4 * act);
+  p.rows = ar.take<float>((size_t)B * w->width);
+  p.rows_ln = ar.take<float>((size_t)B * w->width);
+  p.eot = ar.take<int32_t>(B);
+  return ar.ok();
+}
+
+size_t hgl_clip_text_workspace_bytes(const HglClipTextW* w, int B) {
+  if (!valid_text(w) || B <= 0) return 0;
+  HglArena ar(nullptr, 0);
+  TextPlan p;
+  carve_text(ar, w, B, p);
+  return ar.off;
+}
+
+int hgl_clip_encode_text(const HglClipTextW* w, const int32_t* tokens, int B, float* out,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(valid_text(w), "clip_encode_text: invalid weight struct");
+  HGL_REQUIRE(tokens && out && B > 0, "clip_encode_text: null input");
+  HglArena ar(workspace, workspace_bytes);
+  TextPlan p;
+  if (!workspace || !carve_text(ar, w, B, p)) {
+    hgl_set_error("clip_encode_text: workspace too small (%zu bytes given)", workspace_bytes);
+    return HGL_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int D = w->width, S = w->context;
+  HGL_TRY(hgl_launch_text_embed(tokens, w->token_embedding, w->positional_embedding, p.X, B, S, D,
+                                w->vocab, p.eot, st));
+  BlockBufs bf{p.H, p.QKV, p.F};
+  for (int l = 0; l < w->layers; ++l)
+    HGL_TRY(run_block(w->blocks[l], p.X, B, S, D, w->heads, bf, HGL_MASK_CAUSAL, nullptr, 0, 0, st));
+  // ln_final is row-wise: normalise only the EOT rows, then project (clip/model.py:424-429)
+  HGL_TRY(hgl_launch_gather_eot(p.X, p.eot, B, S, D, p.rows, st));
+  HGL_TRY(hgl_launch_layernorm(p.rows, w->ln_final_w, w->ln_final_b, p.rows_ln, B, D, 1e-5f, st));
+  HGL_TRY(hgl_launch_gemm(p.rows_ln, w->text_projection_t, nullptr, nullptr, out, B, w->embed, D, D, D,
+                          0, w->embed, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
+  return HGL_OK;
+}
+
+}  // extern "C"

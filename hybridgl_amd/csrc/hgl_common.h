@@ -1,0 +1,77 @@
+// Internal declarations shared by the HIP translation units of libhybridgl.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/hybridgl.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void hgl_set_error(const char* fmt, ...);
+int hgl_check_launch(const char* what);  // hipGetLastError -> HGL_ELAUNCH
+int hgl_require_device();                // HGL_ENODEVICE when no GPU is visible
+
+#define HGL_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      hgl_set_error(__VA_ARGS__);       \
+      return HGL_EINVAL;                \
+    }                                   \
+  } while (0)
+
+#define HGL_TRY(expr)            \
+  do {                           \
+    int _rc = (expr);            \
+    if (_rc != HGL_OK) return _rc; \
+  } while (0)
+
+static inline size_t hgl_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller-provided workspace.
+struct HglArena {
+  char* base;
+  size_t cap;
+  size_t off;
+  bool dry;  // size query: no base
+  HglArena(void* b, size_t c) : base((char*)b), cap(c), off(0), dry(b == nullptr) {}
+  template <typename T>
+  T* take(size_t n) {
+    size_t bytes = hgl_align_up(n * sizeof(T), 256);
+    size_t o = off;
+    off += bytes;
+    if (dry) return nullptr;
+    return (T*)(base + o);
+  }
+  bool ok() const { return dry || off <= cap; }
+};
+
+// ---- internal launchers (each returns HGL_*) -------------------------------
+int hgl_launch_gemm(const float* A, const float* W, const float* bias, const float* R, float* C,
+                    int M, int N, int K, int lda, int ldw, int ldr, int ldc, int batch,
+                    long long sA, long long sW, long long sR, long long sC, int act,
+                    hipStream_t st);
+int hgl_launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D,
+                         float eps, hipStream_t st);
+int hgl_launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H,
+                         int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
+                         long long skb, long long svb, long long sob, float scale, int mask_kind,
+                         const uint8_t* keep, int keep_b0, int keep_n, const float* rel_h,
+                         const float* rel_w, int kh, int kw, hipStream_t st);
+
+// CLIP glue (clip_glue.hip)
+int hgl_launch_im2col_patch(const float* img, int N, int res, int patch, float* cols, hipStream_t st);
+int hgl_launch_assemble_lnpre(const float* tok, const float* cls, const float* pos, const float* lw,
+                              const float* lb, float* x, int B, int S, int D, hipStream_t st);
+int hgl_launch_mask_resize(const uint8_t* masks, int N, int Hm, int Wm, int g, float* pm,
+                           uint8_t* keep, hipStream_t st);
+// out[n,s,:] = a[n,s,:]*ca + cb * b[n,s,:] * (s==0 ? 1 : pm[n,s-1]) ; pm may be null, a may be null
+int hgl_launch_mix(float* out, const float* a, float ca, const float* b, float cb, const float* pm,
+                   int N, int S, int D, hipStream_t st);
+int hgl_launch_gather_rows(const float* x, long long row_stride, int rows, int D, float* y,
+                           hipStream_t st);
+int hgl_launch_add_inplace(float* y, const float* x, long long n, hipStream_t st);
+int hgl_launch_text_embed(const int32_t* tokens, const float* emb, const float* pos, float* x, int B,
+                          int S, int D, int vocab, int32_t* eot, hipStream_t st);
+int hgl_launch_gather_eot(const float* x, const int32_t* eot, int B, int S, int D, float* y,
+                          hipStream_t st);

@@ -1,0 +1,542 @@
+// Scoring tail + image synthesis kernels (all HBM / latency bound, no matrix work).
+//   calculate_score      model/backbone.py:74-87
+//   coherence scores     Hybridgl_main.py:201-223 (+ gen_dir_mask utils.py:135-161)
+//   IoU                  utils.py:365-384
+//   score_sentence       Hybridgl_main.py:153-196,225-228 (+ relation_boxes utils.py:240-268)
+//   synthesize_views     Hybridgl_main.py:93-125
+#include "hgl_common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- calculate_score: one wave per (n,t) ----
+__global__ __launch_bounds__(256) void calc_score_kernel(const float* __restrict__ img,
+                                                         const float* __restrict__ txt, int N, int T,
+                                                         int E, float logit_scale,
+                                                         float* __restrict__ logits) {
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= N * T) return;
+  const int n = pair / T, tt = pair - n * T;
+  const float* ir = img + (long long)n * E;
+  const float* tr = txt + (long long)tt * E;
+  float si = 0.f, stx = 0.f;
+  for (int i = lane; i < E; i += 64) {
+    si += ir[i] * ir[i];
+    stx += tr[i] * tr[i];
+  }
+  const float ni = sqrtf(wave_sum_f(si)), nt = sqrtf(wave_sum_f(stx));
+  float d = 0.f;
+  for (int i = lane; i < E; i += 64) d += (logit_scale * (ir[i] / ni)) * (tr[i] / nt);
+  d = wave_sum_f(d);
+  if (lane == 0) logits[pair] = d;
+}
+
+// ---- heat-map statistics ----
+// stats[0]=min, stats[1]=max (as ordered-int encodings), reduced with atomics on monotone keys
+__device__ __forceinline__ int f2ord(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ a, long long n,
+                                                     int* __restrict__ stats) {
+  float mn = INFINITY, mx = -INFINITY;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float v = a[i];
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&stats[0], f2ord(mn));
+    atomicMax(&stats[1], f2ord(mx));
+  }
+}
+
+__global__ void init_stats_kernel(int* stats) {
+  stats[0] = 0x7fffffff;          // +max ordered key
+  stats[1] = (int)0x80000000;     // -max ordered key
+}
+
+// torch.linspace(start,end,steps)[i] in fp32 (ATen RangeFactories: symmetric evaluation)
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+  if (steps == 1) return start;
+  const float step = (end - start) / (float)(steps - 1);
+  const int half = steps / 2;
+  return i < half ? fmaf(step, (float)i, start) : fmaf(-step, (float)(steps - i - 1), end);  // fmas, as ATen
+}
+
+// gen_dir_mask column weight (utils.py:135-161): 0 none, 1 left, 2 right, 3 middle
+__device__ __forceinline__ float dir_weight(int dirflag, int x, int W) {
+  switch (dirflag) {
+    case 1: return linspace_at(1.f, 0.f, W, x);
+    case 2: return linspace_at(0.f, 1.f, W, x);
+    case 3: {
+      const int w1 = W / 2;
+      return x < w1 ? linspace_at(0.f, 1.f, w1, x) : linspace_at(1.f, 0.f, W - w1, x - w1);
+    }
+    default: return 1.f;
+  }
+}
+
+// Masked pooling.  One block = PIX_PER_BLOCK consecutive pixels x all masks.
+// The normalised heat-map tile lives in registers (16 px per lane); each mask's bytes
+// are read exactly once with 16-byte loads; partial sums (double) go to part[blk][n].
+constexpr int PX_LANE = 16;
+constexpr int PIX_PER_BLOCK = 256 * PX_LANE;  // 4096
+
+constexpr int MASK_GROUP = 8;  // masks per blockIdx.y
+
+__global__ __launch_bounds__(256) void masked_pool_kernel(const float* __restrict__ attn,
+                                                          const uint8_t* __restrict__ masks, int N,
+                                                          int H, int W, int dirflag,
+                                                          const int* __restrict__ stats,
+                                                          double* __restrict__ part_sum,
+                                                          unsigned* __restrict__ part_cnt,
+                                                          double* __restrict__ part_tot) {
+  const long long HW = (long long)H * W;
+  const long long p0 = (long long)blockIdx.x * PIX_PER_BLOCK + threadIdx.x * PX_LANE;
+  const float mn = ord2f(stats[0]), mx = ord2f(stats[1]);
+  const float range = mx - mn;
+  float v[PX_LANE];
+  double tot = 0.0;
+  const bool inb = p0 + PX_LANE <= HW;
+#pragma unroll
+  for (int e = 0; e < PX_LANE; ++e) {
+    const long long p = p0 + e;
+    float val = 0.f;
+    if (p < HW) {
+      const int x = (int)(p % W);
+      val = ((attn[p] - mn) / range) * dir_weight(dirflag, x, W);
+    }
+    v[e] = val;
+    tot += (double)val;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long part = (long long)blockIdx.x * 4 + wave;  // one partial per wave: no block sync
+  if (blockIdx.y == 0) {
+    tot = wave_sum_d(tot);
+    if (lane == 0) part_tot[part] = tot;
+  }
+  const int n0 = blockIdx.y * MASK_GROUP;
+  const int n1 = min(N, n0 + MASK_GROUP);
+  for (int n = n0; n < n1; ++n) {
+    const uint8_t* m = masks + (long long)n * HW + p0;
+    double s = 0.0;
+    unsigned c = 0;
+    if (inb && (((uintptr_t)m) & 15) == 0) {
+      const uint4 mv = *(const uint4*)m;
+      const unsigned w4[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+      for (int e = 0; e < PX_LANE; ++e) {
+        const bool on = ((w4[e >> 2] >> (8 * (e & 3))) & 0xff) != 0;
+        s += on ? (double)v[e] : 0.0;
+        c += on ? 1u : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < PX_LANE; ++e) {
+        const bool on = (p0 + e < HW) && m[e] != 0;
+        s += on ? (double)v[e] : 0.0;
+        c += on ? 1u : 0u;
+      }
+    }
+    s = wave_sum_d(s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) {
+      part_sum[part * N + n] = s;
+      part_cnt[part * N + n] = c;
+    }
+  }
+}
+
+// one thread per mask: fixed-order reduction over blocks (deterministic), final formula
+__global__ __launch_bounds__(256) void coherence_final_kernel(const double* __restrict__ part_sum,
+                                                              const unsigned* __restrict__ part_cnt,
+                                                              const double* __restrict__ part_tot,
+                                                              int nblk, int N, long long HW,
+                                                              float black, float* __restrict__ score) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double tot = 0.0, s = 0.0;
+  unsigned long long c = 0;
+  for (int b = 0; b < nblk; ++b) {
+    tot += part_tot[b];
+    s += part_sum[(long long)b * N + n];
+    c += part_cnt[(long long)b * N + n];
+  }
+  const double mean = tot / (double)HW;
+  const double in_sum = s / mean, out_sum = (tot - s) / mean;
+  // (imgattn*(2-black)*m/m.sum()).sum() - (imgattn*black*(1-m)/(1-m).sum()).sum()
+  const double a = (double)(2.f - black) * in_sum / (double)c;
+  const double bterm = (double)black * out_sum / (double)(HW - (long long)c);
+  score[n] = (float)(a - bterm);
+}
+
+// ---- IoU ----
+__global__ __launch_bounds__(256) void iou_kernel(const uint8_t* __restrict__ p,
+                                                  const uint8_t* __restrict__ g, long long n,
+                                                  unsigned long long* __restrict__ out) {
+  unsigned I = 0, U = 0;
+  const long long n16 = n / 16;
+  const bool al = (((uintptr_t)p | (uintptr_t)g) & 15) == 0;
+  if (al) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n16;
+         i += (long long)gridDim.x * blockDim.x) {
+      const uint4 a = ((const uint4*)p)[i], b = ((const uint4*)g)[i];
+      const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        // nonzero byte -> 0x01 per byte
+        unsigned x = aw[w], y = bw[w];
+        x |= x >> 4; x |= x >> 2; x |= x >> 1; x &= 0x01010101u;
+        y |= y >> 4; y |= y >> 2; y |= y >> 1; y &= 0x01010101u;
+        I += __popc(x & y);
+        U += __popc(x | y);
+      }
+    }
+  }
+  const long long tail0 = al ? n16 * 16 : 0;
+  for (long long i = tail0 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const bool a = p[i] != 0, b = g[i] != 0;
+    I += (a && b);
+    U += (a || b);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    I += __shfl_xor(I, o);
+    U += __shfl_xor(U, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], (unsigned long long)I);
+    atomicAdd(&out[1], (unsigned long long)U);
+  }
+}
+
+// ---- per-sentence tail: single workgroup ----
+constexpr int MAXK = 16;
+
+__device__ float relation_boxes_dev(const long long* bi, const long long* bj, float si, float sj,
+                                    int rela) {
+  // utils.py:240-268 ; integer tensors /2 -> float32 true division
+  switch (rela) {
+    case 1: return si * sj * (float)(((float)bi[0] + (float)bi[2] / 2.f) < ((float)bj[0] + (float)bj[2] / 2.f));
+    case 2: return si * sj * (float)(((float)bi[0] + (float)bi[2] / 2.f) > ((float)bj[0] + (float)bj[2] / 2.f));
+    case 3: return si * sj * (float)(((float)bi[1] + (float)bi[3] / 2.f) < ((float)bj[1] + (float)bj[3] / 2.f));
+    case 4: return si * sj * (float)(((float)bi[1] + (float)bi[3] / 2.f) > ((float)bj[1] + (float)bj[3] / 2.f));
+    case 5: return si * sj * (float)((bi[2] * bi[3]) > (bj[2] * bj[3]));
+    case 6: return si * sj * (float)((bi[2] * bi[3]) < (bj[2] * bj[3]));
+    case 7: {
+      const long long x1 = max(bi[0], bj[0]);
+      const long long x2 = max(x1, min(bi[0] + bi[2], bj[0] + bj[2]));
+      const long long y1 = max(bi[1], bj[1]);
+      const long long y2 = max(y1, min(bi[1] + bi[3], bj[1] + bj[3]));
+      return si * sj * (float)(x2 - x1) * (float)(y2 - y1) / (float)(bi[2] * bi[3]);
+    }
+    default: return si;
+  }
+}
+
+__global__ __launch_bounds__(256) void score_sentence_kernel(
+    const float* __restrict__ hybrid, const float* __restrict__ tpos, const float* __restrict__ tneg,
+    const long long* __restrict__ boxes, const float* __restrict__ gem, int N, int E,
+    float logit_scale, int k1, int k2, float alpha, int rela, int has_other, int* __restrict__ idx,
+    float* __restrict__ score_clip, float* __restrict__ score_neg, float* __restrict__ soft_scratch) {
+  // soft_scratch: [2*N] softmax values (global scratch so N is unbounded)
+  __shared__ float red[8];
+  __shared__ int redi[8];
+  __shared__ int top1[MAXK], top2[MAXK];
+  __shared__ float nrm[2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+  // text norms
+  for (int which = wave; which < 2; which += 4) {
+    const float* tv = which == 0 ? tpos : tneg;
+    float s = 0.f;
+    for (int i = lane; i < E; i += 64) s += tv[i] * tv[i];
+    s = wave_sum_f(s);
+    if (lane == 0) nrm[which] = sqrtf(s);
+  }
+  __syncthreads();
+  // logits: one wave per mask (strided)
+  for (int n = wave; n < N; n += 4) {
+    const float* ir = hybrid + (long long)n * E;
+    float s = 0.f;
+    for (int i = lane; i < E; i += 64) s += ir[i] * ir[i];
+    const float ni = sqrtf(wave_sum_f(s));
+    float d0 = 0.f, d1 = 0.f;
+    for (int i = lane; i < E; i += 64) {
+      const float v = logit_scale * (ir[i] / ni);
+      d0 += v * (tpos[i] / nrm[0]);
+      d1 += v * (tneg[i] / nrm[1]);
+    }
+    d0 = wave_sum_f(d0);
+    d1 = wave_sum_f(d1);
+    if (lane == 0) {
+      score_clip[n] = d0;
+      score_neg[n] = d1;
+    }
+  }
+  __syncthreads();
+  __threadfence_block();
+
+  // softmax over masks of both logit vectors + argmax of score_clip
+  for (int which = 0; which < 2; ++which) {
+    const float* lg = which == 0 ? score_clip : score_neg;
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int n = t; n < N; n += 256) {
+      const float v = lg[n];
+      if (v > mx || (v == mx && n < mi)) { mx = v; mi = n; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(mx, o);
+      const int oi = __shfl_xor(mi, o);
+      if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+    }
+    if (lane == 0) { red[wave] = mx; redi[wave] = mi; }
+    __syncthreads();
+    float gmx = red[0];
+    int gmi = redi[0];
+    for (int w = 1; w < 4; ++w)
+      if (red[w] > gmx || (red[w] == gmx && redi[w] < gmi)) { gmx = red[w]; gmi = redi[w]; }
+    __syncthreads();
+    if (which == 0 && t == 0) idx[0] = gmi;
+    float se = 0.f;
+    for (int n = t; n < N; n += 256) se += expf(lg[n] - gmx);
+    se = wave_sum_f(se);
+    if (lane == 0) red[wave] = se;
+    __syncthreads();
+    const float denom = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    for (int n = t; n < N; n += 256) soft_scratch[which * N + n] = expf(lg[n] - gmx) / denom;
+  }
+  __syncthreads();
+  __threadfence_block();
+
+  // top-k (descending, lowest index on ties) by repeated argmax -- wave 0 for list 1, wave 1 for list 2
+  if (wave < 2) {
+    const float* sv = soft_scratch + wave * N;
+    int* top = wave == 0 ? top1 : top2;
+    const int kk = wave == 0 ? k1 : k2;
+    for (int j = 0; j < kk; ++j) {
+      float mx = -INFINITY;
+      int mi = 0x7fffffff;
+      for (int n = lane; n < N; n += 64) {
+        bool used = false;
+        for (int u = 0; u < j; ++u) used |= top[u] == n;
+        const float v = sv[n];
+        if (!used && (v > mx || (v == mx && n < mi))) { mx = v; mi = n; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o);
+        const int oi = __shfl_xor(mi, o);
+        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+      }
+      if (lane == 0) top[j] = mi;
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+    }
+  }
+  __syncthreads();
+
+  if (t == 0) {
+    // Hybridgl_main.py:183-196 relation sums, softmax, blend with the coherence score, argmax
+    const float* sc = soft_scratch;
+    const float* sn = soft_scratch + N;
+    // partial sums are fp32 in the reference (np.float64 + Tensor -> Tensor.__radd__ -> fp32)
+    float ts[MAXK];
+    for (int i = 0; i < k1; ++i) {
+      float acc = 0.f;
+      const int ii = top1[i];
+      if (!has_other) {
+        for (int j = 0; j < k1; ++j) {
+          const int jj = top1[j];
+          acc += relation_boxes_dev(boxes + 4 * ii, boxes + 4 * jj, sc[ii], sc[jj], rela);
+        }
+      } else {
+        for (int j = 0; j < k2; ++j) {
+          const int jj = top2[j];
+          acc += relation_boxes_dev(boxes + 4 * ii, boxes + 4 * jj, sc[ii], sn[jj], rela);
+        }
+      }
+      ts[i] = acc;
+    }
+    float tf[MAXK];
+    float mx = -INFINITY;
+    for (int i = 0; i < k1; ++i) { tf[i] = ts[i]; mx = fmaxf(mx, tf[i]); }
+    float den = 0.f;
+    for (int i = 0; i < k1; ++i) { tf[i] = expf(tf[i] - mx); den += tf[i]; }
+    int best = 0;
+    float bv = -INFINITY;
+    for (int i = 0; i < k1; ++i) {
+      const float v = (tf[i] / den) * (1.f - alpha) + alpha * gem[top1[i]];
+      if (v > bv) { bv = v; best = i; }
+    }
+    idx[1] = top1[best];
+  }
+}
+
+// ---- image synthesis: local (mean-filled) and global (blurred background) views ----
+__global__ __launch_bounds__(256) void synth_views_kernel(
+    const uint8_t* __restrict__ sam_img, const uint8_t* __restrict__ blurred,
+    const float* __restrict__ image_norm, const uint8_t* __restrict__ masks, int N, int H, int W,
+    int res, float* __restrict__ local_imgs, float* __restrict__ global_imgs) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long total = (long long)N * res * res;
+  if (i >= total) return;
+  const int ox = (int)(i % res), oy = (int)((i / res) % res), n = (int)(i / ((long long)res * res));
+  const float sy = (float)H / (float)res, sx = (float)W / (float)res;
+  float fy = fmaf(sy, oy + 0.5f, -0.5f), fx = fmaf(sx, ox + 0.5f, -0.5f);  // one fma, as ATen
+  fy = fy < 0.f ? 0.f : fy;
+  fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  const long long HW = (long long)H * W;
+  const uint8_t* m = masks + (long long)n * HW;
+  const long long t00 = (long long)y0 * W + x0, t01 = (long long)y0 * W + x1;
+  const long long t10 = (long long)y1 * W + x0, t11 = (long long)y1 * W + x1;
+  const bool m00 = m[t00] != 0, m01 = m[t01] != 0, m10 = m[t10] != 0, m11 = m[t11] != 0;
+  const float clip_mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};   // Hybridgl_main.py:93
+  const float in_mean[3] = {0.485f, 0.456f, 0.406f};                   // Hybridgl_main.py:117
+  const float in_std[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* im = image_norm + (long long)c * HW;
+    const float l00 = m00 ? im[t00] : clip_mean[c], l01 = m01 ? im[t01] : clip_mean[c];
+    const float l10 = m10 ? im[t10] : clip_mean[c], l11 = m11 ? im[t11] : clip_mean[c];
+    const float lv = ly0 * (lx0 * l00 + lx1 * l01) + ly1 * (lx0 * l10 + lx1 * l11);
+    const float g00 = (float)(m00 ? sam_img[t00 * 3 + c] : blurred[t00 * 3 + c]) / 255.f;
+    const float g01 = (float)(m01 ? sam_img[t01 * 3 + c] : blurred[t01 * 3 + c]) / 255.f;
+    const float g10 = (float)(m10 ? sam_img[t10 * 3 + c] : blurred[t10 * 3 + c]) / 255.f;
+    const float g11 = (float)(m11 ? sam_img[t11 * 3 + c] : blurred[t11 * 3 + c]) / 255.f;
+    const float gv = ly0 * (lx0 * g00 + lx1 * g01) + ly1 * (lx0 * g10 + lx1 * g11);
+    const long long o = (((long long)n * 3 + c) * res + oy) * res + ox;
+    local_imgs[o] = lv;
+    global_imgs[o] = (gv - in_mean[c]) / in_std[c];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hgl_calculate_score(const float* img, const float* txt, int N, int T, int E, float logit_scale,
+                        float* logits, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(img && txt && logits && N > 0 && T > 0 && E > 0, "calculate_score: bad arguments");
+  const int pairs = N * T;
+  hipLaunchKernelGGL(calc_score_kernel, dim3((pairs + 3) / 4), dim3(256), 0, (hipStream_t)stream, img, txt, N, T, E, logit_scale, logits);
+  return hgl_check_launch("calculate_score");
+}
+
+static inline int coh_nblk(int H, int W) {
+  return (int)(((long long)H * W + PIX_PER_BLOCK - 1) / PIX_PER_BLOCK);
+}
+static inline int coh_nparts(int H, int W) { return coh_nblk(H, W) * 4; }
+
+size_t hgl_coherence_workspace_bytes(int N, int H, int W) {
+  const size_t nb = coh_nparts(H, W);
+  return 256 + hgl_align_up(nb * N * sizeof(double), 256) + hgl_align_up(nb * N * sizeof(unsigned), 256) +
+         hgl_align_up(nb * sizeof(double), 256);
+}
+
+int hgl_coherence_scores(const float* imgattn, const uint8_t* masks, int N, int H, int W, int dirflag,
+                         float black, float* score, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(imgattn && masks && score && N > 0 && H > 0 && W > 0, "coherence: bad arguments");
+  HGL_REQUIRE(dirflag >= 0 && dirflag <= 3, "coherence: bad dirflag %d", dirflag);
+  if (!workspace || workspace_bytes < hgl_coherence_workspace_bytes(N, H, W)) {
+    hgl_set_error("coherence: workspace too small (%zu < %zu)", workspace_bytes, hgl_coherence_workspace_bytes(N, H, W));
+    return HGL_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = coh_nparts(H, W);
+  HglArena ar(workspace, workspace_bytes);
+  int* stats = ar.take<int>(64);
+  double* psum = ar.take<double>((size_t)nb * N);
+  unsigned* pcnt = ar.take<unsigned>((size_t)nb * N);
+  double* ptot = ar.take<double>(nb);
+  const long long HW = (long long)H * W;
+  hipLaunchKernelGGL(init_stats_kernel, dim3(1), dim3(1), 0, st, stats);
+  hipLaunchKernelGGL(minmax_kernel, dim3(256), dim3(256), 0, st, imgattn, HW, stats);
+  hipLaunchKernelGGL(masked_pool_kernel, dim3(coh_nblk(H, W), (N + MASK_GROUP - 1) / MASK_GROUP), dim3(256), 0, st, imgattn, masks, N, H, W, dirflag, stats, psum, pcnt, ptot);
+  hipLaunchKernelGGL(coherence_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, psum, pcnt, ptot, nb, N, HW, black, score);
+  return hgl_check_launch("coherence_scores");
+}
+
+int hgl_iou(const uint8_t* pred, const uint8_t* gt, long long HW, int64_t* out_IU, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(pred && gt && out_IU && HW > 0, "iou: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out_IU, 0, 2 * sizeof(int64_t), st) != hipSuccess) {
+    hgl_set_error("iou: memset failed");
+    return HGL_ELAUNCH;
+  }
+  long long blocks = (HW / 16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(iou_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, gt, HW, (unsigned long long*)out_IU);
+  return hgl_check_launch("iou");
+}
+
+size_t hgl_score_sentence_workspace_bytes(int N) { return hgl_align_up((size_t)2 * N * sizeof(float), 256); }
+
+int hgl_score_sentence(const float* hybrid, const float* text_ensemble, const float* neg_text,
+                       const int64_t* boxes, const float* gem_score, int N, int E, float logit_scale,
+                       int k1, int k2, float alpha, int relaword, int has_other_nouns, int32_t* idx,
+                       float* score_clip, float* score_neg, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(hybrid && text_ensemble && neg_text && boxes && gem_score && idx && score_clip && score_neg, "score_sentence: null argument");
+  HGL_REQUIRE(N > 0 && E > 0, "score_sentence: bad shape");
+  // Hybridgl_main.py:178-181: k clamps to the number of masks
+  if (k1 > N) k1 = N;
+  if (k2 > N) k2 = N;
+  HGL_REQUIRE(k1 >= 1 && k1 <= MAXK && k2 >= 1 && k2 <= MAXK, "score_sentence: k1,k2 must be in [1,%d]", MAXK);
+  HGL_REQUIRE(relaword >= 0 && relaword <= 7, "score_sentence: bad relaword %d", relaword);
+  if (!workspace || workspace_bytes < hgl_score_sentence_workspace_bytes(N)) {
+    hgl_set_error("score_sentence: workspace too small");
+    return HGL_EWORKSPACE;
+  }
+  float* pool = (float*)workspace;
+  hipLaunchKernelGGL(score_sentence_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, hybrid, text_ensemble, neg_text, (const long long*)boxes, gem_score, N, E, logit_scale, k1, k2, alpha, relaword, has_other_nouns, (int*)idx, score_clip, score_neg, pool);
+  return hgl_check_launch("score_sentence");
+}
+
+int hgl_synthesize_views(const uint8_t* sam_img, const uint8_t* blurred, const float* image_norm,
+                         const uint8_t* masks, int N, int H, int W, int res, float* local_imgs,
+                         float* global_imgs, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(sam_img && blurred && image_norm && masks && local_imgs && global_imgs, "synthesize_views: null argument");
+  HGL_REQUIRE(N > 0 && H > 0 && W > 0 && res > 0, "synthesize_views: bad shape");
+  const long long total = (long long)N * res * res;
+  hipLaunchKernelGGL(synth_views_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sam_img, blurred, image_norm, masks, N, H, W, res, local_imgs, global_imgs);
+  return hgl_check_launch("synthesize_views");
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+"""Torch-tensor front ends of the C-ABI operators (device memory + stream plumbing only).
+
+Every function validates device/dtype/contiguity, then passes raw pointers to
+libhybridgl.so.  Nothing here computes: a missing library or a CPU tensor raises.
+"""
+import torch
+
+from . import _lib
+from ._lib import check
+
+ACT = {"none": 0, "quickgelu": 1, "gelu": 2, "relu": 3}
+MASK = {"none": 0, "causal": 1, "cls_keep": 2}
+DIRFLAG = {"none": 0, "left": 1, "right": 2, "middle": 3}
+# utils.py:240-268 relation words; anything else falls through to "none" semantics there
+RELAWORD = {"none": 0, "left": 1, "right": 2, "up": 3, "down": 4, "big": 5, "small": 6, "within": 7}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise _lib.HybridGLError(f"{name}: tensor must live on the GPU (no CPU path exists)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _u8(t, name):
+    """bool / uint8 mask tensor -> pointer (torch.bool is one byte, 0/1)."""
+    if t.dtype == torch.bool:
+        t = t.view(torch.uint8)
+    return _dev(t, torch.uint8, name), t
+
+
+def gemm(a, w, bias=None, residual=None, act="none", out=None):
+    """out = act(a @ w.T + bias) + residual   (torch.nn.functional.linear semantics)."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    check(lib.hgl_gemm_f32(_dev(a, torch.float32, "a"), _dev(w, torch.float32, "w"),
+                           _dev(bias, torch.float32, "bias") if bias is not None else None,
+                           _dev(residual, torch.float32, "residual") if residual is not None else None,
+                           _dev(out, torch.float32, "out"), M, N, K, K, K, N, N, 1, 0, 0, 0, 0,
+                           ACT[act], _stream()), "hgl_gemm_f32")
+    return out
+
+
+def layernorm(x, w, b, eps=1e-5):
+    lib = _lib.load()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    check(lib.hgl_layernorm_f32(_dev(x, torch.float32, "x"), _dev(w, torch.float32, "w"),
+                                _dev(b, torch.float32, "b"), _dev(y, torch.float32, "y"), rows, D,
+                                float(eps), _stream()), "hgl_layernorm_f32")
+    return y
+
+
+def attention(q, k, v, heads, scale=None, mask="none", keep=None, keep_b0=0, keep_n=0,
+              rel_h=None, rel_w=None):
+    """q: [B,Sq,H*hd], k,v: [B,Sk,H*hd] contiguous -> [B,Sq,H*hd]."""
+    lib = _lib.load()
+    B, Sq, Dm = q.shape
+    Sk = k.shape[1]
+    hd = Dm // heads
+    if scale is None:
+        scale = hd ** -0.5
+    out = torch.empty_like(q)
+    kp = None
+    if keep is not None:
+        kp, keep = _u8(keep, "keep")
+    kh = kw = 0
+    if rel_h is not None:
+        kh, kw = rel_h.shape[-1], rel_w.shape[-1]
+    check(lib.hgl_attention_f32(_dev(q, torch.float32, "q"), _dev(k, torch.float32, "k"),
+                                _dev(v, torch.float32, "v"), _dev(out, torch.float32, "out"),
+                                B, heads, Sq, Sk, hd, Dm, Dm, Dm, Dm,
+                                Sq * Dm, Sk * Dm, Sk * Dm, Sq * Dm, float(scale), MASK[mask], kp,
+                                keep_b0, keep_n,
+                                _dev(rel_h, torch.float32, "rel_h") if rel_h is not None else None,
+                                _dev(rel_w, torch.float32, "rel_w") if rel_w is not None else None,
+                                kh, kw, _stream()), "hgl_attention_f32")
+    return out
+
+
+def mask_resize(masks, g):
+    """TF.resize(masks.float(), (g,g)) of model/backbone.py:160 -> [N, g*g] fp32."""
+    lib = _lib.load()
+    N, H, W = masks.shape
+    mp, masks = _u8(masks, "masks")
+    pm = torch.empty((N, g * g), dtype=torch.float32, device=masks.device)
+    check(lib.hgl_mask_resize(mp, N, H, W, g, _dev(pm, torch.float32, "pm"), _stream()), "hgl_mask_resize")
+    return pm
+
+
+def calculate_score(img, txt, logit_scale):
+    lib = _lib.load()
+    N, E = img.shape
+    T = txt.shape[0]
+    out = torch.empty((N, T), dtype=torch.float32, device=img.device)
+    check(lib.hgl_calculate_score(_dev(img, torch.float32, "img"), _dev(txt, torch.float32, "txt"), N, T, E,
+                                  float(logit_scale), _dev(out, torch.float32, "out"), _stream()),
+          "hgl_calculate_score")
+    return out
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only device workspace (allocated outside the timed/hot path, reused)."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def coherence_scores(imgattn, masks, dirflag="none", black=1.8):
+    """Hybridgl_main.py:201-223 for all masks at once -> [N] fp32."""
+    lib = _lib.load()
+    N, H, W = masks.shape
+    assert imgattn.shape == (H, W)
+    mp, masks = _u8(masks, "masks")
+    need = lib.hgl_coherence_workspace_bytes(N, H, W)
+    ws = workspace(need, masks.device, "coherence")
+    out = torch.empty((N,), dtype=torch.float32, device=masks.device)
+    check(lib.hgl_coherence_scores(_dev(imgattn, torch.float32, "imgattn"), mp, N, H, W,
+                                   DIRFLAG.get(dirflag, 0), float(black), _dev(out, torch.float32, "out"),
+                                   ws.data_ptr(), ws.numel(), _stream()), "hgl_coherence_scores")
+    return out
+
+
+def iou_counts(pred, gt):
+    """Compute_IoU (utils.py:365-384) counts: tensor([I, U]) int64 on device."""
+    lib = _lib.load()
+    pp, pred = _u8(pred, "pred")
+    gp, gt = _u8(gt, "gt")
+    assert pred.numel() == gt.numel()
+    out = torch.empty((2,), dtype=torch.int64, device=pred.device)
+    check(lib.hgl_iou(pp, gp, pred.numel(), out.data_ptr(), _stream()), "hgl_iou")
+    return out
+
+
+def score_sentence(hybrid, text_ensemble, neg_text, boxes, gem_score, logit_scale=100.0, k1=3, k2=6,
+                   alpha=0.6, relaword="none", has_other_nouns=False):
+    """Per-sentence tail (Hybridgl_main.py:153-196,225-228).
+
+    Returns (idx[2] int32: pure argmax, final index; score_clip [N]; score_neg [N])."""
+    lib = _lib.load()
+    N, E = hybrid.shape
+    dev = hybrid.device
+    idx = torch.empty((2,), dtype=torch.int32, device=dev)
+    sc = torch.empty((N,), dtype=torch.float32, device=dev)
+    sn = torch.empty((N,), dtype=torch.float32, device=dev)
+    need = lib.hgl_score_sentence_workspace_bytes(N)
+    ws = workspace(need, dev, "score_sentence")
+    check(lib.hgl_score_sentence(_dev(hybrid, torch.float32, "hybrid"),
+                                 _dev(text_ensemble.reshape(-1), torch.float32, "text_ensemble"),
+                                 _dev(neg_text.reshape(-1), torch.float32, "neg_text"),
+                                 _dev(boxes, torch.int64, "boxes"), _dev(gem_score, torch.float32, "gem_score"),
+                                 N, E, float(logit_scale), int(k1), int(k2), float(alpha),
+                                 RELAWORD.get(relaword, 0), int(bool(has_other_nouns)),
+                                 idx.data_ptr(), sc.data_ptr(), sn.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 _stream()), "hgl_score_sentence")
+    return idx, sc, sn
+
+
+def synthesize_views(sam_img, blurred, image_norm, masks, res=224):
+    """Hybridgl_main.py:93-125 -> (local_imgs, global_imgs) [N,3,res,res] fp32."""
+    lib = _lib.load()
+    N, H, W = masks.shape
+    mp, masks = _u8(masks, "masks")
+    dev = masks.device
+    loc = torch.empty((N, 3, res, res), dtype=torch.float32, device=dev)
+    glo = torch.empty((N, 3, res, res), dtype=torch.float32, device=dev)
+    check(lib.hgl_synthesize_views(_dev(sam_img, torch.uint8, "sam_img"), _dev(blurred, torch.uint8, "blurred"),
+                                   _dev(image_norm, torch.float32, "image_norm"), mp, N, H, W, res,
+                                   loc.data_ptr(), glo.data_ptr(), _stream()), "hgl_synthesize_views")
+    return loc, glo

@@ -1,0 +1,202 @@
+/*
+ * hybridgl.h -- C ABI of libhybridgl.so, the MI355X (gfx950) hot path of the
+ * HybridGL zero-shot referring-segmentation pipeline.
+ *
+ * Every entry point replaces a Python call surface of the reference
+ * (cited as file:line relative to the reference tree).  Conventions:
+ *   - all pointers are DEVICE pointers (HBM) unless the name says host_;
+ *   - all tensors are dense row-major fp32 unless stated;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*,
+ *     NULL = the default stream); no hidden allocation: scratch memory is a
+ *     caller-provided workspace whose size comes from *_workspace_bytes();
+ *   - return 0 on success, negative HGL_E* otherwise; hgl_last_error() gives
+ *     a thread-local human-readable message;
+ *   - no torch types, no C++ types, no exceptions cross this boundary.
+ *
+ * There is NO CPU implementation behind this ABI: without a HIP device every
+ * compute entry point returns HGL_ENODEVICE.
+ */
+#ifndef HYBRIDGL_H
+#define HYBRIDGL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGL_OK 0
+#define HGL_EINVAL (-1)    /* bad argument (shape, alignment, null) */
+#define HGL_ENODEVICE (-2) /* no HIP device / device error */
+#define HGL_EWORKSPACE (-3)/* workspace too small */
+#define HGL_ELAUNCH (-4)   /* kernel launch failed */
+
+#define HGL_ABI_VERSION 1
+
+/* activation codes for hgl_gemm_f32 */
+#define HGL_ACT_NONE 0
+#define HGL_ACT_QUICKGELU 1 /* x*sigmoid(1.702x): clip/model.py:198-200 */
+#define HGL_ACT_GELU 2      /* erf GELU: nn.GELU, segment_anything/modeling/image_encoder.py:65 */
+#define HGL_ACT_RELU 3      /* transformer.py MLPBlock act=ReLU, mask_decoder.py MLP */
+
+/* fusion modes of CLIPViTFM.forward (model/backbone.py:117-309) */
+#define HGL_FUSION_G2L 0      /* model/backbone.py:227-260 */
+#define HGL_FUSION_L2G 1      /* model/backbone.py:206-225 */
+#define HGL_FUSION_G2L_L2G 2  /* model/backbone.py:262-306 */
+#define HGL_FUSION_TOKEN_MASKING 3 /* model/backbone.py:161-184 */
+#define HGL_FUSION_ATTN_MASKING 4  /* model/backbone.py:186-204 */
+#define HGL_FUSION_CROP 5          /* model/backbone.py:126-128 */
+
+/* attention mask kinds for hgl_attention_f32 */
+#define HGL_MASK_NONE 0
+#define HGL_MASK_CAUSAL 1  /* clip/model.py:396-402 build_attention_mask */
+#define HGL_MASK_CLS_KEEP 2/* model/backbone.py:108-115 make_attn_mask: only the CLS query row is restricted */
+
+int hgl_abi_version(void);
+const char* hgl_last_error(void);
+/* number of visible HIP devices (0 when none); never initialises a context */
+int hgl_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Primitive operators (building blocks; exported so that parity tests can
+ * pin each kernel against the oracle in isolation).
+ * --------------------------------------------------------------------- */
+
+/* C[b] = act(A[b] @ W[b]^T + bias) + R[b]      (torch.nn.functional.linear)
+ * A:[M,K] lda, W:[N,K] ldw, C:[M,N] ldc, R:[M,N] ldr (may be NULL, may alias C),
+ * bias:[N] or NULL.  batch>=1 with element strides sA/sW/sR/sC (0 = shared).
+ * K%4==0, lda%4==0, ldw%4==0, pointers 16-byte aligned.  fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), exact fp32 products and accumulation. */
+int hgl_gemm_f32(const float* A, const float* W, const float* bias, const float* R, float* C,
+                 int M, int N, int K, int lda, int ldw, int ldr, int ldc,
+                 int batch, long long sA, long long sW, long long sR, long long sC,
+                 int act, void* stream);
+
+/* y = (x-mean)/sqrt(var+eps)*w+b over the last dim D for `rows` rows
+ * (clip/model.py:189-195 LayerNorm; eps=1e-5 for CLIP, 1e-6 for SAM). */
+int hgl_layernorm_f32(const float* x, const float* w, const float* b, float* y,
+                      int rows, int D, float eps, void* stream);
+
+/* Fused softmax(scale*Q K^T + mask + bias) V for B sequences x H heads.
+ * q,k,v: row (b*S+s), column (h*hd + d), leading dims ldq/ldk/ldv (so a packed
+ * [B*S,3*D] in_proj output works with pointer offsets).  out: [B*Sq, H*hd] ldo.
+ * hd in {16,32,64,80}.  mask_kind: HGL_MASK_*; keep: [keep_n,Sk-1] uint8 for
+ * HGL_MASK_CLS_KEEP applied to batches b >= keep_b0 (keep row (b-keep_b0)%keep_n;
+ * keep_n<=0 means B).
+ * rel_h/rel_w (may be NULL): decomposed relative position bias tables
+ * [B*H, Sq, kh] and [B*H, Sq, kw] with Sk = kh*kw
+ * (segment_anything/modeling/image_encoder.py:325-361). */
+int hgl_attention_f32(const float* q, const float* k, const float* v, float* out,
+                      int B, int H, int Sq, int Sk, int hd,
+                      int ldq, int ldk, int ldv, int ldo,
+                      long long sqb, long long skb, long long svb, long long sob,
+                      float scale, int mask_kind, const uint8_t* keep, int keep_b0, int keep_n,
+                      const float* rel_h, const float* rel_w, int kh, int kw,
+                      void* stream);
+
+/* ------------------------------------------------------------------------
+ * CLIP hybrid encoder  (model/backbone.py CLIPViTFM, clip/model.py)
+ * --------------------------------------------------------------------- */
+
+typedef struct HglResBlockW {          /* clip/model.py:203-257 ResidualAttentionBlock */
+  const float *ln1_w, *ln1_b;          /* [D] */
+  const float *in_proj_w, *in_proj_b;  /* [3D,D], [3D]  (nn.MultiheadAttention) */
+  const float *out_proj_w, *out_proj_b;/* [D,D], [D] */
+  const float *ln2_w, *ln2_b;          /* [D] */
+  const float *fc_w, *fc_b;            /* mlp.c_fc   [4D,D],[4D] */
+  const float *proj_w, *proj_b;        /* mlp.c_proj [D,4D],[D] */
+} HglResBlockW;
+
+typedef struct HglClipVisionW {        /* clip/model.py:272-305 VisionTransformer */
+  int width, layers, heads, patch, grid, embed; /* ViT-B/16: 768,12,12,16,14,512 */
+  const float* conv1_w;                /* [width, 3*patch*patch] (conv weight flattened c,ky,kx) */
+  const float* class_embedding;        /* [width] */
+  const float* positional_embedding;   /* [grid*grid+1, width] */
+  const float *ln_pre_w, *ln_pre_b;
+  const HglResBlockW* blocks;          /* host array of `layers` structs (device pointers inside) */
+  const float *ln_post_w, *ln_post_b;
+  const float* proj_t;                 /* visual.proj transposed: [embed, width] */
+} HglClipVisionW;
+
+typedef struct HglClipTextW {          /* clip/model.py:340-431 */
+  int width, layers, heads, context, vocab, embed; /* 512,12,8,77,49408,512 */
+  const float* token_embedding;        /* [vocab, width] */
+  const float* positional_embedding;   /* [context, width] */
+  const HglResBlockW* blocks;
+  const float *ln_final_w, *ln_final_b;
+  const float* text_projection_t;      /* text_projection transposed: [embed, width] */
+} HglClipTextW;
+
+/* CLIPViTFM.forward(local_imgs, global_imgs, pred_masks, masking_block, fusion_mode)
+ * (model/backbone.py:117).  local,global: [N,3,res,res] NCHW fp32 (res=patch*grid);
+ * masks: [N,Hm,Wm] uint8 (0/1, torch.bool storage); out: [N,embed].
+ * last_layer is CLIPViTFM.last_layer (10 for ViT-B/16, model/backbone.py:16-21);
+ * masking_block<0 means "use last_layer" (model/backbone.py:118-119). */
+size_t hgl_clip_hybrid_workspace_bytes(const HglClipVisionW* w, int N, int Hm, int Wm, int fusion_mode);
+int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, const float* global_imgs,
+                            const uint8_t* masks, int N, int Hm, int Wm,
+                            int fusion_mode, int masking_block, int last_layer,
+                            float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* CLIP.encode_text(text) (clip/model.py:414-431): tokens [B,context] int32
+ * -> out [B,embed]; pooled at argmax(token id) (the EOT token). */
+size_t hgl_clip_text_workspace_bytes(const HglClipTextW* w, int B);
+int hgl_clip_encode_text(const HglClipTextW* w, const int32_t* tokens, int B, float* out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* TF.resize(pred_masks.float(), (g,g)) bilinear, align_corners=False, no
+ * antialias (model/backbone.py:160): masks [N,Hm,Wm] uint8 -> pm [N,g*g] f32. */
+int hgl_mask_resize(const uint8_t* masks, int N, int Hm, int Wm, int g, float* pm, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Scoring tail  (Hybridgl_main.py:153-230, utils.py:135-161,240-268,365-384)
+ * --------------------------------------------------------------------- */
+
+/* CLIPViTFM.calculate_score (model/backbone.py:74-87):
+ * logits[n,t] = logit_scale * <I_n/|I_n|, T_t/|T_t|>.  img [N,E], txt [T,E]. */
+int hgl_calculate_score(const float* img, const float* txt, int N, int T, int E,
+                        float logit_scale, float* logits, void* stream);
+
+/* Spatial-coherence score of every mask against a heat-map
+ * (Hybridgl_main.py:201-223): given raw imgattn [H,W] (already resized),
+ * applies min-max normalisation, the direction mask of gen_dir_mask
+ * (utils.py:135-161; dir: 0 none,1 left,2 right,3 middle), division by the mean,
+ * then score[n] = (2-black)*sum(attn*m_n)/sum(m_n) - black*sum(attn*(1-m_n))/sum(1-m_n).
+ * masks [N,H,W] uint8; score [N] f32; work: >= hgl_coherence_workspace_bytes(). */
+size_t hgl_coherence_workspace_bytes(int N, int H, int W);
+int hgl_coherence_scores(const float* imgattn, const uint8_t* masks, int N, int H, int W,
+                         int dirflag, float black, float* score,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Compute_IoU (utils.py:365-384): out[0]=|pred&gt|, out[1]=|pred|gt| as int64. */
+int hgl_iou(const uint8_t* pred, const uint8_t* gt, long long HW, int64_t* out_IU, void* stream);
+
+/* Whole per-sentence tail in one launch sequence (Hybridgl_main.py:153-230).
+ * hybrid [N,E]; text_ensemble [E]; neg_text [E]; boxes [N,4] int64 XYWH;
+ * gem_score [N] (from hgl_coherence_scores); relaword: 0 none,1 left,2 right,
+ * 3 up,4 down,5 big,6 small,7 within; has_other_nouns: len(nouns)!=0.
+ * Outputs: idx[0]=argmax(score_clip) ("pure hybridgl"), idx[1]=final index;
+ * score_clip [N] logits (pre-softmax), score_neg [N] logits. */
+size_t hgl_score_sentence_workspace_bytes(int N);
+int hgl_score_sentence(const float* hybrid, const float* text_ensemble, const float* neg_text,
+                       const int64_t* boxes, const float* gem_score,
+                       int N, int E, float logit_scale, int k1, int k2, float alpha,
+                       int relaword, int has_other_nouns,
+                       int32_t* idx, float* score_clip, float* score_neg,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Image synthesis (Hybridgl_main.py:93-125): per mask, the blurred-background
+ * "global" view and mean-filled "local" view, bilinear (no antialias) to res x res.
+ * sam_img [H,W,3] uint8, blurred [H,W,3] uint8 (cv2.GaussianBlur output),
+ * image_norm [3,H,W] f32 (ImageNet-normalised), masks [N,H,W] uint8.
+ * local,global: [N,3,res,res] f32. */
+int hgl_synthesize_views(const uint8_t* sam_img, const uint8_t* blurred, const float* image_norm,
+                         const uint8_t* masks, int N, int H, int W, int res,
+                         float* local_imgs, float* global_imgs, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYBRIDGL_H */

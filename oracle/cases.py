@@ -1,0 +1,62 @@
+"""ORACLE support (test infrastructure): seeded inputs of the golden cases, shared by
+oracle/gen_golden.py (which produced tests/golden/*.npz from the reference) and tests/."""
+import numpy as np
+
+from hybridgl_amd.synth import synth_masks
+
+
+def views_for_case(N, res, H, W):
+    """Seeded (local, global, masks) of one golden case -- shared with tests/ via import."""
+    rng = np.random.default_rng(100 + N)
+    loc = rng.standard_normal((N, 3, res, res)).astype(np.float32)
+    glo = rng.standard_normal((N, 3, res, res)).astype(np.float32)
+    return loc, glo, edge_masks(N, H, W, 200 + N)
+
+
+def edge_masks(N, H, W, seed):
+    """ragged set: seeded blobs + empty-after-resize (1 px), full, thin line, empty."""
+    m = synth_masks(N, H, W, seed)
+    specials = []
+    e = np.zeros((H, W), bool); e[H // 2 + 1, W // 2 + 1] = True; specials.append(e)   # single pixel
+    specials.append(np.ones((H, W), bool))                                             # full
+    t = np.zeros((H, W), bool); t[:, W // 3] = True; specials.append(t)                # thin column
+    specials.append(np.zeros((H, W), bool))                                            # empty
+    for i, s in enumerate(specials):
+        if i < N:
+            m[N - 1 - i] = s
+    return m
+
+
+
+
+RESIZE_CASES = [(640, 640, 14, 14), (427, 640, 14, 14), (97, 33, 4, 4),
+                (64, 48, 56, 56), (480, 640, 224, 224), (5, 7, 14, 14)]
+
+
+def resize_case(i):
+    """input [C,H,W] fp32 of resize golden case i (first three are 0/1 masks)."""
+    H, W, oh, ow = RESIZE_CASES[i]
+    rng = np.random.default_rng(30 + i)
+    x = rng.random((2 if i != 4 else 1, H, W)).astype(np.float32)
+    if i < 3:
+        x = (x > 0.7).astype(np.float32)
+    return x, (H, W, oh, ow)
+
+
+TAIL_CASES = [("none", "none", False), ("left", "left", True), ("big", "middle", False),
+              ("within", "right", True), ("small", "none", True), ("up", "left", False),
+              ("down", "none", True), ("right", "none", False)]
+
+
+def tail_case(ci, N=12, E=32, H=96, W=128):
+    """inputs of scoring-tail golden case ci: hybrid, t_pos, t_neg, masks, boxes, attn, gt."""
+    from hybridgl_amd.synth import boxes_from_masks, synth_heatmap
+    r = np.random.default_rng(500 + ci)
+    hybrid = r.standard_normal((N, E)).astype(np.float32)
+    t_pos = r.standard_normal((1, E)).astype(np.float32)
+    t_neg = r.standard_normal((1, E)).astype(np.float32)
+    masks = synth_masks(N, H, W, 600 + ci)
+    boxes = boxes_from_masks(masks)
+    attn = synth_heatmap(H, W, 700 + ci)
+    gt = masks[(7 * ci) % N]
+    return hybrid, t_pos, t_neg, masks, boxes, attn, gt

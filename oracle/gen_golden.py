@@ -1,0 +1,266 @@
+"""Golden-vector generator: runs the REFERENCE's own Python (read-only import from
+/root/reference, build container only) on seeded inputs and stores inputs/outputs as small
+.npz fixtures under tests/golden/.  Nothing from the reference (source or bytecode) is copied.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--only clip_tiny,...]
+
+Stubs (packages absent offline; semantics restated from the pinned versions in
+environment.yaml): torchvision 0.15.2 `TF.resize` on a float tensor == F.interpolate(bilinear,
+align_corners=False, antialias=False); `clip.load` returns the reference's own CLIP class built
+from our seeded state_dict; spacy/cv2/matplotlib/gem are import-only stubs (never called).
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = os.environ.get("HYBRIDGL_REFERENCE", "/root/reference")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hybridgl_amd import weights  # noqa: E402
+from hybridgl_amd.synth import synth_masks, synth_image  # noqa: E402
+from oracle.cases import views_for_case, resize_case, RESIZE_CASES, tail_case  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def install_stubs():
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+
+    def resize(img, size, interpolation=None, max_size=None, antialias=None):
+        if isinstance(size, int):
+            size = (size, size)
+        x = img
+        squeeze = 0
+        while x.dim() < 4:
+            x = x.unsqueeze(0)
+            squeeze += 1
+        y = F.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False, antialias=bool(antialias))
+        for _ in range(squeeze):
+            y = y.squeeze(0)
+        return y
+
+    tvf.resize = resize
+    tvt.functional = tvf
+    tv.transforms = tvt
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt,
+                        "torchvision.transforms.functional": tvf})
+    for name in ("spacy", "cv2", "gem", "ftfy"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["ftfy"].fix_text = lambda s: s
+    try:
+        import matplotlib  # noqa: F401
+    except ImportError:
+        mpl = types.ModuleType("matplotlib")
+        sys.modules["matplotlib"] = mpl
+        sys.modules["matplotlib.pyplot"] = types.ModuleType("matplotlib.pyplot")
+        sys.modules["matplotlib.gridspec"] = types.ModuleType("matplotlib.gridspec")
+
+
+def ref_clip_model_module():
+    return _load("ref_clip_model", os.path.join(REF, "third_party/modified_CLIP/clip/model.py"))
+
+
+def build_ref_clip(cfg_name, seed):
+    """The reference's CLIP class with our seeded weights (fp32, as clip/model.py:509 leaves it)."""
+    m = ref_clip_model_module()
+    cfg = weights.CLIP_CONFIGS[cfg_name]
+    model = m.CLIP(cfg["embed_dim"], cfg["image_resolution"], cfg["vision_layers"], cfg["vision_width"],
+                   cfg["vision_patch_size"], cfg["context_length"], cfg["vocab_size"],
+                   cfg["transformer_width"], cfg["transformer_heads"], cfg["transformer_layers"])
+    sd = weights.clip_state_dict(cfg_name, seed)
+    missing = model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    return model.eval().float()
+
+
+def build_ref_backbone(cfg_name, seed):
+    """The reference's CLIPViTFM with `clip.load` stubbed to return build_ref_clip()."""
+    clip_stub = types.ModuleType("clip")
+    clip_stub.load = lambda name, *a, **k: (build_ref_clip(cfg_name, seed), None)
+    sys.modules["clip"] = clip_stub
+    bb = _load("ref_backbone", os.path.join(REF, "model/backbone.py"))
+    model = bb.CLIPViTFM(model_name="ViT-B/16")
+    # make_attn_mask expands to N*num_heads rows (model/backbone.py:113-114): must equal the
+    # transformer's real head count for geometries other than ViT-B
+    model.num_heads = weights.CLIP_CONFIGS[cfg_name]["vision_width"] // 64
+    return model.eval()
+
+
+MODES = ["G2L", "L2G", "G2L&L2G", "token_masking", "attn_masking", "crop"]
+
+
+def gen_clip(cfg_name, seed, Ns, H, W, modes, tag):
+    model = build_ref_backbone(cfg_name, seed)
+    res = weights.CLIP_CONFIGS[cfg_name]["image_resolution"]
+    out = {}
+    for N in Ns:
+        # inputs are NOT stored: tests regenerate them from the same seeds (views_for_case)
+        loc, glo, masks = views_for_case(N, res, H, W)
+        out[f"N{N}_masks"] = np.packbits(masks, axis=-1)
+        loc_t, glo_t = torch.from_numpy(loc), torch.from_numpy(glo)
+        for mode in modes:
+            with torch.no_grad():
+                y = model(local_imgs=loc_t, global_imgs=glo_t, pred_masks=torch.from_numpy(masks),
+                          fusion_mode=mode, masking_block=9)
+            out[f"N{N}_{mode}"] = y.numpy().astype(np.float32)
+            print(tag, N, mode, y.shape, float(y.abs().mean()))
+    out["meta"] = np.array([seed, H, W], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+
+
+def gen_text(cfg_name, seed, tag):
+    model = build_ref_clip(cfg_name, seed)
+    cfg = weights.CLIP_CONFIGS[cfg_name]
+    rng = np.random.default_rng(7)
+    B, S, V = 6, cfg["context_length"], cfg["vocab_size"]
+    tok = np.zeros((B, S), dtype=np.int64)
+    for b in range(B):
+        n = int(rng.integers(1, S - 2))
+        tok[b, 0] = V - 2                       # SOT (49406 for the real vocab)
+        tok[b, 1:1 + n] = rng.integers(1, V - 2, size=n)
+        tok[b, 1 + n] = V - 1                   # EOT = highest id -> argmax pooling
+    with torch.no_grad():
+        y = model.encode_text(torch.from_numpy(tok))
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), tokens=tok.astype(np.int32),
+                        out=y.numpy().astype(np.float32), meta=np.array([seed], dtype=np.int64))
+    print(tag, y.shape)
+
+
+def gen_scoring():
+    """utils.py functions + CLIPViTFM.calculate_score + the inline tail of Hybridgl_main.py:153-230
+    driven through the reference's own helpers (relation_boxes, gen_dir_mask, Compute_IoU)."""
+    sys.path.insert(0, REF)
+    utils = _load("ref_utils", os.path.join(REF, "utils.py"))
+    bb = build_ref_backbone("tiny", 0)
+    rng = np.random.default_rng(11)
+    out = {}
+    # --- calculate_score
+    img = rng.standard_normal((9, 32)).astype(np.float32)
+    txt = rng.standard_normal((2, 32)).astype(np.float32)
+    with torch.no_grad():
+        out["cs_img"], out["cs_txt"] = img, txt
+        out["cs_out"] = bb.calculate_score(torch.from_numpy(img), torch.from_numpy(txt)).numpy()
+        out["cs_logit_scale"] = np.float32(bb.model.logit_scale.exp().item())
+    # --- relation_boxes table over all words (+ an unknown word)
+    boxes = np.array([[10, 10, 50, 40], [100, 20, 30, 30], [5, 5, 200, 200], [60, 60, 50, 40]], dtype=np.int64)
+    scores = np.array([0.5, 0.3, 0.2, 0.1], dtype=np.float32)
+    words = ["none", "left", "right", "up", "down", "big", "small", "within", "other"]
+    tab = np.zeros((len(words), 4, 4), dtype=np.float32)
+    bt, st = torch.from_numpy(boxes), torch.from_numpy(scores)
+    for w, word in enumerate(words):
+        for i in range(4):
+            for j in range(4):
+                tab[w, i, j] = float(utils.relation_boxes(bt[i], bt[j], st[i], st[j], word))
+    out["rb_boxes"], out["rb_scores"], out["rb_table"] = boxes, scores, tab
+    out["rb_words"] = np.array(words)
+    # --- gen_dir_mask
+    for flag in ["left", "right", "middle", "none", "up"]:
+        for (h, w) in [(3, 5), (4, 8), (2, 640), (2, 427)]:
+            out[f"dm_{flag}_{h}_{w}"] = utils.gen_dir_mask(flag, h, w, None).numpy().astype(np.float32)
+    # --- Compute_IoU
+    p = rng.random((24, 31)) > 0.6
+    t = rng.random((24, 31)) > 0.5
+    iou, lst, cI, cU = utils.Compute_IoU(torch.from_numpy(p), torch.from_numpy(t[None].astype(np.uint8)), 0, 0, [])
+    out["iou_pred"], out["iou_gt"] = p, t
+    out["iou_IU"] = np.array([int(cI), int(cU)], dtype=np.int64)
+    # --- whole tail (restated glue, reference helpers) on synthetic inputs
+    softmax0 = torch.nn.Softmax(0)
+    cases = []
+    H, W, N, E = 96, 128, 12, 32
+    for ci, (rela, dirflag, has_other) in enumerate([("none", "none", False), ("left", "left", True),
+                                                      ("big", "middle", False), ("within", "right", True),
+                                                      ("small", "none", True), ("up", "left", False),
+                                                      ("down", "none", True), ("right", "none", False)]):
+        hybrid, t_pos, t_neg, masks, boxes, attn, gt = tail_case(ci, N, E, H, W)
+        with torch.no_grad():
+            vf = torch.from_numpy(hybrid)
+            score_clip = bb.calculate_score(vf, torch.from_numpy(t_pos))
+            score_neg = bb.calculate_score(vf, torch.from_numpy(t_neg))
+            idx_pure = int(torch.argmax(score_clip))
+            sc_raw, sn_raw = score_clip.numpy()[:, 0].copy(), score_neg.numpy()[:, 0].copy()
+            score_clip, score_neg = softmax0(score_clip), softmax0(score_neg)
+            k1, k2 = min(3, N), min(6, N)
+            _, maxidxs = torch.topk(score_clip.view(-1), k=k1)
+            _, maxneg = torch.topk(score_neg.view(-1), k=k2)
+            bx = torch.from_numpy(boxes)
+            topscores = np.zeros(k1)
+            for i in range(k1):
+                for j in (maxidxs if not has_other else maxneg):
+                    sj = score_clip[j][0] if not has_other else score_neg[j][0]
+                    topscores[i] = topscores[i] + utils.relation_boxes(bx[maxidxs[i]], bx[j], score_clip[maxidxs[i]][0], sj, rela)
+            topscores = softmax0(torch.Tensor(topscores))
+            a = torch.from_numpy(attn)
+            a = (a - a.min()) / (a.max() - a.min())
+            a = a * utils.gen_dir_mask(dirflag, H, W, None)
+            a = a / a.mean()
+            black = 1.95 if rela == "big" else (1.5 if rela == "small" else 1.8)
+            gem = []
+            for pm_ in torch.from_numpy(masks):
+                pm_ = pm_.type(torch.uint8)
+                gem.append(float((a * (2 - black) * pm_ / (pm_.sum())).sum() - (a * black * (1 - pm_) / ((1 - pm_).sum())).sum()))
+            gem = np.array(gem, dtype=np.float32)
+            for i in range(k1):
+                topscores[i] = topscores[i] * (1 - 0.6) + 0.6 * float(gem[maxidxs[i]])
+            idx_final = int(maxidxs[torch.argmax(topscores)])
+            _, _, cI, cU = utils.Compute_IoU(torch.from_numpy(masks[idx_final]), torch.from_numpy(gt[None].astype(np.uint8)), 0, 0, [])
+        out[f"tail{ci}_gem"] = gem
+        out[f"tail{ci}_sc"], out[f"tail{ci}_sn"] = sc_raw, sn_raw
+        out[f"tail{ci}_idx"] = np.array([idx_pure, idx_final], dtype=np.int64)
+        out[f"tail{ci}_IU"] = np.array([int(cI), int(cU)], dtype=np.int64)
+        cases.append(f"{rela},{dirflag},{int(has_other)}")
+        print("tail", ci, rela, dirflag, has_other, idx_pure, idx_final)
+    out["tail_cases"] = np.array(cases)
+    out["tail_hw"] = np.array([H, W, N], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "scoring.npz"), **out)
+
+
+def gen_resize():
+    """bilinear no-antialias resize vs the real torch F.interpolate (mask down-sample and 224 views).
+    Inputs are regenerated from the seed by the tests (oracle/cases.py:resize_case)."""
+    out = {}
+    for i in range(len(RESIZE_CASES)):
+        x, (H, W, oh, ow) = resize_case(i)
+        out[f"r{i}_out"] = F.interpolate(torch.from_numpy(x)[None], size=(oh, ow), mode="bilinear",
+                                         align_corners=False)[0].numpy()
+    np.savez_compressed(os.path.join(GOLD, "resize.npz"), **out)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    install_stubs()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    sel = set(args.only.split(",")) if args.only else None
+    want = lambda k: sel is None or k in sel
+    if want("clip_tiny"):
+        gen_clip("tiny", 0, [1, 3, 5], 97, 130, MODES, "clip_tiny")
+    if want("clip_b16"):
+        gen_clip("ViT-B/16", 0, [4], 640, 640, ["G2L", "L2G", "G2L&L2G"], "clip_b16")
+    if want("text_tiny"):
+        gen_text("tiny", 0, "text_tiny")
+    if want("text_b16"):
+        gen_text("ViT-B/16", 0, "text_b16")
+    if want("scoring"):
+        gen_scoring()
+    if want("resize"):
+        gen_resize()

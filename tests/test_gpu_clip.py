@@ -1,0 +1,110 @@
+"""GPU parity of the CLIP hybrid encoder / text encoder (drop-in CLIPViTFM surface) against
+(1) fixtures captured from the reference and (2) the numpy oracle on the same seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hybridgl_amd import weights
+from hybridgl_amd.backbone import CLIPViTFM
+from oracle import clip_oracle as O
+from oracle.cases import views_for_case
+
+pytestmark = pytest.mark.gpu
+
+MODES = ["G2L", "L2G", "G2L&L2G", "token_masking", "attn_masking", "crop"]
+
+
+@pytest.fixture(scope="module")
+def tiny(cuda):
+    sd = weights.clip_state_dict("tiny", 0)
+    return sd, CLIPViTFM("tiny", state_dict=sd, device=cuda)
+
+
+@pytest.fixture(scope="module")
+def b16(cuda):
+    sd = weights.clip_state_dict("ViT-B/16", 0)
+    return sd, CLIPViTFM("ViT-B/16", state_dict=sd, device=cuda)
+
+
+def _run(model, loc, glo, masks, mode, dev, mb=9):
+    return model(torch.from_numpy(loc).to(dev), torch.from_numpy(glo).to(dev), torch.from_numpy(masks).to(dev),
+                 masking_block=mb, fusion_mode=mode).cpu().numpy()
+
+
+@pytest.mark.parametrize("N", [1, 3, 5])
+@pytest.mark.parametrize("mode", MODES)
+def test_tiny_vs_reference_golden(cuda, golden_dir, tiny, N, mode):
+    g = np.load(os.path.join(golden_dir, "clip_tiny.npz"))
+    _, H, W = (int(v) for v in g["meta"])
+    loc, glo, masks = views_for_case(N, 64, H, W)
+    y = _run(tiny[1], loc, glo, masks, mode, cuda)
+    np.testing.assert_allclose(y, g[f"N{N}_{mode}"], rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize("mode", ["G2L", "L2G", "G2L&L2G"])
+def test_b16_vs_reference_golden(cuda, golden_dir, b16, mode):
+    g = np.load(os.path.join(golden_dir, "clip_b16.npz"))
+    _, H, W = (int(v) for v in g["meta"])
+    loc, glo, masks = views_for_case(4, 224, H, W)
+    y = _run(b16[1], loc, glo, masks, mode, cuda)
+    np.testing.assert_allclose(y, g[f"N4_{mode}"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("mb", [0, 5, 11])
+def test_tiny_other_masking_blocks_vs_oracle(cuda, tiny, mb):
+    loc, glo, masks = views_for_case(3, 64, 97, 130)
+    for mode in ["G2L", "L2G", "G2L&L2G"]:
+        y = _run(tiny[1], loc, glo, masks, mode, cuda, mb)
+        ref = O.clip_hybrid_forward(tiny[0], loc, glo, masks, mb, mode, 10)
+        np.testing.assert_allclose(y, ref, rtol=0, atol=5e-5)
+
+
+def test_b16_scores_and_winner_vs_oracle(cuda, b16):
+    """north_star bar: similarity scores within 1e-3 (logits are x100), winning index bit-exact."""
+    sd, model = b16
+    N = 8
+    rng = np.random.default_rng(77)
+    loc = rng.standard_normal((N, 3, 224, 224)).astype(np.float32)
+    glo = rng.standard_normal((N, 3, 224, 224)).astype(np.float32)
+    from hybridgl_amd.synth import synth_masks, synth_tokens
+    masks = synth_masks(N, 640, 640, 5)
+    tok = synth_tokens(2, 77, 49408, 6)
+    feats = model(torch.from_numpy(loc).to(cuda), torch.from_numpy(glo).to(cuda), torch.from_numpy(masks).to(cuda),
+                  masking_block=9, fusion_mode="G2L")
+    txt = model.model.encode_text(torch.from_numpy(tok).to(cuda))
+    logits = model.calculate_score(feats, txt).cpu().numpy()
+    rf = O.clip_hybrid_forward(sd, loc, glo, masks, 9, "G2L", 10)
+    rt = O.encode_text(sd, tok, heads=8)
+    rl = O.calculate_score(rf, rt, float(np.exp(sd["logit_scale"])))
+    np.testing.assert_allclose(txt.cpu().numpy(), rt, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(logits, rl, rtol=0, atol=1e-3)
+    assert np.array_equal(logits.argmax(0), rl.argmax(0))
+
+
+@pytest.mark.parametrize("name,cfg", [("text_tiny.npz", "tiny"), ("text_b16.npz", "ViT-B/16")])
+def test_encode_text_vs_reference_golden(cuda, golden_dir, tiny, b16, name, cfg):
+    g = np.load(os.path.join(golden_dir, name))
+    model = tiny[1] if cfg == "tiny" else b16[1]
+    y = model.model.encode_text(torch.from_numpy(g["tokens"]).to(cuda)).cpu().numpy()
+    np.testing.assert_allclose(y, g["out"], rtol=0, atol=5e-5)
+
+
+def test_linearity_of_head_and_determinism(cuda, b16):
+    """size-independent properties at the BASELINE size (N=64): the result does not depend on the
+    batch composition (each mask row is independent) and repeated runs are bit-identical."""
+    _, model = b16
+    N = 64
+    rng = np.random.default_rng(78)
+    loc = torch.from_numpy(rng.standard_normal((N, 3, 224, 224)).astype(np.float32)).to(cuda)
+    glo = torch.from_numpy(rng.standard_normal((N, 3, 224, 224)).astype(np.float32)).to(cuda)
+    from hybridgl_amd.synth import synth_masks
+    masks = torch.from_numpy(synth_masks(N, 640, 640, 9)).to(cuda)
+    y1 = model(loc, glo, masks, masking_block=9, fusion_mode="G2L")
+    y2 = model(loc, glo, masks, masking_block=9, fusion_mode="G2L")
+    assert torch.equal(y1, y2)
+    sub = model(loc[10:14].contiguous(), glo[10:14].contiguous(), masks[10:14].contiguous(), masking_block=9,
+                fusion_mode="G2L")
+    np.testing.assert_allclose(sub.cpu().numpy(), y1[10:14].cpu().numpy(), rtol=0, atol=2e-5)
+    assert torch.isfinite(y1).all()

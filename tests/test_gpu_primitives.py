@@ -1,0 +1,234 @@
+"""GPU parity of every primitive kernel against the numpy oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from hybridgl_amd import ops
+from oracle import clip_oracle as O
+from oracle.cases import RESIZE_CASES, TAIL_CASES, resize_case, tail_case
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (197, 2304, 768), (64, 512, 768), (1, 4, 256),
+                                   (300, 96, 100), (1000, 136, 3072), (77, 32, 64)])
+@pytest.mark.parametrize("act", ["none", "quickgelu", "gelu", "relu"])
+def test_gemm(cuda, M, N, K, act):
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    y = ops.gemm(T(a, cuda), T(w, cuda), T(b, cuda), T(r, cuda), act).cpu().numpy()
+    z = a.astype(np.float64) @ w.astype(np.float64).T + b
+    if act == "quickgelu":
+        z = z / (1 + np.exp(-1.702 * z))
+    elif act == "gelu":
+        from scipy.special import erf
+        z = 0.5 * z * (1 + erf(z / np.sqrt(2)))
+    elif act == "relu":
+        z = np.maximum(z, 0)
+    z = z + r
+    np.testing.assert_allclose(y, z, rtol=0, atol=2e-5)
+
+
+def test_gemm_inplace_residual_and_asymmetry(cuda):
+    """A = I with an asymmetric W catches a transposed C write; residual aliasing C must work."""
+    n = 160
+    w = np.arange(n * n, dtype=np.float32).reshape(n, n) / (n * n)
+    x = T(np.eye(n, dtype=np.float32), cuda)
+    c = T(np.ones((n, n), np.float32), cuda)
+    ops.gemm(x, T(w, cuda), None, c, "none", out=c)
+    np.testing.assert_allclose(c.cpu().numpy(), w.T + 1, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("D", [256, 512, 768, 1280, 96, 128])
+def test_layernorm(cuda, D):
+    rng = np.random.default_rng(D)
+    x = (rng.standard_normal((301, D)) * 3 + 1).astype(np.float32)
+    w = rng.standard_normal(D).astype(np.float32)
+    b = rng.standard_normal(D).astype(np.float32)
+    for eps in (1e-5, 1e-6):
+        y = ops.layernorm(T(x, cuda), T(w, cuda), T(b, cuda), eps).cpu().numpy()
+        np.testing.assert_allclose(y, O.layer_norm(x, w, b, eps), rtol=0, atol=2e-5)
+
+
+def _attn_ref(q, k, v, heads, scale, add_mask=None, bias=None):
+    B, Sq, D = q.shape
+    Sk = k.shape[1]
+    hd = D // heads
+    qh = q.reshape(B, Sq, heads, hd).transpose(0, 2, 1, 3).astype(np.float64) * scale
+    kh = k.reshape(B, Sk, heads, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    vh = v.reshape(B, Sk, heads, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    s = qh @ kh.transpose(0, 1, 3, 2)
+    if bias is not None:
+        s = s + bias
+    if add_mask is not None:
+        s = s + add_mask
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    return (p @ vh).transpose(0, 2, 1, 3).reshape(B, Sq, D)
+
+
+@pytest.mark.parametrize("B,heads,S,hd", [(3, 12, 197, 64), (2, 2, 17, 64), (2, 16, 196, 80), (5, 8, 7, 32),
+                                          (2, 8, 300, 16), (1, 4, 64, 64), (1, 2, 129, 64)])
+def test_attention_plain(cuda, B, heads, S, hd):
+    rng = np.random.default_rng(B * 100 + S)
+    D = heads * hd
+    q, k, v = (rng.standard_normal((B, S, D)).astype(np.float32) for _ in range(3))
+    y = ops.attention(T(q, cuda), T(k, cuda), T(v, cuda), heads).cpu().numpy()
+    np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5), rtol=0, atol=2e-5)
+
+
+def test_attention_cross_lengths(cuda):
+    """decoder shapes: few queries x many keys and the reverse (transformer.py:185-240)."""
+    rng = np.random.default_rng(5)
+    for Sq, Sk, heads, hd in [(7, 4096, 8, 16), (4096, 7, 8, 16), (33, 95, 4, 32)]:
+        D = heads * hd
+        q = rng.standard_normal((2, Sq, D)).astype(np.float32)
+        k = rng.standard_normal((2, Sk, D)).astype(np.float32)
+        v = rng.standard_normal((2, Sk, D)).astype(np.float32)
+        y = ops.attention(T(q, cuda), T(k, cuda), T(v, cuda), heads).cpu().numpy()
+        np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5), rtol=0, atol=2e-5)
+
+
+def test_attention_causal(cuda):
+    rng = np.random.default_rng(9)
+    B, heads, S, hd = 4, 8, 77, 64
+    D = heads * hd
+    q, k, v = (rng.standard_normal((B, S, D)).astype(np.float32) for _ in range(3))
+    mask = np.triu(np.full((S, S), -np.inf), 1)
+    y = ops.attention(T(q, cuda), T(k, cuda), T(v, cuda), heads, mask="causal").cpu().numpy()
+    np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5, mask), rtol=0, atol=2e-5)
+
+
+def test_attention_cls_keep_with_offsets(cuda):
+    """keep bytes apply to batches >= keep_b0, row (b-keep_b0)%keep_n; empty keep row -> CLS sees itself."""
+    rng = np.random.default_rng(10)
+    B, heads, S, hd, n = 6, 12, 197, 64, 2
+    D = heads * hd
+    q, k, v = (rng.standard_normal((B, S, D)).astype(np.float32) for _ in range(3))
+    keep = rng.random((n, S - 1)) > 0.5
+    keep[1] = False
+    add = np.zeros((B, 1, S, S))
+    for b in range(2, B):
+        add[b, 0, 0, 1:] = np.where(keep[(b - 2) % n], 0, -np.inf)
+    y = ops.attention(T(q, cuda), T(k, cuda), T(v, cuda), heads, mask="cls_keep", keep=T(keep, cuda),
+                      keep_b0=2, keep_n=n).cpu().numpy()
+    np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5, add), rtol=0, atol=2e-5)
+
+
+def test_attention_spiked_scores_online_softmax(cuda):
+    """force the running max to jump at a late key tile (rescale branch of the online softmax)."""
+    rng = np.random.default_rng(12)
+    B, heads, S, hd = 1, 1, 200, 64
+    q, k, v = (rng.standard_normal((B, S, hd)).astype(np.float32) for _ in range(3))
+    k[0, 150] = q[0, 3] * 4
+    k[0, 199] = q[0, 100] * 6
+    y = ops.attention(T(q, cuda), T(k, cuda), T(v, cuda), heads).cpu().numpy()
+    np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5), rtol=0, atol=2e-5)
+
+
+def test_attention_rel_pos_bias(cuda):
+    """decomposed relative position bias tables (image_encoder.py:325-361)."""
+    rng = np.random.default_rng(13)
+    B, heads, kh, kw, hd = 2, 3, 14, 14, 80
+    S, D = kh * kw, heads * hd
+    q, k, v = (rng.standard_normal((B, S, D)).astype(np.float32) for _ in range(3))
+    rel_h = rng.standard_normal((B * heads, S, kh)).astype(np.float32)
+    rel_w = rng.standard_normal((B * heads, S, kw)).astype(np.float32)
+    bias = (rel_h[:, :, :, None] + rel_w[:, :, None, :]).reshape(B, heads, S, S)
+    y = ops.attention(T(q, cuda), T(k, cuda), T(v, cuda), heads, rel_h=T(rel_h, cuda), rel_w=T(rel_w, cuda)).cpu().numpy()
+    np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5, None, bias), rtol=0, atol=3e-5)
+
+
+@pytest.mark.parametrize("i", range(3))
+def test_mask_resize_matches_golden(cuda, golden_dir, i):
+    import os
+    g = np.load(os.path.join(golden_dir, "resize.npz"))
+    x, (H, W, oh, ow) = resize_case(i)
+    pm = ops.mask_resize(T(x.astype(bool), cuda), oh).cpu().numpy().reshape(-1, oh, ow)
+    np.testing.assert_allclose(pm, g[f"r{i}_out"], rtol=0, atol=1e-6)
+    assert np.array_equal(pm != 0, g[f"r{i}_out"] != 0)
+
+
+def test_calculate_score(cuda):
+    rng = np.random.default_rng(14)
+    img = rng.standard_normal((64, 512)).astype(np.float32)
+    txt = rng.standard_normal((3, 512)).astype(np.float32)
+    y = ops.calculate_score(T(img, cuda), T(txt, cuda), 100.0).cpu().numpy()
+    np.testing.assert_allclose(y, O.calculate_score(img, txt, 100.0), rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("ci", range(len(TAIL_CASES)))
+def test_scoring_tail_vs_golden(cuda, golden_dir, ci):
+    import os
+    g = np.load(os.path.join(golden_dir, "scoring.npz"))
+    H, W, N = (int(v) for v in g["tail_hw"])
+    rela, dirflag, has_other = TAIL_CASES[ci]
+    hybrid, t_pos, t_neg, masks, boxes, attn, gt = tail_case(ci, N, 32, H, W)
+    black = 1.95 if rela == "big" else (1.5 if rela == "small" else 1.8)
+    gem = ops.coherence_scores(T(attn, cuda), T(masks, cuda), dirflag, black)
+    np.testing.assert_allclose(gem.cpu().numpy(), g[f"tail{ci}_gem"], rtol=2e-5, atol=2e-5)
+    idx, sc, sn = ops.score_sentence(T(hybrid, cuda), T(t_pos, cuda), T(t_neg, cuda), T(boxes, cuda), gem,
+                                     float(g["cs_logit_scale"]), 3, 6, 0.6, rela, has_other)
+    np.testing.assert_allclose(sc.cpu().numpy(), g[f"tail{ci}_sc"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(sn.cpu().numpy(), g[f"tail{ci}_sn"], rtol=0, atol=1e-3)
+    assert [int(v) for v in idx.cpu()] == [int(v) for v in g[f"tail{ci}_idx"]]   # bit-exact indices
+    iu = ops.iou_counts(T(masks[int(idx[1])], cuda), T(gt, cuda)).cpu().numpy()
+    assert tuple(int(v) for v in iu) == tuple(int(v) for v in g[f"tail{ci}_IU"])
+
+
+def test_coherence_full_size_and_edges(cuda):
+    """640x640 x 64 masks (BASELINE size) vs the oracle; odd sizes exercise the unaligned path."""
+    from hybridgl_amd.synth import synth_heatmap, synth_masks
+    for (N, H, W, flag) in [(64, 640, 640, "middle"), (5, 37, 53, "left"), (3, 427, 640, "right")]:
+        masks = synth_masks(N, H, W, 1)
+        attn = synth_heatmap(H, W, 2)
+        y = ops.coherence_scores(T(attn, cuda), T(masks, cuda), flag, 1.8).cpu().numpy()
+        np.testing.assert_allclose(y, O.coherence_scores(attn, masks, flag, 1.8), rtol=2e-5, atol=2e-5)
+
+
+def test_iou_sizes_and_properties(cuda):
+    rng = np.random.default_rng(15)
+    for n in [1, 15, 16, 17, 640 * 640, 427 * 640 + 3]:
+        p = rng.random(n) > 0.5
+        g = rng.random(n) > 0.3
+        iu = ops.iou_counts(T(p, cuda), T(g, cuda)).cpu().numpy()
+        assert tuple(iu) == O.compute_iou(p, g)
+        same = ops.iou_counts(T(p, cuda), T(p, cuda)).cpu().numpy()
+        assert same[0] == same[1] == p.sum()
+    z = np.zeros(100, bool)
+    assert tuple(ops.iou_counts(T(z, cuda), T(z, cuda)).cpu().numpy()) == (0, 0)
+    # nonzero bytes other than 1 count as True (target.type(torch.bool), utils.py:367-368)
+    a = np.array([0, 2, 255, 1] * 8, np.uint8)
+    b = np.array([1, 0, 7, 0] * 8, np.uint8)
+    assert tuple(ops.iou_counts(T(a, cuda), T(b, cuda)).cpu().numpy()) == (8, 32)
+
+
+def test_synthesize_views(cuda):
+    from hybridgl_amd.synth import box_blur_u8, imagenet_normalize, synth_image, synth_masks
+    for (N, H, W, res) in [(4, 97, 130, 64), (3, 640, 640, 224)]:
+        img = synth_image(H, W, 3)
+        blur = box_blur_u8(img)
+        norm = imagenet_normalize(img)
+        masks = synth_masks(N, H, W, 4)
+        loc, glo = ops.synthesize_views(T(img, cuda), T(blur, cuda), T(norm, cuda), T(masks, cuda), res)
+        rl, rg = O.synthesize_views(img, blur, norm, masks, res)
+        np.testing.assert_allclose(loc.cpu().numpy(), rl, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(glo.cpu().numpy(), rg, rtol=0, atol=5e-6)
+
+
+def test_errors_are_loud(cuda):
+    from hybridgl_amd._lib import HybridGLError
+    with pytest.raises(HybridGLError):
+        ops.gemm(torch.zeros(4, 6, device=cuda), torch.zeros(4, 6, device=cuda))  # K % 4 != 0
+    with pytest.raises(HybridGLError):
+        ops.layernorm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8))  # CPU tensor
+    with pytest.raises(HybridGLError):
+        ops.attention(*(torch.zeros(1, 8, 24, device=cuda) for _ in range(3)), heads=1)  # hd=24

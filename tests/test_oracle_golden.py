@@ -1,0 +1,122 @@
+"""CPU: the numpy oracle against fixtures captured from the reference itself
+(oracle/gen_golden.py, run in the build container with /root/reference imported read-only)."""
+import os
+
+import numpy as np
+import pytest
+
+from hybridgl_amd import weights
+from oracle import clip_oracle as O
+from oracle.cases import RESIZE_CASES, TAIL_CASES, resize_case, tail_case, views_for_case
+
+
+def _load(golden_dir, name):
+    path = os.path.join(golden_dir, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated")
+    return np.load(path)
+
+
+def _unpack(bits, W):
+    return np.unpackbits(bits, axis=-1)[..., :W].astype(bool)
+
+
+MODES = ["G2L", "L2G", "G2L&L2G", "token_masking", "attn_masking", "crop"]
+
+
+@pytest.mark.parametrize("N", [1, 3, 5])
+@pytest.mark.parametrize("mode", MODES)
+def test_clip_tiny_all_modes(golden_dir, N, mode):
+    g = _load(golden_dir, "clip_tiny.npz")
+    seed, H, W = (int(v) for v in g["meta"])
+    sd = weights.clip_state_dict("tiny", seed)
+    loc, glo, masks = views_for_case(N, 64, H, W)
+    assert np.array_equal(masks, _unpack(g[f"N{N}_masks"], W))  # the seeded inputs are the fixture's
+    y = O.clip_hybrid_forward(sd, loc, glo, masks, masking_block=9, fusion_mode=mode, last_layer=10)
+    ref = g[f"N{N}_{mode}"]
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("mode", ["G2L", "L2G", "G2L&L2G"])
+def test_clip_b16(golden_dir, mode):
+    g = _load(golden_dir, "clip_b16.npz")
+    seed, H, W = (int(v) for v in g["meta"])
+    sd = weights.clip_state_dict("ViT-B/16", seed)
+    loc, glo, masks = views_for_case(4, 224, H, W)
+    y = O.clip_hybrid_forward(sd, loc, glo, masks, masking_block=9, fusion_mode=mode, last_layer=10)
+    np.testing.assert_allclose(y, g[f"N4_{mode}"], rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize("name,cfg", [("text_tiny.npz", "tiny"), ("text_b16.npz", "ViT-B/16")])
+def test_encode_text(golden_dir, name, cfg):
+    g = _load(golden_dir, name)
+    sd = weights.clip_state_dict(cfg, int(g["meta"][0]))
+    y = O.encode_text(sd, g["tokens"], heads=weights.CLIP_CONFIGS[cfg]["transformer_heads"])
+    np.testing.assert_allclose(y, g["out"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("i", range(len(RESIZE_CASES)))
+def test_bilinear_resize(golden_dir, i):
+    g = _load(golden_dir, "resize.npz")
+    x, (H, W, oh, ow) = resize_case(i)
+    y = O.bilinear_resize(x, oh, ow)
+    np.testing.assert_allclose(y, g[f"r{i}_out"], rtol=0, atol=1e-6)
+
+
+def test_calculate_score(golden_dir):
+    g = _load(golden_dir, "scoring.npz")
+    y = O.calculate_score(g["cs_img"], g["cs_txt"], float(g["cs_logit_scale"]))
+    np.testing.assert_allclose(y, g["cs_out"], rtol=0, atol=2e-5)
+    assert abs(float(g["cs_logit_scale"]) - 1 / 0.07) < 1e-4
+
+
+def test_relation_boxes_table(golden_dir):
+    g = _load(golden_dir, "scoring.npz")
+    boxes, scores, tab = g["rb_boxes"], g["rb_scores"], g["rb_table"]
+    for w, word in enumerate(g["rb_words"]):
+        for i in range(4):
+            for j in range(4):
+                got = O.relation_boxes(boxes[i], boxes[j], scores[i], scores[j], str(word))
+                assert abs(float(got) - float(tab[w, i, j])) <= 1e-7, (word, i, j)
+    # SURVEY.md known answers: left:[0,.15,.10] big:[0,.15,0] within:[.25,0,.10] for box 0
+    words = [str(w) for w in g["rb_words"]]
+    np.testing.assert_allclose(tab[words.index("left"), 0, :3], [0, .15, .10], atol=1e-7)
+    np.testing.assert_allclose(tab[words.index("big"), 0, :3], [0, .15, 0], atol=1e-7)
+    np.testing.assert_allclose(tab[words.index("within"), 0, :3], [.25, 0, .10], atol=1e-7)
+
+
+def test_gen_dir_mask(golden_dir):
+    g = _load(golden_dir, "scoring.npz")
+    for flag in ["left", "right", "middle", "none", "up"]:
+        for (h, w) in [(3, 5), (4, 8), (2, 640), (2, 427)]:
+            np.testing.assert_array_equal(O.gen_dir_mask(flag, h, w), g[f"dm_{flag}_{h}_{w}"])
+    np.testing.assert_allclose(O.gen_dir_mask("left", 1, 5)[0], [1, .75, .5, .25, 0])
+    np.testing.assert_allclose(O.gen_dir_mask("middle", 1, 5)[0], [0, 1, 1, .5, 0])
+
+
+def test_compute_iou(golden_dir):
+    g = _load(golden_dir, "scoring.npz")
+    assert O.compute_iou(g["iou_pred"], g["iou_gt"]) == tuple(int(v) for v in g["iou_IU"])
+    p = np.zeros((4, 4), bool); p[:2] = True
+    t = np.zeros((4, 4), bool); t[1:] = True
+    assert O.compute_iou(p, t) == (4, 16)
+    assert O.compute_iou(np.zeros((3, 3), bool), np.zeros((3, 3), bool)) == (0, 0)
+
+
+@pytest.mark.parametrize("ci", range(len(TAIL_CASES)))
+def test_scoring_tail(golden_dir, ci):
+    g = _load(golden_dir, "scoring.npz")
+    H, W, N = (int(v) for v in g["tail_hw"])
+    rela, dirflag, has_other = TAIL_CASES[ci]
+    assert str(g["tail_cases"][ci]) == f"{rela},{dirflag},{int(has_other)}"
+    hybrid, t_pos, t_neg, masks, boxes, attn, gt = tail_case(ci, N, 32, H, W)
+    black = 1.95 if rela == "big" else (1.5 if rela == "small" else 1.8)
+    gem = O.coherence_scores(attn, masks, dirflag, black)
+    np.testing.assert_allclose(gem, g[f"tail{ci}_gem"], rtol=2e-5, atol=2e-5)
+    ip, ifin, sc, sn = O.score_sentence(hybrid, t_pos, t_neg, boxes, gem, float(g["cs_logit_scale"]), 3, 6,
+                                        0.6, rela, has_other)
+    np.testing.assert_allclose(sc, g[f"tail{ci}_sc"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(sn, g[f"tail{ci}_sn"], rtol=0, atol=2e-5)
+    assert [ip, ifin] == [int(v) for v in g[f"tail{ci}_idx"]]
+    assert O.compute_iou(masks[ifin], gt) == tuple(int(v) for v in g[f"tail{ci}_IU"])
