@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Benchmark of the HybridGL hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One step = one dataset item ("ref") of BASELINE.json configs[1]: a 640x640 image with 64 mask
+proposals and 3 text queries, G2L fusion, CLIP ViT-B/16 -- view synthesis, CLIP hybrid encoder,
+text encoder (9 strings), and the per-sentence scoring tail with IoU.  All inputs are synthetic
+(hybridgl_amd/synth.py), weights are seeded random (no checkpoints offline), and every input is
+resident in HBM before the timed region.  Refs are sharded over ranks with no data-path
+collective (weak scaling); metrics are all-gathered once at the end.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+# dense fp32 matrix peak and HBM peak from /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops_per_ref(N=64, n_strings=9):
+    """SURVEY.md 8d, minimal variant (dead final-block streams removed), ViT-B/16 G2L."""
+    blk = 2.908e9          # per sequence per block (qkv .697, proj .232, mlp 1.859, attn .119)
+    patch = 0.231e9        # patch embed per sequence
+    clip = 2 * N * patch + 23 * N * blk
+    text = 5.96e9 * n_strings
+    return clip + text
+
+
+def prof_read(lib, cls):
+    n = C.c_longlong()
+    ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+    lib.hgl_prof_read(cls, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
+    return n.value, ms.value, fl.value, by.value
+
+
+def cpu_baseline(fusion_mode, n_sample=8):
+    """Oracle (numpy port of the reference algorithm, oracle/clip_oracle.py) timed on the host
+    cores for a bounded sample of the same workload; extrapolated to one ref."""
+    from hybridgl_amd import synth, weights
+    from oracle import clip_oracle as O
+    threads = os.cpu_count() or 1
+    sd = weights.clip_state_dict("ViT-B/16", 0)
+    H = W = 640
+    img = synth.synth_image(H, W, 1000)
+    blur = synth.box_blur_u8(img)
+    norm = synth.imagenet_normalize(img)
+    masks = synth.synth_masks(64, H, W, 2000)
+    boxes = synth.boxes_from_masks(masks)
+    tokens = synth.synth_tokens(9, 77, 49408, 3000)
+    t0 = time.perf_counter()
+    loc, glo = O.synthesize_views(img, blur, norm, masks[:n_sample], 224)
+    t1 = time.perf_counter()
+    feats = O.clip_hybrid_forward(sd, loc, glo, masks[:n_sample], 9, fusion_mode, 10)
+    t2 = time.perf_counter()
+    text = O.encode_text(sd, tokens, heads=8)
+    t3 = time.perf_counter()
+    hyb = np.concatenate([feats] * (64 // n_sample), 0)
+    for j in range(3):
+        d, r, nn = synth.PARSE_RECORDS[j]
+        attn = synth.synth_heatmap(H, W, 4000 + j)
+        gem = O.coherence_scores(attn, masks, d, 1.8)
+        ip, ifin, _, _ = O.score_sentence(hyb, 0.5 * text[3 * j:3 * j + 1] + 0.5 * text[3 * j + 1:3 * j + 2],
+                                          text[3 * j + 2:3 * j + 3], boxes, gem, 100.0, 3, 6, 0.6, r, nn != 0)
+        O.compute_iou(masks[ip], masks[0]); O.compute_iou(masks[ifin], masks[0])
+    t4 = time.perf_counter()
+    scale = 64 / n_sample
+    t_ref = (t1 - t0) * scale + (t2 - t1) * scale + (t3 - t2) + (t4 - t3)
+    return {"value": 1.0 / t_ref, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"numpy oracle: views+CLIP hybrid {fusion_mode} on {n_sample} of 64 masks "
+                      f"({t2 - t0:.1f}s, scaled x{scale:g}), 9 text strings ({t3 - t2:.1f}s), "
+                      f"3-sentence tail on 64 masks ({t4 - t3:.1f}s); numpy BLAS threads = host default"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--fusion", default="G2L", choices=["G2L", "L2G", "G2L&L2G"])
+    ap.add_argument("--masks", type=int, default=64)
+    ap.add_argument("--pool", type=int, default=2, help="distinct synthetic refs resident per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from hybridgl_amd import _lib
+    from hybridgl_amd.backbone import CLIPViTFM
+    from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
+
+    lib = _lib.load()
+    model = CLIPViTFM("ViT-B/16", seed=0, device=dev)
+    pipe = HybridGLPipeline(model, fusion_mode=args.fusion, masking_block=9)
+    # rank r owns refs i = r (mod world) of the shuffle=False order
+    refs = [synthetic_ref(rank + world * j, dev, N=args.masks)[0] for j in range(args.pool)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        pipe.step(refs[i % len(refs)])
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pipe.step(refs[i % len(refs)])
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    # ---- roofline leg: the same steps with HIP events around every launch of the dominant kernel
+    lib.hgl_prof_enable(1)
+    nprof = 2
+    for i in range(nprof):
+        pipe.step(refs[i % len(refs)])
+    torch.cuda.synchronize()
+    lib.hgl_prof_enable(0)
+    g_n, g_ms, g_fl, g_by = prof_read(lib, 0)
+    a_n, a_ms, a_fl, a_by = prof_read(lib, 1)
+
+    m = pipe.metrics()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        # the only collective of the path: one all-gather of the metric vector (RCCL over xGMI)
+        vec = torch.tensor(m["cum"] + [m["n_sentences"]], dtype=torch.int64, device=dev)
+        out = [torch.zeros_like(vec) for _ in range(world)]
+        dist.all_gather(out, vec)
+        tot = torch.stack(out).sum(0).cpu().numpy()
+        m["cum"] = [int(v) for v in tot[:4]]
+        m["oIoU"] = tot[0] * 100.0 / max(int(tot[1]), 1)
+        m["oIoU_final"] = tot[2] * 100.0 / max(int(tot[3]), 1)
+
+    if rank == 0:
+        total_refs = args.steps * world
+        achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("gemm_f32_kernel", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        rec = {
+            "metric": "images/sec (whole node)",
+            "value": total_refs / dt,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (seeded images/masks/tokens/heat-maps; seeded random weights)",
+            "config": {
+                "workload": f"RefCOCO-shaped ref: 640x640 image, {args.masks} proposals given, 3 queries x "
+                            f"(sentence+noun phrase+1 other noun); view synthesis + CLIP ViT-B/16 hybrid "
+                            f"{args.fusion} (masking_block 9) + text encoder (9 strings) + scoring tail + IoU; "
+                            f"SAM proposal generation NOT included yet (scope A of SURVEY.md 8d)",
+                "fusion_mode": args.fusion, "proposals": args.masks, "image": "640x640", "queries": 3,
+                "parallelism": f"image-parallel x{world}",
+            },
+            "roofline": {
+                "bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "launches_per_step": g_n / nprof, "avg_launch_ms": g_ms / max(g_n, 1),
+                "algorithmic_flops_per_step": g_fl / nprof,
+                "traffic": traffic,
+                "attention": {"achieved": a_fl / (a_ms * 1e-3) / 1e12 if a_ms > 0 else 0.0,
+                              "launches_per_step": a_n / nprof, "ms_per_step": a_ms / nprof},
+                "gemm_ms_per_step": g_ms / nprof,
+                "whole_step_algorithmic_tflops": algorithmic_flops_per_ref(args.masks) / (dt / args.steps) / 1e12,
+            },
+            "metrics": m,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(args.fusion)
+        print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,6 +50,9 @@ PROTOTYPES = {
     "hgl_abi_version": (_I, []),
     "hgl_last_error": (C.c_char_p, []),
     "hgl_device_count": (_I, []),
+    "hgl_prof_enable": (_I, [_I]),
+    "hgl_prof_read": (_I, [_I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                           C.POINTER(C.c_double)]),
     "hgl_gemm_f32": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _LL, _LL, _LL, _I, _VP]),
     "hgl_layernorm_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I, _F, _VP]),
     "hgl_attention_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _LL, _LL, _LL,
@@ -64,9 +67,10 @@ PROTOTYPES = {
     "hgl_coherence_workspace_bytes": (_SZ, [_I, _I, _I]),
     "hgl_coherence_scores": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _VP, _VP, _SZ, _VP]),
     "hgl_iou": (_I, [_VP, _VP, _LL, _VP, _VP]),
-    "hgl_score_sentence_workspace_bytes": (_SZ, [_I]),
-    "hgl_score_sentence": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _F, _I, _I, _F, _I, _I, _VP, _VP, _VP,
-                                _VP, _SZ, _VP]),
+    "hgl_iou_select": (_I, [_VP, _VP, _I, _VP, _LL, _VP, _VP]),
+    "hgl_score_sentence_workspace_bytes": (_SZ, [_I, _I]),
+    "hgl_score_sentence": (_I, [_VP, _VP, _VP, _VP, _I, _F, _VP, _VP, _I, _I, _F, _I, _I, _F, _I, _I,
+                                _VP, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_synthesize_views": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
 }
 

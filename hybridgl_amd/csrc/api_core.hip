@@ -36,7 +36,55 @@ int hgl_require_device() {
   return HGL_OK;
 }
 
+// ---- profiler: event pairs recorded around launches while enabled ----
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+bool g_prof_on = false;
+hipEvent_t take_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+}  // namespace
+
+HglProfScope::HglProfScope(int cls, double flops, double bytes, hipStream_t s) : slot(-1), st(s) {
+  if (!g_prof_on) return;
+  ProfRec r{take_event(), take_event(), cls, flops, bytes};
+  (void)hipEventRecord(r.a, st);
+  slot = (int)g_recs.size();
+  g_recs.push_back(r);
+}
+HglProfScope::~HglProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_recs[slot].b, st);
+}
+
 extern "C" {
+
+int hgl_prof_enable(int on) {
+  HGL_TRY(hgl_require_device());
+  g_prof_on = on != 0;
+  return HGL_OK;
+}
+
+// Synchronises, sums and clears the records of class `cls`: launches, total ms, total
+// algorithmic flops and bytes the launchers declared.
+int hgl_prof_read(int cls, long long* launches, double* ms, double* flops, double* bytes) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(cls >= 0 && cls < HGL_PROF_NCLASS && launches && ms && flops && bytes, "prof_read: bad arguments");
+  *launches = 0; *ms = 0; *flops = 0; *bytes = 0;
+  std::vector<ProfRec> keep;
+  for (auto& r : g_recs) {
+    if (r.cls != cls) { keep.push_back(r); continue; }
+    (void)hipEventSynchronize(r.b);
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { *ms += t; *flops += r.flops; *bytes += r.bytes; ++*launches; }
+    g_pool.push_back(r.a); g_pool.push_back(r.b);
+  }
+  g_recs.swap(keep);
+  return HGL_OK;
+}
 
 int hgl_abi_version(void) { return HGL_ABI_VERSION; }
 const char* hgl_last_error(void) { return g_err; }

@@ -192,6 +192,8 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(AttnArgs a) {
 template <int HD>
 int launch_hd(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.Sq + 127) / 128, a.B * a.H);
+  HglProfScope prof(HGL_PROF_ATTN, 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD,
+                    4.0 * a.B * a.H * HD * (2.0 * a.Sq + 2.0 * a.Sk), st);
   hipLaunchKernelGGL(attn_f32_kernel<HD>, grid, dim3(256), 0, st, a);
   return hgl_check_launch("attention_f32");
 }

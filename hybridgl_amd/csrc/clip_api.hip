@@ -185,7 +185,7 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
       for (int l = masking_block; l <= ret_block; ++l) {
         HGL_TRY(hgl_launch_mix(Y, X, 1.f, X + sN, 2.f, p.pm, N, S, D, st));
         if (l < ret_block) {
-          hipMemcpyAsync(Y + sN, X + sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+          (void)hipMemcpyAsync(Y + sN, X + sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
           HGL_TRY(run_block(w->blocks[l], Y, 2 * N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, N, N, st));
         } else {  // the global stream of the returning block is dead
           HGL_TRY(run_block(w->blocks[l], Y, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
@@ -199,7 +199,7 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
       for (int l = masking_block; l <= ret_block; ++l) {
         HGL_TRY(hgl_launch_mix(Y + sN, X, 1.f, X + sN, 2.f, nullptr, N, S, D, st));
         if (l < ret_block) {
-          hipMemcpyAsync(Y, X, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+          (void)hipMemcpyAsync(Y, X, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
           HGL_TRY(run_block(w->blocks[l], Y, 2 * N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, N, N, st));
         } else {  // the local stream of the returning block is dead
           HGL_TRY(run_block(w->blocks[l], Y + sN, N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 0, N, st));
@@ -211,16 +211,16 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
     case HGL_FUSION_G2L_L2G: {
       // stream order here: [xl | hl | xg | hg]  (keep applies to the last two)
       // init: xg currently at X+sN -> move to slot 2; hl = xl, hg = xg (model/backbone.py:272-276)
-      hipMemcpyAsync(X + 2 * sN, X + sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
-      hipMemcpyAsync(X + sN, X, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
-      hipMemcpyAsync(X + 3 * sN, X + 2 * sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(X + 2 * sN, X + sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(X + sN, X, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(X + 3 * sN, X + 2 * sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
       for (int l = masking_block; l <= ret_block; ++l) {
         // hl_in = hl + 2*tokmask(xg) ; hg_in = xl + 2*hg   (pre-block values of xl, xg)
         HGL_TRY(hgl_launch_mix(Y + sN, X + sN, 1.f, X + 2 * sN, 2.f, p.pm, N, S, D, st));
         HGL_TRY(hgl_launch_mix(Y + 3 * sN, X, 1.f, X + 3 * sN, 2.f, nullptr, N, S, D, st));
         if (l < ret_block) {
-          hipMemcpyAsync(Y, X, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
-          hipMemcpyAsync(Y + 2 * sN, X + 2 * sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+          (void)hipMemcpyAsync(Y, X, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
+          (void)hipMemcpyAsync(Y + 2 * sN, X + 2 * sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
           HGL_TRY(run_block(w->blocks[l], Y, 4 * N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 2 * N, N, st));
         } else {  // plain xl / xg streams of the returning block are dead
           HGL_TRY(run_block(w->blocks[l], Y + sN, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));

@@ -196,9 +196,11 @@ int hgl_launch_gemm(const float* A, const float* W, const float* bias, const flo
   const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  HglProfScope prof(HGL_PROF_GEMM, 2.0 * M * (double)N * K * batch,
+                    4.0 * batch * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
   hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)nwg), dim3(NTHREADS), lds, st, g);
   return hgl_check_launch("gemm_f32");
 }

@@ -75,3 +75,12 @@ int hgl_launch_text_embed(const int32_t* tokens, const float* emb, const float* 
                           int S, int D, int vocab, int32_t* eot, hipStream_t st);
 int hgl_launch_gather_eot(const float* x, const int32_t* eot, int B, int S, int D, float* y,
                           hipStream_t st);
+
+// ---- optional per-kernel-class timing with HIP events on the launch stream (bench roofline) ----
+enum HglProfClass { HGL_PROF_GEMM = 0, HGL_PROF_ATTN = 1, HGL_PROF_OTHER = 2, HGL_PROF_NCLASS = 3 };
+struct HglProfScope {
+  int slot;
+  hipStream_t st;
+  HglProfScope(int cls, double flops, double bytes, hipStream_t s);
+  ~HglProfScope();
+};

@@ -233,6 +233,30 @@ __global__ __launch_bounds__(256) void iou_kernel(const uint8_t* __restrict__ p,
   }
 }
 
+// same with pred = masks[idx[which]] resolved on the device
+__global__ __launch_bounds__(256) void iou_select_kernel(const uint8_t* __restrict__ masks,
+                                                         const int* __restrict__ idx, int which,
+                                                         const uint8_t* __restrict__ g, long long n,
+                                                         unsigned long long* __restrict__ out) {
+  const uint8_t* p = masks + (long long)idx[which] * n;
+  unsigned I = 0, U = 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const bool a = p[i] != 0, b = g[i] != 0;
+    I += (a && b);
+    U += (a || b);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    I += __shfl_xor(I, o);
+    U += __shfl_xor(U, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], (unsigned long long)I);
+    atomicAdd(&out[1], (unsigned long long)U);
+  }
+}
+
 // ---- per-sentence tail: single workgroup ----
 constexpr int MAXK = 16;
 
@@ -258,11 +282,24 @@ __device__ float relation_boxes_dev(const long long* bi, const long long* bj, fl
 }
 
 __global__ __launch_bounds__(256) void score_sentence_kernel(
-    const float* __restrict__ hybrid, const float* __restrict__ tpos, const float* __restrict__ tneg,
+    const float* __restrict__ hybrid, const float* __restrict__ sent, const float* __restrict__ nphr,
+    const float* __restrict__ others, int n_other, float r_mix,
     const long long* __restrict__ boxes, const float* __restrict__ gem, int N, int E,
     float logit_scale, int k1, int k2, float alpha, int rela, int has_other, int* __restrict__ idx,
     float* __restrict__ score_clip, float* __restrict__ score_neg, float* __restrict__ soft_scratch) {
-  // soft_scratch: [2*N] softmax values (global scratch so N is unbounded)
+  // soft_scratch: [2*N] softmax values + [2*E] text vectors (global scratch so N, E are unbounded)
+  float* tpos = soft_scratch + 2 * N;
+  float* tneg = tpos + E;
+  // text_ensemble = r*sentence + (1-r)*noun_phrase ; neg = mean of "a photo of <other noun>"
+  // features accumulated in order (Hybridgl_main.py:153,157-164); zeros when there is none
+  for (int i = threadIdx.x; i < E; i += 256) {
+    tpos[i] = r_mix * sent[i] + (1.f - r_mix) * nphr[i];
+    float a = 0.f;
+    for (int k = 0; k < n_other; ++k) a += others[(long long)k * E + i];
+    tneg[i] = n_other > 0 ? a / (float)n_other : 0.f;
+  }
+  __syncthreads();
+  __threadfence_block();
   __shared__ float red[8];
   __shared__ int redi[8];
   __shared__ int top1[MAXK], top2[MAXK];
@@ -355,6 +392,7 @@ __global__ __launch_bounds__(256) void score_sentence_kernel(
         const int oi = __shfl_xor(mi, o);
         if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
       }
+      if (mi == 0x7fffffff) mi = j < N ? j : 0;  // all-NaN scores (no other nouns): any valid index
       if (lane == 0) top[j] = mi;
       __builtin_amdgcn_wave_barrier();
       __threadfence_block();
@@ -504,27 +542,46 @@ int hgl_iou(const uint8_t* pred, const uint8_t* gt, long long HW, int64_t* out_I
   return hgl_check_launch("iou");
 }
 
-size_t hgl_score_sentence_workspace_bytes(int N) { return hgl_align_up((size_t)2 * N * sizeof(float), 256); }
+int hgl_iou_select(const uint8_t* masks, const int32_t* idx, int which, const uint8_t* gt,
+                   long long HW, int64_t* out_IU, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(masks && idx && gt && out_IU && HW > 0 && which >= 0, "iou_select: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out_IU, 0, 2 * sizeof(int64_t), st) != hipSuccess) {
+    hgl_set_error("iou_select: memset failed");
+    return HGL_ELAUNCH;
+  }
+  long long blocks = (HW + 255) / 256;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(iou_select_kernel, dim3((unsigned)blocks), dim3(256), 0, st, masks, (const int*)idx, which, gt, HW, (unsigned long long*)out_IU);
+  return hgl_check_launch("iou_select");
+}
 
-int hgl_score_sentence(const float* hybrid, const float* text_ensemble, const float* neg_text,
+size_t hgl_score_sentence_workspace_bytes(int N, int E) {
+  return hgl_align_up(((size_t)2 * N + 2 * (size_t)E) * sizeof(float), 256);
+}
+
+int hgl_score_sentence(const float* hybrid, const float* sentence_feat, const float* noun_phrase_feat,
+                       const float* other_noun_feats, int n_other, float r,
                        const int64_t* boxes, const float* gem_score, int N, int E, float logit_scale,
                        int k1, int k2, float alpha, int relaword, int has_other_nouns, int32_t* idx,
                        float* score_clip, float* score_neg, void* workspace, size_t workspace_bytes,
                        void* stream) {
   HGL_TRY(hgl_require_device());
-  HGL_REQUIRE(hybrid && text_ensemble && neg_text && boxes && gem_score && idx && score_clip && score_neg, "score_sentence: null argument");
+  HGL_REQUIRE(hybrid && sentence_feat && noun_phrase_feat && boxes && gem_score && idx && score_clip && score_neg, "score_sentence: null argument");
+  HGL_REQUIRE(n_other >= 0 && (n_other == 0 || other_noun_feats), "score_sentence: other_noun_feats missing");
   HGL_REQUIRE(N > 0 && E > 0, "score_sentence: bad shape");
   // Hybridgl_main.py:178-181: k clamps to the number of masks
   if (k1 > N) k1 = N;
   if (k2 > N) k2 = N;
   HGL_REQUIRE(k1 >= 1 && k1 <= MAXK && k2 >= 1 && k2 <= MAXK, "score_sentence: k1,k2 must be in [1,%d]", MAXK);
   HGL_REQUIRE(relaword >= 0 && relaword <= 7, "score_sentence: bad relaword %d", relaword);
-  if (!workspace || workspace_bytes < hgl_score_sentence_workspace_bytes(N)) {
+  if (!workspace || workspace_bytes < hgl_score_sentence_workspace_bytes(N, E)) {
     hgl_set_error("score_sentence: workspace too small");
     return HGL_EWORKSPACE;
   }
   float* pool = (float*)workspace;
-  hipLaunchKernelGGL(score_sentence_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, hybrid, text_ensemble, neg_text, (const long long*)boxes, gem_score, N, E, logit_scale, k1, k2, alpha, relaword, has_other_nouns, (int*)idx, score_clip, score_neg, pool);
+  hipLaunchKernelGGL(score_sentence_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, hybrid, sentence_feat, noun_phrase_feat, other_noun_feats, n_other, r, (const long long*)boxes, gem_score, N, E, logit_scale, k1, k2, alpha, relaword, has_other_nouns, (int*)idx, score_clip, score_neg, pool);
   return hgl_check_launch("score_sentence");
 }
 

@@ -152,22 +152,41 @@ def iou_counts(pred, gt):
     return out
 
 
-def score_sentence(hybrid, text_ensemble, neg_text, boxes, gem_score, logit_scale=100.0, k1=3, k2=6,
-                   alpha=0.6, relaword="none", has_other_nouns=False):
+def iou_select(masks, idx, which, gt):
+    """Compute_IoU(masks[idx[which]], gt) with the index resolved on the device -> tensor([I,U])."""
+    lib = _lib.load()
+    mp, masks = _u8(masks, "masks")
+    gp, gt = _u8(gt, "gt")
+    HW = gt.numel()
+    assert masks.numel() % HW == 0
+    out = torch.empty((2,), dtype=torch.int64, device=masks.device)
+    check(lib.hgl_iou_select(mp, _dev(idx, torch.int32, "idx"), int(which), gp, HW, out.data_ptr(), _stream()),
+          "hgl_iou_select")
+    return out
+
+
+def score_sentence(hybrid, sentence_feat, noun_phrase_feat, other_noun_feats, boxes, gem_score,
+                   logit_scale=100.0, r=0.5, k1=3, k2=6, alpha=0.6, relaword="none", has_other_nouns=False):
     """Per-sentence tail (Hybridgl_main.py:153-196,225-228).
 
-    Returns (idx[2] int32: pure argmax, final index; score_clip [N]; score_neg [N])."""
+    other_noun_feats: [K,E] tensor or None.  Returns (idx[2] int32: pure argmax, final index;
+    score_clip [N]; score_neg [N])."""
     lib = _lib.load()
     N, E = hybrid.shape
     dev = hybrid.device
     idx = torch.empty((2,), dtype=torch.int32, device=dev)
     sc = torch.empty((N,), dtype=torch.float32, device=dev)
     sn = torch.empty((N,), dtype=torch.float32, device=dev)
-    need = lib.hgl_score_sentence_workspace_bytes(N)
+    need = lib.hgl_score_sentence_workspace_bytes(N, E)
     ws = workspace(need, dev, "score_sentence")
+    n_other = 0 if other_noun_feats is None else int(other_noun_feats.shape[0])
+    sent = sentence_feat.reshape(-1)
+    nphr = noun_phrase_feat.reshape(-1)
     check(lib.hgl_score_sentence(_dev(hybrid, torch.float32, "hybrid"),
-                                 _dev(text_ensemble.reshape(-1), torch.float32, "text_ensemble"),
-                                 _dev(neg_text.reshape(-1), torch.float32, "neg_text"),
+                                 _dev(sent, torch.float32, "sentence_feat"),
+                                 _dev(nphr, torch.float32, "noun_phrase_feat"),
+                                 _dev(other_noun_feats, torch.float32, "other_noun_feats") if n_other else None,
+                                 n_other, float(r),
                                  _dev(boxes, torch.int64, "boxes"), _dev(gem_score, torch.float32, "gem_score"),
                                  N, E, float(logit_scale), int(k1), int(k2), float(alpha),
                                  RELAWORD.get(relaword, 0), int(bool(has_other_nouns)),

@@ -1,0 +1,135 @@
+"""Per-ref evaluation step of Hybridgl_main.main (Hybridgl_main.py:79-230) on the GPU.
+
+One `RefBatch` = one dataset item: an image, its mask proposals, its sentences (already
+tokenised; spaCy parse records and the GEM heat-map are inputs -- both are external
+packages in the reference).  `HybridGLPipeline.step` runs, without any host
+synchronisation, the reference's per-ref work:
+
+    views   Hybridgl_main.py:93-125   hgl_synthesize_views
+    hybrid  Hybridgl_main.py:128      hgl_clip_hybrid_forward
+    text    Hybridgl_main.py:146-161  hgl_clip_encode_text (all strings of the ref in one batch)
+    tail    Hybridgl_main.py:153-230  hgl_coherence_scores, hgl_score_sentence, hgl_iou_select
+
+and accumulates cum_I/cum_U and the per-sentence IoUs on the device (Hybridgl_main.py:52-55,
+240-247).  Metrics are read back once, at the end.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import ops, synth
+
+
+@dataclass
+class Sentence:
+    """One referring expression after the (external) spaCy pre-processing of
+    Hybridgl_main.py:131-146,156,176: token rows index into RefBatch.tokens."""
+    sentence_row: int
+    noun_phrase_row: int
+    other_noun_rows: List[int]
+    dirflag: str = "none"          # extract_dir_phrase (utils.py:100-133)
+    relaflag: str = "none"         # extract_rela_word  (utils.py:206-238)
+    n_nouns: int = 0               # len(nouns) of extract_nouns (Hybridgl_main.py:184)
+    imgattn: Optional[torch.Tensor] = None  # [H,W] fp32: gem_model(...) resized to the image (:200-202)
+
+
+@dataclass
+class RefBatch:
+    sam_img: torch.Tensor      # [H,W,3] uint8   image['sam_img']
+    blurred: torch.Tensor      # [H,W,3] uint8   cv2.GaussianBlur(sam_img,(15,15),0)  (:99)
+    image_norm: torch.Tensor   # [3,H,W] fp32    image['image'] (ImageNet-normalised)
+    masks: torch.Tensor        # [N,H,W] bool    SAM proposals (:86-87)
+    boxes: torch.Tensor        # [N,4] int64     XYWH (:89-90)
+    tokens: torch.Tensor       # [T,77] int32    every string of the ref
+    target: torch.Tensor       # [H,W] bool/uint8 ground truth
+    sentences: List[Sentence] = field(default_factory=list)
+
+
+def _rows(text, rows):
+    """rows of the text-feature matrix without a host->device index copy when they are consecutive."""
+    if not rows:
+        return None
+    if list(rows) == list(range(rows[0], rows[0] + len(rows))):
+        return text[rows[0]:rows[0] + len(rows)]
+    return text.index_select(0, torch.as_tensor(rows, device=text.device)).contiguous()
+
+
+def black_for(relaflag):
+    """Hybridgl_main.py:211-216."""
+    return 1.95 if relaflag == "big" else (1.5 if relaflag == "small" else 1.8)
+
+
+class HybridGLPipeline:
+    def __init__(self, model, fusion_mode="G2L", masking_block=9, r=0.5, alpha=0.6, k1=3, k2=6, res=224):
+        self.model = model
+        self.fusion_mode = fusion_mode
+        self.masking_block = masking_block
+        self.r, self.alpha, self.k1, self.k2 = r, alpha, k1, k2  # Hybridgl_main.py:57-63
+        self.res = res
+        dev = model.device
+        # metric accumulators stay on the device: [cum_I, cum_U, cum_I_final, cum_U_final]
+        self.cum = torch.zeros(4, dtype=torch.int64, device=dev)
+        self.iu_log = []  # per sentence (IU_pure, IU_final) device tensors
+
+    def step(self, ref: RefBatch):
+        """One dataset item; returns the device tensors of the last sentence (idx, scores)."""
+        m = self.model
+        local, glob = ops.synthesize_views(ref.sam_img, ref.blurred, ref.image_norm, ref.masks, self.res)
+        hybrid = m(local, glob, ref.masks, masking_block=self.masking_block, fusion_mode=self.fusion_mode)
+        text = m.model.encode_text(ref.tokens)
+        # the k1/k2 clamp of Hybridgl_main.py:178-181 persists across refs in the reference
+        self.k1 = min(self.k1, hybrid.shape[0])
+        self.k2 = min(self.k2, hybrid.shape[0])
+        last = None
+        for s in ref.sentences:
+            gem = ops.coherence_scores(s.imgattn, ref.masks, s.dirflag, black_for(s.relaflag))
+            others = _rows(text, s.other_noun_rows)
+            idx, sc, sn = ops.score_sentence(hybrid, text[s.sentence_row], text[s.noun_phrase_row], others,
+                                             ref.boxes, gem, m.model._logit_scale_exp, self.r, self.k1,
+                                             self.k2, self.alpha, s.relaflag, s.n_nouns != 0)
+            iu0 = ops.iou_select(ref.masks, idx, 0, ref.target)
+            iu1 = ops.iou_select(ref.masks, idx, 1, ref.target)
+            self.cum[0:2] += iu0
+            self.cum[2:4] += iu1
+            self.iu_log.append((iu0, iu1))
+            last = (idx, sc, sn, gem)
+        return hybrid, text, last
+
+    def metrics(self):
+        """Hybridgl_main.py:240-247: overall IoU and mean IoU, pure and with spatial guidance."""
+        cum = self.cum.cpu().numpy().astype(np.float64)
+        ious = np.array([[float(a[0]) / float(a[1]) if int(a[1]) else 0.0, float(b[0]) / float(b[1]) if int(b[1]) else 0.0]
+                         for a, b in ((x.cpu().numpy(), y.cpu().numpy()) for x, y in self.iu_log)]).reshape(-1, 2)
+        return {
+            "cum": [int(v) for v in cum],
+            "oIoU": cum[0] * 100.0 / cum[1] if cum[1] else 0.0,
+            "mIoU": float(ious[:, 0].mean() * 100.0) if len(ious) else 0.0,
+            "oIoU_final": cum[2] * 100.0 / cum[3] if cum[3] else 0.0,
+            "mIoU_final": float(ious[:, 1].mean() * 100.0) if len(ious) else 0.0,
+            "n_sentences": len(ious),
+        }
+
+
+def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=49408):
+    """The benchmark item of SURVEY.md 8d: 640x640 image, 64 proposals, 3 queries, each with a
+    sentence, a noun phrase and one other noun (9 token rows).  Returns (RefBatch, numpy dict)."""
+    img = synth.synth_image(H, W, 1000 + i)
+    blur = synth.box_blur_u8(img)
+    norm = synth.imagenet_normalize(img)
+    masks = synth.synth_masks(N, H, W, 2000 + i)
+    boxes = synth.boxes_from_masks(masks)
+    tokens = synth.synth_tokens(3 * n_sent, context, vocab, 3000 + i)
+    gt = masks[(7 * i) % N]
+    sents, attn_np = [], []
+    for j in range(n_sent):
+        dirflag, relaflag, n_nouns = synth.PARSE_RECORDS[j % len(synth.PARSE_RECORDS)]
+        attn = synth.synth_heatmap(H, W, 4000 + 10 * i + j)
+        attn_np.append(attn)
+        sents.append(Sentence(3 * j, 3 * j + 1, [3 * j + 2], dirflag, relaflag, n_nouns,
+                              torch.from_numpy(attn).to(device)))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    ref = RefBatch(t(img), t(blur), t(norm), t(masks), t(boxes), t(tokens), t(gt), sents)
+    host = dict(img=img, blur=blur, norm=norm, masks=masks, boxes=boxes, tokens=tokens, gt=gt, attn=attn_np)
+    return ref, host

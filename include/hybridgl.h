@@ -58,6 +58,13 @@ const char* hgl_last_error(void);
 /* number of visible HIP devices (0 when none); never initialises a context */
 int hgl_device_count(void);
 
+/* Per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg).
+ * cls: 0 = fp32 MFMA GEMM, 1 = fused attention, 2 = other.  hgl_prof_read synchronises,
+ * returns and clears the records of one class: launches, summed event ms, and the summed
+ * ALGORITHMIC flops / bytes of those launches (2*M*N*K per GEMM; 4*B*H*Sq*Sk*hd per attention). */
+int hgl_prof_enable(int on);
+int hgl_prof_read(int cls, long long* launches, double* ms, double* flops, double* bytes);
+
 /* ------------------------------------------------------------------------
  * Primitive operators (building blocks; exported so that parity tests can
  * pin each kernel against the oracle in isolation).
@@ -172,19 +179,28 @@ int hgl_coherence_scores(const float* imgattn, const uint8_t* masks, int N, int 
 /* Compute_IoU (utils.py:365-384): out[0]=|pred&gt|, out[1]=|pred|gt| as int64. */
 int hgl_iou(const uint8_t* pred, const uint8_t* gt, long long HW, int64_t* out_IU, void* stream);
 
-/* Whole per-sentence tail in one launch sequence (Hybridgl_main.py:153-230).
- * hybrid [N,E]; text_ensemble [E]; neg_text [E]; boxes [N,4] int64 XYWH;
- * gem_score [N] (from hgl_coherence_scores); relaword: 0 none,1 left,2 right,
- * 3 up,4 down,5 big,6 small,7 within; has_other_nouns: len(nouns)!=0.
- * Outputs: idx[0]=argmax(score_clip) ("pure hybridgl"), idx[1]=final index;
- * score_clip [N] logits (pre-softmax), score_neg [N] logits. */
-size_t hgl_score_sentence_workspace_bytes(int N);
-int hgl_score_sentence(const float* hybrid, const float* text_ensemble, const float* neg_text,
+/* Whole per-sentence tail in one launch (Hybridgl_main.py:153-196,225-228).
+ * hybrid [N,E]; sentence_feat [E], noun_phrase_feat [E] (text_ensemble = r*sentence +
+ * (1-r)*noun_phrase, :153); other_noun_feats [n_other,E] = encode_text("a photo of "+noun)
+ * rows averaged in order (:157-164; n_other==0 -> the reference scores against zeros and
+ * gets NaN logits that it never uses: score_neg is filled with NaN); boxes [N,4] int64
+ * XYWH; gem_score [N] (from hgl_coherence_scores); relaword: 0 none,1 left,2 right,3 up,
+ * 4 down,5 big,6 small,7 within (utils.py:240-268); has_other_nouns: len(nouns)!=0 (:184).
+ * k1,k2 clamp to N (:178-181).  Outputs: idx[0]=argmax(score_clip) ("pure hybridgl"),
+ * idx[1]=final index; score_clip [N], score_neg [N] logits before the softmax. */
+size_t hgl_score_sentence_workspace_bytes(int N, int E);
+int hgl_score_sentence(const float* hybrid, const float* sentence_feat, const float* noun_phrase_feat,
+                       const float* other_noun_feats, int n_other, float r,
                        const int64_t* boxes, const float* gem_score,
                        int N, int E, float logit_scale, int k1, int k2, float alpha,
                        int relaword, int has_other_nouns,
                        int32_t* idx, float* score_clip, float* score_neg,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Compute_IoU on a mask selected on the device: pred = masks[idx[which]] ([N,HW] uint8),
+ * so the winning index never travels to the host (Hybridgl_main.py:169-171,227-230). */
+int hgl_iou_select(const uint8_t* masks, const int32_t* idx, int which, const uint8_t* gt,
+                   long long HW, int64_t* out_IU, void* stream);
 
 /* ------------------------------------------------------------------------
  * Image synthesis (Hybridgl_main.py:93-125): per mask, the blurred-background

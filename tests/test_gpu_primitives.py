@@ -175,13 +175,42 @@ def test_scoring_tail_vs_golden(cuda, golden_dir, ci):
     black = 1.95 if rela == "big" else (1.5 if rela == "small" else 1.8)
     gem = ops.coherence_scores(T(attn, cuda), T(masks, cuda), dirflag, black)
     np.testing.assert_allclose(gem.cpu().numpy(), g[f"tail{ci}_gem"], rtol=2e-5, atol=2e-5)
-    idx, sc, sn = ops.score_sentence(T(hybrid, cuda), T(t_pos, cuda), T(t_neg, cuda), T(boxes, cuda), gem,
-                                     float(g["cs_logit_scale"]), 3, 6, 0.6, rela, has_other)
+    # sentence == noun phrase == t_pos makes the r-ensemble exact; one "other noun" row = t_neg
+    idx, sc, sn = ops.score_sentence(T(hybrid, cuda), T(t_pos, cuda), T(t_pos, cuda), T(t_neg, cuda), T(boxes, cuda),
+                                     gem, float(g["cs_logit_scale"]), 0.5, 3, 6, 0.6, rela, has_other)
     np.testing.assert_allclose(sc.cpu().numpy(), g[f"tail{ci}_sc"], rtol=0, atol=1e-3)
     np.testing.assert_allclose(sn.cpu().numpy(), g[f"tail{ci}_sn"], rtol=0, atol=1e-3)
     assert [int(v) for v in idx.cpu()] == [int(v) for v in g[f"tail{ci}_idx"]]   # bit-exact indices
     iu = ops.iou_counts(T(masks[int(idx[1])], cuda), T(gt, cuda)).cpu().numpy()
     assert tuple(int(v) for v in iu) == tuple(int(v) for v in g[f"tail{ci}_IU"])
+    iu2 = ops.iou_select(T(masks, cuda), idx, 1, T(gt, cuda)).cpu().numpy()   # device-side selection
+    assert tuple(int(v) for v in iu2) == tuple(int(v) for v in iu)
+
+
+def test_score_sentence_ensemble_and_no_other_nouns(cuda):
+    """text ensemble r*s+(1-r)*np and the mean of K other-noun rows are formed in the kernel;
+    with no other nouns the negative logits are NaN (as in the reference) and are unused."""
+    rng = np.random.default_rng(21)
+    N, E = 20, 512
+    hybrid = rng.standard_normal((N, E)).astype(np.float32)
+    s, p = rng.standard_normal((2, E)).astype(np.float32)
+    oth = rng.standard_normal((3, E)).astype(np.float32)
+    from hybridgl_amd.synth import boxes_from_masks, synth_masks
+    boxes = boxes_from_masks(synth_masks(N, 64, 64, 1))
+    gem = rng.standard_normal(N).astype(np.float32)
+    for others, has in [(oth, True), (None, False)]:
+        idx, sc, sn = ops.score_sentence(T(hybrid, cuda), T(s, cuda), T(p, cuda),
+                                         T(others, cuda) if others is not None else None, T(boxes, cuda),
+                                         T(gem, cuda), 100.0, 0.5, 3, 6, 0.6, "left", has)
+        tpos = (np.float32(0.5) * s + np.float32(0.5) * p)[None]
+        tneg = (others.sum(0, dtype=np.float32) / np.float32(3))[None] if others is not None else np.ones((1, E), np.float32)
+        ip, ifin, rsc, rsn = O.score_sentence(hybrid, tpos, tneg, boxes, gem, 100.0, 3, 6, 0.6, "left", has)
+        np.testing.assert_allclose(sc.cpu().numpy(), rsc, rtol=0, atol=1e-3)
+        assert [int(v) for v in idx.cpu()] == [ip, ifin]
+        if others is None:
+            assert torch.isnan(sn).all()
+        else:
+            np.testing.assert_allclose(sn.cpu().numpy(), rsn, rtol=0, atol=1e-3)
 
 
 def test_coherence_full_size_and_edges(cuda):
