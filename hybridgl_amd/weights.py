@@ -95,3 +95,110 @@ def clip_state_dict(name="ViT-B/16", seed=0):
 
 def clip_vision_heads(cfg):
     return cfg["vision_width"] // 64  # clip/model.py:333
+
+
+# ----------------------------------------------------------------------------- SAM
+SAM_CONFIGS = {
+    # segment_anything/build_sam.py:14-21 (vit_h) + :55-101
+    "vit_h": dict(embed_dim=1280, depth=32, num_heads=16, global_attn_indexes=(7, 15, 23, 31),
+                  img_size=1024, patch_size=16, window_size=14, out_chans=256),
+    # tiny geometry for parity tests: 16x16 tokens, 2 heads of 80, windowed + global blocks
+    "tiny": dict(embed_dim=160, depth=4, num_heads=2, global_attn_indexes=(1, 3),
+                 img_size=256, patch_size=16, window_size=14, out_chans=256),
+}
+
+
+def sam_state_dict(name="vit_h", seed=0):
+    """Seeded SAM state_dict (numpy fp32) with the reference's key names
+    (segment_anything/modeling/*.py).  Linear/conv weights use std = fan_in^-0.5 so that
+    activations and mask logits stay O(1) with random weights."""
+    cfg = SAM_CONFIGS[name]
+    D, L, H = cfg["embed_dim"], cfg["depth"], cfg["num_heads"]
+    ps, g = cfg["patch_size"], cfg["img_size"] // cfg["patch_size"]
+    hd, C = D // H, cfg["out_chans"]
+    sd = OrderedDict()
+
+    def lin(key, out_f, in_f, bias=True):
+        sd[f"{key}.weight"] = _draw(seed, f"{key}.weight", (out_f, in_f), in_f ** -0.5)
+        if bias:
+            sd[f"{key}.bias"] = _draw(seed, f"{key}.bias", (out_f,), 0.02)
+
+    def norm(key, n):
+        sd[f"{key}.weight"] = _draw(seed, f"{key}.weight", (n,), 0.1, 1.0)
+        sd[f"{key}.bias"] = _draw(seed, f"{key}.bias", (n,), 0.02)
+
+    e = "image_encoder"
+    sd[f"{e}.pos_embed"] = _draw(seed, f"{e}.pos_embed", (1, g, g, D), 0.02)
+    sd[f"{e}.patch_embed.proj.weight"] = _draw(seed, f"{e}.patch_embed.proj.weight", (D, 3, ps, ps), (3 * ps * ps) ** -0.5)
+    sd[f"{e}.patch_embed.proj.bias"] = _draw(seed, f"{e}.patch_embed.proj.bias", (D,), 0.02)
+    for i in range(L):
+        b = f"{e}.blocks.{i}"
+        s = g if i in cfg["global_attn_indexes"] else cfg["window_size"]
+        norm(f"{b}.norm1", D)
+        lin(f"{b}.attn.qkv", 3 * D, D)
+        lin(f"{b}.attn.proj", D, D)
+        sd[f"{b}.attn.rel_pos_h"] = _draw(seed, f"{b}.attn.rel_pos_h", (2 * s - 1, hd), 0.1)
+        sd[f"{b}.attn.rel_pos_w"] = _draw(seed, f"{b}.attn.rel_pos_w", (2 * s - 1, hd), 0.1)
+        norm(f"{b}.norm2", D)
+        lin(f"{b}.mlp.lin1", 4 * D, D)
+        lin(f"{b}.mlp.lin2", D, 4 * D)
+    sd[f"{e}.neck.0.weight"] = _draw(seed, f"{e}.neck.0.weight", (C, D, 1, 1), D ** -0.5)
+    norm(f"{e}.neck.1", C)
+    sd[f"{e}.neck.2.weight"] = _draw(seed, f"{e}.neck.2.weight", (C, C, 3, 3), (9 * C) ** -0.5)
+    norm(f"{e}.neck.3", C)
+
+    p = "prompt_encoder"
+    sd[f"{p}.pe_layer.positional_encoding_gaussian_matrix"] = _draw(seed, f"{p}.pe_gauss", (2, C // 2), 1.0)
+    for i in range(4):
+        sd[f"{p}.point_embeddings.{i}.weight"] = _draw(seed, f"{p}.point_embeddings.{i}.weight", (1, C), 1.0)
+    sd[f"{p}.not_a_point_embed.weight"] = _draw(seed, f"{p}.not_a_point_embed.weight", (1, C), 1.0)
+    sd[f"{p}.no_mask_embed.weight"] = _draw(seed, f"{p}.no_mask_embed.weight", (1, C), 1.0)
+    # mask_downscaling (dense mask prompts) is never used by the automatic generator but is part
+    # of the reference state_dict (modeling/prompt_encoder.py:50-58, mask_in_chans=16)
+    sd[f"{p}.mask_downscaling.0.weight"] = _draw(seed, f"{p}.md0.w", (4, 1, 2, 2), 0.5)
+    sd[f"{p}.mask_downscaling.0.bias"] = _draw(seed, f"{p}.md0.b", (4,), 0.02)
+    norm(f"{p}.mask_downscaling.1", 4)
+    sd[f"{p}.mask_downscaling.3.weight"] = _draw(seed, f"{p}.md3.w", (16, 4, 2, 2), 0.25)
+    sd[f"{p}.mask_downscaling.3.bias"] = _draw(seed, f"{p}.md3.b", (16,), 0.02)
+    norm(f"{p}.mask_downscaling.4", 16)
+    sd[f"{p}.mask_downscaling.6.weight"] = _draw(seed, f"{p}.md6.w", (C, 16, 1, 1), 0.25)
+    sd[f"{p}.mask_downscaling.6.bias"] = _draw(seed, f"{p}.md6.b", (C,), 0.02)
+
+    m = "mask_decoder"
+    sd[f"{m}.iou_token.weight"] = _draw(seed, f"{m}.iou_token.weight", (1, C), 1.0)
+    sd[f"{m}.mask_tokens.weight"] = _draw(seed, f"{m}.mask_tokens.weight", (4, C), 1.0)
+
+    def attn(key, internal):
+        lin(f"{key}.q_proj", internal, C)
+        lin(f"{key}.k_proj", internal, C)
+        lin(f"{key}.v_proj", internal, C)
+        lin(f"{key}.out_proj", C, internal)
+
+    for i in range(2):
+        l = f"{m}.transformer.layers.{i}"
+        attn(f"{l}.self_attn", C)
+        norm(f"{l}.norm1", C)
+        attn(f"{l}.cross_attn_token_to_image", C // 2)
+        norm(f"{l}.norm2", C)
+        lin(f"{l}.mlp.lin1", 2048, C)
+        lin(f"{l}.mlp.lin2", C, 2048)
+        norm(f"{l}.norm3", C)
+        norm(f"{l}.norm4", C)
+        attn(f"{l}.cross_attn_image_to_token", C // 2)
+    attn(f"{m}.transformer.final_attn_token_to_image", C // 2)
+    norm(f"{m}.transformer.norm_final_attn", C)
+    sd[f"{m}.output_upscaling.0.weight"] = _draw(seed, f"{m}.up0.w", (C, C // 4, 2, 2), C ** -0.5)
+    sd[f"{m}.output_upscaling.0.bias"] = _draw(seed, f"{m}.up0.b", (C // 4,), 0.02)
+    norm(f"{m}.output_upscaling.1", C // 4)
+    sd[f"{m}.output_upscaling.3.weight"] = _draw(seed, f"{m}.up3.w", (C // 4, C // 8, 2, 2), (C // 4) ** -0.5)
+    sd[f"{m}.output_upscaling.3.bias"] = _draw(seed, f"{m}.up3.b", (C // 8,), 0.02)
+    for i in range(4):
+        h = f"{m}.output_hypernetworks_mlps.{i}"
+        lin(f"{h}.layers.0", C, C)
+        lin(f"{h}.layers.1", C, C)
+        lin(f"{h}.layers.2", C // 8, C)
+    h = f"{m}.iou_prediction_head"
+    lin(f"{h}.layers.0", 256, C)
+    lin(f"{h}.layers.1", 256, 256)
+    lin(f"{h}.layers.2", 4, 256)
+    return sd

@@ -60,3 +60,20 @@ def tail_case(ci, N=12, E=32, H=96, W=128):
     attn = synth_heatmap(H, W, 700 + ci)
     gt = masks[(7 * ci) % N]
     return hybrid, t_pos, t_neg, masks, boxes, attn, gt
+
+
+def sam_tiny_case():
+    """inputs of the SAM tiny-geometry golden: a 160x200 RGB image, its PIL-bilinear resize to the
+    256 long side (done here exactly as ResizeLongestSide.apply_image does), and 5 prompt points."""
+    from PIL import Image
+    from hybridgl_amd.synth import synth_image
+    img = synth_image(160, 200, 42)
+    oh, ow = 160, 200
+    scale = 256.0 / max(oh, ow)
+    nh, nw = int(oh * scale + 0.5), int(ow * scale + 0.5)
+    resized = np.array(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+    pts = np.array([[20.5, 30.25], [100.0, 80.0], [199.0, 159.0], [0.0, 0.0], [150.5, 10.0]], dtype=np.float64)
+    pts_in = pts.copy()
+    pts_in[:, 0] *= nw / ow
+    pts_in[:, 1] *= nh / oh
+    return dict(image=img, resized=resized, input_size=(nh, nw), orig_size=(oh, ow), points=pts, points_in=pts_in)

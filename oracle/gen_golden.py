@@ -57,6 +57,7 @@ def install_stubs():
         return y
 
     tvf.resize = resize
+    tvf._tensor_resize = resize
     tvt.functional = tvf
     tv.transforms = tvt
     sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt,
@@ -242,6 +243,119 @@ def gen_resize():
     np.savez_compressed(os.path.join(GOLD, "resize.npz"), **out)
 
 
+def install_sam_stubs():
+    """torchvision / cv2 entry points the segment_anything package imports (absent offline).
+    batched_nms and connectedComponentsWithStats are OUR restatements -> NMS / CC parity stays
+    unpinned; everything else below runs the reference's own code."""
+    from oracle import sam_oracle as S
+    from PIL import Image
+    tv = sys.modules["torchvision"]
+    ops = types.ModuleType("torchvision.ops")
+    boxes = types.ModuleType("torchvision.ops.boxes")
+
+    def batched_nms(b, s, idxs, iou_threshold):
+        if b.numel() == 0:
+            return torch.empty((0,), dtype=torch.int64)
+        return torch.from_numpy(S.nms(b.numpy(), s.numpy(), iou_threshold))
+
+    boxes.batched_nms = batched_nms
+    boxes.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    ops.boxes = boxes
+    tv.ops = ops
+    sys.modules["torchvision.ops"] = ops
+    sys.modules["torchvision.ops.boxes"] = boxes
+    tvf = sys.modules["torchvision.transforms.functional"]
+    tvf.to_pil_image = lambda a: Image.fromarray(a)
+    tvf.resize = lambda img, size: img.resize((size[1], size[0]), Image.BILINEAR) if isinstance(img, Image.Image) else tvf._tensor_resize(img, size)
+    cv2 = sys.modules["cv2"]
+
+    def cc(mask, conn):
+        from scipy import ndimage
+        lab, n = ndimage.label(mask, structure=np.ones((3, 3), int))
+        stats = np.zeros((n + 1, 5), dtype=np.int64)
+        stats[:, -1] = np.bincount(lab.ravel(), minlength=n + 1)
+        return n + 1, lab.astype(np.int32), stats, None
+
+    cv2.connectedComponentsWithStats = cc
+
+
+def build_ref_sam(cfg_name, seed):
+    """The reference's Sam assembled as build_sam._build_sam does, at the geometry of
+    weights.SAM_CONFIGS[cfg_name], with our seeded state_dict."""
+    from functools import partial
+    sys.path.insert(0, os.path.join(REF, "third_party/segment-anything"))
+    import segment_anything  # noqa: F401
+    from segment_anything.modeling import ImageEncoderViT, MaskDecoder, PromptEncoder, Sam, TwoWayTransformer
+    cfg = weights.SAM_CONFIGS[cfg_name]
+    g = cfg["img_size"] // cfg["patch_size"]
+    sam = Sam(
+        image_encoder=ImageEncoderViT(depth=cfg["depth"], embed_dim=cfg["embed_dim"], img_size=cfg["img_size"],
+                                      mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+                                      num_heads=cfg["num_heads"], patch_size=cfg["patch_size"], qkv_bias=True,
+                                      use_rel_pos=True, global_attn_indexes=cfg["global_attn_indexes"],
+                                      window_size=cfg["window_size"], out_chans=256),
+        prompt_encoder=PromptEncoder(embed_dim=256, image_embedding_size=(g, g),
+                                     input_image_size=(cfg["img_size"], cfg["img_size"]), mask_in_chans=16),
+        mask_decoder=MaskDecoder(num_multimask_outputs=3,
+                                 transformer=TwoWayTransformer(depth=2, embedding_dim=256, mlp_dim=2048, num_heads=8),
+                                 transformer_dim=256, iou_head_depth=3, iou_head_hidden_dim=256),
+        pixel_mean=[123.675, 116.28, 103.53], pixel_std=[58.395, 57.12, 57.375])
+    sd = weights.sam_state_dict(cfg_name, seed)
+    sam.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    return sam.eval()
+
+
+def gen_sam_tiny():
+    """Stage tensors of the reference SAM at the tiny geometry."""
+    from oracle.cases import sam_tiny_case
+    sam = build_ref_sam("tiny", 0)
+    from segment_anything import SamAutomaticMaskGenerator
+    from segment_anything.utils import amg as ref_amg
+    c = sam_tiny_case()
+    out = {}
+    with torch.no_grad():
+        x = sam.preprocess(torch.from_numpy(c["resized"]).permute(2, 0, 1).float()[None])
+        emb = sam.image_encoder(x)                                   # [1,256,16,16]
+        out["emb_nhwc"] = emb[0].permute(1, 2, 0).numpy()[::2, ::2]
+        # intermediate: first (windowed) and second (global) block outputs for bisecting
+        t = sam.image_encoder.patch_embed(x) + sam.image_encoder.pos_embed
+        t0 = sam.image_encoder.blocks[0](t)
+        t1 = sam.image_encoder.blocks[1](t0)
+        out["blk0"], out["blk1"] = t0[0].numpy()[::3, ::3], t1[0].numpy()[::3, ::3]
+        pts = torch.as_tensor(c["points_in"])                         # float64 [P,2]
+        lab = torch.ones(pts.shape[0], dtype=torch.int)
+        sparse, dense = sam.prompt_encoder(points=(pts[:, None, :], lab[:, None]), boxes=None, masks=None)
+        out["sparse"] = sparse.numpy()
+        out["dense_pe"] = sam.prompt_encoder.get_dense_pe()[0].permute(1, 2, 0).reshape(-1, 256).numpy()[::5]
+        low, iou = sam.mask_decoder(image_embeddings=emb, image_pe=sam.prompt_encoder.get_dense_pe(),
+                                    sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense,
+                                    multimask_output=True)
+        out["low_res"], out["iou"] = low.numpy(), iou.numpy()
+        full = sam.postprocess_masks(low, c["input_size"], c["orig_size"])
+        out["full_logits"] = full.numpy()[:, :, ::4, ::4]
+        out["stability"] = ref_amg.calculate_stability_score(full.flatten(0, 1), 0.0, 1.0).numpy()
+        out["boxes"] = ref_amg.batched_mask_to_box(full.flatten(0, 1) > 0).numpy()
+        rles = ref_amg.mask_to_rle_pytorch(full.flatten(0, 1)[:2] > 0)
+        back = np.stack([ref_amg.rle_to_mask(r) for r in rles])
+        assert np.array_equal(back, (full.flatten(0, 1)[:2] > 0).numpy())
+        out["point_grid8"] = ref_amg.build_point_grid(8)
+        # whole generator, thresholds relaxed so that random weights keep some masks
+        gen = SamAutomaticMaskGenerator(sam, points_per_side=4, pred_iou_thresh=-1e9, stability_score_thresh=0.0,
+                                        crop_n_layers=0, min_mask_region_area=20, box_nms_thresh=1.5)
+        anns = gen.generate(c["image"])
+        out["amg_n"] = np.array([len(anns)])
+        if anns:
+            out["amg_masks"] = np.packbits(np.stack([a["segmentation"] for a in anns]), axis=-1)
+            out["amg_bbox"] = np.array([a["bbox"] for a in anns], dtype=np.int64)
+            out["amg_iou"] = np.array([a["predicted_iou"] for a in anns], dtype=np.float32)
+            out["amg_stab"] = np.array([a["stability_score"] for a in anns], dtype=np.float32)
+            out["amg_points"] = np.array([a["point_coords"][0] for a in anns], dtype=np.float64)
+            out["amg_area"] = np.array([a["area"] for a in anns], dtype=np.int64)
+        print("sam_tiny: emb", out["emb_nhwc"].shape, "low", low.shape, "iou range", float(iou.min()), float(iou.max()),
+              "logit range", float(full.min()), float(full.max()), "amg masks", len(anns))
+    np.savez_compressed(os.path.join(GOLD, "sam_tiny.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -264,3 +378,6 @@ if __name__ == "__main__":
         gen_scoring()
     if want("resize"):
         gen_resize()
+    if want("sam_tiny"):
+        install_sam_stubs()
+        gen_sam_tiny()
