@@ -43,6 +43,51 @@ class HglClipTextW(C.Structure):
                 ("ln_final_w", C.c_void_p), ("ln_final_b", C.c_void_p), ("text_projection_t", C.c_void_p)]
 
 
+class HglSamBlockW(C.Structure):
+    _fields_ = [("window", C.c_int), ("rel_len", C.c_int)] + [(n, C.c_void_p) for n in (
+        "norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "rel_pos_h", "rel_pos_w",
+        "norm2_w", "norm2_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b")]
+
+
+class HglSamEncoderW(C.Structure):
+    _fields_ = [("embed_dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int), ("img_size", C.c_int),
+                ("patch", C.c_int), ("out_chans", C.c_int),
+                ("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("pos_embed", C.c_void_p),
+                ("blocks", C.POINTER(HglSamBlockW)),
+                ("neck0_w", C.c_void_p), ("neck1_w", C.c_void_p), ("neck1_b", C.c_void_p),
+                ("neck2_w", C.c_void_p), ("neck3_w", C.c_void_p), ("neck3_b", C.c_void_p)]
+
+
+class HglLinearW(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p)]
+
+
+class HglNormW(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p)]
+
+
+class HglSamAttnW(C.Structure):
+    _fields_ = [("q", HglLinearW), ("k", HglLinearW), ("v", HglLinearW), ("out", HglLinearW), ("internal", C.c_int)]
+
+
+class _Layer(C.Structure):
+    _fields_ = [("self_attn", HglSamAttnW), ("t2i", HglSamAttnW), ("i2t", HglSamAttnW),
+                ("n1", HglNormW), ("n2", HglNormW), ("n3", HglNormW), ("n4", HglNormW),
+                ("lin1", HglLinearW), ("lin2", HglLinearW)]
+
+
+class HglSamDecoderW(C.Structure):
+    _fields_ = [("C", C.c_int), ("grid", C.c_int), ("heads", C.c_int), ("mlp_dim", C.c_int),
+                ("pe_gauss", C.c_void_p), ("point_embed_pos", C.c_void_p), ("not_a_point", C.c_void_p),
+                ("no_mask", C.c_void_p), ("dense_pe", C.c_void_p), ("iou_token", C.c_void_p),
+                ("mask_tokens", C.c_void_p),
+                ("layer", _Layer * 2), ("final_t2i", HglSamAttnW), ("norm_final", HglNormW),
+                ("up0_w", C.c_void_p), ("up0_b", C.c_void_p), ("up1", HglNormW),
+                ("up3_w", C.c_void_p), ("up3_b", C.c_void_p),
+                ("hyper", (HglLinearW * 3) * 4), ("iou_head", HglLinearW * 3)]
+
+
+
 # name -> (restype, argtypes).  Must list EVERY symbol declared in include/hybridgl.h
 # (tests/test_abi.py cross-checks this table against the header).
 _VP, _I, _LL, _F, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
@@ -72,6 +117,16 @@ PROTOTYPES = {
     "hgl_score_sentence": (_I, [_VP, _VP, _VP, _VP, _I, _F, _VP, _VP, _I, _I, _F, _I, _I, _F, _I, _I,
                                 _VP, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_synthesize_views": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
+    "hgl_sam_encode_workspace_bytes": (_SZ, [C.POINTER(HglSamEncoderW)]),
+    "hgl_sam_encode": (_I, [C.POINTER(HglSamEncoderW), _VP, _I, _I, _VP, _VP, _SZ, _VP]),
+    "hgl_sam_dense_pe": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _VP]),
+    "hgl_sam_decode_workspace_bytes": (_SZ, [C.POINTER(HglSamDecoderW), _I]),
+    "hgl_sam_decode_points": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "hgl_sam_postprocess_workspace_bytes": (_SZ, [_I]),
+    "hgl_sam_postprocess": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _VP, _VP, _VP, _VP, _VP,
+                                 _VP, _SZ, _VP]),
+    "hgl_nms": (_I, [_VP, _VP, _VP, _I, _F, _VP, _VP, _VP]),
+    "hgl_gather_masks": (_I, [_VP, _VP, _VP, _I, _LL, _VP, _VP]),
 }
 
 _lib = None

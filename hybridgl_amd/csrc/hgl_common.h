@@ -84,3 +84,19 @@ struct HglProfScope {
   HglProfScope(int cls, double flops, double bytes, hipStream_t s);
   ~HglProfScope();
 };
+
+// SAM glue (sam_glue.hip)
+int hgl_launch_sam_preprocess(const uint8_t* img, int h, int w, int S, float* out, hipStream_t st);
+int hgl_launch_win_partition(const float* H, int g, int ws, int nw, int D, float* Hw, hipStream_t st);
+int hgl_launch_win_unpartition_add(float* X, int g, int ws, int nw, int D, const float* P, hipStream_t st);
+int hgl_launch_relpos_gather(const float* T, int B, int heads, int S, int size, int L, int use_w,
+                             float* rel, hipStream_t st);
+int hgl_launch_im2col3x3(const float* in, int g, int C, float* cols, hipStream_t st);
+int hgl_launch_add_rows_bcast(const float* a, long long a_bstride, const float* pe, long long rows_elems,
+                              int B, float* out, hipStream_t st);
+int hgl_launch_pe(const float* coords01, const float* G, int n, int F, int mode, const float* pos_embed,
+                  const float* not_a_point, float* out, hipStream_t st);
+int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const float* sparse, int P, int C,
+                            float* tokens, hipStream_t st);
+int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long rows, float eps, hipStream_t st);
+int hgl_launch_unshuffle_logits(const float* Lg, int P, int g, float* out, hipStream_t st);

@@ -1,0 +1,329 @@
+// Host orchestration of the SAM image encoder and prompt/mask decoder behind the C ABI.
+//   hgl_sam_encode         == Sam.preprocess + ImageEncoderViT.forward
+//                             (modeling/sam.py:164-174, modeling/image_encoder.py:106-116)
+//   hgl_sam_decode_points  == PromptEncoder(points) + MaskDecoder(multimask_output=True)
+//                             (predictor.py:222-235, modeling/mask_decoder.py:71-149)
+// Every contraction is the fp32 MFMA GEMM / fused attention of gemm.hip / attention.hip.
+// Tokens stay NHWC ([g*g, C] rows) end to end; the reference's NCHW permutes disappear.
+#include "hgl_common.h"
+#include <math.h>
+
+namespace {
+
+struct EncPlan {
+  float *img, *cols, *X, *H, *Hw, *QKV, *O, *P, *F, *Th, *Tw, *relh, *relw, *neckA, *neckB, *cols3;
+};
+
+bool carve_enc(HglArena& ar, const HglSamEncoderW* w, EncPlan& p) {
+  const int D = w->embed_dim, S = w->img_size, g = S / w->patch, C = w->out_chans;
+  const size_t T = (size_t)g * g;
+  // windowed blocks pad the grid up to a multiple of the window size
+  size_t Tw_max = T;
+  int rl_max = 0;
+  for (int i = 0; i < w->depth; ++i) {
+    const int ws = w->blocks[i].window;
+    if (ws > 0) {
+      const size_t nw = (g + ws - 1) / ws;
+      Tw_max = Tw_max > nw * nw * ws * ws ? Tw_max : nw * nw * ws * ws;
+    }
+    rl_max = rl_max > w->blocks[i].rel_len ? rl_max : w->blocks[i].rel_len;
+  }
+  p.img = ar.take<float>((size_t)3 * S * S);
+  p.cols = ar.take<float>(T * 3 * w->patch * w->patch);
+  p.X = ar.take<float>(T * D);
+  p.H = ar.take<float>(T * D);
+  p.Hw = ar.take<float>(Tw_max * D);
+  p.QKV = ar.take<float>(Tw_max * 3 * D);
+  p.O = ar.take<float>(Tw_max * D);
+  p.P = ar.take<float>(Tw_max * D);
+  p.F = ar.take<float>(T * 4 * D);
+  p.Th = ar.take<float>((size_t)w->heads * Tw_max * rl_max);
+  p.Tw = ar.take<float>((size_t)w->heads * Tw_max * rl_max);
+  p.relh = ar.take<float>((size_t)w->heads * Tw_max * g);
+  p.relw = ar.take<float>((size_t)w->heads * Tw_max * g);
+  p.neckA = ar.take<float>(T * C);
+  p.neckB = ar.take<float>(T * C);
+  p.cols3 = ar.take<float>(T * C * 9);
+  return ar.ok();
+}
+
+bool valid_enc(const HglSamEncoderW* w) {
+  return w && w->embed_dim > 0 && w->depth > 0 && w->heads > 0 && w->img_size > 0 && w->patch > 0 &&
+         w->out_chans > 0 && w->img_size % w->patch == 0 && w->embed_dim % w->heads == 0 &&
+         (w->embed_dim & 3) == 0 && w->patch_w && w->patch_b && w->pos_embed && w->blocks && w->neck0_w &&
+         w->neck1_w && w->neck1_b && w->neck2_w && w->neck3_w && w->neck3_b;
+}
+
+// Block.forward (modeling/image_encoder.py:166-182)
+int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, hipStream_t st) {
+  const int D = w->embed_dim, g = w->img_size / w->patch, heads = w->heads, hd = D / heads;
+  const int T = g * g;
+  const int ws = b.window;
+  const int size = ws > 0 ? ws : g;       // attention grid side
+  const int nw = ws > 0 ? (g + ws - 1) / ws : 1;
+  const int B = nw * nw;                  // windows (1 for global attention)
+  const int S = size * size;              // tokens per window
+  const int M = B * S;
+  const int L = b.rel_len;
+  HGL_REQUIRE(L == 2 * size - 1, "sam_encode: rel_pos length %d does not match attention size %d", L, size);
+
+  HGL_TRY(hgl_launch_layernorm(p.X, b.norm1_w, b.norm1_b, p.H, T, D, 1e-6f, st));
+  const float* A = p.H;
+  if (ws > 0) {
+    HGL_TRY(hgl_launch_win_partition(p.H, g, ws, nw, D, p.Hw, st));
+    A = p.Hw;
+  }
+  HGL_TRY(hgl_launch_gemm(A, b.qkv_w, b.qkv_b, nullptr, p.QKV, M, 3 * D, D, D, D, 0, 3 * D, 1, 0, 0, 0, 0,
+                          HGL_ACT_NONE, st));
+  // decomposed rel-pos: T[h][row][r] = q_h[row] . rel_pos[r] for every r, then gathered per (q,k)
+  HGL_TRY(hgl_launch_gemm(p.QKV, b.rel_pos_h, nullptr, nullptr, p.Th, M, L, hd, 3 * D, hd, 0, L, heads, hd, 0,
+                          0, (long long)M * L, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_gemm(p.QKV, b.rel_pos_w, nullptr, nullptr, p.Tw, M, L, hd, 3 * D, hd, 0, L, heads, hd, 0,
+                          0, (long long)M * L, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_relpos_gather(p.Th, B, heads, S, size, L, 0, p.relh, st));
+  HGL_TRY(hgl_launch_relpos_gather(p.Tw, B, heads, S, size, L, 1, p.relw, st));
+  HGL_TRY(hgl_launch_attention(p.QKV, p.QKV + D, p.QKV + 2 * D, p.O, B, heads, S, S, hd, 3 * D, 3 * D, 3 * D, D,
+                               (long long)S * 3 * D, (long long)S * 3 * D, (long long)S * 3 * D,
+                               (long long)S * D, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, p.relh,
+                               p.relw, size, size, st));
+  if (ws > 0) {
+    HGL_TRY(hgl_launch_gemm(p.O, b.proj_w, b.proj_b, nullptr, p.P, M, D, D, D, D, 0, D, 1, 0, 0, 0, 0,
+                            HGL_ACT_NONE, st));
+    HGL_TRY(hgl_launch_win_unpartition_add(p.X, g, ws, nw, D, p.P, st));
+  } else {
+    HGL_TRY(hgl_launch_gemm(p.O, b.proj_w, b.proj_b, p.X, p.X, T, D, D, D, D, D, D, 1, 0, 0, 0, 0,
+                            HGL_ACT_NONE, st));
+  }
+  HGL_TRY(hgl_launch_layernorm(p.X, b.norm2_w, b.norm2_b, p.H, T, D, 1e-6f, st));
+  HGL_TRY(hgl_launch_gemm(p.H, b.lin1_w, b.lin1_b, nullptr, p.F, T, 4 * D, D, D, D, 0, 4 * D, 1, 0, 0, 0, 0,
+                          HGL_ACT_GELU, st));
+  HGL_TRY(hgl_launch_gemm(p.F, b.lin2_w, b.lin2_b, p.X, p.X, T, D, 4 * D, 4 * D, 4 * D, D, D, 1, 0, 0, 0, 0,
+                          HGL_ACT_NONE, st));
+  return HGL_OK;
+}
+
+// ------------------------------------------------------------------------------ decoder
+struct DecPlan {
+  float *coords, *sparse, *tokens, *queries, *qpe, *q1, *k1, *v1, *att, *keys0, *kpe0, *keys, *kpe, *kp, *vp,
+      *qi, *atti, *mlp, *u1, *u2, *hy_a, *hy_b, *hyper, *lg, *iou_a, *iou_b;
+};
+
+bool carve_dec(HglArena& ar, const HglSamDecoderW* w, int P, DecPlan& p) {
+  const size_t C = w->C, HW = (size_t)w->grid * w->grid, T = 7;
+  p.sparse = ar.take<float>((size_t)P * 2 * C);
+  p.tokens = ar.take<float>(P * T * C);
+  p.queries = ar.take<float>(P * T * C);
+  p.qpe = ar.take<float>(P * T * C);
+  p.q1 = ar.take<float>(P * T * C);
+  p.k1 = ar.take<float>(P * T * C);
+  p.v1 = ar.take<float>(P * T * C);
+  p.att = ar.take<float>(P * T * C);
+  p.keys0 = ar.take<float>(HW * C);
+  p.kpe0 = ar.take<float>(HW * C);
+  p.keys = ar.take<float>(P * HW * C);
+  p.kpe = ar.take<float>(P * HW * C);
+  p.kp = ar.take<float>(P * HW * C / 2);
+  p.vp = ar.take<float>(P * HW * C / 2);
+  p.qi = ar.take<float>(P * HW * C / 2);
+  p.atti = ar.take<float>(P * HW * C / 2);
+  p.mlp = ar.take<float>(P * T * w->mlp_dim);
+  p.u1 = ar.take<float>(P * HW * C);           // [P*HW*4, C/4]
+  p.u2 = ar.take<float>(P * HW * 16 * (C / 8)); // [P*HW*16, C/8]
+  p.hy_a = ar.take<float>((size_t)P * C);
+  p.hy_b = ar.take<float>((size_t)P * C);
+  p.hyper = ar.take<float>((size_t)P * 4 * (C / 8));
+  p.lg = ar.take<float>(P * HW * 16 * 4);
+  p.iou_a = ar.take<float>((size_t)P * C);
+  p.iou_b = ar.take<float>((size_t)P * C);
+  return ar.ok();
+}
+
+bool valid_lin(const HglLinearW& l) { return l.w && l.b; }
+bool valid_attn(const HglSamAttnW& a) {
+  return valid_lin(a.q) && valid_lin(a.k) && valid_lin(a.v) && valid_lin(a.out) && a.internal > 0;
+}
+bool valid_dec(const HglSamDecoderW* w) {
+  if (!w || w->C <= 0 || w->grid <= 0 || w->heads <= 0 || w->mlp_dim <= 0 || (w->C & 31)) return false;
+  if (!w->pe_gauss || !w->point_embed_pos || !w->not_a_point || !w->no_mask || !w->iou_token || !w->mask_tokens) return false;
+  for (int i = 0; i < 2; ++i) {
+    const auto& l = w->layer[i];
+    if (!valid_attn(l.self_attn) || !valid_attn(l.t2i) || !valid_attn(l.i2t) || !valid_lin(l.lin1) || !valid_lin(l.lin2) ||
+        !l.n1.w || !l.n2.w || !l.n3.w || !l.n4.w) return false;
+  }
+  if (!valid_attn(w->final_t2i) || !w->norm_final.w || !w->up0_w || !w->up0_b || !w->up1.w || !w->up3_w || !w->up3_b) return false;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 3; ++j) if (!valid_lin(w->hyper[i][j])) return false;
+  for (int j = 0; j < 3; ++j) if (!valid_lin(w->iou_head[j])) return false;
+  return true;
+}
+
+inline int lin(const float* A, int lda, const HglLinearW& l, const float* R, int ldr, float* Cc, int ldc, int M,
+               int N, int K, int act, hipStream_t st) {
+  return hgl_launch_gemm(A, l.w, l.b, R, Cc, M, N, K, lda, K, ldr, ldc, 1, 0, 0, 0, 0, act, st);
+}
+
+// Attention.forward (modeling/transformer.py:218-240).  q: [Bq? , Nq, C] rows; when q_shared the same
+// Nq rows serve every batch (batch stride 0).  out: [B, Nq, C] (+ residual R, may alias out).
+int dec_attn(const HglSamDecoderW* w, const HglSamAttnW& a, const float* q, bool q_shared, int Nq, const float* k,
+             const float* v, bool kv_shared, int Nk, int B, float* qp, float* kp, float* vp, float* att,
+             const float* R, long long sR, float* out, hipStream_t st) {
+  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads;
+  const int Bq = q_shared ? 1 : B, Bk = kv_shared ? 1 : B;
+  HGL_TRY(lin(q, C, a.q, nullptr, 0, qp, I, Bq * Nq, I, C, HGL_ACT_NONE, st));
+  HGL_TRY(lin(k, C, a.k, nullptr, 0, kp, I, Bk * Nk, I, C, HGL_ACT_NONE, st));
+  HGL_TRY(lin(v, C, a.v, nullptr, 0, vp, I, Bk * Nk, I, C, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_attention(qp, kp, vp, att, B, heads, Nq, Nk, hd, I, I, I, I, q_shared ? 0 : (long long)Nq * I,
+                               kv_shared ? 0 : (long long)Nk * I, kv_shared ? 0 : (long long)Nk * I,
+                               (long long)Nq * I, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, nullptr,
+                               nullptr, 0, 0, st));
+  // out_proj (+ residual); batched so that a shared residual (stride 0) can be broadcast
+  return hgl_launch_gemm(att, a.out.w, a.out.b, R, out, Nq, C, I, I, I, C, C, B, (long long)Nq * I, 0, sR,
+                         (long long)Nq * C, HGL_ACT_NONE, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hgl_sam_encode_workspace_bytes(const HglSamEncoderW* w) {
+  if (!valid_enc(w)) return 0;
+  HglArena ar(nullptr, 0);
+  EncPlan p;
+  carve_enc(ar, w, p);
+  return ar.off;
+}
+
+int hgl_sam_encode(const HglSamEncoderW* w, const uint8_t* resized_img, int in_h, int in_w, float* emb,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(valid_enc(w), "sam_encode: invalid weight struct");
+  HGL_REQUIRE(resized_img && emb && in_h > 0 && in_w > 0 && in_h <= w->img_size && in_w <= w->img_size,
+              "sam_encode: bad image (%dx%d for img_size %d)", in_h, in_w, w->img_size);
+  HglArena ar(workspace, workspace_bytes);
+  EncPlan p;
+  if (!workspace || !carve_enc(ar, w, p)) {
+    hgl_set_error("sam_encode: workspace too small (%zu bytes given)", workspace_bytes);
+    return HGL_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int D = w->embed_dim, S = w->img_size, g = S / w->patch, C = w->out_chans, T = g * g;
+  const int kd = 3 * w->patch * w->patch;
+  HGL_TRY(hgl_launch_sam_preprocess(resized_img, in_h, in_w, S, p.img, st));
+  HGL_TRY(hgl_launch_im2col_patch(p.img, 1, S, w->patch, p.cols, st));
+  // patch embedding + bias + absolute position embedding (image_encoder.py:107-109)
+  HGL_TRY(hgl_launch_gemm(p.cols, w->patch_w, w->patch_b, w->pos_embed, p.X, T, D, kd, kd, kd, D, D, 1, 0, 0, 0, 0,
+                          HGL_ACT_NONE, st));
+  for (int i = 0; i < w->depth; ++i) HGL_TRY(enc_block(w, w->blocks[i], p, st));
+  // neck: conv1x1 -> LayerNorm2d -> conv3x3(pad 1) -> LayerNorm2d, all on NHWC rows
+  HGL_TRY(hgl_launch_gemm(p.X, w->neck0_w, nullptr, nullptr, p.neckA, T, C, D, D, D, 0, C, 1, 0, 0, 0, 0,
+                          HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_layernorm(p.neckA, w->neck1_w, w->neck1_b, p.neckB, T, C, 1e-6f, st));
+  HGL_TRY(hgl_launch_im2col3x3(p.neckB, g, C, p.cols3, st));
+  HGL_TRY(hgl_launch_gemm(p.cols3, w->neck2_w, nullptr, nullptr, p.neckA, T, C, C * 9, C * 9, C * 9, 0, C, 1, 0, 0,
+                          0, 0, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_layernorm(p.neckA, w->neck3_w, w->neck3_b, emb, T, C, 1e-6f, st));
+  return HGL_OK;
+}
+
+int hgl_sam_dense_pe(const HglSamDecoderW* w, const float* grid_coords01, float* dense_pe, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(w && w->pe_gauss && grid_coords01 && dense_pe && w->grid > 0 && w->C > 0, "sam_dense_pe: bad arguments");
+  return hgl_launch_pe(grid_coords01, w->pe_gauss, w->grid * w->grid, w->C / 2, 0, nullptr, nullptr, dense_pe,
+                       (hipStream_t)stream);
+}
+
+size_t hgl_sam_decode_workspace_bytes(const HglSamDecoderW* w, int P) {
+  if (!valid_dec(w) || P <= 0) return 0;
+  HglArena ar(nullptr, 0);
+  DecPlan p;
+  carve_dec(ar, w, P, p);
+  return ar.off;
+}
+
+int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float* points01, int P, float* low_res,
+                          float* iou_pred, void* workspace, size_t workspace_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(valid_dec(w) && w->dense_pe, "sam_decode: invalid weight struct (dense_pe missing?)");
+  HGL_REQUIRE(emb && points01 && low_res && iou_pred && P > 0, "sam_decode: null input");
+  HglArena ar(workspace, workspace_bytes);
+  DecPlan p;
+  if (!workspace || !carve_dec(ar, w, P, p)) {
+    hgl_set_error("sam_decode: workspace too small (%zu bytes given)", workspace_bytes);
+    return HGL_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int C = w->C, g = w->grid, HW = g * g, T = 7;
+  const long long sQ = (long long)T * C, sK = (long long)HW * C;
+
+  // ---- prompt encoder + token assembly ----
+  HGL_TRY(hgl_launch_pe(points01, w->pe_gauss, 2 * P, C / 2, 1, w->point_embed_pos, w->not_a_point, p.sparse, st));
+  HGL_TRY(hgl_launch_build_tokens(w->iou_token, w->mask_tokens, p.sparse, P, C, p.tokens, st));
+  // src = image_embedding + no_mask_embed (dense prompt) ; shared by all prompts until the first update
+  HGL_TRY(hgl_launch_add_rows_bcast(emb, C, w->no_mask, C, HW, p.keys0, st));   // rows of C, "pe" = no_mask [C]
+  HGL_TRY(hgl_launch_add_rows_bcast(p.keys0, 0, w->dense_pe, (long long)HW * C, 1, p.kpe0, st));
+  (void)hipMemcpyAsync(p.queries, p.tokens, sizeof(float) * P * sQ, hipMemcpyDeviceToDevice, st);
+
+  for (int li = 0; li < 2; ++li) {
+    const auto& L = w->layer[li];
+    const bool shared = li == 0;   // keys identical for every prompt in layer 0
+    const float* keys = shared ? p.keys0 : p.keys;
+    const float* kpe = shared ? p.kpe0 : p.kpe;
+    // (1) self attention of the tokens
+    if (li == 0) {  // skip_first_layer_pe: queries = self_attn(q,q,q), no residual
+      HGL_TRY(dec_attn(w, L.self_attn, p.queries, false, T, p.queries, p.queries, false, T, P, p.q1, p.k1, p.v1, p.att,
+                       nullptr, 0, p.qpe, st));
+      (void)hipMemcpyAsync(p.queries, p.qpe, sizeof(float) * P * sQ, hipMemcpyDeviceToDevice, st);
+    } else {
+      HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
+      HGL_TRY(dec_attn(w, L.self_attn, p.qpe, false, T, p.qpe, p.queries, false, T, P, p.q1, p.k1, p.v1, p.att,
+                       p.queries, sQ, p.queries, st));
+    }
+    HGL_TRY(hgl_launch_layernorm(p.queries, L.n1.w, L.n1.b, p.queries, P * T, C, 1e-5f, st));
+    // (2) tokens attend to the image
+    HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
+    HGL_TRY(dec_attn(w, L.t2i, p.qpe, false, T, kpe, keys, shared, HW, P, p.q1, p.kp, p.vp, p.att, p.queries, sQ,
+                     p.queries, st));
+    HGL_TRY(hgl_launch_layernorm(p.queries, L.n2.w, L.n2.b, p.queries, P * T, C, 1e-5f, st));
+    // (3) MLP on the tokens
+    HGL_TRY(lin(p.queries, C, L.lin1, nullptr, 0, p.mlp, w->mlp_dim, P * T, w->mlp_dim, C, HGL_ACT_RELU, st));
+    HGL_TRY(lin(p.mlp, w->mlp_dim, L.lin2, p.queries, C, p.queries, C, P * T, C, w->mlp_dim, HGL_ACT_NONE, st));
+    HGL_TRY(hgl_launch_layernorm(p.queries, L.n3.w, L.n3.b, p.queries, P * T, C, 1e-5f, st));
+    // (4) image attends to the tokens: q = keys+pe, k = queries+pe, v = queries ; keys += out
+    HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
+    HGL_TRY(dec_attn(w, L.i2t, kpe, shared, HW, p.qpe, p.queries, false, T, P, p.qi, p.k1, p.v1, p.atti, keys,
+                     shared ? 0 : sK, p.keys, st));
+    HGL_TRY(hgl_launch_layernorm(p.keys, L.n4.w, L.n4.b, p.keys, P * HW, C, 1e-5f, st));
+    HGL_TRY(hgl_launch_add_rows_bcast(p.keys, sK, w->dense_pe, sK, P, p.kpe, st));
+  }
+  // final token -> image attention
+  HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
+  HGL_TRY(dec_attn(w, w->final_t2i, p.qpe, false, T, p.kpe, p.keys, false, HW, P, p.q1, p.kp, p.vp, p.att, p.queries,
+                   sQ, p.queries, st));
+  HGL_TRY(hgl_launch_layernorm(p.queries, w->norm_final.w, w->norm_final.b, p.queries, P * T, C, 1e-5f, st));
+
+  // ---- output upscaling: two ConvTranspose2d(k=2,s=2) as GEMMs, columns ordered (pos, out_channel) ----
+  const int C4 = C / 4, C8 = C / 8;
+  HGL_TRY(hgl_launch_gemm(p.keys, w->up0_w, w->up0_b, nullptr, p.u1, P * HW, 4 * C4, C, C, C, 0, 4 * C4, 1, 0, 0, 0, 0,
+                          HGL_ACT_NONE, st));
+  HGL_REQUIRE(C4 == 64, "sam_decode: LayerNorm2d width %d unsupported (64 expected)", C4);
+  HGL_TRY(hgl_launch_ln_gelu64(p.u1, w->up1.w, w->up1.b, (long long)P * HW * 4, 1e-6f, st));
+  HGL_TRY(hgl_launch_gemm(p.u1, w->up3_w, w->up3_b, nullptr, p.u2, P * HW * 4, 4 * C8, C4, C4, C4, 0, 4 * C8, 1, 0, 0,
+                          0, 0, HGL_ACT_GELU, st));
+  // ---- hyper-networks on the mask tokens (rows 1..4 of each prompt's 7 tokens) ----
+  for (int i = 0; i < 4; ++i) {
+    HGL_TRY(lin(p.queries + (1 + i) * C, T * C, w->hyper[i][0], nullptr, 0, p.hy_a, C, P, C, C, HGL_ACT_RELU, st));
+    HGL_TRY(lin(p.hy_a, C, w->hyper[i][1], nullptr, 0, p.hy_b, C, P, C, C, HGL_ACT_RELU, st));
+    HGL_TRY(lin(p.hy_b, C, w->hyper[i][2], nullptr, 0, p.hyper + i * C8, 4 * C8, P, C8, C, HGL_ACT_NONE, st));
+  }
+  // masks[p, t, pix] = hyper[p, t, :] . upscaled[p, pix, :]   (one batched GEMM, N = 4 tokens)
+  HGL_TRY(hgl_launch_gemm(p.u2, p.hyper, nullptr, nullptr, p.lg, HW * 16, 4, C8, C8, C8, 0, 4, P,
+                          (long long)HW * 16 * C8, 4 * C8, 0, (long long)HW * 16 * 4, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_unshuffle_logits(p.lg, P, g, low_res, st));
+  // ---- IoU head on the iou token (row 0); multimask output = columns 1..3 ----
+  HGL_TRY(lin(p.queries, T * C, w->iou_head[0], nullptr, 0, p.iou_a, C, P, C, C, HGL_ACT_RELU, st));
+  HGL_TRY(lin(p.iou_a, C, w->iou_head[1], nullptr, 0, p.iou_b, C, P, C, C, HGL_ACT_RELU, st));
+  HGL_TRY(lin(p.iou_b, C, w->iou_head[2], nullptr, 0, p.iou_a, 4, P, 4, C, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_gather_rows(p.iou_a + 1, 4, P, 3, iou_pred, st));
+  return HGL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,473 @@
+// HBM-bound glue kernels of the SAM path (third_party/segment-anything/segment_anything/*).
+//   sam_preprocess        modeling/sam.py:164-174 (normalise + zero-pad the resized image)
+//   win_partition / win_unpartition_add   modeling/image_encoder.py:243-290 (+ residual add, :176-179)
+//   relpos_gather         modeling/image_encoder.py:325-361 (tables for the fused attention bias)
+//   im2col3x3_nhwc        neck conv3x3, modeling/image_encoder.py:95-101
+//   add_rows_bcast        keys + key_pe / queries + query_pe, modeling/transformer.py:160-179
+//   pe_points / build_tokens  modeling/prompt_encoder.py:73-91,185-214, modeling/mask_decoder.py:120-123
+//   ln_gelu_rows          LayerNorm2d + GELU of output_upscaling, modeling/mask_decoder.py:53-59
+//   unshuffle_logits      pixel order of the two ConvTranspose2d(k=2,s=2) stages -> [P,3,4g,4g]
+//   sam_postprocess       modeling/sam.py:133-162 + utils/amg.py:156-176,303-346 fused
+//   sam_select / nms      automatic_mask_generator.py:251-257,287-319
+#include "hgl_common.h"
+#include <math.h>
+
+namespace {
+
+inline unsigned grid1(long long n, int block = 256) { return (unsigned)((n + block - 1) / block); }
+
+__global__ __launch_bounds__(256) void sam_preprocess_kernel(const uint8_t* __restrict__ img, int h, int w,
+                                                             int S, float* __restrict__ out) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= 3ll * S * S) return;
+  const int x = (int)(i % S), y = (int)((i / S) % S), c = (int)(i / ((long long)S * S));
+  const float mean[3] = {123.675f, 116.28f, 103.53f};
+  const float stdv[3] = {58.395f, 57.12f, 57.375f};
+  float v = 0.f;
+  if (y < h && x < w) v = ((float)img[((long long)y * w + x) * 3 + c] - mean[c]) / stdv[c];
+  out[i] = v;
+}
+
+// Hw[(wy*nwx + wx)*ws*ws + py*ws + px, :] = (y<g && x<g) ? H[y*g+x, :] : 0
+__global__ __launch_bounds__(256) void win_partition_kernel(const float* __restrict__ H, int g, int ws,
+                                                            int nw, int D4, float* __restrict__ Hw,
+                                                            long long total4) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total4) return;
+  const int d = (int)(i % D4);
+  const long long row = i / D4;
+  const int p = (int)(row % (ws * ws)), win = (int)(row / (ws * ws));
+  const int y = (win / nw) * ws + p / ws, x = (win % nw) * ws + p % ws;
+  f32x4 v = {0, 0, 0, 0};
+  if (y < g && x < g) v = ((const f32x4*)H)[((long long)y * g + x) * D4 + d];
+  ((f32x4*)Hw)[i] = v;
+}
+
+// X[y*g+x, :] += P[window row, :]
+__global__ __launch_bounds__(256) void win_unpartition_add_kernel(float* __restrict__ X, int g, int ws,
+                                                                  int nw, int D4,
+                                                                  const float* __restrict__ P,
+                                                                  long long total4) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total4) return;
+  const int d = (int)(i % D4);
+  const long long tok = i / D4;
+  const int y = (int)(tok / g), x = (int)(tok % g);
+  const long long prow = ((long long)(y / ws) * nw + x / ws) * ws * ws + (y % ws) * ws + x % ws;
+  f32x4 a = ((f32x4*)X)[i];
+  const f32x4 b = ((const f32x4*)P)[prow * D4 + d];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) a[e] += b[e];
+  ((f32x4*)X)[i] = a;
+}
+
+// T: [heads][B*S][L] (q . rel_pos[r]);  rel: [(b*heads+h)][S][size], rel[q][k] = T[h][b*S+q][qc - k + size-1]
+// use_w: qc = q % size (width axis) else q / size (height axis)
+__global__ __launch_bounds__(256) void relpos_gather_kernel(const float* __restrict__ T, int B, int heads,
+                                                            int S, int size, int L, int use_w,
+                                                            float* __restrict__ rel, long long total) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % size);
+  const int q = (int)((i / size) % S);
+  const int bh = (int)(i / ((long long)size * S));
+  const int b = bh / heads, h = bh % heads;
+  const int qc = use_w ? q % size : q / size;
+  rel[i] = T[((long long)h * B * S + (long long)b * S + q) * L + (qc - k + size - 1)];
+}
+
+// cols[(y*g+x), c*9 + ky*3+kx] = in[(y+ky-1), (x+kx-1), c] (zero padded), NHWC input
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ in, int g, int C,
+                                                        float* __restrict__ cols, long long total) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i % (C * 9));
+  const long long tok = i / (C * 9);
+  const int c = col / 9, kk = col % 9;
+  const int y = (int)(tok / g) + kk / 3 - 1, x = (int)(tok % g) + kk % 3 - 1;
+  cols[i] = (y >= 0 && y < g && x >= 0 && x < g) ? in[((long long)y * g + x) * C + c] : 0.f;
+}
+
+// out[b, r, :] = a[b (or shared), r, :] + pe[r, :]
+__global__ __launch_bounds__(256) void add_rows_bcast_kernel(const float* __restrict__ a, long long a_bstride4,
+                                                             const float* __restrict__ pe, long long rows4,
+                                                             float* __restrict__ out, long long total4) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total4) return;
+  const long long b = i / rows4, r = i - b * rows4;
+  const f32x4 x = ((const f32x4*)a)[b * a_bstride4 + r];
+  const f32x4 p = ((const f32x4*)pe)[r];
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = x[e] + p[e];
+  ((f32x4*)out)[i] = o;
+}
+
+// random-Fourier positional encoding: out[n, 0:F] = sin(2*pi*((2c-1) @ G)), out[n, F:2F] = cos(...)
+// coords01: [n,2] fp32 already normalised to [0,1]; then optional label embedding / replacement.
+// mode 0: dense grid rows (no label); mode 1: prompt rows [P,2,C]: row 0 += pos_embed, row 1 = not_a_point
+__global__ __launch_bounds__(256) void pe_kernel(const float* __restrict__ coords01,
+                                                 const float* __restrict__ G, int n, int F, int mode,
+                                                 const float* __restrict__ pos_embed,
+                                                 const float* __restrict__ not_a_point,
+                                                 float* __restrict__ out) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= (long long)n * F) return;
+  const int f = (int)(i % F);
+  const int r = (int)(i / F);
+  const int C = 2 * F;
+  float* o = out + (long long)r * C;
+  if (mode == 1 && (r & 1)) {  // padding point: label -1 -> embedding replaced (prompt_encoder.py:86-87)
+    o[f] = not_a_point[f];
+    o[f + F] = not_a_point[f + F];
+    return;
+  }
+  const float cx = 2.f * coords01[2 * r] - 1.f, cy = 2.f * coords01[2 * r + 1] - 1.f;
+  const float v = 6.283185307179586f * (cx * G[f] + cy * G[F + f]);
+  float s = sinf(v), c = cosf(v);
+  if (mode == 1) { s += pos_embed[f]; c += pos_embed[f + F]; }
+  o[f] = s;
+  o[f + F] = c;
+}
+
+// tokens[p, 0] = iou_token; tokens[p, 1..4] = mask_tokens; tokens[p, 5..6] = sparse[p, 0..1]
+__global__ __launch_bounds__(256) void build_tokens_kernel(const float* __restrict__ iou_tok,
+                                                           const float* __restrict__ mask_tok,
+                                                           const float* __restrict__ sparse, int P, int C,
+                                                           float* __restrict__ tokens) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= (long long)P * 7 * C) return;
+  const int c = (int)(i % C), t = (int)((i / C) % 7), p = (int)(i / (7ll * C));
+  float v;
+  if (t == 0) v = iou_tok[c];
+  else if (t < 5) v = mask_tok[(t - 1) * C + c];
+  else v = sparse[((long long)p * 2 + (t - 5)) * C + c];
+  tokens[i] = v;
+}
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// in-place LayerNorm over rows of 64 channels followed by erf-GELU: one wave per row
+__global__ __launch_bounds__(256) void ln_gelu64_kernel(float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, long long rows,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v = x[row * 64 + lane];
+  const float mean = wsum(v) * (1.f / 64.f);
+  const float d = v - mean;
+  const float var = wsum(d * d) * (1.f / 64.f);
+  v = d * rsqrtf(var + eps) * w[lane] + b[lane];
+  x[row * 64 + lane] = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+}
+
+// Lg: [P][g*g*16][4]  ->  out: [P][3][4g][4g] (mask tokens 1..3)
+__global__ __launch_bounds__(256) void unshuffle_logits_kernel(const float* __restrict__ Lg, int P, int g,
+                                                               float* __restrict__ out) {
+  const int S4 = 4 * g;
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= (long long)P * 3 * S4 * S4) return;
+  const int X = (int)(i % S4), Y = (int)((i / S4) % S4);
+  const int t = (int)((i / ((long long)S4 * S4)) % 3), p = (int)(i / (3ll * S4 * S4));
+  const int y = Y >> 2, x = X >> 2, ky = (Y >> 1) & 1, kx = (X >> 1) & 1, ky2 = Y & 1, kx2 = X & 1;
+  const long long row = (((long long)y * g + x) * 4 + (ky * 2 + kx)) * 4 + (ky2 * 2 + kx2);
+  out[i] = Lg[((long long)p * g * g * 16 + row) * 4 + (t + 1)];
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused post-processing of the mask logits (never writes a full-resolution fp32 tensor):
+// low-res logits [K][hl][wl] -> bilinear to S x S -> crop [hi, wi] -> bilinear to H x W
+// (both align_corners=False, ATen source-index fma) -> mask byte (> thr), stability counters
+// (> thr+off, > thr-off) and the inclusive XYXY box, per candidate.
+struct PostArgs {
+  const float* low;      // [K, hl, wl]
+  const float* iou;      // [K] predicted IoU (candidates <= iou_thresh are skipped) or null
+  float iou_thresh;
+  int K, hl, wl, S, hi, wi, H, W;
+  float thr, off;
+  uint8_t* masks;        // [K, H, W]
+  unsigned* counters;    // [K, 6]: inter, union, minx, miny, maxx, maxy  (pre-initialised)
+  float* full_logits;    // optional [K, H, W] (tests only) or null
+};
+
+__device__ __forceinline__ void src_idx(float scale, int dst, int in_size, int& i0, int& i1, float& l0,
+                                        float& l1) {
+  float f = fmaf(scale, dst + 0.5f, -0.5f);
+  f = f < 0.f ? 0.f : f;
+  i0 = (int)f;
+  i0 = i0 < in_size - 1 ? i0 : in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = f - i0;
+  l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void sam_postprocess_kernel(PostArgs a) {
+  const int k = blockIdx.y;
+  if (a.iou && !(a.iou[k] > a.iou_thresh)) return;  // filtered before any pixel work
+  const long long HW = (long long)a.H * a.W;
+  const long long pix = blockIdx.x * 256ll + threadIdx.x;
+  unsigned inter = 0, uni = 0, minx = 0x7fffffff, miny = 0x7fffffff, maxx = 0, maxy = 0, any = 0;
+  if (pix < HW) {
+    const int X = (int)(pix % a.W), Y = (int)(pix / a.W);
+    const float* L = a.low + (long long)k * a.hl * a.wl;
+    // outer interpolation: from the cropped S-grid [hi, wi] to [H, W]
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_idx((float)a.hi / (float)a.H, Y, a.hi, y0, y1, ly0, ly1);
+    src_idx((float)a.wi / (float)a.W, X, a.wi, x0, x1, lx0, lx1);
+    // inner interpolation: low-res -> S grid at the four taps
+    const float s2y = (float)a.hl / (float)a.S, s2x = (float)a.wl / (float)a.S;
+    float tap[2][2];
+    const int ty[2] = {y0, y1}, tx[2] = {x0, x1};
+#pragma unroll
+    for (int iy = 0; iy < 2; ++iy) {
+      int v0, v1;
+      float m0, m1;
+      src_idx(s2y, ty[iy], a.hl, v0, v1, m0, m1);
+#pragma unroll
+      for (int ix = 0; ix < 2; ++ix) {
+        int u0, u1;
+        float n0, n1;
+        src_idx(s2x, tx[ix], a.wl, u0, u1, n0, n1);
+        const float top = L[(long long)v0 * a.wl + u0] * n0 + L[(long long)v0 * a.wl + u1] * n1;
+        const float bot = L[(long long)v1 * a.wl + u0] * n0 + L[(long long)v1 * a.wl + u1] * n1;
+        tap[iy][ix] = top * m0 + bot * m1;
+      }
+    }
+    const float top = tap[0][0] * lx0 + tap[0][1] * lx1;
+    const float bot = tap[1][0] * lx0 + tap[1][1] * lx1;
+    const float v = top * ly0 + bot * ly1;
+    const bool on = v > a.thr;
+    a.masks[(long long)k * HW + pix] = on ? 1 : 0;
+    if (a.full_logits) a.full_logits[(long long)k * HW + pix] = v;
+    inter = v > a.thr + a.off;
+    uni = v > a.thr - a.off;
+    if (on) { minx = maxx = X; miny = maxy = Y; any = 1; }
+  }
+  // wave reduction then one set of atomics per wave
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    inter += __shfl_xor(inter, o);
+    uni += __shfl_xor(uni, o);
+    minx = min(minx, (unsigned)__shfl_xor(minx, o));
+    miny = min(miny, (unsigned)__shfl_xor(miny, o));
+    maxx = max(maxx, (unsigned)__shfl_xor(maxx, o));
+    maxy = max(maxy, (unsigned)__shfl_xor(maxy, o));
+    any |= __shfl_xor(any, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    unsigned* c = a.counters + (long long)k * 6;
+    if (inter) atomicAdd(&c[0], inter);
+    if (uni) atomicAdd(&c[1], uni);
+    if (any) {
+      atomicMin(&c[2], minx);
+      atomicMin(&c[3], miny);
+      atomicMax(&c[4], maxx);
+      atomicMax(&c[5], maxy);
+    }
+  }
+}
+
+__global__ void init_counters_kernel(unsigned* c, int K) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  c[k * 6 + 0] = 0; c[k * 6 + 1] = 0;
+  c[k * 6 + 2] = 0x7fffffff; c[k * 6 + 3] = 0x7fffffff;
+  c[k * 6 + 4] = 0; c[k * 6 + 5] = 0;
+}
+
+// per candidate: stability = inter/union, XYXY box ([0,0,0,0] when empty), keep flag
+__global__ void sam_finalize_kernel(const unsigned* __restrict__ c, const float* __restrict__ iou, int K,
+                                    float iou_thresh, float stab_thresh, float* __restrict__ stab,
+                                    int* __restrict__ boxes, uint8_t* __restrict__ keep) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const bool pass_iou = !iou || iou[k] > iou_thresh;
+  const float s = (float)c[k * 6 + 0] / (float)c[k * 6 + 1];  // 0/0 -> NaN as in the reference
+  stab[k] = pass_iou ? s : 0.f;
+  const bool empty = c[k * 6 + 2] == 0x7fffffff;
+  boxes[k * 4 + 0] = empty ? 0 : (int)c[k * 6 + 2];
+  boxes[k * 4 + 1] = empty ? 0 : (int)c[k * 6 + 3];
+  boxes[k * 4 + 2] = empty ? 0 : (int)c[k * 6 + 4];
+  boxes[k * 4 + 3] = empty ? 0 : (int)c[k * 6 + 5];
+  keep[k] = (pass_iou && s >= stab_thresh) ? 1 : 0;  // NaN >= x is false
+}
+
+// Greedy NMS in one workgroup (K <= 1024): candidates with keep[k]!=0, descending score with the
+// original index as tie-break (stable sort), suppress IoU > thr.  out_idx[0..n) in kept order.
+__global__ __launch_bounds__(1024) void nms_kernel(const int* __restrict__ boxes,
+                                                   const float* __restrict__ scores,
+                                                   const uint8_t* __restrict__ keep, int K, float thr,
+                                                   int* __restrict__ out_idx, int* __restrict__ out_n) {
+  __shared__ int order[1024];
+  __shared__ unsigned char alive[1024];
+  __shared__ int cur, nkept;
+  const int t = threadIdx.x;
+  int valid = 0;
+  float sc = 0.f;
+  if (t < K && keep[t]) { valid = 1; sc = scores[t]; }
+  // rank by counting (K small): position among valid candidates
+  if (t < 1024) order[t] = -1;
+  __syncthreads();
+  if (valid) {
+    int rank = 0;
+    for (int j = 0; j < K; ++j) {
+      if (!keep[j]) continue;
+      const float sj = scores[j];
+      if (sj > sc || (sj == sc && j < t)) ++rank;
+    }
+    order[rank] = t;
+  }
+  if (t < 1024) alive[t] = 1;
+  if (t == 0) nkept = 0;
+  __syncthreads();
+  int nvalid = 0;
+  for (int j = 0; j < K; ++j) nvalid += keep[j] ? 1 : 0;  // uniform
+  for (int r = 0; r < nvalid; ++r) {
+    if (t == 0) cur = alive[r] ? order[r] : -1;
+    __syncthreads();
+    const int ci = cur;
+    if (ci >= 0) {
+      if (t == 0) { out_idx[nkept] = ci; ++nkept; }
+      // suppress lower-ranked boxes overlapping ci
+      const int me = (t > r && t < nvalid) ? order[t] : -1;
+      if (me >= 0 && alive[t]) {
+        const float ax0 = boxes[ci * 4], ay0 = boxes[ci * 4 + 1], ax1 = boxes[ci * 4 + 2], ay1 = boxes[ci * 4 + 3];
+        const float bx0 = boxes[me * 4], by0 = boxes[me * 4 + 1], bx1 = boxes[me * 4 + 2], by1 = boxes[me * 4 + 3];
+        const float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.f);
+        const float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.f);
+        const float inter = iw * ih;
+        const float iou = inter / ((ax1 - ax0) * (ay1 - ay0) + (bx1 - bx0) * (by1 - by0) - inter);
+        if (iou > thr) alive[t] = 0;
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) *out_n = nkept;
+}
+
+// dst[i] = src[idx[i]] for i < *n (rows of row_bytes bytes, 16-byte multiples)
+__global__ __launch_bounds__(256) void gather_masks_kernel(const uint8_t* __restrict__ src,
+                                                           const int* __restrict__ idx,
+                                                           const int* __restrict__ n, long long row16,
+                                                           uint8_t* __restrict__ dst) {
+  const int i = blockIdx.y;
+  if (i >= *n) return;
+  const uint4* s = (const uint4*)(src + (long long)idx[i] * row16 * 16);
+  uint4* d = (uint4*)(dst + (long long)i * row16 * 16);
+  for (long long j = blockIdx.x * 256ll + threadIdx.x; j < row16; j += (long long)gridDim.x * 256) d[j] = s[j];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ launchers
+int hgl_launch_sam_preprocess(const uint8_t* img, int h, int w, int S, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(sam_preprocess_kernel, dim3(grid1(3ll * S * S)), dim3(256), 0, st, img, h, w, S, out);
+  return hgl_check_launch("sam_preprocess");
+}
+int hgl_launch_win_partition(const float* H, int g, int ws, int nw, int D, float* Hw, hipStream_t st) {
+  const long long total4 = (long long)nw * nw * ws * ws * (D / 4);
+  hipLaunchKernelGGL(win_partition_kernel, dim3(grid1(total4)), dim3(256), 0, st, H, g, ws, nw, D / 4, Hw, total4);
+  return hgl_check_launch("win_partition");
+}
+int hgl_launch_win_unpartition_add(float* X, int g, int ws, int nw, int D, const float* P, hipStream_t st) {
+  const long long total4 = (long long)g * g * (D / 4);
+  hipLaunchKernelGGL(win_unpartition_add_kernel, dim3(grid1(total4)), dim3(256), 0, st, X, g, ws, nw, D / 4, P, total4);
+  return hgl_check_launch("win_unpartition_add");
+}
+int hgl_launch_relpos_gather(const float* T, int B, int heads, int S, int size, int L, int use_w,
+                             float* rel, hipStream_t st) {
+  const long long total = (long long)B * heads * S * size;
+  hipLaunchKernelGGL(relpos_gather_kernel, dim3(grid1(total)), dim3(256), 0, st, T, B, heads, S, size, L, use_w, rel, total);
+  return hgl_check_launch("relpos_gather");
+}
+int hgl_launch_im2col3x3(const float* in, int g, int C, float* cols, hipStream_t st) {
+  const long long total = (long long)g * g * C * 9;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid1(total)), dim3(256), 0, st, in, g, C, cols, total);
+  return hgl_check_launch("im2col3x3");
+}
+int hgl_launch_add_rows_bcast(const float* a, long long a_bstride, const float* pe, long long rows_elems,
+                              int B, float* out, hipStream_t st) {
+  const long long total4 = (long long)B * rows_elems / 4;
+  hipLaunchKernelGGL(add_rows_bcast_kernel, dim3(grid1(total4)), dim3(256), 0, st, a, a_bstride / 4, pe, rows_elems / 4, out, total4);
+  return hgl_check_launch("add_rows_bcast");
+}
+int hgl_launch_pe(const float* coords01, const float* G, int n, int F, int mode, const float* pos_embed,
+                  const float* not_a_point, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(pe_kernel, dim3(grid1((long long)n * F)), dim3(256), 0, st, coords01, G, n, F, mode, pos_embed, not_a_point, out);
+  return hgl_check_launch("pe");
+}
+int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const float* sparse, int P, int C,
+                            float* tokens, hipStream_t st) {
+  hipLaunchKernelGGL(build_tokens_kernel, dim3(grid1((long long)P * 7 * C)), dim3(256), 0, st, iou_tok, mask_tok, sparse, P, C, tokens);
+  return hgl_check_launch("build_tokens");
+}
+int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long rows, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(ln_gelu64_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, w, b, rows, eps);
+  return hgl_check_launch("ln_gelu64");
+}
+int hgl_launch_unshuffle_logits(const float* Lg, int P, int g, float* out, hipStream_t st) {
+  const long long total = (long long)P * 3 * 16 * g * g;
+  hipLaunchKernelGGL(unshuffle_logits_kernel, dim3(grid1(total)), dim3(256), 0, st, Lg, P, g, out);
+  return hgl_check_launch("unshuffle_logits");
+}
+
+extern "C" {
+
+size_t hgl_sam_postprocess_workspace_bytes(int K) { return hgl_align_up((size_t)K * 6 * sizeof(unsigned), 256); }
+
+int hgl_sam_postprocess(const float* low_res, const float* iou_pred, int K, int hl, int wl, int img_size,
+                        int in_h, int in_w, int H, int W, float mask_threshold, float stability_offset,
+                        float pred_iou_thresh, float stability_thresh, uint8_t* masks, int32_t* boxes_xyxy,
+                        float* stability, uint8_t* keep, float* full_logits, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(low_res && masks && boxes_xyxy && stability && keep, "sam_postprocess: null argument");
+  HGL_REQUIRE(K > 0 && K <= 65535 && hl > 0 && wl > 0 && img_size > 0 && in_h > 0 && in_w > 0 && H > 0 && W > 0 &&
+              in_h <= img_size && in_w <= img_size, "sam_postprocess: bad shape");
+  if (!workspace || workspace_bytes < hgl_sam_postprocess_workspace_bytes(K)) {
+    hgl_set_error("sam_postprocess: workspace too small");
+    return HGL_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* counters = (unsigned*)workspace;
+  hipLaunchKernelGGL(init_counters_kernel, dim3((K + 255) / 256), dim3(256), 0, st, counters, K);
+  // candidates failing the predicted-IoU filter keep an all-zero mask
+  if (hipMemsetAsync(masks, 0, (size_t)K * H * W, st) != hipSuccess) {
+    hgl_set_error("sam_postprocess: memset failed");
+    return HGL_ELAUNCH;
+  }
+  PostArgs a;
+  a.low = low_res; a.iou = iou_pred; a.iou_thresh = pred_iou_thresh;
+  a.K = K; a.hl = hl; a.wl = wl; a.S = img_size; a.hi = in_h; a.wi = in_w; a.H = H; a.W = W;
+  a.thr = mask_threshold; a.off = stability_offset;
+  a.masks = masks; a.counters = counters; a.full_logits = full_logits;
+  hipLaunchKernelGGL(sam_postprocess_kernel, dim3(grid1((long long)H * W), K), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(sam_finalize_kernel, dim3((K + 255) / 256), dim3(256), 0, st, counters, iou_pred, K,
+                     pred_iou_thresh, stability_thresh, stability, (int*)boxes_xyxy, keep);
+  return hgl_check_launch("sam_postprocess");
+}
+
+int hgl_nms(const int32_t* boxes_xyxy, const float* scores, const uint8_t* keep, int K, float iou_threshold,
+            int32_t* out_idx, int32_t* out_n, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(boxes_xyxy && scores && keep && out_idx && out_n, "nms: null argument");
+  HGL_REQUIRE(K > 0 && K <= 1024, "nms: K must be in [1,1024] (got %d)", K);
+  hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)boxes_xyxy, scores, keep, K, iou_threshold, (int*)out_idx, (int*)out_n);
+  return hgl_check_launch("nms");
+}
+
+int hgl_gather_masks(const uint8_t* masks, const int32_t* idx, const int32_t* n, int max_n, long long HW,
+                     uint8_t* out, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(masks && idx && n && out && max_n > 0 && HW > 0 && (HW & 15) == 0, "gather_masks: bad arguments (HW must be a multiple of 16)");
+  hipLaunchKernelGGL(gather_masks_kernel, dim3(64, max_n), dim3(256), 0, (hipStream_t)stream, masks, (const int*)idx, (const int*)n, HW / 16, out);
+  return hgl_check_launch("gather_masks");
+}
+
+}  // extern "C"

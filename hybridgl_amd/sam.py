@@ -1,0 +1,383 @@
+"""Drop-in for the segment-anything surface Hybridgl_main.py uses (Hybridgl_main.py:66-74,85):
+`sam_model_registry[...]`, `SamAutomaticMaskGenerator(model, ...).generate(image)`.
+
+The ViT-H image encoder, the prompt encoder, the two-way mask decoder and the fused mask
+post-processing (upsampling, thresholds, stability score, boxes, NMS) run in libhybridgl.so
+(hand-written HIP, fp32 MFMA).  Host work kept here, as in the reference: the PIL bilinear
+resize of ResizeLongestSide.apply_image (utils/transforms.py:26-31) and list-of-dict packaging.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, ops, weights
+from ._lib import check
+
+
+from ._lib import (HglLinearW, HglNormW, HglSamAttnW, HglSamBlockW, HglSamDecoderW,  # noqa: E402
+                   HglSamEncoderW)
+
+
+def _dev(a, device):
+    if isinstance(a, torch.Tensor):
+        t = a.detach().to(torch.float32)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return t.contiguous().to(device)
+
+
+def load_sam_state_dict(path):
+    """`torch.load` of the released checkpoint (build_sam.py:103-106)."""
+    sd = torch.load(path, map_location="cpu")
+    return {k: v.float().numpy() for k, v in sd.items()}
+
+
+class Sam:
+    """Weights of segment_anything.modeling.Sam on the device + the C weight structs."""
+
+    mask_threshold = 0.0  # modeling/sam.py:19
+    image_format = "RGB"
+
+    def __init__(self, state_dict, cfg, device="cuda"):
+        _lib.load()
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        self._t = []  # keep every device tensor alive
+        sd = state_dict
+        D, L, H = cfg["embed_dim"], cfg["depth"], cfg["num_heads"]
+        S, ps, Cc = cfg["img_size"], cfg["patch_size"], cfg["out_chans"]
+        g = S // ps
+        self.img_size, self.grid = S, g
+
+        def t(a):
+            x = _dev(a, self.device)
+            self._t.append(x)
+            return x.data_ptr()
+
+        e = "image_encoder"
+        self._blocks = (HglSamBlockW * L)()
+        for i in range(L):
+            b, p = self._blocks[i], f"{e}.blocks.{i}"
+            b.window = 0 if i in cfg["global_attn_indexes"] else cfg["window_size"]
+            b.rel_len = sd[f"{p}.attn.rel_pos_h"].shape[0]
+            for f, k in [("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"),
+                         ("qkv_b", "attn.qkv.bias"), ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"),
+                         ("rel_pos_h", "attn.rel_pos_h"), ("rel_pos_w", "attn.rel_pos_w"),
+                         ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"), ("lin1_w", "mlp.lin1.weight"),
+                         ("lin1_b", "mlp.lin1.bias"), ("lin2_w", "mlp.lin2.weight"), ("lin2_b", "mlp.lin2.bias")]:
+                setattr(b, f, t(sd[f"{p}.{k}"]))
+        enc = HglSamEncoderW()
+        enc.embed_dim, enc.depth, enc.heads, enc.img_size, enc.patch, enc.out_chans = D, L, H, S, ps, Cc
+        enc.patch_w = t(np.asarray(sd[f"{e}.patch_embed.proj.weight"]).reshape(D, -1))
+        enc.patch_b = t(sd[f"{e}.patch_embed.proj.bias"])
+        enc.pos_embed = t(np.asarray(sd[f"{e}.pos_embed"]).reshape(g * g, D))
+        enc.blocks = C.cast(self._blocks, C.POINTER(HglSamBlockW))
+        enc.neck0_w = t(np.asarray(sd[f"{e}.neck.0.weight"]).reshape(Cc, D))
+        enc.neck1_w, enc.neck1_b = t(sd[f"{e}.neck.1.weight"]), t(sd[f"{e}.neck.1.bias"])
+        enc.neck2_w = t(np.asarray(sd[f"{e}.neck.2.weight"]).reshape(Cc, Cc * 9))
+        enc.neck3_w, enc.neck3_b = t(sd[f"{e}.neck.3.weight"]), t(sd[f"{e}.neck.3.bias"])
+        self.enc_w = enc
+
+        m, pe = "mask_decoder", "prompt_encoder"
+        dec = HglSamDecoderW()
+        dec.C, dec.grid, dec.heads, dec.mlp_dim = Cc, g, 8, sd[f"{m}.transformer.layers.0.mlp.lin1.weight"].shape[0]
+        dec.pe_gauss = t(sd[f"{pe}.pe_layer.positional_encoding_gaussian_matrix"])
+        dec.point_embed_pos = t(np.asarray(sd[f"{pe}.point_embeddings.1.weight"]).reshape(-1))
+        dec.not_a_point = t(np.asarray(sd[f"{pe}.not_a_point_embed.weight"]).reshape(-1))
+        dec.no_mask = t(np.asarray(sd[f"{pe}.no_mask_embed.weight"]).reshape(-1))
+        dec.iou_token = t(np.asarray(sd[f"{m}.iou_token.weight"]).reshape(-1))
+        dec.mask_tokens = t(sd[f"{m}.mask_tokens.weight"])
+
+        def lin(dst, key):
+            dst.w, dst.b = t(sd[f"{key}.weight"]), t(sd[f"{key}.bias"])
+
+        def attn(dst, key):
+            for nm in ("q", "k", "v", "out"):
+                lin(getattr(dst, nm), f"{key}.{nm}_proj")
+            dst.internal = sd[f"{key}.q_proj.weight"].shape[0]
+
+        for i in range(2):
+            l, lay = f"{m}.transformer.layers.{i}", dec.layer[i]
+            attn(lay.self_attn, f"{l}.self_attn")
+            attn(lay.t2i, f"{l}.cross_attn_token_to_image")
+            attn(lay.i2t, f"{l}.cross_attn_image_to_token")
+            for j, nm in enumerate(("n1", "n2", "n3", "n4")):
+                lin(getattr(lay, nm), f"{l}.norm{j + 1}")
+            lin(lay.lin1, f"{l}.mlp.lin1")
+            lin(lay.lin2, f"{l}.mlp.lin2")
+        attn(dec.final_t2i, f"{m}.transformer.final_attn_token_to_image")
+        lin(dec.norm_final, f"{m}.transformer.norm_final_attn")
+        # ConvTranspose2d(k=2,s=2) weights [Cin,Cout,2,2] -> GEMM rows ordered (ky,kx,cout)
+        w0 = np.asarray(sd[f"{m}.output_upscaling.0.weight"])
+        dec.up0_w = t(np.transpose(w0, (2, 3, 1, 0)).reshape(-1, w0.shape[0]))
+        dec.up0_b = t(np.tile(np.asarray(sd[f"{m}.output_upscaling.0.bias"]), 4))
+        lin(dec.up1, f"{m}.output_upscaling.1")
+        w3 = np.asarray(sd[f"{m}.output_upscaling.3.weight"])
+        dec.up3_w = t(np.transpose(w3, (2, 3, 1, 0)).reshape(-1, w3.shape[0]))
+        dec.up3_b = t(np.tile(np.asarray(sd[f"{m}.output_upscaling.3.bias"]), 4))
+        for i in range(4):
+            for j in range(3):
+                lin(dec.hyper[i][j], f"{m}.output_hypernetworks_mlps.{i}.layers.{j}")
+        for j in range(3):
+            lin(dec.iou_head[j], f"{m}.iou_prediction_head.layers.{j}")
+        # dense positional encoding of the embedding grid, once (prompt_encoder.py:194-205)
+        ax = ((np.arange(g, dtype=np.float32) + np.float32(1)) - np.float32(0.5)) / np.float32(g)
+        coords = np.stack(np.broadcast_arrays(ax[None, :], ax[:, None]), axis=-1).reshape(-1, 2)
+        self.dense_pe = torch.empty((g * g, Cc), dtype=torch.float32, device=self.device)
+        dec.dense_pe = self.dense_pe.data_ptr()
+        cd = _dev(coords, self.device)
+        check(_lib.load().hgl_sam_dense_pe(C.byref(dec), cd.data_ptr(), self.dense_pe.data_ptr(), ops._stream()),
+              "hgl_sam_dense_pe")
+        torch.cuda.current_stream().synchronize()
+        self.dec_w = dec
+
+    def to(self, device):
+        if torch.device(device).type != "cuda":
+            raise _lib.HybridGLError("Sam runs on the GPU only (no CPU path exists)")
+        return self
+
+    def eval(self):
+        return self
+
+    # ---- the three device stages -------------------------------------------------------
+    def encode(self, resized_u8):
+        """resized_u8: [h,w,3] uint8 device tensor (long side == img_size) -> emb [g*g, C]."""
+        lib = _lib.load()
+        h, w = resized_u8.shape[:2]
+        need = lib.hgl_sam_encode_workspace_bytes(C.byref(self.enc_w))
+        ws = ops.workspace(need, self.device, "sam_encode")
+        emb = torch.empty((self.grid * self.grid, self.cfg["out_chans"]), dtype=torch.float32, device=self.device)
+        check(lib.hgl_sam_encode(C.byref(self.enc_w), ops._dev(resized_u8, torch.uint8, "resized_img"), h, w,
+                                 emb.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "hgl_sam_encode")
+        return emb
+
+    def decode_points(self, emb, points01):
+        """points01: [P,2] fp32 device ((point+0.5)/img_size) -> (low_res [P,3,4g,4g], iou [P,3])."""
+        lib = _lib.load()
+        P = points01.shape[0]
+        need = lib.hgl_sam_decode_workspace_bytes(C.byref(self.dec_w), P)
+        ws = ops.workspace(need, self.device, "sam_decode")
+        g4 = 4 * self.grid
+        low = torch.empty((P, 3, g4, g4), dtype=torch.float32, device=self.device)
+        iou = torch.empty((P, 3), dtype=torch.float32, device=self.device)
+        check(lib.hgl_sam_decode_points(C.byref(self.dec_w), ops._dev(emb, torch.float32, "emb"),
+                                        ops._dev(points01, torch.float32, "points01"), P, low.data_ptr(),
+                                        iou.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()),
+              "hgl_sam_decode_points")
+        return low, iou
+
+    def postprocess(self, low_res, iou_pred, input_size, original_size, pred_iou_thresh=-1e30,
+                    stability_thresh=0.0, stability_offset=1.0, return_logits=False):
+        """low_res [K,hl,wl], iou_pred [K] -> masks [K,H,W] u8, boxes XYXY [K,4] i32, stability [K], keep [K]."""
+        lib = _lib.load()
+        K, hl, wl = low_res.shape
+        H, W = original_size
+        dev = self.device
+        masks = torch.empty((K, H, W), dtype=torch.uint8, device=dev)
+        boxes = torch.empty((K, 4), dtype=torch.int32, device=dev)
+        stab = torch.empty((K,), dtype=torch.float32, device=dev)
+        keep = torch.empty((K,), dtype=torch.uint8, device=dev)
+        full = torch.empty((K, H, W), dtype=torch.float32, device=dev) if return_logits else None
+        need = lib.hgl_sam_postprocess_workspace_bytes(K)
+        ws = ops.workspace(need, dev, "sam_post")
+        check(lib.hgl_sam_postprocess(ops._dev(low_res, torch.float32, "low_res"),
+                                      ops._dev(iou_pred, torch.float32, "iou_pred"), K, hl, wl, self.img_size,
+                                      int(input_size[0]), int(input_size[1]), H, W, float(self.mask_threshold),
+                                      float(stability_offset), float(pred_iou_thresh), float(stability_thresh),
+                                      masks.data_ptr(), boxes.data_ptr(), stab.data_ptr(), keep.data_ptr(),
+                                      full.data_ptr() if full is not None else None, ws.data_ptr(), ws.numel(),
+                                      ops._stream()), "hgl_sam_postprocess")
+        return masks, boxes, stab, keep, full
+
+
+def nms(boxes_xyxy, scores, keep, iou_threshold):
+    """Device NMS -> (idx [K] int32, n [1] int32), both on the device."""
+    lib = _lib.load()
+    K = boxes_xyxy.shape[0]
+    idx = torch.empty((K,), dtype=torch.int32, device=boxes_xyxy.device)
+    n = torch.empty((1,), dtype=torch.int32, device=boxes_xyxy.device)
+    check(lib.hgl_nms(ops._dev(boxes_xyxy, torch.int32, "boxes"), ops._dev(scores, torch.float32, "scores"),
+                      ops._dev(keep, torch.uint8, "keep"), K, float(iou_threshold), idx.data_ptr(), n.data_ptr(),
+                      ops._stream()), "hgl_nms")
+    return idx, n
+
+
+def _build(cfg_name, checkpoint=None, state_dict=None, seed=0, device="cuda"):
+    checkpoint = checkpoint or os.environ.get("HYBRIDGL_SAM_CHECKPOINT")
+    if state_dict is None and checkpoint:
+        state_dict = load_sam_state_dict(checkpoint)
+    if state_dict is None:
+        state_dict = weights.sam_state_dict(cfg_name, seed)
+    return Sam(state_dict, weights.SAM_CONFIGS[cfg_name], device)
+
+
+def build_sam_vit_h(checkpoint=None, **kw):
+    """build_sam.py:14-21."""
+    return _build("vit_h", checkpoint, **kw)
+
+
+# build_sam.py:47-52 (vit_l / vit_b are not on the reference's path: Hybridgl_main.py:66 uses 'default')
+sam_model_registry = {"default": build_sam_vit_h, "vit_h": build_sam_vit_h,
+                      "tiny": lambda checkpoint=None, **kw: _build("tiny", checkpoint, **kw)}
+
+
+def build_point_grid(n):
+    """utils/amg.py:179-186."""
+    off = 1 / (2 * n)
+    p = np.linspace(off, 1 - off, n)
+    return np.stack([np.tile(p[None, :], (n, 1)), np.tile(p[:, None], (1, n))], axis=-1).reshape(-1, 2)
+
+
+def get_preprocess_shape(oldh, oldw, long_side):
+    """utils/transforms.py:93-102."""
+    scale = long_side * 1.0 / max(oldh, oldw)
+    return int(oldh * scale + 0.5), int(oldw * scale + 0.5)
+
+
+class SamAutomaticMaskGenerator:
+    """automatic_mask_generator.py:35-372 for crop_n_layers == 0 (the Hybridgl_main.py:67-73 configuration)."""
+
+    def __init__(self, model, points_per_side=32, points_per_batch=64, pred_iou_thresh=0.88,
+                 stability_score_thresh=0.95, stability_score_offset=1.0, box_nms_thresh=0.7, crop_n_layers=0,
+                 crop_nms_thresh=0.7, crop_overlap_ratio=512 / 1500, crop_n_points_downscale_factor=1,
+                 point_grids=None, min_mask_region_area=0, output_mode="binary_mask"):
+        assert (points_per_side is None) != (point_grids is None), \
+            "Exactly one of points_per_side or point_grid must be provided."
+        if crop_n_layers != 0:
+            raise NotImplementedError("crop layers (PhraseCut configuration) are a later row of SURVEY.md 8f")
+        assert output_mode == "binary_mask", "only binary_mask output is on the reference's path"
+        self.model = model
+        self.point_grids = [build_point_grid(points_per_side)] if point_grids is None else point_grids
+        self.points_per_batch = points_per_batch
+        self.pred_iou_thresh = pred_iou_thresh
+        self.stability_score_thresh = stability_score_thresh
+        self.stability_score_offset = stability_score_offset
+        self.box_nms_thresh = box_nms_thresh
+        self.crop_nms_thresh = crop_nms_thresh
+        self.min_mask_region_area = min_mask_region_area
+
+    # ---- device part: everything up to and including the first NMS, no host sync -----------
+    def propose(self, image, resized=None):
+        """image: uint8 [H,W,3] numpy (or device tensor when `resized` is given).
+        Returns device tensors (masks [K,H,W] u8, boxes_xyxy [K,4] i32, iou [K], stab [K], order [K] i32,
+        n [1] i32, points [K,2] float64 numpy): candidates order[:n] survive the filters + NMS."""
+        from PIL import Image
+        m = self.model
+        H, W = image.shape[:2]
+        nh, nw = get_preprocess_shape(H, W, m.img_size)
+        if resized is None:
+            # ResizeLongestSide.apply_image: PIL bilinear on the host (utils/transforms.py:26-31)
+            resized = torch.from_numpy(np.array(Image.fromarray(np.asarray(image)).resize((nw, nh), Image.BILINEAR))).to(m.device)
+        emb = m.encode(resized)
+        pts = self.point_grids[0] * np.array([[W, H]], dtype=np.float64)       # automatic_mask_generator.py:240-241
+        tp = pts.copy()
+        tp[:, 0] *= nw / W                                                       # apply_coords, utils/transforms.py:33-45
+        tp[:, 1] *= nh / H
+        p01 = torch.from_numpy(((tp + 0.5) / float(m.img_size)).astype(np.float32)).to(m.device)
+        lows, ious = [], []
+        for s in range(0, len(pts), self.points_per_batch):
+            low, iou = m.decode_points(emb, p01[s:s + self.points_per_batch].contiguous())
+            lows.append(low.flatten(0, 1))
+            ious.append(iou.flatten())
+        low = lows[0] if len(lows) == 1 else torch.cat(lows)
+        iou = ious[0] if len(ious) == 1 else torch.cat(ious)
+        masks, boxes, stab, keep, _ = m.postprocess(low, iou, (nh, nw), (H, W), self.pred_iou_thresh,
+                                                    self.stability_score_thresh, self.stability_score_offset)
+        order, n = nms(boxes, iou, keep, self.box_nms_thresh)
+        return masks, boxes, iou, stab, order, n, np.repeat(pts, 3, axis=0)
+
+    def generate(self, image):
+        """automatic_mask_generator.py:137-195 -> list of records (binary masks)."""
+        masks, boxes, iou, stab, order, n, points = self.propose(image)
+        n = int(n.item())                       # the one host sync of the proposal stage
+        idx = order[:n].long()
+        sel_masks = masks.index_select(0, idx).bool().cpu().numpy()
+        sel_boxes = boxes.index_select(0, idx).cpu().numpy().astype(np.int64)
+        sel_iou = iou.index_select(0, idx).cpu().numpy()
+        sel_stab = stab.index_select(0, idx).cpu().numpy()
+        idx_np = idx.cpu().numpy()
+        if self.min_mask_region_area > 0 and n > 0:
+            sel_masks, sel_boxes, kept = postprocess_small_regions(
+                sel_masks, sel_boxes, self.min_mask_region_area, max(self.box_nms_thresh, self.crop_nms_thresh))
+            sel_iou, sel_stab, idx_np = sel_iou[kept], sel_stab[kept], idx_np[kept]
+        H, W = image.shape[:2]
+        out = []
+        for i in range(len(sel_masks)):
+            x0, y0, x1, y1 = (int(v) for v in sel_boxes[i])
+            out.append({"segmentation": sel_masks[i], "area": int(sel_masks[i].sum()),
+                        "bbox": [x0, y0, x1 - x0, y1 - y0], "predicted_iou": float(sel_iou[i]),
+                        "point_coords": [points[idx_np[i]].tolist()], "stability_score": float(sel_stab[i]),
+                        "crop_box": [0, 0, W, H]})
+        return out
+
+
+# ---- host side of postprocess_small_regions (automatic_mask_generator.py:324-372) -----------------
+def _label8(mask):
+    from scipy import ndimage
+    return ndimage.label(mask, structure=np.ones((3, 3), dtype=np.int32))
+
+
+def remove_small_regions(mask, area_thresh, mode):
+    """utils/amg.py:267-291 (connected components on the host, as the reference does with OpenCV)."""
+    correct_holes = mode == "holes"
+    working = correct_holes ^ mask
+    regions, n = _label8(working)
+    sizes = np.bincount(regions.ravel(), minlength=n + 1)[1:]
+    small = [i + 1 for i, s in enumerate(sizes) if s < area_thresh]
+    if not small:
+        return mask, False
+    fill = [0] + small
+    if not correct_holes:
+        fill = [i for i in range(n + 1) if i not in fill]
+        if not fill:
+            fill = [int(np.argmax(sizes)) + 1]
+    return np.isin(regions, fill), True
+
+
+def _mask_boxes(masks):
+    out = np.zeros((len(masks), 4), dtype=np.int64)
+    for i, m in enumerate(masks):
+        ys, xs = np.nonzero(m)
+        if len(ys):
+            out[i] = [xs.min(), ys.min(), xs.max(), ys.max()]
+    return out
+
+
+def _nms_host(boxes, scores, thr):
+    b = boxes.astype(np.float32)
+    order = np.argsort(-scores, kind="stable")
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    alive = np.ones(len(b), bool)
+    keep = []
+    for i in order:
+        if not alive[i]:
+            continue
+        keep.append(i)
+        lt = np.maximum(b[i, :2], b[:, :2])
+        rb = np.minimum(b[i, 2:], b[:, 2:])
+        wh = np.clip(rb - lt, 0, None)
+        inter = wh[:, 0] * wh[:, 1]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iou = inter / (area[i] + area - inter)
+        alive &= ~(iou > thr)
+        alive[i] = False
+    return np.array(keep, dtype=np.int64)
+
+
+def postprocess_small_regions(masks, boxes, min_area, nms_thresh):
+    new, scores = [], []
+    for m in masks:
+        m1, c1 = remove_small_regions(m, min_area, "holes")
+        m2, c2 = remove_small_regions(m1, min_area, "islands")
+        new.append(m2)
+        scores.append(float(not (c1 or c2)))
+    new = np.stack(new)
+    nb = _mask_boxes(new)
+    keep = _nms_host(nb, np.asarray(scores, dtype=np.float32), nms_thresh)
+    masks, boxes = masks.copy(), boxes.copy()
+    for i in keep:
+        if scores[i] == 0.0:
+            masks[i], boxes[i] = new[i], nb[i]
+    return masks[keep], boxes[keep], keep

@@ -102,6 +102,9 @@ SAM_CONFIGS = {
     # segment_anything/build_sam.py:14-21 (vit_h) + :55-101
     "vit_h": dict(embed_dim=1280, depth=32, num_heads=16, global_attn_indexes=(7, 15, 23, 31),
                   img_size=1024, patch_size=16, window_size=14, out_chans=256),
+    # full ViT-H width/grid but two blocks (one windowed, one global): full-size parity test
+    "vit_h_d2": dict(embed_dim=1280, depth=2, num_heads=16, global_attn_indexes=(1,),
+                     img_size=1024, patch_size=16, window_size=14, out_chans=256),
     # tiny geometry for parity tests: 16x16 tokens, 2 heads of 80, windowed + global blocks
     "tiny": dict(embed_dim=160, depth=4, num_heads=2, global_attn_indexes=(1, 3),
                  img_size=256, patch_size=16, window_size=14, out_chans=256),

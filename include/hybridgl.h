@@ -212,6 +212,97 @@ int hgl_synthesize_views(const uint8_t* sam_img, const uint8_t* blurred, const f
                          const uint8_t* masks, int N, int H, int W, int res,
                          float* local_imgs, float* global_imgs, void* stream);
 
+/* ------------------------------------------------------------------------
+ * SAM ViT-H mask proposals (third_party/segment-anything/segment_anything/,
+ * driven by SamAutomaticMaskGenerator at Hybridgl_main.py:66-74,85)
+ * --------------------------------------------------------------------- */
+
+typedef struct HglSamBlockW {          /* modeling/image_encoder.py:119-182 Block */
+  int window;                          /* 14, or 0 for the global-attention blocks (build_sam.py:19) */
+  int rel_len;                         /* rows of rel_pos_h/w = 2*size-1 (27 windowed, 127 global) */
+  const float *norm1_w, *norm1_b;
+  const float *qkv_w, *qkv_b;          /* [3D,D],[3D] */
+  const float *proj_w, *proj_b;        /* [D,D],[D] */
+  const float *rel_pos_h, *rel_pos_w;  /* [rel_len, D/heads] */
+  const float *norm2_w, *norm2_b;
+  const float *lin1_w, *lin1_b;        /* [4D,D],[4D] */
+  const float *lin2_w, *lin2_b;        /* [D,4D],[D] */
+} HglSamBlockW;
+
+typedef struct HglSamEncoderW {        /* modeling/image_encoder.py:17-116 ImageEncoderViT */
+  int embed_dim, depth, heads, img_size, patch, out_chans; /* ViT-H: 1280,32,16,1024,16,256 */
+  const float *patch_w, *patch_b;      /* [D, 3*patch*patch], [D] */
+  const float* pos_embed;              /* [g*g, D] */
+  const HglSamBlockW* blocks;          /* host array of `depth` */
+  const float* neck0_w;                /* conv1x1 [C, D] */
+  const float *neck1_w, *neck1_b;      /* LayerNorm2d */
+  const float* neck2_w;                /* conv3x3 [C, C*9] (weight flattened c,ky,kx) */
+  const float *neck3_w, *neck3_b;
+} HglSamEncoderW;
+
+typedef struct HglLinearW { const float *w, *b; } HglLinearW;   /* [out,in],[out] */
+typedef struct HglNormW { const float *w, *b; } HglNormW;
+typedef struct HglSamAttnW { HglLinearW q, k, v, out; int internal; } HglSamAttnW; /* transformer.py:185-240 */
+
+typedef struct HglSamDecoderW {        /* prompt_encoder.py + mask_decoder.py + transformer.py */
+  int C, grid, heads, mlp_dim;         /* 256, 64, 8, 2048 */
+  const float* pe_gauss;               /* [2, C/2] positional_encoding_gaussian_matrix */
+  const float *point_embed_pos, *not_a_point, *no_mask;   /* [C] each */
+  const float* dense_pe;               /* [grid*grid, C] = get_dense_pe() (filled by hgl_sam_dense_pe) */
+  const float *iou_token, *mask_tokens;/* [C], [4,C] */
+  struct { HglSamAttnW self_attn, t2i, i2t; HglNormW n1, n2, n3, n4; HglLinearW lin1, lin2; } layer[2];
+  HglSamAttnW final_t2i;
+  HglNormW norm_final;
+  const float *up0_w, *up0_b;          /* ConvT 256->64 as GEMM: [(pos,oc)=256, 256], bias [(pos,oc)] */
+  HglNormW up1;                        /* LayerNorm2d(64) */
+  const float *up3_w, *up3_b;          /* ConvT 64->32 as GEMM: [(pos,oc)=128, 64], bias [(pos,oc)] */
+  HglLinearW hyper[4][3];              /* output_hypernetworks_mlps */
+  HglLinearW iou_head[3];
+} HglSamDecoderW;
+
+/* Sam.preprocess + ImageEncoderViT.forward (modeling/sam.py:164-174, image_encoder.py:106-116).
+ * resized_img: [in_h,in_w,3] uint8 -- the image after ResizeLongestSide.apply_image (PIL
+ * bilinear on the host, utils/transforms.py:26-31).  emb: [g*g, out_chans] NHWC rows
+ * (the reference's [1,256,64,64] transposed; it is consumed in this order by the decoder). */
+size_t hgl_sam_encode_workspace_bytes(const HglSamEncoderW* w);
+int hgl_sam_encode(const HglSamEncoderW* w, const uint8_t* resized_img, int in_h, int in_w, float* emb,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* get_dense_pe() (prompt_encoder.py:194-205): grid_coords01 [grid*grid,2] fp32 = ((x+1)-0.5)/grid,
+ * ((y+1)-0.5)/grid; fills dense_pe [grid*grid, C]; call once per model. */
+int hgl_sam_dense_pe(const HglSamDecoderW* w, const float* grid_coords01, float* dense_pe, void* stream);
+
+/* PromptEncoder (one positive point per prompt + padding point) + MaskDecoder(multimask)
+ * (predictor.py:222-235): points01 [P,2] fp32 = (point+0.5)/img_size computed in float64 by the
+ * caller (prompt_encoder.py:79, :207-214) -> low_res [P,3,4*grid,4*grid] logits, iou [P,3]. */
+size_t hgl_sam_decode_workspace_bytes(const HglSamDecoderW* w, int P);
+int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float* points01, int P,
+                          float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* Sam.postprocess_masks + the per-candidate AMG statistics in one pass
+ * (modeling/sam.py:133-162, automatic_mask_generator.py:287-308, utils/amg.py:156-176,303-346):
+ * low_res [K,hl,wl] -> masks [K,H,W] uint8 (logit > mask_threshold), stability [K]
+ * (= |logit>thr+off| / |logit>thr-off|), boxes_xyxy [K,4] int32 inclusive (0 when empty), keep [K]
+ * (iou_pred > pred_iou_thresh && stability >= stability_thresh).  Candidates failing the IoU
+ * filter are skipped (zero mask).  full_logits: optional [K,H,W] fp32 (tests), else NULL. */
+size_t hgl_sam_postprocess_workspace_bytes(int K);
+int hgl_sam_postprocess(const float* low_res, const float* iou_pred, int K, int hl, int wl, int img_size,
+                        int in_h, int in_w, int H, int W, float mask_threshold, float stability_offset,
+                        float pred_iou_thresh, float stability_thresh, uint8_t* masks, int32_t* boxes_xyxy,
+                        float* stability, uint8_t* keep, float* full_logits, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* torchvision.ops.batched_nms with one category (automatic_mask_generator.py:251-257): greedy,
+ * descending score, suppress IoU > iou_threshold among candidates with keep!=0; K <= 1024.
+ * out_idx [K] receives the kept candidate indices in order, *out_n their count (device memory). */
+int hgl_nms(const int32_t* boxes_xyxy, const float* scores, const uint8_t* keep, int K, float iou_threshold,
+            int32_t* out_idx, int32_t* out_n, void* stream);
+
+/* out[i] = masks[idx[i]] for i < *n (device-side count), rows of HW bytes (HW % 16 == 0). */
+int hgl_gather_masks(const uint8_t* masks, const int32_t* idx, const int32_t* n, int max_n, long long HW,
+                     uint8_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

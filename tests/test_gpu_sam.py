@@ -1,0 +1,165 @@
+"""GPU parity of the SAM path (image encoder, prompt encoder + mask decoder, fused post-processing,
+NMS, whole SamAutomaticMaskGenerator) against reference stage tensors and the numpy oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hybridgl_amd import sam as hsam
+from hybridgl_amd import weights
+from oracle import sam_oracle as S
+from oracle.cases import sam_tiny_case
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "sam_tiny.npz"))
+
+
+@pytest.fixture(scope="module")
+def tiny(cuda):
+    sd = weights.sam_state_dict("tiny", 0)
+    return sd, hsam.Sam(sd, weights.SAM_CONFIGS["tiny"], cuda)
+
+
+def _p01(points_in, img_size):
+    return ((points_in + 0.5) / float(img_size)).astype(np.float32)
+
+
+def test_tiny_encoder_vs_reference(cuda, g, tiny):
+    c = sam_tiny_case()
+    emb = tiny[1].encode(T(c["resized"], cuda)).cpu().numpy().reshape(16, 16, 256)
+    np.testing.assert_allclose(emb[::2, ::2], g["emb_nhwc"], rtol=0, atol=1e-4)
+    ref = S.image_encoder(tiny[0], S.preprocess(c["resized"], 256), weights.SAM_CONFIGS["tiny"])
+    np.testing.assert_allclose(emb, ref, rtol=0, atol=1e-4)
+
+
+def test_tiny_decoder_vs_reference(cuda, g, tiny):
+    c = sam_tiny_case()
+    sd, m = tiny
+    emb = S.image_encoder(sd, S.preprocess(c["resized"], 256), weights.SAM_CONFIGS["tiny"])
+    low, iou = m.decode_points(T(emb.reshape(256, 256), cuda), T(_p01(c["points_in"], 256), cuda))
+    np.testing.assert_allclose(low.cpu().numpy(), g["low_res"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(iou.cpu().numpy(), g["iou"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(m.dense_pe.cpu().numpy()[::5], g["dense_pe"], rtol=0, atol=2e-5)
+
+
+def test_tiny_postprocess_vs_reference(cuda, g, tiny):
+    c = sam_tiny_case()
+    m = tiny[1]
+    low = g["low_res"].reshape(15, 64, 64)
+    iou = g["iou"].reshape(15)
+    masks, boxes, stab, keep, full = m.postprocess(T(low, cuda), T(iou, cuda), c["input_size"], c["orig_size"],
+                                                   -1e30, 0.0, 1.0, return_logits=True)
+    full = full.cpu().numpy()
+    np.testing.assert_allclose(full[:, ::4, ::4], g["full_logits"].reshape(15, 40, 50), rtol=0, atol=2e-5)
+    ref_full = S.postprocess_masks(g["low_res"], c["input_size"], c["orig_size"], 256).reshape(15, 160, 200)
+    np.testing.assert_allclose(full, ref_full, rtol=0, atol=2e-5)
+    # masks / counters are exact functions of the logits this kernel produced
+    assert np.array_equal(masks.cpu().numpy().astype(bool), full > 0)
+    st, _, _ = S.stability_score(full)
+    np.testing.assert_allclose(stab.cpu().numpy(), st, rtol=0, atol=1e-6)
+    assert np.array_equal(boxes.cpu().numpy().astype(np.int64), S.mask_to_box(full > 0))
+    np.testing.assert_allclose(stab.cpu().numpy(), g["stability"], rtol=0, atol=2e-3)
+    assert np.abs(boxes.cpu().numpy() - g["boxes"]).max() <= 1
+    assert keep.cpu().numpy().all()
+
+
+def test_postprocess_filters_and_empty(cuda, tiny):
+    """iou filter skips candidates (zero mask, keep=0); empty masks give box 0 and NaN stability -> keep=0."""
+    m = tiny[1]
+    rng = np.random.default_rng(1)
+    low = rng.standard_normal((6, 64, 64)).astype(np.float32) * 3
+    low[2] = -5.0   # never above threshold -> empty mask, 0/0 stability
+    iou = np.array([0.9, 0.5, 0.9, 0.95, 0.71, 0.7], np.float32)
+    masks, boxes, stab, keep, _ = m.postprocess(T(low, cuda), T(iou, cuda), (205, 256), (160, 200), 0.7, 0.1, 1.0)
+    keep, masks, boxes = keep.cpu().numpy(), masks.cpu().numpy(), boxes.cpu().numpy()
+    assert keep.tolist() == [1, 0, 0, 1, 1, 0]
+    assert masks[1].sum() == 0 and masks[5].sum() == 0 and masks[2].sum() == 0
+    assert boxes[2].tolist() == [0, 0, 0, 0]
+    full = S.postprocess_masks(low[None], (205, 256), (160, 200), 256)[0]
+    assert np.array_equal(masks[0].astype(bool), full[0] > 0)
+
+
+def test_nms_vs_oracle(cuda):
+    rng = np.random.default_rng(2)
+    for K in [1, 7, 192, 700]:
+        xy = rng.integers(0, 500, size=(K, 2))
+        wh = rng.integers(1, 200, size=(K, 2))
+        boxes = np.concatenate([xy, xy + wh], 1).astype(np.int32)
+        boxes[K // 2] = boxes[0]                     # duplicates
+        scores = rng.random(K).astype(np.float32)
+        if K > 3:
+            scores[3] = scores[1]                    # score tie -> lower index first
+        keep = (rng.random(K) > 0.2).astype(np.uint8)
+        keep[0] = 1
+        idx, n = hsam.nms(T(boxes, cuda), T(scores, cuda), T(keep, cuda), 0.7)
+        n = int(n.item())
+        got = idx.cpu().numpy()[:n]
+        sel = np.nonzero(keep)[0]
+        ref = sel[S.nms(boxes[sel].astype(np.int64), scores[sel], 0.7)]
+        assert got.tolist() == ref.tolist()
+
+
+def test_tiny_generate_vs_reference(cuda, g, tiny):
+    c = sam_tiny_case()
+    gen = hsam.SamAutomaticMaskGenerator(tiny[1], points_per_side=4, pred_iou_thresh=-1e9,
+                                         stability_score_thresh=0.0, crop_n_layers=0, min_mask_region_area=20,
+                                         box_nms_thresh=1.5)
+    anns = gen.generate(c["image"])
+    assert len(anns) == int(g["amg_n"][0])
+    ref_masks = np.unpackbits(g["amg_masks"], axis=-1)[..., :200].astype(bool)
+    np.testing.assert_allclose([a["predicted_iou"] for a in anns], g["amg_iou"], rtol=0, atol=1e-4)
+    mism = np.array([(a["segmentation"] != r).mean() for a, r in zip(anns, ref_masks)])
+    assert mism.max() < 2e-3, mism.max()
+    np.testing.assert_allclose([a["point_coords"][0] for a in anns], g["amg_points"], rtol=0, atol=1e-9)
+    assert np.abs(np.array([a["bbox"] for a in anns]) - g["amg_bbox"]).max() <= 2
+    assert all(a["crop_box"] == [0, 0, 200, 160] for a in anns)
+
+
+def test_vit_h_two_blocks_full_width(cuda):
+    """ViT-H width (1280, 16 heads of 80, 64x64 tokens, 25 padded windows, 127-entry rel-pos tables):
+    one windowed + one global block + neck against the oracle at full size."""
+    cfg = weights.SAM_CONFIGS["vit_h_d2"]
+    sd = weights.sam_state_dict("vit_h_d2", 0)
+    m = hsam.Sam(sd, cfg, cuda)
+    from hybridgl_amd.synth import synth_image
+    img = synth_image(683, 1024, 5)      # a 427x640 image resized: exercises the zero padding
+    emb = m.encode(T(img, cuda)).cpu().numpy().reshape(64, 64, 256)
+    ref = S.image_encoder(sd, S.preprocess(img, 1024), cfg)
+    np.testing.assert_allclose(emb, ref, rtol=0, atol=2e-4)
+    emb2 = m.encode(T(img, cuda)).cpu().numpy().reshape(64, 64, 256)
+    assert np.array_equal(emb, emb2)      # run-to-run bit reproducible
+
+
+def test_full_size_decoder_properties(cuda):
+    """64 prompts x 64x64 embedding (BASELINE size): finite, deterministic, prompt-batch independent."""
+    cfg = weights.SAM_CONFIGS["vit_h_d2"]
+    sd = weights.sam_state_dict("vit_h_d2", 0)
+    m = hsam.Sam(sd, cfg, cuda)
+    rng = np.random.default_rng(7)
+    emb = T(rng.standard_normal((4096, 256)).astype(np.float32), cuda)
+    pts = hsam.build_point_grid(8) * 1024.0
+    p01 = T(((pts + 0.5) / 1024.0).astype(np.float32), cuda)
+    low, iou = m.decode_points(emb, p01)
+    assert torch.isfinite(low).all() and torch.isfinite(iou).all()
+    low2, iou2 = m.decode_points(emb, p01)
+    assert torch.equal(low, low2) and torch.equal(iou, iou2)
+    sub_low, sub_iou = m.decode_points(emb, p01[10:13].contiguous())
+    np.testing.assert_allclose(sub_low.cpu().numpy(), low[10:13].cpu().numpy(), rtol=0, atol=2e-4)
+    # oracle on three prompts at full grid size
+    rl, ri = S.mask_decoder(sd, emb.cpu().numpy().reshape(64, 64, 256), S.embed_points(sd, pts[10:13], 1024))
+    np.testing.assert_allclose(sub_low.cpu().numpy(), rl, rtol=0, atol=5e-4)
+    np.testing.assert_allclose(sub_iou.cpu().numpy(), ri, rtol=0, atol=2e-4)
+    # post-process all 192 candidates at 640x640 and compare three with the oracle
+    masks, boxes, stab, keep, _ = m.postprocess(low.flatten(0, 1), iou.flatten(), (1024, 1024), (640, 640))
+    full = S.postprocess_masks(low[10:11].cpu().numpy(), (1024, 1024), (640, 640))[0]
+    got = masks[30:33].cpu().numpy().astype(bool)
+    assert ((got != (full > 0)).mean(axis=(1, 2)) < 1e-4).all()
