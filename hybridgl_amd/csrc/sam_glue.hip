@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void pe_kernel(const float* __restrict__ coord
     o[f + F] = not_a_point[f + F];
     return;
   }
-  const float cx = 2.f * coords01[2 * r] - 1.f, cy = 2.f * coords01[2 * r + 1] - 1.f;
+  const int pt = mode == 1 ? (r >> 1) : r;  // prompts: rows (point, padding) share one coordinate
+  const float cx = 2.f * coords01[2 * pt] - 1.f, cy = 2.f * coords01[2 * pt + 1] - 1.f;
   const float v = 6.283185307179586f * (cx * G[f] + cy * G[F + f]);
   float s = sinf(v), c = cosf(v);
   if (mode == 1) { s += pos_embed[f]; c += pos_embed[f + F]; }
