@@ -28,13 +28,14 @@ PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
-def algorithmic_flops_per_ref(N=64, n_strings=9):
-    """SURVEY.md 8d, minimal variant (dead final-block streams removed), ViT-B/16 G2L."""
+def algorithmic_flops_per_ref(N=64, n_strings=9, sam=True):
+    """SURVEY.md 8d, minimal variant (dead final-block streams removed), ViT-B/16 G2L;
+    SAM ViT-H encoder 5.961 TFLOP + decoder 3.62 GFLOP x 64 prompts."""
     blk = 2.908e9          # per sequence per block (qkv .697, proj .232, mlp 1.859, attn .119)
     patch = 0.231e9        # patch embed per sequence
     clip = 2 * N * patch + 23 * N * blk
     text = 5.96e9 * n_strings
-    return clip + text
+    return clip + text + ((5.961e12 + 64 * 3.62e9) if sam else 0.0)
 
 
 def prof_read(lib, cls):
@@ -44,7 +45,41 @@ def prof_read(lib, cls):
     return n.value, ms.value, fl.value, by.value
 
 
-def cpu_baseline(fusion_mode, n_sample=8):
+def cpu_baseline_sam():
+    """SAM stages of the oracle on a bounded sample: one windowed + one global ViT-H block (scaled
+    x28 / x4), the neck, the decoder on 2 of 64 prompts (x32), post-processing on 6 of 192 (x32)."""
+    from hybridgl_amd import synth, weights
+    from oracle import sam_oracle as S
+    cfg = weights.SAM_CONFIGS["vit_h_d2"]
+    sd = weights.sam_state_dict("vit_h_d2", 0)
+    img = synth.synth_image(1024, 1024, 1000)
+    x = S.preprocess(img, 1024)
+    t0 = time.perf_counter()
+    w = sd["image_encoder.patch_embed.proj.weight"]
+    cols = x.reshape(3, 64, 16, 64, 16).transpose(1, 3, 0, 2, 4).reshape(4096, 768)
+    tk = (cols @ w.reshape(1280, -1).T + sd["image_encoder.patch_embed.proj.bias"]).reshape(1, 64, 64, 1280)
+    tk = (tk + sd["image_encoder.pos_embed"]).astype(np.float32)
+    t1 = time.perf_counter()
+    b0 = S.encoder_block(tk, sd, "image_encoder.blocks.0", 16, 14)
+    t2 = time.perf_counter()
+    b1 = S.encoder_block(b0, sd, "image_encoder.blocks.1", 16, 0)
+    t3 = time.perf_counter()
+    n = b1[0].reshape(4096, 1280) @ sd["image_encoder.neck.0.weight"].reshape(-1, 1280).T
+    n = S.layer_norm_2d(n.reshape(64, 64, -1).astype(np.float32), sd["image_encoder.neck.1.weight"], sd["image_encoder.neck.1.bias"])
+    n = S.layer_norm_2d(S.conv3x3_nhwc(n, sd["image_encoder.neck.2.weight"]), sd["image_encoder.neck.3.weight"], sd["image_encoder.neck.3.bias"])
+    t4 = time.perf_counter()
+    pts = S.point_grid(8)[:2] * 1024.0
+    low, iou = S.mask_decoder(sd, n, S.embed_points(sd, pts, 1024))
+    t5 = time.perf_counter()
+    full = S.postprocess_masks(low, (1024, 1024), (640, 640))
+    S.stability_score(full.reshape(6, 640, 640)); S.mask_to_box(full.reshape(6, 640, 640) > 0)
+    t6 = time.perf_counter()
+    t_img = (t1 - t0) + (t2 - t1) * 28 + (t3 - t2) * 4 + (t4 - t3) + (t5 - t4) * 32 + (t6 - t5) * 32
+    return t_img, (f"SAM ViT-H: 1 windowed block {t2 - t1:.1f}s x28 + 1 global block {t3 - t2:.1f}s x4 + neck, "
+                   f"decoder on 2 of 64 prompts {t5 - t4:.1f}s x32, post-process 6 of 192 {t6 - t5:.1f}s x32")
+
+
+def cpu_baseline(fusion_mode, n_sample=8, with_sam=True):
     """Oracle (numpy port of the reference algorithm, oracle/clip_oracle.py) timed on the host
     cores for a bounded sample of the same workload; extrapolated to one ref."""
     from hybridgl_amd import synth, weights
@@ -76,10 +111,15 @@ def cpu_baseline(fusion_mode, n_sample=8):
     t4 = time.perf_counter()
     scale = 64 / n_sample
     t_ref = (t1 - t0) * scale + (t2 - t1) * scale + (t3 - t2) + (t4 - t3)
+    sam_note = ""
+    if with_sam:
+        t_sam, sam_note = cpu_baseline_sam()
+        t_ref += t_sam
+        sam_note = "; " + sam_note
     return {"value": 1.0 / t_ref, "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"numpy oracle: views+CLIP hybrid {fusion_mode} on {n_sample} of 64 masks "
                       f"({t2 - t0:.1f}s, scaled x{scale:g}), 9 text strings ({t3 - t2:.1f}s), "
-                      f"3-sentence tail on 64 masks ({t4 - t3:.1f}s); numpy BLAS threads = host default"}
+                      f"3-sentence tail on 64 masks ({t4 - t3:.1f}s){sam_note}; numpy BLAS threads = host default"}
 
 
 def main():
@@ -91,6 +131,8 @@ def main():
     ap.add_argument("--masks", type=int, default=64)
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic refs resident per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scope", default="B", choices=["A", "B"],
+                    help="A: proposals given (CLIP + scoring only); B: + SAM ViT-H proposal stage (full path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,9 +152,18 @@ def main():
 
     lib = _lib.load()
     model = CLIPViTFM("ViT-B/16", seed=0, device=dev)
-    pipe = HybridGLPipeline(model, fusion_mode=args.fusion, masking_block=9)
+    gen = None
+    if args.scope == "B":
+        from hybridgl_amd.sam import SamAutomaticMaskGenerator, sam_model_registry
+        sam = sam_model_registry["default"](seed=0, device=dev)
+        # Hybridgl_main.py:67-73
+        gen = SamAutomaticMaskGenerator(sam, points_per_side=8, pred_iou_thresh=0.7, stability_score_thresh=0.7,
+                                        crop_n_layers=0, crop_n_points_downscale_factor=1, min_mask_region_area=800)
+    # the CLIP stage scores the 64 seeded proposals (fixed N): random SAM weights give an arbitrary count
+    pipe = HybridGLPipeline(model, fusion_mode=args.fusion, masking_block=9, mask_generator=gen, use_sam_masks=False)
     # rank r owns refs i = r (mod world) of the shuffle=False order
-    refs = [synthetic_ref(rank + world * j, dev, N=args.masks)[0] for j in range(args.pool)]
+    refs = [synthetic_ref(rank + world * j, dev, N=args.masks, sam_img_size=1024 if gen else 0)[0]
+            for j in range(args.pool)]
 
     def barrier():
         if world > 1:
@@ -179,10 +230,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic (seeded images/masks/tokens/heat-maps; seeded random weights)",
             "config": {
-                "workload": f"RefCOCO-shaped ref: 640x640 image, {args.masks} proposals given, 3 queries x "
-                            f"(sentence+noun phrase+1 other noun); view synthesis + CLIP ViT-B/16 hybrid "
-                            f"{args.fusion} (masking_block 9) + text encoder (9 strings) + scoring tail + IoU; "
-                            f"SAM proposal generation NOT included yet (scope A of SURVEY.md 8d)",
+                "workload": (f"RefCOCO-shaped ref (BASELINE configs[1]): 640x640 image, 3 queries x (sentence+noun "
+                             f"phrase+1 other noun); "
+                             + ("SAM ViT-H proposal stage (encoder, 8x8 point grid = 64 prompts x 3 masks, fused "
+                                "post-processing, NMS; PIL resize to 1024 and small-region clean-up outside the "
+                                "timed step) + " if args.scope == "B" else "proposals given (scope A) + ")
+                             + f"view synthesis + CLIP ViT-B/16 hybrid {args.fusion} (masking_block 9) on "
+                             f"{args.masks} seeded proposals + text encoder (9 strings) + scoring tail + IoU"),
+                "scope": args.scope,
                 "fusion_mode": args.fusion, "proposals": args.masks, "image": "640x640", "queries": 3,
                 "parallelism": f"image-parallel x{world}",
             },
@@ -196,12 +251,12 @@ def main():
                 "attention": {"achieved": a_fl / (a_ms * 1e-3) / 1e12 if a_ms > 0 else 0.0,
                               "launches_per_step": a_n / nprof, "ms_per_step": a_ms / nprof},
                 "gemm_ms_per_step": g_ms / nprof,
-                "whole_step_algorithmic_tflops": algorithmic_flops_per_ref(args.masks) / (dt / args.steps) / 1e12,
+                "whole_step_algorithmic_tflops": algorithmic_flops_per_ref(args.masks, sam=args.scope == "B") / (dt / args.steps) / 1e12,
             },
             "metrics": m,
         }
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(args.fusion)
+            rec["cpu_baseline"] = cpu_baseline(args.fusion, with_sam=args.scope == "B")
         print(json.dumps(rec))
     if world > 1:
         dist.destroy_process_group()

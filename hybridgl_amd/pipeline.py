@@ -45,6 +45,7 @@ class RefBatch:
     tokens: torch.Tensor       # [T,77] int32    every string of the ref
     target: torch.Tensor       # [H,W] bool/uint8 ground truth
     sentences: List[Sentence] = field(default_factory=list)
+    sam_resized: Optional[torch.Tensor] = None  # [h,w,3] uint8: sam_img after ResizeLongestSide (PIL, host)
 
 
 def _rows(text, rows):
@@ -62,8 +63,15 @@ def black_for(relaflag):
 
 
 class HybridGLPipeline:
-    def __init__(self, model, fusion_mode="G2L", masking_block=9, r=0.5, alpha=0.6, k1=3, k2=6, res=224):
+    def __init__(self, model, fusion_mode="G2L", masking_block=9, r=0.5, alpha=0.6, k1=3, k2=6, res=224,
+                 mask_generator=None, use_sam_masks=False):
+        """mask_generator: a hybridgl_amd.sam.SamAutomaticMaskGenerator; when given, every step runs the
+        SAM proposal stage (encoder, decoder, post-processing, NMS) on ref.sam_img first.
+        use_sam_masks=False keeps ref.masks for the CLIP stage (fixed N; synthetic benchmark, where
+        random SAM weights give an arbitrary number of proposals); True feeds the SAM proposals."""
         self.model = model
+        self.mask_generator = mask_generator
+        self.use_sam_masks = use_sam_masks
         self.fusion_mode = fusion_mode
         self.masking_block = masking_block
         self.r, self.alpha, self.k1, self.k2 = r, alpha, k1, k2  # Hybridgl_main.py:57-63
@@ -76,6 +84,11 @@ class HybridGLPipeline:
     def step(self, ref: RefBatch):
         """One dataset item; returns the device tensors of the last sentence (idx, scores)."""
         m = self.model
+        if self.mask_generator is not None:
+            prop = self.mask_generator.propose(ref.sam_img, resized=ref.sam_resized)   # Hybridgl_main.py:85
+            if self.use_sam_masks:
+                ref = self._with_sam_masks(ref, prop)
+            self.last_proposals = prop
         local, glob = ops.synthesize_views(ref.sam_img, ref.blurred, ref.image_norm, ref.masks, self.res)
         hybrid = m(local, glob, ref.masks, masking_block=self.masking_block, fusion_mode=self.fusion_mode)
         text = m.model.encode_text(ref.tokens)
@@ -97,6 +110,15 @@ class HybridGLPipeline:
             last = (idx, sc, sn, gem)
         return hybrid, text, last
 
+    def _with_sam_masks(self, ref, prop):
+        """Hybridgl_main.py:86-90: masks/boxes of the surviving proposals (one host sync for the count)."""
+        import dataclasses
+        masks, boxes, iou, stab, order, n, _ = prop
+        idx = order[: int(n.item())].long()
+        b = boxes.index_select(0, idx).long()
+        xywh = torch.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1).contiguous()
+        return dataclasses.replace(ref, masks=masks.index_select(0, idx).contiguous(), boxes=xywh)
+
     def metrics(self):
         """Hybridgl_main.py:240-247: overall IoU and mean IoU, pure and with spatial guidance."""
         cum = self.cum.cpu().numpy().astype(np.float64)
@@ -112,7 +134,7 @@ class HybridGLPipeline:
         }
 
 
-def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=49408):
+def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=49408, sam_img_size=0):
     """The benchmark item of SURVEY.md 8d: 640x640 image, 64 proposals, 3 queries, each with a
     sentence, a noun phrase and one other noun (9 token rows).  Returns (RefBatch, numpy dict)."""
     img = synth.synth_image(H, W, 1000 + i)
@@ -130,6 +152,12 @@ def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=494
         sents.append(Sentence(3 * j, 3 * j + 1, [3 * j + 2], dirflag, relaflag, n_nouns,
                               torch.from_numpy(attn).to(device)))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-    ref = RefBatch(t(img), t(blur), t(norm), t(masks), t(boxes), t(tokens), t(gt), sents)
+    resized = None
+    if sam_img_size:
+        from PIL import Image
+        from .sam import get_preprocess_shape
+        nh, nw = get_preprocess_shape(H, W, sam_img_size)
+        resized = t(np.array(Image.fromarray(img).resize((nw, nh), Image.BILINEAR)))
+    ref = RefBatch(t(img), t(blur), t(norm), t(masks), t(boxes), t(tokens), t(gt), sents, resized)
     host = dict(img=img, blur=blur, norm=norm, masks=masks, boxes=boxes, tokens=tokens, gt=gt, attn=attn_np)
     return ref, host
