@@ -14,16 +14,18 @@
 //     ds_read_b128 fragment reads are bank-conflict free.
 //   * A lane's fragment is 4 consecutive k (one ds_read_b128) feeding 4 MFMA
 //     k-steps; the k-permutation is the same for A and W so the sum is unchanged.
-//   * register prefetch of tile t+1 is issued before the MFMAs of tile t and
-//     written to the other LDS buffer afterwards: one barrier per K-tile.
+//   * register prefetch of tile t+1 is issued before the MFMAs of tile t and written to LDS
+//     afterwards; ONE LDS buffer (two barriers per K-tile) so that three workgroups fit a CU:
+//     the extra wave per SIMD hides the staging/barrier gaps better than double buffering did.
 //   * 1-D grid with a bijective XCD-aware remap so that blocks sharing A/W panels
 //     run on the same XCD (private L2).
 #include "hgl_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDS_LD = BK + 4;  // floats per LDS row (padded)
+constexpr int BM = 128, BN = 128;
 constexpr int NTHREADS = 256;
 
 struct GemmArgs {
@@ -39,23 +41,24 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-__device__ __forceinline__ float act_apply(float x, int act) {
-  switch (act) {
-    case HGL_ACT_QUICKGELU:
-      return x / (1.0f + __expf(-1.702f * x));
-    case HGL_ACT_GELU:
-      return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-    case HGL_ACT_RELU:
-      return x > 0.0f ? x : 0.0f;
-    default:
-      return x;
-  }
+template <int ACT>
+__device__ __forceinline__ float act_apply(float x) {
+  if constexpr (ACT == HGL_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+  if constexpr (ACT == HGL_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  if constexpr (ACT == HGL_ACT_RELU) return x > 0.0f ? x : 0.0f;
+  return x;
 }
 
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmArgs g) {
+// ACT is a template parameter so that the epilogue carries no per-element switch.
+template <int ACT, int BK, int NBUF, int OCC>
+__global__ __launch_bounds__(NTHREADS, OCC) void gemm_f32_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // layout: [2 buffers][A: BM x LDS_LD | W: BN x LDS_LD]
+  // layout: [NBUF buffers][A: BM x LDS_LD | W: BN x LDS_LD]
+  constexpr int LDS_LD = BK + 4;  // floats per LDS row (padded by one float4: conflict-free b128 reads)
   constexpr int TILE_F = (BM + BN) * LDS_LD;
+  constexpr int K4 = BK / 4;            // float4 per row of a K tile
+  constexpr int RSTEP = NTHREADS / K4;  // rows covered by one pass of the block
+  constexpr int NLD = BM / RSTEP;       // float4 loads per thread per operand per K tile
 
   // ---- XCD-aware bijective block remap (blocks b, b+8 share an XCD) ----
   const int nwg = gridDim.x;
@@ -87,29 +90,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
 
   // global staging coordinates: 4 float4 of A and 4 of W per thread per K-tile
-  const int ld_k4 = t & 7;   // float4 index within the 32-wide K tile
-  const int ld_row = t >> 3; // 0..31, +32*i
+  const int ld_k4 = t % K4;   // float4 index within the K tile
+  const int ld_row = t / K4;  // + RSTEP*i
   const int row0 = tile_m * BM, col0 = tile_n * BN;
 
-  f32x4 pa[4], pw[4];
+  f32x4 pa[NLD], pw[NLD];
+  // branch-free staging loads: out-of-range rows / k are clamped to a valid address and zeroed
+  const int mclamp = g.M - 1, nclamp = g.N - 1, kclamp = g.K - 4;
   auto load_tile = [&](int kt) {
     const int k = kt * BK + ld_k4 * 4;
     const bool kok = k < g.K;
+    const int kk = kok ? k : kclamp;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ra = row0 + ld_row + 32 * i;
-      const int rw = col0 + ld_row + 32 * i;
-      pa[i] = (kok && ra < g.M) ? *(const f32x4*)(A + (long long)ra * g.lda + k) : f32x4{0, 0, 0, 0};
-      pw[i] = (kok && rw < g.N) ? *(const f32x4*)(W + (long long)rw * g.ldw + k) : f32x4{0, 0, 0, 0};
+    for (int i = 0; i < NLD; ++i) {
+      const int ra = row0 + ld_row + RSTEP * i;
+      const int rw = col0 + ld_row + RSTEP * i;
+      const f32x4 va = *(const f32x4*)(A + (long long)min(ra, mclamp) * g.lda + kk);
+      const f32x4 vw = *(const f32x4*)(W + (long long)min(rw, nclamp) * g.ldw + kk);
+      const bool oka = kok && ra < g.M, okw = kok && rw < g.N;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pa[i][e] = oka ? va[e] : 0.f;
+        pw[i][e] = okw ? vw[e] : 0.f;
+      }
     }
   };
   auto store_tile = [&](int buf) {
     float* As = smem + buf * TILE_F;
     float* Ws = As + BM * LDS_LD;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(f32x4*)(As + (ld_row + 32 * i) * LDS_LD + ld_k4 * 4) = pa[i];
-      *(f32x4*)(Ws + (ld_row + 32 * i) * LDS_LD + ld_k4 * 4) = pw[i];
+    for (int i = 0; i < NLD; ++i) {
+      *(f32x4*)(As + (ld_row + RSTEP * i) * LDS_LD + ld_k4 * 4) = pa[i];
+      *(f32x4*)(Ws + (ld_row + RSTEP * i) * LDS_LD + ld_k4 * 4) = pw[i];
     }
   };
 
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmArgs g) {
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+    const int buf = NBUF == 2 ? (kt & 1) : 0;
     if (kt + 1 < nk) load_tile(kt + 1);
     const float* As = smem + buf * TILE_F + (wm * 64 + r) * LDS_LD + 4 * h;
     const float* Ws = smem + buf * TILE_F + BM * LDS_LD + (wn * 64 + r) * LDS_LD + 4 * h;
@@ -145,26 +157,48 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmArgs g) {
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
       }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+    if (NBUF == 1) __syncthreads();  // single buffer: everyone done reading before it is overwritten
+    if (kt + 1 < nk) store_tile(NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
 
   // ---- epilogue: bias, activation, residual, store ----
-  // acc[i][j][e]: row = (e&3) + 8*(e>>2) + 4*h, col = r within the 32x32 tile
+  // acc[i][j][e]: row = (e&3) + 8*(e>>2) + 4*h, col = r within the 32x32 tile.
+  // Residual values of a whole 32x32 tile are fetched first (16 loads in flight, clamped
+  // addresses: no per-element wait), then combined and stored.
+  const bool full_tile = (row0 + BM <= g.M) && (col0 + BN <= g.N);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = col0 + wn * 64 + j * 32 + r;
-    if (col >= g.N) continue;
-    const float bv = g.bias ? g.bias[col] : 0.0f;
+    const bool cok = col < g.N;
+    const int colc = cok ? col : nclamp;
+    const float bv = g.bias ? g.bias[colc] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      const int rbase = row0 + wm * 64 + i * 32 + 4 * h;
+      float rv[16];
+      if (R) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = row0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < g.M) {
-          float v = act_apply(acc[i][j][e] + bv, g.act);
-          if (R) v += R[(long long)row * g.ldr + col];
-          C[(long long)row * g.ldc + col] = v;
+        for (int e = 0; e < 16; ++e) {
+          const int row = min(rbase + (e & 3) + 8 * (e >> 2), mclamp);
+          rv[e] = R[(long long)row * g.ldr + colc];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+      }
+      if (full_tile) {  // uniform: interior tiles store without per-element predicates
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = rbase + (e & 3) + 8 * (e >> 2);
+          C[(long long)row * g.ldc + col] = act_apply<ACT>(acc[i][j][e] + bv) + rv[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = rbase + (e & 3) + 8 * (e >> 2);
+          const float v = act_apply<ACT>(acc[i][j][e] + bv) + rv[e];
+          if (cok && row < g.M) C[(long long)row * g.ldc + col] = v;
         }
       }
     }
@@ -193,14 +227,38 @@ int hgl_launch_gemm(const float* A, const float* W, const float* bias, const flo
   g.tiles_n = (N + BN - 1) / BN;
   const long long nwg = (long long)g.tiles_m * g.tiles_n * batch;
   HGL_REQUIRE(nwg < (1ll << 31), "gemm: grid too large");
-  const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  // default: single LDS buffer (36.9 KB) -> 3 workgroups per CU (3 waves/SIMD); measured on MI355X
+  // 104-121 TF/s on the CLIP shapes vs 87-108 for the double-buffered 2-workgroup variant, which
+  // HGL_GEMM_VARIANT=bk32x2 keeps selectable for A/B runs.
+  static int variant = -1;
+  if (variant < 0) {
+    const char* v = getenv("HGL_GEMM_VARIANT");
+    variant = (v && !strcmp(v, "bk32x2")) ? 1 : 0;
   }
   HglProfScope prof(HGL_PROF_GEMM, 2.0 * M * (double)N * K * batch,
                     4.0 * batch * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)nwg), dim3(NTHREADS), lds, st, g);
+#define HGL_GEMM_LAUNCH(ACT_, BK_, NBUF_, OCC_)                                                            \
+  do {                                                                                                  \
+    const size_t lds_ = (size_t)NBUF_ * (BM + BN) * (BK_ + 4) * sizeof(float);                          \
+    static bool set_ = false;                                                                           \
+    if (!set_) {                                                                                        \
+      (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<ACT_, BK_, NBUF_, OCC_>,                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                 \
+      set_ = true;                                                                                      \
+    }                                                                                                   \
+    hipLaunchKernelGGL((gemm_f32_kernel<ACT_, BK_, NBUF_, OCC_>), dim3((unsigned)nwg), dim3(NTHREADS), lds_,  \
+                       st, g);                                                                          \
+  } while (0)
+#define HGL_GEMM_VARIANTS(ACT_)                               \
+  do {                                                        \
+    if (variant == 1) HGL_GEMM_LAUNCH(ACT_, 32, 2, 2);        \
+    else HGL_GEMM_LAUNCH(ACT_, 32, 1, 3);                     \
+  } while (0)
+  switch (act) {
+    case HGL_ACT_QUICKGELU: HGL_GEMM_VARIANTS(HGL_ACT_QUICKGELU); break;
+    case HGL_ACT_GELU: HGL_GEMM_VARIANTS(HGL_ACT_GELU); break;
+    case HGL_ACT_RELU: HGL_GEMM_VARIANTS(HGL_ACT_RELU); break;
+    default: HGL_GEMM_VARIANTS(HGL_ACT_NONE); break;
+  }
   return hgl_check_launch("gemm_f32");
 }
