@@ -98,6 +98,11 @@ PROTOTYPES = {
     "hgl_prof_enable": (_I, [_I]),
     "hgl_prof_read": (_I, [_I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double),
                            C.POINTER(C.c_double)]),
+    "hgl_set_precision": (_I, [_I]),
+    "hgl_get_precision": (_I, []),
+    "hgl_register_split_weight": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP]),
+    "hgl_unregister_split_weight": (_I, [_VP]),
+    "hgl_gemm_f16x3": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _SZ, _VP]),
     "hgl_gemm_f32": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _LL, _LL, _LL, _I, _VP]),
     "hgl_layernorm_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I, _F, _VP]),
     "hgl_attention_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _LL, _LL, _LL,

@@ -45,7 +45,7 @@ def _infer_config(sd):
 class _Blocks:
     """Device tensors + the C array of HglResBlockW for one transformer."""
 
-    def __init__(self, sd, prefix, layers, device):
+    def __init__(self, sd, prefix, layers, device, precision="f32"):
         self.t = []  # keep tensors alive
         self.arr = (HglResBlockW * layers)()
         names = [("ln1_w", "ln_1.weight"), ("ln1_b", "ln_1.bias"),
@@ -59,6 +59,8 @@ class _Blocks:
                 t = _to_dev(sd[f"{prefix}.resblocks.{i}.{key}"], device)
                 self.t.append(t)
                 setattr(self.arr[i], field, t.data_ptr())
+                if precision == "f16x3" and field in ("in_proj_w", "out_proj_w", "fc_w", "proj_w"):
+                    ops.register_split_weight(t)   # fp16 hi/lo halves for the split matrix-core path
 
 
 def _to_dev(a, device):
@@ -72,14 +74,15 @@ def _to_dev(a, device):
 class _ClipModel:
     """The `.model` attribute: what the reference reaches as Model.model.* (clip/model.py:340-431)."""
 
-    def __init__(self, sd, cfg, device):
+    def __init__(self, sd, cfg, device, precision="f32"):
         self.cfg = cfg
+        self.precision = precision
         self.device = torch.device(device)
         self.dtype = torch.float32  # convert_weights is disabled in the reference (clip/model.py:509)
         vw, vl = cfg["vision_width"], cfg["vision_layers"]
         p = cfg["vision_patch_size"]
         grid = cfg["image_resolution"] // p
-        self._vb = _Blocks(sd, "visual.transformer", vl, device)
+        self._vb = _Blocks(sd, "visual.transformer", vl, device, precision)
         self._vt = {
             "conv1": _to_dev(np.asarray(sd["visual.conv1.weight"]).reshape(vw, -1), device),
             "cls": _to_dev(sd["visual.class_embedding"], device),
@@ -102,7 +105,7 @@ class _ClipModel:
         self.visual_w = v
 
         tw, tl = cfg["transformer_width"], cfg["transformer_layers"]
-        self._tb = _Blocks(sd, "transformer", tl, device)
+        self._tb = _Blocks(sd, "transformer", tl, device, precision)
         self._tt = {
             "emb": _to_dev(sd["token_embedding.weight"], device),
             "pos": _to_dev(sd["positional_embedding"], device),
@@ -150,8 +153,12 @@ class CLIPViTFM:
     """
 
     def __init__(self, model_name="ViT-B/16", size=224, state_dict=None, checkpoint=None, seed=0,
-                 device="cuda"):
+                 device="cuda", precision=None):
+        """precision: 'f32' (exact fp32 MFMA) or 'f16x3' (split-fp16 MFMA, fp32-class accuracy, ~2.4x
+        faster GEMMs); default from HYBRIDGL_PRECISION (ops.default_precision)."""
         _lib.load()
+        precision = precision or ops.default_precision()
+        ops.set_precision(precision)
         # model/backbone.py:16-21 (+ the ViT-L/14 extension of SURVEY.md note 2)
         if model_name in ("ViT-B/32", "ViT-B/16", "tiny"):
             self.last_layer, self.num_heads = 10, 12
@@ -166,7 +173,7 @@ class CLIPViTFM:
             state_dict = weights.clip_state_dict(model_name, seed)
         cfg = _infer_config(state_dict)
         self.model_name = model_name
-        self.model = _ClipModel(state_dict, cfg, device)
+        self.model = _ClipModel(state_dict, cfg, device, precision)
 
     # nn.Module-compatible no-ops used by Hybridgl_main.py:47-48
     def to(self, device):

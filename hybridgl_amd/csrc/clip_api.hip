@@ -23,12 +23,37 @@ int run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, c
               int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st) {
   const int M = B * S;
   const int hd = D / heads;
+  const long long sQKV = (long long)S * 3 * D;
+  if (hgl_use_x3(w.in_proj_w, D) && hgl_use_x3(w.out_proj_w, D) && hgl_use_x3(w.fc_w, D) && hgl_use_x3(w.proj_w, 4 * D) &&
+      (D % 256) == 0) {
+    // split-fp16 matrix-core path: activations feeding a GEMM exist only as fp16 (hi, lo) halves,
+    // which alias the fp32 scratch buffers (same byte size).
+    uint16_t* Hh = (uint16_t*)bf.H;
+    uint16_t* Hl = Hh + (size_t)M * D;
+    uint16_t* Fh = (uint16_t*)bf.F;
+    uint16_t* Fl = Fh + (size_t)M * 4 * D;
+    float* O = bf.F;  // attention output (fp32) borrows the MLP buffer until it is split
+    HGL_TRY(hgl_launch_layernorm_split(X, w.ln1_w, w.ln1_b, Hh, Hl, M, D, 1e-5f, st));
+    HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, w.in_proj_w, w.in_proj_b, nullptr, 0, bf.QKV, nullptr, nullptr, 3 * D, M,
+                                  3 * D, D, HGL_ACT_NONE, st));
+    HGL_TRY(hgl_launch_attention(bf.QKV, bf.QKV + D, bf.QKV + 2 * D, O, B, heads, S, S, hd, 3 * D, 3 * D, 3 * D, D, sQKV,
+                                 sQKV, sQKV, (long long)S * D, 1.0f / sqrtf((float)hd), mask_kind, keep, keep_b0,
+                                 keep_n, nullptr, nullptr, 0, 0, st));
+    HGL_TRY(hgl_launch_split_f16(O, 1.0f, Hh, Hl, (long long)M * D, st));
+    HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, w.out_proj_w, w.out_proj_b, X, D, X, nullptr, nullptr, D, M, D, D,
+                                  HGL_ACT_NONE, st));
+    HGL_TRY(hgl_launch_layernorm_split(X, w.ln2_w, w.ln2_b, Hh, Hl, M, D, 1e-5f, st));
+    HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, w.fc_w, w.fc_b, nullptr, 0, nullptr, Fh, Fl, 4 * D, M, 4 * D, D,
+                                  HGL_ACT_QUICKGELU, st));
+    HGL_TRY(hgl_launch_gemm_f16x3(Fh, Fl, 4 * D, w.proj_w, w.proj_b, X, D, X, nullptr, nullptr, D, M, D, 4 * D,
+                                  HGL_ACT_NONE, st));
+    return HGL_OK;
+  }
   HGL_TRY(hgl_launch_layernorm(X, w.ln1_w, w.ln1_b, bf.H, M, D, 1e-5f, st));
   HGL_TRY(hgl_launch_gemm(bf.H, w.in_proj_w, w.in_proj_b, nullptr, bf.QKV, M, 3 * D, D, D, D, 0,
                           3 * D, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
   HGL_TRY(hgl_launch_attention(bf.QKV, bf.QKV + D, bf.QKV + 2 * D, bf.H, B, heads, S, S, hd, 3 * D,
-                               3 * D, 3 * D, D, (long long)S * 3 * D, (long long)S * 3 * D,
-                               (long long)S * 3 * D, (long long)S * D, 1.0f / sqrtf((float)hd),
+                               3 * D, 3 * D, D, sQKV, sQKV, sQKV, (long long)S * D, 1.0f / sqrtf((float)hd),
                                mask_kind, keep, keep_b0, keep_n, nullptr, nullptr, 0, 0, st));
   HGL_TRY(hgl_launch_gemm(bf.H, w.out_proj_w, w.out_proj_b, X, X, M, D, D, D, D, D, D, 1, 0, 0, 0, 0,
                           HGL_ACT_NONE, st));

@@ -95,24 +95,29 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f32_kernel(GemmArgs g) {
   const int row0 = tile_m * BM, col0 = tile_n * BN;
 
   f32x4 pa[NLD], pw[NLD];
-  // branch-free staging loads: out-of-range rows / k are clamped to a valid address and zeroed
+  // Staging loads carry no arithmetic on the loaded registers (that would pull the wait for the
+  // loads in front of the MFMA section): out-of-range rows read a clamped (valid) row whose
+  // accumulators are never stored; only a partial last K tile is zero-masked, at store time.
   const int mclamp = g.M - 1, nclamp = g.N - 1, kclamp = g.K - 4;
+  const float *pa_p[NLD], *pw_p[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    pa_p[i] = A + (long long)min(row0 + ld_row + RSTEP * i, mclamp) * g.lda;
+    pw_p[i] = W + (long long)min(col0 + ld_row + RSTEP * i, nclamp) * g.ldw;
+  }
   auto load_tile = [&](int kt) {
-    const int k = kt * BK + ld_k4 * 4;
-    const bool kok = k < g.K;
-    const int kk = kok ? k : kclamp;
+    const int kk = min(kt * BK + ld_k4 * 4, kclamp);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int ra = row0 + ld_row + RSTEP * i;
-      const int rw = col0 + ld_row + RSTEP * i;
-      const f32x4 va = *(const f32x4*)(A + (long long)min(ra, mclamp) * g.lda + kk);
-      const f32x4 vw = *(const f32x4*)(W + (long long)min(rw, nclamp) * g.ldw + kk);
-      const bool oka = kok && ra < g.M, okw = kok && rw < g.N;
+      pa[i] = *(const f32x4*)(pa_p[i] + kk);
+      pw[i] = *(const f32x4*)(pw_p[i] + kk);
+    }
+  };
+  const bool k_partial = (g.K % BK) != 0;
+  auto mask_tail = [&](int kt) {  // only for the last, partial K tile
+    if (k_partial && kt * BK + ld_k4 * 4 >= g.K) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        pa[i][e] = oka ? va[e] : 0.f;
-        pw[i][e] = okw ? vw[e] : 0.f;
-      }
+      for (int i = 0; i < NLD; ++i) { pa[i] = f32x4{0, 0, 0, 0}; pw[i] = f32x4{0, 0, 0, 0}; }
     }
   };
   auto store_tile = [&](int buf) {
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f32_kernel(GemmArgs g) {
 
   const int nk = (g.K + BK - 1) / BK;
   load_tile(0);
+  mask_tail(0);
   store_tile(0);
   __syncthreads();
 
@@ -158,7 +164,10 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f32_kernel(GemmArgs g) {
       }
     }
     if (NBUF == 1) __syncthreads();  // single buffer: everyone done reading before it is overwritten
-    if (kt + 1 < nk) store_tile(NBUF == 2 ? (buf ^ 1) : 0);
+    if (kt + 1 < nk) {
+      if (kt + 2 == nk) mask_tail(kt + 1);
+      store_tile(NBUF == 2 ? (buf ^ 1) : 0);
+    }
     __syncthreads();
   }
 

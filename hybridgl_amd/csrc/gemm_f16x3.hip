@@ -1,0 +1,391 @@
+// fp32-accurate GEMM on the fp16 matrix cores: C = act(A @ W^T + bias) + R with every fp32 operand
+// split into two fp16 halves, x = hi + lo (hi = fp16(x), lo = fp16(x - hi)), and
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi        (the dropped a_lo*b_lo term is 2^-22 relative)
+// evaluated by three v_mfma_f32_32x32x16_f16 per tile step into ONE fp32 accumulator.  Each
+// fp16 x fp16 product is exact in fp32 and the representation error of hi+lo is 2^-23, so the
+// result carries ~2^-22 relative error per term -- within 4x of the fp32 MFMA path (gemm.hip) at
+// 16/3 = 5.3x its matrix-core rate.  Weights are scaled by a power of two before splitting so
+// that their lo halves stay in the fp16 normal range; the scale is undone in the epilogue.
+//
+// Same geometry as gemm.hip: 128x128 block tile, 4 waves x (2x2) 32x32 MFMA tiles, K-contiguous
+// operands staged global -> registers -> LDS with 16-byte accesses.  An LDS row holds the hi and
+// the lo halves of one operand row for BK = 64 (128 B + 128 B) plus one 16-byte pad, so the
+// ds_read_b128 fragment reads are conflict free (row stride 272 B = 17 x 16 B).
+#include "hgl_common.h"
+#include <unordered_map>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // 16-byte staging register (HIP's uint4 struct defeats SROA)
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int ROW_H = 2 * BK + 8;        // halfs per LDS row: hi | lo | pad
+constexpr int NTHREADS = 256;
+
+struct SplitW {
+  const _Float16 *hi, *lo;
+  int scale_log2;
+  int N, K;
+};
+std::unordered_map<const void*, SplitW> g_split;   // fp32 weight pointer -> its fp16 split
+int g_precision = HGL_PREC_F32;
+
+struct Args {
+  const _Float16 *Ah, *Al, *Wh, *Wl;
+  const float *bias, *R;
+  float* C;
+  _Float16 *Ch, *Cl;   // split output (when C == nullptr)
+  int M, N, K, lda, ldw, ldr, ldc;
+  float out_scale;
+  int tiles_m, tiles_n;
+};
+
+template <int ACT>
+__device__ __forceinline__ float act_apply(float x) {
+  if constexpr (ACT == HGL_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+  if constexpr (ACT == HGL_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  if constexpr (ACT == HGL_ACT_RELU) return x > 0.0f ? x : 0.0f;
+  return x;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f16x3_kernel(Args g) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];  // [A: BM rows | W: BN rows] x ROW_H
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GM = 8;
+  const int group = bid / (GM * g.tiles_n);
+  const int first_m = group * GM;
+  const int gm = min(g.tiles_m - first_m, GM);
+  const int rem = bid - group * GM * g.tiles_n;
+  const int tile_m = first_m + rem % gm;
+  const int tile_n = rem / gm;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
+  const int ld_c = t & 7;     // 16-byte chunk (8 halfs) within the 64-wide K tile
+  const int ld_row = t >> 3;  // 0..31 (+32*i)
+  const int mclamp = g.M - 1, nclamp = g.N - 1;
+
+  // Staging loads carry NO arithmetic on the loaded registers (anything that touches them would
+  // make the compiler wait for the loads before the MFMA section): out-of-range rows read a
+  // clamped (valid) row -- those accumulator rows/columns are never stored -- and K is a
+  // multiple of BK (checked by the launcher), so there is no K tail.
+  u32x4 pah[4], pal[4], pwh[4], pwl[4];
+  const _Float16 *pa_h[4], *pa_l[4], *pw_h[4], *pw_l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long oa = (long long)min(row0 + ld_row + 32 * i, mclamp) * g.lda + ld_c * 8;
+    const long long ow = (long long)min(col0 + ld_row + 32 * i, nclamp) * g.ldw + ld_c * 8;
+    pa_h[i] = g.Ah + oa; pa_l[i] = g.Al + oa; pw_h[i] = g.Wh + ow; pw_l[i] = g.Wl + ow;
+  }
+  auto load_tile = [&](int kt) {
+    const int k = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pah[i] = *(const u32x4*)(pa_h[i] + k); pal[i] = *(const u32x4*)(pa_l[i] + k);
+      pwh[i] = *(const u32x4*)(pw_h[i] + k); pwl[i] = *(const u32x4*)(pw_l[i] + k);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      _Float16* ar = smem + (ld_row + 32 * i) * ROW_H + ld_c * 8;
+      _Float16* wr = smem + (BM + ld_row + 32 * i) * ROW_H + ld_c * 8;
+      *(u32x4*)ar = pah[i]; *(u32x4*)(ar + BK) = pal[i];
+      *(u32x4*)wr = pwh[i]; *(u32x4*)(wr + BK) = pwl[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int nk = (g.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  const _Float16* As = smem + (wm * 64 + r) * ROW_H + 8 * h;
+  const _Float16* Ws = smem + (BM + wn * 64 + r) * ROW_H + 8 * h;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const f16x8 ah0 = *(const f16x8*)(As + 16 * s), al0 = *(const f16x8*)(As + BK + 16 * s);
+      const f16x8 ah1 = *(const f16x8*)(As + 32 * ROW_H + 16 * s), al1 = *(const f16x8*)(As + 32 * ROW_H + BK + 16 * s);
+      const f16x8 bh0 = *(const f16x8*)(Ws + 16 * s), bl0 = *(const f16x8*)(Ws + BK + 16 * s);
+      const f16x8 bh1 = *(const f16x8*)(Ws + 32 * ROW_H + 16 * s), bl1 = *(const f16x8*)(Ws + 32 * ROW_H + BK + 16 * s);
+      // small cross terms first, then the hi*hi term
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) store_tile();
+    __syncthreads();
+  }
+
+  // ---- epilogue (same element map as gemm.hip) ----
+  const bool full_tile = (row0 + BM <= g.M) && (col0 + BN <= g.N);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = col0 + wn * 64 + j * 32 + r;
+    const bool cok = col < g.N;
+    const int colc = cok ? col : nclamp;
+    const float bv = g.bias ? g.bias[colc] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbase = row0 + wm * 64 + i * 32 + 4 * h;
+      float rv[16];
+      if (g.R) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = g.R[(long long)min(rbase + (e & 3) + 8 * (e >> 2), mclamp) * g.ldr + colc];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rbase + (e & 3) + 8 * (e >> 2);
+        const float v = act_apply<ACT>(acc[i][j][e] * g.out_scale + bv) + rv[e];
+        if (full_tile || (cok && row < g.M)) {
+          const long long o = (long long)row * g.ldc + col;
+          if (g.C) {
+            g.C[o] = v;
+          } else {
+            const _Float16 hi = (_Float16)v;
+            g.Ch[o] = hi;
+            g.Cl[o] = (_Float16)(v - (float)hi);
+          }
+        }
+      }
+    }
+  }
+}
+
+// x (fp32) * 2^scale_log2 -> hi, lo fp16
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, float scale,
+                                                        _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                        long long n4) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = ((const f32x4*)x)[i];
+    f16x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float s = v[e] * scale;
+      a[e] = (_Float16)s;
+      b[e] = (_Float16)(s - (float)a[e]);
+    }
+    ((f16x4*)hi)[i] = a;
+    ((f16x4*)lo)[i] = b;
+  }
+}
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// LayerNorm writing the split form directly (one wave per row, D % 256 == 0)
+template <int VEC>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, _Float16* __restrict__ hi,
+                                                              _Float16* __restrict__ lo, int rows, float eps) {
+  constexpr int D = VEC * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const f32x4* xr = (const f32x4*)(x + (long long)row * D);
+  f32x4 v[VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    v[i] = xr[lane + 64 * i];
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wsum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[i][e] - mean;
+      q += d * d;
+    }
+  const float rstd = rsqrtf(wsum(q) * (1.0f / D) + eps);
+  f16x4* hr = (f16x4*)(hi + (long long)row * D);
+  f16x4* lr = (f16x4*)(lo + (long long)row * D);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const f32x4 wv = ((const f32x4*)w)[lane + 64 * i];
+    const f32x4 bv = ((const f32x4*)b)[lane + 64 * i];
+    f16x4 a, c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float o = (v[i][e] - mean) * rstd * wv[e] + bv[e];
+      a[e] = (_Float16)o;
+      c[e] = (_Float16)(o - (float)a[e]);
+    }
+    hr[lane + 64 * i] = a;
+    lr[lane + 64 * i] = c;
+  }
+}
+
+// window partition (image_encoder.py:243-266) writing the split form: rows of padded windows
+__global__ __launch_bounds__(256) void win_partition_split_kernel(const float* __restrict__ H, int g, int ws, int nw,
+                                                                  int D4, _Float16* __restrict__ hi,
+                                                                  _Float16* __restrict__ lo, long long total4) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total4) return;
+  const int d = (int)(i % D4);
+  const long long row = i / D4;
+  const int p = (int)(row % (ws * ws)), win = (int)(row / (ws * ws));
+  const int y = (win / nw) * ws + p / ws, x = (win % nw) * ws + p % ws;
+  f32x4 v = {0, 0, 0, 0};
+  if (y < g && x < g) v = ((const f32x4*)H)[((long long)y * g + x) * D4 + d];
+  f16x4 a, b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = (_Float16)v[e];
+    b[e] = (_Float16)(v[e] - (float)a[e]);
+  }
+  ((f16x4*)hi)[i] = a;
+  ((f16x4*)lo)[i] = b;
+}
+
+}  // namespace
+
+int hgl_launch_win_partition_split(const float* H, int g, int ws, int nw, int D, void* hi, void* lo, hipStream_t st) {
+  const long long total4 = (long long)nw * nw * ws * ws * (D / 4);
+  hipLaunchKernelGGL(win_partition_split_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, H, g, ws,
+                     nw, D / 4, (_Float16*)hi, (_Float16*)lo, total4);
+  return hgl_check_launch("win_partition_split");
+}
+
+int hgl_precision() { return g_precision; }
+
+bool hgl_has_split_weight(const float* W) { return g_split.find((const void*)W) != g_split.end(); }
+
+int hgl_launch_split_f16(const float* x, float scale, void* hi, void* lo, long long n, hipStream_t st) {
+  HGL_REQUIRE(x && hi && lo && n > 0 && (n & 3) == 0, "split_f16: bad arguments (n %% 4 != 0?)");
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, scale, (_Float16*)hi, (_Float16*)lo, n / 4);
+  return hgl_check_launch("split_f16");
+}
+
+int hgl_launch_layernorm_split(const float* x, const float* w, const float* b, void* hi, void* lo, int rows, int D,
+                               float eps, hipStream_t st) {
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  _Float16 *h = (_Float16*)hi, *l = (_Float16*)lo;
+  switch (D) {
+    case 256: hipLaunchKernelGGL(layernorm_split_kernel<1>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps); break;
+    case 512: hipLaunchKernelGGL(layernorm_split_kernel<2>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps); break;
+    case 768: hipLaunchKernelGGL(layernorm_split_kernel<3>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps); break;
+    case 1024: hipLaunchKernelGGL(layernorm_split_kernel<4>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps); break;
+    case 1280: hipLaunchKernelGGL(layernorm_split_kernel<5>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps); break;
+    default: hgl_set_error("layernorm_split: unsupported D=%d", D); return HGL_EINVAL;
+  }
+  return hgl_check_launch("layernorm_split");
+}
+
+// A given as split halves (Ah, Al) [M,K] lda (in halfs); W looked up in the registry by its fp32 pointer.
+// Output: C fp32 (ldc) or, when C == nullptr, the split pair (Ch, Cl).
+int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* W32, const float* bias, const float* R,
+                          int ldr, float* C, void* Ch, void* Cl, int ldc, int M, int N, int K, int act, hipStream_t st) {
+  auto it = g_split.find((const void*)W32);
+  HGL_REQUIRE(it != g_split.end(), "gemm_f16x3: weight %p has no registered fp16 split", (const void*)W32);
+  const SplitW& sw = it->second;
+  HGL_REQUIRE(sw.N == N && sw.K == K, "gemm_f16x3: registered split is [%d,%d], GEMM wants [%d,%d]", sw.N, sw.K, N, K);
+  HGL_REQUIRE(Ah && Al && (C || (Ch && Cl)) && M > 0 && N > 0 && K > 0, "gemm_f16x3: bad arguments");
+  HGL_REQUIRE((K % BK) == 0 && (lda & 7) == 0, "gemm_f16x3: K must be a multiple of %d and lda of 8 (K=%d lda=%d)", BK, K, lda);
+  Args g;
+  g.Ah = (const _Float16*)Ah; g.Al = (const _Float16*)Al; g.Wh = sw.hi; g.Wl = sw.lo;
+  g.bias = bias; g.R = R; g.C = C; g.Ch = (_Float16*)Ch; g.Cl = (_Float16*)Cl;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldr = ldr; g.ldc = ldc;
+  g.out_scale = ldexpf(1.0f, -sw.scale_log2);
+  g.tiles_m = (M + BM - 1) / BM;
+  g.tiles_n = (N + BN - 1) / BN;
+  const long long nwg = (long long)g.tiles_m * g.tiles_n;
+  HGL_REQUIRE(nwg < (1ll << 31), "gemm_f16x3: grid too large");
+  const size_t lds = (size_t)(BM + BN) * ROW_H * sizeof(_Float16);
+  HglProfScope prof(HGL_PROF_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
+#define HGL_X3_LAUNCH(ACT_)                                                                                   \
+  do {                                                                                                        \
+    static bool set_ = false;                                                                                 \
+    if (!set_) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)gemm_f16x3_kernel<ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      set_ = true;                                                                                            \
+    }                                                                                                         \
+    hipLaunchKernelGGL(gemm_f16x3_kernel<ACT_>, dim3((unsigned)nwg), dim3(NTHREADS), lds, st, g);             \
+  } while (0)
+  switch (act) {
+    case HGL_ACT_QUICKGELU: HGL_X3_LAUNCH(HGL_ACT_QUICKGELU); break;
+    case HGL_ACT_GELU: HGL_X3_LAUNCH(HGL_ACT_GELU); break;
+    case HGL_ACT_RELU: HGL_X3_LAUNCH(HGL_ACT_RELU); break;
+    default: HGL_X3_LAUNCH(HGL_ACT_NONE); break;
+  }
+  return hgl_check_launch("gemm_f16x3");
+}
+
+extern "C" {
+
+int hgl_set_precision(int mode) {
+  HGL_REQUIRE(mode == HGL_PREC_F32 || mode == HGL_PREC_F16X3, "set_precision: unknown mode %d", mode);
+  g_precision = mode;
+  return HGL_OK;
+}
+
+int hgl_get_precision(void) { return g_precision; }
+
+int hgl_register_split_weight(const float* w_fp32, int N, int K, int scale_log2, void* hi, void* lo, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(w_fp32 && hi && lo && N > 0 && K > 0 && (K & 7) == 0, "register_split_weight: bad arguments (K %% 8)");
+  HGL_REQUIRE(scale_log2 >= -24 && scale_log2 <= 24, "register_split_weight: scale_log2 out of range");
+  HGL_TRY(hgl_launch_split_f16(w_fp32, ldexpf(1.0f, scale_log2), hi, lo, (long long)N * K, (hipStream_t)stream));
+  g_split[(const void*)w_fp32] = SplitW{(const _Float16*)hi, (const _Float16*)lo, scale_log2, N, K};
+  return HGL_OK;
+}
+
+int hgl_unregister_split_weight(const float* w_fp32) {
+  g_split.erase((const void*)w_fp32);
+  return HGL_OK;
+}
+
+// C = act(A @ W^T + bias) + R through the split-fp16 path with A split on the fly into `scratch`
+// (>= M*K*4 bytes).  Exported for the per-kernel parity tests and micro-benchmarks.
+int hgl_gemm_f16x3(const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K,
+                   int act, void* scratch, size_t scratch_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(A && W && C && scratch, "gemm_f16x3: null argument");
+  HGL_REQUIRE(scratch_bytes >= (size_t)M * K * 4, "gemm_f16x3: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  _Float16* ah = (_Float16*)scratch;
+  _Float16* al = ah + (size_t)M * K;
+  HGL_TRY(hgl_launch_split_f16(A, 1.0f, ah, al, (long long)M * K, st));
+  return hgl_launch_gemm_f16x3(ah, al, K, W, bias, R, N, C, nullptr, nullptr, N, M, N, K, act, st);
+}
+
+}  // extern "C"

@@ -67,14 +67,33 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
   const int L = b.rel_len;
   HGL_REQUIRE(L == 2 * size - 1, "sam_encode: rel_pos length %d does not match attention size %d", L, size);
 
-  HGL_TRY(hgl_launch_layernorm(p.X, b.norm1_w, b.norm1_b, p.H, T, D, 1e-6f, st));
-  const float* A = p.H;
-  if (ws > 0) {
-    HGL_TRY(hgl_launch_win_partition(p.H, g, ws, nw, D, p.Hw, st));
-    A = p.Hw;
+  const bool x3 = hgl_use_x3(b.qkv_w, D) && hgl_use_x3(b.proj_w, D) && hgl_use_x3(b.lin1_w, D) &&
+                  hgl_use_x3(b.lin2_w, 4 * D) && (D % 256) == 0;
+  uint16_t* Ah = (uint16_t*)p.Hw;                   // split GEMM input (aliases the window buffer)
+  uint16_t* Al = Ah + (size_t)M * D;
+  uint16_t* Hh = (uint16_t*)p.H;
+  uint16_t* Hl = Hh + (size_t)T * D;
+  uint16_t* Fh = (uint16_t*)p.F;
+  uint16_t* Fl = Fh + (size_t)T * 4 * D;
+  if (x3) {
+    if (ws > 0) {
+      HGL_TRY(hgl_launch_layernorm(p.X, b.norm1_w, b.norm1_b, p.H, T, D, 1e-6f, st));
+      HGL_TRY(hgl_launch_win_partition_split(p.H, g, ws, nw, D, Ah, Al, st));
+    } else {
+      HGL_TRY(hgl_launch_layernorm_split(p.X, b.norm1_w, b.norm1_b, Ah, Al, T, D, 1e-6f, st));
+    }
+    HGL_TRY(hgl_launch_gemm_f16x3(Ah, Al, D, b.qkv_w, b.qkv_b, nullptr, 0, p.QKV, nullptr, nullptr, 3 * D, M, 3 * D, D,
+                                  HGL_ACT_NONE, st));
+  } else {
+    HGL_TRY(hgl_launch_layernorm(p.X, b.norm1_w, b.norm1_b, p.H, T, D, 1e-6f, st));
+    const float* A = p.H;
+    if (ws > 0) {
+      HGL_TRY(hgl_launch_win_partition(p.H, g, ws, nw, D, p.Hw, st));
+      A = p.Hw;
+    }
+    HGL_TRY(hgl_launch_gemm(A, b.qkv_w, b.qkv_b, nullptr, p.QKV, M, 3 * D, D, D, D, 0, 3 * D, 1, 0, 0, 0, 0,
+                            HGL_ACT_NONE, st));
   }
-  HGL_TRY(hgl_launch_gemm(A, b.qkv_w, b.qkv_b, nullptr, p.QKV, M, 3 * D, D, D, D, 0, 3 * D, 1, 0, 0, 0, 0,
-                          HGL_ACT_NONE, st));
   // decomposed rel-pos: T[h][row][r] = q_h[row] . rel_pos[r] for every r, then gathered per (q,k)
   HGL_TRY(hgl_launch_gemm(p.QKV, b.rel_pos_h, nullptr, nullptr, p.Th, M, L, hd, 3 * D, hd, 0, L, heads, hd, 0,
                           0, (long long)M * L, HGL_ACT_NONE, st));
@@ -86,6 +105,23 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
                                (long long)S * 3 * D, (long long)S * 3 * D, (long long)S * 3 * D,
                                (long long)S * D, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, p.relh,
                                p.relw, size, size, st));
+  if (x3) {
+    HGL_TRY(hgl_launch_split_f16(p.O, 1.0f, Ah, Al, (long long)M * D, st));
+    if (ws > 0) {
+      HGL_TRY(hgl_launch_gemm_f16x3(Ah, Al, D, b.proj_w, b.proj_b, nullptr, 0, p.P, nullptr, nullptr, D, M, D, D,
+                                    HGL_ACT_NONE, st));
+      HGL_TRY(hgl_launch_win_unpartition_add(p.X, g, ws, nw, D, p.P, st));
+    } else {
+      HGL_TRY(hgl_launch_gemm_f16x3(Ah, Al, D, b.proj_w, b.proj_b, p.X, D, p.X, nullptr, nullptr, D, T, D, D,
+                                    HGL_ACT_NONE, st));
+    }
+    HGL_TRY(hgl_launch_layernorm_split(p.X, b.norm2_w, b.norm2_b, Hh, Hl, T, D, 1e-6f, st));
+    HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, b.lin1_w, b.lin1_b, nullptr, 0, nullptr, Fh, Fl, 4 * D, T, 4 * D, D,
+                                  HGL_ACT_GELU, st));
+    HGL_TRY(hgl_launch_gemm_f16x3(Fh, Fl, 4 * D, b.lin2_w, b.lin2_b, p.X, D, p.X, nullptr, nullptr, D, T, D, 4 * D,
+                                  HGL_ACT_NONE, st));
+    return HGL_OK;
+  }
   if (ws > 0) {
     HGL_TRY(hgl_launch_gemm(p.O, b.proj_w, b.proj_b, nullptr, p.P, M, D, D, D, D, 0, D, 1, 0, 0, 0, 0,
                             HGL_ACT_NONE, st));

@@ -40,8 +40,11 @@ class Sam:
     mask_threshold = 0.0  # modeling/sam.py:19
     image_format = "RGB"
 
-    def __init__(self, state_dict, cfg, device="cuda"):
+    def __init__(self, state_dict, cfg, device="cuda", precision=None):
         _lib.load()
+        precision = precision or ops.default_precision()
+        ops.set_precision(precision)
+        self.precision = precision
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         self._t = []  # keep every device tensor alive
@@ -68,6 +71,8 @@ class Sam:
                          ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"), ("lin1_w", "mlp.lin1.weight"),
                          ("lin1_b", "mlp.lin1.bias"), ("lin2_w", "mlp.lin2.weight"), ("lin2_b", "mlp.lin2.bias")]:
                 setattr(b, f, t(sd[f"{p}.{k}"]))
+                if precision == "f16x3" and f in ("qkv_w", "proj_w", "lin1_w", "lin2_w"):
+                    ops.register_split_weight(self._t[-1])
         enc = HglSamEncoderW()
         enc.embed_dim, enc.depth, enc.heads, enc.img_size, enc.patch, enc.out_chans = D, L, H, S, ps, Cc
         enc.patch_w = t(np.asarray(sd[f"{e}.patch_embed.proj.weight"]).reshape(D, -1))
@@ -204,13 +209,13 @@ def nms(boxes_xyxy, scores, keep, iou_threshold):
     return idx, n
 
 
-def _build(cfg_name, checkpoint=None, state_dict=None, seed=0, device="cuda"):
+def _build(cfg_name, checkpoint=None, state_dict=None, seed=0, device="cuda", precision=None):
     checkpoint = checkpoint or os.environ.get("HYBRIDGL_SAM_CHECKPOINT")
     if state_dict is None and checkpoint:
         state_dict = load_sam_state_dict(checkpoint)
     if state_dict is None:
         state_dict = weights.sam_state_dict(cfg_name, seed)
-    return Sam(state_dict, weights.SAM_CONFIGS[cfg_name], device)
+    return Sam(state_dict, weights.SAM_CONFIGS[cfg_name], device, precision)
 
 
 def build_sam_vit_h(checkpoint=None, **kw):

@@ -65,6 +65,25 @@ int hgl_device_count(void);
 int hgl_prof_enable(int on);
 int hgl_prof_read(int cls, long long* launches, double* ms, double* flops, double* bytes);
 
+/* GEMM precision mode of the encoders.  HGL_PREC_F32: v_mfma_f32_32x32x2_f32 (exact fp32 products).
+ * HGL_PREC_F16X3: every fp32 operand split into fp16 hi+lo, three v_mfma_f32_32x32x16_f16 per
+ * step into one fp32 accumulator (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi; ~2^-22 relative error per
+ * term, i.e. fp32-class accuracy at 16/3 of the fp32 matrix rate).  It applies to GEMMs whose
+ * weight has been registered with hgl_register_split_weight; all others stay on the fp32 path. */
+#define HGL_PREC_F32 0
+#define HGL_PREC_F16X3 1
+int hgl_set_precision(int mode);
+int hgl_get_precision(void);
+/* Splits w_fp32 [N,K] * 2^scale_log2 into caller-owned fp16 arrays hi, lo ([N,K] each) and
+ * records them under the fp32 pointer (scale_log2 keeps the lo half in the fp16 normal range;
+ * choose max|w| * 2^scale_log2 <= 2^14). */
+int hgl_register_split_weight(const float* w_fp32, int N, int K, int scale_log2, void* hi, void* lo, void* stream);
+int hgl_unregister_split_weight(const float* w_fp32);
+/* hgl_gemm_f32 semantics (no batch, dense leading dims) through the split path; A is split into
+ * `scratch` (>= M*K*4 bytes) first.  W must be registered. */
+int hgl_gemm_f16x3(const float* A, const float* W, const float* bias, const float* R, float* C,
+                   int M, int N, int K, int act, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Primitive operators (building blocks; exported so that parity tests can
  * pin each kernel against the oracle in isolation).

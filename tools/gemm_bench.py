@@ -51,7 +51,13 @@ def main():
         out = torch.empty(M, N, device=dev)
         ms = bench(lambda: ops.gemm(A, W, b, R, act, out=out))
         tf = 2.0 * M * N * K / ms / 1e9
-        print(f"gemm {name:14s} M={M:7d} N={N:5d} K={K:5d} {ms:8.3f} ms {tf:7.1f} TF/s")
+        line = f"gemm {name:14s} M={M:7d} N={N:5d} K={K:5d} f32 {ms:8.3f} ms {tf:7.1f} TF/s"
+        if K % 64 == 0:
+            ms3 = bench(lambda: ops.gemm_f16x3(A, W, b, R, act, out=out))
+            ref = ops.gemm(A, W, b, R, act)
+            err = float((ops.gemm_f16x3(A, W, b, R, act) - ref).abs().max() / ref.abs().max())
+            line += f" | f16x3 {ms3:8.3f} ms {2.0 * M * N * K / ms3 / 1e9:7.1f} TF/s (incl. A split) relerr {err:.1e}"
+        print(line)
     for name, B, H, S, hd in [("clip", 128, 12, 197, 64), ("sam win", 25, 16, 196, 80), ("sam glob", 1, 16, 4096, 80),
                               ("text", 9, 8, 77, 64)]:
         q, k, v = (torch.randn(B, S, H * hd, device=dev) for _ in range(3))
