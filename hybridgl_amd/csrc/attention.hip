@@ -126,12 +126,30 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(AttnArgs a) {
           s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[c][j], s, 0, 0, 0);
       }
       // s[e] = S^T[key = kbase + (e&3) + 8*(e>>2) + 4*h][query qi]
+      if (relh) {
+        if ((a.kw & 31) == 0) {
+          // a 32-key tile lies inside one key row: one rel_h value, rel_w as four aligned float4
+          const float rh = relh[kbase / a.kw];
+          const float* rw = relw + (kbase % a.kw) + 4 * h;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 w4 = *(const f32x4*)(rw + 8 * g4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[4 * g4 + i] += rh + w4[i];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (kg < a.Sk) s[e] += relh[kg / a.kw] + relw[kg % a.kw];
+          }
+        }
+      }
       float mx = NEG_INF;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
         float sv = s[e];
-        if (relh && kg < a.Sk) sv += relh[kg / a.kw] + relw[kg % a.kw];
         bool masked = kg >= a.Sk;
         if (a.mask_kind == HGL_MASK_CAUSAL) masked |= kg > qi;
         if (keep_row && qi == 0 && kg >= 1 && kg < a.Sk) masked |= keep_row[kg - 1] == 0;

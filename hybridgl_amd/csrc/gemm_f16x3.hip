@@ -331,7 +331,7 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
   const long long nwg = (long long)g.tiles_m * g.tiles_n;
   HGL_REQUIRE(nwg < (1ll << 31), "gemm_f16x3: grid too large");
   const size_t lds = (size_t)(BM + BN) * ROW_H * sizeof(_Float16);
-  HglProfScope prof(HGL_PROF_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
+  HglProfScope prof(HGL_PROF_GEMM_X3, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
 #define HGL_X3_LAUNCH(ACT_)                                                                                   \
   do {                                                                                                        \
     static bool set_ = false;                                                                                 \

@@ -169,21 +169,28 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(const float* __restric
   }
 }
 
-// one thread per mask: fixed-order reduction over blocks (deterministic), final formula
+// one wave per mask: lanes stride over the per-wave partials in a fixed pattern, then a fixed-order
+// butterfly -- deterministic run to run
 __global__ __launch_bounds__(256) void coherence_final_kernel(const double* __restrict__ part_sum,
                                                               const unsigned* __restrict__ part_cnt,
                                                               const double* __restrict__ part_tot,
                                                               int nblk, int N, long long HW,
                                                               float black, float* __restrict__ score) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   double tot = 0.0, s = 0.0;
   unsigned long long c = 0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = lane; b < nblk; b += 64) {
     tot += part_tot[b];
     s += part_sum[(long long)b * N + n];
     c += part_cnt[(long long)b * N + n];
   }
+  tot = wave_sum_d(tot);
+  s = wave_sum_d(s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if (lane != 0) return;
   const double mean = tot / (double)HW;
   const double in_sum = s / mean, out_sum = (tot - s) / mean;
   // (imgattn*(2-black)*m/m.sum()).sum() - (imgattn*black*(1-m)/(1-m).sum()).sum()
@@ -240,7 +247,22 @@ __global__ __launch_bounds__(256) void iou_select_kernel(const uint8_t* __restri
                                                          unsigned long long* __restrict__ out) {
   const uint8_t* p = masks + (long long)idx[which] * n;
   unsigned I = 0, U = 0;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+  const bool al = ((((uintptr_t)p) | ((uintptr_t)g)) & 15) == 0;
+  const long long n16 = al ? n / 16 : 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n16;
+       i += (long long)gridDim.x * blockDim.x) {
+    const uint4 a = ((const uint4*)p)[i], b = ((const uint4*)g)[i];
+    const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned x = aw[w], y = bw[w];
+      x |= x >> 4; x |= x >> 2; x |= x >> 1; x &= 0x01010101u;
+      y |= y >> 4; y |= y >> 2; y |= y >> 1; y &= 0x01010101u;
+      I += __popc(x & y);
+      U += __popc(x | y);
+    }
+  }
+  for (long long i = n16 * 16 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     const bool a = p[i] != 0, b = g[i] != 0;
     I += (a && b);
@@ -523,7 +545,7 @@ int hgl_coherence_scores(const float* imgattn, const uint8_t* masks, int N, int 
   hipLaunchKernelGGL(init_stats_kernel, dim3(1), dim3(1), 0, st, stats);
   hipLaunchKernelGGL(minmax_kernel, dim3(256), dim3(256), 0, st, imgattn, HW, stats);
   hipLaunchKernelGGL(masked_pool_kernel, dim3(coh_nblk(H, W), (N + MASK_GROUP - 1) / MASK_GROUP), dim3(256), 0, st, imgattn, masks, N, H, W, dirflag, stats, psum, pcnt, ptot);
-  hipLaunchKernelGGL(coherence_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, psum, pcnt, ptot, nb, N, HW, black, score);
+  hipLaunchKernelGGL(coherence_final_kernel, dim3((N + 3) / 4), dim3(256), 0, st, psum, pcnt, ptot, nb, N, HW, black, score);
   return hgl_check_launch("coherence_scores");
 }
 
@@ -551,7 +573,8 @@ int hgl_iou_select(const uint8_t* masks, const int32_t* idx, int which, const ui
     hgl_set_error("iou_select: memset failed");
     return HGL_ELAUNCH;
   }
-  long long blocks = (HW + 255) / 256;
+  long long blocks = (HW / 16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(iou_select_kernel, dim3((unsigned)blocks), dim3(256), 0, st, masks, (const int*)idx, which, gt, HW, (unsigned long long*)out_IU);
   return hgl_check_launch("iou_select");
