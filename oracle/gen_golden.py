@@ -356,6 +356,32 @@ def gen_sam_tiny():
     np.savez_compressed(os.path.join(GOLD, "sam_tiny.npz"), **out)
 
 
+TOKENIZER_STRINGS = [
+    "the cat on left", "a photo of the bigger elephant", "Person in BLUE shirt, holding an umbrella!",
+    "second banana from right", "woman's red hat isn't there", "they're we've i'm you'll he'd",
+    "3 zebras   and 42\tgiraffes", "caf\u00e9 na\u00efve \u00fcber", "tom &amp; jerry &lt;3", "  leading and trailing  ",
+    "the man standing inside the doorway near the larger window closest to the camera", "x", "",
+    "emoji \U0001f600 ok", "under_score-dash/slash",
+]
+
+
+def gen_tokenizer():
+    """SimpleTokenizer / clip.tokenize of the reference on (1) our tiny synthetic merges file and
+    (2) the real merges file that sits in the reference tree (token ids are data, the file is not copied)."""
+    st = _load("ref_simple_tokenizer", os.path.join(REF, "third_party/modified_CLIP/clip/simple_tokenizer.py"))
+    out = {"strings": np.array(TOKENIZER_STRINGS)}
+    tiny = st.SimpleTokenizer(os.path.join(GOLD, "tiny_bpe_vocab.txt.gz"))
+    real = st.SimpleTokenizer(os.path.join(REF, "third_party/modified_CLIP/clip/bpe_simple_vocab_16e6.txt.gz"))
+    for tag, tk in (("tiny", tiny), ("real", real)):
+        ids = [tk.encode(s) for s in TOKENIZER_STRINGS]
+        out[f"{tag}_len"] = np.array([len(i) for i in ids], dtype=np.int64)
+        out[f"{tag}_ids"] = np.array(sum(ids, []), dtype=np.int64)
+        out[f"{tag}_sot_eot"] = np.array([tk.encoder["<|startoftext|>"], tk.encoder["<|endoftext|>"]], dtype=np.int64)
+        out[f"{tag}_decoded0"] = np.array(tk.decode(ids[2]))
+    print("tokenizer:", out["real_ids"][:6], out["real_sot_eot"], out["tiny_sot_eot"])
+    np.savez_compressed(os.path.join(GOLD, "tokenizer.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -378,6 +404,8 @@ if __name__ == "__main__":
         gen_scoring()
     if want("resize"):
         gen_resize()
+    if want("tokenizer"):
+        gen_tokenizer()
     if want("sam_tiny"):
         install_sam_stubs()
         gen_sam_tiny()
