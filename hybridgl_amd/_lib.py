@@ -131,6 +131,9 @@ PROTOTYPES = {
     "hgl_sam_postprocess": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _VP, _VP, _VP, _VP, _VP,
                                  _VP, _SZ, _VP]),
     "hgl_nms": (_I, [_VP, _VP, _VP, _I, _F, _VP, _VP, _VP]),
+    "hgl_remove_small_regions_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "hgl_remove_small_regions": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "hgl_mask_boxes": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "hgl_gather_masks": (_I, [_VP, _VP, _VP, _I, _LL, _VP, _VP]),
 }
 

@@ -293,96 +293,64 @@ class SamAutomaticMaskGenerator:
         order, n = nms(boxes, iou, keep, self.box_nms_thresh)
         return masks, boxes, iou, stab, order, n, np.repeat(pts, 3, axis=0)
 
-    def generate(self, image):
-        """automatic_mask_generator.py:137-195 -> list of records (binary masks)."""
-        masks, boxes, iou, stab, order, n, points = self.propose(image)
+    def generate_device(self, image, resized=None):
+        """Whole `generate` on the device.  Returns (masks [n,H,W] uint8, boxes_xywh [n,4] int64,
+        iou [n], stability [n], cand [n] int64 indices into the 3*points candidates), all device
+        tensors, in the reference's output order.  One host sync (the proposal count)."""
+        masks, boxes, iou, stab, order, n, points = self.propose(image, resized)
         n = int(n.item())                       # the one host sync of the proposal stage
         idx = order[:n].long()
-        sel_masks = masks.index_select(0, idx).bool().cpu().numpy()
-        sel_boxes = boxes.index_select(0, idx).cpu().numpy().astype(np.int64)
-        sel_iou = iou.index_select(0, idx).cpu().numpy()
-        sel_stab = stab.index_select(0, idx).cpu().numpy()
-        idx_np = idx.cpu().numpy()
+        m = masks.index_select(0, idx).contiguous()
+        bx = boxes.index_select(0, idx).contiguous()
         if self.min_mask_region_area > 0 and n > 0:
-            sel_masks, sel_boxes, kept = postprocess_small_regions(
-                sel_masks, sel_boxes, self.min_mask_region_area, max(self.box_nms_thresh, self.crop_nms_thresh))
-            sel_iou, sel_stab, idx_np = sel_iou[kept], sel_stab[kept], idx_np[kept]
+            # postprocess_small_regions (automatic_mask_generator.py:324-372) on the device
+            m1, c1 = remove_small_regions(m, self.min_mask_region_area, "holes")
+            m2, c2 = remove_small_regions(m1, self.min_mask_region_area, "islands")
+            unchanged = ((c1 | c2) == 0).to(torch.float32)           # score 1 for untouched masks
+            nb = mask_boxes(m2)
+            keep_all = torch.ones(n, dtype=torch.uint8, device=m.device)
+            order2, n2 = nms(nb, unchanged, keep_all, max(self.box_nms_thresh, self.crop_nms_thresh))
+            k = order2[: int(n2.item())].long()
+            m, bx, idx = m2.index_select(0, k), nb.index_select(0, k), idx.index_select(0, k)
+        b = bx.long()
+        xywh = torch.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1) if n > 0 else b
+        return m, xywh, iou.index_select(0, idx), stab.index_select(0, idx), idx
+
+    def generate(self, image):
+        """automatic_mask_generator.py:137-195 -> list of records (binary masks)."""
+        m, xywh, iou, stab, idx = self.generate_device(image)
+        masks = m.bool().cpu().numpy()
+        xywh, iou, stab, idx = xywh.cpu().numpy(), iou.cpu().numpy(), stab.cpu().numpy(), idx.cpu().numpy()
         H, W = image.shape[:2]
+        points = np.repeat(self.point_grids[0] * np.array([[W, H]], dtype=np.float64), 3, axis=0)
         out = []
-        for i in range(len(sel_masks)):
-            x0, y0, x1, y1 = (int(v) for v in sel_boxes[i])
-            out.append({"segmentation": sel_masks[i], "area": int(sel_masks[i].sum()),
-                        "bbox": [x0, y0, x1 - x0, y1 - y0], "predicted_iou": float(sel_iou[i]),
-                        "point_coords": [points[idx_np[i]].tolist()], "stability_score": float(sel_stab[i]),
+        for i in range(len(masks)):
+            out.append({"segmentation": masks[i], "area": int(masks[i].sum()),
+                        "bbox": [int(v) for v in xywh[i]], "predicted_iou": float(iou[i]),
+                        "point_coords": [points[idx[i]].tolist()], "stability_score": float(stab[i]),
                         "crop_box": [0, 0, W, H]})
         return out
 
 
-# ---- host side of postprocess_small_regions (automatic_mask_generator.py:324-372) -----------------
-def _label8(mask):
-    from scipy import ndimage
-    return ndimage.label(mask, structure=np.ones((3, 3), dtype=np.int32))
+def remove_small_regions(masks, area_thresh, mode):
+    """utils/amg.py:267-291 for a batch [n,H,W] uint8 on the device -> (new masks, changed [n] uint8)."""
+    lib = _lib.load()
+    n, H, W = masks.shape
+    out = torch.empty_like(masks)
+    changed = torch.empty((n,), dtype=torch.uint8, device=masks.device)
+    need = lib.hgl_remove_small_regions_workspace_bytes(n, H, W)
+    ws = ops.workspace(need, masks.device, "sam_ccl")
+    check(lib.hgl_remove_small_regions(ops._dev(masks, torch.uint8, "masks"), n, H, W, int(area_thresh),
+                                       1 if mode == "holes" else 0, out.data_ptr(), changed.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), ops._stream()), "hgl_remove_small_regions")
+    return out, changed
 
 
-def remove_small_regions(mask, area_thresh, mode):
-    """utils/amg.py:267-291 (connected components on the host, as the reference does with OpenCV)."""
-    correct_holes = mode == "holes"
-    working = correct_holes ^ mask
-    regions, n = _label8(working)
-    sizes = np.bincount(regions.ravel(), minlength=n + 1)[1:]
-    small = [i + 1 for i, s in enumerate(sizes) if s < area_thresh]
-    if not small:
-        return mask, False
-    fill = [0] + small
-    if not correct_holes:
-        fill = [i for i in range(n + 1) if i not in fill]
-        if not fill:
-            fill = [int(np.argmax(sizes)) + 1]
-    return np.isin(regions, fill), True
-
-
-def _mask_boxes(masks):
-    out = np.zeros((len(masks), 4), dtype=np.int64)
-    for i, m in enumerate(masks):
-        ys, xs = np.nonzero(m)
-        if len(ys):
-            out[i] = [xs.min(), ys.min(), xs.max(), ys.max()]
-    return out
-
-
-def _nms_host(boxes, scores, thr):
-    b = boxes.astype(np.float32)
-    order = np.argsort(-scores, kind="stable")
-    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    alive = np.ones(len(b), bool)
-    keep = []
-    for i in order:
-        if not alive[i]:
-            continue
-        keep.append(i)
-        lt = np.maximum(b[i, :2], b[:, :2])
-        rb = np.minimum(b[i, 2:], b[:, 2:])
-        wh = np.clip(rb - lt, 0, None)
-        inter = wh[:, 0] * wh[:, 1]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            iou = inter / (area[i] + area - inter)
-        alive &= ~(iou > thr)
-        alive[i] = False
-    return np.array(keep, dtype=np.int64)
-
-
-def postprocess_small_regions(masks, boxes, min_area, nms_thresh):
-    new, scores = [], []
-    for m in masks:
-        m1, c1 = remove_small_regions(m, min_area, "holes")
-        m2, c2 = remove_small_regions(m1, min_area, "islands")
-        new.append(m2)
-        scores.append(float(not (c1 or c2)))
-    new = np.stack(new)
-    nb = _mask_boxes(new)
-    keep = _nms_host(nb, np.asarray(scores, dtype=np.float32), nms_thresh)
-    masks, boxes = masks.copy(), boxes.copy()
-    for i in keep:
-        if scores[i] == 0.0:
-            masks[i], boxes[i] = new[i], nb[i]
-    return masks[keep], boxes[keep], keep
+def mask_boxes(masks):
+    """batched_mask_to_box (utils/amg.py:303-346) -> int32 XYXY [n,4]."""
+    lib = _lib.load()
+    n, H, W = masks.shape
+    boxes = torch.empty((n, 4), dtype=torch.int32, device=masks.device)
+    check(lib.hgl_mask_boxes(ops._dev(masks, torch.uint8, "masks"), n, H, W, boxes.data_ptr(), ops._stream()),
+          "hgl_mask_boxes")
+    return boxes

@@ -318,6 +318,17 @@ int hgl_sam_postprocess(const float* low_res, const float* iou_pred, int K, int 
 int hgl_nms(const int32_t* boxes_xyxy, const float* scores, const uint8_t* keep, int K, float iou_threshold,
             int32_t* out_idx, int32_t* out_n, void* stream);
 
+/* remove_small_regions (utils/amg.py:267-291) for a batch of masks on the device: 8-connected
+ * components of the mask (holes=0: "islands") or of its complement (holes=1), components with
+ * area < area_thresh are removed / filled; changed[n] tells whether mask n had any.  out may not
+ * alias masks.  N*H*W < 2^31. */
+size_t hgl_remove_small_regions_workspace_bytes(int N, int H, int W);
+int hgl_remove_small_regions(const uint8_t* masks, int N, int H, int W, int area_thresh, int holes,
+                             uint8_t* out, uint8_t* changed, void* workspace, size_t workspace_bytes,
+                             void* stream);
+/* batched_mask_to_box (utils/amg.py:303-346): inclusive XYXY, [0,0,0,0] for an empty mask. */
+int hgl_mask_boxes(const uint8_t* masks, int N, int H, int W, int32_t* boxes_xyxy, void* stream);
+
 /* out[i] = masks[idx[i]] for i < *n (device-side count), rows of HW bytes (HW % 16 == 0). */
 int hgl_gather_masks(const uint8_t* masks, const int32_t* idx, const int32_t* n, int max_n, long long HW,
                      uint8_t* out, void* stream);

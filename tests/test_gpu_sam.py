@@ -163,3 +163,42 @@ def test_full_size_decoder_properties(cuda):
     full = S.postprocess_masks(low[10:11].cpu().numpy(), (1024, 1024), (640, 640))[0]
     got = masks[30:33].cpu().numpy().astype(bool)
     assert ((got != (full > 0)).mean(axis=(1, 2)) < 1e-4).all()
+
+
+@pytest.mark.parametrize("mode", ["holes", "islands"])
+def test_remove_small_regions_vs_oracle(cuda, mode):
+    """device connected components (8-connectivity) vs the oracle on noisy + structured masks,
+    incl. all-small islands (keep the first largest), untouched masks, empty and full masks."""
+    rng = np.random.default_rng(3)
+    H, W = 97, 130
+    from hybridgl_amd.synth import synth_masks
+    masks = synth_masks(10, H, W, 8)
+    masks[0] ^= rng.random((H, W)) > 0.97             # salt-and-pepper holes and islands
+    masks[1] = rng.random((H, W)) > 0.5               # pure noise: many tiny components
+    masks[2] = False; masks[2, 5:8, 5:8] = True; masks[2, 50:52, 60:63] = True   # only small islands
+    masks[3] = False                                   # empty
+    masks[4] = True                                    # full
+    masks[5] = False; masks[5, 10:13, 10:13] = True; masks[5, 40:43, 40:43] = True   # tie: equal areas
+    masks[6, ::2, ::2] = False                         # checkerboard holes inside the blob (diagonal links)
+    out, changed = hsam.remove_small_regions(T(masks.astype(np.uint8), cuda), 20, mode)
+    out, changed = out.cpu().numpy().astype(bool), changed.cpu().numpy()
+    for i in range(len(masks)):
+        ref, ch = S.remove_small_regions(masks[i], 20, mode)
+        assert bool(changed[i]) == ch, (i, mode)
+        assert np.array_equal(out[i], ref), (i, mode)
+    boxes = hsam.mask_boxes(T(out.astype(np.uint8), cuda)).cpu().numpy()
+    assert np.array_equal(boxes.astype(np.int64), S.mask_to_box(out))
+
+
+def test_remove_small_regions_full_size(cuda):
+    """64 masks of 640x640 at once (BASELINE size) against the oracle on a few of them."""
+    from hybridgl_amd.synth import synth_masks
+    rng = np.random.default_rng(4)
+    masks = synth_masks(64, 640, 640, 9)
+    masks ^= rng.random(masks.shape) > 0.999
+    for mode in ("holes", "islands"):
+        out, changed = hsam.remove_small_regions(T(masks.astype(np.uint8), cuda), 800, mode)
+        out = out.cpu().numpy().astype(bool)
+        for i in (0, 17, 63):
+            ref, ch = S.remove_small_regions(masks[i], 800, mode)
+            assert np.array_equal(out[i], ref) and bool(changed[i]) == ch
