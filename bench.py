@@ -190,10 +190,16 @@ def main():
         from hybridgl_amd.sam import SamAutomaticMaskGenerator, sam_model_registry
         sam = sam_model_registry["default"](seed=0, device=dev)
         # Hybridgl_main.py:67-73
-        gen = SamAutomaticMaskGenerator(sam, points_per_side=8, pred_iou_thresh=0.7, stability_score_thresh=0.7,
-                                        crop_n_layers=0, crop_n_points_downscale_factor=1, min_mask_region_area=800)
-    # the CLIP stage scores the 64 seeded proposals (fixed N): random SAM weights give an arbitrary count
-    pipe = HybridGLPipeline(model, fusion_mode=args.fusion, masking_block=9, mask_generator=gen, use_sam_masks=False)
+        # Hybridgl_main.py:67-73 (8x8 grid, no crops, min_mask_region_area=800).  With random weights the
+        # reference thresholds (0.7 / 0.7 / NMS 0.7) would keep an arbitrary number of proposals, so the
+        # benchmark opens the three filters and cleans up a FIXED 64 survivors (scope B):
+        # every kernel of the stage runs on the full-size work, with no host sync.
+        gen = SamAutomaticMaskGenerator(sam, points_per_side=8, pred_iou_thresh=-1e30, stability_score_thresh=0.0,
+                                        box_nms_thresh=2.0, crop_n_layers=0, crop_n_points_downscale_factor=1,
+                                        min_mask_region_area=800)
+    # the CLIP stage scores the 64 seeded proposals (fixed N, meaningful shapes)
+    pipe = HybridGLPipeline(model, fusion_mode=args.fusion, masking_block=9, mask_generator=gen, use_sam_masks=False,
+                            fixed_proposals=None, cleanup_given_masks=gen is not None)
     # rank r owns refs i = r (mod world) of the shuffle=False order
     refs = [synthetic_ref(rank + world * j, dev, N=args.masks, sam_img_size=1024 if gen else 0)[0]
             for j in range(args.pool)]
@@ -269,8 +275,10 @@ def main():
                 "workload": (f"RefCOCO-shaped ref (BASELINE configs[1]): 640x640 image, 3 queries x (sentence+noun "
                              f"phrase+1 other noun); "
                              + ("SAM ViT-H proposal stage (encoder, 8x8 point grid = 64 prompts x 3 masks, fused "
-                                "post-processing, NMS; PIL resize to 1024 and small-region clean-up outside the "
-                                "timed step) + " if args.scope == "B" else "proposals given (scope A) + ")
+                                "post-processing of the 192 candidates, NMS) whose noise masks (random weights) are "
+                                "discarded; connected-component clean-up (min area 800) + second NMS run on the 64 "
+                                "seeded proposal-shaped masks; PIL resize to 1024 done on the host before the timed "
+                                "region) + " if args.scope == "B" else "proposals given (scope A) + ")
                              + f"view synthesis + CLIP ViT-B/16 hybrid {args.fusion} (masking_block 9) on "
                              f"{args.masks} seeded proposals + text encoder (9 strings) + scoring tail + IoU"),
                 "scope": args.scope,

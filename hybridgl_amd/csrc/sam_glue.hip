@@ -207,36 +207,73 @@ __device__ __forceinline__ void src_idx(float scale, int dst, int in_size, int& 
   l0 = 1.f - l1;
 }
 
+// One workgroup = a 16x16 tile of output pixels of one candidate.  The low-res logits the tile
+// touches (a <= 32x32 patch for every realistic size ratio) are staged in LDS once, so the 16
+// taps per pixel are LDS reads instead of scattered global loads.
+constexpr int PT = 16;     // output tile side
+constexpr int PR = 32;     // max staged low-res patch side
+
 __global__ __launch_bounds__(256) void sam_postprocess_kernel(PostArgs a) {
-  const int k = blockIdx.y;
-  if (a.iou && !(a.iou[k] > a.iou_thresh)) return;  // filtered before any pixel work
+  __shared__ float patch[PR * PR];
+  __shared__ unsigned red[6 * 4];
+  const int k = blockIdx.z;
+  if (a.iou && !(a.iou[k] > a.iou_thresh)) return;  // filtered before any pixel work (uniform)
+  const int tx = threadIdx.x & (PT - 1), ty = threadIdx.x >> 4;
+  const int X0 = blockIdx.x * PT, Y0 = blockIdx.y * PT;
+  const int X = X0 + tx, Y = Y0 + ty;
+  const int Xl = min(X0 + PT - 1, a.W - 1), Yl = min(Y0 + PT - 1, a.H - 1);
+  const float* L = a.low + (long long)k * a.hl * a.wl;
+  const float sy1 = (float)a.hi / (float)a.H, sx1 = (float)a.wi / (float)a.W;
+  const float s2y = (float)a.hl / (float)a.S, s2x = (float)a.wl / (float)a.S;
+  // low-res patch bounds of the tile: taps are monotone in the output coordinate
+  int i0, i1, j0, j1;
+  float f0, f1;
+  src_idx(sy1, Y0, a.hi, i0, i1, f0, f1);
+  int vb, vdummy;
+  src_idx(s2y, i0, a.hl, vb, vdummy, f0, f1);
+  src_idx(sy1, Yl, a.hi, i0, i1, f0, f1);
+  int ve0, ve;
+  src_idx(s2y, i1, a.hl, ve0, ve, f0, f1);
+  src_idx(sx1, X0, a.wi, j0, j1, f0, f1);
+  int ub, udummy;
+  src_idx(s2x, j0, a.wl, ub, udummy, f0, f1);
+  src_idx(sx1, Xl, a.wi, j0, j1, f0, f1);
+  int ue0, ue;
+  src_idx(s2x, j1, a.wl, ue0, ue, f0, f1);
+  const int ph = ve - vb + 1, pw = ue - ub + 1;
+  const bool staged = ph <= PR && pw <= PR;      // uniform
+  if (staged) {
+    for (int i = threadIdx.x; i < ph * pw; i += 256) {
+      const int v = i / pw, u = i - v * pw;
+      patch[v * PR + u] = L[(long long)(vb + v) * a.wl + (ub + u)];
+    }
+  }
+  __syncthreads();
+  auto ld = [&](int v, int u) -> float {
+    return staged ? patch[(v - vb) * PR + (u - ub)] : L[(long long)v * a.wl + u];
+  };
+
   const long long HW = (long long)a.H * a.W;
-  const long long pix = blockIdx.x * 256ll + threadIdx.x;
   unsigned inter = 0, uni = 0, minx = 0x7fffffff, miny = 0x7fffffff, maxx = 0, maxy = 0, any = 0;
-  if (pix < HW) {
-    const int X = (int)(pix % a.W), Y = (int)(pix / a.W);
-    const float* L = a.low + (long long)k * a.hl * a.wl;
-    // outer interpolation: from the cropped S-grid [hi, wi] to [H, W]
+  if (X < a.W && Y < a.H) {
     int y0, y1, x0, x1;
     float ly0, ly1, lx0, lx1;
-    src_idx((float)a.hi / (float)a.H, Y, a.hi, y0, y1, ly0, ly1);
-    src_idx((float)a.wi / (float)a.W, X, a.wi, x0, x1, lx0, lx1);
-    // inner interpolation: low-res -> S grid at the four taps
-    const float s2y = (float)a.hl / (float)a.S, s2x = (float)a.wl / (float)a.S;
+    src_idx(sy1, Y, a.hi, y0, y1, ly0, ly1);
+    src_idx(sx1, X, a.wi, x0, x1, lx0, lx1);
     float tap[2][2];
-    const int ty[2] = {y0, y1}, tx[2] = {x0, x1};
+    const int tyv[2] = {y0, y1}, txv[2] = {x0, x1};
 #pragma unroll
     for (int iy = 0; iy < 2; ++iy) {
       int v0, v1;
       float m0, m1;
-      src_idx(s2y, ty[iy], a.hl, v0, v1, m0, m1);
+      src_idx(s2y, tyv[iy], a.hl, v0, v1, m0, m1);
 #pragma unroll
       for (int ix = 0; ix < 2; ++ix) {
         int u0, u1;
         float n0, n1;
-        src_idx(s2x, tx[ix], a.wl, u0, u1, n0, n1);
-        const float top = L[(long long)v0 * a.wl + u0] * n0 + L[(long long)v0 * a.wl + u1] * n1;
-        const float bot = L[(long long)v1 * a.wl + u0] * n0 + L[(long long)v1 * a.wl + u1] * n1;
+        src_idx(s2x, txv[ix], a.wl, u0, u1, n0, n1);
+        const float top = ld(v0, u0) * n0 + ld(v0, u1) * n1;
+        const float bot = ld(v1, u0) * n0 + ld(v1, u1) * n1;
         tap[iy][ix] = top * m0 + bot * m1;
       }
     }
@@ -244,13 +281,14 @@ __global__ __launch_bounds__(256) void sam_postprocess_kernel(PostArgs a) {
     const float bot = tap[1][0] * lx0 + tap[1][1] * lx1;
     const float v = top * ly0 + bot * ly1;
     const bool on = v > a.thr;
+    const long long pix = (long long)Y * a.W + X;
     a.masks[(long long)k * HW + pix] = on ? 1 : 0;
     if (a.full_logits) a.full_logits[(long long)k * HW + pix] = v;
     inter = v > a.thr + a.off;
     uni = v > a.thr - a.off;
     if (on) { minx = maxx = X; miny = maxy = Y; any = 1; }
   }
-  // wave reduction then one set of atomics per wave
+  // wave reduction, then one set of atomics per workgroup
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     inter += __shfl_xor(inter, o);
@@ -261,15 +299,26 @@ __global__ __launch_bounds__(256) void sam_postprocess_kernel(PostArgs a) {
     maxy = max(maxy, (unsigned)__shfl_xor(maxy, o));
     any |= __shfl_xor(any, o);
   }
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
+    red[wave * 6 + 0] = inter; red[wave * 6 + 1] = uni;
+    red[wave * 6 + 2] = any ? minx : 0x7fffffffu; red[wave * 6 + 3] = any ? miny : 0x7fffffffu;
+    red[wave * 6 + 4] = any ? maxx : 0u; red[wave * 6 + 5] = any ? (maxy | 0x80000000u) : 0u;  // top bit: "has pixels"
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned I = 0, U = 0, mnx = 0x7fffffff, mny = 0x7fffffff, mxx = 0, mxy = 0, has = 0;
+    for (int w = 0; w < 4; ++w) {
+      I += red[w * 6]; U += red[w * 6 + 1];
+      mnx = min(mnx, red[w * 6 + 2]); mny = min(mny, red[w * 6 + 3]);
+      if (red[w * 6 + 5] & 0x80000000u) { has = 1; mxx = max(mxx, red[w * 6 + 4]); mxy = max(mxy, red[w * 6 + 5] & 0x7fffffffu); }
+    }
     unsigned* c = a.counters + (long long)k * 6;
-    if (inter) atomicAdd(&c[0], inter);
-    if (uni) atomicAdd(&c[1], uni);
-    if (any) {
-      atomicMin(&c[2], minx);
-      atomicMin(&c[3], miny);
-      atomicMax(&c[4], maxx);
-      atomicMax(&c[5], maxy);
+    if (I) atomicAdd(&c[0], I);
+    if (U) atomicAdd(&c[1], U);
+    if (has) {
+      atomicMin(&c[2], mnx); atomicMin(&c[3], mny);
+      atomicMax(&c[4], mxx); atomicMax(&c[5], mxy);
     }
   }
 }
@@ -448,7 +497,7 @@ int hgl_sam_postprocess(const float* low_res, const float* iou_pred, int K, int 
   a.K = K; a.hl = hl; a.wl = wl; a.S = img_size; a.hi = in_h; a.wi = in_w; a.H = H; a.W = W;
   a.thr = mask_threshold; a.off = stability_offset;
   a.masks = masks; a.counters = counters; a.full_logits = full_logits;
-  hipLaunchKernelGGL(sam_postprocess_kernel, dim3(grid1((long long)H * W), K), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(sam_postprocess_kernel, dim3((W + PT - 1) / PT, (H + PT - 1) / PT, K), dim3(256), 0, st, a);
   hipLaunchKernelGGL(sam_finalize_kernel, dim3((K + 255) / 256), dim3(256), 0, st, counters, iou_pred, K,
                      pred_iou_thresh, stability_thresh, stability, (int*)boxes_xyxy, keep);
   return hgl_check_launch("sam_postprocess");

@@ -293,12 +293,20 @@ class SamAutomaticMaskGenerator:
         order, n = nms(boxes, iou, keep, self.box_nms_thresh)
         return masks, boxes, iou, stab, order, n, np.repeat(pts, 3, axis=0)
 
-    def generate_device(self, image, resized=None):
+    def generate_device(self, image, resized=None, fixed_n=None):
         """Whole `generate` on the device.  Returns (masks [n,H,W] uint8, boxes_xywh [n,4] int64,
         iou [n], stability [n], cand [n] int64 indices into the 3*points candidates), all device
-        tensors, in the reference's output order.  One host sync (the proposal count)."""
+        tensors, in the reference's output order.  Two host syncs (the two proposal counts).
+        fixed_n (benchmark only): take the first fixed_n survivors of the first NMS without reading
+        the count back (the caller guarantees that many survive), run the clean-up kernels on them
+        and skip the final gather -- no host sync at all."""
         masks, boxes, iou, stab, order, n, points = self.propose(image, resized)
-        n = int(n.item())                       # the one host sync of the proposal stage
+        if fixed_n is not None:
+            idx = order[:fixed_n].long()
+            m = masks.index_select(0, idx).contiguous()
+            m, nb = self.cleanup_fixed(m)
+            return m, nb, iou.index_select(0, idx), stab.index_select(0, idx), idx
+        n = int(n.item())                       # host sync: number of survivors of the first NMS
         idx = order[:n].long()
         m = masks.index_select(0, idx).contiguous()
         bx = boxes.index_select(0, idx).contiguous()
@@ -315,6 +323,18 @@ class SamAutomaticMaskGenerator:
         b = bx.long()
         xywh = torch.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1) if n > 0 else b
         return m, xywh, iou.index_select(0, idx), stab.index_select(0, idx), idx
+
+    def cleanup_fixed(self, m):
+        """postprocess_small_regions kernels on a fixed batch of masks [n,H,W] uint8 without reading any
+        count back: holes, islands, boxes, second NMS (its order is left on the device)."""
+        if self.min_mask_region_area <= 0:
+            return m, mask_boxes(m)
+        m1, c1 = remove_small_regions(m, self.min_mask_region_area, "holes")
+        m2, c2 = remove_small_regions(m1, self.min_mask_region_area, "islands")
+        nb = mask_boxes(m2)
+        nms(nb, ((c1 | c2) == 0).to(torch.float32), torch.ones(m.shape[0], dtype=torch.uint8, device=m.device),
+            max(self.box_nms_thresh, self.crop_nms_thresh))
+        return m2, nb
 
     def generate(self, image):
         """automatic_mask_generator.py:137-195 -> list of records (binary masks)."""
