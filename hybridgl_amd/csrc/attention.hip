@@ -86,28 +86,46 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(AttnArgs a) {
   int sk_eff = a.Sk;
   if (a.mask_kind == HGL_MASK_CAUSAL) sk_eff = min(a.Sk, (int)(blockIdx.x * 4 + 4) * 32);
 
+  // K/V staging is software pipelined: the next 64-key chunk is fetched into registers while the
+  // current one is consumed from LDS (rows beyond Sk read a clamped valid row: their scores are
+  // masked to -inf, so P = 0 multiplies finite values).
+  constexpr int F4_PER_ROW = HD / 4;
+  constexpr int NLD = KV_CHUNK * F4_PER_ROW / 256;   // float4 per thread per matrix (exact for hd 16/32/64/80)
+  static_assert(KV_CHUNK * F4_PER_ROW % 256 == 0, "chunk must divide evenly over the workgroup");
+  f32x4 pk[NLD], pv[NLD];
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / F4_PER_ROW, c4 = idx - row * F4_PER_ROW;
+      const int kg = min(kc + row, a.Sk - 1);
+      pk[i] = *(const f32x4*)(kp + (long long)kg * a.ldk + c4 * 4);
+      pv[i] = *(const f32x4*)(vp + (long long)kg * a.ldv + c4 * 4);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / F4_PER_ROW, c4 = idx - row * F4_PER_ROW;
+      *(f32x4*)(Ks + row * HDP + c4 * 4) = pk[i];
+      *(f32x4*)(Vs + row * VLD + c4 * 4) = pv[i];
+    }
+  };
+  if (VLD > HD) {  // zero the d padding of V once (the staging stores never touch it)
+    constexpr int PADW = (VLD - HD) > 0 ? (VLD - HD) : 1;
+    for (int i = t; i < KV_CHUNK * PADW; i += 256) {
+      const int row = i / PADW, c = i - row * PADW;
+      Vs[row * VLD + HD + c] = 0.f;
+    }
+  }
+  load_chunk(0);
+  store_chunk();
+  __syncthreads();
+
   for (int kc = 0; kc < sk_eff; kc += KV_CHUNK) {
-    __syncthreads();  // previous chunk fully consumed
-    // ---- stage K,V chunk (rows beyond Sk are zero) ----
-    for (int i = t; i < KV_CHUNK * (HD / 4); i += 256) {
-      const int row = i / (HD / 4), c4 = i - row * (HD / 4);
-      const int kg = kc + row;
-      f32x4 kvv = f32x4{0, 0, 0, 0}, vvv = f32x4{0, 0, 0, 0};
-      if (kg < a.Sk) {
-        kvv = *(const f32x4*)(kp + (long long)kg * a.ldk + c4 * 4);
-        vvv = *(const f32x4*)(vp + (long long)kg * a.ldv + c4 * 4);
-      }
-      *(f32x4*)(Ks + row * HDP + c4 * 4) = kvv;
-      *(f32x4*)(Vs + row * VLD + c4 * 4) = vvv;
-    }
-    if (VLD > HD) {  // zero the d padding of V once per chunk
-      constexpr int PADW = (VLD - HD) > 0 ? (VLD - HD) : 1;
-      for (int i = t; i < KV_CHUNK * PADW; i += 256) {
-        const int row = i / PADW, c = i - row * PADW;
-        Vs[row * VLD + HD + c] = 0.f;
-      }
-    }
-    __syncthreads();
+    const bool has_next = kc + KV_CHUNK < sk_eff;
+    if (has_next) load_chunk(kc + KV_CHUNK);
 
 #pragma unroll
     for (int kt = 0; kt < KV_CHUNK / 32; ++kt) {
@@ -185,6 +203,11 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(AttnArgs a) {
           o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[d * 32], s[e], o[d], 0, 0, 0);
       }
     }
+    __syncthreads();              // chunk fully consumed by every wave
+    if (has_next) {
+      store_chunk();
+      __syncthreads();
+    }
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -207,13 +230,253 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(AttnArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Same algorithm on the fp16 matrix cores with fp32-class accuracy (HGL_PREC_F16X3): Q, K, V and the
+// probabilities P are split into fp16 hi+lo halves and every product is evaluated as
+// hi*hi + hi*lo + lo*hi with v_mfma_f32_32x32x16_f16 into fp32 accumulators (see gemm_f16x3.hip
+// for the error analysis).  K is staged as rows [hi | lo]; V is staged TRANSPOSED ([d][key], hi
+// and lo planes) because the P^T accumulator registers 8s..8s+7 of a lane form the B operand of
+// k-step s with the key order 16s + 8(j>>2) + 4h + (j&3): the matching A operand is then two
+// 8-byte reads of consecutive keys from a V^T row.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4(const f32x4 v, h16x4& hi, h16x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (_Float16)v[e];
+    lo[e] = (_Float16)(v[e] - (float)hi[e]);
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
+  constexpr int KS = HD / 16;                 // k-steps of the QK^T contraction
+  constexpr int KROW = 2 * HD + 8;            // halfs per staged K row: hi | lo | pad (odd multiple of 16 B)
+  constexpr int DT = (HD + 31) / 32;          // 32-wide d tiles of the output
+  constexpr int VROWS = DT * 32;              // V^T rows (zero rows beyond HD)
+  constexpr int VLD = KV_CHUNK + 4;           // halfs per V^T row (136 B: conflict-free 8-byte reads)
+  constexpr int F4 = HD / 4;
+  constexpr int NLK = KV_CHUNK * F4 / 256;    // K float4 per thread per chunk
+  constexpr int NLV = HD / 16;                // V float4 per thread per chunk (key = t&63, 4 d-groups apart)
+  static_assert(HD % 16 == 0 && KV_CHUNK * F4 % 256 == 0, "unsupported head dim");
+  __shared__ __attribute__((aligned(16))) _Float16 Ks[KV_CHUNK * KROW];
+  __shared__ __attribute__((aligned(16))) _Float16 Vh[VROWS * VLD];
+  __shared__ __attribute__((aligned(16))) _Float16 Vl[VROWS * VLD];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y;
+  const int b = bh / a.H, hh = bh - b * a.H;
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int qi = q0 + r;
+  const bool qvalid = qi < a.Sq;
+  const float* qp = a.q + b * a.sqb + (long long)(qvalid ? qi : 0) * a.ldq + hh * HD;
+  const float* kp = a.k + b * a.skb + hh * HD;
+  const float* vp = a.v + b * a.svb + hh * HD;
+
+  // Q fragments (pre-scaled in fp32, then split): lane (r,h) element j of step s = Q[q][16s + 8h + j]
+  h16x8 qh[KS], ql[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 v = qvalid ? *(const f32x4*)(qp + 16 * s + 8 * h + 4 * half) : f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = v[e] * a.scale;
+        const _Float16 hi = (_Float16)x;
+        qh[s][4 * half + e] = hi;
+        ql[s][4 * half + e] = (_Float16)(x - (float)hi);
+      }
+    }
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  const float NEG_INF = __int_as_float(NEG_BIG_BITS);
+  float m_run = NEG_INF, l_run = 0.f;
+
+  const uint8_t* keep_row = nullptr;
+  if (a.mask_kind == HGL_MASK_CLS_KEEP && b >= a.keep_b0)
+    keep_row = a.keep + (long long)((b - a.keep_b0) % a.keep_n) * (a.Sk - 1);
+  const float* relh = a.rel_h ? a.rel_h + ((long long)bh * a.Sq + (qvalid ? qi : 0)) * a.kh : nullptr;
+  const float* relw = a.rel_w ? a.rel_w + ((long long)bh * a.Sq + (qvalid ? qi : 0)) * a.kw : nullptr;
+  int sk_eff = a.Sk;
+  if (a.mask_kind == HGL_MASK_CAUSAL) sk_eff = min(a.Sk, (int)(blockIdx.x * 4 + 4) * 32);
+
+  // ---- staging (software pipelined through registers) ----
+  f32x4 pk[NLK], pv[NLV];
+  const int vkey = t & 63, vg = t >> 6;
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NLK; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / F4, c4 = idx - row * F4;
+      pk[i] = *(const f32x4*)(kp + (long long)min(kc + row, a.Sk - 1) * a.ldk + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NLV; ++i)
+      pv[i] = *(const f32x4*)(vp + (long long)min(kc + vkey, a.Sk - 1) * a.ldv + 4 * (vg + 4 * i));
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLK; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / F4, c4 = idx - row * F4;
+      h16x4 hi, lo;
+      split4(pk[i], hi, lo);
+      *(h16x4*)(Ks + row * KROW + c4 * 4) = hi;
+      *(h16x4*)(Ks + row * KROW + HD + c4 * 4) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < NLV; ++i) {
+      const int d0 = 4 * (vg + 4 * i);
+      h16x4 hi, lo;
+      split4(pv[i], hi, lo);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {   // transposed: a wave writes 64 consecutive keys of one d row
+        Vh[(d0 + e) * VLD + vkey] = hi[e];
+        Vl[(d0 + e) * VLD + vkey] = lo[e];
+      }
+    }
+  };
+  if (VROWS > HD) {  // zero V^T rows d >= HD once
+    for (int i = t; i < (VROWS - HD) * VLD; i += 256) {
+      Vh[HD * VLD + i] = (_Float16)0.f;
+      Vl[HD * VLD + i] = (_Float16)0.f;
+    }
+  }
+  load_chunk(0);
+  store_chunk();
+  __syncthreads();
+
+  for (int kc = 0; kc < sk_eff; kc += KV_CHUNK) {
+    const bool has_next = kc + KV_CHUNK < sk_eff;
+    if (has_next) load_chunk(kc + KV_CHUNK);
+#pragma unroll
+    for (int kt = 0; kt < KV_CHUNK / 32; ++kt) {
+      const int kbase = kc + kt * 32;
+      if (kbase >= sk_eff) break;  // uniform
+      f32x16 s;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+      const _Float16* krow = Ks + (kt * 32 + r) * KROW + 8 * h;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        const h16x8 kh8 = *(const h16x8*)(krow + 16 * c);
+        const h16x8 kl8 = *(const h16x8*)(krow + HD + 16 * c);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, ql[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh[c], s, 0, 0, 0);
+      }
+      // s[e] = S^T[key = kbase + (e&3) + 8*(e>>2) + 4*h][query qi]
+      if (relh) {
+        if ((a.kw & 31) == 0) {
+          const float rh = relh[kbase / a.kw];
+          const float* rw = relw + (kbase % a.kw) + 4 * h;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 w4 = *(const f32x4*)(rw + 8 * g4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[4 * g4 + i] += rh + w4[i];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (kg < a.Sk) s[e] += relh[kg / a.kw] + relw[kg % a.kw];
+          }
+        }
+      }
+      float mx = NEG_INF;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float sv = s[e];
+        bool masked = kg >= a.Sk;
+        if (a.mask_kind == HGL_MASK_CAUSAL) masked |= kg > qi;
+        if (keep_row && qi == 0 && kg >= 1 && kg < a.Sk) masked |= keep_row[kg - 1] == 0;
+        sv = masked ? NEG_INF : sv;
+        s[e] = sv;
+        mx = fmaxf(mx, sv);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+      const float alpha = expf(m_run - m_use);
+      float rs = 0.f;
+      h16x8 ph[2], pl[2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = expf(s[e] - m_use);
+        rs += p;
+        const _Float16 hi = (_Float16)p;
+        ph[e >> 3][e & 7] = hi;
+        pl[e >> 3][e & 7] = (_Float16)(p - (float)hi);
+      }
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+      // O^T += V^T P^T ; A operand element j of lane (d, h) = V^T[d][kt*32 + 16*s2 + 8*(j>>2) + 4*h + (j&3)]
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const int off = (d * 32 + r) * VLD + kt * 32 + 16 * s2 + 4 * h;
+          const h16x4 vh0 = *(const h16x4*)(Vh + off), vh1 = *(const h16x4*)(Vh + off + 8);
+          const h16x4 vl0 = *(const h16x4*)(Vl + off), vl1 = *(const h16x4*)(Vl + off + 8);
+          h16x8 vh8, vl8;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vh8[e] = vh0[e]; vh8[4 + e] = vh1[e]; vl8[e] = vl0[e]; vl8[4 + e] = vl1[e]; }
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph[s2], o[d], 0, 0, 0);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl[s2], o[d], 0, 0, 0);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph[s2], o[d], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (has_next) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (qvalid) {
+    float* op = a.out + b * a.sob + (long long)qi * a.ldo + hh * HD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * h;
+        if (dd < HD) {
+          f32x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = o[d][4 * g + e] * inv;
+          *(f32x4*)(op + dd) = w;
+        }
+      }
+    }
+  }
+}
+
 template <int HD>
 int launch_hd(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.Sq + 127) / 128, a.B * a.H);
   HglProfScope prof(HGL_PROF_ATTN, 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD,
                     4.0 * a.B * a.H * HD * (2.0 * a.Sq + 2.0 * a.Sk), st);
-  hipLaunchKernelGGL(attn_f32_kernel<HD>, grid, dim3(256), 0, st, a);
-  return hgl_check_launch("attention_f32");
+  if (hgl_precision() == HGL_PREC_F16X3) hipLaunchKernelGGL(attn_x3_kernel<HD>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(attn_f32_kernel<HD>, grid, dim3(256), 0, st, a);
+  return hgl_check_launch("attention");
 }
 
 }  // namespace

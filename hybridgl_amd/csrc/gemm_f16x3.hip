@@ -12,6 +12,8 @@
 // the lo halves of one operand row for BK = 64 (128 B + 128 B) plus one 16-byte pad, so the
 // ds_read_b128 fragment reads are conflict free (row stride 272 B = 17 x 16 B).
 #include "hgl_common.h"
+#include <stdlib.h>
+#include <string.h>
 #include <unordered_map>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -20,8 +22,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // 16-byte staging 
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int ROW_H = 2 * BK + 8;        // halfs per LDS row: hi | lo | pad
+constexpr int BM = 128, BN = 128;
 constexpr int NTHREADS = 256;
 
 struct SplitW {
@@ -50,9 +51,13 @@ __device__ __forceinline__ float act_apply(float x) {
   return x;
 }
 
-template <int ACT>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_f16x3_kernel(Args g) {
+template <int ACT, int BK, int OCC>
+__global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];  // [A: BM rows | W: BN rows] x ROW_H
+  constexpr int ROW_H = 2 * BK + 8;   // halfs per LDS row: hi | lo | pad
+  constexpr int CH = BK / 8;          // 16-byte chunks per row per half
+  constexpr int RSTEP = NTHREADS / CH; // rows covered per pass
+  constexpr int NLD = BM / RSTEP;      // loads per thread per array per K tile
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
   {
@@ -71,35 +76,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f16x3_kernel(Args g) {
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
-  const int ld_c = t & 7;     // 16-byte chunk (8 halfs) within the 64-wide K tile
-  const int ld_row = t >> 3;  // 0..31 (+32*i)
+  const int ld_c = t % CH;     // 16-byte chunk (8 halfs) within the K tile
+  const int ld_row = t / CH;   // (+RSTEP*i)
   const int mclamp = g.M - 1, nclamp = g.N - 1;
 
   // Staging loads carry NO arithmetic on the loaded registers (anything that touches them would
   // make the compiler wait for the loads before the MFMA section): out-of-range rows read a
   // clamped (valid) row -- those accumulator rows/columns are never stored -- and K is a
   // multiple of BK (checked by the launcher), so there is no K tail.
-  u32x4 pah[4], pal[4], pwh[4], pwl[4];
-  const _Float16 *pa_h[4], *pa_l[4], *pw_h[4], *pw_l[4];
+  u32x4 pah[NLD], pal[NLD], pwh[NLD], pwl[NLD];
+  const _Float16 *pa_h[NLD], *pa_l[NLD], *pw_h[NLD], *pw_l[NLD];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long long oa = (long long)min(row0 + ld_row + 32 * i, mclamp) * g.lda + ld_c * 8;
-    const long long ow = (long long)min(col0 + ld_row + 32 * i, nclamp) * g.ldw + ld_c * 8;
+  for (int i = 0; i < NLD; ++i) {
+    const long long oa = (long long)min(row0 + ld_row + RSTEP * i, mclamp) * g.lda + ld_c * 8;
+    const long long ow = (long long)min(col0 + ld_row + RSTEP * i, nclamp) * g.ldw + ld_c * 8;
     pa_h[i] = g.Ah + oa; pa_l[i] = g.Al + oa; pw_h[i] = g.Wh + ow; pw_l[i] = g.Wl + ow;
   }
   auto load_tile = [&](int kt) {
     const int k = kt * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       pah[i] = *(const u32x4*)(pa_h[i] + k); pal[i] = *(const u32x4*)(pa_l[i] + k);
       pwh[i] = *(const u32x4*)(pw_h[i] + k); pwl[i] = *(const u32x4*)(pw_l[i] + k);
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      _Float16* ar = smem + (ld_row + 32 * i) * ROW_H + ld_c * 8;
-      _Float16* wr = smem + (BM + ld_row + 32 * i) * ROW_H + ld_c * 8;
+    for (int i = 0; i < NLD; ++i) {
+      _Float16* ar = smem + (ld_row + RSTEP * i) * ROW_H + ld_c * 8;
+      _Float16* wr = smem + (BM + ld_row + RSTEP * i) * ROW_H + ld_c * 8;
       *(u32x4*)ar = pah[i]; *(u32x4*)(ar + BK) = pal[i];
       *(u32x4*)wr = pwh[i]; *(u32x4*)(wr + BK) = pwl[i];
     }
@@ -320,7 +325,7 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
   const SplitW& sw = it->second;
   HGL_REQUIRE(sw.N == N && sw.K == K, "gemm_f16x3: registered split is [%d,%d], GEMM wants [%d,%d]", sw.N, sw.K, N, K);
   HGL_REQUIRE(Ah && Al && (C || (Ch && Cl)) && M > 0 && N > 0 && K > 0, "gemm_f16x3: bad arguments");
-  HGL_REQUIRE((K % BK) == 0 && (lda & 7) == 0, "gemm_f16x3: K must be a multiple of %d and lda of 8 (K=%d lda=%d)", BK, K, lda);
+  HGL_REQUIRE((K % 64) == 0 && (lda & 7) == 0, "gemm_f16x3: K must be a multiple of 64 and lda of 8 (K=%d lda=%d)", K, lda);
   Args g;
   g.Ah = (const _Float16*)Ah; g.Al = (const _Float16*)Al; g.Wh = sw.hi; g.Wl = sw.lo;
   g.bias = bias; g.R = R; g.C = C; g.Ch = (_Float16*)Ch; g.Cl = (_Float16*)Cl;
@@ -330,22 +335,28 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
   g.tiles_n = (N + BN - 1) / BN;
   const long long nwg = (long long)g.tiles_m * g.tiles_n;
   HGL_REQUIRE(nwg < (1ll << 31), "gemm_f16x3: grid too large");
-  const size_t lds = (size_t)(BM + BN) * ROW_H * sizeof(_Float16);
+  static int variant = -1;   // HGL_X3_VARIANT=bk32 selects BK=32 / 3 workgroups per CU (A/B experiments)
+  if (variant < 0) {
+    const char* v = getenv("HGL_X3_VARIANT");
+    variant = (v && !strcmp(v, "bk32")) ? 1 : 0;
+  }
   HglProfScope prof(HGL_PROF_GEMM_X3, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
-#define HGL_X3_LAUNCH(ACT_)                                                                                   \
+#define HGL_X3_LAUNCH(ACT_, BK_, OCC_)                                                                        \
   do {                                                                                                        \
+    const size_t lds_ = (size_t)(BM + BN) * (2 * BK_ + 8) * sizeof(_Float16);                                 \
     static bool set_ = false;                                                                                 \
     if (!set_) {                                                                                              \
-      (void)hipFuncSetAttribute((const void*)gemm_f16x3_kernel<ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      (void)hipFuncSetAttribute((const void*)gemm_f16x3_kernel<ACT_, BK_, OCC_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
       set_ = true;                                                                                            \
     }                                                                                                         \
-    hipLaunchKernelGGL(gemm_f16x3_kernel<ACT_>, dim3((unsigned)nwg), dim3(NTHREADS), lds, st, g);             \
+    hipLaunchKernelGGL((gemm_f16x3_kernel<ACT_, BK_, OCC_>), dim3((unsigned)nwg), dim3(NTHREADS), lds_, st, g); \
   } while (0)
+#define HGL_X3_VARIANTS(ACT_) do { if (variant == 1) HGL_X3_LAUNCH(ACT_, 32, 3); else HGL_X3_LAUNCH(ACT_, 64, 2); } while (0)
   switch (act) {
-    case HGL_ACT_QUICKGELU: HGL_X3_LAUNCH(HGL_ACT_QUICKGELU); break;
-    case HGL_ACT_GELU: HGL_X3_LAUNCH(HGL_ACT_GELU); break;
-    case HGL_ACT_RELU: HGL_X3_LAUNCH(HGL_ACT_RELU); break;
-    default: HGL_X3_LAUNCH(HGL_ACT_NONE); break;
+    case HGL_ACT_QUICKGELU: HGL_X3_VARIANTS(HGL_ACT_QUICKGELU); break;
+    case HGL_ACT_GELU: HGL_X3_VARIANTS(HGL_ACT_GELU); break;
+    case HGL_ACT_RELU: HGL_X3_VARIANTS(HGL_ACT_RELU); break;
+    default: HGL_X3_VARIANTS(HGL_ACT_NONE); break;
   }
   return hgl_check_launch("gemm_f16x3");
 }

@@ -14,6 +14,14 @@ def T(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+@pytest.fixture(params=["f32", "f16x3"])
+def precision(request, cuda):
+    """run a test under both matrix-core modes (fp32 MFMA / split-fp16 MFMA) and restore the mode"""
+    ops.set_precision(request.param)
+    yield request.param
+    ops.set_precision(ops.default_precision())
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (197, 2304, 768), (64, 512, 768), (1, 4, 256),
                                    (300, 96, 100), (1000, 136, 3072), (77, 32, 64)])
 @pytest.mark.parametrize("act", ["none", "quickgelu", "gelu", "relu"])
@@ -34,6 +42,30 @@ def test_gemm(cuda, M, N, K, act):
         z = np.maximum(z, 0)
     z = z + r
     np.testing.assert_allclose(y, z, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (197, 2304, 768), (300, 96, 128), (1000, 136, 3072), (77, 32, 64)])
+@pytest.mark.parametrize("act", ["none", "quickgelu", "gelu", "relu"])
+def test_gemm_f16x3(cuda, M, N, K, act):
+    """split-fp16 matrix-core GEMM: fp32-class accuracy (tolerance 1.5x the fp32 kernel's)."""
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = (rng.standard_normal((M, K)) * rng.choice([0.01, 1.0, 30.0], size=(M, 1))).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    y = ops.gemm_f16x3(T(a, cuda), T(w, cuda), T(b, cuda), T(r, cuda), act).cpu().numpy()
+    z = a.astype(np.float64) @ w.astype(np.float64).T + b
+    if act == "quickgelu":
+        z = z / (1 + np.exp(-1.702 * z))
+    elif act == "gelu":
+        from scipy.special import erf
+        z = 0.5 * z * (1 + erf(z / np.sqrt(2)))
+    elif act == "relu":
+        z = np.maximum(z, 0)
+    z = z + r
+    # error budget relative to the magnitude of the row's terms (rows are scaled by 0.01 / 1 / 30)
+    scale = np.maximum(1.0, np.abs(z)) * np.maximum(1.0, np.abs(a).max(axis=1, keepdims=True) / 4)
+    assert (np.abs(y - z) / scale).max() < 3e-5
 
 
 def test_gemm_inplace_residual_and_asymmetry(cuda):
@@ -77,7 +109,7 @@ def _attn_ref(q, k, v, heads, scale, add_mask=None, bias=None):
 
 @pytest.mark.parametrize("B,heads,S,hd", [(3, 12, 197, 64), (2, 2, 17, 64), (2, 16, 196, 80), (5, 8, 7, 32),
                                           (2, 8, 300, 16), (1, 4, 64, 64), (1, 2, 129, 64)])
-def test_attention_plain(cuda, B, heads, S, hd):
+def test_attention_plain(cuda, precision, B, heads, S, hd):
     rng = np.random.default_rng(B * 100 + S)
     D = heads * hd
     q, k, v = (rng.standard_normal((B, S, D)).astype(np.float32) for _ in range(3))
@@ -85,7 +117,7 @@ def test_attention_plain(cuda, B, heads, S, hd):
     np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5), rtol=0, atol=2e-5)
 
 
-def test_attention_cross_lengths(cuda):
+def test_attention_cross_lengths(cuda, precision):
     """decoder shapes: few queries x many keys and the reverse (transformer.py:185-240)."""
     rng = np.random.default_rng(5)
     for Sq, Sk, heads, hd in [(7, 4096, 8, 16), (4096, 7, 8, 16), (33, 95, 4, 32)]:
@@ -97,7 +129,7 @@ def test_attention_cross_lengths(cuda):
         np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5), rtol=0, atol=2e-5)
 
 
-def test_attention_causal(cuda):
+def test_attention_causal(cuda, precision):
     rng = np.random.default_rng(9)
     B, heads, S, hd = 4, 8, 77, 64
     D = heads * hd
@@ -107,7 +139,7 @@ def test_attention_causal(cuda):
     np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5, mask), rtol=0, atol=2e-5)
 
 
-def test_attention_cls_keep_with_offsets(cuda):
+def test_attention_cls_keep_with_offsets(cuda, precision):
     """keep bytes apply to batches >= keep_b0, row (b-keep_b0)%keep_n; empty keep row -> CLS sees itself."""
     rng = np.random.default_rng(10)
     B, heads, S, hd, n = 6, 12, 197, 64, 2
@@ -123,7 +155,7 @@ def test_attention_cls_keep_with_offsets(cuda):
     np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5, add), rtol=0, atol=2e-5)
 
 
-def test_attention_spiked_scores_online_softmax(cuda):
+def test_attention_spiked_scores_online_softmax(cuda, precision):
     """force the running max to jump at a late key tile (rescale branch of the online softmax)."""
     rng = np.random.default_rng(12)
     B, heads, S, hd = 1, 1, 200, 64
@@ -134,7 +166,7 @@ def test_attention_spiked_scores_online_softmax(cuda):
     np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5), rtol=0, atol=2e-5)
 
 
-def test_attention_rel_pos_bias(cuda):
+def test_attention_rel_pos_bias(cuda, precision):
     """decomposed relative position bias tables (image_encoder.py:325-361)."""
     rng = np.random.default_rng(13)
     B, heads, kh, kw, hd = 2, 3, 14, 14, 80
