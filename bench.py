@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--masks", type=int, default=64)
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic refs resident per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="scope B: run the SAM stage and the CLIP stage back to back on one stream instead of "
+                         "overlapping ref i's CLIP stage with ref i+1's SAM stage on two streams")
     ap.add_argument("--scope", default="B", choices=["A", "B"],
                     help="A: proposals given (CLIP + scoring only); B: + SAM ViT-H proposal stage (full path)")
     args = ap.parse_args()
@@ -208,14 +211,24 @@ def main():
         if world > 1:
             dist.barrier()
 
+    overlap = gen is not None and not args.no_overlap
+
+    def do_step(i):
+        # one step = one ref completed: its SAM stage + its CLIP/scoring stage.  With overlap the two
+        # stages of consecutive refs run concurrently on two streams (software pipeline over refs).
+        if overlap:
+            pipe.step_overlapped(refs[i % len(refs)], refs[(i + 1) % len(refs)])
+        else:
+            pipe.step(refs[i % len(refs)])
+
     for i in range(args.warmup):
-        pipe.step(refs[i % len(refs)])
+        do_step(i)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        pipe.step(refs[i % len(refs)])
+        do_step(i)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -225,7 +238,7 @@ def main():
     lib.hgl_prof_enable(1)
     nprof = 2
     for i in range(nprof):
-        pipe.step(refs[i % len(refs)])
+        pipe.step(refs[i % len(refs)])   # serial on one stream: per-kernel event times are not overlapped
     torch.cuda.synchronize()
     lib.hgl_prof_enable(0)
     g_n, g_ms, g_fl, g_by = prof_read(lib, 0)
@@ -282,6 +295,7 @@ def main():
                              + f"view synthesis + CLIP ViT-B/16 hybrid {args.fusion} (masking_block 9) on "
                              f"{args.masks} seeded proposals + text encoder (9 strings) + scoring tail + IoU"),
                 "scope": args.scope,
+                "stage_overlap": bool(overlap),
                 "fusion_mode": args.fusion, "proposals": args.masks, "image": "640x640", "queries": 3,
                 "parallelism": f"image-parallel x{world}",
             },

@@ -41,6 +41,7 @@ struct Args {
   int M, N, K, lda, ldw, ldr, ldc;
   float out_scale;
   int tiles_m, tiles_n;
+  int ablate;  // timing experiments only (HGL_X3_ABLATE): 1 = no global loads in the loop, 2 = no LDS stores in the loop
 };
 
 template <int ACT>
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
   const _Float16* As = smem + (wm * 64 + r) * ROW_H + 8 * h;
   const _Float16* Ws = smem + (BM + wn * 64 + r) * ROW_H + 8 * h;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < nk && g.ablate != 1) load_tile(kt + 1);
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       const f16x8 ah0 = *(const f16x8*)(As + 16 * s), al0 = *(const f16x8*)(As + BK + 16 * s);
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);
     }
     __syncthreads();
-    if (kt + 1 < nk) store_tile();
+    if (kt + 1 < nk && g.ablate != 2) store_tile();
     __syncthreads();
   }
 
@@ -331,6 +332,11 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
   g.bias = bias; g.R = R; g.C = C; g.Ch = (_Float16*)Ch; g.Cl = (_Float16*)Cl;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldr = ldr; g.ldc = ldc;
   g.out_scale = ldexpf(1.0f, -sw.scale_log2);
+  {
+    static int abl = -1;
+    if (abl < 0) { const char* v = getenv("HGL_X3_ABLATE"); abl = v ? atoi(v) : 0; }
+    g.ablate = abl;
+  }
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
   const long long nwg = (long long)g.tiles_m * g.tiles_n;

@@ -83,6 +83,39 @@ class HybridGLPipeline:
         self.cum = torch.zeros(4, dtype=torch.int64, device=dev)
         self.iu_log = []  # per sentence (IU_pure, IU_final) device tensors
 
+    def step_overlapped(self, ref: RefBatch, next_ref: RefBatch):
+        """Two-stage software pipeline over refs on two HIP streams: the SAM proposal stage of
+        `next_ref` runs concurrently with the CLIP + scoring stage of `ref` (whose proposals were
+        produced one call earlier).  Fills the CUs that SAM's small-M kernels leave idle.  Only for
+        flows where the CLIP stage does not consume this call's SAM output (benchmark / prefetching
+        driver); results are identical to step()."""
+        if not hasattr(self, "_s_sam"):
+            self._s_sam, self._s_clip = torch.cuda.Stream(), torch.cuda.Stream()
+            self._ev = torch.cuda.Event()
+        cur = torch.cuda.current_stream()
+        self._ev.record(cur)
+        self._s_sam.wait_event(self._ev)
+        self._s_clip.wait_event(self._ev)
+        gen = self.mask_generator
+        with torch.cuda.stream(self._s_sam):
+            self.last_proposals = gen.propose(next_ref.sam_img, resized=next_ref.sam_resized)
+        with torch.cuda.stream(self._s_clip):
+            self.mask_generator = None          # the CLIP stage below must not re-run the SAM stage
+            try:
+                if self.cleanup_given_masks:
+                    import dataclasses
+                    cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
+                    ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
+                out = self.step(ref)
+            finally:
+                self.mask_generator = gen
+        e1, e2 = torch.cuda.Event(), torch.cuda.Event()
+        e1.record(self._s_sam)
+        e2.record(self._s_clip)
+        cur.wait_event(e1)
+        cur.wait_event(e2)
+        return out
+
     def step(self, ref: RefBatch):
         """One dataset item; returns the device tensors of the last sentence (idx, scores)."""
         m = self.model
