@@ -91,6 +91,8 @@ int hgl_launch_win_partition(const float* H, int g, int ws, int nw, int D, float
 int hgl_launch_win_unpartition_add(float* X, int g, int ws, int nw, int D, const float* P, hipStream_t st);
 int hgl_launch_relpos_gather(const float* T, int B, int heads, int S, int size, int L, int use_w,
                              float* rel, hipStream_t st);
+int hgl_launch_relpos_direct(const float* qkv, int ldq, int B, int heads, int S, int size, int hd,
+                             const float* Rh, const float* Rw, float* rel_h, float* rel_w, hipStream_t st);
 int hgl_launch_im2col3x3(const float* in, int g, int C, float* cols, hipStream_t st);
 int hgl_launch_add_rows_bcast(const float* a, long long a_bstride, const float* pe, long long rows_elems,
                               int B, float* out, hipStream_t st);

@@ -94,13 +94,17 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
     HGL_TRY(hgl_launch_gemm(A, b.qkv_w, b.qkv_b, nullptr, p.QKV, M, 3 * D, D, D, D, 0, 3 * D, 1, 0, 0, 0, 0,
                             HGL_ACT_NONE, st));
   }
-  // decomposed rel-pos: T[h][row][r] = q_h[row] . rel_pos[r] for every r, then gathered per (q,k)
-  HGL_TRY(hgl_launch_gemm(p.QKV, b.rel_pos_h, nullptr, nullptr, p.Th, M, L, hd, 3 * D, hd, 0, L, heads, hd, 0,
-                          0, (long long)M * L, HGL_ACT_NONE, st));
-  HGL_TRY(hgl_launch_gemm(p.QKV, b.rel_pos_w, nullptr, nullptr, p.Tw, M, L, hd, 3 * D, hd, 0, L, heads, hd, 0,
-                          0, (long long)M * L, HGL_ACT_NONE, st));
-  HGL_TRY(hgl_launch_relpos_gather(p.Th, B, heads, S, size, L, 0, p.relh, st));
-  HGL_TRY(hgl_launch_relpos_gather(p.Tw, B, heads, S, size, L, 1, p.relw, st));
+  // decomposed rel-pos tables rel_h/rel_w [B*heads, S, size] from the UNSCALED q (image_encoder.py:351-354)
+  if (hd == 80 || hd == 64) {
+    HGL_TRY(hgl_launch_relpos_direct(p.QKV, 3 * D, B, heads, S, size, hd, b.rel_pos_h, b.rel_pos_w, p.relh, p.relw, st));
+  } else {  // generic head dims: q . rel_pos[r] for every r as a batched GEMM, then gathered per (q,k)
+    HGL_TRY(hgl_launch_gemm(p.QKV, b.rel_pos_h, nullptr, nullptr, p.Th, M, L, hd, 3 * D, hd, 0, L, heads, hd, 0,
+                            0, (long long)M * L, HGL_ACT_NONE, st));
+    HGL_TRY(hgl_launch_gemm(p.QKV, b.rel_pos_w, nullptr, nullptr, p.Tw, M, L, hd, 3 * D, hd, 0, L, heads, hd, 0,
+                            0, (long long)M * L, HGL_ACT_NONE, st));
+    HGL_TRY(hgl_launch_relpos_gather(p.Th, B, heads, S, size, L, 0, p.relh, st));
+    HGL_TRY(hgl_launch_relpos_gather(p.Tw, B, heads, S, size, L, 1, p.relw, st));
+  }
   HGL_TRY(hgl_launch_attention(p.QKV, p.QKV + D, p.QKV + 2 * D, p.O, B, heads, S, S, hd, 3 * D, 3 * D, 3 * D, D,
                                (long long)S * 3 * D, (long long)S * 3 * D, (long long)S * 3 * D,
                                (long long)S * D, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, p.relh,

@@ -76,6 +76,37 @@ __global__ __launch_bounds__(256) void relpos_gather_kernel(const float* __restr
   rel[i] = T[((long long)h * B * S + (long long)b * S + q) * L + (qc - k + size - 1)];
 }
 
+// Decomposed rel-pos tables computed directly (image_encoder.py:325-361):
+//   rel_h[bh][q][k] = q_vec . rel_pos_h[qy - k + size-1],  rel_w[bh][q][k] = q_vec . rel_pos_w[qx - k + size-1]
+// one thread per (bh, q, axis, k): an hd-long dot product with float4 loads (q_vec is shared by
+// the 2*size threads of a query, the table rows are L2 resident).  Replaces two padded GEMMs + two gathers.
+template <int HD>
+__global__ __launch_bounds__(256) void relpos_direct_kernel(const float* __restrict__ qkv, int ldq, int B,
+                                                            int heads, int S, int size,
+                                                            const float* __restrict__ Rh,
+                                                            const float* __restrict__ Rw,
+                                                            float* __restrict__ rel_h,
+                                                            float* __restrict__ rel_w, long long total) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= total) return;
+  const int k2 = (int)(i % (2 * size));
+  const int q = (int)((i / (2 * size)) % S);
+  const int bh = (int)(i / ((long long)2 * size * S));
+  const int b = bh / heads, h = bh % heads;
+  const bool wax = k2 >= size;
+  const int k = wax ? k2 - size : k2;
+  const int qc = wax ? q % size : q / size;
+  const float* qv = qkv + ((long long)b * S + q) * ldq + h * HD;
+  const float* rv = (wax ? Rw : Rh) + (long long)(qc - k + size - 1) * HD;
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < HD / 4; ++c) {
+    const f32x4 a = *(const f32x4*)(qv + 4 * c), r = *(const f32x4*)(rv + 4 * c);
+    acc += a[0] * r[0]; acc += a[1] * r[1]; acc += a[2] * r[2]; acc += a[3] * r[3];
+  }
+  (wax ? rel_w : rel_h)[((long long)bh * S + q) * size + k] = acc;
+}
+
 // cols[(y*g+x), c*9 + ky*3+kx] = in[(y+ky-1), (x+kx-1), c] (zero padded), NHWC input
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ in, int g, int C,
                                                         float* __restrict__ cols, long long total) {
@@ -435,6 +466,14 @@ int hgl_launch_relpos_gather(const float* T, int B, int heads, int S, int size, 
   const long long total = (long long)B * heads * S * size;
   hipLaunchKernelGGL(relpos_gather_kernel, dim3(grid1(total)), dim3(256), 0, st, T, B, heads, S, size, L, use_w, rel, total);
   return hgl_check_launch("relpos_gather");
+}
+int hgl_launch_relpos_direct(const float* qkv, int ldq, int B, int heads, int S, int size, int hd,
+                             const float* Rh, const float* Rw, float* rel_h, float* rel_w, hipStream_t st) {
+  const long long total = (long long)B * heads * S * 2 * size;
+  HGL_REQUIRE(hd == 80 || hd == 64, "relpos_direct: head dim %d unsupported", hd);
+  if (hd == 80) hipLaunchKernelGGL(relpos_direct_kernel<80>, dim3(grid1(total)), dim3(256), 0, st, qkv, ldq, B, heads, S, size, Rh, Rw, rel_h, rel_w, total);
+  else hipLaunchKernelGGL(relpos_direct_kernel<64>, dim3(grid1(total)), dim3(256), 0, st, qkv, ldq, B, heads, S, size, Rh, Rw, rel_h, rel_w, total);
+  return hgl_check_launch("relpos_direct");
 }
 int hgl_launch_im2col3x3(const float* in, int g, int C, float* cols, hipStream_t st) {
   const long long total = (long long)g * g * C * 9;
