@@ -41,6 +41,7 @@ struct Args {
   int M, N, K, lda, ldw, ldr, ldc;
   float out_scale;
   int tiles_m, tiles_n;
+  int gm;      // M-tiles per tile group (L2 blocking of the resident tile set)
   int ablate;  // timing experiments only (HGL_X3_ABLATE): 1 = no global loads in the loop, 2 = no LDS stores in the loop
 };
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  constexpr int GM = 8;
+  const int GM = g.gm;
   const int group = bid / (GM * g.tiles_n);
   const int first_m = group * GM;
   const int gm = min(g.tiles_m - first_m, GM);
@@ -336,6 +337,9 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
     static int abl = -1;
     if (abl < 0) { const char* v = getenv("HGL_X3_ABLATE"); abl = v ? atoi(v) : 0; }
     g.ablate = abl;
+    static int gmv = -1;
+    if (gmv < 0) { const char* v = getenv("HGL_X3_GM"); gmv = v ? atoi(v) : 8; if (gmv < 1) gmv = 8; }
+    g.gm = gmv;
   }
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;

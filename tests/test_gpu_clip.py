@@ -108,3 +108,21 @@ def test_linearity_of_head_and_determinism(cuda, b16):
                 fusion_mode="G2L")
     np.testing.assert_allclose(sub.cpu().numpy(), y1[10:14].cpu().numpy(), rtol=0, atol=2e-5)
     assert torch.isfinite(y1).all()
+
+
+def test_pipeline_image_cache_identical(cuda, b16):
+    """two refs of the same image: the cached second ref gives the same indices/metrics as recomputing"""
+    import dataclasses
+    from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
+    _, model = b16
+    ref0, _ = synthetic_ref(0, cuda, N=8)
+    ref1, _ = synthetic_ref(1, cuda, N=8)
+    # second ref: same image/masks as ref0, its own sentences
+    ref_b = dataclasses.replace(ref0, tokens=ref1.tokens, sentences=ref1.sentences, target=ref0.target)
+    p1 = HybridGLPipeline(model, "G2L", 9)
+    p1.step(ref0); out_plain = p1.step(ref_b)
+    p2 = HybridGLPipeline(model, "G2L", 9)
+    p2.step(dataclasses.replace(ref0, image_id=7)); out_cached = p2.step(dataclasses.replace(ref_b, image_id=7))
+    assert torch.equal(out_plain[2][0], out_cached[2][0])          # winning indices
+    assert torch.equal(out_plain[0], out_cached[0])                # hybrid features bit-identical
+    assert p1.metrics()["cum"] == p2.metrics()["cum"]
