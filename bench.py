@@ -290,8 +290,8 @@ def main():
                              + ("SAM ViT-H proposal stage (encoder, 8x8 point grid = 64 prompts x 3 masks, fused "
                                 "post-processing of the 192 candidates, NMS) whose noise masks (random weights) are "
                                 "discarded; connected-component clean-up (min area 800) + second NMS run on the 64 "
-                                "seeded proposal-shaped masks; PIL resize to 1024 done on the host before the timed "
-                                "region) + " if args.scope == "B" else "proposals given (scope A) + ")
+                                "seeded proposal-shaped masks; the Pillow-exact resize to 1024 runs on the device inside "
+                                "the step) + " if args.scope == "B" else "proposals given (scope A) + ")
                              + f"view synthesis + CLIP ViT-B/16 hybrid {args.fusion} (masking_block 9) on "
                              f"{args.masks} seeded proposals + text encoder (9 strings) + scoring tail + IoU"),
                 "scope": args.scope,

@@ -122,6 +122,8 @@ PROTOTYPES = {
     "hgl_score_sentence": (_I, [_VP, _VP, _VP, _VP, _I, _F, _VP, _VP, _I, _I, _F, _I, _I, _F, _I, _I,
                                 _VP, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_synthesize_views": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
+    "hgl_resize_pil_bilinear_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "hgl_resize_pil_bilinear": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _SZ, _VP]),
     "hgl_sam_encode_workspace_bytes": (_SZ, [C.POINTER(HglSamEncoderW)]),
     "hgl_sam_encode": (_I, [C.POINTER(HglSamEncoderW), _VP, _I, _I, _VP, _VP, _SZ, _VP]),
     "hgl_sam_dense_pe": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _VP]),

@@ -28,6 +28,30 @@ __global__ __launch_bounds__(256) void sam_preprocess_kernel(const uint8_t* __re
   out[i] = v;
 }
 
+// One pass of Pillow's 8-bit resampler (Resample.c ImagingResampleHorizontal/Vertical_8bpc) along one
+// axis: out[o][..] = clip8((2^21 + sum_x in[first+x] * k[x]) >> 22), weights/bounds precomputed on the host
+// exactly as precompute_coeffs/normalize_coeffs_8bpc do.  stride_in/out: element strides of the resampled axis;
+// `inner` contiguous bytes (other axis x channels) are handled by consecutive threads.
+__global__ __launch_bounds__(256) void pil_resample_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                           const int* __restrict__ kk, const int* __restrict__ bounds,
+                                                           int ksize, int n_out, long long outer, long long inner,
+                                                           long long in_outer_stride, long long in_axis_stride,
+                                                           long long out_outer_stride, long long out_axis_stride) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  const long long total = outer * n_out * inner;
+  if (i >= total) return;
+  const long long c = i % inner;
+  const int o = (int)((i / inner) % n_out);
+  const long long r = i / (inner * n_out);
+  const int first = bounds[2 * o], cnt = bounds[2 * o + 1];
+  const int* k = kk + (long long)o * ksize;
+  int acc = 1 << 21;
+  const uint8_t* p = in + r * in_outer_stride + (long long)first * in_axis_stride + c;
+  for (int x = 0; x < cnt; ++x) acc += (int)p[(long long)x * in_axis_stride] * k[x];
+  acc >>= 22;
+  out[r * out_outer_stride + (long long)o * out_axis_stride + c] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+}
+
 // Hw[(wy*nwx + wx)*ws*ws + py*ws + px, :] = (y<g && x<g) ? H[y*g+x, :] : 0
 __global__ __launch_bounds__(256) void win_partition_kernel(const float* __restrict__ H, int g, int ws,
                                                             int nw, int D4, float* __restrict__ Hw,
@@ -507,6 +531,36 @@ int hgl_launch_unshuffle_logits(const float* Lg, int P, int g, float* out, hipSt
 }
 
 extern "C" {
+
+size_t hgl_resize_pil_bilinear_workspace_bytes(int H, int out_w, int C) { return hgl_align_up((size_t)H * out_w * C, 256); }
+
+int hgl_resize_pil_bilinear(const uint8_t* img, int H, int W, int C, int out_h, int out_w, const int32_t* kx,
+                            const int32_t* bx, int ksize_x, const int32_t* ky, const int32_t* by, int ksize_y,
+                            uint8_t* out, void* workspace, size_t workspace_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(img && out && kx && bx && ky && by && H > 0 && W > 0 && C > 0 && out_h > 0 && out_w > 0 && ksize_x > 0 && ksize_y > 0,
+              "resize_pil_bilinear: bad arguments");
+  if (!workspace || workspace_bytes < hgl_resize_pil_bilinear_workspace_bytes(H, out_w, C)) {
+    hgl_set_error("resize_pil_bilinear: workspace too small");
+    return HGL_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  uint8_t* tmp = (uint8_t*)workspace;   // [H, out_w, C] after the horizontal pass
+  // horizontal: outer = rows, axis = x (stride C), inner = C
+  {
+    const long long total = (long long)H * out_w * C;
+    hipLaunchKernelGGL(pil_resample_kernel, dim3(grid1(total)), dim3(256), 0, st, img, tmp, (const int*)kx, (const int*)bx,
+                       ksize_x, out_w, (long long)H, (long long)C, (long long)W * C, (long long)C, (long long)out_w * C,
+                       (long long)C);
+  }
+  // vertical: outer = 1, axis = y (stride out_w*C), inner = out_w*C
+  {
+    const long long total = (long long)out_h * out_w * C;
+    hipLaunchKernelGGL(pil_resample_kernel, dim3(grid1(total)), dim3(256), 0, st, tmp, out, (const int*)ky, (const int*)by,
+                       ksize_y, out_h, 1ll, (long long)out_w * C, 0ll, (long long)out_w * C, 0ll, (long long)out_w * C);
+  }
+  return hgl_check_launch("resize_pil_bilinear");
+}
 
 size_t hgl_sam_postprocess_workspace_bytes(int K) { return hgl_align_up((size_t)K * 6 * sizeof(unsigned), 256); }
 

@@ -200,12 +200,7 @@ def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=494
         sents.append(Sentence(3 * j, 3 * j + 1, [3 * j + 2], dirflag, relaflag, n_nouns,
                               torch.from_numpy(attn).to(device)))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-    resized = None
-    if sam_img_size:
-        from PIL import Image
-        from .sam import get_preprocess_shape
-        nh, nw = get_preprocess_shape(H, W, sam_img_size)
-        resized = t(np.array(Image.fromarray(img).resize((nw, nh), Image.BILINEAR)))
+    resized = None   # ResizeLongestSide runs on the device (hgl_resize_pil_bilinear), inside the step
     ref = RefBatch(t(img), t(blur), t(norm), t(masks), t(boxes), t(tokens), t(gt), sents, resized)
     host = dict(img=img, blur=blur, norm=norm, masks=masks, boxes=boxes, tokens=tokens, gt=gt, attn=attn_np)
     return ref, host

@@ -2,9 +2,9 @@
 `sam_model_registry[...]`, `SamAutomaticMaskGenerator(model, ...).generate(image)`.
 
 The ViT-H image encoder, the prompt encoder, the two-way mask decoder and the fused mask
-post-processing (upsampling, thresholds, stability score, boxes, NMS) run in libhybridgl.so
-(hand-written HIP, fp32 MFMA).  Host work kept here, as in the reference: the PIL bilinear
-resize of ResizeLongestSide.apply_image (utils/transforms.py:26-31) and list-of-dict packaging.
+post-processing (upsampling, thresholds, stability score, boxes, NMS, connected-component clean-up)
+and the Pillow-exact ResizeLongestSide resize run in libhybridgl.so (hand-written HIP).  Host work
+kept here: the point grid, the two proposal counts read back, and the list-of-dict packaging.
 """
 import ctypes as C
 import os
@@ -228,6 +228,54 @@ sam_model_registry = {"default": build_sam_vit_h, "vit_h": build_sam_vit_h,
                       "tiny": lambda checkpoint=None, **kw: _build("tiny", checkpoint, **kw)}
 
 
+_PIL_PB = 22
+_coeff_cache = {}
+
+
+def pil_bilinear_coeffs(in_size, out_size):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bilinear filter (host, double precision):
+    int32 weights [out, ksize] and (first, count) bounds."""
+    import math
+    scale = in_size / out_size
+    fs = max(scale, 1.0)
+    support = 1.0 * fs
+    ksize = int(math.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        cnt = min(int(center + support + 0.5), in_size) - xmin
+        w = [max(0.0, 1.0 - abs((x + xmin - center + 0.5) / fs)) for x in range(cnt)]
+        ww = sum(w)
+        for x in range(cnt):
+            kk[xx, x] = int(0.5 + (w[x] / ww if ww != 0.0 else w[x]) * (1 << _PIL_PB))
+        bounds[xx] = (xmin, cnt)
+    return kk, bounds
+
+
+def resize_longest_side(img_u8, long_side):
+    """ResizeLongestSide.apply_image on the device, bit-exact with Pillow: img_u8 [H,W,3] uint8 device tensor."""
+    lib = _lib.load()
+    H, W, Cc = img_u8.shape
+    nh, nw = get_preprocess_shape(H, W, long_side)
+    key = (H, W, nh, nw, str(img_u8.device))
+    tabs = _coeff_cache.get(key)
+    if tabs is None:
+        kx, bx = pil_bilinear_coeffs(W, nw)
+        ky, by = pil_bilinear_coeffs(H, nh)
+        tabs = tuple(torch.from_numpy(a).to(img_u8.device) for a in (kx, bx, ky, by))
+        _coeff_cache[key] = tabs
+    kx, bx, ky, by = tabs
+    out = torch.empty((nh, nw, Cc), dtype=torch.uint8, device=img_u8.device)
+    need = lib.hgl_resize_pil_bilinear_workspace_bytes(H, nw, Cc)
+    ws = ops.workspace(need, img_u8.device, "pil_resize")
+    check(lib.hgl_resize_pil_bilinear(ops._dev(img_u8, torch.uint8, "img"), H, W, Cc, nh, nw, kx.data_ptr(), bx.data_ptr(),
+                                      kx.shape[1], ky.data_ptr(), by.data_ptr(), ky.shape[1], out.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), ops._stream()), "hgl_resize_pil_bilinear")
+    return out
+
+
 def build_point_grid(n):
     """utils/amg.py:179-186."""
     off = 1 / (2 * n)
@@ -268,13 +316,13 @@ class SamAutomaticMaskGenerator:
         """image: uint8 [H,W,3] numpy (or device tensor when `resized` is given).
         Returns device tensors (masks [K,H,W] u8, boxes_xyxy [K,4] i32, iou [K], stab [K], order [K] i32,
         n [1] i32, points [K,2] float64 numpy): candidates order[:n] survive the filters + NMS."""
-        from PIL import Image
         m = self.model
         H, W = image.shape[:2]
         nh, nw = get_preprocess_shape(H, W, m.img_size)
         if resized is None:
-            # ResizeLongestSide.apply_image: PIL bilinear on the host (utils/transforms.py:26-31)
-            resized = torch.from_numpy(np.array(Image.fromarray(np.asarray(image)).resize((nw, nh), Image.BILINEAR))).to(m.device)
+            # ResizeLongestSide.apply_image (utils/transforms.py:26-31): Pillow's bilinear resampler, bit-exact, on the device
+            dev_img = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image)).to(m.device)
+            resized = resize_longest_side(dev_img.contiguous(), m.img_size)
         emb = m.encode(resized)
         pts = self.point_grids[0] * np.array([[W, H]], dtype=np.float64)       # automatic_mask_generator.py:240-241
         tp = pts.copy()

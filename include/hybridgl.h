@@ -279,6 +279,15 @@ typedef struct HglSamDecoderW {        /* prompt_encoder.py + mask_decoder.py + 
   HglLinearW iou_head[3];
 } HglSamDecoderW;
 
+/* ResizeLongestSide.apply_image (utils/transforms.py:26-31) = Pillow Image.resize(BILINEAR) on uint8 HWC,
+ * bit-exact: horizontal then vertical pass of Pillow's 8-bit resampler with 22-bit fixed-point weights.
+ * kx/ky: int32 weights [out, ksize]; bx/by: int32 (first, count) per output index -- computed on the host as
+ * Resample.c precompute_coeffs + normalize_coeffs_8bpc do (hybridgl_amd/sam.py:pil_bilinear_coeffs). */
+size_t hgl_resize_pil_bilinear_workspace_bytes(int H, int out_w, int C);
+int hgl_resize_pil_bilinear(const uint8_t* img, int H, int W, int C, int out_h, int out_w, const int32_t* kx,
+                            const int32_t* bx, int ksize_x, const int32_t* ky, const int32_t* by, int ksize_y,
+                            uint8_t* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Sam.preprocess + ImageEncoderViT.forward (modeling/sam.py:164-174, image_encoder.py:106-116).
  * resized_img: [in_h,in_w,3] uint8 -- the image after ResizeLongestSide.apply_image (PIL
  * bilinear on the host, utils/transforms.py:26-31).  emb: [g*g, out_chans] NHWC rows

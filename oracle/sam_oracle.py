@@ -304,6 +304,55 @@ def preprocess_shape(oldh, oldw, long_side=1024):
     return int(oldh * scale + 0.5), int(oldw * scale + 0.5)
 
 
+_PIL_PB = 32 - 8 - 2   # PRECISION_BITS of Pillow's 8-bit resampler
+
+
+def pil_bilinear_coeffs(in_size, out_size):
+    """Pillow ImagingResample precompute_coeffs + normalize_coeffs_8bpc for the bilinear filter
+    (support 1.0, anti-aliased when shrinking): int32 weights [out, ksize] and (first, count) bounds."""
+    scale = in_size / out_size
+    fs = max(scale, 1.0)
+    support = 1.0 * fs
+    ksize = int(math.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [max(0.0, 1.0 - abs((x + xmin - center + 0.5) / fs)) for x in range(xmax)]
+        ww = sum(w)
+        for x in range(xmax):
+            v = (w[x] / ww if ww != 0.0 else w[x]) * (1 << _PIL_PB)
+            kk[xx, x] = int(0.5 + v)
+        bounds[xx] = (xmin, xmax)
+    return kk, bounds
+
+
+def pil_bilinear_resize(img, oh, ow):
+    """ResizeLongestSide.apply_image (utils/transforms.py:26-31) = PIL Image.resize(BILINEAR) on uint8
+    HWC: horizontal pass then vertical pass, 22-bit fixed-point weights, uint8 intermediate.
+    Bit-exact against Pillow (tests/test_oracle_sam_golden.py)."""
+    H, W, C = img.shape
+    kx, bx = pil_bilinear_coeffs(W, ow)
+    ky, by = pil_bilinear_coeffs(H, oh)
+    tmp = np.zeros((H, ow, C), dtype=np.uint8)
+    for xx in range(ow):
+        xmin, n = bx[xx]
+        acc = np.full((H, C), 1 << (_PIL_PB - 1), dtype=np.int64)
+        for x in range(n):
+            acc += img[:, xmin + x, :].astype(np.int64) * int(kx[xx, x])
+        tmp[:, xx, :] = np.clip(acc >> _PIL_PB, 0, 255)
+    out = np.zeros((oh, ow, C), dtype=np.uint8)
+    for yy in range(oh):
+        ymin, n = by[yy]
+        acc = np.full((ow, C), 1 << (_PIL_PB - 1), dtype=np.int64)
+        for y in range(n):
+            acc += tmp[ymin + y].astype(np.int64) * int(ky[yy, y])
+        out[yy] = np.clip(acc >> _PIL_PB, 0, 255)
+    return out
+
+
 def remove_small_regions(mask, area_thresh, mode):
     """utils/amg.py:267-291 with scipy.ndimage.label (8-connectivity) in place of
     cv2.connectedComponentsWithStats (parity unpinned: OpenCV absent offline)."""

@@ -202,3 +202,14 @@ def test_remove_small_regions_full_size(cuda):
         for i in (0, 17, 63):
             ref, ch = S.remove_small_regions(masks[i], 800, mode)
             assert np.array_equal(out[i], ref) and bool(changed[i]) == ch
+
+
+@pytest.mark.parametrize("shape", [(160, 200, 256), (427, 640, 1024), (640, 640, 1024), (1500, 2000, 1024)])
+def test_resize_longest_side_bit_exact_vs_pillow(cuda, shape):
+    from PIL import Image
+    H, W, L = shape
+    img = np.random.default_rng(H + W).integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    nh, nw = hsam.get_preprocess_shape(H, W, L)
+    ref = np.array(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+    got = hsam.resize_longest_side(T(img, cuda), L).cpu().numpy()
+    assert got.shape == ref.shape and np.array_equal(got, ref)

@@ -96,3 +96,13 @@ def test_amg_generate(g, sd):
     xywh = boxes.copy(); xywh[:, 2] -= xywh[:, 0]; xywh[:, 3] -= xywh[:, 1]
     assert np.abs(xywh - g["amg_bbox"]).max() <= 2
     np.testing.assert_allclose(pts[idx // 3], g["amg_points"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("shape", [(160, 200, 205, 256), (427, 640, 683, 1024), (300, 200, 256, 171), (1500, 2000, 768, 1024)])
+def test_pil_bilinear_resize_bit_exact(shape):
+    """the restated Pillow resampler against Pillow itself (what torchvision's resize(to_pil_image(.)) calls)"""
+    from PIL import Image
+    H, W, oh, ow = shape
+    img = np.random.default_rng(H).integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    ref = np.array(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+    assert np.array_equal(S.pil_bilinear_resize(img, oh, ow), ref)
