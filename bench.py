@@ -267,8 +267,11 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = "gemm_f16x3_kernel<0>" if precision == "f16x3" else "gemm_f32_kernel<0, 32, 1, 3>"
-                traffic = (tj.get(key) or tj.get("gemm_f32_kernel") or {}).get("hbm_bytes_per_launch")
+                prefix = "gemm_f16x3_kernel<0" if precision == "f16x3" else "gemm_f32_kernel<0"
+                for k, v in tj.items():
+                    if k.startswith(prefix) and isinstance(v, dict):
+                        traffic = v.get("hbm_bytes_per_launch")
+                        break
             except Exception:
                 traffic = None
         rec = {
