@@ -100,6 +100,7 @@ PROTOTYPES = {
                            C.POINTER(C.c_double)]),
     "hgl_set_precision": (_I, [_I]),
     "hgl_get_precision": (_I, []),
+    "hgl_gemm_f16x3_select": (_I, [_I]),
     "hgl_register_split_weight": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP]),
     "hgl_unregister_split_weight": (_I, [_VP]),
     "hgl_gemm_f16x3": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _SZ, _VP]),

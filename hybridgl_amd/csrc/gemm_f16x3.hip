@@ -12,8 +12,10 @@
 // the lo halves of one operand row for BK = 64 (128 B + 128 B) plus one 16-byte pad, so the
 // ds_read_b128 fragment reads are conflict free (row stride 272 B = 17 x 16 B).
 #include "hgl_common.h"
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <unordered_map>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -32,6 +34,7 @@ struct SplitW {
 };
 std::unordered_map<const void*, SplitW> g_split;   // fp32 weight pointer -> its fp16 split
 int g_precision = HGL_PREC_F32;
+enum { HGL_X3_V1 = 0, HGL_X3_L = 1, HGL_X3_M = 2, HGL_X3_S = 3 };
 
 struct Args {
   const _Float16 *Ah, *Al, *Wh, *Wl;
@@ -44,6 +47,33 @@ struct Args {
   int gm;      // M-tiles per tile group (L2 blocking of the resident tile set)
   int ablate;  // timing experiments only (HGL_X3_ABLATE): 1 = no global loads in the loop, 2 = no LDS stores in the loop
 };
+
+int g_x3_kernel = -2;   // -2: read HGL_X3_KERNEL on first use; -1: cost model; >= 0: forced
+
+// Cost model on 256 CUs, calibrated on MI355X with cold caches between launches (tools/x3_bench.py with
+// X3_COLD=1, the regime of the pipeline; us): one round of tiles costs a + b * (K / 32), and a partial last round
+// costs nearly a full one.  The 256x256 LDS-DMA tiling wins where there are many tiles and a wide N (the CLIP
+// qkv / fc1 GEMMs, SAM's global-attention qkv); the 128x128 tilings at two workgroups per CU win on the rest (their
+// epilogues overlap the other workgroup's K loop and they quantise better).  Between the two 128x128 kernels the
+// register-staged one keeps two K tiles in flight per workgroup and tolerates HBM-latency weights slightly better,
+// so it is the default; the LDS-DMA 256x128 / 128x128 tilings stay selectable (hgl_gemm_f16x3_select).
+int pick_x3_kernel(int M, int N, int K) {
+  struct Cfg { int kind, bm, bn, slots; double a, b, d; };
+  static const Cfg cfgs[2] = {
+      {HGL_X3_L, 256, 256, 256, 18.0, 2.30, 0.10},
+      {HGL_X3_V1, 128, 128, 512, 13.8, 1.37, 0.25},
+  };
+  const double nk = K / 32.0;
+  int best = HGL_X3_V1;
+  double best_t = 1e30;
+  for (const Cfg& c : cfgs) {
+    const double tiles = (double)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+    const double x = tiles / c.slots, up = ceil(x);
+    const double t = (up - c.d * (up - x)) * (c.a + c.b * nk);
+    if (t < best_t) { best_t = t; best = c.kind; }
+  }
+  return best;
+}
 
 template <int ACT>
 __device__ __forceinline__ float act_apply(float x) {
@@ -164,6 +194,227 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int rbase = row0 + wm * 64 + i * 32 + 4 * h;
+      float rv[16];
+      if (g.R) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = g.R[(long long)min(rbase + (e & 3) + 8 * (e >> 2), mclamp) * g.ldr + colc];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rbase + (e & 3) + 8 * (e >> 2);
+        const float v = act_apply<ACT>(acc[i][j][e] * g.out_scale + bv) + rv[e];
+        if (full_tile || (cok && row < g.M)) {
+          const long long o = (long long)row * g.ldc + col;
+          if (g.C) {
+            g.C[o] = v;
+          } else {
+            const _Float16 hi = (_Float16)v;
+            g.Ch[o] = hi;
+            g.Cl[o] = (_Float16)(v - (float)hi);
+          }
+        }
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Direct-to-LDS variant (global_load_lds_dwordx4): no VGPR staging and no ds_write pass -- on the
+// register-staged kernel above the ds_write_b128 stream (13 cycles per wave-instruction) costs
+// about half of the MFMA time of a K tile.  BK = 32; one stage holds four planes
+// [A_hi | A_lo | W_hi | W_lo], each rows x 64 B with no padding (an LDS-DMA wave-instruction
+// writes 1 KiB = 16 rows contiguously).  Bank conflicts are avoided by an XOR swizzle of the
+// 16-byte chunk index with (row >> 2) & 3, applied to the per-lane GLOBAL source address on the way
+// in and to the ds_read_b128 address on the way out.  Two stages: the DMA for tile t+1 is in flight
+// while tile t is multiplied; one barrier per K tile.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+// One LDS-DMA wave-instruction: lane i copies 16 B from sbase + voff(i) to LDS byte lds_addr + 16*i.  Written as
+// inline asm for the SGPR-base + 32-bit-VGPR-offset addressing form (the builtin keeps a 64-bit VGPR address
+// per piece, which on the 256x256 tile pushes the K loop into scratch).  M0 is compiler-reserved: saved and
+// restored around the instruction.  The compiler does not count these on vmcnt -- every consumer below waits
+// with an explicit s_waitcnt vmcnt(0).
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+
+template <int ACT, int TBM, int TBN, int WGM, int WGN, int OCC, bool INTERLEAVE>
+__global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
+  constexpr int NW = WGM * WGN;
+  constexpr int WTM = TBM / WGM, WTN = TBN / WGN, MI = WTM / 32, NI = WTN / 32;
+  constexpr int PA = TBM / 16 / NW, PW = TBN / 16 / NW;   // 1-KiB pieces per wave per plane
+  constexpr int A_BYTES = TBM * 64, W_BYTES = TBN * 64;    // one plane of one stage
+  constexpr int STAGE = 2 * (A_BYTES + W_BYTES);
+  static_assert(PA >= 1 && PW >= 1 && PA * 16 * NW == TBM && PW * 16 * NW == TBN, "tile/wave shape");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_g[];
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  }
+  const int GM = g.gm;
+  const int group = bid / (GM * g.tiles_n);
+  const int first_m = group * GM;
+  const int gmn = min(g.tiles_m - first_m, GM);
+  const int rem = bid - group * GM * g.tiles_n;
+  const int tile_m = first_m + rem % gmn;
+  const int tile_n = rem / gmn;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int row0 = tile_m * TBM, col0 = tile_n * TBN;
+  const int mclamp = g.M - 1, nclamp = g.N - 1;
+
+  // staging: lane -> (row within the 16-row piece, swizzled source chunk).  Per-lane state is one 32-bit byte
+  // offset per piece row; the plane bases are wave-uniform (SGPR) and advance by 64 B per K tile.
+  const int prow = lane >> 2, pchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  unsigned oa[PA], ow[PW];
+#pragma unroll
+  for (int j = 0; j < PA; ++j)
+    oa[j] = (unsigned)(min(row0 + (wave * PA + j) * 16 + prow, mclamp) * g.lda + pchunk * 8) * 2u;
+#pragma unroll
+  for (int j = 0; j < PW; ++j)
+    ow[j] = (unsigned)(min(col0 + (wave * PW + j) * 16 + prow, nclamp) * g.ldw + pchunk * 8) * 2u;
+  const unsigned char *bAh = (const unsigned char*)g.Ah, *bAl = (const unsigned char*)g.Al;
+  const unsigned char *bWh = (const unsigned char*)g.Wh, *bWl = (const unsigned char*)g.Wl;
+
+  // one 1-KiB piece q (0 .. 2*(PA+PW)-1) of this wave's share of K tile kt; the pieces are spread between the
+  // MFMA groups of the first k-step so that their issue cost hides under the other waves' MFMAs
+  constexpr int NPIECE = 2 * (PA + PW);
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem_g;
+  auto issue_piece = [&](int kt, int stage, int q) {
+    const unsigned sb = lds0 + stage * STAGE;
+    const long long ko = (long long)kt * 64;
+    if (q < 2 * PA) {
+      const int j = q >> 1, lo = q & 1;
+      glds16((lo ? bAl : bAh) + ko, oa[j], sb + lo * A_BYTES + (wave * PA + j) * 1024);
+    } else {
+      const int j = (q - 2 * PA) >> 1, lo = q & 1;
+      glds16((lo ? bWl : bWh) + ko, ow[j], sb + 2 * A_BYTES + lo * W_BYTES + (wave * PW + j) * 1024);
+    }
+  };
+  auto issue = [&](int kt, int stage) {
+#pragma unroll
+    for (int q = 0; q < NPIECE; ++q) issue_piece(kt, stage, q);
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int sw = (r >> 2) & 3;
+  const int co0 = ((0 + h) ^ sw) * 16, co1 = ((2 + h) ^ sw) * 16;
+  const unsigned char* Ab = smem_g + (wm * WTM + r) * 64;
+  const unsigned char* Wb = smem_g + 2 * A_BYTES + (wn * WTN + r) * 64;
+  // Register-double-buffered schedule.  F0 / F1 hold the fragments of k-step 0 / 1 of a stage; the reads of
+  // (t, 0) are issued right after the barrier that publishes stage t and are covered by the MFMAs of (t-1, 1);
+  // the reads of (t, 1) are covered by the MFMAs of (t, 0).  The DMA for stage t+1 is issued between the MFMAs
+  // of (t-1, 1) -- after the barrier, so every wave has finished reading that buffer -- and has a whole K tile
+  // of MFMAs to land.
+  struct Frag { f16x8 ah[MI], al[MI], bh[NI], bl[NI]; };
+  auto read_frag = [&](Frag& f, int stage, int s) {
+    const int co = stage * STAGE + (s ? co1 : co0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      f.bh[j] = *(const f16x8*)(Wb + j * 2048 + co);
+      f.bl[j] = *(const f16x8*)(Wb + W_BYTES + j * 2048 + co);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      f.ah[i] = *(const f16x8*)(Ab + i * 2048 + co);
+      f.al[i] = *(const f16x8*)(Ab + A_BYTES + i * 2048 + co);
+    }
+  };
+  // the 3*MI*NI MFMAs of one k-step (small cross terms first, then hi*hi); with ISSUE also the DMA pieces of
+  // K tile nxt into buffer nstage, spread between the MFMAs
+  auto mfma_step = [&](const Frag& f, int nxt, int nstage, auto issue_tag) {
+    constexpr bool ISSUE = decltype(issue_tag)::value;
+    constexpr int NMF = 3 * MI * NI;
+    constexpr int EVERY = NMF / NPIECE > 0 ? NMF / NPIECE : 1;
+    int q = 0, n = 0;
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const f16x8 a = term == 0 ? f.al[i] : f.ah[i];
+          const f16x8 b = term == 1 ? f.bl[j] : f.bh[j];
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][j], 0, 0, 0);
+          ++n;
+          if (ISSUE && n % EVERY == 0 && q < NPIECE) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(nxt, nstage, q++);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    if (ISSUE)
+      for (; q < NPIECE; ++q) issue_piece(nxt, nstage, q);
+  };
+  const std::true_type yes;
+  const std::false_type no;
+  Frag F0, F1;
+  // stage landed (own DMA pieces) + own LDS reads retired, then the workgroup barrier
+  auto publish = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto iter = [&](int stage, int t, auto issue_tag) {
+    publish();
+    read_frag(F0, stage, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(F1, t + 1, stage ^ 1, issue_tag);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frag(F1, stage, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(F0, 0, 0, no);
+  };
+
+  const int nk = g.K / 32;   // even and >= 2 (K % 64 == 0, checked by the launcher)
+  issue(0, 0);
+  publish();
+  read_frag(F0, 0, 0);
+  issue(1, 1);
+  read_frag(F1, 0, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_step(F0, 0, 0, no);
+  for (int t = 1; t + 1 < nk; t += 2) {
+    iter(1, t, yes);
+    iter(0, t + 1, yes);
+  }
+  iter(1, nk - 1, no);
+  mfma_step(F1, 0, 0, no);
+
+  // ---- epilogue ----
+  const bool full_tile = (row0 + TBM <= g.M) && (col0 + TBN <= g.N);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int col = col0 + wn * WTN + j * 32 + r;
+    const bool cok = col < g.N;
+    const int colc = cok ? col : nclamp;
+    const float bv = g.bias ? g.bias[colc] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int rbase = row0 + wm * WTM + i * 32 + 4 * h;
       float rv[16];
       if (g.R) {
 #pragma unroll
@@ -341,18 +592,29 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
     if (gmv < 0) { const char* v = getenv("HGL_X3_GM"); gmv = v ? atoi(v) : 8; if (gmv < 1) gmv = 8; }
     g.gm = gmv;
   }
-  g.tiles_m = (M + BM - 1) / BM;
-  g.tiles_n = (N + BN - 1) / BN;
-  const long long nwg = (long long)g.tiles_m * g.tiles_n;
-  HGL_REQUIRE(nwg < (1ll << 31), "gemm_f16x3: grid too large");
-  static int variant = -1;   // HGL_X3_VARIANT=bk32 selects BK=32 / 3 workgroups per CU (A/B experiments)
-  if (variant < 0) {
-    const char* v = getenv("HGL_X3_VARIANT");
-    variant = (v && !strcmp(v, "bk32")) ? 1 : 0;
+  // kernel selection (hgl_gemm_f16x3_select / HGL_X3_KERNEL={v1,L,M,S,auto}); all variants accumulate in the
+  // same order and give bit-identical results
+  if (g_x3_kernel == -2) {
+    const char* v = getenv("HGL_X3_KERNEL");
+    g_x3_kernel = -1;
+    if (v) {
+      if (!strcmp(v, "v1")) g_x3_kernel = HGL_X3_V1;
+      else if (!strcmp(v, "L")) g_x3_kernel = HGL_X3_L;
+      else if (!strcmp(v, "M")) g_x3_kernel = HGL_X3_M;
+      else if (!strcmp(v, "S")) g_x3_kernel = HGL_X3_S;
+    }
   }
+  // the LDS-DMA kernels address the operands with 32-bit byte offsets from the plane bases
+  const bool small_offsets = (double)M * lda * 2.0 < 4.0e9 && (double)N * K * 2.0 < 4.0e9;
+  int kind = g_x3_kernel >= 0 ? g_x3_kernel : pick_x3_kernel(M, N, K);
+  if (!small_offsets) kind = HGL_X3_V1;
   HglProfScope prof(HGL_PROF_GEMM_X3, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
 #define HGL_X3_LAUNCH(ACT_, BK_, OCC_)                                                                        \
   do {                                                                                                        \
+    g.tiles_m = (M + BM - 1) / BM;                                                                            \
+    g.tiles_n = (N + BN - 1) / BN;                                                                            \
+    const long long nwg = (long long)g.tiles_m * g.tiles_n;                                                   \
+    HGL_REQUIRE(nwg < (1ll << 31), "gemm_f16x3: grid too large");                                            \
     const size_t lds_ = (size_t)(BM + BN) * (2 * BK_ + 8) * sizeof(_Float16);                                 \
     static bool set_ = false;                                                                                 \
     if (!set_) {                                                                                              \
@@ -361,7 +623,27 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
     }                                                                                                         \
     hipLaunchKernelGGL((gemm_f16x3_kernel<ACT_, BK_, OCC_>), dim3((unsigned)nwg), dim3(NTHREADS), lds_, st, g); \
   } while (0)
-#define HGL_X3_VARIANTS(ACT_) do { if (variant == 1) HGL_X3_LAUNCH(ACT_, 32, 3); else HGL_X3_LAUNCH(ACT_, 64, 2); } while (0)
+#define HGL_X3G_LAUNCH(ACT_, TBM_, TBN_, WGM_, WGN_, OCC_, IL_)                                                  \
+  do {                                                                                                        \
+    g.tiles_m = (M + TBM_ - 1) / TBM_;                                                                        \
+    g.tiles_n = (N + TBN_ - 1) / TBN_;                                                                        \
+    const long long nwg = (long long)g.tiles_m * g.tiles_n;                                                   \
+    HGL_REQUIRE(nwg < (1ll << 31), "gemm_f16x3: grid too large");                                            \
+    const size_t lds_ = (size_t)4 * (TBM_ + TBN_) * 64;                                                     \
+    static bool set_ = false;                                                                                 \
+    if (!set_) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)gemm_x3g_kernel<ACT_, TBM_, TBN_, WGM_, WGN_, OCC_, IL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+      set_ = true;                                                                                            \
+    }                                                                                                         \
+    hipLaunchKernelGGL((gemm_x3g_kernel<ACT_, TBM_, TBN_, WGM_, WGN_, OCC_, IL_>), dim3((unsigned)nwg), dim3(WGM_ * WGN_ * 64), lds_, st, g); \
+  } while (0)
+#define HGL_X3_VARIANTS(ACT_)                                  \
+  do {                                                         \
+    if (kind == 1) HGL_X3G_LAUNCH(ACT_, 256, 256, 2, 4, 1, true);    \
+    else if (kind == 2) HGL_X3G_LAUNCH(ACT_, 256, 128, 4, 2, 1, true); \
+    else if (kind == 3) HGL_X3G_LAUNCH(ACT_, 128, 128, 2, 2, 2, true); \
+    else HGL_X3_LAUNCH(ACT_, 64, 2);                           \
+  } while (0)
   switch (act) {
     case HGL_ACT_QUICKGELU: HGL_X3_VARIANTS(HGL_ACT_QUICKGELU); break;
     case HGL_ACT_GELU: HGL_X3_VARIANTS(HGL_ACT_GELU); break;
@@ -380,6 +662,12 @@ int hgl_set_precision(int mode) {
 }
 
 int hgl_get_precision(void) { return g_precision; }
+
+int hgl_gemm_f16x3_select(int kind) {
+  HGL_REQUIRE(kind >= -1 && kind <= HGL_X3_S, "gemm_f16x3_select: unknown kernel %d", kind);
+  g_x3_kernel = kind;
+  return HGL_OK;
+}
 
 int hgl_register_split_weight(const float* w_fp32, int N, int K, int scale_log2, void* hi, void* lo, void* stream) {
   HGL_TRY(hgl_require_device());

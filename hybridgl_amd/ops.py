@@ -86,6 +86,14 @@ def set_precision(mode):
     check(_lib.load().hgl_set_precision({"f32": 0, "f16x3": 1}[mode]), "hgl_set_precision")
 
 
+X3_KERNELS = {"auto": -1, "v1": 0, "L": 1, "M": 2, "S": 3}
+
+
+def select_x3_kernel(kind="auto"):
+    """Pins the tiling of the f16x3 GEMM ('auto' = cost model; all tilings are bit-identical)."""
+    check(_lib.load().hgl_gemm_f16x3_select(X3_KERNELS[kind]), "hgl_gemm_f16x3_select")
+
+
 def gemm_f16x3(a, w, bias=None, residual=None, act="none", out=None):
     """gemm() through the split-fp16 matrix-core path (registers w on first use)."""
     lib = _lib.load()

@@ -68,6 +68,52 @@ def test_gemm_f16x3(cuda, M, N, K, act):
     assert (np.abs(y - z) / scale).max() < 3e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 200, 64), (777, 1000, 192), (1031, 520, 1280), (64, 3000, 128)])
+def test_gemm_f16x3_tilings_bit_identical(cuda, M, N, K):
+    """Every tiling of the f16x3 GEMM (register-staged, LDS-DMA 256x256 / 256x128 / 128x128) accumulates in the
+    same order: outputs must be bit-identical, ragged edges included, and the cost model must pick one of them."""
+    rng = np.random.default_rng(M + N + K)
+    a = T(rng.standard_normal((M, K)).astype(np.float32), cuda)
+    w = T((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32), cuda)
+    b = T(rng.standard_normal(N).astype(np.float32), cuda)
+    r = T(rng.standard_normal((M, N)).astype(np.float32), cuda)
+    try:
+        outs = {}
+        for kind in ("v1", "L", "M", "S", "auto"):
+            ops.select_x3_kernel(kind)
+            outs[kind] = ops.gemm_f16x3(a, w, b, r, "gelu").cpu().numpy()
+    finally:
+        ops.select_x3_kernel("auto")
+    for kind in ("L", "M", "S", "auto"):
+        assert np.array_equal(outs[kind], outs["v1"]), kind
+    z = a.cpu().numpy().astype(np.float64) @ w.cpu().numpy().astype(np.float64).T + b.cpu().numpy()
+    from scipy.special import erf
+    z = 0.5 * z * (1 + erf(z / np.sqrt(2))) + r.cpu().numpy()
+    assert np.abs(outs["v1"] - z).max() < 3e-5
+
+
+def test_gemm_f16x3_inplace_residual(cuda):
+    """residual aliasing the output (x += proj(...)) on every tiling"""
+    rng = np.random.default_rng(5)
+    M, N, K = 520, 384, 128
+    a = T(rng.standard_normal((M, K)).astype(np.float32), cuda)
+    w = T((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32), cuda)
+    c0 = rng.standard_normal((M, N)).astype(np.float32)
+    try:
+        ref = None
+        for kind in ("v1", "L", "M", "S"):
+            ops.select_x3_kernel(kind)
+            c = T(c0, cuda)
+            ops.gemm_f16x3(a, w, None, c, "none", out=c)
+            y = c.cpu().numpy()
+            ref = y if ref is None else ref
+            assert np.array_equal(y, ref), kind
+    finally:
+        ops.select_x3_kernel("auto")
+    z = a.cpu().numpy().astype(np.float64) @ w.cpu().numpy().astype(np.float64).T + c0
+    assert np.abs(ref - z).max() < 3e-5
+
+
 def test_gemm_inplace_residual_and_asymmetry(cuda):
     """A = I with an asymmetric W catches a transposed C write; residual aliasing C must work."""
     n = 160

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Kernel-only timing of the f16x3 GEMM variants (HGL_X3_KERNEL=v1|L|M|S) on the hot-path shapes.
+
+Uses the library's HIP-event profiler (class 3 = the f16x3 GEMM launch alone, without the A split) and checks
+every variant against the fp32-MFMA GEMM.  Run one process per variant: the choice is read once.
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from hybridgl_amd import _lib, ops
+
+SHAPES = [  # (name, M, N, K, act, residual)
+    ("clip qkv", 25216, 2304, 768, "none", False),
+    ("clip out", 25216, 768, 768, "none", True),
+    ("clip fc1", 25216, 3072, 768, "quickgelu", False),
+    ("clip fc2", 25216, 768, 3072, "none", True),
+    ("clip qkv N", 12608, 2304, 768, "none", False),
+    ("sam qkv win", 4900, 3840, 1280, "none", False),
+    ("sam proj win", 4900, 1280, 1280, "none", False),
+    ("sam lin1", 4096, 5120, 1280, "gelu", False),
+    ("sam lin2", 4096, 1280, 5120, "none", True),
+    ("sam qkv glob", 4096, 3840, 1280, "none", False),
+    ("sam proj glob", 4096, 1280, 1280, "none", False),
+    ("k2560", 4096, 3840, 2560, "none", False),
+    ("k5120", 4096, 3840, 5120, "none", False),
+    ("h1280", 4096, 1920, 1280, "none", False),
+    ("h5120", 4096, 1920, 5120, "none", False),
+    ("text qkv", 693, 1536, 512, "none", False),
+    ("ragged", 1000, 1000, 192, "relu", True),
+]
+
+
+def main():
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    kind = os.environ.get("HGL_X3_KERNEL", "auto")
+    tot_ms = tot_fl = 0.0
+    for name, M, N, K, act, res in SHAPES:
+        torch.manual_seed(0)
+        A = torch.randn(M, K, device=dev)
+        W = torch.randn(N, K, device=dev) / K ** 0.5
+        b = torch.randn(N, device=dev)
+        R = torch.randn(M, N, device=dev) if res else None
+        ref = ops.gemm(A, W, b, R, act)
+        out = ops.gemm_f16x3(A, W, b, R, act)
+        err = float((out - ref).abs().max() / ref.abs().max())
+        for _ in range(3):
+            ops.gemm_f16x3(A, W, b, R, act, out=out)
+        torch.cuda.synchronize()
+        lib.hgl_prof_enable(1)
+        flush = torch.empty(1 << 28, device=dev) if os.environ.get("X3_COLD") else None   # 1 GiB: evicts L2 + MALL
+        for _ in range(10):
+            if flush is not None:
+                flush.fill_(1.0)
+            ops.gemm_f16x3(A, W, b, R, act, out=out)
+        torch.cuda.synchronize()
+        lib.hgl_prof_enable(0)
+        n, ms, fl, by = C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
+        lib.hgl_prof_read(3, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
+        tf = fl.value / ms.value / 1e9
+        if not name.startswith(("text", "ragged", "k", "h")):
+            tot_ms += ms.value / n.value
+            tot_fl += fl.value / n.value
+        print(f"x3[{kind}] {name:14s} M={M:6d} N={N:5d} K={K:5d} {ms.value / n.value * 1e3:8.1f} us {tf:7.1f} TF/s relerr {err:.1e}"
+              + ("  MISMATCH" if not err < 2e-6 else ""))
+    print(f"x3[{kind}] total {tot_ms * 1e3:8.1f} us  {tot_fl / tot_ms / 1e9:7.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
