@@ -18,6 +18,8 @@
 //   * everything fp32: exact products, fp32 accumulation -> matches the fp32 reference.
 #include "hgl_common.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 namespace {
 
 constexpr int KV_CHUNK = 64;
@@ -250,10 +252,18 @@ __device__ __forceinline__ void split4(const f32x4 v, h16x4& hi, h16x4& lo) {
   }
 }
 
-template <int HD>
+// RELW > 0: decomposed rel-pos bias of a RELW x RELW window (Sk == RELW*RELW, 2*RELW <= 32, e.g. SAM's 14 x 14)
+// evaluated ON THE MATRIX CORES: bias[q][key] = rel_h[q][key / RELW] + rel_w[q][key % RELW] = R[q][:] . E[key][:]
+// with R[q] = [rel_h row | rel_w row | 0] (32 wide, split hi+lo like every other operand) and E[key] the 0/1
+// indicator of (key / RELW, RELW + key % RELW).  E is appended to the staged K rows, so the bias costs two more
+// k-steps (4 MFMAs) per key tile and no index arithmetic.  (The generic path divides and issues two dependent
+// global loads per score; on the windowed blocks that made the kernel 3x slower than its MFMA work.)
+template <int HD, int RELW>
 __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   constexpr int KS = HD / 16;                 // k-steps of the QK^T contraction
-  constexpr int KROW = 2 * HD + 8;            // halfs per staged K row: hi | lo | pad (odd multiple of 16 B)
+  constexpr int EW = RELW > 0 ? 32 : 0;       // indicator columns appended to a K row
+  constexpr int KROW = 2 * HD + EW + 8;       // halfs per staged K row: hi | lo | E | pad (odd multiple of 16 B)
+  static_assert(2 * RELW <= 32, "window side too large for the MFMA bias");
   constexpr int DT = (HD + 31) / 32;          // 32-wide d tiles of the output
   constexpr int VROWS = DT * 32;              // V^T rows (zero rows beyond HD)
   constexpr int VLD = KV_CHUNK + 4;           // halfs per V^T row (136 B: conflict-free 8-byte reads)
@@ -276,7 +286,13 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   const float* kp = a.k + b * a.skb + hh * HD;
   const float* vp = a.v + b * a.svb + hh * HD;
 
-  // Q fragments (pre-scaled in fp32, then split): lane (r,h) element j of step s = Q[q][16s + 8h + j]
+  // Q fragments (pre-scaled in fp32, then split): lane (r,h) element j of step s = Q[q][16s + 8h + j].
+  // The scores are moved to log2 units AFTER the QK^T product (one multiply per score) so that the softmax is one
+  // v_exp_f32 per element: the precise expf made this kernel VALU-bound (~10 instructions per exponential
+  // against 33 MFMAs per key tile).  Folding log2(e) into the Q scale instead is NOT equivalent in practice: it
+  // produced rows with 4e-5 errors in the parity tests.
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float qscale = a.scale;
   h16x8 qh[KS], ql[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
@@ -285,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
       f32x4 v = qvalid ? *(const f32x4*)(qp + 16 * s + 8 * h + 4 * half) : f32x4{0, 0, 0, 0};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float x = v[e] * a.scale;
+        const float x = v[e] * qscale;
         const _Float16 hi = (_Float16)x;
         qh[s][4 * half + e] = hi;
         ql[s][4 * half + e] = (_Float16)(x - (float)hi);
@@ -308,6 +324,22 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   const float* relw = a.rel_w ? a.rel_w + ((long long)bh * a.Sq + (qvalid ? qi : 0)) * a.kw : nullptr;
   int sk_eff = a.Sk;
   if (a.mask_kind == HGL_MASK_CAUSAL) sk_eff = min(a.Sk, (int)(blockIdx.x * 4 + 4) * 32);
+  // R fragments of the MFMA bias: lane (r,h) element j of step c = R[q][16c + 8h + j]
+  h16x8 rbh[2], rbl[2];
+  if constexpr (RELW > 0) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = 16 * c + 8 * h + j;
+        float x = 0.f;
+        if (idx < RELW) x = relh[idx];
+        else if (idx < 2 * RELW) x = relw[idx - RELW];
+        const _Float16 hi = (_Float16)x;
+        rbh[c][j] = hi;
+        rbl[c][j] = (_Float16)(x - (float)hi);
+      }
+  }
 
   // ---- staging (software pipelined through registers) ----
   f32x4 pk[NLK], pv[NLV];
@@ -323,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
     for (int i = 0; i < NLV; ++i)
       pv[i] = *(const f32x4*)(vp + (long long)min(kc + vkey, a.Sk - 1) * a.ldv + 4 * (vg + 4 * i));
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NLK; ++i) {
       const int idx = t + 256 * i;
@@ -332,6 +364,14 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
       split4(pk[i], hi, lo);
       *(h16x4*)(Ks + row * KROW + c4 * 4) = hi;
       *(h16x4*)(Ks + row * KROW + HD + c4 * 4) = lo;
+    }
+    if constexpr (RELW > 0) {   // indicator columns: thread -> (key row t/4, 8 of the 32 columns)
+      const int row = t >> 2, j0 = 8 * (t & 3), kg = kc + row;
+      const int ih = kg / RELW, iw = RELW + kg - ih * RELW;
+      h16x8 e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = (j0 + j == ih || j0 + j == iw) ? (_Float16)1.f : (_Float16)0.f;
+      *(h16x8*)(Ks + row * KROW + 2 * HD + j0) = e;
     }
 #pragma unroll
     for (int i = 0; i < NLV; ++i) {
@@ -352,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
     }
   }
   load_chunk(0);
-  store_chunk();
+  store_chunk(0);
   __syncthreads();
 
   for (int kc = 0; kc < sk_eff; kc += KV_CHUNK) {
@@ -374,8 +414,20 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, ql[c], s, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh[c], s, 0, 0, 0);
       }
+      if constexpr (RELW > 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const h16x8 e8 = *(const h16x8*)(krow + 2 * HD + 16 * c);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(e8, rbl[c], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(e8, rbh[c], s, 0, 0, 0);
+        }
+      }
       // s[e] = S^T[key = kbase + (e&3) + 8*(e>>2) + 4*h][query qi]
-      if (relh) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] *= LOG2E;
+      if constexpr (RELW > 0) {
+        // bias already accumulated by the MFMAs above
+      } else if (relh) {
         if ((a.kw & 31) == 0) {
           const float rh = relh[kbase / a.kw];
           const float* rw = relw + (kbase % a.kw) + 4 * h;
@@ -383,13 +435,13 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
           for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 w4 = *(const f32x4*)(rw + 8 * g4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s[4 * g4 + i] += rh + w4[i];
+            for (int i = 0; i < 4; ++i) s[4 * g4 + i] = fmaf(rh + w4[i], LOG2E, s[4 * g4 + i]);
           }
         } else {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (kg < a.Sk) s[e] += relh[kg / a.kw] + relw[kg % a.kw];
+            if (kg < a.Sk) s[e] = fmaf(relh[kg / a.kw] + relw[kg % a.kw], LOG2E, s[e]);
           }
         }
       }
@@ -408,12 +460,12 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(m_run, mx);
       const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-      const float alpha = expf(m_run - m_use);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
       float rs = 0.f;
       h16x8 ph[2], pl[2];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float p = expf(s[e] - m_use);
+        const float p = __builtin_amdgcn_exp2f(s[e] - m_use);
         rs += p;
         const _Float16 hi = (_Float16)p;
         ph[e >> 3][e & 7] = hi;
@@ -428,6 +480,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
       // O^T += V^T P^T ; A operand element j of lane (d, h) = V^T[d][kt*32 + 16*s2 + 8*(j>>2) + 4*h + (j&3)]
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        if (kbase + 16 * s2 >= sk_eff) break;   // uniform: the keys of this k-step are all beyond the sequence (P = 0)
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
           const int off = (d * 32 + r) * VLD + kt * 32 + 16 * s2 + 4 * h;
@@ -444,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
     }
     __syncthreads();
     if (has_next) {
-      store_chunk();
+      store_chunk(kc + KV_CHUNK);
       __syncthreads();
     }
   }
@@ -474,7 +527,12 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.Sq + 127) / 128, a.B * a.H);
   HglProfScope prof(HGL_PROF_ATTN, 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD,
                     4.0 * a.B * a.H * HD * (2.0 * a.Sq + 2.0 * a.Sk), st);
-  if (hgl_precision() == HGL_PREC_F16X3) hipLaunchKernelGGL(attn_x3_kernel<HD>, grid, dim3(256), 0, st, a);
+  if (hgl_precision() == HGL_PREC_F16X3) {
+    if (HD == 80 && a.rel_h && a.kh == 14 && a.kw == 14 && a.Sk == 196 && a.mask_kind == HGL_MASK_NONE)
+      hipLaunchKernelGGL((attn_x3_kernel<HD, HD == 80 ? 14 : 0>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((attn_x3_kernel<HD, 0>), grid, dim3(256), 0, st, a);
+  }
   else hipLaunchKernelGGL(attn_f32_kernel<HD>, grid, dim3(256), 0, st, a);
   return hgl_check_launch("attention");
 }

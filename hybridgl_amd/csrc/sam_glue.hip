@@ -12,6 +12,9 @@
 #include "hgl_common.h"
 #include <math.h>
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+
 namespace {
 
 inline unsigned grid1(long long n, int block = 256) { return (unsigned)((n + block - 1) / block); }
@@ -102,33 +105,49 @@ __global__ __launch_bounds__(256) void relpos_gather_kernel(const float* __restr
 
 // Decomposed rel-pos tables computed directly (image_encoder.py:325-361):
 //   rel_h[bh][q][k] = q_vec . rel_pos_h[qy - k + size-1],  rel_w[bh][q][k] = q_vec . rel_pos_w[qx - k + size-1]
-// one thread per (bh, q, axis, k): an hd-long dot product with float4 loads (q_vec is shared by
-// the 2*size threads of a query, the table rows are L2 resident).  Replaces two padded GEMMs + two gathers.
+// One workgroup = (bh, 256 queries, axis).  The axis' (2*size-1) x HD table sits in LDS with rows padded to HD+4
+// floats (row stride 84 / 68 dwords: the 16 lanes of a ds_read_b128 group, which read consecutive rows on the w
+// axis, fall on distinct banks; on the h axis a row of the image shares one table row = broadcast).  Each thread
+// keeps its query vector in registers and walks the `size` table rows it needs.  Replaces two padded GEMMs + two
+// gathers; the per-output version of this kernel was load-instruction bound (64 us per windowed block, now ~10).
 template <int HD>
-__global__ __launch_bounds__(256) void relpos_direct_kernel(const float* __restrict__ qkv, int ldq, int B,
-                                                            int heads, int S, int size,
-                                                            const float* __restrict__ Rh,
+__global__ __launch_bounds__(256) void relpos_direct_kernel(const float* __restrict__ qkv, int ldq, int heads, int S,
+                                                            int size, const float* __restrict__ Rh,
                                                             const float* __restrict__ Rw,
-                                                            float* __restrict__ rel_h,
-                                                            float* __restrict__ rel_w, long long total) {
-  const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i >= total) return;
-  const int k2 = (int)(i % (2 * size));
-  const int q = (int)((i / (2 * size)) % S);
-  const int bh = (int)(i / ((long long)2 * size * S));
+                                                            float* __restrict__ rel_h, float* __restrict__ rel_w) {
+  extern __shared__ __attribute__((aligned(16))) float rp_tab[];   // [(2*size-1)][HD+4]
+  constexpr int LD = HD + 4;
+  const int axis = blockIdx.z, bh = blockIdx.y;
   const int b = bh / heads, h = bh % heads;
-  const bool wax = k2 >= size;
-  const int k = wax ? k2 - size : k2;
-  const int qc = wax ? q % size : q / size;
-  const float* qv = qkv + ((long long)b * S + q) * ldq + h * HD;
-  const float* rv = (wax ? Rw : Rh) + (long long)(qc - k + size - 1) * HD;
-  float acc = 0.f;
-#pragma unroll
-  for (int c = 0; c < HD / 4; ++c) {
-    const f32x4 a = *(const f32x4*)(qv + 4 * c), r = *(const f32x4*)(rv + 4 * c);
-    acc += a[0] * r[0]; acc += a[1] * r[1]; acc += a[2] * r[2]; acc += a[3] * r[3];
+  const float* R = axis ? Rw : Rh;
+  const int nrow = 2 * size - 1;
+  for (int i = threadIdx.x; i < nrow * (HD / 4); i += 256) {
+    const int rr = i / (HD / 4), c = i % (HD / 4);
+    *(f32x4*)(rp_tab + rr * LD + 4 * c) = *(const f32x4*)(R + (long long)rr * HD + 4 * c);
   }
-  (wax ? rel_w : rel_h)[((long long)bh * S + q) * size + k] = acc;
+  __syncthreads();
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= S) return;
+  f32x4 qv[HD / 4];
+  const float* qp = qkv + ((long long)b * S + q) * ldq + h * HD;
+#pragma unroll
+  for (int c = 0; c < HD / 4; ++c) qv[c] = *(const f32x4*)(qp + 4 * c);
+  const int qc = axis ? q % size : q / size;
+  float* out = (axis ? rel_w : rel_h) + ((long long)bh * S + q) * size;
+  const float* row = rp_tab + (qc + size - 1) * LD;   // k = 0; row index falls by one per k
+  for (int k = 0; k < size; k += 2) {                 // size is even (14 or 64): two outputs per 8-byte store
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      const f32x4 r0 = *(const f32x4*)(row + 4 * c), r1 = *(const f32x4*)(row - LD + 4 * c);
+      // same summation order as a sequential dot product over the head dim
+      a0 += qv[c][0] * r0[0]; a0 += qv[c][1] * r0[1]; a0 += qv[c][2] * r0[2]; a0 += qv[c][3] * r0[3];
+      a1 += qv[c][0] * r1[0]; a1 += qv[c][1] * r1[1]; a1 += qv[c][2] * r1[2]; a1 += qv[c][3] * r1[3];
+    }
+    f32x2 o; o[0] = a0; o[1] = a1;
+    *(f32x2*)(out + k) = o;
+    row -= 2 * LD;
+  }
 }
 
 // cols[(y*g+x), c*9 + ky*3+kx] = in[(y+ky-1), (x+kx-1), c] (zero padded), NHWC input
@@ -262,21 +281,37 @@ __device__ __forceinline__ void src_idx(float scale, int dst, int in_size, int& 
   l0 = 1.f - l1;
 }
 
-// One workgroup = a 16x16 tile of output pixels of one candidate.  The low-res logits the tile
-// touches (a <= 32x32 patch for every realistic size ratio) are staged in LDS once, so the 16
-// taps per pixel are LDS reads instead of scattered global loads.
-constexpr int PT = 16;     // output tile side
-constexpr int PR = 32;     // max staged low-res patch side
+// One workgroup = a 64x64 tile of output pixels of one candidate; a thread computes 16 consecutive pixels of one
+// row and stores them as one 16-byte word.  The low-res logits the tile touches (a <= 48x48 patch for every
+// realistic size ratio) are staged in LDS once, so the 16 taps per pixel are LDS reads instead of scattered global
+// loads.  (The first version used 16x16 tiles with one pixel per thread: 300k workgroups whose fixed cost -- bounds,
+// staging, two barriers, the reduction, atomics -- was 95 % of the 3.3 ms the kernel took.)
+constexpr int PTW = 64, PTH = 64;   // output tile
+constexpr int PPX = 16;             // pixels per thread (one row segment)
+constexpr int PR = 48;              // max staged low-res patch side
 
 __global__ __launch_bounds__(256) void sam_postprocess_kernel(PostArgs a) {
   __shared__ float patch[PR * PR];
   __shared__ unsigned red[6 * 4];
   const int k = blockIdx.z;
-  if (a.iou && !(a.iou[k] > a.iou_thresh)) return;  // filtered before any pixel work (uniform)
-  const int tx = threadIdx.x & (PT - 1), ty = threadIdx.x >> 4;
-  const int X0 = blockIdx.x * PT, Y0 = blockIdx.y * PT;
-  const int X = X0 + tx, Y = Y0 + ty;
-  const int Xl = min(X0 + PT - 1, a.W - 1), Yl = min(Y0 + PT - 1, a.H - 1);
+  const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;
+  const int X0 = blockIdx.x * PTW, Y0 = blockIdx.y * PTH;
+  const int Xb = X0 + tx * PPX, Y = Y0 + ty;
+  if (a.iou && !(a.iou[k] > a.iou_thresh)) {
+    // filtered before any pixel work (uniform): the candidate keeps an all-zero mask
+    if (Xb < a.W && Y < a.H) {
+      const int npx = min(PPX, a.W - Xb);
+      const long long pix0 = (long long)k * a.H * a.W + (long long)Y * a.W + Xb;
+      if (npx == PPX && (pix0 & 15) == 0) {
+        const u32x4g z = {0, 0, 0, 0};
+        *(u32x4g*)(a.masks + pix0) = z;
+      } else {
+        for (int p = 0; p < npx; ++p) a.masks[pix0 + p] = 0;
+      }
+    }
+    return;
+  }
+  const int Xl = min(X0 + PTW - 1, a.W - 1), Yl = min(Y0 + PTH - 1, a.H - 1);
   const float* L = a.low + (long long)k * a.hl * a.wl;
   const float sy1 = (float)a.hi / (float)a.H, sx1 = (float)a.wi / (float)a.W;
   const float s2y = (float)a.hl / (float)a.S, s2x = (float)a.wl / (float)a.S;
@@ -310,38 +345,58 @@ __global__ __launch_bounds__(256) void sam_postprocess_kernel(PostArgs a) {
 
   const long long HW = (long long)a.H * a.W;
   unsigned inter = 0, uni = 0, minx = 0x7fffffff, miny = 0x7fffffff, maxx = 0, maxy = 0, any = 0;
-  if (X < a.W && Y < a.H) {
-    int y0, y1, x0, x1;
-    float ly0, ly1, lx0, lx1;
+  if (Xb < a.W && Y < a.H) {
+    // row-dependent part, shared by the thread's pixels
+    int y0, y1;
+    float ly0, ly1;
     src_idx(sy1, Y, a.hi, y0, y1, ly0, ly1);
-    src_idx(sx1, X, a.wi, x0, x1, lx0, lx1);
-    float tap[2][2];
-    const int tyv[2] = {y0, y1}, txv[2] = {x0, x1};
+    const int tyv[2] = {y0, y1};
+    int v0[2], v1[2];
+    float m0[2], m1[2];
 #pragma unroll
-    for (int iy = 0; iy < 2; ++iy) {
-      int v0, v1;
-      float m0, m1;
-      src_idx(s2y, tyv[iy], a.hl, v0, v1, m0, m1);
+    for (int iy = 0; iy < 2; ++iy) src_idx(s2y, tyv[iy], a.hl, v0[iy], v1[iy], m0[iy], m1[iy]);
+    unsigned bytes[PPX / 4] = {0, 0, 0, 0};
+    const int npx = min(PPX, a.W - Xb);
+    const long long pix0 = (long long)k * HW + (long long)Y * a.W + Xb;
 #pragma unroll
-      for (int ix = 0; ix < 2; ++ix) {
-        int u0, u1;
-        float n0, n1;
-        src_idx(s2x, txv[ix], a.wl, u0, u1, n0, n1);
-        const float top = ld(v0, u0) * n0 + ld(v0, u1) * n1;
-        const float bot = ld(v1, u0) * n0 + ld(v1, u1) * n1;
-        tap[iy][ix] = top * m0 + bot * m1;
+    for (int p = 0; p < PPX; ++p) {
+      if (p < npx) {
+        const int X = Xb + p;
+        int x0, x1;
+        float lx0, lx1;
+        src_idx(sx1, X, a.wi, x0, x1, lx0, lx1);
+        float tap[2][2];
+        const int txv[2] = {x0, x1};
+#pragma unroll
+        for (int ix = 0; ix < 2; ++ix) {
+          int u0, u1;
+          float n0, n1;
+          src_idx(s2x, txv[ix], a.wl, u0, u1, n0, n1);
+#pragma unroll
+          for (int iy = 0; iy < 2; ++iy) {
+            const float top = ld(v0[iy], u0) * n0 + ld(v0[iy], u1) * n1;
+            const float bot = ld(v1[iy], u0) * n0 + ld(v1[iy], u1) * n1;
+            tap[iy][ix] = top * m0[iy] + bot * m1[iy];
+          }
+        }
+        const float top = tap[0][0] * lx0 + tap[0][1] * lx1;
+        const float bot = tap[1][0] * lx0 + tap[1][1] * lx1;
+        const float v = top * ly0 + bot * ly1;
+        const bool on = v > a.thr;
+        bytes[p >> 2] |= (on ? 1u : 0u) << (8 * (p & 3));
+        if (a.full_logits) a.full_logits[pix0 + p] = v;
+        inter += v > a.thr + a.off;
+        uni += v > a.thr - a.off;
+        if (on) { minx = min(minx, (unsigned)X); maxx = max(maxx, (unsigned)X); any = 1; }
       }
     }
-    const float top = tap[0][0] * lx0 + tap[0][1] * lx1;
-    const float bot = tap[1][0] * lx0 + tap[1][1] * lx1;
-    const float v = top * ly0 + bot * ly1;
-    const bool on = v > a.thr;
-    const long long pix = (long long)Y * a.W + X;
-    a.masks[(long long)k * HW + pix] = on ? 1 : 0;
-    if (a.full_logits) a.full_logits[(long long)k * HW + pix] = v;
-    inter = v > a.thr + a.off;
-    uni = v > a.thr - a.off;
-    if (on) { minx = maxx = X; miny = maxy = Y; any = 1; }
+    if (any) miny = maxy = Y;
+    if (npx == PPX && (pix0 & 15) == 0) {
+      u32x4g w; w[0] = bytes[0]; w[1] = bytes[1]; w[2] = bytes[2]; w[3] = bytes[3];
+      *(u32x4g*)(a.masks + pix0) = w;
+    } else {
+      for (int p = 0; p < npx; ++p) a.masks[pix0 + p] = (uint8_t)((bytes[p >> 2] >> (8 * (p & 3))) & 1u);
+    }
   }
   // wave reduction, then one set of atomics per workgroup
 #pragma unroll
@@ -493,10 +548,12 @@ int hgl_launch_relpos_gather(const float* T, int B, int heads, int S, int size, 
 }
 int hgl_launch_relpos_direct(const float* qkv, int ldq, int B, int heads, int S, int size, int hd,
                              const float* Rh, const float* Rw, float* rel_h, float* rel_w, hipStream_t st) {
-  const long long total = (long long)B * heads * S * 2 * size;
   HGL_REQUIRE(hd == 80 || hd == 64, "relpos_direct: head dim %d unsupported", hd);
-  if (hd == 80) hipLaunchKernelGGL(relpos_direct_kernel<80>, dim3(grid1(total)), dim3(256), 0, st, qkv, ldq, B, heads, S, size, Rh, Rw, rel_h, rel_w, total);
-  else hipLaunchKernelGGL(relpos_direct_kernel<64>, dim3(grid1(total)), dim3(256), 0, st, qkv, ldq, B, heads, S, size, Rh, Rw, rel_h, rel_w, total);
+  HGL_REQUIRE((size & 1) == 0 && size > 0 && size <= 64, "relpos_direct: window size %d unsupported (even, <= 64)", size);
+  const dim3 grid((unsigned)((S + 255) / 256), (unsigned)(B * heads), 2);
+  const size_t lds = (size_t)(2 * size - 1) * (hd + 4) * sizeof(float);
+  if (hd == 80) hipLaunchKernelGGL(relpos_direct_kernel<80>, grid, dim3(256), lds, st, qkv, ldq, heads, S, size, Rh, Rw, rel_h, rel_w);
+  else hipLaunchKernelGGL(relpos_direct_kernel<64>, grid, dim3(256), lds, st, qkv, ldq, heads, S, size, Rh, Rw, rel_h, rel_w);
   return hgl_check_launch("relpos_direct");
 }
 int hgl_launch_im2col3x3(const float* in, int g, int C, float* cols, hipStream_t st) {
@@ -580,17 +637,12 @@ int hgl_sam_postprocess(const float* low_res, const float* iou_pred, int K, int 
   hipStream_t st = (hipStream_t)stream;
   unsigned* counters = (unsigned*)workspace;
   hipLaunchKernelGGL(init_counters_kernel, dim3((K + 255) / 256), dim3(256), 0, st, counters, K);
-  // candidates failing the predicted-IoU filter keep an all-zero mask
-  if (hipMemsetAsync(masks, 0, (size_t)K * H * W, st) != hipSuccess) {
-    hgl_set_error("sam_postprocess: memset failed");
-    return HGL_ELAUNCH;
-  }
   PostArgs a;
   a.low = low_res; a.iou = iou_pred; a.iou_thresh = pred_iou_thresh;
   a.K = K; a.hl = hl; a.wl = wl; a.S = img_size; a.hi = in_h; a.wi = in_w; a.H = H; a.W = W;
   a.thr = mask_threshold; a.off = stability_offset;
   a.masks = masks; a.counters = counters; a.full_logits = full_logits;
-  hipLaunchKernelGGL(sam_postprocess_kernel, dim3((W + PT - 1) / PT, (H + PT - 1) / PT, K), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(sam_postprocess_kernel, dim3((W + PTW - 1) / PTW, (H + PTH - 1) / PTH, K), dim3(256), 0, st, a);
   hipLaunchKernelGGL(sam_finalize_kernel, dim3((K + 255) / 256), dim3(256), 0, st, counters, iou_pred, K,
                      pred_iou_thresh, stability_thresh, stability, (int*)boxes_xyxy, keep);
   return hgl_check_launch("sam_postprocess");

@@ -212,10 +212,12 @@ def test_attention_spiked_scores_online_softmax(cuda, precision):
     np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5), rtol=0, atol=2e-5)
 
 
-def test_attention_rel_pos_bias(cuda, precision):
-    """decomposed relative position bias tables (image_encoder.py:325-361)."""
-    rng = np.random.default_rng(13)
-    B, heads, kh, kw, hd = 2, 3, 14, 14, 80
+@pytest.mark.parametrize("kh,kw,hd", [(14, 14, 80), (6, 10, 64), (4, 32, 80), (5, 64, 32)])
+def test_attention_rel_pos_bias(cuda, precision, kh, kw, hd):
+    """decomposed relative position bias tables (image_encoder.py:325-361): the 14x14 / hd 80 window (bias on the
+    matrix cores in f16x3 mode), a ragged window (generic path) and row widths that are multiples of 32 (vector path)."""
+    rng = np.random.default_rng(13 + kh)
+    B, heads = 2, 3
     S, D = kh * kw, heads * hd
     q, k, v = (rng.standard_normal((B, S, D)).astype(np.float32) for _ in range(3))
     rel_h = rng.standard_normal((B * heads, S, kh)).astype(np.float32)

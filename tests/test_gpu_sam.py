@@ -88,6 +88,25 @@ def test_postprocess_filters_and_empty(cuda, tiny):
     assert np.array_equal(masks[0].astype(bool), full[0] > 0)
 
 
+@pytest.mark.parametrize("orig,inp", [((192, 256), (192, 256)), ((96, 128), (192, 256)), ((333, 500), (171, 256))])
+def test_postprocess_tile_paths_vs_oracle(cuda, tiny, orig, inp):
+    """16-byte aligned rows (W % 16 == 0), ragged rows and up/down-scaling ratios against the oracle's two-stage
+    bilinear: logits within 2e-5, masks / boxes / stability exact functions of the produced logits."""
+    m = tiny[1]
+    rng = np.random.default_rng(orig[0])
+    low = rng.standard_normal((5, 64, 64)).astype(np.float32) * 2
+    iou = np.full(5, 0.9, np.float32)
+    masks, boxes, stab, keep, full = m.postprocess(T(low, cuda), T(iou, cuda), inp, orig, 0.5, 0.0, 1.0,
+                                                   return_logits=True)
+    full = full.cpu().numpy()
+    ref = S.postprocess_masks(low[None], inp, orig, 256)[0]
+    np.testing.assert_allclose(full, ref, rtol=0, atol=2e-5)
+    assert np.array_equal(masks.cpu().numpy().astype(bool), full > 0)
+    assert np.array_equal(boxes.cpu().numpy().astype(np.int64), S.mask_to_box(full > 0))
+    st, _, _ = S.stability_score(full)
+    np.testing.assert_allclose(stab.cpu().numpy(), st, rtol=0, atol=1e-6)
+
+
 def test_nms_vs_oracle(cuda):
     rng = np.random.default_rng(2)
     for K in [1, 7, 192, 700]:
