@@ -34,7 +34,7 @@ struct SplitW {
 };
 std::unordered_map<const void*, SplitW> g_split;   // fp32 weight pointer -> its fp16 split
 int g_precision = HGL_PREC_F32;
-enum { HGL_X3_V1 = 0, HGL_X3_L = 1, HGL_X3_M = 2, HGL_X3_S = 3 };
+enum { HGL_X3_V1 = 0, HGL_X3_L = 1, HGL_X3_M = 2, HGL_X3_S = 3, HGL_X3_N = 4, HGL_X3_Q = 5 };
 
 struct Args {
   const _Float16 *Ah, *Al, *Wh, *Wl;
@@ -56,12 +56,14 @@ int g_x3_kernel = -2;   // -2: read HGL_X3_KERNEL on first use; -1: cost model; 
 // qkv / fc1 GEMMs, SAM's global-attention qkv); the 128x128 tilings at two workgroups per CU win on the rest (their
 // epilogues overlap the other workgroup's K loop and they quantise better).  Between the two 128x128 kernels the
 // register-staged one keeps two K tiles in flight per workgroup and tolerates HBM-latency weights slightly better,
-// so it is the default; the LDS-DMA 256x128 / 128x128 tilings stay selectable (hgl_gemm_f16x3_select).
+// so it is the default there; a 128x160 LDS-DMA tiling takes the SAM shapes whose N it divides evenly (fewer, fuller
+// rounds).  The LDS-DMA 256x128 / 128x128 / 160x160 tilings stay selectable (hgl_gemm_f16x3_select).
 int pick_x3_kernel(int M, int N, int K) {
   struct Cfg { int kind, bm, bn, slots; double a, b, d; };
-  static const Cfg cfgs[2] = {
+  static const Cfg cfgs[3] = {
       {HGL_X3_L, 256, 256, 256, 18.0, 2.30, 0.10},
       {HGL_X3_V1, 128, 128, 512, 13.8, 1.37, 0.25},
+      {HGL_X3_N, 128, 160, 512, 10.4, 2.10, 0.25},   // 128x160 LDS-DMA: N = 1280 / 3840 / 5120 divide evenly
   };
   const double nk = K / 32.0;
   int best = HGL_X3_V1;
@@ -69,7 +71,10 @@ int pick_x3_kernel(int M, int N, int K) {
   for (const Cfg& c : cfgs) {
     const double tiles = (double)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
     const double x = tiles / c.slots, up = ceil(x);
-    const double t = (up - c.d * (up - x)) * (c.a + c.b * nk);
+    // two-workgroup-per-CU tilings: a CU that holds a single workgroup finishes it in ~0.62 (register-staged) /
+    // ~0.70 (4-wave LDS-DMA) of the pair's time
+    const double rounds = (c.slots == 512 && x <= 0.5) ? (c.kind == HGL_X3_V1 ? 0.62 : 0.70) : up - c.d * (up - x);
+    const double t = rounds * (c.a + c.b * nk);
     if (t < best_t) { best_t = t; best = c.kind; }
   }
   return best;
@@ -251,10 +256,16 @@ template <int ACT, int TBM, int TBN, int WGM, int WGN, int OCC, bool INTERLEAVE>
 __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
   constexpr int NW = WGM * WGN;
   constexpr int WTM = TBM / WGM, WTN = TBN / WGN, MI = WTM / 32, NI = WTN / 32;
-  constexpr int PA = TBM / 16 / NW, PW = TBN / 16 / NW;   // 1-KiB pieces per wave per plane
+  // 1-KiB staging pieces (16 rows x 64 B of one plane).  When both operands' pieces divide evenly over the waves
+  // each wave takes PA (A) + PW (W) row groups and their hi and lo planes share one per-lane offset; otherwise
+  // (e.g. 128x160 on 4 waves) the flat list [A_hi | A_lo | W_hi | W_lo] is cut into NW equal runs.
+  constexpr bool FLAT = (TBM / 16) % NW != 0 || (TBN / 16) % NW != 0;
+  constexpr int PA = FLAT ? 0 : TBM / 16 / NW, PW = FLAT ? 0 : TBN / 16 / NW;
+  constexpr int NPT = 2 * (TBM + TBN) / 16;               // pieces per stage
+  constexpr int NPIECE = NPT / NW;                        // per wave
   constexpr int A_BYTES = TBM * 64, W_BYTES = TBN * 64;    // one plane of one stage
   constexpr int STAGE = 2 * (A_BYTES + W_BYTES);
-  static_assert(PA >= 1 && PW >= 1 && PA * 16 * NW == TBM && PW * 16 * NW == TBN, "tile/wave shape");
+  static_assert(NPT % NW == 0 && TBM % (32 * WGM) == 0 && TBN % (32 * WGN) == 0, "tile/wave shape");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_g[];
 
   const int nwg = gridDim.x;
@@ -281,24 +292,47 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
   // staging: lane -> (row within the 16-row piece, swizzled source chunk).  Per-lane state is one 32-bit byte
   // offset per piece row; the plane bases are wave-uniform (SGPR) and advance by 64 B per K tile.
   const int prow = lane >> 2, pchunk = (lane & 3) ^ ((lane >> 4) & 3);
-  unsigned oa[PA], ow[PW];
-#pragma unroll
-  for (int j = 0; j < PA; ++j)
-    oa[j] = (unsigned)(min(row0 + (wave * PA + j) * 16 + prow, mclamp) * g.lda + pchunk * 8) * 2u;
-#pragma unroll
-  for (int j = 0; j < PW; ++j)
-    ow[j] = (unsigned)(min(col0 + (wave * PW + j) * 16 + prow, nclamp) * g.ldw + pchunk * 8) * 2u;
   const unsigned char *bAh = (const unsigned char*)g.Ah, *bAl = (const unsigned char*)g.Al;
   const unsigned char *bWh = (const unsigned char*)g.Wh, *bWl = (const unsigned char*)g.Wl;
-
-  // one 1-KiB piece q (0 .. 2*(PA+PW)-1) of this wave's share of K tile kt; the pieces are spread between the
-  // MFMA groups of the first k-step so that their issue cost hides under the other waves' MFMAs
-  constexpr int NPIECE = 2 * (PA + PW);
   const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem_g;
+  unsigned oa[FLAT ? 1 : PA], ow[FLAT ? 1 : PW];        // paired mode: per-lane byte offsets of the row groups
+  unsigned pvoff[FLAT ? NPIECE : 1], plds[FLAT ? NPIECE : 1];   // flat mode: per piece offset (VGPR), LDS offset (SGPR)
+  const unsigned char* pbase[FLAT ? NPIECE : 1];         //            and plane base (SGPR)
+  if constexpr (!FLAT) {
+#pragma unroll
+    for (int j = 0; j < PA; ++j)
+      oa[j] = (unsigned)(min(row0 + (wave * PA + j) * 16 + prow, mclamp) * g.lda + pchunk * 8) * 2u;
+#pragma unroll
+    for (int j = 0; j < PW; ++j)
+      ow[j] = (unsigned)(min(col0 + (wave * PW + j) * 16 + prow, nclamp) * g.ldw + pchunk * 8) * 2u;
+  } else {
+    constexpr int PAh = TBM / 16, PWh = TBN / 16;
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int gidx = wave * NPIECE + i;                  // wave-uniform
+      if (gidx < 2 * PAh) {
+        const int lo = gidx >= PAh, rp = gidx - lo * PAh;
+        pbase[i] = lo ? bAl : bAh;
+        plds[i] = lo * A_BYTES + rp * 1024;
+        pvoff[i] = (unsigned)(min(row0 + rp * 16 + prow, mclamp) * g.lda + pchunk * 8) * 2u;
+      } else {
+        const int g2 = gidx - 2 * PAh;
+        const int lo = g2 >= PWh, rp = g2 - lo * PWh;
+        pbase[i] = lo ? bWl : bWh;
+        plds[i] = 2 * A_BYTES + lo * W_BYTES + rp * 1024;
+        pvoff[i] = (unsigned)(min(col0 + rp * 16 + prow, nclamp) * g.ldw + pchunk * 8) * 2u;
+      }
+    }
+  }
+
+  // one 1-KiB piece q (0 .. NPIECE-1) of this wave's share of K tile kt; the pieces are spread between the
+  // MFMAs of a k-step so that their issue cost hides under the other waves' MFMAs
   auto issue_piece = [&](int kt, int stage, int q) {
     const unsigned sb = lds0 + stage * STAGE;
     const long long ko = (long long)kt * 64;
-    if (q < 2 * PA) {
+    if constexpr (FLAT) {
+      glds16(pbase[q] + ko, pvoff[q], sb + plds[q]);
+    } else if (q < 2 * PA) {
       const int j = q >> 1, lo = q & 1;
       glds16((lo ? bAl : bAh) + ko, oa[j], sb + lo * A_BYTES + (wave * PA + j) * 1024);
     } else {
@@ -602,6 +636,8 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
       else if (!strcmp(v, "L")) g_x3_kernel = HGL_X3_L;
       else if (!strcmp(v, "M")) g_x3_kernel = HGL_X3_M;
       else if (!strcmp(v, "S")) g_x3_kernel = HGL_X3_S;
+      else if (!strcmp(v, "N")) g_x3_kernel = HGL_X3_N;
+      else if (!strcmp(v, "Q")) g_x3_kernel = HGL_X3_Q;
     }
   }
   // the LDS-DMA kernels address the operands with 32-bit byte offsets from the plane bases
@@ -642,6 +678,8 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
     if (kind == 1) HGL_X3G_LAUNCH(ACT_, 256, 256, 2, 4, 1, true);    \
     else if (kind == 2) HGL_X3G_LAUNCH(ACT_, 256, 128, 4, 2, 1, true); \
     else if (kind == 3) HGL_X3G_LAUNCH(ACT_, 128, 128, 2, 2, 2, true); \
+    else if (kind == 4) HGL_X3G_LAUNCH(ACT_, 128, 160, 4, 1, 2, true); \
+    else if (kind == 5) HGL_X3G_LAUNCH(ACT_, 160, 160, 5, 1, 1, true); \
     else HGL_X3_LAUNCH(ACT_, 64, 2);                           \
   } while (0)
   switch (act) {
@@ -664,7 +702,7 @@ int hgl_set_precision(int mode) {
 int hgl_get_precision(void) { return g_precision; }
 
 int hgl_gemm_f16x3_select(int kind) {
-  HGL_REQUIRE(kind >= -1 && kind <= HGL_X3_S, "gemm_f16x3_select: unknown kernel %d", kind);
+  HGL_REQUIRE(kind >= -1 && kind <= HGL_X3_Q, "gemm_f16x3_select: unknown kernel %d", kind);
   g_x3_kernel = kind;
   return HGL_OK;
 }

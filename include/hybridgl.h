@@ -75,7 +75,7 @@ int hgl_prof_read(int cls, long long* launches, double* ms, double* flops, doubl
 int hgl_set_precision(int mode);
 int hgl_get_precision(void);
 /* Pins the tiling of the f16x3 GEMM: -1 = cost model (default), 0 = register-staged 128x128,
- * 1 / 2 / 3 = LDS-DMA 256x256 / 256x128 / 128x128.  All tilings give bit-identical results; the
+ * 1..5 = LDS-DMA 256x256 / 256x128 / 128x128 / 128x160 / 160x160.  All tilings give bit-identical results; the
  * switch exists for the parity tests and micro-benchmarks. */
 int hgl_gemm_f16x3_select(int kind);
 /* Splits w_fp32 [N,K] * 2^scale_log2 into caller-owned fp16 arrays hi, lo ([N,K] each) and
