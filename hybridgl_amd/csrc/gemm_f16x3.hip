@@ -644,7 +644,7 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
   const bool small_offsets = (double)M * lda * 2.0 < 4.0e9 && (double)N * K * 2.0 < 4.0e9;
   int kind = g_x3_kernel >= 0 ? g_x3_kernel : pick_x3_kernel(M, N, K);
   if (!small_offsets) kind = HGL_X3_V1;
-  HglProfScope prof(HGL_PROF_GEMM_X3, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
+  HglProfScope prof(kind == HGL_X3_V1 ? HGL_PROF_GEMM_X3 : HGL_PROF_GEMM_X3G, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
 #define HGL_X3_LAUNCH(ACT_, BK_, OCC_)                                                                        \
   do {                                                                                                        \
     g.tiles_m = (M + BM - 1) / BM;                                                                            \

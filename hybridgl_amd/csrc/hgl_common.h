@@ -77,7 +77,7 @@ int hgl_launch_gather_eot(const float* x, const int32_t* eot, int B, int S, int 
                           hipStream_t st);
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench roofline) ----
-enum HglProfClass { HGL_PROF_GEMM = 0, HGL_PROF_ATTN = 1, HGL_PROF_OTHER = 2, HGL_PROF_GEMM_X3 = 3, HGL_PROF_NCLASS = 4 };
+enum HglProfClass { HGL_PROF_GEMM = 0, HGL_PROF_ATTN = 1, HGL_PROF_OTHER = 2, HGL_PROF_GEMM_X3 = 3, HGL_PROF_GEMM_X3G = 4, HGL_PROF_NCLASS = 5 };
 struct HglProfScope {
   int slot;
   hipStream_t st;

@@ -59,7 +59,8 @@ const char* hgl_last_error(void);
 int hgl_device_count(void);
 
 /* Per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg).
- * cls: 0 = fp32 MFMA GEMM, 1 = fused attention, 2 = other, 3 = split-fp16 (f16x3) GEMM.  hgl_prof_read synchronises,
+ * cls: 0 = fp32 MFMA GEMM, 1 = fused attention, 2 = other, 3 = split-fp16 (f16x3) GEMM, register-staged kernel
+ * (gemm_f16x3_kernel), 4 = f16x3 GEMM, LDS-DMA kernels (gemm_x3g_kernel).  hgl_prof_read synchronises,
  * returns and clears the records of one class: launches, summed event ms, and the summed
  * ALGORITHMIC flops / bytes of those launches (2*M*N*K per GEMM; 4*B*H*Sq*Sk*hd per attention). */
 int hgl_prof_enable(int on);

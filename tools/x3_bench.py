@@ -60,7 +60,9 @@ def main():
         torch.cuda.synchronize()
         lib.hgl_prof_enable(0)
         n, ms, fl, by = C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
-        lib.hgl_prof_read(3, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
+        lib.hgl_prof_read(3, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))   # register-staged kernel
+        if n.value == 0:
+            lib.hgl_prof_read(4, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))   # LDS-DMA kernels
         tf = fl.value / ms.value / 1e9
         if not name.startswith(("text", "ragged", "k", "h")):
             tot_ms += ms.value / n.value
