@@ -134,6 +134,9 @@ PROTOTYPES = {
     "hgl_sam_postprocess": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _VP, _VP, _VP, _VP, _VP,
                                  _VP, _SZ, _VP]),
     "hgl_nms": (_I, [_VP, _VP, _VP, _I, _F, _VP, _VP, _VP]),
+    "hgl_nms_large_workspace_bytes": (_SZ, [_I]),
+    "hgl_nms_large": (_I, [_VP, _VP, _VP, _I, _F, _VP, _VP, _VP, _SZ, _VP]),
+    "hgl_box_near_crop_edge": (_I, [_VP, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _F, _VP, _VP]),
     "hgl_remove_small_regions_workspace_bytes": (_SZ, [_I, _I, _I]),
     "hgl_remove_small_regions": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_mask_boxes": (_I, [_VP, _I, _I, _I, _VP, _VP]),

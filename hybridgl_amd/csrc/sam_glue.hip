@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void sam_postprocess_kernel(PostArgs a) {
   const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;
   const int X0 = blockIdx.x * PTW, Y0 = blockIdx.y * PTH;
   const int Xb = X0 + tx * PPX, Y = Y0 + ty;
-  if (a.iou && !(a.iou[k] > a.iou_thresh)) {
+  if (a.iou && a.iou_thresh > 0.f && !(a.iou[k] > a.iou_thresh)) {   // the filter exists only for thresholds > 0 (:287)
     // filtered before any pixel work (uniform): the candidate keeps an all-zero mask
     if (Xb < a.W && Y < a.H) {
       const int npx = min(PPX, a.W - Xb);
@@ -447,7 +447,9 @@ __global__ void sam_finalize_kernel(const unsigned* __restrict__ c, const float*
                                     int* __restrict__ boxes, uint8_t* __restrict__ keep) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
-  const bool pass_iou = !iou || iou[k] > iou_thresh;
+  // automatic_mask_generator.py:287-298: each filter is applied only when its threshold is > 0 (so a NaN
+  // stability score -- an empty mask -- survives a zero threshold, as in the reference)
+  const bool pass_iou = !iou || !(iou_thresh > 0.f) || iou[k] > iou_thresh;
   const float s = (float)c[k * 6 + 0] / (float)c[k * 6 + 1];  // 0/0 -> NaN as in the reference
   stab[k] = pass_iou ? s : 0.f;
   const bool empty = c[k * 6 + 2] == 0x7fffffff;
@@ -455,7 +457,7 @@ __global__ void sam_finalize_kernel(const unsigned* __restrict__ c, const float*
   boxes[k * 4 + 1] = empty ? 0 : (int)c[k * 6 + 3];
   boxes[k * 4 + 2] = empty ? 0 : (int)c[k * 6 + 4];
   boxes[k * 4 + 3] = empty ? 0 : (int)c[k * 6 + 5];
-  keep[k] = (pass_iou && s >= stab_thresh) ? 1 : 0;  // NaN >= x is false
+  keep[k] = (pass_iou && (!(stab_thresh > 0.f) || s >= stab_thresh)) ? 1 : 0;  // NaN >= x is false
 }
 
 // Greedy NMS in one workgroup (K <= 1024): candidates with keep[k]!=0, descending score with the
@@ -509,6 +511,119 @@ __global__ __launch_bounds__(1024) void nms_kernel(const int* __restrict__ boxes
     __syncthreads();
   }
   if (t == 0) *out_n = nkept;
+}
+
+// ---- NMS for any K (crop layers / dense point grids, automatic_mask_generator.py:209-220,259-266) ----------
+// Same semantics as nms_kernel (descending score, original index breaks ties, suppress IoU > thr), in three passes:
+// rank by counting -> 64x64-bit suppression words of the sorted boxes -> one workgroup walks the row blocks,
+// resolving each 64-row block with wave shuffles and OR-ing the kept rows into the running "removed" bit set.
+__global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__ scores, const uint8_t* __restrict__ keep,
+                                                       int K, int* __restrict__ order, int* __restrict__ nvalid) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K || !keep[i]) return;
+  const float sc = scores[i];
+  int rank = 0;
+  for (int j = 0; j < K; ++j) {
+    if (!keep[j]) continue;
+    const float sj = scores[j];
+    rank += (sj > sc || (sj == sc && j < i)) ? 1 : 0;
+  }
+  order[rank] = i;
+  atomicAdd(nvalid, 1);
+}
+
+__device__ __forceinline__ bool nms_overlap(const int4 a, const int4 b, float thr) {
+  const float ax0 = (float)a.x, ay0 = (float)a.y, ax1 = (float)a.z, ay1 = (float)a.w;
+  const float bx0 = (float)b.x, by0 = (float)b.y, bx1 = (float)b.z, by1 = (float)b.w;
+  const float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.f);
+  const float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.f);
+  const float inter = iw * ih;
+  const float iou = inter / ((ax1 - ax0) * (ay1 - ay0) + (bx1 - bx0) * (by1 - by0) - inter);
+  return iou > thr;
+}
+
+// grid (W, W), 64 threads: word (row a = 64*by + t, column block bx) of the upper triangle
+__global__ __launch_bounds__(64) void nms_mask_kernel(const int* __restrict__ boxes, const int* __restrict__ order,
+                                                      const int* __restrict__ nvalid, int W, float thr,
+                                                      unsigned long long* __restrict__ mask) {
+  const int cb = blockIdx.x, rb = blockIdx.y, t = threadIdx.x;
+  const int n = *nvalid;
+  if (cb < rb || rb * 64 >= n) return;
+  __shared__ int4 colbox[64];
+  const int b = cb * 64 + t;
+  colbox[t] = b < n ? ((const int4*)boxes)[order[b]] : make_int4(0, 0, 0, 0);
+  __syncthreads();
+  const int a = rb * 64 + t;
+  unsigned long long w = 0;
+  if (a < n) {
+    const int4 me = ((const int4*)boxes)[order[a]];
+    const int jmax = min(64, n - cb * 64);
+    for (int j = 0; j < jmax; ++j) {
+      if (cb * 64 + j > a && nms_overlap(me, colbox[j], thr)) w |= 1ull << j;
+    }
+  }
+  mask[(long long)a * W + cb] = w;
+}
+
+__global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                       const int* __restrict__ order, const int* __restrict__ nvalid,
+                                                       int W, int* __restrict__ out_idx, int* __restrict__ out_n) {
+  __shared__ unsigned long long removed[1024];
+  __shared__ unsigned long long kept_word;
+  __shared__ int nkept_s;
+  const int t = threadIdx.x, lane = t & 63;
+  const int n = *nvalid;
+  for (int w = t; w < W; w += 256) removed[w] = 0;
+  if (t == 0) nkept_s = 0;
+  __syncthreads();
+  const int nblk = (n + 63) / 64;
+  for (int rb = 0; rb < nblk; ++rb) {
+    if (t < 64) {
+      const int a = rb * 64 + lane;
+      const unsigned long long d = a < n ? mask[(long long)a * W + rb] : 0ull;
+      unsigned long long rem = removed[rb], km = 0;
+      for (int s2 = 0; s2 < 64; ++s2) {
+        const unsigned lo = __shfl((unsigned)(d & 0xffffffffull), s2), hi = __shfl((unsigned)(d >> 32), s2);
+        if (rb * 64 + s2 < n && !((rem >> s2) & 1ull)) {
+          km |= 1ull << s2;
+          rem |= ((unsigned long long)hi << 32) | lo;
+        }
+      }
+      const int base = nkept_s;
+      if ((km >> lane) & 1ull) out_idx[base + __popcll(km & ((1ull << lane) - 1ull))] = order[a];
+      if (lane == 0) { kept_word = km; nkept_s = base + __popcll(km); }
+    }
+    __syncthreads();
+    const unsigned long long km = kept_word;
+    for (int w = rb + 1 + t; w < W; w += 256) {
+      unsigned long long acc = removed[w];
+      unsigned long long bits = km;
+      while (bits) {
+        const int s2 = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        acc |= mask[(long long)(rb * 64 + s2) * W + w];
+      }
+      removed[w] = acc;
+    }
+    __syncthreads();
+  }
+  if (t == 0) *out_n = nkept_s;
+}
+
+// is_box_near_crop_edge (utils/amg.py:78-88) applied to keep flags: boxes are in crop coordinates
+__global__ __launch_bounds__(256) void crop_edge_kernel(const int* __restrict__ boxes, int K, int cx0, int cy0, int cx1,
+                                                        int cy1, int ox0, int oy0, int ox1, int oy1, float atol,
+                                                        uint8_t* __restrict__ keep) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K) return;
+  const float b[4] = {(float)(boxes[i * 4] + cx0), (float)(boxes[i * 4 + 1] + cy0), (float)(boxes[i * 4 + 2] + cx0),
+                      (float)(boxes[i * 4 + 3] + cy0)};
+  const float c[4] = {(float)cx0, (float)cy0, (float)cx1, (float)cy1};
+  const float o[4] = {(float)ox0, (float)oy0, (float)ox1, (float)oy1};
+  bool near = false;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) near |= (fabsf(b[e] - c[e]) <= atol) && !(fabsf(b[e] - o[e]) <= atol);
+  if (near) keep[i] = 0;
 }
 
 // dst[i] = src[idx[i]] for i < *n (rows of row_bytes bytes, 16-byte multiples)
@@ -655,6 +770,47 @@ int hgl_nms(const int32_t* boxes_xyxy, const float* scores, const uint8_t* keep,
   HGL_REQUIRE(K > 0 && K <= 1024, "nms: K must be in [1,1024] (got %d)", K);
   hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)boxes_xyxy, scores, keep, K, iou_threshold, (int*)out_idx, (int*)out_n);
   return hgl_check_launch("nms");
+}
+
+size_t hgl_nms_large_workspace_bytes(int K) {
+  const size_t W = ((size_t)K + 63) / 64;
+  return hgl_align_up((size_t)K * sizeof(int), 256) + hgl_align_up(sizeof(int), 256) + hgl_align_up((size_t)K * W * 8, 256);
+}
+
+int hgl_nms_large(const int32_t* boxes_xyxy, const float* scores, const uint8_t* keep, int K, float iou_threshold,
+                  int32_t* out_idx, int32_t* out_n, void* workspace, size_t workspace_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(boxes_xyxy && scores && keep && out_idx && out_n, "nms_large: null argument");
+  HGL_REQUIRE(K > 0 && K <= 32768, "nms_large: K must be in [1,32768] (got %d)", K);
+  HGL_REQUIRE(((uintptr_t)boxes_xyxy & 15) == 0, "nms_large: boxes must be 16-byte aligned");
+  if (!workspace || workspace_bytes < hgl_nms_large_workspace_bytes(K)) {
+    hgl_set_error("nms_large: workspace too small");
+    return HGL_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int W = (K + 63) / 64;
+  HglArena ar(workspace, workspace_bytes);
+  int* order = ar.take<int>((size_t)K);
+  int* nvalid = ar.take<int>(1);
+  unsigned long long* mask = ar.take<unsigned long long>((size_t)K * W);
+  if (hipMemsetAsync(nvalid, 0, sizeof(int), st) != hipSuccess) {
+    hgl_set_error("nms_large: memset failed");
+    return HGL_ELAUNCH;
+  }
+  hipLaunchKernelGGL(nms_rank_kernel, dim3((K + 255) / 256), dim3(256), 0, st, scores, keep, K, order, nvalid);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(W, W), dim3(64), 0, st, (const int*)boxes_xyxy, order, nvalid, W, iou_threshold, mask);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(256), 0, st, mask, order, nvalid, W, (int*)out_idx, (int*)out_n);
+  return hgl_check_launch("nms_large");
+}
+
+int hgl_box_near_crop_edge(const int32_t* boxes_xyxy, int K, const int32_t* crop_box_xyxy, const int32_t* orig_box_xyxy,
+                           float atol, uint8_t* keep, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(boxes_xyxy && crop_box_xyxy && orig_box_xyxy && keep && K > 0, "box_near_crop_edge: bad arguments");
+  hipLaunchKernelGGL(crop_edge_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const int*)boxes_xyxy, K,
+                     crop_box_xyxy[0], crop_box_xyxy[1], crop_box_xyxy[2], crop_box_xyxy[3], orig_box_xyxy[0],
+                     orig_box_xyxy[1], orig_box_xyxy[2], orig_box_xyxy[3], atol, keep);
+  return hgl_check_launch("box_near_crop_edge");
 }
 
 int hgl_gather_masks(const uint8_t* masks, const int32_t* idx, const int32_t* n, int max_n, long long HW,

@@ -198,15 +198,47 @@ class Sam:
 
 
 def nms(boxes_xyxy, scores, keep, iou_threshold):
-    """Device NMS -> (idx [K] int32, n [1] int32), both on the device."""
+    """Device NMS -> (idx [K] int32, n [1] int32), both on the device.  K <= 1024: one workgroup; larger K
+    (dense grids, crop layers): the three-pass bit-matrix kernels, same semantics."""
     lib = _lib.load()
     K = boxes_xyxy.shape[0]
     idx = torch.empty((K,), dtype=torch.int32, device=boxes_xyxy.device)
     n = torch.empty((1,), dtype=torch.int32, device=boxes_xyxy.device)
-    check(lib.hgl_nms(ops._dev(boxes_xyxy, torch.int32, "boxes"), ops._dev(scores, torch.float32, "scores"),
-                      ops._dev(keep, torch.uint8, "keep"), K, float(iou_threshold), idx.data_ptr(), n.data_ptr(),
-                      ops._stream()), "hgl_nms")
+    if K <= 1024:
+        check(lib.hgl_nms(ops._dev(boxes_xyxy, torch.int32, "boxes"), ops._dev(scores, torch.float32, "scores"),
+                          ops._dev(keep, torch.uint8, "keep"), K, float(iou_threshold), idx.data_ptr(), n.data_ptr(),
+                          ops._stream()), "hgl_nms")
+    else:
+        need = lib.hgl_nms_large_workspace_bytes(K)
+        ws = ops.workspace(need, boxes_xyxy.device, "nms_large")
+        check(lib.hgl_nms_large(ops._dev(boxes_xyxy, torch.int32, "boxes"), ops._dev(scores, torch.float32, "scores"),
+                                ops._dev(keep, torch.uint8, "keep"), K, float(iou_threshold), idx.data_ptr(),
+                                n.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "hgl_nms_large")
     return idx, n
+
+
+def nms_large(boxes_xyxy, scores, keep, iou_threshold):
+    """hgl_nms_large regardless of K (tests)."""
+    lib = _lib.load()
+    K = boxes_xyxy.shape[0]
+    idx = torch.empty((K,), dtype=torch.int32, device=boxes_xyxy.device)
+    n = torch.empty((1,), dtype=torch.int32, device=boxes_xyxy.device)
+    ws = ops.workspace(lib.hgl_nms_large_workspace_bytes(K), boxes_xyxy.device, "nms_large")
+    check(lib.hgl_nms_large(ops._dev(boxes_xyxy, torch.int32, "boxes"), ops._dev(scores, torch.float32, "scores"),
+                            ops._dev(keep, torch.uint8, "keep"), K, float(iou_threshold), idx.data_ptr(), n.data_ptr(),
+                            ws.data_ptr(), ws.numel(), ops._stream()), "hgl_nms_large")
+    return idx, n
+
+
+def box_near_crop_edge(boxes_xyxy, keep, crop_box, orig_box, atol=20.0):
+    """keep[i] = 0 where box i (crop coordinates) touches a crop edge that is not an image edge (amg.py:78-88)."""
+    import ctypes as C
+    lib = _lib.load()
+    cb = (C.c_int32 * 4)(*[int(v) for v in crop_box])
+    ob = (C.c_int32 * 4)(*[int(v) for v in orig_box])
+    check(lib.hgl_box_near_crop_edge(ops._dev(boxes_xyxy, torch.int32, "boxes"), boxes_xyxy.shape[0], cb, ob, float(atol),
+                                     ops._dev(keep, torch.uint8, "keep"), ops._stream()), "hgl_box_near_crop_edge")
+    return keep
 
 
 def _build(cfg_name, checkpoint=None, state_dict=None, seed=0, device="cuda", precision=None):
@@ -283,6 +315,37 @@ def build_point_grid(n):
     return np.stack([np.tile(p[None, :], (n, 1)), np.tile(p[:, None], (1, n))], axis=-1).reshape(-1, 2)
 
 
+def build_all_layer_point_grids(n_per_side, n_layers, scale_per_layer):
+    """utils/amg.py:189-198."""
+    return [build_point_grid(int(n_per_side / (scale_per_layer ** i))) for i in range(n_layers + 1)]
+
+
+def generate_crop_boxes(im_size, n_layers, overlap_ratio):
+    """utils/amg.py:201-238 -> (crop boxes XYXY, layer index of each); the first box is the whole image."""
+    import math
+    from itertools import product
+    crop_boxes, layer_idxs = [], []
+    im_h, im_w = im_size
+    short_side = min(im_h, im_w)
+    crop_boxes.append([0, 0, im_w, im_h])
+    layer_idxs.append(0)
+
+    def crop_len(orig_len, n_crops, overlap):
+        return int(math.ceil((overlap * (n_crops - 1) + orig_len) / n_crops))
+
+    for i_layer in range(n_layers):
+        n_crops_per_side = 2 ** (i_layer + 1)
+        overlap = int(overlap_ratio * short_side * (2 / n_crops_per_side))
+        crop_w = crop_len(im_w, n_crops_per_side, overlap)
+        crop_h = crop_len(im_h, n_crops_per_side, overlap)
+        crop_box_x0 = [int((crop_w - overlap) * i) for i in range(n_crops_per_side)]
+        crop_box_y0 = [int((crop_h - overlap) * i) for i in range(n_crops_per_side)]
+        for x0, y0 in product(crop_box_x0, crop_box_y0):
+            crop_boxes.append([x0, y0, min(x0 + crop_w, im_w), min(y0 + crop_h, im_h)])
+            layer_idxs.append(i_layer + 1)
+    return crop_boxes, layer_idxs
+
+
 def get_preprocess_shape(oldh, oldw, long_side):
     """utils/transforms.py:93-102."""
     scale = long_side * 1.0 / max(oldh, oldw)
@@ -290,7 +353,9 @@ def get_preprocess_shape(oldh, oldw, long_side):
 
 
 class SamAutomaticMaskGenerator:
-    """automatic_mask_generator.py:35-372 for crop_n_layers == 0 (the Hybridgl_main.py:67-73 configuration)."""
+    """automatic_mask_generator.py:35-372: the Hybridgl_main.py:67-73 configuration (one crop, 8x8 points) runs
+    entirely on the device with two host syncs; crop layers / dense grids (Hybridgl_main_PhraseCut.py) add one
+    sync per crop (its survivor count) and the cross-crop NMS."""
 
     def __init__(self, model, points_per_side=32, points_per_batch=64, pred_iou_thresh=0.88,
                  stability_score_thresh=0.95, stability_score_offset=1.0, box_nms_thresh=0.7, crop_n_layers=0,
@@ -298,11 +363,15 @@ class SamAutomaticMaskGenerator:
                  point_grids=None, min_mask_region_area=0, output_mode="binary_mask"):
         assert (points_per_side is None) != (point_grids is None), \
             "Exactly one of points_per_side or point_grid must be provided."
-        if crop_n_layers != 0:
-            raise NotImplementedError("crop layers (PhraseCut configuration) are a later row of SURVEY.md 8f")
         assert output_mode == "binary_mask", "only binary_mask output is on the reference's path"
         self.model = model
-        self.point_grids = [build_point_grid(points_per_side)] if point_grids is None else point_grids
+        if point_grids is None:
+            self.point_grids = build_all_layer_point_grids(points_per_side, crop_n_layers, crop_n_points_downscale_factor)
+        else:
+            self.point_grids = point_grids
+        assert len(self.point_grids) >= crop_n_layers + 1, "one point grid per crop layer"
+        self.crop_n_layers = crop_n_layers
+        self.crop_overlap_ratio = crop_overlap_ratio
         self.points_per_batch = points_per_batch
         self.pred_iou_thresh = pred_iou_thresh
         self.stability_score_thresh = stability_score_thresh
@@ -312,10 +381,13 @@ class SamAutomaticMaskGenerator:
         self.min_mask_region_area = min_mask_region_area
 
     # ---- device part: everything up to and including the first NMS, no host sync -----------
-    def propose(self, image, resized=None):
-        """image: uint8 [H,W,3] numpy (or device tensor when `resized` is given).
+    def propose(self, image, resized=None, layer_idx=0, crop_box=None, orig_size=None):
+        """image: uint8 [H,W,3] numpy or device tensor: the crop (automatic_mask_generator.py:222-267; the whole
+        image in the reference's own configuration).  crop_box / orig_size (H, W) of the full image enable the
+        crop-edge filter (:305-307).
         Returns device tensors (masks [K,H,W] u8, boxes_xyxy [K,4] i32, iou [K], stab [K], order [K] i32,
-        n [1] i32, points [K,2] float64 numpy): candidates order[:n] survive the filters + NMS."""
+        n [1] i32, points [K,2] float64 numpy): candidates order[:n] survive the filters + NMS; boxes, masks and
+        points are in crop coordinates."""
         m = self.model
         H, W = image.shape[:2]
         nh, nw = get_preprocess_shape(H, W, m.img_size)
@@ -324,7 +396,7 @@ class SamAutomaticMaskGenerator:
             dev_img = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image)).to(m.device)
             resized = resize_longest_side(dev_img.contiguous(), m.img_size)
         emb = m.encode(resized)
-        pts = self.point_grids[0] * np.array([[W, H]], dtype=np.float64)       # automatic_mask_generator.py:240-241
+        pts = self.point_grids[layer_idx] * np.array([[W, H]], dtype=np.float64)   # automatic_mask_generator.py:240-241
         tp = pts.copy()
         tp[:, 0] *= nw / W                                                       # apply_coords, utils/transforms.py:33-45
         tp[:, 1] *= nh / H
@@ -338,8 +410,65 @@ class SamAutomaticMaskGenerator:
         iou = ious[0] if len(ious) == 1 else torch.cat(ious)
         masks, boxes, stab, keep, _ = m.postprocess(low, iou, (nh, nw), (H, W), self.pred_iou_thresh,
                                                     self.stability_score_thresh, self.stability_score_offset)
+        if crop_box is not None and orig_size is not None and list(crop_box) != [0, 0, orig_size[1], orig_size[0]]:
+            box_near_crop_edge(boxes, keep, crop_box, [0, 0, orig_size[1], orig_size[0]])
         order, n = nms(boxes, iou, keep, self.box_nms_thresh)
         return masks, boxes, iou, stab, order, n, np.repeat(pts, 3, axis=0)
+
+    def generate_device_crops(self, image):
+        """_generate_masks with crop layers (automatic_mask_generator.py:197-220) + postprocess_small_regions.
+        Returns device tensors (masks [n,H,W] u8, boxes_xywh [n,4] i64, iou [n], stability [n]) and host arrays
+        (points [n,2] f64, crop_boxes [n,4] i64), in the reference's output order."""
+        m = self.model
+        dev_img = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image)).to(m.device)
+        H, W = dev_img.shape[:2]
+        crop_boxes, layer_idxs = generate_crop_boxes((H, W), self.crop_n_layers, self.crop_overlap_ratio)
+        all_m, all_b, all_iou, all_stab, all_pts, all_cb = [], [], [], [], [], []
+        for crop_box, layer_idx in zip(crop_boxes, layer_idxs):
+            x0, y0, x1, y1 = crop_box
+            crop = dev_img[y0:y1, x0:x1, :].contiguous()
+            masks, boxes, iou, stab, order, n, pts = self.propose(crop, None, layer_idx, crop_box, (H, W))
+            n = int(n.item())                                    # host sync: survivors of this crop
+            if n == 0:
+                continue
+            idx = order[:n].long()
+            full = torch.zeros((n, H, W), dtype=torch.uint8, device=m.device)     # uncrop_masks (amg.py:241-252)
+            full[:, y0:y1, x0:x1] = masks.index_select(0, idx)
+            off = torch.tensor([x0, y0, x0, y0], dtype=torch.int32, device=m.device)
+            all_m.append(full)
+            all_b.append(boxes.index_select(0, idx) + off)       # uncrop_boxes_xyxy (amg.py:225-231)
+            all_iou.append(iou.index_select(0, idx))
+            all_stab.append(stab.index_select(0, idx))
+            all_pts.append(pts[idx.cpu().numpy()] + np.array([[x0, y0]], dtype=np.float64))   # uncrop_points
+            all_cb.append(np.tile(np.array([crop_box], dtype=np.int64), (n, 1)))
+        if not all_m:
+            e = torch.empty
+            return (e((0, H, W), dtype=torch.uint8, device=m.device), e((0, 4), dtype=torch.int64, device=m.device),
+                    e((0,), device=m.device), e((0,), device=m.device), np.zeros((0, 2)), np.zeros((0, 4), np.int64))
+        mk, bx = torch.cat(all_m), torch.cat(all_b).contiguous()
+        iou, stab = torch.cat(all_iou), torch.cat(all_stab)
+        pts, cbs = np.concatenate(all_pts), np.concatenate(all_cb)
+        if len(crop_boxes) > 1:
+            # duplicates between crops: prefer masks from smaller crops (automatic_mask_generator.py:209-220)
+            area = (cbs[:, 2] - cbs[:, 0]) * (cbs[:, 3] - cbs[:, 1])
+            scores = torch.from_numpy((1.0 / torch.from_numpy(area)).to(torch.float32).numpy()).to(m.device)
+            order, n = nms(bx, scores, torch.ones(len(bx), dtype=torch.uint8, device=m.device), self.crop_nms_thresh)
+            k = order[: int(n.item())].long()
+            kc = k.cpu().numpy()
+            mk, bx, iou, stab, pts, cbs = mk.index_select(0, k), bx.index_select(0, k).contiguous(), iou[k], stab[k], pts[kc], cbs[kc]
+        if self.min_mask_region_area > 0 and len(bx) > 0:
+            m1, c1 = remove_small_regions(mk.contiguous(), self.min_mask_region_area, "holes")
+            m2, c2 = remove_small_regions(m1, self.min_mask_region_area, "islands")
+            unchanged = ((c1 | c2) == 0).to(torch.float32)
+            nb = mask_boxes(m2)
+            order2, n2 = nms(nb, unchanged, torch.ones(len(nb), dtype=torch.uint8, device=m.device),
+                             max(self.box_nms_thresh, self.crop_nms_thresh))
+            k = order2[: int(n2.item())].long()
+            kc = k.cpu().numpy()
+            mk, bx, iou, stab, pts, cbs = m2.index_select(0, k), nb.index_select(0, k), iou[k], stab[k], pts[kc], cbs[kc]
+        b = bx.long()
+        xywh = torch.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1)
+        return mk, xywh, iou, stab, pts, cbs
 
     def generate_device(self, image, resized=None, fixed_n=None):
         """Whole `generate` on the device.  Returns (masks [n,H,W] uint8, boxes_xywh [n,4] int64,
@@ -386,6 +515,18 @@ class SamAutomaticMaskGenerator:
 
     def generate(self, image):
         """automatic_mask_generator.py:137-195 -> list of records (binary masks)."""
+        if self.crop_n_layers > 0:
+            m, xywh, iou, stab, pts, cbs = self.generate_device_crops(image)
+            masks = m.bool().cpu().numpy()
+            xywh, iou, stab = xywh.cpu().numpy(), iou.cpu().numpy(), stab.cpu().numpy()
+            out = []
+            for i in range(len(masks)):
+                cb = cbs[i]
+                out.append({"segmentation": masks[i], "area": int(masks[i].sum()), "bbox": [int(v) for v in xywh[i]],
+                            "predicted_iou": float(iou[i]), "point_coords": [pts[i].tolist()],
+                            "stability_score": float(stab[i]),
+                            "crop_box": [int(cb[0]), int(cb[1]), int(cb[2] - cb[0]), int(cb[3] - cb[1])]})   # XYWH
+            return out
         m, xywh, iou, stab, idx = self.generate_device(image)
         masks = m.bool().cpu().numpy()
         xywh, iou, stab, idx = xywh.cpu().numpy(), iou.cpu().numpy(), stab.cpu().numpy(), idx.cpu().numpy()

@@ -317,8 +317,10 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
  * (modeling/sam.py:133-162, automatic_mask_generator.py:287-308, utils/amg.py:156-176,303-346):
  * low_res [K,hl,wl] -> masks [K,H,W] uint8 (logit > mask_threshold), stability [K]
  * (= |logit>thr+off| / |logit>thr-off|), boxes_xyxy [K,4] int32 inclusive (0 when empty), keep [K]
- * (iou_pred > pred_iou_thresh && stability >= stability_thresh).  Candidates failing the IoU
- * filter are skipped (zero mask).  full_logits: optional [K,H,W] fp32 (tests), else NULL. */
+ * (iou_pred > pred_iou_thresh && stability >= stability_thresh; as in the reference each of the two
+ * filters exists only when its threshold is > 0, so an empty mask with its NaN stability survives a zero
+ * threshold).  Candidates failing the IoU filter are skipped (zero mask).  full_logits: optional
+ * [K,H,W] fp32 (tests), else NULL. */
 size_t hgl_sam_postprocess_workspace_bytes(int K);
 int hgl_sam_postprocess(const float* low_res, const float* iou_pred, int K, int hl, int wl, int img_size,
                         int in_h, int in_w, int H, int W, float mask_threshold, float stability_offset,
@@ -340,6 +342,17 @@ size_t hgl_remove_small_regions_workspace_bytes(int N, int H, int W);
 int hgl_remove_small_regions(const uint8_t* masks, int N, int H, int W, int area_thresh, int holes,
                              uint8_t* out, uint8_t* changed, void* workspace, size_t workspace_bytes,
                              void* stream);
+/* NMS for any K <= 32768 (dense point grids, crop layers and the cross-crop pass of
+ * automatic_mask_generator.py:209-220,259-266): identical semantics to hgl_nms (descending score, the original
+ * index breaks ties, suppress IoU > threshold), three kernels through a caller-supplied workspace. */
+size_t hgl_nms_large_workspace_bytes(int K);
+int hgl_nms_large(const int32_t* boxes_xyxy, const float* scores, const uint8_t* keep, int K, float iou_threshold,
+                  int32_t* out_idx, int32_t* out_n, void* workspace, size_t workspace_bytes, void* stream);
+/* is_box_near_crop_edge (segment_anything/utils/amg.py:78-88) folded into the keep flags: boxes (crop
+ * coordinates, XYXY) that come within atol of a crop edge which is not also an image edge get keep = 0.
+ * crop_box / orig_box are HOST arrays of 4 ints (XYXY). */
+int hgl_box_near_crop_edge(const int32_t* boxes_xyxy, int K, const int32_t* crop_box_xyxy, const int32_t* orig_box_xyxy,
+                           float atol, uint8_t* keep, void* stream);
 /* batched_mask_to_box (utils/amg.py:303-346): inclusive XYXY, [0,0,0,0] for an empty mask. */
 int hgl_mask_boxes(const uint8_t* masks, int N, int H, int W, int32_t* boxes_xyxy, void* stream);
 

@@ -77,3 +77,14 @@ def sam_tiny_case():
     pts_in[:, 0] *= nw / ow
     pts_in[:, 1] *= nh / oh
     return dict(image=img, resized=resized, input_size=(nh, nw), orig_size=(oh, ow), points=pts, points_in=pts_in)
+
+
+def sam_crops_case():
+    """inputs of the crop-layer generator golden (tests/golden/sam_crops.npz): a 240x320 RGB image run through
+    SamAutomaticMaskGenerator(points_per_side=8, crop_n_layers=1, crop_n_points_downscale_factor=2) at the
+    tiny geometry.  With seeded random weights the mask logits are pixel noise, so the model's mask_threshold is
+    raised until a mask is a handful of pixels: the boxes then differ from mask to mask and the crop-edge filter,
+    the per-crop NMS and the cross-crop NMS all have something to decide."""
+    from hybridgl_amd.synth import synth_image
+    return dict(image=synth_image(240, 320, 77), points_per_side=8, crop_n_layers=1, downscale=2,
+                box_nms_thresh=0.7, crop_nms_thresh=0.7, logit_quantile=0.9995)

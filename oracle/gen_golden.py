@@ -365,6 +365,60 @@ TOKENIZER_STRINGS = [
 ]
 
 
+def gen_sam_crops():
+    """Crop-layer generator (automatic_mask_generator.py:197-267, amg.py:78-88,201-252) at the tiny geometry."""
+    from oracle.cases import sam_crops_case
+    sam = build_ref_sam("tiny", 0)
+    from segment_anything import SamAutomaticMaskGenerator
+    from segment_anything.utils import amg as ref_amg
+    c = sam_crops_case()
+    out = {}
+    with torch.no_grad():
+        # threshold: a high quantile of the full-image logits of the first 64 prompts
+        probe = SamAutomaticMaskGenerator(sam, points_per_side=c["points_per_side"], pred_iou_thresh=-1e9,
+                                          stability_score_thresh=0.0, box_nms_thresh=1.5)
+        probe.predictor.set_image(c["image"])
+        H, W = c["image"].shape[:2]
+        pts = probe.point_grids[0] * np.array([[W, H]])
+        tp = probe.predictor.transform.apply_coords(pts, (H, W))
+        lg, _, _ = probe.predictor.predict_torch(torch.as_tensor(tp)[:, None, :], torch.ones(len(tp), 1, dtype=torch.int),
+                                                 multimask_output=True, return_logits=True)
+        thr = float(np.quantile(lg.numpy(), c["logit_quantile"]))
+        sam.mask_threshold = thr
+        out["mask_threshold"] = np.array([thr], np.float64)
+        for tag, min_area in (("a", 0), ("b", 3)):
+            gen = SamAutomaticMaskGenerator(sam, points_per_side=c["points_per_side"], pred_iou_thresh=-1e9,
+                                            stability_score_thresh=0.0, box_nms_thresh=c["box_nms_thresh"],
+                                            crop_n_layers=c["crop_n_layers"], crop_nms_thresh=c["crop_nms_thresh"],
+                                            crop_n_points_downscale_factor=c["downscale"], min_mask_region_area=min_area)
+            anns = gen.generate(c["image"])
+            out[tag + "_n"] = np.array([len(anns)])
+            out[tag + "_masks"] = np.packbits(np.stack([a["segmentation"] for a in anns]), axis=-1)
+            out[tag + "_bbox"] = np.array([a["bbox"] for a in anns], dtype=np.int64)
+            out[tag + "_iou"] = np.array([a["predicted_iou"] for a in anns], dtype=np.float32)
+            out[tag + "_stab"] = np.array([a["stability_score"] for a in anns], dtype=np.float32)
+            out[tag + "_points"] = np.array([a["point_coords"][0] for a in anns], dtype=np.float64)
+            out[tag + "_area"] = np.array([a["area"] for a in anns], dtype=np.int64)
+            out[tag + "_crop_box"] = np.array([a["crop_box"] for a in anns], dtype=np.int64)
+            print("sam_crops", tag, "masks", len(anns), "from crops", sorted(set(map(tuple, out[tag + "_crop_box"].tolist()))))
+        # helper known-answers
+        cb, li = ref_amg.generate_crop_boxes((240, 320), 2, 512 / 1500)
+        out["crop_boxes_240x320_l2"] = np.array(cb, dtype=np.int64)
+        out["crop_layers_240x320_l2"] = np.array(li, dtype=np.int64)
+        cb, li = ref_amg.generate_crop_boxes((640, 480), 1, 512 / 1500)
+        out["crop_boxes_640x480_l1"] = np.array(cb, dtype=np.int64)
+        grids = ref_amg.build_all_layer_point_grids(16, 2, 2)
+        out["grid_sizes_16_2_2"] = np.array([len(gx) for gx in grids])
+        out["grid_l2_16_2_2"] = grids[2]
+        rng = np.random.default_rng(3)
+        bx = rng.integers(0, 100, size=(200, 4))
+        bx[:, 2:] = np.minimum(bx[:, :2] + rng.integers(0, 60, size=(200, 2)), 127)
+        crop = [40, 30, 167, 137]
+        near = ref_amg.is_box_near_crop_edge(torch.from_numpy(bx), crop, [0, 0, 320, 240])
+        out["edge_boxes"], out["edge_crop"], out["edge_near"] = bx.astype(np.int64), np.array(crop), near.numpy()
+    np.savez_compressed(os.path.join(GOLD, "sam_crops.npz"), **out)
+
+
 def gen_tokenizer():
     """SimpleTokenizer / clip.tokenize of the reference on (1) our tiny synthetic merges file and
     (2) the real merges file that sits in the reference tree (token ids are data, the file is not copied)."""
@@ -409,3 +463,6 @@ if __name__ == "__main__":
     if want("sam_tiny"):
         install_sam_stubs()
         gen_sam_tiny()
+    if want("sam_crops"):
+        install_sam_stubs()
+        gen_sam_crops()

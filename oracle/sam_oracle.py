@@ -378,10 +378,13 @@ def amg_filter(logits_full, iou_pred, pred_iou_thresh=0.7, stab_thresh=0.7, nms_
     (automatic_mask_generator.py:251-257,287-372).  logits_full: [K,H,W] at the original size,
     iou_pred: [K].  Returns (kept candidate indices in output order, masks, boxes XYXY, stability)."""
     K = len(iou_pred)
-    idx = np.arange(K)[iou_pred > pred_iou_thresh]
+    idx = np.arange(K)
+    if pred_iou_thresh > 0.0:        # :287-290: the filters exist only for positive thresholds
+        idx = idx[iou_pred > pred_iou_thresh]
     stab, _, _ = stability_score(logits_full[idx])
-    keep = stab >= stab_thresh
-    idx, stab = idx[keep], stab[keep]
+    if stab_thresh > 0.0:            # :293-298
+        keep = stab >= stab_thresh
+        idx, stab = idx[keep], stab[keep]
     masks = logits_full[idx] > 0
     boxes = mask_to_box(masks)
     k = nms(boxes, iou_pred[idx], nms_thresh)

@@ -143,6 +143,96 @@ def test_tiny_generate_vs_reference(cuda, g, tiny):
     assert all(a["crop_box"] == [0, 0, 200, 160] for a in anns)
 
 
+def test_nms_large_vs_oracle_and_small(cuda):
+    """the bit-matrix NMS (any K) against the oracle's greedy NMS and, for K <= 1024, against the one-workgroup
+    kernel: identical kept lists (score ties and duplicates included)."""
+    rng = np.random.default_rng(4)
+    for K in [1, 65, 700, 1025, 5000]:
+        xy = rng.integers(0, 900, size=(K, 2))
+        wh = rng.integers(1, 250, size=(K, 2))
+        boxes = np.concatenate([xy, xy + wh], 1).astype(np.int32)
+        boxes[K // 2] = boxes[0]
+        scores = rng.random(K).astype(np.float32)
+        if K > 70:
+            scores[70] = scores[3]
+            scores[K - 1] = scores[3]
+        keep = (rng.random(K) > 0.2).astype(np.uint8)
+        keep[0] = 1
+        idx, n = hsam.nms_large(T(boxes, cuda), T(scores, cuda), T(keep, cuda), 0.7)
+        got = idx.cpu().numpy()[: int(n.item())]
+        sel = np.nonzero(keep)[0]
+        ref = sel[S.nms(boxes[sel].astype(np.int64), scores[sel], 0.7)]
+        assert got.tolist() == ref.tolist(), K
+        if K <= 1024:
+            idx2, n2 = hsam.nms(T(boxes, cuda), T(scores, cuda), T(keep, cuda), 0.7)
+            assert idx2.cpu().numpy()[: int(n2.item())].tolist() == got.tolist()
+    # all-equal scores (the cross-crop pass scores every mask of a crop alike): index order decides
+    boxes = np.array([[0, 0, 10, 10], [1, 1, 11, 11], [50, 50, 60, 60], [0, 0, 10, 10]], np.int32)
+    idx, n = hsam.nms_large(T(boxes, cuda), T(np.ones(4, np.float32), cuda), T(np.ones(4, np.uint8), cuda), 0.5)
+    assert idx.cpu().numpy()[: int(n.item())].tolist() == [0, 2]
+
+
+def test_crop_helpers_vs_reference(cuda, golden_dir):
+    """generate_crop_boxes / build_all_layer_point_grids / is_box_near_crop_edge against reference outputs."""
+    import os
+    gc = np.load(os.path.join(golden_dir, "sam_crops.npz"))
+    cb, li = hsam.generate_crop_boxes((240, 320), 2, 512 / 1500)
+    assert np.array_equal(np.array(cb), gc["crop_boxes_240x320_l2"]) and np.array_equal(np.array(li), gc["crop_layers_240x320_l2"])
+    cb, _ = hsam.generate_crop_boxes((640, 480), 1, 512 / 1500)
+    assert np.array_equal(np.array(cb), gc["crop_boxes_640x480_l1"])
+    grids = hsam.build_all_layer_point_grids(16, 2, 2)
+    assert [len(x) for x in grids] == gc["grid_sizes_16_2_2"].tolist()
+    np.testing.assert_allclose(grids[2], gc["grid_l2_16_2_2"], rtol=0, atol=0)
+    crop = gc["edge_crop"].tolist()
+    bx = gc["edge_boxes"].astype(np.int32)
+    keep = hsam.box_near_crop_edge(T(bx, cuda), T(np.ones(len(bx), np.uint8), cuda), crop, [0, 0, 320, 240])
+    assert np.array_equal(keep.cpu().numpy() == 0, gc["edge_near"])
+
+
+@pytest.mark.parametrize("tag,min_area", [("a", 0), ("b", 3)])
+def test_tiny_generate_crops_vs_reference(cuda, golden_dir, tiny, tag, min_area):
+    """SamAutomaticMaskGenerator with one crop layer (automatic_mask_generator.py:197-267): per-crop point grids,
+    crop-edge filter, per-crop NMS, uncrop, cross-crop NMS, small-region clean-up -- against a reference run."""
+    import os
+    from oracle.cases import sam_crops_case
+    gc = np.load(os.path.join(golden_dir, "sam_crops.npz"))
+    c = sam_crops_case()
+    m = tiny[1]
+    old = m.mask_threshold
+    m.mask_threshold = float(gc["mask_threshold"][0])
+    try:
+        gen = hsam.SamAutomaticMaskGenerator(m, points_per_side=c["points_per_side"], pred_iou_thresh=-1e9,
+                                             stability_score_thresh=0.0, box_nms_thresh=c["box_nms_thresh"],
+                                             crop_n_layers=c["crop_n_layers"], crop_nms_thresh=c["crop_nms_thresh"],
+                                             crop_n_points_downscale_factor=c["downscale"], min_mask_region_area=min_area)
+        anns = gen.generate(c["image"])
+    finally:
+        m.mask_threshold = old
+    n_ref = int(gc[tag + "_n"][0])
+    ref_masks = np.unpackbits(gc[tag + "_masks"], axis=-1)[..., :320].astype(bool)
+    # thresholded noise: a logit within 1e-5 of the threshold may flip a pixel and with it an NMS decision, so the
+    # records are matched by (point, crop) and a few are allowed to differ
+    assert abs(len(anns) - n_ref) <= 3, (len(anns), n_ref)
+    key = lambda p, cb: (round(float(p[0]), 6), round(float(p[1]), 6), tuple(int(v) for v in cb))
+    ref = {}
+    for i in range(n_ref):
+        ref.setdefault(key(gc[tag + "_points"][i], gc[tag + "_crop_box"][i]), []).append(i)
+    matched = same_pos = 0
+    for j, a in enumerate(anns):
+        for i in ref.get(key(a["point_coords"][0], a["crop_box"]), []):
+            # the three masks of a point share the key: the predicted IoU tells them apart
+            if abs(a["predicted_iou"] - gc[tag + "_iou"][i]) < 1e-4 and (a["segmentation"] != ref_masks[i]).mean() < 1e-4 \
+                    and np.abs(np.array(a["bbox"]) - gc[tag + "_bbox"][i]).max() <= 1:
+                assert a["area"] == int(a["segmentation"].sum())
+                s_ref = gc[tag + "_stab"][i]
+                assert (np.isnan(s_ref) and np.isnan(a["stability_score"])) or abs(a["stability_score"] - s_ref) < 0.35
+                matched += 1
+                same_pos += int(i == j)
+                break
+    assert matched >= n_ref - 3, (matched, n_ref)
+    assert same_pos >= n_ref - 12, (same_pos, n_ref)      # output order (NMS order) agrees
+
+
 def test_vit_h_two_blocks_full_width(cuda):
     """ViT-H width (1280, 16 heads of 80, 64x64 tokens, 25 padded windows, 127-entry rel-pos tables):
     one windowed + one global block + neck against the oracle at full size."""
