@@ -1,0 +1,174 @@
+// Ground-truth masks of the REFER annotations, host side (no device work).
+//
+// The reference forms a ref's target mask on the CPU inside its DataLoader workers:
+// refer/refer.py:277-291 getMask -> pycocotools-style mask.frPyObjects / mask.decode, i.e.
+// refer/external/maskApi.c rleFrPoly (:161-201), rleDecode (:43-47), rleFrString (:217-230); the dataset then
+// keeps the pixels whose polygon count is exactly one (data/dataset_refer_bert.py:118-121).  These entry
+// points restate that arithmetic (5x super-sampled boundary walk, column crossings, even-odd fill in
+// column-major order) and write the row-major uint8 image that hgl_iou consumes, without materialising
+// the intermediate RLE objects.  Bit-exact against the reference's C file (oracle/_ref, tests/golden/gtmask.npz).
+#include "hgl_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace {
+
+// Column-major positions (x*H + y) at which the polygon's fill toggles (maskApi.c:161-196).
+void polygon_crossings(const double* xy, int k, int H, int W, std::vector<unsigned>& pos) {
+  const double scale = 5.0;
+  std::vector<int> px(k + 1), py(k + 1);
+  for (int j = 0; j < k; ++j) {
+    px[j] = (int)(scale * xy[2 * j] + 0.5);
+    py[j] = (int)(scale * xy[2 * j + 1] + 0.5);
+  }
+  px[k] = px[0];
+  py[k] = py[0];
+  // dense integer walk along every edge, major axis one step at a time, in the edge's own direction
+  std::vector<int> u, v;
+  for (int j = 0; j < k; ++j) {
+    int xs = px[j], xe = px[j + 1], ys = py[j], ye = py[j + 1];
+    const int dx = std::abs(xe - xs), dy = std::abs(ys - ye);
+    const bool x_major = dx >= dy;
+    const bool flip = (x_major && xs > xe) || (!x_major && ys > ye);
+    if (flip) { std::swap(xs, xe); std::swap(ys, ye); }
+    const double slope = x_major ? (double)(ye - ys) / dx : (double)(xe - xs) / dy;   // 0/0 -> NaN, used for one point only
+    const int n = x_major ? dx : dy;
+    for (int d = 0; d <= n; ++d) {
+      const int t = flip ? n - d : d;
+      if (x_major) { u.push_back(t + xs); v.push_back((int)(ys + slope * t + 0.5)); }
+      else { v.push_back(t + ys); u.push_back((int)(xs + slope * t + 0.5)); }
+    }
+  }
+  // where the walk moves to another super-sampled column: the crossing, back at pixel resolution
+  for (size_t j = 1; j < u.size(); ++j) {
+    if (u[j] == u[j - 1]) continue;
+    double xd = (double)(u[j] < u[j - 1] ? u[j] : u[j] - 1);
+    xd = (xd + 0.5) / scale - 0.5;
+    if (std::floor(xd) != xd || xd < 0 || xd > W - 1) continue;
+    double yd = (double)(v[j] < v[j - 1] ? v[j] : v[j - 1]);
+    yd = (yd + 0.5) / scale - 0.5;
+    if (yd < 0) yd = 0; else if (yd > H) yd = H;
+    yd = std::ceil(yd);
+    pos.push_back((unsigned)((int)xd * H + (int)yd));
+  }
+}
+
+// even-odd fill of sorted toggle positions, column-major scan, added into the row-major image
+long long fill_toggles(std::vector<unsigned>& pos, int H, int W, uint8_t* mask) {
+  std::sort(pos.begin(), pos.end());
+  long long area = 0;
+  const unsigned total = (unsigned)H * (unsigned)W;
+  size_t i = 0;
+  while (i < pos.size()) {
+    // a position listed an even number of times does not toggle (maskApi.c:192-196 merges the empty runs)
+    size_t j = i;
+    while (j < pos.size() && pos[j] == pos[i]) ++j;
+    const bool toggles = ((j - i) & 1) != 0;
+    const unsigned start = pos[i];
+    i = j;
+    if (!toggles) continue;
+    // find the next toggling position
+    unsigned end = total;
+    while (i < pos.size()) {
+      size_t j2 = i;
+      while (j2 < pos.size() && pos[j2] == pos[i]) ++j2;
+      const bool t2 = ((j2 - i) & 1) != 0;
+      const unsigned p2 = pos[i];
+      i = j2;
+      if (t2) { end = p2; break; }
+    }
+    {
+      unsigned x = start / (unsigned)H, y = start - x * (unsigned)H;
+      for (unsigned p = start; p < end && p < total; ++p) {
+        mask[(size_t)y * W + x] += 1;
+        if (++y == (unsigned)H) { y = 0; ++x; }
+      }
+    }
+    area += (long long)(std::min(end, total) - std::min(start, total));
+  }
+  return area;
+}
+
+long long fill_counts(const unsigned* cnts, long long m, int H, int W, uint8_t* mask) {
+  const unsigned long long total = (unsigned long long)H * W;
+  unsigned long long p = 0;
+  long long area = 0;
+  for (long long j = 0; j < m; ++j) {
+    const unsigned long long c = cnts[j];
+    if (j & 1) {
+      unsigned long long x = p / (unsigned)H, y = p - x * (unsigned)H;
+      for (unsigned long long q = p; q < p + c && q < total; ++q) {
+        mask[(size_t)y * W + x] += 1;
+        if (++y == (unsigned long long)H) { y = 0; ++x; }
+      }
+      area += (long long)c;
+    }
+    p += c;
+  }
+  return area;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hgl_gt_mask_from_polygons(const double* xy, const int32_t* n_points, int n_polys, int H, int W, uint8_t* mask,
+                              int64_t* area) {
+  HGL_REQUIRE(xy && n_points && mask && n_polys >= 0 && H > 0 && W > 0, "gt_mask_from_polygons: bad arguments");
+  HGL_REQUIRE((long long)H * W < (1ll << 31), "gt_mask_from_polygons: image too large");
+  std::fill(mask, mask + (size_t)H * W, (uint8_t)0);
+  long long total = 0;
+  const double* p = xy;
+  std::vector<unsigned> pos;
+  for (int i = 0; i < n_polys; ++i) {
+    const int k = n_points[i];
+    HGL_REQUIRE(k >= 1, "gt_mask_from_polygons: polygon %d has %d points", i, k);
+    pos.clear();
+    polygon_crossings(p, k, H, W, pos);
+    total += fill_toggles(pos, H, W, mask);
+    p += 2 * (size_t)k;
+  }
+  if (area) *area = total;
+  return HGL_OK;
+}
+
+int hgl_gt_mask_from_rle_counts(const uint32_t* counts, int m, int H, int W, uint8_t* mask, int64_t* area) {
+  HGL_REQUIRE(counts && mask && m >= 0 && H > 0 && W > 0, "gt_mask_from_rle_counts: bad arguments");
+  std::fill(mask, mask + (size_t)H * W, (uint8_t)0);
+  const long long a = fill_counts(counts, m, H, W, mask);
+  if (area) *area = a;
+  return HGL_OK;
+}
+
+int hgl_gt_mask_from_rle_string(const char* s, int H, int W, uint8_t* mask, int64_t* area) {
+  HGL_REQUIRE(s && mask && H > 0 && W > 0, "gt_mask_from_rle_string: bad arguments");
+  // LEB128-like, 5 payload bits + continuation bit per character (offset 48), every count after the third stored
+  // as a difference to the count two places earlier (maskApi.c:217-230)
+  std::vector<unsigned> cnts;
+  size_t p = 0;
+  while (s[p]) {
+    long x = 0;
+    int k = 0;
+    bool more = true;
+    while (more) {
+      HGL_REQUIRE(s[p] != 0, "gt_mask_from_rle_string: truncated string");
+      const char c = (char)(s[p] - 48);
+      x |= (long)(c & 0x1f) << (5 * k);
+      more = (c & 0x20) != 0;
+      ++p;
+      ++k;
+      if (!more && (c & 0x10)) x |= -1L << (5 * k);
+    }
+    if (cnts.size() > 2) x += (long)cnts[cnts.size() - 2];
+    cnts.push_back((unsigned)x);
+  }
+  std::fill(mask, mask + (size_t)H * W, (uint8_t)0);
+  const long long a = fill_counts(cnts.data(), (long long)cnts.size(), H, W, mask);
+  if (area) *area = a;
+  return HGL_OK;
+}
+
+}  // extern "C"

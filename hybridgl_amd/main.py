@@ -1,11 +1,19 @@
 """Evaluation driver with the reference's command line and report format (Hybridgl_main.py:23-261,
 flags of utils.py:397-471) for the pieces this package owns.
 
-Datasets (REFER/COCO), spaCy parsing and the GEM heat-map are host/external inputs of the reference
- and are not re-implemented: `--synthetic N` evaluates N seeded RefCOCO-shaped refs
-(hybridgl_amd/synth.py) through the full device pipeline and prints/appends the same two result lines.
+`--synthetic N` evaluates N seeded RefCOCO-shaped refs (hybridgl_amd/synth.py) through the full device pipeline
+and prints/appends the reference's two result lines.
+
+`--real` walks the REFER annotations under --refer_data_root (hybridgl_amd/refer_io.py: refs(<splitBy>).p,
+instances.json, COCO images; ground truth from the native polygon/RLE codec) with real checkpoints
+(HYBRIDGL_CLIP_CHECKPOINT / HYBRIDGL_SAM_CHECKPOINT / HYBRIDGL_BPE_VOCAB).  The two external models of the
+reference stay inputs: the spaCy parse (--parse_json: {sent_id: {"noun_phrase", "other_nouns", "dirflag",
+"relaflag"}}, default = whole sentence, no relation words) and the GEM heat-map (--heatmap_dir/<sent_id>.npy,
+default = uniform, i.e. no spatial guidance); the blurred background uses this package's own Gaussian (cv2 parity
+is unpinned).
 
     python -m hybridgl_amd.main --dataset refcocog --split val --fusion_mode G2L --synthetic 8
+    python -m hybridgl_amd.main --dataset refcoco --split testA --real --refer_data_root ./refer/data
 """
 import argparse
 import os
@@ -24,28 +32,94 @@ def default_argument_parser():
     p.add_argument("--proposals", type=int, default=64)
     p.add_argument("--sam", action="store_true", help="also run the SAM ViT-H proposal stage on every ref")
     p.add_argument("--result_dir", default="./result_log")
+    p.add_argument("--real", action="store_true", help="evaluate the REFER refs under --refer_data_root")
+    p.add_argument("--parse_json", default="", help="pre-computed parse records keyed by sent_id")
+    p.add_argument("--heatmap_dir", default="", help="pre-computed heat-maps <sent_id>.npy ([H,W] or any size, fp32)")
+    p.add_argument("--max_refs", type=int, default=0, help="stop after this many refs (0 = all)")
+    p.add_argument("--clip_model", default="ViT-B/16")
+    p.add_argument("--sam_model", default="default")
+    p.add_argument("--bpe_vocab", default="", help="bpe_simple_vocab_16e6.txt.gz (or HYBRIDGL_BPE_VOCAB)")
+    # proposal thresholds of Hybridgl_main.py:67-73
+    p.add_argument("--points_per_side", type=int, default=8)
+    p.add_argument("--pred_iou_thresh", type=float, default=0.7)
+    p.add_argument("--stability_score_thresh", type=float, default=0.7)
+    p.add_argument("--min_mask_region_area", type=int, default=800)
     return p
+
+
+def real_refs(args, dev, splitBy, context_length):
+    """RefBatch per dataset item, in the loader's order (Hybridgl_main.py:40-45,79-146)."""
+    import json
+    import numpy as np
+    from . import synth
+    from .pipeline import RefBatch, Sentence
+    from .refer_io import ReferDataset
+    from .tokenizer import SimpleTokenizer, tokenize
+    ds = ReferDataset(args.refer_data_root, args.dataset, splitBy, args.split)
+    tk = SimpleTokenizer(args.bpe_vocab or None)
+    parse = json.load(open(args.parse_json)) if args.parse_json else {}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    n = len(ds) if args.max_refs <= 0 else min(len(ds), args.max_refs)
+    for i in range(n):
+        data, annot, sentences = ds[i]
+        img = data["sam_img"]
+        H, W = img.shape[:2]
+        strings, sents = [], []
+        for sent_id, raw in zip(data["sent_ids"], sentences):
+            rec = parse.get(str(sent_id), {})
+            row = len(strings)
+            others = list(rec.get("other_nouns", []))
+            strings += [raw, rec.get("noun_phrase", raw)] + others
+            attn = None
+            if args.heatmap_dir and os.path.exists(os.path.join(args.heatmap_dir, f"{sent_id}.npy")):
+                a = torch.from_numpy(np.load(os.path.join(args.heatmap_dir, f"{sent_id}.npy")).astype(np.float32))
+                if tuple(a.shape) != (H, W):     # Hybridgl_main.py:201-202: bilinear to the image size
+                    a = torch.nn.functional.interpolate(a[None, None], size=(H, W), mode="bilinear", align_corners=False)[0, 0]
+                attn = a.to(dev).contiguous()
+            if attn is None:
+                attn = torch.ones((H, W), dtype=torch.float32, device=dev)
+            sents.append(Sentence(row, row + 1, list(range(row + 2, row + 2 + len(others))), rec.get("dirflag", "none"),
+                                  rec.get("relaflag", "none"), len(others), attn))
+        tokens = tokenize(strings, context_length=context_length, tokenizer=tk)   # raises on over-long text, as clip.tokenize
+        placeholder = torch.zeros((1, H, W), dtype=torch.bool, device=dev)
+        yield RefBatch(t(img), t(synth.box_blur_u8(img)), t(synth.imagenet_normalize(img)), placeholder,
+                       torch.zeros((1, 4), dtype=torch.int64, device=dev), t(tokens), t(annot), sents, None,
+                       int(data["img_id"][0]))
 
 
 def main(args):
     from .backbone import CLIPViTFM
-    from .pipeline import HybridGLPipeline, synthetic_ref
+    from .pipeline import EmptyProposals, HybridGLPipeline, synthetic_ref
     assert torch.cuda.is_available(), "hybridgl_amd has no CPU path"
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     splitBy = "umd" if args.dataset == "refcocog" else "unc"          # Hybridgl_main.py:26-29
-    model = CLIPViTFM(model_name="ViT-B/16", device=dev).eval()
+    model = CLIPViTFM(model_name=args.clip_model, device=dev).eval()
     gen = None
-    if args.sam:
+    if args.sam or args.real:
         from .sam import SamAutomaticMaskGenerator, sam_model_registry
-        sam = sam_model_registry["default"](device=dev)
-        gen = SamAutomaticMaskGenerator(sam, points_per_side=8, pred_iou_thresh=0.7, stability_score_thresh=0.7,
-                                        crop_n_layers=0, crop_n_points_downscale_factor=1, min_mask_region_area=800)
-    pipe = HybridGLPipeline(model, fusion_mode=args.fusion_mode, masking_block=9, mask_generator=gen)
+        sam = sam_model_registry[args.sam_model](device=dev)
+        # Hybridgl_main.py:67-73
+        gen = SamAutomaticMaskGenerator(sam, points_per_side=args.points_per_side, pred_iou_thresh=args.pred_iou_thresh,
+                                        stability_score_thresh=args.stability_score_thresh, crop_n_layers=0,
+                                        crop_n_points_downscale_factor=1, min_mask_region_area=args.min_mask_region_area)
+    pipe = HybridGLPipeline(model, fusion_mode=args.fusion_mode, masking_block=9, mask_generator=gen,
+                            use_sam_masks=args.real)
     print(f"fusion mode={args.fusion_mode}")
-    for i in range(args.synthetic):
-        ref, _ = synthetic_ref(i, dev, N=args.proposals, sam_img_size=1024 if gen else 0)
-        pipe.step(ref)
+    if args.real:
+        from .weights import CLIP_CONFIGS
+        skipped = 0
+        for ref in real_refs(args, dev, splitBy, CLIP_CONFIGS[args.clip_model]["context_length"]):
+            try:
+                pipe.step(ref)
+            except EmptyProposals:
+                skipped += 1      # the reference would fail on an image without proposals; count and go on
+        if skipped:
+            print(f"{skipped} refs skipped: the proposal stage returned no mask")
+    else:
+        for i in range(args.synthetic):
+            ref, _ = synthetic_ref(i, dev, N=args.proposals, sam_img_size=1024 if gen else 0)
+            pipe.step(ref)
     m = pipe.metrics()
     text = (f"\n\n fusion_mode={args.fusion_mode} "
             f"\nDataset: {args.dataset} / {args.split} / {splitBy}"

@@ -49,6 +49,10 @@ class RefBatch:
     image_id: Optional[int] = None  # COCO image id: consecutive refs of one image reuse proposals + hybrid features
 
 
+class EmptyProposals(RuntimeError):
+    """the proposal stage kept no mask for this image"""
+
+
 def _rows(text, rows):
     """rows of the text-feature matrix without a host->device index copy when they are consecutive."""
     if not rows:
@@ -136,6 +140,8 @@ class HybridGLPipeline:
                 else:  # proposal kernels only, nothing read back
                     prop = self.mask_generator.propose(ref.sam_img, resized=ref.sam_resized)
                 if self.use_sam_masks:
+                    if prop[0].shape[0] == 0:
+                        raise EmptyProposals("no proposals")
                     ref = dataclasses.replace(ref, masks=prop[0].view(torch.bool) if prop[0].dtype == torch.uint8 else prop[0],
                                               boxes=prop[1].contiguous())
                 self.last_proposals = prop

@@ -360,6 +360,18 @@ int hgl_mask_boxes(const uint8_t* masks, int N, int H, int W, int32_t* boxes_xyx
 int hgl_gather_masks(const uint8_t* masks, const int32_t* idx, const int32_t* n, int max_n, long long HW,
                      uint8_t* out, void* stream);
 
+/* ---- ground-truth masks of the REFER annotations (host functions, no device work) --------------------
+ * refer/refer.py:277-291 getMask over refer/external/maskApi.c (rleFrPoly :161-201, rleDecode :43-47,
+ * rleFrString :217-230).  mask: caller-owned [H,W] row-major uint8, set to the per-pixel COUNT of covering
+ * polygons (what np.sum(mask.decode(rle), axis=2) returns; the dataset keeps count == 1,
+ * data/dataset_refer_bert.py:118-121); area: sum of the polygons' areas (may be NULL).
+ * xy: the polygons' x0,y0,x1,y1,... concatenated; n_points[i] = vertices of polygon i. */
+int hgl_gt_mask_from_polygons(const double* xy, const int32_t* n_points, int n_polys, int H, int W, uint8_t* mask,
+                              int64_t* area);
+/* uncompressed RLE counts (column-major runs, zeros first) / the compressed string form */
+int hgl_gt_mask_from_rle_counts(const uint32_t* counts, int m, int H, int W, uint8_t* mask, int64_t* area);
+int hgl_gt_mask_from_rle_string(const char* s, int H, int W, uint8_t* mask, int64_t* area);
+
 #ifdef __cplusplus
 }
 #endif
