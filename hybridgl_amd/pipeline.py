@@ -33,6 +33,7 @@ class Sentence:
     relaflag: str = "none"         # extract_rela_word  (utils.py:206-238)
     n_nouns: int = 0               # len(nouns) of extract_nouns (Hybridgl_main.py:184)
     imgattn: Optional[torch.Tensor] = None  # [H,W] fp32: gem_model(...) resized to the image (:200-202)
+    target: Optional[torch.Tensor] = None   # [H,W] per-phrase ground truth (Hybridgl_main_PhraseCut.py:117-119); else RefBatch.target
 
 
 @dataclass
@@ -134,7 +135,10 @@ class HybridGLPipeline:
         else:
             if self.mask_generator is not None:
                 # Hybridgl_main.py:85 mask_generator.generate(sam_img), kept on the device
-                if self.use_sam_masks or self.fixed_proposals is not None:
+                if self.use_sam_masks and getattr(self.mask_generator, "crop_n_layers", 0) > 0:
+                    # PhraseCut configuration (Hybridgl_main_PhraseCut.py:56-62): crop layers, cross-crop NMS
+                    prop = self.mask_generator.generate_device_crops(ref.sam_img)[:4]
+                elif self.use_sam_masks or self.fixed_proposals is not None:
                     prop = self.mask_generator.generate_device(ref.sam_img, resized=ref.sam_resized,
                                                                fixed_n=self.fixed_proposals)
                 else:  # proposal kernels only, nothing read back
@@ -165,8 +169,9 @@ class HybridGLPipeline:
             idx, sc, sn = ops.score_sentence(hybrid, text[s.sentence_row], text[s.noun_phrase_row], others,
                                              ref.boxes, gem, m.model._logit_scale_exp, self.r, self.k1,
                                              self.k2, self.alpha, s.relaflag, s.n_nouns != 0)
-            iu0 = ops.iou_select(ref.masks, idx, 0, ref.target)
-            iu1 = ops.iou_select(ref.masks, idx, 1, ref.target)
+            tgt = s.target if s.target is not None else ref.target
+            iu0 = ops.iou_select(ref.masks, idx, 0, tgt)
+            iu1 = ops.iou_select(ref.masks, idx, 1, tgt)
             self.cum[0:2] += iu0
             self.cum[2:4] += iu1
             self.iu_log.append((iu0, iu1))

@@ -161,3 +161,46 @@ class ReferDataset:
                     cat_name=self.cat_names[index], img_id=[ref["image_id"]], ref_id=rid,
                     sent_ids=list(ref["sent_ids"]))
         return data, annot, self.sentence_raws[index]
+
+
+def phrasecut_polygons_to_mask(polygons, w, h):
+    """data/dataset_phrasecut.py:108-122: instance polygons [[(x, y), ...], ...] -> bool [h, w]; vertices are
+    truncated to int and filled with Pillow's polygon rasteriser (outline + fill), exactly as the reference does."""
+    from PIL import Image, ImageDraw
+    acc = np.zeros((h, w))
+    for polygon in polygons:
+        if len(polygon) < 2:
+            continue
+        pts = [(int(x), int(y)) for x, y in polygon]
+        img = Image.new("L", (w, h), 0)
+        ImageDraw.Draw(img).polygon(pts, outline=1, fill=1)
+        acc += np.array(img)
+    return acc > 0
+
+
+def phrasecut_item(sam_img, phrases, gt_polygons, device, tokenizer, parse=None, heatmaps=None, image_id=None,
+                   context_length=77):
+    """One PhraseCut dataset item (data/dataset_phrasecut.py:36-104; Hybridgl_main_PhraseCut.py:67-119): one image,
+    all its phrases, one ground-truth mask per phrase (gt_polygons[i] = the list of instance polygon lists of
+    phrase i, flattened as the reference does) -> pipeline.RefBatch whose sentences carry their own targets."""
+    import torch
+    from . import synth
+    from .pipeline import RefBatch, Sentence
+    from .tokenizer import tokenize
+    H, W = sam_img.shape[:2]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    strings, sents = [], []
+    for i, phrase in enumerate(phrases):
+        rec = (parse or {}).get(phrase, {})
+        row = len(strings)
+        others = list(rec.get("other_nouns", []))
+        strings += [phrase, rec.get("noun_phrase", phrase)] + others
+        flat = [p for inst in gt_polygons[i] for p in inst]
+        gt = phrasecut_polygons_to_mask(flat, W, H)
+        attn = t(np.asarray(heatmaps[i], np.float32)) if heatmaps is not None else torch.ones((H, W), dtype=torch.float32, device=device)
+        sents.append(Sentence(row, row + 1, list(range(row + 2, row + 2 + len(others))), rec.get("dirflag", "none"),
+                              rec.get("relaflag", "none"), len(others), attn, t(gt.astype(np.uint8))))
+    tokens = tokenize(strings, context_length=context_length, tokenizer=tokenizer)
+    return RefBatch(t(sam_img), t(synth.box_blur_u8(sam_img)), t(synth.imagenet_normalize(sam_img)),
+                    torch.zeros((1, H, W), dtype=torch.bool, device=device), torch.zeros((1, 4), dtype=torch.int64, device=device),
+                    t(tokens), sents[0].target, sents, None, image_id)
