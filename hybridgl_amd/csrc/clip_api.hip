@@ -24,8 +24,10 @@ int run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, c
   const int M = B * S;
   const int hd = D / heads;
   const long long sQKV = (long long)S * 3 * D;
-  if (hgl_use_x3(w.in_proj_w, D) && hgl_use_x3(w.out_proj_w, D) && hgl_use_x3(w.fc_w, D) && hgl_use_x3(w.proj_w, 4 * D) &&
-      (D % 256) == 0) {
+  // (M <= 1024 -- the text encoder, tiny batches -- goes through hgl_launch_gemm below, which hands GEMMs with a
+  // registered weight to the small-tile f16x3 kernel: a handful of 128x128 tiles would be latency-bound)
+  if (M > 1024 && hgl_use_x3(w.in_proj_w, D) && hgl_use_x3(w.out_proj_w, D) && hgl_use_x3(w.fc_w, D) &&
+      hgl_use_x3(w.proj_w, 4 * D) && (D % 256) == 0) {
     // split-fp16 matrix-core path: activations feeding a GEMM exist only as fp16 (hi, lo) halves,
     // which alias the fp32 scratch buffers (same byte size).
     uint16_t* Hh = (uint16_t*)bf.H;

@@ -226,6 +226,9 @@ int hgl_launch_gemm(const float* A, const float* W, const float* bias, const flo
   HGL_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: A and W must be 16-byte aligned");
   HGL_REQUIRE((sA & 3) == 0 && (sW & 3) == 0, "gemm: batch strides of A and W must be multiples of 4");
   HGL_REQUIRE(act >= 0 && act <= 3, "gemm: bad activation %d", act);
+  // f16x3 mode, small M, registered weight: the split-fp16 small-tile kernel (gemm_f16x3.hip)
+  if (hgl_gemm_skinny_applicable(W, M, N, K, lda, ldw, batch))
+    return hgl_launch_gemm_x3_skinny(A, lda, W, bias, R, ldr, C, ldc, M, N, K, act, st);
   GemmArgs g;
   g.A = A; g.W = W; g.bias = bias; g.R = R; g.C = C;
   g.M = M; g.N = N; g.K = K;

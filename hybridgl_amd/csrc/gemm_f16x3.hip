@@ -476,6 +476,86 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-M GEMMs (token MLPs / hyper-networks / IoU head of the SAM decoder, the text encoder, the heads): a few
+// dozen output tiles with K up to 2048 leave the 128x128 kernels latency-bound (8 workgroups, 64 serial K tiles:
+// 53 us for 448x256x2048).  Here one workgroup owns a 32x32 tile and its four waves split the K range
+// (k-steps w, w+4, ...), fragments come straight from global memory in MFMA operand layout (A split to hi+lo in
+// registers, W from the registered fp16 planes), partial accumulators are summed through LDS in a fixed order.
+struct SkinnyArgs {
+  const float* A;
+  const _Float16 *Wh, *Wl;
+  const float *bias, *R;
+  float* C;
+  int M, N, K, lda, ldr, ldc;
+  float out_scale;
+};
+
+template <int ACT>
+__global__ __launch_bounds__(256) void gemm_x3_skinny_kernel(SkinnyArgs g) {
+  __shared__ float red[3][16][64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int row0 = blockIdx.y * 32, col0 = blockIdx.x * 32;
+  const float* ap = g.A + (long long)min(row0 + r, g.M - 1) * g.lda + 8 * h;
+  const long long wo = (long long)min(col0 + r, g.N - 1) * g.K + 8 * h;
+  const _Float16 *whp = g.Wh + wo, *wlp = g.Wl + wo;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int nks = g.K >> 4;
+  auto step = [&](const f32x4 a0, const f32x4 a1, const f16x8 wh, const f16x8 wl) {
+    f16x8 ah, al;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const _Float16 h0 = (_Float16)a0[e], h1 = (_Float16)a1[e];
+      ah[e] = h0; ah[4 + e] = h1;
+      al[e] = (_Float16)(a0[e] - (float)h0);
+      al[4 + e] = (_Float16)(a1[e] - (float)h1);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc, 0, 0, 0);
+  };
+  int ks = wave;
+  for (; ks + 12 < nks; ks += 16) {   // four of this wave's k-steps per trip: 16 loads in flight
+    f32x4 a0[4], a1[4];
+    f16x8 wh[4], wl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = 16 * (ks + 4 * u);
+      a0[u] = *(const f32x4*)(ap + k); a1[u] = *(const f32x4*)(ap + k + 4);
+      wh[u] = *(const f16x8*)(whp + k); wl[u] = *(const f16x8*)(wlp + k);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) step(a0[u], a1[u], wh[u], wl[u]);
+  }
+  for (; ks < nks; ks += 4) {
+    const int k = 16 * ks;
+    step(*(const f32x4*)(ap + k), *(const f32x4*)(ap + k + 4), *(const f16x8*)(whp + k), *(const f16x8*)(wlp + k));
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave - 1][e][lane] = acc[e];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = ((acc[e] + red[0][e][lane]) + red[1][e][lane]) + red[2][e][lane];
+  const int col = col0 + r;
+  if (col >= g.N) return;
+  const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    if (row < g.M) {
+      float v = act_apply<ACT>(acc[e] * g.out_scale + bv);
+      if (g.R) v += g.R[(long long)row * g.ldr + col];
+      g.C[(long long)row * g.ldc + col] = v;
+    }
+  }
+}
+
 // x (fp32) * 2^scale_log2 -> hi, lo fp16
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, float scale,
                                                         _Float16* __restrict__ hi, _Float16* __restrict__ lo,
@@ -689,6 +769,33 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
     default: HGL_X3_VARIANTS(HGL_ACT_NONE); break;
   }
   return hgl_check_launch("gemm_f16x3");
+}
+
+// fp32-A entry for small M (called from hgl_launch_gemm): true when the GEMM was taken
+bool hgl_gemm_skinny_applicable(const float* W32, int M, int N, int K, int lda, int ldw, int batch) {
+  if (g_precision != HGL_PREC_F16X3 || batch != 1 || M > 1024 || (K & 15) || (lda & 3) || ldw != K) return false;
+  auto it = g_split.find((const void*)W32);
+  return it != g_split.end() && it->second.N == N && it->second.K == K;
+}
+
+int hgl_launch_gemm_x3_skinny(const float* A, int lda, const float* W32, const float* bias, const float* R, int ldr,
+                              float* C, int ldc, int M, int N, int K, int act, hipStream_t st) {
+  auto it = g_split.find((const void*)W32);
+  HGL_REQUIRE(it != g_split.end(), "gemm_x3_skinny: weight has no registered split");
+  const SplitW& sw = it->second;
+  SkinnyArgs g;
+  g.A = A; g.Wh = sw.hi; g.Wl = sw.lo; g.bias = bias; g.R = R; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldr = ldr; g.ldc = ldc;
+  g.out_scale = ldexpf(1.0f, -sw.scale_log2);
+  const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
+  HglProfScope prof(HGL_PROF_OTHER, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
+  switch (act) {
+    case HGL_ACT_QUICKGELU: hipLaunchKernelGGL(gemm_x3_skinny_kernel<HGL_ACT_QUICKGELU>, grid, dim3(256), 0, st, g); break;
+    case HGL_ACT_GELU: hipLaunchKernelGGL(gemm_x3_skinny_kernel<HGL_ACT_GELU>, grid, dim3(256), 0, st, g); break;
+    case HGL_ACT_RELU: hipLaunchKernelGGL(gemm_x3_skinny_kernel<HGL_ACT_RELU>, grid, dim3(256), 0, st, g); break;
+    default: hipLaunchKernelGGL(gemm_x3_skinny_kernel<HGL_ACT_NONE>, grid, dim3(256), 0, st, g); break;
+  }
+  return hgl_check_launch("gemm_x3_skinny");
 }
 
 extern "C" {

@@ -101,6 +101,7 @@ int hgl_launch_pe(const float* coords01, const float* G, int n, int F, int mode,
 int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const float* sparse, int P, int C,
                             float* tokens, hipStream_t st);
 int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long rows, float eps, hipStream_t st);
+int hgl_launch_hyper_logits(const float* u2, const float* hyper, int P, int g, float* low_res, hipStream_t st);
 int hgl_launch_unshuffle_logits(const float* Lg, int P, int g, float* out, hipStream_t st);
 
 // split-fp16 GEMM path (gemm_f16x3.hip)
@@ -109,6 +110,9 @@ bool hgl_has_split_weight(const float* W);
 int hgl_launch_split_f16(const float* x, float scale, void* hi, void* lo, long long n, hipStream_t st);
 int hgl_launch_layernorm_split(const float* x, const float* w, const float* b, void* hi, void* lo, int rows, int D,
                                float eps, hipStream_t st);
+bool hgl_gemm_skinny_applicable(const float* W32, int M, int N, int K, int lda, int ldw, int batch);
+int hgl_launch_gemm_x3_skinny(const float* A, int lda, const float* W32, const float* bias, const float* R, int ldr,
+                              float* C, int ldc, int M, int N, int K, int act, hipStream_t st);
 int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* W32, const float* bias, const float* R,
                           int ldr, float* C, void* Ch, void* Cl, int ldc, int M, int N, int K, int act, hipStream_t st);
 int hgl_launch_win_partition_split(const float* H, int g, int ws, int nw, int D, void* hi, void* lo, hipStream_t st);

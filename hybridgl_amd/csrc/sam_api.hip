@@ -354,10 +354,10 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
     HGL_TRY(lin(p.hy_a, C, w->hyper[i][1], nullptr, 0, p.hy_b, C, P, C, C, HGL_ACT_RELU, st));
     HGL_TRY(lin(p.hy_b, C, w->hyper[i][2], nullptr, 0, p.hyper + i * C8, 4 * C8, P, C8, C, HGL_ACT_NONE, st));
   }
-  // masks[p, t, pix] = hyper[p, t, :] . upscaled[p, pix, :]   (one batched GEMM, N = 4 tokens)
-  HGL_TRY(hgl_launch_gemm(p.u2, p.hyper, nullptr, nullptr, p.lg, HW * 16, 4, C8, C8, C8, 0, 4, P,
-                          (long long)HW * 16 * C8, 4 * C8, 0, (long long)HW * 16 * 4, HGL_ACT_NONE, st));
-  HGL_TRY(hgl_launch_unshuffle_logits(p.lg, P, g, low_res, st));
+  // masks[p, t, pix] = hyper[p, t, :] . upscaled[p, pix, :] for the three multimask tokens, un-shuffled into
+  // [P,3,4g,4g] by the same kernel
+  HGL_REQUIRE(C8 == 32, "sam_decode: hyper-network width %d unsupported (32 expected)", C8);
+  HGL_TRY(hgl_launch_hyper_logits(p.u2, p.hyper, P, g, low_res, st));
   // ---- IoU head on the iou token (row 0); multimask output = columns 1..3 ----
   HGL_TRY(lin(p.queries, T * C, w->iou_head[0], nullptr, 0, p.iou_a, C, P, C, C, HGL_ACT_RELU, st));
   HGL_TRY(lin(p.iou_a, C, w->iou_head[1], nullptr, 0, p.iou_b, C, P, C, C, HGL_ACT_RELU, st));

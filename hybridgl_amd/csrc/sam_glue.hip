@@ -254,6 +254,41 @@ __global__ __launch_bounds__(256) void unshuffle_logits_kernel(const float* __re
   out[i] = Lg[((long long)p * g * g * 16 + row) * 4 + (t + 1)];
 }
 
+// masks[p, t, Y, X] = hyper[p, t+1, :] . upscaled[p, pixel(Y,X), :]  (mask_decoder.py:146-151, multimask rows 1..3),
+// written straight into the [P,3,4g,4g] low-res layout.  upscaled = u2 [P*g*g*16, 32]: one 128-byte row per output
+// pixel, ordered (y, x, ky, kx, ky2, kx2) by the two stride-2 transposed convolutions.  Eight lanes share a row (one
+// 16-byte load each: every 128-byte line is fetched by one coalesced access) and reduce with three shuffle steps;
+// a wave covers 8 consecutive X, so the three plane writes are 32-byte segments.  Replaces a [.., 4]-column GEMM
+// (a 128-wide MFMA tile 97 % empty, 431 us) plus the un-shuffle pass (46 us); HBM-bound: 537 MB read, 50 MB written.
+__global__ __launch_bounds__(256) void hyper_logits_kernel(const float* __restrict__ u2, const float* __restrict__ hyper,
+                                                           int g, float* __restrict__ out) {
+  const int S4 = 4 * g;
+  const int p = blockIdx.y, Y = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int sub = lane & 7, grp = lane >> 3;
+  const float* hp = hyper + (long long)p * 4 * 32;
+  const f32x4 h1 = *(const f32x4*)(hp + 32 + 4 * sub), h2 = *(const f32x4*)(hp + 64 + 4 * sub),
+              h3 = *(const f32x4*)(hp + 96 + 4 * sub);
+  const int y = Y >> 2, ky = (Y >> 1) & 1, ky2 = Y & 1;
+  const float* base = u2 + (long long)p * g * g * 16 * 32;
+  float* o = out + ((long long)p * 3 * S4 + Y) * S4;
+  const long long plane = (long long)S4 * S4;
+  for (int X0 = wave * 8; X0 < S4; X0 += 32) {
+    const int X = X0 + grp;
+    const int x = X >> 2, kx = (X >> 1) & 1, kx2 = X & 1;
+    const long long row = (((long long)y * g + x) * 4 + (ky * 2 + kx)) * 4 + (ky2 * 2 + kx2);
+    const f32x4 v = *(const f32x4*)(base + row * 32 + 4 * sub);
+    float a1 = v[0] * h1[0], a2 = v[0] * h2[0], a3 = v[0] * h3[0];
+#pragma unroll
+    for (int e = 1; e < 4; ++e) { a1 += v[e] * h1[e]; a2 += v[e] * h2[e]; a3 += v[e] * h3[e]; }
+#pragma unroll
+    for (int s2 = 1; s2 < 8; s2 <<= 1) {
+      a1 += __shfl_xor(a1, s2); a2 += __shfl_xor(a2, s2); a3 += __shfl_xor(a3, s2);
+    }
+    if (sub == 0) { o[X] = a1; o[plane + X] = a2; o[2 * plane + X] = a3; }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Fused post-processing of the mask logits (never writes a full-resolution fp32 tensor):
 // low-res logits [K][hl][wl] -> bilinear to S x S -> crop [hi, wi] -> bilinear to H x W
@@ -695,6 +730,11 @@ int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const f
 int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long rows, float eps, hipStream_t st) {
   hipLaunchKernelGGL(ln_gelu64_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, w, b, rows, eps);
   return hgl_check_launch("ln_gelu64");
+}
+int hgl_launch_hyper_logits(const float* u2, const float* hyper, int P, int g, float* low_res, hipStream_t st) {
+  HGL_REQUIRE((4 * g) % 32 == 0, "hyper_logits: 4*grid must be a multiple of 32 (grid %d)", g);
+  hipLaunchKernelGGL(hyper_logits_kernel, dim3(4 * g, P), dim3(256), 0, st, u2, hyper, g, low_res);
+  return hgl_check_launch("hyper_logits");
 }
 int hgl_launch_unshuffle_logits(const float* Lg, int P, int g, float* out, hipStream_t st) {
   const long long total = (long long)P * 3 * 16 * g * g;

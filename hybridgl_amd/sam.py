@@ -97,6 +97,9 @@ class Sam:
 
         def lin(dst, key):
             dst.w, dst.b = t(sd[f"{key}.weight"]), t(sd[f"{key}.bias"])
+            wshape = np.asarray(sd[f"{key}.weight"]).shape
+            if precision == "f16x3" and len(wshape) == 2 and wshape[1] % 16 == 0:
+                ops.register_split_weight(self._t[-2])     # small-M GEMMs of the decoder (token MLPs, hyper-nets, IoU head)
 
         def attn(dst, key):
             for nm in ("q", "k", "v", "out"):
