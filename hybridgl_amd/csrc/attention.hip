@@ -522,6 +522,223 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Attention with a handful of keys (the mask decoder's image -> token direction, transformer.py:139-150: 4096
+// image queries per prompt against the 7 prompt tokens, 8 heads of 16).  An MFMA tile would be 78 % padding;
+// here one thread owns one (query, head): 16 q values in registers, the prompt's K and V (Sk x H*16 floats each)
+// in LDS, scores / softmax / PV on the VALU.  HBM-bound: reads q once, writes the output once -- as fp32 or
+// directly as the fp16 hi+lo pair the following f16x3 out-projection consumes.
+struct SmallKArgs {
+  const float *q, *k, *v;
+  float* out;
+  _Float16 *out_hi, *out_lo;
+  int B, H, Sq, Sk, ldq, ldk, ldv, ldo;
+  long long sqb, skb, svb, sob;
+  float scale;
+};
+
+constexpr int SMALLK_MAX = 8;
+
+__global__ __launch_bounds__(256) void attn_smallk_kernel(SmallKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float kv_s[];   // [2][Sk][H*16]
+  const int HD = 16, W = a.H * HD;
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < a.Sk * (W / 4); i += 256) {
+    const int j = i / (W / 4), c = i - j * (W / 4);
+    ((f32x4*)kv_s)[i] = *(const f32x4*)(a.k + b * a.skb + (long long)j * a.ldk + 4 * c);
+    ((f32x4*)kv_s)[a.Sk * (W / 4) + i] = *(const f32x4*)(a.v + b * a.svb + (long long)j * a.ldv + 4 * c);
+  }
+  __syncthreads();
+  const int qpb = 256 / a.H;                       // queries per workgroup
+  const int hh = threadIdx.x % a.H, ql = threadIdx.x / a.H;
+  const int qi = blockIdx.x * qpb + ql;
+  if (ql >= qpb || qi >= a.Sq) return;
+  const float* qp = a.q + b * a.sqb + (long long)qi * a.ldq + hh * HD;
+  f32x4 qv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) qv[c] = *(const f32x4*)(qp + 4 * c);
+  float sc[SMALLK_MAX];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < SMALLK_MAX; ++j) {
+    sc[j] = -3.0e38f;
+    if (j < a.Sk) {
+      const float* kr = kv_s + j * W + hh * HD;
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 kk = *(const f32x4*)(kr + 4 * c);
+        d += qv[c][0] * kk[0]; d += qv[c][1] * kk[1]; d += qv[c][2] * kk[2]; d += qv[c][3] * kk[3];
+      }
+      sc[j] = d * a.scale;
+      mx = fmaxf(mx, sc[j]);
+    }
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < SMALLK_MAX; ++j) {
+    sc[j] = j < a.Sk ? expf(sc[j] - mx) : 0.f;
+    l += sc[j];
+  }
+  const float inv = 1.0f / l;
+  f32x4 o[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < SMALLK_MAX; ++j) {
+    if (j < a.Sk) {
+      const float* vr = kv_s + (a.Sk + j) * W + hh * HD;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 vv = *(const f32x4*)(vr + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[c][e] += sc[j] * vv[e];
+      }
+    }
+  }
+  const long long oo = b * a.sob + (long long)qi * a.ldo + hh * HD;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = o[c][e] * inv;
+    if (a.out) {
+      *(f32x4*)(a.out + oo + 4 * c) = r;
+    } else {
+      h16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (_Float16)r[e];
+        lo[e] = (_Float16)(r[e] - (float)hi[e]);
+      }
+      *(h16x4*)(a.out_hi + oo + 4 * c) = hi;
+      *(h16x4*)(a.out_lo + oo + 4 * c) = lo;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention with a handful of QUERIES over many keys (the mask decoder's token -> image direction,
+// transformer.py:126-131: 7 prompt tokens against 4096 image tokens, 8 heads of 16).  One workgroup per (batch, head);
+// a thread walks keys t, t+256, ... with the running (max, sum, 16-wide output) of all queries in registers, the
+// query vectors broadcast from LDS; the per-thread states are merged with the usual (m, l, o) rule by wave
+// shuffles, then across the four waves through LDS.  HBM-bound (K and V read once); the MFMA kernel spent 78 % of
+// its tile on padding queries.  Workgroups are numbered so that the heads of one batch element share an XCD (they
+// read complementary 64-byte halves of the same 128-byte lines).
+struct FewQArgs {
+  const float *q, *k, *v;
+  float* out;
+  int B, H, Sq, Sk, ldq, ldk, ldv, ldo;
+  long long sqb, skb, svb, sob;
+  float scale;
+};
+
+constexpr int FEWQ_MAX = 8;
+
+__global__ __launch_bounds__(256) void attn_fewq_kernel(FewQArgs a) {
+  constexpr int HD = 16;
+  __shared__ __attribute__((aligned(16))) float q_s[FEWQ_MAX * HD];
+  __shared__ float part[4][FEWQ_MAX][HD + 2];
+  // (b, h) of this workgroup: consecutive workgroups round-robin over the 8 XCDs
+  int bh;
+  {
+    const int bid = blockIdx.x, n = gridDim.x;
+    const int per = a.H * 8;                     // workgroups of 8 batch elements
+    const int full = (n / per) * per;
+    if (bid < full) {
+      const int grp = bid / per, r = bid - grp * per;
+      const int xcd = r & 7, j = r >> 3;          // j-th workgroup of this XCD inside the group
+      bh = (grp * 8 + xcd) * a.H + j;
+    } else {
+      bh = bid;
+    }
+  }
+  const int b = bh / a.H, hh = bh - b * a.H;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < a.Sq * HD) q_s[t] = a.q[b * a.sqb + (long long)(t / HD) * a.ldq + hh * HD + (t % HD)] * a.scale;
+  else if (t < FEWQ_MAX * HD) q_s[t] = 0.f;
+  __syncthreads();
+  float m[FEWQ_MAX], l[FEWQ_MAX];
+  f32x4 o[FEWQ_MAX][4];
+#pragma unroll
+  for (int qi = 0; qi < FEWQ_MAX; ++qi) {
+    m[qi] = -3.0e38f; l[qi] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[qi][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float* kp = a.k + b * a.skb + hh * HD;
+  const float* vp = a.v + b * a.svb + hh * HD;
+  for (int key = t; key < a.Sk; key += 256) {
+    f32x4 kk[4], vv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      kk[c] = *(const f32x4*)(kp + (long long)key * a.ldk + 4 * c);
+      vv[c] = *(const f32x4*)(vp + (long long)key * a.ldv + 4 * c);
+    }
+#pragma unroll
+    for (int qi = 0; qi < FEWQ_MAX; ++qi) {
+      if (qi < a.Sq) {     // uniform
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 qq = *(const f32x4*)(q_s + qi * HD + 4 * c);
+          s += qq[0] * kk[c][0]; s += qq[1] * kk[c][1]; s += qq[2] * kk[c][2]; s += qq[3] * kk[c][3];
+        }
+        const float mn = fmaxf(m[qi], s);
+        const float al = expf(m[qi] - mn), p = expf(s - mn);
+        l[qi] = l[qi] * al + p;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[qi][c][e] = o[qi][c][e] * al + p * vv[c][e];
+        m[qi] = mn;
+      }
+    }
+  }
+  // merge the 64 lanes of a wave
+#pragma unroll
+  for (int qi = 0; qi < FEWQ_MAX; ++qi) {
+    if (qi < a.Sq) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float m2 = __shfl_xor(m[qi], off), l2 = __shfl_xor(l[qi], off);
+        const float mn = fmaxf(m[qi], m2);
+        const float a1 = expf(m[qi] - mn), a2 = expf(m2 - mn);
+        l[qi] = l[qi] * a1 + l2 * a2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[qi][c][e] = o[qi][c][e] * a1 + __shfl_xor(o[qi][c][e], off) * a2;
+        m[qi] = mn;
+      }
+      if (lane == 0) {
+        part[wave][qi][HD] = m[qi];
+        part[wave][qi][HD + 1] = l[qi];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part[wave][qi][4 * c + e] = o[qi][c][e];
+      }
+    }
+  }
+  __syncthreads();
+  // the four waves: thread (qi, d) combines in wave order
+  if (t < a.Sq * HD) {
+    const int qi = t / HD, d = t % HD;
+    float mm = part[0][qi][HD];
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) mm = fmaxf(mm, part[w2][qi][HD]);
+    float ll = 0.f, oo = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const float sc = expf(part[w2][qi][HD] - mm);
+      ll += part[w2][qi][HD + 1] * sc;
+      oo += part[w2][qi][d] * sc;
+    }
+    a.out[b * a.sob + (long long)qi * a.ldo + hh * HD + d] = oo / ll;
+  }
+}
+
 template <int HD>
 int launch_hd(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.Sq + 127) / 128, a.B * a.H);
@@ -539,6 +756,39 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// few-key attention (Sk <= 8, head dim 16): output fp32 (out) or the fp16 split pair (out == nullptr)
+int hgl_launch_attention_smallk(const float* q, const float* k, const float* v, float* out, void* out_hi, void* out_lo,
+                                int B, int H, int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
+                                long long skb, long long svb, long long sob, float scale, hipStream_t st) {
+  HGL_REQUIRE(q && k && v && (out || (out_hi && out_lo)), "attention_smallk: null operand");
+  HGL_REQUIRE(hd == 16 && Sk >= 1 && Sk <= SMALLK_MAX && H >= 1 && 256 % H == 0, "attention_smallk: unsupported shape (hd %d, Sk %d, H %d)", hd, Sk, H);
+  HGL_REQUIRE(((ldq | ldk | ldv | ldo) & 3) == 0 && ((sqb | skb | svb | sob) & 3) == 0, "attention_smallk: strides must be multiples of 4");
+  HGL_REQUIRE(B <= 65535, "attention_smallk: B too large");
+  SmallKArgs a;
+  a.q = q; a.k = k; a.v = v; a.out = out; a.out_hi = (_Float16*)out_hi; a.out_lo = (_Float16*)out_lo;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.sqb = sqb; a.skb = skb; a.svb = svb; a.sob = sob; a.scale = scale;
+  const int qpb = 256 / H;
+  HglProfScope prof(HGL_PROF_ATTN, 4.0 * B * (double)H * Sq * Sk * hd, 0.0, st);
+  hipLaunchKernelGGL(attn_smallk_kernel, dim3((unsigned)((Sq + qpb - 1) / qpb), (unsigned)B), dim3(256),
+                     (size_t)2 * Sk * H * 16 * sizeof(float), st, a);
+  return hgl_check_launch("attention_smallk");
+}
+
+int hgl_launch_attention_fewq(const float* q, const float* k, const float* v, float* out, int B, int H, int Sq, int Sk,
+                              int hd, int ldq, int ldk, int ldv, int ldo, long long sqb, long long skb, long long svb,
+                              long long sob, float scale, hipStream_t st) {
+  HGL_REQUIRE(q && k && v && out, "attention_fewq: null operand");
+  HGL_REQUIRE(hd == 16 && Sq >= 1 && Sq <= FEWQ_MAX, "attention_fewq: unsupported shape (hd %d, Sq %d)", hd, Sq);
+  HGL_REQUIRE(((ldk | ldv) & 3) == 0 && ((skb | svb) & 3) == 0, "attention_fewq: K/V strides must be multiples of 4");
+  FewQArgs a;
+  a.q = q; a.k = k; a.v = v; a.out = out; a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.sqb = sqb; a.skb = skb; a.svb = svb; a.sob = sob; a.scale = scale;
+  HglProfScope prof(HGL_PROF_ATTN, 4.0 * B * (double)H * Sq * Sk * hd, 0.0, st);
+  hipLaunchKernelGGL(attn_fewq_kernel, dim3((unsigned)(B * H)), dim3(256), 0, st, a);
+  return hgl_check_launch("attention_fewq");
+}
+
 int hgl_launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H,
                          int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
                          long long skb, long long svb, long long sob, float scale, int mask_kind,
@@ -554,6 +804,11 @@ int hgl_launch_attention(const float* q, const float* k, const float* v, float* 
   HGL_REQUIRE((rel_h == nullptr) == (rel_w == nullptr), "attention: rel_h and rel_w go together");
   HGL_REQUIRE(!rel_h || (kh > 0 && kw > 0 && kh * kw == Sk), "attention: kh*kw must equal Sk");
   HGL_REQUIRE((long long)B * H <= 65535, "attention: B*H too large for grid.y");
+  if (hd == 16 && Sq <= FEWQ_MAX && Sk >= 1024 && mask_kind == HGL_MASK_NONE && !rel_h)
+    return hgl_launch_attention_fewq(q, k, v, out, B, H, Sq, Sk, hd, ldq, ldk, ldv, ldo, sqb, skb, svb, sob, scale, st);
+  if (hd == 16 && Sk <= SMALLK_MAX && Sq >= 256 && mask_kind == HGL_MASK_NONE && !rel_h && 256 % H == 0)
+    return hgl_launch_attention_smallk(q, k, v, out, nullptr, nullptr, B, H, Sq, Sk, hd, ldq, ldk, ldv, ldo, sqb, skb, svb,
+                                       sob, scale, st);
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.out = out;
   a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk;

@@ -45,6 +45,7 @@ struct Args {
   float out_scale;
   int tiles_m, tiles_n;
   int gm;      // M-tiles per tile group (L2 blocking of the resident tile set)
+  int rmod;    // residual row = row % rmod when > 0 (a residual shared by every batch of rows), else row
   int ablate;  // timing experiments only (HGL_X3_ABLATE): 1 = no global loads in the loop, 2 = no LDS stores in the loop
 };
 
@@ -63,7 +64,7 @@ int pick_x3_kernel(int M, int N, int K) {
   static const Cfg cfgs[3] = {
       {HGL_X3_L, 256, 256, 256, 18.0, 2.30, 0.10},
       {HGL_X3_V1, 128, 128, 512, 13.8, 1.37, 0.25},
-      {HGL_X3_N, 128, 160, 512, 10.4, 2.10, 0.25},   // 128x160 LDS-DMA: N = 1280 / 3840 / 5120 divide evenly
+      {HGL_X3_N, 128, 160, 512, 17.2, 1.93, 0.25},   // 128x160 LDS-DMA: N = 1280 / 3840 / 5120 divide evenly
   };
   const double nk = K / 32.0;
   int best = HGL_X3_V1;
@@ -202,7 +203,10 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
       float rv[16];
       if (g.R) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) rv[e] = g.R[(long long)min(rbase + (e & 3) + 8 * (e >> 2), mclamp) * g.ldr + colc];
+        for (int e = 0; e < 16; ++e) {
+          const int rr = min(rbase + (e & 3) + 8 * (e >> 2), mclamp);
+          rv[e] = g.R[(long long)(g.rmod > 0 ? rr % g.rmod : rr) * g.ldr + colc];
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) rv[e] = 0.f;
@@ -452,7 +456,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
       float rv[16];
       if (g.R) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) rv[e] = g.R[(long long)min(rbase + (e & 3) + 8 * (e >> 2), mclamp) * g.ldr + colc];
+        for (int e = 0; e < 16; ++e) {
+          const int rr = min(rbase + (e & 3) + 8 * (e >> 2), mclamp);
+          rv[e] = g.R[(long long)(g.rmod > 0 ? rr % g.rmod : rr) * g.ldr + colc];
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) rv[e] = 0.f;
@@ -687,6 +694,12 @@ int hgl_launch_layernorm_split(const float* x, const float* w, const float* b, v
 // Output: C fp32 (ldc) or, when C == nullptr, the split pair (Ch, Cl).
 int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* W32, const float* bias, const float* R,
                           int ldr, float* C, void* Ch, void* Cl, int ldc, int M, int N, int K, int act, hipStream_t st) {
+  return hgl_launch_gemm_f16x3_rmod(Ah, Al, lda, W32, bias, R, ldr, 0, C, Ch, Cl, ldc, M, N, K, act, st);
+}
+
+int hgl_launch_gemm_f16x3_rmod(const void* Ah, const void* Al, int lda, const float* W32, const float* bias, const float* R,
+                               int ldr, int rmod, float* C, void* Ch, void* Cl, int ldc, int M, int N, int K, int act,
+                               hipStream_t st) {
   auto it = g_split.find((const void*)W32);
   HGL_REQUIRE(it != g_split.end(), "gemm_f16x3: weight %p has no registered fp16 split", (const void*)W32);
   const SplitW& sw = it->second;
@@ -697,6 +710,7 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
   g.Ah = (const _Float16*)Ah; g.Al = (const _Float16*)Al; g.Wh = sw.hi; g.Wl = sw.lo;
   g.bias = bias; g.R = R; g.C = C; g.Ch = (_Float16*)Ch; g.Cl = (_Float16*)Cl;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldr = ldr; g.ldc = ldc;
+  g.rmod = rmod;
   g.out_scale = ldexpf(1.0f, -sw.scale_log2);
   {
     static int abl = -1;

@@ -53,6 +53,9 @@ int hgl_launch_gemm(const float* A, const float* W, const float* bias, const flo
                     hipStream_t st);
 int hgl_launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D,
                          float eps, hipStream_t st);
+int hgl_launch_attention_smallk(const float* q, const float* k, const float* v, float* out, void* out_hi, void* out_lo,
+                                int B, int H, int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
+                                long long skb, long long svb, long long sob, float scale, hipStream_t st);
 int hgl_launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H,
                          int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
                          long long skb, long long svb, long long sob, float scale, int mask_kind,
@@ -100,7 +103,10 @@ int hgl_launch_pe(const float* coords01, const float* G, int n, int F, int mode,
                   const float* not_a_point, float* out, hipStream_t st);
 int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const float* sparse, int P, int C,
                             float* tokens, hipStream_t st);
-int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long rows, float eps, hipStream_t st);
+int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long rows, float eps, void* hi, void* lo,
+                         hipStream_t st);
+int hgl_launch_ln256_pe_split(float* x, const float* w, const float* b, const float* pe, int pe_rows, long long rows,
+                              float eps, int write_f32, void* kh, void* kl, void* ph, void* pl, hipStream_t st);
 int hgl_launch_hyper_logits(const float* u2, const float* hyper, int P, int g, float* low_res, hipStream_t st);
 int hgl_launch_unshuffle_logits(const float* Lg, int P, int g, float* out, hipStream_t st);
 
@@ -113,6 +119,8 @@ int hgl_launch_layernorm_split(const float* x, const float* w, const float* b, v
 bool hgl_gemm_skinny_applicable(const float* W32, int M, int N, int K, int lda, int ldw, int batch);
 int hgl_launch_gemm_x3_skinny(const float* A, int lda, const float* W32, const float* bias, const float* R, int ldr,
                               float* C, int ldc, int M, int N, int K, int act, hipStream_t st);
+int hgl_launch_gemm_f16x3_rmod(const void* Ah, const void* Al, int lda, const float* W32, const float* bias, const float* R,
+                               int ldr, int rmod, float* C, void* Ch, void* Cl, int ldc, int M, int N, int K, int act, hipStream_t st);
 int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* W32, const float* bias, const float* R,
                           int ldr, float* C, void* Ch, void* Cl, int ldc, int M, int N, int K, int act, hipStream_t st);
 int hgl_launch_win_partition_split(const float* H, int g, int ws, int nw, int D, void* hi, void* lo, hipStream_t st);

@@ -145,7 +145,7 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
 // ------------------------------------------------------------------------------ decoder
 struct DecPlan {
   float *coords, *sparse, *tokens, *queries, *qpe, *q1, *k1, *v1, *att, *keys0, *kpe0, *keys, *kpe, *kp, *vp,
-      *qi, *atti, *mlp, *u1, *u2, *hy_a, *hy_b, *hyper, *lg, *iou_a, *iou_b;
+      *qi, *atti, *mlp, *u1, *u2, *hy_a, *hy_b, *hyper, *iou_a, *iou_b, *keysS;
 };
 
 bool carve_dec(HglArena& ar, const HglSamDecoderW* w, int P, DecPlan& p) {
@@ -172,7 +172,7 @@ bool carve_dec(HglArena& ar, const HglSamDecoderW* w, int P, DecPlan& p) {
   p.hy_a = ar.take<float>((size_t)P * C);
   p.hy_b = ar.take<float>((size_t)P * C);
   p.hyper = ar.take<float>((size_t)P * 4 * (C / 8));
-  p.lg = ar.take<float>(P * HW * 16 * 4);
+  p.keysS = ar.take<float>(P * HW * C);        // f16x3 mode: the normalised image tokens as fp16 hi | lo planes
   p.iou_a = ar.take<float>((size_t)P * C);
   p.iou_b = ar.take<float>((size_t)P * C);
   return ar.ok();
@@ -215,9 +215,64 @@ int dec_attn(const HglSamDecoderW* w, const HglSamAttnW& a, const float* q, bool
                                kv_shared ? 0 : (long long)Nk * I, kv_shared ? 0 : (long long)Nk * I,
                                (long long)Nq * I, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, nullptr,
                                nullptr, 0, 0, st));
-  // out_proj (+ residual); batched so that a shared residual (stride 0) can be broadcast
+  // out_proj (+ residual): one GEMM over all B*Nq rows when the residual is laid out like the output (small row
+  // counts then take the small-tile kernel); batched when a shared residual (stride 0) has to be broadcast
+  if (!R || sR == (long long)Nq * C)
+    return hgl_launch_gemm(att, a.out.w, a.out.b, R, out, B * Nq, C, I, I, I, C, C, 1, 0, 0, 0, 0, HGL_ACT_NONE, st);
   return hgl_launch_gemm(att, a.out.w, a.out.b, R, out, Nq, C, I, I, I, C, C, B, (long long)Nq * I, 0, sR,
                          (long long)Nq * C, HGL_ACT_NONE, st);
+}
+
+// ---- f16x3 path of the decoder's image-token side (M = P*HW rows) -------------------------------------------
+// The normalised image tokens exist as fp16 hi|lo planes (keysS) and, with the positional encoding added, as a
+// second pair (kpeS): ln256_pe_split emits both, the few-key attention emits its output split, so every large
+// GEMM below reads split operands and nothing is converted in a separate pass.
+struct SplitPair { uint16_t *hi, *lo; };
+inline SplitPair split_view(float* buf, size_t elems) { return SplitPair{(uint16_t*)buf, (uint16_t*)buf + elems}; }
+
+bool dec_x3_ready(const HglSamDecoderW* w) {
+  if (hgl_precision() != HGL_PREC_F16X3 || w->C != 256) return false;
+  const float* need[] = {w->layer[0].i2t.out.w, w->layer[1].i2t.out.w, w->layer[1].i2t.q.w, w->layer[1].t2i.k.w,
+                         w->layer[1].t2i.v.w, w->final_t2i.k.w, w->final_t2i.v.w, w->up0_w, w->up3_w};
+  for (const float* x : need) if (!hgl_has_split_weight(x)) return false;
+  return true;
+}
+
+// image -> token attention of one layer (transformer.py:139-150): q = (keys + pe) Wq, 7 token keys / values,
+// keys' = keys + out_proj(attn)   (LayerNorm follows in the caller)
+int dec_i2t_x3(const HglSamDecoderW* w, const HglSamAttnW& a, bool shared, const float* kpe0, const SplitPair& kpeS,
+               const float* tok_k, const float* tok_v, int P, int HW, float* qi, float* k1, float* v1, float* atti,
+               const float* R, int rmod, float* keys_out, hipStream_t st) {
+  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads, T = 7;
+  if (shared) {
+    HGL_TRY(lin(kpe0, C, a.q, nullptr, 0, qi, I, HW, I, C, HGL_ACT_NONE, st));
+  } else {
+    HGL_TRY(hgl_launch_gemm_f16x3(kpeS.hi, kpeS.lo, C, a.q.w, a.q.b, nullptr, 0, qi, nullptr, nullptr, I, P * HW, I, C,
+                                  HGL_ACT_NONE, st));
+  }
+  HGL_TRY(lin(tok_k, C, a.k, nullptr, 0, k1, I, P * T, I, C, HGL_ACT_NONE, st));
+  HGL_TRY(lin(tok_v, C, a.v, nullptr, 0, v1, I, P * T, I, C, HGL_ACT_NONE, st));
+  const SplitPair at = split_view(atti, (size_t)P * HW * I);
+  HGL_TRY(hgl_launch_attention_smallk(qi, k1, v1, nullptr, at.hi, at.lo, P, heads, HW, T, hd, I, I, I, I,
+                                      shared ? 0 : (long long)HW * I, (long long)T * I, (long long)T * I, (long long)HW * I,
+                                      1.0f / sqrtf((float)hd), st));
+  return hgl_launch_gemm_f16x3_rmod(at.hi, at.lo, I, a.out.w, a.out.b, R, C, rmod, keys_out, nullptr, nullptr, C, P * HW, C,
+                                    I, HGL_ACT_NONE, st);
+}
+
+// token -> image attention with per-prompt image tokens (transformer.py:126-131): K/V projections read the split planes
+int dec_t2i_x3(const HglSamDecoderW* w, const HglSamAttnW& a, const float* qpe, const SplitPair& kpeS, const SplitPair& keysS,
+               int P, int HW, float* q1, float* kp, float* vp, float* att, float* queries, hipStream_t st) {
+  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads, T = 7;
+  HGL_TRY(lin(qpe, C, a.q, nullptr, 0, q1, I, P * T, I, C, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_gemm_f16x3(kpeS.hi, kpeS.lo, C, a.k.w, a.k.b, nullptr, 0, kp, nullptr, nullptr, I, P * HW, I, C,
+                                HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_gemm_f16x3(keysS.hi, keysS.lo, C, a.v.w, a.v.b, nullptr, 0, vp, nullptr, nullptr, I, P * HW, I, C,
+                                HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_attention(q1, kp, vp, att, P, heads, T, HW, hd, I, I, I, I, (long long)T * I, (long long)HW * I,
+                               (long long)HW * I, (long long)T * I, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0,
+                               nullptr, nullptr, 0, 0, st));
+  return hgl_launch_gemm(att, a.out.w, a.out.b, queries, queries, P * T, C, I, I, I, C, C, 1, 0, 0, 0, 0, HGL_ACT_NONE, st);
 }
 
 }  // namespace
@@ -302,6 +357,8 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
   HGL_TRY(hgl_launch_add_rows_bcast(p.keys0, 0, w->dense_pe, (long long)HW * C, 1, p.kpe0, st));
   (void)hipMemcpyAsync(p.queries, p.tokens, sizeof(float) * P * sQ, hipMemcpyDeviceToDevice, st);
 
+  const bool x3 = dec_x3_ready(w);
+  const SplitPair keysS = split_view(p.keysS, (size_t)P * HW * C), kpeS = split_view(p.kpe, (size_t)P * HW * C);
   for (int li = 0; li < 2; ++li) {
     const auto& L = w->layer[li];
     const bool shared = li == 0;   // keys identical for every prompt in layer 0
@@ -320,8 +377,12 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
     HGL_TRY(hgl_launch_layernorm(p.queries, L.n1.w, L.n1.b, p.queries, P * T, C, 1e-5f, st));
     // (2) tokens attend to the image
     HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
-    HGL_TRY(dec_attn(w, L.t2i, p.qpe, false, T, kpe, keys, shared, HW, P, p.q1, p.kp, p.vp, p.att, p.queries, sQ,
-                     p.queries, st));
+    if (x3 && !shared) {
+      HGL_TRY(dec_t2i_x3(w, L.t2i, p.qpe, kpeS, keysS, P, HW, p.q1, p.kp, p.vp, p.att, p.queries, st));
+    } else {
+      HGL_TRY(dec_attn(w, L.t2i, p.qpe, false, T, kpe, keys, shared, HW, P, p.q1, p.kp, p.vp, p.att, p.queries, sQ,
+                       p.queries, st));
+    }
     HGL_TRY(hgl_launch_layernorm(p.queries, L.n2.w, L.n2.b, p.queries, P * T, C, 1e-5f, st));
     // (3) MLP on the tokens
     HGL_TRY(lin(p.queries, C, L.lin1, nullptr, 0, p.mlp, w->mlp_dim, P * T, w->mlp_dim, C, HGL_ACT_RELU, st));
@@ -329,25 +390,47 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
     HGL_TRY(hgl_launch_layernorm(p.queries, L.n3.w, L.n3.b, p.queries, P * T, C, 1e-5f, st));
     // (4) image attends to the tokens: q = keys+pe, k = queries+pe, v = queries ; keys += out
     HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
-    HGL_TRY(dec_attn(w, L.i2t, kpe, shared, HW, p.qpe, p.queries, false, T, P, p.qi, p.k1, p.v1, p.atti, keys,
-                     shared ? 0 : sK, p.keys, st));
-    HGL_TRY(hgl_launch_layernorm(p.keys, L.n4.w, L.n4.b, p.keys, P * HW, C, 1e-5f, st));
-    HGL_TRY(hgl_launch_add_rows_bcast(p.keys, sK, w->dense_pe, sK, P, p.kpe, st));
+    if (x3) {
+      HGL_TRY(dec_i2t_x3(w, L.i2t, shared, p.kpe0, kpeS, p.qpe, p.queries, P, HW, p.qi, p.k1, p.v1, p.atti, keys,
+                         shared ? HW : 0, p.keys, st));
+      // norm4, then keys and keys + dense_pe as split planes; the fp32 rows are kept only while a later layer needs
+      // them as a residual
+      HGL_TRY(hgl_launch_ln256_pe_split(p.keys, L.n4.w, L.n4.b, w->dense_pe, HW, (long long)P * HW, 1e-5f, li == 0 ? 1 : 0,
+                                        keysS.hi, keysS.lo, kpeS.hi, kpeS.lo, st));
+    } else {
+      HGL_TRY(dec_attn(w, L.i2t, kpe, shared, HW, p.qpe, p.queries, false, T, P, p.qi, p.k1, p.v1, p.atti, keys,
+                       shared ? 0 : sK, p.keys, st));
+      HGL_TRY(hgl_launch_layernorm(p.keys, L.n4.w, L.n4.b, p.keys, P * HW, C, 1e-5f, st));
+      HGL_TRY(hgl_launch_add_rows_bcast(p.keys, sK, w->dense_pe, sK, P, p.kpe, st));
+    }
   }
   // final token -> image attention
   HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
-  HGL_TRY(dec_attn(w, w->final_t2i, p.qpe, false, T, p.kpe, p.keys, false, HW, P, p.q1, p.kp, p.vp, p.att, p.queries,
-                   sQ, p.queries, st));
+  if (x3) {
+    HGL_TRY(dec_t2i_x3(w, w->final_t2i, p.qpe, kpeS, keysS, P, HW, p.q1, p.kp, p.vp, p.att, p.queries, st));
+  } else {
+    HGL_TRY(dec_attn(w, w->final_t2i, p.qpe, false, T, p.kpe, p.keys, false, HW, P, p.q1, p.kp, p.vp, p.att, p.queries,
+                     sQ, p.queries, st));
+  }
   HGL_TRY(hgl_launch_layernorm(p.queries, w->norm_final.w, w->norm_final.b, p.queries, P * T, C, 1e-5f, st));
 
   // ---- output upscaling: two ConvTranspose2d(k=2,s=2) as GEMMs, columns ordered (pos, out_channel) ----
   const int C4 = C / 4, C8 = C / 8;
-  HGL_TRY(hgl_launch_gemm(p.keys, w->up0_w, w->up0_b, nullptr, p.u1, P * HW, 4 * C4, C, C, C, 0, 4 * C4, 1, 0, 0, 0, 0,
-                          HGL_ACT_NONE, st));
   HGL_REQUIRE(C4 == 64, "sam_decode: LayerNorm2d width %d unsupported (64 expected)", C4);
-  HGL_TRY(hgl_launch_ln_gelu64(p.u1, w->up1.w, w->up1.b, (long long)P * HW * 4, 1e-6f, st));
-  HGL_TRY(hgl_launch_gemm(p.u1, w->up3_w, w->up3_b, nullptr, p.u2, P * HW * 4, 4 * C8, C4, C4, C4, 0, 4 * C8, 1, 0, 0,
-                          0, 0, HGL_ACT_GELU, st));
+  if (x3) {
+    HGL_TRY(hgl_launch_gemm_f16x3(keysS.hi, keysS.lo, C, w->up0_w, w->up0_b, nullptr, 0, p.u1, nullptr, nullptr, 4 * C4,
+                                  P * HW, 4 * C4, C, HGL_ACT_NONE, st));
+    const SplitPair u1S = split_view(p.kpe, (size_t)P * HW * 4 * C4);   // kpeS is dead from here on
+    HGL_TRY(hgl_launch_ln_gelu64(p.u1, w->up1.w, w->up1.b, (long long)P * HW * 4, 1e-6f, u1S.hi, u1S.lo, st));
+    HGL_TRY(hgl_launch_gemm_f16x3(u1S.hi, u1S.lo, C4, w->up3_w, w->up3_b, nullptr, 0, p.u2, nullptr, nullptr, 4 * C8,
+                                  P * HW * 4, 4 * C8, C4, HGL_ACT_GELU, st));
+  } else {
+    HGL_TRY(hgl_launch_gemm(p.keys, w->up0_w, w->up0_b, nullptr, p.u1, P * HW, 4 * C4, C, C, C, 0, 4 * C4, 1, 0, 0, 0, 0,
+                            HGL_ACT_NONE, st));
+    HGL_TRY(hgl_launch_ln_gelu64(p.u1, w->up1.w, w->up1.b, (long long)P * HW * 4, 1e-6f, nullptr, nullptr, st));
+    HGL_TRY(hgl_launch_gemm(p.u1, w->up3_w, w->up3_b, nullptr, p.u2, P * HW * 4, 4 * C8, C4, C4, C4, 0, 4 * C8, 1, 0, 0,
+                            0, 0, HGL_ACT_GELU, st));
+  }
   // ---- hyper-networks on the mask tokens (rows 1..4 of each prompt's 7 tokens) ----
   for (int i = 0; i < 4; ++i) {
     HGL_TRY(lin(p.queries + (1 + i) * C, T * C, w->hyper[i][0], nullptr, 0, p.hy_a, C, P, C, C, HGL_ACT_RELU, st));

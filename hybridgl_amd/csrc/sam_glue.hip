@@ -13,6 +13,7 @@
 #include <math.h>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4g __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -226,10 +227,11 @@ __device__ __forceinline__ float wsum(float v) {
   return v;
 }
 
-// in-place LayerNorm over rows of 64 channels followed by erf-GELU: one wave per row
+// LayerNorm over rows of 64 channels followed by erf-GELU: one wave per row; in place (hi == nullptr) or into the
+// fp16 hi+lo pair that the following f16x3 GEMM reads
 __global__ __launch_bounds__(256) void ln_gelu64_kernel(float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, long long rows,
-                                                        float eps) {
+                                                        float eps, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -238,7 +240,51 @@ __global__ __launch_bounds__(256) void ln_gelu64_kernel(float* __restrict__ x, c
   const float d = v - mean;
   const float var = wsum(d * d) * (1.f / 64.f);
   v = d * rsqrtf(var + eps) * w[lane] + b[lane];
-  x[row * 64 + lane] = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  const float o = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  if (hi) {
+    const _Float16 h = (_Float16)o;
+    hi[row * 64 + lane] = h;
+    lo[row * 64 + lane] = (_Float16)(o - (float)h);
+  } else {
+    x[row * 64 + lane] = o;
+  }
+}
+
+// LayerNorm of the decoder's image tokens (rows of 256) emitting what the next GEMMs read: optionally the fp32 row
+// (in place; the residual of the next layer), the row as fp16 hi+lo, and row + positional encoding (pe[row % pe_rows])
+// as hi+lo (TwoWayAttentionBlock: k = keys + key_pe, transformer.py:139-150).  One wave per row.
+__global__ __launch_bounds__(256) void ln256_pe_split_kernel(float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, const float* __restrict__ pe,
+                                                             int pe_rows, long long rows, float eps, int write_f32,
+                                                             _Float16* __restrict__ kh, _Float16* __restrict__ kl,
+                                                             _Float16* __restrict__ ph, _Float16* __restrict__ pl) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 v = ((const f32x4*)(x + row * 256))[lane];
+  const float mean = wsum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / 256.f);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+  const float rstd = rsqrtf(wsum(q) * (1.f / 256.f) + eps);
+  const f32x4 wv = ((const f32x4*)w)[lane], bv = ((const f32x4*)b)[lane];
+  const f32x4 pv = ((const f32x4*)(pe + (row % pe_rows) * 256))[lane];
+  f32x4 o;
+  f16x4g a, c, a2, c2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] = (v[e] - mean) * rstd * wv[e] + bv[e];
+    a[e] = (_Float16)o[e];
+    c[e] = (_Float16)(o[e] - (float)a[e]);
+    const float s2 = o[e] + pv[e];
+    a2[e] = (_Float16)s2;
+    c2[e] = (_Float16)(s2 - (float)a2[e]);
+  }
+  if (write_f32) ((f32x4*)(x + row * 256))[lane] = o;
+  ((f16x4g*)(kh + row * 256))[lane] = a;
+  ((f16x4g*)(kl + row * 256))[lane] = c;
+  ((f16x4g*)(ph + row * 256))[lane] = a2;
+  ((f16x4g*)(pl + row * 256))[lane] = c2;
 }
 
 // Lg: [P][g*g*16][4]  ->  out: [P][3][4g][4g] (mask tokens 1..3)
@@ -727,9 +773,17 @@ int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const f
   hipLaunchKernelGGL(build_tokens_kernel, dim3(grid1((long long)P * 7 * C)), dim3(256), 0, st, iou_tok, mask_tok, sparse, P, C, tokens);
   return hgl_check_launch("build_tokens");
 }
-int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long rows, float eps, hipStream_t st) {
-  hipLaunchKernelGGL(ln_gelu64_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, w, b, rows, eps);
+int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long rows, float eps, void* hi, void* lo,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(ln_gelu64_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, w, b, rows, eps,
+                     (_Float16*)hi, (_Float16*)lo);
   return hgl_check_launch("ln_gelu64");
+}
+int hgl_launch_ln256_pe_split(float* x, const float* w, const float* b, const float* pe, int pe_rows, long long rows,
+                              float eps, int write_f32, void* kh, void* kl, void* ph, void* pl, hipStream_t st) {
+  hipLaunchKernelGGL(ln256_pe_split_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, w, b, pe, pe_rows, rows,
+                     eps, write_f32, (_Float16*)kh, (_Float16*)kl, (_Float16*)ph, (_Float16*)pl);
+  return hgl_check_launch("ln256_pe_split");
 }
 int hgl_launch_hyper_logits(const float* u2, const float* hyper, int P, int g, float* low_res, hipStream_t st) {
   HGL_REQUIRE((4 * g) % 32 == 0, "hyper_logits: 4*grid must be a multiple of 32 (grid %d)", g);

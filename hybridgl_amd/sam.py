@@ -120,10 +120,14 @@ class Sam:
         # ConvTranspose2d(k=2,s=2) weights [Cin,Cout,2,2] -> GEMM rows ordered (ky,kx,cout)
         w0 = np.asarray(sd[f"{m}.output_upscaling.0.weight"])
         dec.up0_w = t(np.transpose(w0, (2, 3, 1, 0)).reshape(-1, w0.shape[0]))
+        if precision == "f16x3":
+            ops.register_split_weight(self._t[-1])
         dec.up0_b = t(np.tile(np.asarray(sd[f"{m}.output_upscaling.0.bias"]), 4))
         lin(dec.up1, f"{m}.output_upscaling.1")
         w3 = np.asarray(sd[f"{m}.output_upscaling.3.weight"])
         dec.up3_w = t(np.transpose(w3, (2, 3, 1, 0)).reshape(-1, w3.shape[0]))
+        if precision == "f16x3":
+            ops.register_split_weight(self._t[-1])
         dec.up3_b = t(np.tile(np.asarray(sd[f"{m}.output_upscaling.3.bias"]), 4))
         for i in range(4):
             for j in range(3):
