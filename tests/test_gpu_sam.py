@@ -29,6 +29,16 @@ def tiny(cuda):
     return sd, hsam.Sam(sd, weights.SAM_CONFIGS["tiny"], cuda)
 
 
+@pytest.fixture(scope="module")
+def tiny_f32(cuda):
+    """the exact fp32 matrix-core path of the same model (the decoder / encoder have separate code for the two modes)"""
+    from hybridgl_amd import ops
+    sd = weights.sam_state_dict("tiny", 0)
+    m = hsam.Sam(sd, weights.SAM_CONFIGS["tiny"], cuda, precision="f32")
+    yield sd, m
+    ops.set_precision(ops.default_precision())
+
+
 def _p01(points_in, img_size):
     return ((points_in + 0.5) / float(img_size)).astype(np.float32)
 
@@ -49,6 +59,23 @@ def test_tiny_decoder_vs_reference(cuda, g, tiny):
     np.testing.assert_allclose(low.cpu().numpy(), g["low_res"], rtol=0, atol=3e-4)
     np.testing.assert_allclose(iou.cpu().numpy(), g["iou"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(m.dense_pe.cpu().numpy()[::5], g["dense_pe"], rtol=0, atol=2e-5)
+
+
+def test_tiny_decoder_and_encoder_fp32_mode(cuda, g, tiny_f32):
+    """HYBRIDGL_PRECISION=f32: same goldens, same tolerances, through the fp32 MFMA kernels"""
+    from hybridgl_amd import ops
+    c = sam_tiny_case()
+    sd, m = tiny_f32
+    ops.set_precision("f32")
+    try:
+        emb = m.encode(T(c["resized"], cuda)).cpu().numpy().reshape(16, 16, 256)
+        np.testing.assert_allclose(emb[::2, ::2], g["emb_nhwc"], rtol=0, atol=1e-4)
+        ref = S.image_encoder(sd, S.preprocess(c["resized"], 256), weights.SAM_CONFIGS["tiny"])
+        low, iou = m.decode_points(T(ref.reshape(256, 256), cuda), T(_p01(c["points_in"], 256), cuda))
+        np.testing.assert_allclose(low.cpu().numpy(), g["low_res"], rtol=0, atol=3e-4)
+        np.testing.assert_allclose(iou.cpu().numpy(), g["iou"], rtol=0, atol=1e-4)
+    finally:
+        ops.set_precision(ops.default_precision())
 
 
 def test_tiny_postprocess_vs_reference(cuda, g, tiny):
