@@ -45,6 +45,7 @@ struct Args {
   float out_scale;
   int tiles_m, tiles_n;
   int gm;      // M-tiles per tile group (L2 blocking of the resident tile set)
+  const int *amap, *cmap;   // optional row maps: A row m is read from row amap[m]; output / residual row m lives at cmap[m]
   int rmod;    // residual row = row % rmod when > 0 (a residual shared by every batch of rows), else row
   int ablate;  // timing experiments only (HGL_X3_ABLATE): 1 = no global loads in the loop, 2 = no LDS stores in the loop
 };
@@ -64,12 +65,13 @@ int pick_x3_kernel(int M, int N, int K) {
   static const Cfg cfgs[3] = {
       {HGL_X3_L, 256, 256, 256, 18.0, 2.30, 0.10},
       {HGL_X3_V1, 128, 128, 512, 13.8, 1.37, 0.25},
-      {HGL_X3_N, 128, 160, 512, 17.2, 1.93, 0.25},   // 128x160 LDS-DMA: N = 1280 / 3840 / 5120 divide evenly
+      {HGL_X3_N, 128, 160, 512, 10.4, 2.10, 0.25},   // 128x160 LDS-DMA: only where 160 divides N (1280 / 3840 / 5120)
   };
   const double nk = K / 32.0;
   int best = HGL_X3_V1;
   double best_t = 1e30;
   for (const Cfg& c : cfgs) {
+    if (c.kind == HGL_X3_N && (N % 160) != 0) continue;
     const double tiles = (double)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
     const double x = tiles / c.slots, up = ceil(x);
     // two-workgroup-per-CU tilings: a CU that holds a single workgroup finishes it in ~0.62 (register-staged) /
@@ -126,7 +128,9 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
   const _Float16 *pa_h[NLD], *pa_l[NLD], *pw_h[NLD], *pw_l[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    const long long oa = (long long)min(row0 + ld_row + RSTEP * i, mclamp) * g.lda + ld_c * 8;
+    int arow = min(row0 + ld_row + RSTEP * i, mclamp);
+    if (g.amap) arow = g.amap[arow];
+    const long long oa = (long long)arow * g.lda + ld_c * 8;
     const long long ow = (long long)min(col0 + ld_row + RSTEP * i, nclamp) * g.ldw + ld_c * 8;
     pa_h[i] = g.Ah + oa; pa_l[i] = g.Al + oa; pw_h[i] = g.Wh + ow; pw_l[i] = g.Wl + ow;
   }
@@ -191,6 +195,15 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
 
   // ---- epilogue (same element map as gemm.hip) ----
   const bool full_tile = (row0 + BM <= g.M) && (col0 + BN <= g.N);
+  // output rows of this lane (through the optional row map), fetched in one batch ahead of the dependent loads
+  int crow[2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rr = min(row0 + wm * 64 + i * 32 + 4 * h + (e & 3) + 8 * (e >> 2), mclamp);
+      crow[i][e] = g.cmap ? g.cmap[rr] : rr;
+    }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = col0 + wn * 64 + j * 32 + r;
@@ -203,10 +216,8 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
       float rv[16];
       if (g.R) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int rr = min(rbase + (e & 3) + 8 * (e >> 2), mclamp);
-          rv[e] = g.R[(long long)(g.rmod > 0 ? rr % g.rmod : rr) * g.ldr + colc];
-        }
+        for (int e = 0; e < 16; ++e)
+          rv[e] = g.R[(long long)(g.rmod > 0 ? crow[i][e] % g.rmod : crow[i][e]) * g.ldr + colc];
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) rv[e] = 0.f;
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
         const int row = rbase + (e & 3) + 8 * (e >> 2);
         const float v = act_apply<ACT>(acc[i][j][e] * g.out_scale + bv) + rv[e];
         if (full_tile || (cok && row < g.M)) {
-          const long long o = (long long)row * g.ldc + col;
+          const long long o = (long long)crow[i][e] * g.ldc + col;
           if (g.C) {
             g.C[o] = v;
           } else {
@@ -229,7 +240,6 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
     }
   }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Direct-to-LDS variant (global_load_lds_dwordx4): no VGPR staging and no ds_write pass -- on the
@@ -305,7 +315,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
   if constexpr (!FLAT) {
 #pragma unroll
     for (int j = 0; j < PA; ++j)
-      oa[j] = (unsigned)(min(row0 + (wave * PA + j) * 16 + prow, mclamp) * g.lda + pchunk * 8) * 2u;
+    {
+      int arow = min(row0 + (wave * PA + j) * 16 + prow, mclamp);
+      if (g.amap) arow = g.amap[arow];
+      oa[j] = (unsigned)(arow * g.lda + pchunk * 8) * 2u;
+    }
 #pragma unroll
     for (int j = 0; j < PW; ++j)
       ow[j] = (unsigned)(min(col0 + (wave * PW + j) * 16 + prow, nclamp) * g.ldw + pchunk * 8) * 2u;
@@ -318,7 +332,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
         const int lo = gidx >= PAh, rp = gidx - lo * PAh;
         pbase[i] = lo ? bAl : bAh;
         plds[i] = lo * A_BYTES + rp * 1024;
-        pvoff[i] = (unsigned)(min(row0 + rp * 16 + prow, mclamp) * g.lda + pchunk * 8) * 2u;
+        int arow = min(row0 + rp * 16 + prow, mclamp);
+        if (g.amap) arow = g.amap[arow];
+        pvoff[i] = (unsigned)(arow * g.lda + pchunk * 8) * 2u;
       } else {
         const int g2 = gidx - 2 * PAh;
         const int lo = g2 >= PWh, rp = g2 - lo * PWh;
@@ -445,21 +461,25 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
   // ---- epilogue ----
   const bool full_tile = (row0 + TBM <= g.M) && (col0 + TBN <= g.N);
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int col = col0 + wn * WTN + j * 32 + r;
-    const bool cok = col < g.N;
-    const int colc = cok ? col : nclamp;
-    const float bv = g.bias ? g.bias[colc] : 0.0f;
+  for (int i = 0; i < MI; ++i) {
+    const int rbase = row0 + wm * WTM + i * 32 + 4 * h;
+    int crow[16];   // output rows of this lane (through the optional row map), fetched in one batch
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int rbase = row0 + wm * WTM + i * 32 + 4 * h;
+    for (int e = 0; e < 16; ++e) {
+      const int rr = min(rbase + (e & 3) + 8 * (e >> 2), mclamp);
+      crow[e] = g.cmap ? g.cmap[rr] : rr;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = col0 + wn * WTN + j * 32 + r;
+      const bool cok = col < g.N;
+      const int colc = cok ? col : nclamp;
+      const float bv = g.bias ? g.bias[colc] : 0.0f;
       float rv[16];
       if (g.R) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int rr = min(rbase + (e & 3) + 8 * (e >> 2), mclamp);
-          rv[e] = g.R[(long long)(g.rmod > 0 ? rr % g.rmod : rr) * g.ldr + colc];
-        }
+        for (int e = 0; e < 16; ++e)
+          rv[e] = g.R[(long long)(g.rmod > 0 ? crow[e] % g.rmod : crow[e]) * g.ldr + colc];
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) rv[e] = 0.f;
@@ -469,7 +489,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
         const int row = rbase + (e & 3) + 8 * (e >> 2);
         const float v = act_apply<ACT>(acc[i][j][e] * g.out_scale + bv) + rv[e];
         if (full_tile || (cok && row < g.M)) {
-          const long long o = (long long)row * g.ldc + col;
+          const long long o = (long long)crow[e] * g.ldc + col;
           if (g.C) {
             g.C[o] = v;
           } else {
@@ -700,6 +720,12 @@ int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* 
 int hgl_launch_gemm_f16x3_rmod(const void* Ah, const void* Al, int lda, const float* W32, const float* bias, const float* R,
                                int ldr, int rmod, float* C, void* Ch, void* Cl, int ldc, int M, int N, int K, int act,
                                hipStream_t st) {
+  return hgl_launch_gemm_f16x3_maps(Ah, Al, lda, nullptr, W32, bias, R, ldr, rmod, nullptr, C, Ch, Cl, ldc, M, N, K, act, st);
+}
+
+int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const int* amap, const float* W32, const float* bias,
+                               const float* R, int ldr, int rmod, const int* cmap, float* C, void* Ch, void* Cl, int ldc,
+                               int M, int N, int K, int act, hipStream_t st) {
   auto it = g_split.find((const void*)W32);
   HGL_REQUIRE(it != g_split.end(), "gemm_f16x3: weight %p has no registered fp16 split", (const void*)W32);
   const SplitW& sw = it->second;
@@ -710,7 +736,7 @@ int hgl_launch_gemm_f16x3_rmod(const void* Ah, const void* Al, int lda, const fl
   g.Ah = (const _Float16*)Ah; g.Al = (const _Float16*)Al; g.Wh = sw.hi; g.Wl = sw.lo;
   g.bias = bias; g.R = R; g.C = C; g.Ch = (_Float16*)Ch; g.Cl = (_Float16*)Cl;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldr = ldr; g.ldc = ldc;
-  g.rmod = rmod;
+  g.rmod = rmod; g.amap = amap; g.cmap = cmap;
   g.out_scale = ldexpf(1.0f, -sw.scale_log2);
   {
     static int abl = -1;
@@ -735,7 +761,7 @@ int hgl_launch_gemm_f16x3_rmod(const void* Ah, const void* Al, int lda, const fl
     }
   }
   // the LDS-DMA kernels address the operands with 32-bit byte offsets from the plane bases
-  const bool small_offsets = (double)M * lda * 2.0 < 4.0e9 && (double)N * K * 2.0 < 4.0e9;
+  const bool small_offsets = (double)M * lda * (amap ? 4.0 : 2.0) < 4.0e9 && (double)N * K * 2.0 < 4.0e9;   // gathered rows: <= 2M
   int kind = g_x3_kernel >= 0 ? g_x3_kernel : pick_x3_kernel(M, N, K);
   if (!small_offsets) kind = HGL_X3_V1;
   HglProfScope prof(kind == HGL_X3_V1 ? HGL_PROF_GEMM_X3 : HGL_PROF_GEMM_X3G, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);

@@ -103,6 +103,9 @@ int hgl_launch_pe(const float* coords01, const float* G, int n, int F, int mode,
                   const float* not_a_point, float* out, hipStream_t st);
 int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const float* sparse, int P, int C,
                             float* tokens, hipStream_t st);
+int hgl_launch_win_maps(int g, int ws, int nw, int* pad_of, int* tok_of, int* pad_list, int* pad_count, hipStream_t st);
+int hgl_launch_fill_rows(float* dst, int ld, const int* rows, const int* nrows, int max_rows, const float* v, int N,
+                         hipStream_t st);
 int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long rows, float eps, void* hi, void* lo,
                          hipStream_t st);
 int hgl_launch_ln256_pe_split(float* x, const float* w, const float* b, const float* pe, int pe_rows, long long rows,
@@ -119,6 +122,9 @@ int hgl_launch_layernorm_split(const float* x, const float* w, const float* b, v
 bool hgl_gemm_skinny_applicable(const float* W32, int M, int N, int K, int lda, int ldw, int batch);
 int hgl_launch_gemm_x3_skinny(const float* A, int lda, const float* W32, const float* bias, const float* R, int ldr,
                               float* C, int ldc, int M, int N, int K, int act, hipStream_t st);
+int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const int* amap, const float* W32, const float* bias,
+                               const float* R, int ldr, int rmod, const int* cmap, float* C, void* Ch, void* Cl, int ldc,
+                               int M, int N, int K, int act, hipStream_t st);
 int hgl_launch_gemm_f16x3_rmod(const void* Ah, const void* Al, int lda, const float* W32, const float* bias, const float* R,
                                int ldr, int rmod, float* C, void* Ch, void* Cl, int ldc, int M, int N, int K, int act, hipStream_t st);
 int hgl_launch_gemm_f16x3(const void* Ah, const void* Al, int lda, const float* W32, const float* bias, const float* R,

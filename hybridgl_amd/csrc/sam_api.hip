@@ -6,12 +6,15 @@
 // Every contraction is the fp32 MFMA GEMM / fused attention of gemm.hip / attention.hip.
 // Tokens stay NHWC ([g*g, C] rows) end to end; the reference's NCHW permutes disappear.
 #include "hgl_common.h"
+#include <stdlib.h>
 #include <math.h>
 
 namespace {
 
 struct EncPlan {
   float *img, *cols, *X, *H, *Hw, *QKV, *O, *P, *F, *Th, *Tw, *relh, *relw, *neckA, *neckB, *cols3;
+  int *pad_of, *tok_of, *pad_list, *pad_count;   // row maps of the padded window partition (win_maps_kernel)
+  int n_pad_max;
 };
 
 bool carve_enc(HglArena& ar, const HglSamEncoderW* w, EncPlan& p) {
@@ -44,6 +47,11 @@ bool carve_enc(HglArena& ar, const HglSamEncoderW* w, EncPlan& p) {
   p.neckA = ar.take<float>(T * C);
   p.neckB = ar.take<float>(T * C);
   p.cols3 = ar.take<float>(T * C * 9);
+  p.pad_of = ar.take<int>(T);
+  p.tok_of = ar.take<int>(T);
+  p.n_pad_max = (int)(Tw_max - T);
+  p.pad_list = ar.take<int>(Tw_max - T + 1);
+  p.pad_count = ar.take<int>(1);
   return ar.ok();
 }
 
@@ -69,6 +77,8 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
 
   const bool x3 = hgl_use_x3(b.qkv_w, D) && hgl_use_x3(b.proj_w, D) && hgl_use_x3(b.lin1_w, D) &&
                   hgl_use_x3(b.lin2_w, 4 * D) && (D % 256) == 0;
+  static int padskip = -1;   // HGL_SAM_PADSKIP=0: run the windowed GEMMs over the padded rows as well (A/B timing)
+  if (padskip < 0) { const char* v = getenv("HGL_SAM_PADSKIP"); padskip = (v && v[0] == '0') ? 0 : 1; }
   uint16_t* Ah = (uint16_t*)p.Hw;                   // split GEMM input (aliases the window buffer)
   uint16_t* Al = Ah + (size_t)M * D;
   uint16_t* Hh = (uint16_t*)p.H;
@@ -82,8 +92,15 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
     } else {
       HGL_TRY(hgl_launch_layernorm_split(p.X, b.norm1_w, b.norm1_b, Ah, Al, T, D, 1e-6f, st));
     }
-    HGL_TRY(hgl_launch_gemm_f16x3(Ah, Al, D, b.qkv_w, b.qkv_b, nullptr, 0, p.QKV, nullptr, nullptr, 3 * D, M, 3 * D, D,
-                                  HGL_ACT_NONE, st));
+    if (ws > 0 && M > T && padskip) {
+      // only the real tokens go through the GEMM (16 % fewer rows at 64x64 / 14x14); a padded row of qkv is the bias
+      HGL_TRY(hgl_launch_fill_rows(p.QKV, 3 * D, p.pad_list, p.pad_count, p.n_pad_max, b.qkv_b, 3 * D, st));
+      HGL_TRY(hgl_launch_gemm_f16x3_maps(Ah, Al, D, p.pad_of, b.qkv_w, b.qkv_b, nullptr, 0, 0, p.pad_of, p.QKV, nullptr,
+                                         nullptr, 3 * D, T, 3 * D, D, HGL_ACT_NONE, st));
+    } else {
+      HGL_TRY(hgl_launch_gemm_f16x3(Ah, Al, D, b.qkv_w, b.qkv_b, nullptr, 0, p.QKV, nullptr, nullptr, 3 * D, M, 3 * D, D,
+                                    HGL_ACT_NONE, st));
+    }
   } else {
     HGL_TRY(hgl_launch_layernorm(p.X, b.norm1_w, b.norm1_b, p.H, T, D, 1e-6f, st));
     const float* A = p.H;
@@ -111,7 +128,12 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
                                p.relw, size, size, st));
   if (x3) {
     HGL_TRY(hgl_launch_split_f16(p.O, 1.0f, Ah, Al, (long long)M * D, st));
-    if (ws > 0) {
+    if (ws > 0 && M > T && padskip) {
+      // projection of the real tokens only, written straight back to token order with the residual added
+      // (window_unpartition + shortcut, image_encoder.py:178-180)
+      HGL_TRY(hgl_launch_gemm_f16x3_maps(Ah, Al, D, p.pad_of, b.proj_w, b.proj_b, p.X, D, 0, p.tok_of, p.X, nullptr, nullptr,
+                                         D, T, D, D, HGL_ACT_NONE, st));
+    } else if (ws > 0) {
       HGL_TRY(hgl_launch_gemm_f16x3(Ah, Al, D, b.proj_w, b.proj_b, nullptr, 0, p.P, nullptr, nullptr, D, M, D, D,
                                     HGL_ACT_NONE, st));
       HGL_TRY(hgl_launch_win_unpartition_add(p.X, g, ws, nw, D, p.P, st));
@@ -307,6 +329,13 @@ int hgl_sam_encode(const HglSamEncoderW* w, const uint8_t* resized_img, int in_h
   // patch embedding + bias + absolute position embedding (image_encoder.py:107-109)
   HGL_TRY(hgl_launch_gemm(p.cols, w->patch_w, w->patch_b, w->pos_embed, p.X, T, D, kd, kd, kd, D, D, 1, 0, 0, 0, 0,
                           HGL_ACT_NONE, st));
+  for (int i = 0; i < w->depth; ++i) {
+    const int ws = w->blocks[i].window;
+    if (ws > 0) {   // every windowed block shares one window size (build_sam.py:55-101)
+      HGL_TRY(hgl_launch_win_maps(g, ws, (g + ws - 1) / ws, p.pad_of, p.tok_of, p.pad_list, p.pad_count, st));
+      break;
+    }
+  }
   for (int i = 0; i < w->depth; ++i) HGL_TRY(enc_block(w, w->blocks[i], p, st));
   // neck: conv1x1 -> LayerNorm2d -> conv3x3(pad 1) -> LayerNorm2d, all on NHWC rows
   HGL_TRY(hgl_launch_gemm(p.X, w->neck0_w, nullptr, nullptr, p.neckA, T, C, D, D, D, 0, C, 1, 0, 0, 0, 0,

@@ -151,6 +151,37 @@ __global__ __launch_bounds__(256) void relpos_direct_kernel(const float* __restr
   }
 }
 
+// Row maps of the zero-padded window partition (image_encoder.py:244-283): the r-th REAL token in window order lives
+// at padded row pad_of[r] = window*ws*ws + position and at token-order row tok_of[r] = y*g + x; pad_list collects
+// the padded rows that hold no token.  The f16x3 GEMMs of a windowed block run over the real tokens only: the pad
+// rows of qkv are the bias (filled by fill_rows_kernel) and the pad rows of the projection are never needed.
+__global__ __launch_bounds__(256) void win_maps_kernel(int g, int ws, int nw, int* __restrict__ pad_of,
+                                                       int* __restrict__ tok_of, int* __restrict__ pad_list,
+                                                       int* __restrict__ pad_count) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nw * nw * ws * ws) return;
+  const int w = idx / (ws * ws), p = idx - w * ws * ws;
+  const int wy = w / nw, wx = w - wy * nw, py = p / ws, px = p - py * ws;
+  const int y = wy * ws + py, x = wx * ws + px;
+  if (y < g && x < g) {
+    const int rh = min(ws, g - wy * ws), rw = min(ws, g - wx * ws);
+    const int r = wy * ws * g + rh * (wx * ws) + py * rw + px;
+    pad_of[r] = idx;
+    tok_of[r] = y * g + x;
+  } else {
+    pad_list[atomicAdd(pad_count, 1)] = idx;
+  }
+}
+
+// dst[rows[i], :] = v[:] for i < *nrows   (N % 4 == 0)
+__global__ __launch_bounds__(256) void fill_rows_kernel(float* __restrict__ dst, int ld, const int* __restrict__ rows,
+                                                        const int* __restrict__ nrows, const float* __restrict__ v, int N4) {
+  const int i = blockIdx.y;
+  if (i >= *nrows) return;
+  f32x4* d = (f32x4*)(dst + (long long)rows[i] * ld);
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < N4; c += gridDim.x * 256) d[c] = ((const f32x4*)v)[c];
+}
+
 // cols[(y*g+x), c*9 + ky*3+kx] = in[(y+ky-1), (x+kx-1), c] (zero padded), NHWC input
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ in, int g, int C,
                                                         float* __restrict__ cols, long long total) {
@@ -751,6 +782,21 @@ int hgl_launch_relpos_direct(const float* qkv, int ldq, int B, int heads, int S,
   if (hd == 80) hipLaunchKernelGGL(relpos_direct_kernel<80>, grid, dim3(256), lds, st, qkv, ldq, heads, S, size, Rh, Rw, rel_h, rel_w);
   else hipLaunchKernelGGL(relpos_direct_kernel<64>, grid, dim3(256), lds, st, qkv, ldq, heads, S, size, Rh, Rw, rel_h, rel_w);
   return hgl_check_launch("relpos_direct");
+}
+int hgl_launch_win_maps(int g, int ws, int nw, int* pad_of, int* tok_of, int* pad_list, int* pad_count, hipStream_t st) {
+  if (hipMemsetAsync(pad_count, 0, sizeof(int), st) != hipSuccess) {
+    hgl_set_error("win_maps: memset failed");
+    return HGL_ELAUNCH;
+  }
+  hipLaunchKernelGGL(win_maps_kernel, dim3(grid1((long long)nw * nw * ws * ws)), dim3(256), 0, st, g, ws, nw, pad_of, tok_of,
+                     pad_list, pad_count);
+  return hgl_check_launch("win_maps");
+}
+int hgl_launch_fill_rows(float* dst, int ld, const int* rows, const int* nrows, int max_rows, const float* v, int N,
+                         hipStream_t st) {
+  HGL_REQUIRE((N & 3) == 0 && max_rows > 0, "fill_rows: bad arguments");
+  hipLaunchKernelGGL(fill_rows_kernel, dim3(4, (unsigned)max_rows), dim3(256), 0, st, dst, ld, rows, nrows, v, N / 4);
+  return hgl_check_launch("fill_rows");
 }
 int hgl_launch_im2col3x3(const float* in, int g, int C, float* cols, hipStream_t st) {
   const long long total = (long long)g * g * C * 9;
