@@ -282,6 +282,9 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   const int q0 = (blockIdx.x * 4 + wave) * 32;
   const int qi = q0 + r;
   const bool qvalid = qi < a.Sq;
+  // a wave whose 32 queries all lie beyond the sequence (e.g. the 4th wave of the second 128-query block at S = 197)
+  // only helps staging K/V: it skips its MFMA / softmax work and leaves its SIMD to the co-resident workgroup
+  const bool wave_active = q0 < a.Sq;
   const float* qp = a.q + b * a.sqb + (long long)(qvalid ? qi : 0) * a.ldq + hh * HD;
   const float* kp = a.k + b * a.skb + hh * HD;
   const float* vp = a.v + b * a.svb + hh * HD;
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
 #pragma unroll
     for (int kt = 0; kt < KV_CHUNK / 32; ++kt) {
       const int kbase = kc + kt * 32;
-      if (kbase >= sk_eff) break;  // uniform
+      if (kbase >= sk_eff || !wave_active) break;  // uniform
       f32x16 s;
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] = 0.f;
