@@ -45,6 +45,8 @@ struct Args {
   float out_scale;
   int tiles_m, tiles_n;
   int gm;      // M-tiles per tile group (L2 blocking of the resident tile set)
+  float* part;   // split-K (LDS-DMA kernels, grid.y = ksplit): raw partial sums [ksplit][M][N]; bias / act / residual are
+  int ksplit;    // applied by splitk_reduce_kernel, which sums the parts in a fixed order
   const int *amap, *cmap;   // optional row maps: A row m is read from row amap[m]; output / residual row m lives at cmap[m]
   int rmod;    // residual row = row % rmod when > 0 (a residual shared by every batch of rows), else row
   int ablate;  // timing experiments only (HGL_X3_ABLATE): 1 = no global loads in the loop, 2 = no LDS stores in the loop
@@ -302,6 +304,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
   const int wm = wave / WGN, wn = wave % WGN;
   const int row0 = tile_m * TBM, col0 = tile_n * TBN;
   const int mclamp = g.M - 1, nclamp = g.N - 1;
+  // K range of this workgroup: everything, or the blockIdx.y-th of ksplit even-length slices (split-K)
+  int kbeg = 0, nk = g.K / 32;   // K tiles of 32; even and >= 2 (K % 64 == 0, checked by the launcher)
+  if (g.ksplit > 1) {
+    const int chunk = (nk / g.ksplit) & ~1;
+    kbeg = (int)blockIdx.y * chunk;
+    nk = (int)blockIdx.y == g.ksplit - 1 ? nk - kbeg : chunk;
+  }
 
   // staging: lane -> (row within the 16-row piece, swizzled source chunk).  Per-lane state is one 32-bit byte
   // offset per piece row; the plane bases are wave-uniform (SGPR) and advance by 64 B per K tile.
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
   // MFMAs of a k-step so that their issue cost hides under the other waves' MFMAs
   auto issue_piece = [&](int kt, int stage, int q) {
     const unsigned sb = lds0 + stage * STAGE;
-    const long long ko = (long long)kt * 64;
+    const long long ko = (long long)(kbeg + kt) * 64;
     if constexpr (FLAT) {
       glds16(pbase[q] + ko, pvoff[q], sb + plds[q]);
     } else if (q < 2 * PA) {
@@ -443,7 +452,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
     mfma_step(F0, 0, 0, no);
   };
 
-  const int nk = g.K / 32;   // even and >= 2 (K % 64 == 0, checked by the launcher)
   issue(0, 0);
   publish();
   read_frag(F0, 0, 0);
@@ -460,6 +468,21 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
 
   // ---- epilogue ----
   const bool full_tile = (row0 + TBM <= g.M) && (col0 + TBN <= g.N);
+  if (g.ksplit > 1) {   // raw partial sums; splitk_reduce_kernel finishes
+    float* pp = g.part + (long long)blockIdx.y * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int col = col0 + wn * WTN + j * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row0 + wm * WTM + i * 32 + 4 * h + (e & 3) + 8 * (e >> 2);
+          if (full_tile || (col < g.N && row < g.M)) pp[(long long)row * g.N + col] = acc[i][j][e] * g.out_scale;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int rbase = row0 + wm * WTM + i * 32 + 4 * h;
@@ -580,6 +603,32 @@ __global__ __launch_bounds__(256) void gemm_x3_skinny_kernel(SkinnyArgs g) {
       if (g.R) v += g.R[(long long)row * g.ldr + col];
       g.C[(long long)row * g.ldc + col] = v;
     }
+  }
+}
+
+// C = act(sum_s part[s] + bias) + R, parts added in index order (deterministic)
+template <int ACT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long long MN4, int N4,
+                                                            const float* __restrict__ bias, const float* __restrict__ R,
+                                                            int ldr4, float* __restrict__ C, int ldc4,
+                                                            const int* __restrict__ cmap) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < MN4; i += (long long)gridDim.x * 256) {
+    long long row = i / N4;
+    const int c = (int)(i - row * N4);
+    if (cmap) row = cmap[row];
+    f32x4 v = ((const f32x4*)part)[i];
+    for (int s2 = 1; s2 < ksplit; ++s2) {
+      const f32x4 w = ((const f32x4*)part)[(long long)s2 * MN4 + i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += w[e];
+    }
+    const f32x4 b = bias ? ((const f32x4*)bias)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 rr = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (R) rr = ((const f32x4*)R)[row * ldr4 + c];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = act_apply<ACT>(v[e] + b[e]) + rr[e];
+    ((f32x4*)C)[row * ldc4 + c] = o;
   }
 }
 
@@ -737,6 +786,7 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
   g.bias = bias; g.R = R; g.C = C; g.Ch = (_Float16*)Ch; g.Cl = (_Float16*)Cl;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldr = ldr; g.ldc = ldc;
   g.rmod = rmod; g.amap = amap; g.cmap = cmap;
+  g.part = nullptr; g.ksplit = 1;
   g.out_scale = ldexpf(1.0f, -sw.scale_log2);
   {
     static int abl = -1;
@@ -836,6 +886,62 @@ int hgl_launch_gemm_x3_skinny(const float* A, int lda, const float* W32, const f
     default: hipLaunchKernelGGL(gemm_x3_skinny_kernel<HGL_ACT_NONE>, grid, dim3(256), 0, st, g); break;
   }
   return hgl_check_launch("gemm_x3_skinny");
+}
+
+// Split-K on the 256x256 LDS-DMA tiling for GEMMs with few output tiles and a long K (SAM's mlp.lin2: 80 tiles,
+// K = 5120): ksplit slices of K run as independent workgroups (grid.y), raw partial sums go through `part`
+// (>= ksplit*M*N floats), splitk_reduce adds them in index order and applies bias / activation / residual.
+int hgl_gemm_f16x3_splitk_factor(int M, int N, int K) {
+  const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  if ((N & 3) || K < 1024 || tiles * 2 > 256) return 1;
+  int ks = (int)(256 / tiles);
+  if (ks > 4) ks = 4;
+  while (ks > 1 && ((K / 32 / ks) & ~1) < 8) --ks;   // keep every slice at least 8 K tiles long
+  return ks;
+}
+
+int hgl_launch_gemm_f16x3_splitk(const void* Ah, const void* Al, int lda, const int* amap, const float* W32, const float* bias,
+                                 const float* R, int ldr, const int* cmap, float* C, int ldc, int M, int N, int K, int act,
+                                 int ksplit, float* part, size_t part_bytes, hipStream_t st) {
+  auto it = g_split.find((const void*)W32);
+  HGL_REQUIRE(it != g_split.end(), "gemm_f16x3_splitk: weight %p has no registered fp16 split", (const void*)W32);
+  const SplitW& sw = it->second;
+  HGL_REQUIRE(sw.N == N && sw.K == K && Ah && Al && C && part, "gemm_f16x3_splitk: bad arguments");
+  HGL_REQUIRE(ksplit >= 2 && ksplit <= 8 && (K % 64) == 0 && (lda & 7) == 0 && (N & 3) == 0 && (ldc & 3) == 0 && (ldr & 3) == 0,
+              "gemm_f16x3_splitk: unsupported shape (K %d, N %d, ksplit %d)", K, N, ksplit);
+  HGL_REQUIRE(((K / 32 / ksplit) & ~1) >= 2, "gemm_f16x3_splitk: K too short for %d slices", ksplit);
+  HGL_REQUIRE(part_bytes >= (size_t)ksplit * M * N * sizeof(float), "gemm_f16x3_splitk: partial-sum workspace too small");
+  HGL_REQUIRE((double)M * lda * (amap ? 4.0 : 2.0) < 4.0e9 && (double)N * K * 2.0 < 4.0e9, "gemm_f16x3_splitk: operand too large");
+  Args g;
+  g.Ah = (const _Float16*)Ah; g.Al = (const _Float16*)Al; g.Wh = sw.hi; g.Wl = sw.lo;
+  g.bias = nullptr; g.R = nullptr; g.C = nullptr; g.Ch = nullptr; g.Cl = nullptr;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldr = 0; g.ldc = N;
+  g.rmod = 0; g.amap = amap; g.cmap = nullptr; g.part = part; g.ksplit = ksplit;
+  g.out_scale = ldexpf(1.0f, -sw.scale_log2);
+  g.ablate = 0; g.gm = 8;
+  g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
+  {
+    HglProfScope prof(HGL_PROF_GEMM_X3G, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
+    const size_t lds = (size_t)4 * (256 + 256) * 64;
+    static bool set = false;
+    if (!set) {
+      (void)hipFuncSetAttribute((const void*)gemm_x3g_kernel<HGL_ACT_NONE, 256, 256, 2, 4, 1, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      set = true;
+    }
+    hipLaunchKernelGGL((gemm_x3g_kernel<HGL_ACT_NONE, 256, 256, 2, 4, 1, true>), dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)ksplit),
+                       dim3(512), lds, st, g);
+    const long long MN4 = (long long)M * N / 4;
+    const unsigned blocks = (unsigned)((MN4 + 255) / 256 > 4096 ? 4096 : (MN4 + 255) / 256);
+#define HGL_SPLITK_REDUCE(ACT_) hipLaunchKernelGGL(splitk_reduce_kernel<ACT_>, dim3(blocks), dim3(256), 0, st, part, ksplit, MN4, N / 4, bias, R, ldr / 4, C, ldc / 4, cmap)
+    switch (act) {
+      case HGL_ACT_QUICKGELU: HGL_SPLITK_REDUCE(HGL_ACT_QUICKGELU); break;
+      case HGL_ACT_GELU: HGL_SPLITK_REDUCE(HGL_ACT_GELU); break;
+      case HGL_ACT_RELU: HGL_SPLITK_REDUCE(HGL_ACT_RELU); break;
+      default: HGL_SPLITK_REDUCE(HGL_ACT_NONE); break;
+    }
+  }
+  return hgl_check_launch("gemm_f16x3_splitk");
 }
 
 extern "C" {

@@ -122,6 +122,10 @@ int hgl_launch_layernorm_split(const float* x, const float* w, const float* b, v
 bool hgl_gemm_skinny_applicable(const float* W32, int M, int N, int K, int lda, int ldw, int batch);
 int hgl_launch_gemm_x3_skinny(const float* A, int lda, const float* W32, const float* bias, const float* R, int ldr,
                               float* C, int ldc, int M, int N, int K, int act, hipStream_t st);
+int hgl_gemm_f16x3_splitk_factor(int M, int N, int K);
+int hgl_launch_gemm_f16x3_splitk(const void* Ah, const void* Al, int lda, const int* amap, const float* W32, const float* bias,
+                                 const float* R, int ldr, const int* cmap, float* C, int ldc, int M, int N, int K, int act,
+                                 int ksplit, float* part, size_t part_bytes, hipStream_t st);
 int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const int* amap, const float* W32, const float* bias,
                                const float* R, int ldr, int rmod, const int* cmap, float* C, void* Ch, void* Cl, int ldc,
                                int M, int N, int K, int act, hipStream_t st);

@@ -128,7 +128,16 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
                                p.relw, size, size, st));
   if (x3) {
     HGL_TRY(hgl_launch_split_f16(p.O, 1.0f, Ah, Al, (long long)M * D, st));
-    if (ws > 0 && M > T && padskip) {
+    static int splitk_proj = -1;   // HGL_SAM_SPLITK_PROJ=1 enables split-K for the projection too (measured neutral: K is short)
+    if (splitk_proj < 0) { const char* v = getenv("HGL_SAM_SPLITK_PROJ"); splitk_proj = (v && v[0] == '1') ? 1 : 0; }
+    const int ksp = splitk_proj ? hgl_gemm_f16x3_splitk_factor(T, D, D) : 1;
+    const size_t qkv_cap = (size_t)M * 3 * D * sizeof(float);     // q, k, v are dead after the attention
+    const bool proj_splitk = ksp > 1 && (size_t)ksp * T * D * sizeof(float) <= qkv_cap && (ws == 0 || (M > T && padskip));
+    if (proj_splitk) {
+      // few 256x256 tiles: split-K over the idle CUs; real tokens only, written to token order with the residual
+      HGL_TRY(hgl_launch_gemm_f16x3_splitk(Ah, Al, D, ws > 0 ? p.pad_of : nullptr, b.proj_w, b.proj_b, p.X, D,
+                                           ws > 0 ? p.tok_of : nullptr, p.X, D, T, D, D, HGL_ACT_NONE, ksp, p.QKV, qkv_cap, st));
+    } else if (ws > 0 && M > T && padskip) {
       // projection of the real tokens only, written straight back to token order with the residual added
       // (window_unpartition + shortcut, image_encoder.py:178-180)
       HGL_TRY(hgl_launch_gemm_f16x3_maps(Ah, Al, D, p.pad_of, b.proj_w, b.proj_b, p.X, D, 0, p.tok_of, p.X, nullptr, nullptr,
@@ -144,8 +153,18 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
     HGL_TRY(hgl_launch_layernorm_split(p.X, b.norm2_w, b.norm2_b, Hh, Hl, T, D, 1e-6f, st));
     HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, b.lin1_w, b.lin1_b, nullptr, 0, nullptr, Fh, Fl, 4 * D, T, 4 * D, D,
                                   HGL_ACT_GELU, st));
-    HGL_TRY(hgl_launch_gemm_f16x3(Fh, Fl, 4 * D, b.lin2_w, b.lin2_b, p.X, D, p.X, nullptr, nullptr, D, T, D, 4 * D,
-                                  HGL_ACT_NONE, st));
+    // mlp.lin2: few output tiles, K = 4D -> split-K over the idle CUs; the partial sums borrow the qkv buffer
+    static int splitk_on = -1;   // HGL_SAM_SPLITK=0 disables (A/B timing)
+    if (splitk_on < 0) { const char* v = getenv("HGL_SAM_SPLITK"); splitk_on = (v && v[0] == '0') ? 0 : 1; }
+    const int ks = splitk_on ? hgl_gemm_f16x3_splitk_factor(T, D, 4 * D) : 1;
+    const size_t qkv_bytes = (size_t)M * 3 * D * sizeof(float);
+    if (ks > 1 && (size_t)ks * T * D * sizeof(float) <= qkv_bytes) {
+      HGL_TRY(hgl_launch_gemm_f16x3_splitk(Fh, Fl, 4 * D, nullptr, b.lin2_w, b.lin2_b, p.X, D, nullptr, p.X, D, T, D, 4 * D,
+                                           HGL_ACT_NONE, ks, p.QKV, qkv_bytes, st));
+    } else {
+      HGL_TRY(hgl_launch_gemm_f16x3(Fh, Fl, 4 * D, b.lin2_w, b.lin2_b, p.X, D, p.X, nullptr, nullptr, D, T, D, 4 * D,
+                                    HGL_ACT_NONE, st));
+    }
     return HGL_OK;
   }
   if (ws > 0) {
