@@ -37,6 +37,7 @@ struct AttnArgs {
   int keep_b0, keep_n;
   const float *rel_h, *rel_w;
   int kh, kw;
+  _Float16 *out_hi, *out_lo;   // f16x3 kernels: when out == nullptr the result is written as the fp16 hi+lo pair
 };
 
 template <int HD>
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   if (qvalid) {
-    float* op = a.out + b * a.sob + (long long)qi * a.ldo + hh * HD;
+    const long long oo = b * a.sob + (long long)qi * a.ldo + hh * HD;
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
 #pragma unroll
@@ -518,7 +519,18 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
           f32x4 w;
 #pragma unroll
           for (int e = 0; e < 4; ++e) w[e] = o[d][4 * g + e] * inv;
-          *(f32x4*)(op + dd) = w;
+          if (a.out) {
+            *(f32x4*)(a.out + oo + dd) = w;
+          } else {   // the operand form of the following f16x3 projection
+            h16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              hi[e] = (_Float16)w[e];
+              lo[e] = (_Float16)(w[e] - (float)hi[e]);
+            }
+            *(h16x4*)(a.out_hi + oo + dd) = hi;
+            *(h16x4*)(a.out_lo + oo + dd) = lo;
+          }
         }
       }
     }
@@ -797,20 +809,32 @@ int hgl_launch_attention(const float* q, const float* k, const float* v, float* 
                          long long skb, long long svb, long long sob, float scale, int mask_kind,
                          const uint8_t* keep, int keep_b0, int keep_n, const float* rel_h,
                          const float* rel_w, int kh, int kw, hipStream_t st) {
-  HGL_REQUIRE(q && k && v && out, "attention: null operand");
+  return hgl_launch_attention_split(q, k, v, out, nullptr, nullptr, B, H, Sq, Sk, hd, ldq, ldk, ldv, ldo, sqb, skb, svb, sob,
+                                    scale, mask_kind, keep, keep_b0, keep_n, rel_h, rel_w, kh, kw, st);
+}
+
+// out != nullptr: fp32 output; out == nullptr (f16x3 mode only): the fp16 hi+lo pair (out_hi, out_lo), same strides
+int hgl_launch_attention_split(const float* q, const float* k, const float* v, float* out, void* out_hi, void* out_lo, int B,
+                               int H, int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
+                               long long skb, long long svb, long long sob, float scale, int mask_kind,
+                               const uint8_t* keep, int keep_b0, int keep_n, const float* rel_h,
+                               const float* rel_w, int kh, int kw, hipStream_t st) {
+  HGL_REQUIRE(q && k && v && (out || (out_hi && out_lo)), "attention: null operand");
+  HGL_REQUIRE(out || hgl_precision() == HGL_PREC_F16X3, "attention: split output exists in f16x3 mode only");
   HGL_REQUIRE(B > 0 && H > 0 && Sq > 0 && Sk > 0, "attention: bad shape");
   HGL_REQUIRE((ldq & 3) == 0 && (ldk & 3) == 0 && (ldv & 3) == 0 && (ldo & 3) == 0, "attention: leading dims must be multiples of 4");
-  HGL_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "attention: operands must be 16-byte aligned");
+  HGL_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)out_hi | (uintptr_t)out_lo) & 15) == 0,
+              "attention: operands must be 16-byte aligned");
   HGL_REQUIRE(((sqb | skb | svb | sob) & 3) == 0, "attention: batch strides must be multiples of 4");
   HGL_REQUIRE(mask_kind >= 0 && mask_kind <= 2, "attention: bad mask kind %d", mask_kind);
   HGL_REQUIRE(mask_kind != HGL_MASK_CLS_KEEP || keep, "attention: HGL_MASK_CLS_KEEP needs keep bytes");
   HGL_REQUIRE((rel_h == nullptr) == (rel_w == nullptr), "attention: rel_h and rel_w go together");
   HGL_REQUIRE(!rel_h || (kh > 0 && kw > 0 && kh * kw == Sk), "attention: kh*kw must equal Sk");
   HGL_REQUIRE((long long)B * H <= 65535, "attention: B*H too large for grid.y");
-  if (hd == 16 && Sq <= FEWQ_MAX && Sk >= 1024 && mask_kind == HGL_MASK_NONE && !rel_h)
+  if (out && hd == 16 && Sq <= FEWQ_MAX && Sk >= 1024 && mask_kind == HGL_MASK_NONE && !rel_h)
     return hgl_launch_attention_fewq(q, k, v, out, B, H, Sq, Sk, hd, ldq, ldk, ldv, ldo, sqb, skb, svb, sob, scale, st);
   if (hd == 16 && Sk <= SMALLK_MAX && Sq >= 256 && mask_kind == HGL_MASK_NONE && !rel_h && 256 % H == 0)
-    return hgl_launch_attention_smallk(q, k, v, out, nullptr, nullptr, B, H, Sq, Sk, hd, ldq, ldk, ldv, ldo, sqb, skb, svb,
+    return hgl_launch_attention_smallk(q, k, v, out, out_hi, out_lo, B, H, Sq, Sk, hd, ldq, ldk, ldv, ldo, sqb, skb, svb,
                                        sob, scale, st);
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.out = out;
@@ -819,6 +843,7 @@ int hgl_launch_attention(const float* q, const float* k, const float* v, float* 
   a.sqb = sqb; a.skb = skb; a.svb = svb; a.sob = sob;
   a.scale = scale; a.mask_kind = mask_kind; a.keep = keep; a.keep_b0 = keep_b0; a.keep_n = keep_n > 0 ? keep_n : B;
   a.rel_h = rel_h; a.rel_w = rel_w; a.kh = kh; a.kw = kw;
+  a.out_hi = (_Float16*)out_hi; a.out_lo = (_Float16*)out_lo;
   switch (hd) {
     case 16: return launch_hd<16>(a, st);
     case 32: return launch_hd<32>(a, st);

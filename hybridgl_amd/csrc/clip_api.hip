@@ -34,14 +34,13 @@ int run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, c
     uint16_t* Hl = Hh + (size_t)M * D;
     uint16_t* Fh = (uint16_t*)bf.F;
     uint16_t* Fl = Fh + (size_t)M * 4 * D;
-    float* O = bf.F;  // attention output (fp32) borrows the MLP buffer until it is split
     HGL_TRY(hgl_launch_layernorm_split(X, w.ln1_w, w.ln1_b, Hh, Hl, M, D, 1e-5f, st));
     HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, w.in_proj_w, w.in_proj_b, nullptr, 0, bf.QKV, nullptr, nullptr, 3 * D, M,
                                   3 * D, D, HGL_ACT_NONE, st));
-    HGL_TRY(hgl_launch_attention(bf.QKV, bf.QKV + D, bf.QKV + 2 * D, O, B, heads, S, S, hd, 3 * D, 3 * D, 3 * D, D, sQKV,
-                                 sQKV, sQKV, (long long)S * D, 1.0f / sqrtf((float)hd), mask_kind, keep, keep_b0,
-                                 keep_n, nullptr, nullptr, 0, 0, st));
-    HGL_TRY(hgl_launch_split_f16(O, 1.0f, Hh, Hl, (long long)M * D, st));
+    // the attention writes its output as the fp16 hi+lo pair the out-projection reads
+    HGL_TRY(hgl_launch_attention_split(bf.QKV, bf.QKV + D, bf.QKV + 2 * D, nullptr, Hh, Hl, B, heads, S, S, hd, 3 * D, 3 * D,
+                                       3 * D, D, sQKV, sQKV, sQKV, (long long)S * D, 1.0f / sqrtf((float)hd), mask_kind, keep,
+                                       keep_b0, keep_n, nullptr, nullptr, 0, 0, st));
     HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, w.out_proj_w, w.out_proj_b, X, D, X, nullptr, nullptr, D, M, D, D,
                                   HGL_ACT_NONE, st));
     HGL_TRY(hgl_launch_layernorm_split(X, w.ln2_w, w.ln2_b, Hh, Hl, M, D, 1e-5f, st));

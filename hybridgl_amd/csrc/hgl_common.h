@@ -53,6 +53,11 @@ int hgl_launch_gemm(const float* A, const float* W, const float* bias, const flo
                     hipStream_t st);
 int hgl_launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D,
                          float eps, hipStream_t st);
+int hgl_launch_attention_split(const float* q, const float* k, const float* v, float* out, void* out_hi, void* out_lo, int B,
+                               int H, int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
+                               long long skb, long long svb, long long sob, float scale, int mask_kind,
+                               const uint8_t* keep, int keep_b0, int keep_n, const float* rel_h,
+                               const float* rel_w, int kh, int kw, hipStream_t st);
 int hgl_launch_attention_smallk(const float* q, const float* k, const float* v, float* out, void* out_hi, void* out_lo,
                                 int B, int H, int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
                                 long long skb, long long svb, long long sob, float scale, hipStream_t st);

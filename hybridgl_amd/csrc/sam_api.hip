@@ -122,12 +122,12 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
     HGL_TRY(hgl_launch_relpos_gather(p.Th, B, heads, S, size, L, 0, p.relh, st));
     HGL_TRY(hgl_launch_relpos_gather(p.Tw, B, heads, S, size, L, 1, p.relw, st));
   }
-  HGL_TRY(hgl_launch_attention(p.QKV, p.QKV + D, p.QKV + 2 * D, p.O, B, heads, S, S, hd, 3 * D, 3 * D, 3 * D, D,
-                               (long long)S * 3 * D, (long long)S * 3 * D, (long long)S * 3 * D,
-                               (long long)S * D, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, p.relh,
-                               p.relw, size, size, st));
+  // f16x3: the attention writes its output as the fp16 hi+lo pair the projection reads
+  HGL_TRY(hgl_launch_attention_split(p.QKV, p.QKV + D, p.QKV + 2 * D, x3 ? nullptr : p.O, Ah, Al, B, heads, S, S, hd, 3 * D,
+                                     3 * D, 3 * D, D, (long long)S * 3 * D, (long long)S * 3 * D, (long long)S * 3 * D,
+                                     (long long)S * D, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, p.relh,
+                                     p.relw, size, size, st));
   if (x3) {
-    HGL_TRY(hgl_launch_split_f16(p.O, 1.0f, Ah, Al, (long long)M * D, st));
     static int splitk_proj = -1;   // HGL_SAM_SPLITK_PROJ=1 enables split-K for the projection too (measured neutral: K is short)
     if (splitk_proj < 0) { const char* v = getenv("HGL_SAM_SPLITK_PROJ"); splitk_proj = (v && v[0] == '1') ? 1 : 0; }
     const int ksp = splitk_proj ? hgl_gemm_f16x3_splitk_factor(T, D, D) : 1;
