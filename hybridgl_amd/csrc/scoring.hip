@@ -500,6 +500,57 @@ __global__ __launch_bounds__(256) void synth_views_kernel(
   }
 }
 
+// ---- blurred background of the global views (Hybridgl_main.py:99 cv2.GaussianBlur(img, (15,15), 0)) ----------
+// OpenCV is a third-party package that is absent offline and its 8-bit fixed-point kernel is unpinned
+// (SURVEY.md 8f-2); this is the package's own definition (hybridgl_amd/synth.py box_blur_u8: separable Gaussian with
+// OpenCV's sigma rule, reflect-101 borders, double accumulation in tap order, round half up), evaluated with the same
+// double operations in the same order so that device and host agree bit for bit.
+struct BlurTaps { double w[31]; int k; };
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void blur_v_kernel(const uint8_t* __restrict__ img, int H, int W, int C, BlurTaps t,
+                                                     double* __restrict__ tmp) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  const long long total = (long long)H * W * C;
+  if (i >= total) return;
+  const long long wc = (long long)W * C;
+  const int y = (int)(i / wc);
+  const long long rest = i - (long long)y * wc;
+  const int r = t.k / 2;
+  double a = 0.0;
+  for (int j = 0; j < t.k; ++j) {
+    const int yy = reflect101(y + j - r, H);
+    const double p = (double)img[(long long)yy * wc + rest];
+    a = j == 0 ? __dmul_rn(t.w[0], p) : __dadd_rn(a, __dmul_rn(t.w[j], p));
+  }
+  tmp[i] = a;
+}
+
+__global__ __launch_bounds__(256) void blur_h_kernel(const double* __restrict__ tmp, int H, int W, int C, BlurTaps t,
+                                                     uint8_t* __restrict__ out) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  const long long total = (long long)H * W * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int x = (int)((i / C) % W);
+  const long long y = i / ((long long)W * C);
+  const int r = t.k / 2;
+  double a = 0.0;
+  for (int j = 0; j < t.k; ++j) {
+    const int xx = reflect101(x + j - r, W);
+    const double p = tmp[(y * W + xx) * C + c];
+    a = j == 0 ? __dmul_rn(t.w[0], p) : __dadd_rn(a, __dmul_rn(t.w[j], p));
+  }
+  double v = floor(__dadd_rn(a, 0.5));
+  v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+  out[i] = (uint8_t)v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -606,6 +657,28 @@ int hgl_score_sentence(const float* hybrid, const float* sentence_feat, const fl
   float* pool = (float*)workspace;
   hipLaunchKernelGGL(score_sentence_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, hybrid, sentence_feat, noun_phrase_feat, other_noun_feats, n_other, r, (const long long*)boxes, gem_score, N, E, logit_scale, k1, k2, alpha, relaword, has_other_nouns, (int*)idx, score_clip, score_neg, pool);
   return hgl_check_launch("score_sentence");
+}
+
+size_t hgl_gaussian_blur_u8_workspace_bytes(int H, int W, int C) { return hgl_align_up((size_t)H * W * C * sizeof(double), 256); }
+
+int hgl_gaussian_blur_u8(const uint8_t* img, int H, int W, int C, const double* taps, int k, uint8_t* out, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(img && out && taps && H > 0 && W > 0 && C > 0, "gaussian_blur_u8: bad arguments");
+  HGL_REQUIRE(k >= 1 && k <= 31 && (k & 1) && k / 2 < H && k / 2 < W, "gaussian_blur_u8: kernel size %d unsupported for %dx%d", k, H, W);
+  if (!workspace || workspace_bytes < hgl_gaussian_blur_u8_workspace_bytes(H, W, C)) {
+    hgl_set_error("gaussian_blur_u8: workspace too small");
+    return HGL_EWORKSPACE;
+  }
+  BlurTaps t;
+  t.k = k;
+  for (int i = 0; i < 31; ++i) t.w[i] = i < k ? taps[i] : 0.0;
+  const long long total = (long long)H * W * C;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(blur_v_kernel, dim3(blocks), dim3(256), 0, st, img, H, W, C, t, (double*)workspace);
+  hipLaunchKernelGGL(blur_h_kernel, dim3(blocks), dim3(256), 0, st, (const double*)workspace, H, W, C, t, out);
+  return hgl_check_launch("gaussian_blur_u8");
 }
 
 int hgl_synthesize_views(const uint8_t* sam_img, const uint8_t* blurred, const float* image_norm,

@@ -51,7 +51,7 @@ def real_refs(args, dev, splitBy, context_length):
     """RefBatch per dataset item, in the loader's order (Hybridgl_main.py:40-45,79-146)."""
     import json
     import numpy as np
-    from . import synth
+    from . import ops, synth
     from .pipeline import RefBatch, Sentence
     from .refer_io import ReferDataset
     from .tokenizer import SimpleTokenizer, tokenize
@@ -82,7 +82,7 @@ def real_refs(args, dev, splitBy, context_length):
                                   rec.get("relaflag", "none"), len(others), attn))
         tokens = tokenize(strings, context_length=context_length, tokenizer=tk)   # raises on over-long text, as clip.tokenize
         placeholder = torch.zeros((1, H, W), dtype=torch.bool, device=dev)
-        yield RefBatch(t(img), t(synth.box_blur_u8(img)), t(synth.imagenet_normalize(img)), placeholder,
+        yield RefBatch(t(img), ops.gaussian_blur_u8(t(img)), t(synth.imagenet_normalize(img)), placeholder,
                        torch.zeros((1, 4), dtype=torch.int64, device=dev), t(tokens), t(annot), sents, None,
                        int(data["img_id"][0]))
 

@@ -264,3 +264,23 @@ def synthesize_views(sam_img, blurred, image_norm, masks, res=224):
                                    _dev(image_norm, torch.float32, "image_norm"), mp, N, H, W, res,
                                    loc.data_ptr(), glo.data_ptr(), _stream()), "hgl_synthesize_views")
     return loc, glo
+
+
+def gaussian_blur_u8(img, k=15):
+    """Device version of synth.box_blur_u8 (the stand-in for cv2.GaussianBlur(img,(k,k),0)), bit-identical to it.
+    img: [H,W,C] uint8 device tensor -> blurred [H,W,C] uint8."""
+    import ctypes as C
+    import numpy as np
+    lib = _lib.load()
+    H, W, Cc = img.shape
+    sigma = 0.3 * ((k - 1) * 0.5 - 1) + 0.8
+    r = k // 2
+    x = np.arange(-r, r + 1, dtype=np.float64)
+    g = np.exp(-(x * x) / (2 * sigma * sigma))
+    g /= g.sum()
+    taps = (C.c_double * k)(*[float(v) for v in g])
+    out = torch.empty_like(img)
+    ws = workspace(lib.hgl_gaussian_blur_u8_workspace_bytes(H, W, Cc), img.device, "blur")
+    check(lib.hgl_gaussian_blur_u8(_dev(img, torch.uint8, "img"), H, W, Cc, taps, k, out.data_ptr(), ws.data_ptr(),
+                                   ws.numel(), _stream()), "hgl_gaussian_blur_u8")
+    return out

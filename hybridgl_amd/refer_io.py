@@ -184,7 +184,7 @@ def phrasecut_item(sam_img, phrases, gt_polygons, device, tokenizer, parse=None,
     all its phrases, one ground-truth mask per phrase (gt_polygons[i] = the list of instance polygon lists of
     phrase i, flattened as the reference does) -> pipeline.RefBatch whose sentences carry their own targets."""
     import torch
-    from . import synth
+    from . import ops, synth
     from .pipeline import RefBatch, Sentence
     from .tokenizer import tokenize
     H, W = sam_img.shape[:2]
@@ -201,6 +201,6 @@ def phrasecut_item(sam_img, phrases, gt_polygons, device, tokenizer, parse=None,
         sents.append(Sentence(row, row + 1, list(range(row + 2, row + 2 + len(others))), rec.get("dirflag", "none"),
                               rec.get("relaflag", "none"), len(others), attn, t(gt.astype(np.uint8))))
     tokens = tokenize(strings, context_length=context_length, tokenizer=tokenizer)
-    return RefBatch(t(sam_img), t(synth.box_blur_u8(sam_img)), t(synth.imagenet_normalize(sam_img)),
+    return RefBatch(t(sam_img), ops.gaussian_blur_u8(t(sam_img)), t(synth.imagenet_normalize(sam_img)),
                     torch.zeros((1, H, W), dtype=torch.bool, device=device), torch.zeros((1, 4), dtype=torch.int64, device=device),
                     t(tokens), sents[0].target, sents, None, image_id)

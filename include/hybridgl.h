@@ -226,6 +226,15 @@ int hgl_score_sentence(const float* hybrid, const float* sentence_feat, const fl
 int hgl_iou_select(const uint8_t* masks, const int32_t* idx, int which, const uint8_t* gt,
                    long long HW, int64_t* out_IU, void* stream);
 
+/* Blurred background of the global views (Hybridgl_main.py:99, cv2.GaussianBlur(img, (15,15), 0)).  cv2's 8-bit
+ * fixed-point arithmetic is unpinned (package absent offline): this evaluates the package's own
+ * definition -- separable filter with the caller's k odd taps (HOST array of doubles), reflect-101 borders, double
+ * accumulation in tap order (rows first), round half up -- bit-identically to hybridgl_amd.synth.box_blur_u8.
+ * img/out: [H,W,C] uint8 on the device. */
+size_t hgl_gaussian_blur_u8_workspace_bytes(int H, int W, int C);
+int hgl_gaussian_blur_u8(const uint8_t* img, int H, int W, int C, const double* taps, int k, uint8_t* out, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Image synthesis (Hybridgl_main.py:93-125): per mask, the blurred-background
  * "global" view and mean-filled "local" view, bilinear (no antialias) to res x res.

@@ -126,3 +126,15 @@ def test_pipeline_image_cache_identical(cuda, b16):
     assert torch.equal(out_plain[2][0], out_cached[2][0])          # winning indices
     assert torch.equal(out_plain[0], out_cached[0])                # hybrid features bit-identical
     assert p1.metrics()["cum"] == p2.metrics()["cum"]
+
+
+@pytest.mark.parametrize("H,W", [(40, 56), (157, 203), (480, 640)])
+def test_gaussian_blur_device_matches_host_definition(cuda, H, W):
+    """hgl_gaussian_blur_u8 == synth.box_blur_u8 bit for bit (the package's stand-in for cv2.GaussianBlur, whose
+    own fixed-point arithmetic is unpinned: SURVEY.md 8f-2)."""
+    from hybridgl_amd import ops, synth
+    rng = np.random.default_rng(H)
+    img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    img[: H // 3] = synth.synth_image(H, W, 1)[: H // 3]
+    got = ops.gaussian_blur_u8(torch.from_numpy(img).to(cuda)).cpu().numpy()
+    assert np.array_equal(got, synth.box_blur_u8(img))
