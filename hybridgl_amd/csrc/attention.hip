@@ -253,6 +253,17 @@ __device__ __forceinline__ void split4(const f32x4 v, h16x4& hi, h16x4& lo) {
   }
 }
 
+// ds_read_b64_tr_b16: see attn_x3_kernel (EXEC must be all ones at the call)
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ h16x4 lds_tr4(const _Float16* p) {
+  typedef __attribute__((address_space(3))) fp16x4v lds_v;
+  const fp16x4v v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_v*)p);
+  h16x4 r;
+  __builtin_memcpy(&r, &v, 8);
+  return r;
+}
+
 // RELW > 0: decomposed rel-pos bias of a RELW x RELW window (Sk == RELW*RELW, 2*RELW <= 32, e.g. SAM's 14 x 14)
 // evaluated ON THE MATRIX CORES: bias[q][key] = rel_h[q][key / RELW] + rel_w[q][key % RELW] = R[q][:] . E[key][:]
 // with R[q] = [rel_h row | rel_w row | 0] (32 wide, split hi+lo like every other operand) and E[key] the 0/1
@@ -266,15 +277,19 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   constexpr int KROW = 2 * HD + EW + 8;       // halfs per staged K row: hi | lo | E | pad (odd multiple of 16 B)
   static_assert(2 * RELW <= 32, "window side too large for the MFMA bias");
   constexpr int DT = (HD + 31) / 32;          // 32-wide d tiles of the output
-  constexpr int VROWS = DT * 32;              // V^T rows (zero rows beyond HD)
-  constexpr int VLD = KV_CHUNK + 4;           // halfs per V^T row (136 B: conflict-free 8-byte reads)
+  // V stays ROW-major in LDS (8-byte stores, like K) and the P^T V product reads it with the transposing
+  // ds_read_b64_tr_b16: a 16-lane group fetches a 4-key x 16-d block and each lane receives its d column of the 4
+  // keys -- exactly the 4 consecutive keys an A-operand half wants.  Row pitch 192 B (64 B for narrow heads): the
+  // four rows of a block then fall on four different 64-byte bank groups.
+  constexpr int VP = HD <= 32 ? 32 : 96;      // halfs per staged V row (>= DT*32)
   constexpr int F4 = HD / 4;
   constexpr int NLK = KV_CHUNK * F4 / 256;    // K float4 per thread per chunk
-  constexpr int NLV = HD / 16;                // V float4 per thread per chunk (key = t&63, 4 d-groups apart)
+  constexpr int NLV = NLK;                    // V float4 per thread per chunk (same row-major walk as K)
   static_assert(HD % 16 == 0 && KV_CHUNK * F4 % 256 == 0, "unsupported head dim");
   __shared__ __attribute__((aligned(16))) _Float16 Ks[KV_CHUNK * KROW];
-  __shared__ __attribute__((aligned(16))) _Float16 Vh[VROWS * VLD];
-  __shared__ __attribute__((aligned(16))) _Float16 Vl[VROWS * VLD];
+  static_assert(VP >= DT * 32, "V row pitch");
+  __shared__ __attribute__((aligned(16))) _Float16 Vh[KV_CHUNK * VP];
+  __shared__ __attribute__((aligned(16))) _Float16 Vl[KV_CHUNK * VP];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -347,7 +362,6 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
 
   // ---- staging (software pipelined through registers) ----
   f32x4 pk[NLK], pv[NLV];
-  const int vkey = t & 63, vg = t >> 6;
   auto load_chunk = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NLK; ++i) {
@@ -356,8 +370,11 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
       pk[i] = *(const f32x4*)(kp + (long long)min(kc + row, a.Sk - 1) * a.ldk + c4 * 4);
     }
 #pragma unroll
-    for (int i = 0; i < NLV; ++i)
-      pv[i] = *(const f32x4*)(vp + (long long)min(kc + vkey, a.Sk - 1) * a.ldv + 4 * (vg + 4 * i));
+    for (int i = 0; i < NLV; ++i) {
+      const int idx = t + 256 * i;
+      const int row = idx / F4, c4 = idx - row * F4;
+      pv[i] = *(const f32x4*)(vp + (long long)min(kc + row, a.Sk - 1) * a.ldv + c4 * 4);
+    }
   };
   auto store_chunk = [&](int kc) {
 #pragma unroll
@@ -379,22 +396,25 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NLV; ++i) {
-      const int d0 = 4 * (vg + 4 * i);
+      const int idx = t + 256 * i;
+      const int row = idx / F4, c4 = idx - row * F4;
       h16x4 hi, lo;
       split4(pv[i], hi, lo);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {   // transposed: a wave writes 64 consecutive keys of one d row
-        Vh[(d0 + e) * VLD + vkey] = hi[e];
-        Vl[(d0 + e) * VLD + vkey] = lo[e];
-      }
+      *(h16x4*)(Vh + row * VP + c4 * 4) = hi;
+      *(h16x4*)(Vl + row * VP + c4 * 4) = lo;
     }
   };
-  if (VROWS > HD) {  // zero V^T rows d >= HD once
-    for (int i = t; i < (VROWS - HD) * VLD; i += 256) {
-      Vh[HD * VLD + i] = (_Float16)0.f;
-      Vl[HD * VLD + i] = (_Float16)0.f;
+  if (VP > HD) {  // zero the d padding of every row once (it feeds output rows that are never stored)
+    constexpr int PADW = VP - HD > 0 ? VP - HD : 1;
+    for (int i = t; i < KV_CHUNK * PADW; i += 256) {
+      const int row = i / PADW, c = i - row * PADW;
+      Vh[row * VP + HD + c] = (_Float16)0.f;
+      Vl[row * VP + HD + c] = (_Float16)0.f;
     }
   }
+  // transposed-read addressing: lane = 16*grp + 4*q + p supplies row q, columns 4p..4p+3 of its group's block;
+  // groups 0/1 carry d columns 0-15 / 16-31 for h = 0, groups 2/3 the same for h = 1
+  const int tr_off = (((lane >> 2) & 3) + 4 * h) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   load_chunk(0);
   store_chunk(0);
   __syncthreads();
@@ -426,9 +446,8 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
           s = __builtin_amdgcn_mfma_f32_32x32x16_f16(e8, rbh[c], s, 0, 0, 0);
         }
       }
-      // s[e] = S^T[key = kbase + (e&3) + 8*(e>>2) + 4*h][query qi]
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[e] *= LOG2E;
+      // s[e] = S^T[key = kbase + (e&3) + 8*(e>>2) + 4*h][query qi], in natural-log units; log2(e) is folded into the
+      // exponent's fma below
       if constexpr (RELW > 0) {
         // bias already accumulated by the MFMAs above
       } else if (relh) {
@@ -439,57 +458,76 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
           for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 w4 = *(const f32x4*)(rw + 8 * g4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s[4 * g4 + i] = fmaf(rh + w4[i], LOG2E, s[4 * g4 + i]);
+            for (int i = 0; i < 4; ++i) s[4 * g4 + i] += rh + w4[i];
           }
         } else {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (kg < a.Sk) s[e] = fmaf(relh[kg / a.kw] + relw[kg % a.kw], LOG2E, s[e]);
+            if (kg < a.Sk) s[e] += relh[kg / a.kw] + relw[kg % a.kw];
           }
         }
       }
       float mx = NEG_INF;
+      // only the tile that crosses the end of the sequence, causal tiles and CLS-keep batches need masking (uniform)
+      if (kbase + 32 > a.Sk || a.mask_kind == HGL_MASK_CAUSAL || keep_row) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-        float sv = s[e];
-        bool masked = kg >= a.Sk;
-        if (a.mask_kind == HGL_MASK_CAUSAL) masked |= kg > qi;
-        if (keep_row && qi == 0 && kg >= 1 && kg < a.Sk) masked |= keep_row[kg - 1] == 0;
-        sv = masked ? NEG_INF : sv;
-        s[e] = sv;
-        mx = fmaxf(mx, sv);
+        for (int e = 0; e < 16; ++e) {
+          const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+          float sv = s[e];
+          bool masked = kg >= a.Sk;
+          if (a.mask_kind == HGL_MASK_CAUSAL) masked |= kg > qi;
+          if (keep_row && qi == 0 && kg >= 1 && kg < a.Sk) masked |= keep_row[kg - 1] == 0;
+          sv = masked ? NEG_INF : sv;
+          s[e] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run, mx);
-      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+      // Lazy rescaling: the running maximum follows the scores only when some query of the wave would otherwise see
+      // probabilities above 2^8 (uniform branch).  Until then alpha == 1 and the 16*DT multiplies of O are skipped;
+      // p <= 256 keeps its full relative precision in fp32 and in the fp16 hi+lo pair.
+      const float m_cand = fmaxf(m_run, mx);
+      float m_new = m_run;
+      if (__builtin_amdgcn_ballot_w64(m_cand > m_run + 5.5f)) {   // 5.5 nats ~ 2^8
+        m_new = m_cand;
+        const float m_use0 = (m_new == NEG_INF) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_use0) * LOG2E);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        m_run = m_new;
+      }
+      const float mneg = -((m_new == NEG_INF) ? 0.f : m_new) * LOG2E;
       float rs = 0.f;
       h16x8 ph[2], pl[2];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float p = __builtin_amdgcn_exp2f(s[e] - m_use);
-        rs += p;
-        const _Float16 hi = (_Float16)p;
-        ph[e >> 3][e & 7] = hi;
-        pl[e >> 3][e & 7] = (_Float16)(p - (float)hi);
+      for (int e = 0; e < 16; e += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[e], LOG2E, mneg));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[e + 1], LOG2E, mneg));
+        rs += p0;
+        rs += p1;
+        // hi by one packed round-toward-zero conversion (any rounding works: lo is the exact remainder, rounded to nearest)
+        const h16x2 hi2 = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+        ph[e >> 3][e & 7] = hi2[0]; ph[e >> 3][(e & 7) + 1] = hi2[1];
+        pl[e >> 3][e & 7] = (_Float16)(p0 - (float)hi2[0]);
+        pl[e >> 3][(e & 7) + 1] = (_Float16)(p1 - (float)hi2[1]);
       }
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
-#pragma unroll
-      for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+      l_run += rs;
       // O^T += V^T P^T ; A operand element j of lane (d, h) = V^T[d][kt*32 + 16*s2 + 8*(j>>2) + 4*h + (j&3)]
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         if (kbase + 16 * s2 >= sk_eff) break;   // uniform: the keys of this k-step are all beyond the sequence (P = 0)
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
-          const int off = (d * 32 + r) * VLD + kt * 32 + 16 * s2 + 4 * h;
-          const h16x4 vh0 = *(const h16x4*)(Vh + off), vh1 = *(const h16x4*)(Vh + off + 8);
-          const h16x4 vl0 = *(const h16x4*)(Vl + off), vl1 = *(const h16x4*)(Vl + off + 8);
+          const int off = (kt * 32 + 16 * s2) * VP + d * 32 + tr_off;
+          const h16x4 vh0 = lds_tr4(Vh + off), vh1 = lds_tr4(Vh + off + 8 * VP);
+          const h16x4 vl0 = lds_tr4(Vl + off), vl1 = lds_tr4(Vl + off + 8 * VP);
           h16x8 vh8, vl8;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { vh8[e] = vh0[e]; vh8[4 + e] = vh1[e]; vl8[e] = vl0[e]; vl8[4 + e] = vl1[e]; }
