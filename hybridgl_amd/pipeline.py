@@ -126,6 +126,18 @@ class HybridGLPipeline:
         """One dataset item; returns the device tensors of the last sentence (idx, scores)."""
         import dataclasses
         m = self.model
+        # The text encoder (9 strings: small, latency-bound kernels) is independent of the image path: it runs on its
+        # own stream underneath the SAM / CLIP image kernels and is joined before the scoring tail.
+        cur = torch.cuda.current_stream()
+        if not hasattr(self, "_s_text"):
+            self._s_text = torch.cuda.Stream()
+        ev_in, ev_text = torch.cuda.Event(), torch.cuda.Event()
+        ev_in.record(cur)
+        self._s_text.wait_event(ev_in)
+        with torch.cuda.stream(self._s_text):
+            text = m.model.encode_text(ref.tokens)
+            ev_text.record(self._s_text)
+        text.record_stream(cur)
         # Per-image caching (SURVEY.md 8f-3): the dataset yields one item per REF and the same image backs
         # several consecutive refs (Hybridgl_main.py:79); proposals, views and hybrid features depend on the
         # image only, so they are computed once per image.  Results are identical.
@@ -158,7 +170,7 @@ class HybridGLPipeline:
             hybrid = m(local, glob, ref.masks, masking_block=self.masking_block, fusion_mode=self.fusion_mode)
             if ref.image_id is not None:
                 self._cache_id, self._cache_ref, self._cache_hybrid = ref.image_id, ref, hybrid
-        text = m.model.encode_text(ref.tokens)
+        cur.wait_event(ev_text)
         # the k1/k2 clamp of Hybridgl_main.py:178-181 persists across refs in the reference
         self.k1 = min(self.k1, hybrid.shape[0])
         self.k2 = min(self.k2, hybrid.shape[0])
