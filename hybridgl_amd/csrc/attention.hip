@@ -248,8 +248,10 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split4(const f32x4 v, h16x4& hi, h16x4& lo) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    hi[e] = (_Float16)v[e];
-    lo[e] = (_Float16)(v[e] - (float)hi[e]);
+    _Float16 a, c;
+    hgl_split_hi_lo(v[e], a, c);
+    hi[e] = a;
+    lo[e] = c;
   }
 }
 
@@ -305,11 +307,11 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   const float* kp = a.k + b * a.skb + hh * HD;
   const float* vp = a.v + b * a.svb + hh * HD;
 
-  // Q fragments (pre-scaled in fp32, then split): lane (r,h) element j of step s = Q[q][16s + 8h + j].
+  // Q fragments (pre-scaled in fp32, then split -- through hgl_split_hi_lo, see its comment: this product is where
+  // the inconsistent-rounding problem was found): lane (r,h) element j of step s = Q[q][16s + 8h + j].
   // The scores are moved to log2 units AFTER the QK^T product (one multiply per score) so that the softmax is one
   // v_exp_f32 per element: the precise expf made this kernel VALU-bound (~10 instructions per exponential
-  // against 33 MFMAs per key tile).  Folding log2(e) into the Q scale instead is NOT equivalent in practice: it
-  // produced rows with 4e-5 errors in the parity tests.
+  // against 33 MFMAs per key tile).
   constexpr float LOG2E = 1.4426950408889634f;
   const float qscale = a.scale;
   h16x8 qh[KS], ql[KS];
@@ -321,9 +323,10 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float x = v[e] * qscale;
-        const _Float16 hi = (_Float16)x;
+        _Float16 hi, lo;
+        hgl_split_hi_lo(x, hi, lo);
         qh[s][4 * half + e] = hi;
-        ql[s][4 * half + e] = (_Float16)(x - (float)hi);
+        ql[s][4 * half + e] = lo;
       }
     }
   }
@@ -354,9 +357,10 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
         float x = 0.f;
         if (idx < RELW) x = relh[idx];
         else if (idx < 2 * RELW) x = relw[idx - RELW];
-        const _Float16 hi = (_Float16)x;
+        _Float16 hi, lo;
+        hgl_split_hi_lo(x, hi, lo);
         rbh[c][j] = hi;
-        rbl[c][j] = (_Float16)(x - (float)hi);
+        rbl[c][j] = lo;
       }
   }
 
@@ -563,8 +567,10 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
             h16x4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              hi[e] = (_Float16)w[e];
-              lo[e] = (_Float16)(w[e] - (float)hi[e]);
+              _Float16 a2, c2;
+              hgl_split_hi_lo(w[e], a2, c2);
+              hi[e] = a2;
+              lo[e] = c2;
             }
             *(h16x4*)(a.out_hi + oo + dd) = hi;
             *(h16x4*)(a.out_lo + oo + dd) = lo;
@@ -661,8 +667,10 @@ __global__ __launch_bounds__(256) void attn_smallk_kernel(SmallKArgs a) {
       h16x4 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        hi[e] = (_Float16)r[e];
-        lo[e] = (_Float16)(r[e] - (float)hi[e]);
+        _Float16 a2, c2;
+        hgl_split_hi_lo(r[e], a2, c2);
+        hi[e] = a2;
+        lo[e] = c2;
       }
       *(h16x4*)(a.out_hi + oo + 4 * c) = hi;
       *(h16x4*)(a.out_lo + oo + 4 * c) = lo;

@@ -233,9 +233,10 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
           if (g.C) {
             g.C[o] = v;
           } else {
-            const _Float16 hi = (_Float16)v;
+            _Float16 hi, lo;
+            hgl_split_hi_lo(v, hi, lo);
             g.Ch[o] = hi;
-            g.Cl[o] = (_Float16)(v - (float)hi);
+            g.Cl[o] = lo;
           }
         }
       }
@@ -516,9 +517,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
           if (g.C) {
             g.C[o] = v;
           } else {
-            const _Float16 hi = (_Float16)v;
+            _Float16 hi, lo;
+            hgl_split_hi_lo(v, hi, lo);
             g.Ch[o] = hi;
-            g.Cl[o] = (_Float16)(v - (float)hi);
+            g.Cl[o] = lo;
           }
         }
       }
@@ -558,10 +560,11 @@ __global__ __launch_bounds__(256) void gemm_x3_skinny_kernel(SkinnyArgs g) {
     f16x8 ah, al;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const _Float16 h0 = (_Float16)a0[e], h1 = (_Float16)a1[e];
+      _Float16 h0, l0, h1, l1;
+      hgl_split_hi_lo(a0[e], h0, l0);
+      hgl_split_hi_lo(a1[e], h1, l1);
       ah[e] = h0; ah[4 + e] = h1;
-      al[e] = (_Float16)(a0[e] - (float)h0);
-      al[4 + e] = (_Float16)(a1[e] - (float)h1);
+      al[e] = l0; al[4 + e] = l1;
     }
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc, 0, 0, 0);
@@ -641,9 +644,10 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     f16x4 a, b;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float s = v[e] * scale;
-      a[e] = (_Float16)s;
-      b[e] = (_Float16)(s - (float)a[e]);
+      _Float16 h0, l0;
+      hgl_split_hi_lo(v[e] * scale, h0, l0);
+      a[e] = h0;
+      b[e] = l0;
     }
     ((f16x4*)hi)[i] = a;
     ((f16x4*)lo)[i] = b;
@@ -693,8 +697,10 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float o = (v[i][e] - mean) * rstd * wv[e] + bv[e];
-      a[e] = (_Float16)o;
-      c[e] = (_Float16)(o - (float)a[e]);
+      _Float16 h0, l0;
+      hgl_split_hi_lo(o, h0, l0);
+      a[e] = h0;
+      c[e] = l0;
     }
     hr[lane + 64 * i] = a;
     lr[lane + 64 * i] = c;
@@ -716,8 +722,10 @@ __global__ __launch_bounds__(256) void win_partition_split_kernel(const float* _
   f16x4 a, b;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    a[e] = (_Float16)v[e];
-    b[e] = (_Float16)(v[e] - (float)a[e]);
+    _Float16 h0, l0;
+    hgl_split_hi_lo(v[e], h0, l0);
+    a[e] = h0;
+    b[e] = l0;
   }
   ((f16x4*)hi)[i] = a;
   ((f16x4*)lo)[i] = b;

@@ -273,9 +273,10 @@ __global__ __launch_bounds__(256) void ln_gelu64_kernel(float* __restrict__ x, c
   v = d * rsqrtf(var + eps) * w[lane] + b[lane];
   const float o = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
   if (hi) {
-    const _Float16 h = (_Float16)o;
+    _Float16 h, l;
+    hgl_split_hi_lo(o, h, l);
     hi[row * 64 + lane] = h;
-    lo[row * 64 + lane] = (_Float16)(o - (float)h);
+    lo[row * 64 + lane] = l;
   } else {
     x[row * 64 + lane] = o;
   }
@@ -305,11 +306,11 @@ __global__ __launch_bounds__(256) void ln256_pe_split_kernel(float* __restrict__
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     o[e] = (v[e] - mean) * rstd * wv[e] + bv[e];
-    a[e] = (_Float16)o[e];
-    c[e] = (_Float16)(o[e] - (float)a[e]);
-    const float s2 = o[e] + pv[e];
-    a2[e] = (_Float16)s2;
-    c2[e] = (_Float16)(s2 - (float)a2[e]);
+    _Float16 h0, l0, h1, l1;
+    hgl_split_hi_lo(o[e], h0, l0);
+    hgl_split_hi_lo(o[e] + pv[e], h1, l1);
+    a[e] = h0; c[e] = l0;
+    a2[e] = h1; c2[e] = l1;
   }
   if (write_f32) ((f32x4*)(x + row * 256))[lane] = o;
   ((f16x4g*)(kh + row * 256))[lane] = a;
