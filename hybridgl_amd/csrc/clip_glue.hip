@@ -83,21 +83,25 @@ __global__ __launch_bounds__(256) void layernorm_any_kernel(const float* __restr
 
 // ---- im2col for the stride==kernel patch convolution ----
 // cols[(n*g*g + py*g + px), c*p*p + ky*p + kx] = img[n, c, py*p+ky, px*p+kx]
+// V = elements per thread: 4 when the patch side is a multiple of 4 (ViT-B/16, B/32), 2 for even sides (ViT-L/14), 1 else
+template <int V>
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img,
                                                            float* __restrict__ cols, int N, int res,
                                                            int p, long long total4) {
+  typedef float vec_t __attribute__((ext_vector_type(V)));
   const int g = res / p;
   const int kdim = 3 * p * p;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
        i += (long long)gridDim.x * blockDim.x) {
-    const long long e = i * 4;
+    const long long e = i * V;
     const int col = (int)(e % kdim);
     const long long rowi = e / kdim;
     const int kx = col % p, ky = (col / p) % p, c = col / (p * p);
     const int px = (int)(rowi % g), py = (int)((rowi / g) % g);
     const int n = (int)(rowi / ((long long)g * g));
     const float* src = img + (((long long)n * 3 + c) * res + (py * p + ky)) * res + px * p + kx;
-    *(f32x4*)(cols + e) = *(const f32x4*)src;
+    if constexpr (V == 1) cols[e] = *src;
+    else *(vec_t*)(cols + e) = *(const vec_t*)src;
   }
 }
 
@@ -257,10 +261,14 @@ int hgl_launch_layernorm(const float* x, const float* w, const float* b, float* 
 }
 
 int hgl_launch_im2col_patch(const float* img, int N, int res, int patch, float* cols, hipStream_t st) {
-  HGL_REQUIRE(img && cols && N > 0 && res > 0 && patch > 0 && res % patch == 0 && patch % 4 == 0,
-              "im2col: bad arguments (res=%d patch=%d)", res, patch);
-  const long long total4 = (long long)N * 3 * res * res / 4;
-  hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for(total4)), dim3(256), 0, st, img, cols, N, res, patch, total4);
+  HGL_REQUIRE(img && cols && N > 0 && res > 0 && patch > 0 && res % patch == 0, "im2col: bad arguments (res=%d patch=%d)", res, patch);
+  const long long total = (long long)N * 3 * res * res;
+  if (patch % 4 == 0)
+    hipLaunchKernelGGL(im2col_patch_kernel<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, img, cols, N, res, patch, total / 4);
+  else if (patch % 2 == 0)
+    hipLaunchKernelGGL(im2col_patch_kernel<2>, dim3(grid_for(total / 2)), dim3(256), 0, st, img, cols, N, res, patch, total / 2);
+  else
+    hipLaunchKernelGGL(im2col_patch_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, img, cols, N, res, patch, total);
   return hgl_check_launch("im2col_patch");
 }
 

@@ -52,6 +52,26 @@ def test_b16_vs_reference_golden(cuda, golden_dir, b16, mode):
     np.testing.assert_allclose(y, g[f"N4_{mode}"], rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize("name,last_layer,mb", [("ViT-B/32", 10, 9), ("ViT-L/14", 22, 18)])
+def test_other_clip_geometries_vs_oracle(cuda, name, last_layer, mb):
+    """the other backbones CLIPViTFM accepts (model/backbone.py:16-24): ViT-B/32 (7x7 grid, 50 tokens) and ViT-L/14
+    (width 1024, 24 layers, 16 heads, 257 tokens) through the hybrid forward, against the oracle."""
+    sd = weights.clip_state_dict(name, 0)
+    model = CLIPViTFM(name, state_dict=sd, device=cuda)
+    loc, glo, masks = views_for_case(2, 224, 97, 130)
+    for mode in ["G2L", "G2L&L2G"]:
+        y = _run(model, loc, glo, masks, mode, cuda, mb)
+        ref = O.clip_hybrid_forward(sd, loc, glo, masks, mb, mode, last_layer)
+        np.testing.assert_allclose(y, ref, rtol=0, atol=2e-4)
+    # text tower of the same checkpoint (width 512 / 768, heads = width // 64: clip/model.py:338)
+    from hybridgl_amd.synth import synth_tokens
+    tok = synth_tokens(3, 77, 49408, 11)
+    txt = model.model.encode_text(torch.from_numpy(tok).to(cuda)).cpu().numpy()
+    np.testing.assert_allclose(txt, O.encode_text(sd, tok), rtol=0, atol=5e-5)
+    del model
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("mb", [0, 5, 11])
 def test_tiny_other_masking_blocks_vs_oracle(cuda, tiny, mb):
     loc, glo, masks = views_for_case(3, 64, 97, 130)
