@@ -262,8 +262,10 @@ def build_sam_vit_h(checkpoint=None, **kw):
     return _build("vit_h", checkpoint, **kw)
 
 
-# build_sam.py:47-52 (vit_l / vit_b are not on the reference's path: Hybridgl_main.py:66 uses 'default')
+# build_sam.py:47-52 (Hybridgl_main.py:66 uses 'default' = vit_h)
 sam_model_registry = {"default": build_sam_vit_h, "vit_h": build_sam_vit_h,
+                      "vit_l": lambda checkpoint=None, **kw: _build("vit_l", checkpoint, **kw),
+                      "vit_b": lambda checkpoint=None, **kw: _build("vit_b", checkpoint, **kw),
                       "tiny": lambda checkpoint=None, **kw: _build("tiny", checkpoint, **kw)}
 
 

@@ -105,6 +105,13 @@ SAM_CONFIGS = {
     # full ViT-H width/grid but two blocks (one windowed, one global): full-size parity test
     "vit_h_d2": dict(embed_dim=1280, depth=2, num_heads=16, global_attn_indexes=(1,),
                      img_size=1024, patch_size=16, window_size=14, out_chans=256),
+    # segment_anything/build_sam.py:24-44: the smaller published encoders (head dim 64)
+    "vit_l": dict(embed_dim=1024, depth=24, num_heads=16, global_attn_indexes=(5, 11, 17, 23),
+                  img_size=1024, patch_size=16, window_size=14, out_chans=256),
+    "vit_b": dict(embed_dim=768, depth=12, num_heads=12, global_attn_indexes=(2, 5, 8, 11),
+                  img_size=1024, patch_size=16, window_size=14, out_chans=256),
+    "vit_b_d2": dict(embed_dim=768, depth=2, num_heads=12, global_attn_indexes=(1,),
+                     img_size=1024, patch_size=16, window_size=14, out_chans=256),
     # tiny geometry for parity tests: 16x16 tokens, 2 heads of 80, windowed + global blocks
     "tiny": dict(embed_dim=160, depth=4, num_heads=2, global_attn_indexes=(1, 3),
                  img_size=256, patch_size=16, window_size=14, out_chans=256),

@@ -275,6 +275,19 @@ def test_vit_h_two_blocks_full_width(cuda):
     assert np.array_equal(emb, emb2)      # run-to-run bit reproducible
 
 
+def test_vit_b_two_blocks_full_width(cuda):
+    """ViT-B width (768, 12 heads of 64): one windowed + one global block + neck against the oracle at full size
+    (the head-dim-64 paths of the rel-pos and attention kernels, the 14x14 window without the matrix-core bias)."""
+    cfg = weights.SAM_CONFIGS["vit_b_d2"]
+    sd = weights.sam_state_dict("vit_b_d2", 0)
+    m = hsam.Sam(sd, cfg, cuda)
+    from hybridgl_amd.synth import synth_image
+    img = synth_image(768, 1024, 6)
+    emb = m.encode(T(img, cuda)).cpu().numpy().reshape(64, 64, 256)
+    ref = S.image_encoder(sd, S.preprocess(img, 1024), cfg)
+    np.testing.assert_allclose(emb, ref, rtol=0, atol=2e-4)
+
+
 def test_full_size_decoder_properties(cuda):
     """64 prompts x 64x64 embedding (BASELINE size): finite, deterministic, prompt-batch independent."""
     cfg = weights.SAM_CONFIGS["vit_h_d2"]
