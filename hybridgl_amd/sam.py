@@ -361,6 +361,92 @@ def get_preprocess_shape(oldh, oldw, long_side):
     return int(oldh * scale + 0.5), int(oldw * scale + 0.5)
 
 
+class ResizeLongestSide:
+    """utils/transforms.py:16-102 (the pieces the predictor uses)."""
+
+    def __init__(self, target_length):
+        self.target_length = target_length
+
+    def apply_image(self, image):
+        dev = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image)).cuda()
+        return resize_longest_side(dev.contiguous(), self.target_length)
+
+    def apply_coords(self, coords, original_size):
+        """utils/transforms.py:33-45 (float64, as numpy)."""
+        old_h, old_w = original_size
+        new_h, new_w = get_preprocess_shape(old_h, old_w, self.target_length)
+        c = np.array(coords, dtype=np.float64, copy=True)
+        c[..., 0] = c[..., 0] * (new_w / old_w)
+        c[..., 1] = c[..., 1] * (new_h / old_h)
+        return c
+
+
+class SamPredictor:
+    """predictor.py:17-269 for what the automatic generator drives: set_image, predict_torch with ONE foreground
+    point per prompt (automatic_mask_generator.py:269-285), multimask output.  Other prompt kinds (boxes, mask inputs,
+    background points, several points per prompt) are not on the reference's path and raise NotImplementedError."""
+
+    def __init__(self, sam_model):
+        self.model = sam_model
+        self.transform = ResizeLongestSide(sam_model.img_size)
+        self.reset_image()
+
+    @property
+    def device(self):
+        return self.model.device
+
+    def reset_image(self):
+        self.is_image_set = False
+        self.features = None
+        self.original_size = self.input_size = None
+
+    def set_image(self, image, image_format="RGB"):
+        assert image_format in ("RGB", "BGR"), f"image_format must be in ['RGB', 'BGR'], is {image_format}."
+        img = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image)).to(self.device)
+        if image_format != self.model.image_format:
+            img = img.flip(-1)
+        self.reset_image()
+        self.original_size = tuple(int(v) for v in img.shape[:2])
+        resized = resize_longest_side(img.contiguous(), self.model.img_size)
+        self.input_size = tuple(int(v) for v in resized.shape[:2])
+        self.features = self.model.encode(resized)
+        self.is_image_set = True
+
+    def predict_torch(self, point_coords, point_labels, boxes=None, mask_input=None, multimask_output=True,
+                      return_logits=False):
+        """point_coords [P,1,2] already in the resized frame (transform.apply_coords), point_labels [P,1] all 1.
+        Returns (masks [P,3,H,W] bool or logits, iou_predictions [P,3], low_res_masks [P,3,256,256])."""
+        if not self.is_image_set:
+            raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")   # predictor.py:214
+        if boxes is not None or mask_input is not None or not multimask_output:
+            raise NotImplementedError("only point prompts with multimask output are on the reference's path")
+        pc = torch.as_tensor(point_coords, device=self.device)
+        pl = torch.as_tensor(point_labels, device=self.device)
+        if pc.dim() != 3 or pc.shape[1] != 1 or not bool((pl == 1).all()):
+            raise NotImplementedError("one foreground point per prompt (what SamAutomaticMaskGenerator issues)")
+        p01 = ((pc[:, 0, :].to(torch.float64) + 0.5) / float(self.model.img_size)).to(torch.float32).contiguous()
+        low, iou = self.model.decode_points(self.features, p01)
+        P = low.shape[0]
+        H, W = self.original_size
+        _, _, _, _, full = self.model.postprocess(low.flatten(0, 1), iou.flatten(), self.input_size, (H, W), -1e30, 0.0, 1.0,
+                                                  return_logits=True)
+        full = full.reshape(P, 3, H, W)
+        masks = full if return_logits else full > self.model.mask_threshold
+        return masks, iou, low
+
+    def predict(self, point_coords=None, point_labels=None, box=None, mask_input=None, multimask_output=True,
+                return_logits=False):
+        """predictor.py:90-167 for a single foreground point: numpy in, numpy out ([3,H,W], [3], [3,256,256])."""
+        if point_coords is None or box is not None or mask_input is not None:
+            raise NotImplementedError("only point prompts are on the reference's path")
+        pts = self.transform.apply_coords(np.asarray(point_coords, dtype=np.float64), self.original_size)
+        m, iou, low = self.predict_torch(torch.from_numpy(pts)[:, None, :], torch.as_tensor(point_labels)[:, None],
+                                         multimask_output=multimask_output, return_logits=return_logits)
+        if m.shape[0] != 1:
+            raise NotImplementedError("predict() takes one prompt (several points per prompt are not supported)")
+        return m[0].cpu().numpy(), iou[0].cpu().numpy(), low[0].cpu().numpy()
+
+
 class SamAutomaticMaskGenerator:
     """automatic_mask_generator.py:35-372: the Hybridgl_main.py:67-73 configuration (one crop, 8x8 points) runs
     entirely on the device with two host syncs; crop layers / dense grids (Hybridgl_main_PhraseCut.py) add one
@@ -374,6 +460,7 @@ class SamAutomaticMaskGenerator:
             "Exactly one of points_per_side or point_grid must be provided."
         assert output_mode == "binary_mask", "only binary_mask output is on the reference's path"
         self.model = model
+        self.predictor = SamPredictor(model)
         if point_grids is None:
             self.point_grids = build_all_layer_point_grids(points_per_side, crop_n_layers, crop_n_points_downscale_factor)
         else:

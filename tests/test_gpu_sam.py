@@ -78,6 +78,30 @@ def test_tiny_decoder_and_encoder_fp32_mode(cuda, g, tiny_f32):
         ops.set_precision(ops.default_precision())
 
 
+def test_predictor_mirror_vs_reference(cuda, g, tiny):
+    """SamPredictor.set_image / predict_torch (predictor.py:17-269) on the tiny model against the reference's stage
+    tensors: full-resolution logits, IoU predictions and the error behaviour."""
+    c = sam_tiny_case()
+    pred = hsam.SamPredictor(tiny[1])
+    with pytest.raises(RuntimeError):
+        pred.predict_torch(torch.zeros(1, 1, 2), torch.ones(1, 1))
+    pred.set_image(c["image"])
+    assert pred.original_size == (160, 200) and pred.input_size == c["input_size"]
+    pts = pred.transform.apply_coords(c["points"], pred.original_size)
+    np.testing.assert_allclose(pts, c["points_in"], rtol=0, atol=1e-12)
+    logits, iou, low = pred.predict_torch(torch.from_numpy(pts)[:, None, :], torch.ones(len(pts), 1, dtype=torch.int),
+                                          return_logits=True)
+    np.testing.assert_allclose(iou.cpu().numpy(), g["iou"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(low.cpu().numpy(), g["low_res"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(logits.cpu().numpy()[:, :, ::4, ::4], g["full_logits"], rtol=0, atol=3e-4)
+    masks, _, _ = pred.predict_torch(torch.from_numpy(pts)[:, None, :], torch.ones(len(pts), 1, dtype=torch.int))
+    assert masks.dtype == torch.bool and tuple(masks.shape) == (5, 3, 160, 200)
+    with pytest.raises(NotImplementedError):
+        pred.predict_torch(torch.from_numpy(pts)[:, None, :], torch.zeros(len(pts), 1, dtype=torch.int))
+    m1, i1, l1 = pred.predict(c["points"][:1], np.array([1]))
+    assert m1.shape == (3, 160, 200) and np.array_equal(m1, masks[0].cpu().numpy())
+
+
 def test_tiny_postprocess_vs_reference(cuda, g, tiny):
     c = sam_tiny_case()
     m = tiny[1]
