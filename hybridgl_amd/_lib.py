@@ -141,6 +141,8 @@ PROTOTYPES = {
     "hgl_remove_small_regions": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_mask_boxes": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "hgl_gather_masks": (_I, [_VP, _VP, _VP, _I, _LL, _VP, _VP]),
+    "hgl_gen_dir_mask": (_I, [_I, _I, _I, _VP, _VP]),
+    "hgl_relation_boxes": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
     "hgl_gaussian_blur_u8_workspace_bytes": (_SZ, [_I, _I, _I]),
     "hgl_gaussian_blur_u8": (_I, [_VP, _I, _I, _I, C.POINTER(C.c_double), _I, _VP, _VP, _SZ, _VP]),
     "hgl_gt_mask_from_polygons": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP]),

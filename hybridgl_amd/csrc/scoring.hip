@@ -500,6 +500,22 @@ __global__ __launch_bounds__(256) void synth_views_kernel(
   }
 }
 
+// ---- the reference's free helpers as standalone kernels (utils.py:135-161 gen_dir_mask, :240-268 relation_boxes) ----
+// The fused tail (coherence_scores, score_sentence) does not call these; they exist so that code written against
+// the reference's utils.py finds the same functions, evaluated by the same device arithmetic.
+__global__ __launch_bounds__(256) void gen_dir_mask_kernel(int dirflag, int H, int W, float* __restrict__ out) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= (long long)H * W) return;
+  out[i] = dir_weight(dirflag, (int)(i % W), W);
+}
+
+__global__ __launch_bounds__(256) void relation_boxes_kernel(const long long* __restrict__ bi, const long long* __restrict__ bj,
+                                                             const float* __restrict__ si, const float* __restrict__ sj, int n,
+                                                             int rela, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = relation_boxes_dev(bi + 4 * i, bj + 4 * i, si[i], sj[i], rela);
+}
+
 // ---- blurred background of the global views (Hybridgl_main.py:99 cv2.GaussianBlur(img, (15,15), 0)) ----------
 // OpenCV is a third-party package that is absent offline and its 8-bit fixed-point kernel is unpinned
 // (SURVEY.md 8f-2); this is the package's own definition (hybridgl_amd/synth.py box_blur_u8: separable Gaussian with
@@ -657,6 +673,24 @@ int hgl_score_sentence(const float* hybrid, const float* sentence_feat, const fl
   float* pool = (float*)workspace;
   hipLaunchKernelGGL(score_sentence_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, hybrid, sentence_feat, noun_phrase_feat, other_noun_feats, n_other, r, (const long long*)boxes, gem_score, N, E, logit_scale, k1, k2, alpha, relaword, has_other_nouns, (int*)idx, score_clip, score_neg, pool);
   return hgl_check_launch("score_sentence");
+}
+
+int hgl_gen_dir_mask(int dirflag, int H, int W, float* out, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(out && H > 0 && W > 0 && dirflag >= 0 && dirflag <= 3, "gen_dir_mask: bad arguments");
+  hipLaunchKernelGGL(gen_dir_mask_kernel, dim3((unsigned)(((long long)H * W + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     dirflag, H, W, out);
+  return hgl_check_launch("gen_dir_mask");
+}
+
+int hgl_relation_boxes(const int64_t* boxes_i, const int64_t* boxes_j, const float* score_i, const float* score_j, int n,
+                       int relaword, float* out, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(boxes_i && boxes_j && score_i && score_j && out && n > 0, "relation_boxes: bad arguments");
+  HGL_REQUIRE(relaword >= 0 && relaword <= 7, "relation_boxes: bad relaword %d", relaword);
+  hipLaunchKernelGGL(relation_boxes_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const long long*)boxes_i,
+                     (const long long*)boxes_j, score_i, score_j, n, relaword, out);
+  return hgl_check_launch("relation_boxes");
 }
 
 size_t hgl_gaussian_blur_u8_workspace_bytes(int H, int W, int C) { return hgl_align_up((size_t)H * W * C * sizeof(double), 256); }

@@ -226,6 +226,15 @@ int hgl_score_sentence(const float* hybrid, const float* sentence_feat, const fl
 int hgl_iou_select(const uint8_t* masks, const int32_t* idx, int which, const uint8_t* gt,
                    long long HW, int64_t* out_IU, void* stream);
 
+/* The reference's free helpers, standalone (the fused tail above does not need them):
+ * gen_dir_mask (utils.py:135-161): out [H,W] fp32; dirflag 0 none (ones; also "up"/"down", commented out in the
+ * reference), 1 left, 2 right, 3 middle; torch.linspace's symmetric single-fma evaluation.
+ * relation_boxes (utils.py:240-268) for n independent pairs: boxes XYWH int64 [n,4], scores [n] -> out [n];
+ * relaword 0 none .. 7 within (HGL order: none,left,right,up,down,big,small,within). */
+int hgl_gen_dir_mask(int dirflag, int H, int W, float* out, void* stream);
+int hgl_relation_boxes(const int64_t* boxes_i, const int64_t* boxes_j, const float* score_i, const float* score_j, int n,
+                       int relaword, float* out, void* stream);
+
 /* Blurred background of the global views (Hybridgl_main.py:99, cv2.GaussianBlur(img, (15,15), 0)).  cv2's 8-bit
  * fixed-point arithmetic is unpinned (package absent offline): this evaluates the package's own
  * definition -- separable filter with the caller's k odd taps (HOST array of doubles), reflect-101 borders, double

@@ -158,3 +158,31 @@ def test_gaussian_blur_device_matches_host_definition(cuda, H, W):
     img[: H // 3] = synth.synth_image(H, W, 1)[: H // 3]
     got = ops.gaussian_blur_u8(torch.from_numpy(img).to(cuda)).cpu().numpy()
     assert np.array_equal(got, synth.box_blur_u8(img))
+
+
+def test_reference_named_helpers_vs_golden(cuda, golden_dir):
+    """hybridgl_amd.utils.{gen_dir_mask, relation_boxes, Compute_IoU}: the reference's utils.py names, device
+    arithmetic, against the vectors captured from the reference (tests/golden/scoring.npz)."""
+    from hybridgl_amd import utils as U
+    g = np.load(os.path.join(golden_dir, "scoring.npz"))
+    for flag in ["left", "right", "middle", "none", "up"]:
+        for (h, w) in [(3, 5), (4, 8), (2, 640), (2, 427)]:
+            got = U.gen_dir_mask(flag, h, w, cuda).cpu().numpy()
+            assert np.array_equal(got, g[f"dm_{flag}_{h}_{w}"]), (flag, h, w)      # bit-exact (linspace as single fmas)
+    boxes, scores, tab = g["rb_boxes"], g["rb_scores"], g["rb_table"]
+    tb = torch.from_numpy(boxes.astype(np.int64)).to(cuda)
+    ts = torch.from_numpy(scores.astype(np.float32)).to(cuda)
+    ii, jj = np.meshgrid(np.arange(4), np.arange(4), indexing="ij")
+    for w, word in enumerate(g["rb_words"]):
+        got = U.relation_boxes(tb[ii.ravel()], tb[jj.ravel()], ts[ii.ravel()], ts[jj.ravel()], str(word)).cpu().numpy()
+        np.testing.assert_allclose(got.reshape(4, 4), tab[w], rtol=0, atol=1e-7)
+        one = U.relation_boxes(tb[0], tb[1], ts[0], ts[1], str(word))
+        assert one.dim() == 0 and abs(float(one) - float(tab[w, 0, 1])) <= 1e-7
+    pred, gt = torch.from_numpy(g["iou_pred"]).to(cuda), torch.from_numpy(g["iou_gt"]).to(cuda)
+    cum_I, cum_U = torch.zeros((), dtype=torch.int64, device=cuda), torch.zeros((), dtype=torch.int64, device=cuda)
+    iou, lst, cum_I, cum_U = U.Compute_IoU(pred, gt, cum_I, cum_U, [])
+    I, Uc = (int(v) for v in g["iou_IU"])
+    assert (int(cum_I), int(cum_U)) == (I, Uc) and abs(float(iou) - I / Uc) < 1e-6 and len(lst) == 1
+    z = torch.zeros((3, 3), dtype=torch.bool, device=cuda)
+    iou0, _, _, _ = U.Compute_IoU(z, z, cum_I, cum_U, [])
+    assert iou0 == 0.0
