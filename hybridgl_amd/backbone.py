@@ -192,6 +192,18 @@ class CLIPViTFM:
     def dtype(self):
         return self.model.dtype
 
+    def text_feature(self, text):
+        """model/backbone.py:58-70: the text tower with its causal mask, EOT pooling and projection -- the same
+        computation as CLIP.encode_text."""
+        return self.model.encode_text(text)
+
+    def text_masking_feature(self, text, masking_index=[], masking_block=11):   # noqa: B006 -- reference signature
+        """model/backbone.py:34-56.  Not called anywhere in the reference's drivers; without masked tokens it is
+        text_feature, and the token-zeroing variant is not built."""
+        if masking_index:
+            raise NotImplementedError("text_masking_feature with masked tokens is not on the reference's path")
+        return self.model.encode_text(text)
+
     def calculate_score(self, image_features, text_features, visual_norm_dim=1):
         """model/backbone.py:74-87 -> [N, T] logits."""
         assert visual_norm_dim == 1
