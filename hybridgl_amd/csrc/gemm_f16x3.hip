@@ -49,7 +49,6 @@ struct Args {
   int ksplit;    // applied by splitk_reduce_kernel, which sums the parts in a fixed order
   const int *amap, *cmap;   // optional row maps: A row m is read from row amap[m]; output / residual row m lives at cmap[m]
   int rmod;    // residual row = row % rmod when > 0 (a residual shared by every batch of rows), else row
-  int ablate;  // timing experiments only (HGL_X3_ABLATE): 1 = no global loads in the loop, 2 = no LDS stores in the loop
 };
 
 int g_x3_kernel = -2;   // -2: read HGL_X3_KERNEL on first use; -1: cost model; >= 0: forced
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
   const _Float16* As = smem + (wm * 64 + r) * ROW_H + 8 * h;
   const _Float16* Ws = smem + (BM + wn * 64 + r) * ROW_H + 8 * h;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk && g.ablate != 1) load_tile(kt + 1);
+    if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       const f16x8 ah0 = *(const f16x8*)(As + 16 * s), al0 = *(const f16x8*)(As + BK + 16 * s);
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, acc[1][1], 0, 0, 0);
     }
     __syncthreads();
-    if (kt + 1 < nk && g.ablate != 2) store_tile();
+    if (kt + 1 < nk) store_tile();
     __syncthreads();
   }
 
@@ -269,7 +268,7 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
                : "memory");
 }
 
-template <int ACT, int TBM, int TBN, int WGM, int WGN, int OCC, bool INTERLEAVE>
+template <int ACT, int TBM, int TBN, int WGM, int WGN, int OCC>
 __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
   constexpr int NW = WGM * WGN;
   constexpr int WTM = TBM / WGM, WTN = TBN / WGN, MI = WTM / 32, NI = WTN / 32;
@@ -797,9 +796,6 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
   g.part = nullptr; g.ksplit = 1;
   g.out_scale = ldexpf(1.0f, -sw.scale_log2);
   {
-    static int abl = -1;
-    if (abl < 0) { const char* v = getenv("HGL_X3_ABLATE"); abl = v ? atoi(v) : 0; }
-    g.ablate = abl;
     static int gmv = -1;
     if (gmv < 0) { const char* v = getenv("HGL_X3_GM"); gmv = v ? atoi(v) : 8; if (gmv < 1) gmv = 8; }
     g.gm = gmv;
@@ -837,7 +833,7 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
     }                                                                                                         \
     hipLaunchKernelGGL((gemm_f16x3_kernel<ACT_, BK_, OCC_>), dim3((unsigned)nwg), dim3(NTHREADS), lds_, st, g); \
   } while (0)
-#define HGL_X3G_LAUNCH(ACT_, TBM_, TBN_, WGM_, WGN_, OCC_, IL_)                                                  \
+#define HGL_X3G_LAUNCH(ACT_, TBM_, TBN_, WGM_, WGN_, OCC_)                                                       \
   do {                                                                                                        \
     g.tiles_m = (M + TBM_ - 1) / TBM_;                                                                        \
     g.tiles_n = (N + TBN_ - 1) / TBN_;                                                                        \
@@ -846,18 +842,18 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
     const size_t lds_ = (size_t)4 * (TBM_ + TBN_) * 64;                                                     \
     static bool set_ = false;                                                                                 \
     if (!set_) {                                                                                              \
-      (void)hipFuncSetAttribute((const void*)gemm_x3g_kernel<ACT_, TBM_, TBN_, WGM_, WGN_, OCC_, IL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+      (void)hipFuncSetAttribute((const void*)gemm_x3g_kernel<ACT_, TBM_, TBN_, WGM_, WGN_, OCC_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
       set_ = true;                                                                                            \
     }                                                                                                         \
-    hipLaunchKernelGGL((gemm_x3g_kernel<ACT_, TBM_, TBN_, WGM_, WGN_, OCC_, IL_>), dim3((unsigned)nwg), dim3(WGM_ * WGN_ * 64), lds_, st, g); \
+    hipLaunchKernelGGL((gemm_x3g_kernel<ACT_, TBM_, TBN_, WGM_, WGN_, OCC_>), dim3((unsigned)nwg), dim3(WGM_ * WGN_ * 64), lds_, st, g); \
   } while (0)
 #define HGL_X3_VARIANTS(ACT_)                                  \
   do {                                                         \
-    if (kind == 1) HGL_X3G_LAUNCH(ACT_, 256, 256, 2, 4, 1, true);    \
-    else if (kind == 2) HGL_X3G_LAUNCH(ACT_, 256, 128, 4, 2, 1, true); \
-    else if (kind == 3) HGL_X3G_LAUNCH(ACT_, 128, 128, 2, 2, 2, true); \
-    else if (kind == 4) HGL_X3G_LAUNCH(ACT_, 128, 160, 4, 1, 2, true); \
-    else if (kind == 5) HGL_X3G_LAUNCH(ACT_, 160, 160, 5, 1, 1, true); \
+    if (kind == 1) HGL_X3G_LAUNCH(ACT_, 256, 256, 2, 4, 1);    \
+    else if (kind == 2) HGL_X3G_LAUNCH(ACT_, 256, 128, 4, 2, 1); \
+    else if (kind == 3) HGL_X3G_LAUNCH(ACT_, 128, 128, 2, 2, 2); \
+    else if (kind == 4) HGL_X3G_LAUNCH(ACT_, 128, 160, 4, 1, 2); \
+    else if (kind == 5) HGL_X3G_LAUNCH(ACT_, 160, 160, 5, 1, 1); \
     else HGL_X3_LAUNCH(ACT_, 64, 2);                           \
   } while (0)
   switch (act) {
@@ -926,18 +922,18 @@ int hgl_launch_gemm_f16x3_splitk(const void* Ah, const void* Al, int lda, const 
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldr = 0; g.ldc = N;
   g.rmod = 0; g.amap = amap; g.cmap = nullptr; g.part = part; g.ksplit = ksplit;
   g.out_scale = ldexpf(1.0f, -sw.scale_log2);
-  g.ablate = 0; g.gm = 8;
+  g.gm = 8;
   g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
   {
     HglProfScope prof(HGL_PROF_GEMM_X3G, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
     const size_t lds = (size_t)4 * (256 + 256) * 64;
     static bool set = false;
     if (!set) {
-      (void)hipFuncSetAttribute((const void*)gemm_x3g_kernel<HGL_ACT_NONE, 256, 256, 2, 4, 1, true>,
+      (void)hipFuncSetAttribute((const void*)gemm_x3g_kernel<HGL_ACT_NONE, 256, 256, 2, 4, 1>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       set = true;
     }
-    hipLaunchKernelGGL((gemm_x3g_kernel<HGL_ACT_NONE, 256, 256, 2, 4, 1, true>), dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)ksplit),
+    hipLaunchKernelGGL((gemm_x3g_kernel<HGL_ACT_NONE, 256, 256, 2, 4, 1>), dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)ksplit),
                        dim3(512), lds, st, g);
     const long long MN4 = (long long)M * N / 4;
     const unsigned blocks = (unsigned)((MN4 + 255) / 256 > 4096 ? 4096 : (MN4 + 255) / 256);

@@ -129,7 +129,6 @@ int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long row
 int hgl_launch_ln256_pe_split(float* x, const float* w, const float* b, const float* pe, int pe_rows, long long rows,
                               float eps, int write_f32, void* kh, void* kl, void* ph, void* pl, hipStream_t st);
 int hgl_launch_hyper_logits(const float* u2, const float* hyper, int P, int g, float* low_res, hipStream_t st);
-int hgl_launch_unshuffle_logits(const float* Lg, int P, int g, float* out, hipStream_t st);
 
 // split-fp16 GEMM path (gemm_f16x3.hip)
 int hgl_precision();

@@ -6,7 +6,7 @@
 //   add_rows_bcast        keys + key_pe / queries + query_pe, modeling/transformer.py:160-179
 //   pe_points / build_tokens  modeling/prompt_encoder.py:73-91,185-214, modeling/mask_decoder.py:120-123
 //   ln_gelu_rows          LayerNorm2d + GELU of output_upscaling, modeling/mask_decoder.py:53-59
-//   unshuffle_logits      pixel order of the two ConvTranspose2d(k=2,s=2) stages -> [P,3,4g,4g]
+//   hyper_logits          hyper-network x upscaled embedding, written in the [P,3,4g,4g] pixel order
 //   sam_postprocess       modeling/sam.py:133-162 + utils/amg.py:156-176,303-346 fused
 //   sam_select / nms      automatic_mask_generator.py:251-257,287-319
 #include "hgl_common.h"
@@ -317,19 +317,6 @@ __global__ __launch_bounds__(256) void ln256_pe_split_kernel(float* __restrict__
   ((f16x4g*)(kl + row * 256))[lane] = c;
   ((f16x4g*)(ph + row * 256))[lane] = a2;
   ((f16x4g*)(pl + row * 256))[lane] = c2;
-}
-
-// Lg: [P][g*g*16][4]  ->  out: [P][3][4g][4g] (mask tokens 1..3)
-__global__ __launch_bounds__(256) void unshuffle_logits_kernel(const float* __restrict__ Lg, int P, int g,
-                                                               float* __restrict__ out) {
-  const int S4 = 4 * g;
-  const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i >= (long long)P * 3 * S4 * S4) return;
-  const int X = (int)(i % S4), Y = (int)((i / S4) % S4);
-  const int t = (int)((i / ((long long)S4 * S4)) % 3), p = (int)(i / (3ll * S4 * S4));
-  const int y = Y >> 2, x = X >> 2, ky = (Y >> 1) & 1, kx = (X >> 1) & 1, ky2 = Y & 1, kx2 = X & 1;
-  const long long row = (((long long)y * g + x) * 4 + (ky * 2 + kx)) * 4 + (ky2 * 2 + kx2);
-  out[i] = Lg[((long long)p * g * g * 16 + row) * 4 + (t + 1)];
 }
 
 // masks[p, t, Y, X] = hyper[p, t+1, :] . upscaled[p, pixel(Y,X), :]  (mask_decoder.py:146-151, multimask rows 1..3),
@@ -836,11 +823,6 @@ int hgl_launch_hyper_logits(const float* u2, const float* hyper, int P, int g, f
   HGL_REQUIRE((4 * g) % 32 == 0, "hyper_logits: 4*grid must be a multiple of 32 (grid %d)", g);
   hipLaunchKernelGGL(hyper_logits_kernel, dim3(4 * g, P), dim3(256), 0, st, u2, hyper, g, low_res);
   return hgl_check_launch("hyper_logits");
-}
-int hgl_launch_unshuffle_logits(const float* Lg, int P, int g, float* out, hipStream_t st) {
-  const long long total = (long long)P * 3 * 16 * g * g;
-  hipLaunchKernelGGL(unshuffle_logits_kernel, dim3(grid1(total)), dim3(256), 0, st, Lg, P, g, out);
-  return hgl_check_launch("unshuffle_logits");
 }
 
 extern "C" {
