@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
 One step = one dataset item ("ref") of BASELINE.json configs[1]: a 640x640 image with 64 mask
-proposals and 3 text queries, G2L fusion, CLIP ViT-B/16 -- view synthesis, CLIP hybrid encoder,
-text encoder (9 strings), and the per-sentence scoring tail with IoU.  All inputs are synthetic
+proposals and 3 text queries, G2L fusion, CLIP ViT-B/16 -- SAM ViT-H proposal stage, view synthesis, CLIP hybrid
+encoder, text encoder (9 strings + 3 GEM prompts), the GEM heat-map stage (ViT-B/16 at 448x448) and the
+per-sentence scoring tail with IoU.  All inputs are synthetic
 (hybridgl_amd/synth.py), weights are seeded random (no checkpoints offline), and every input is
 resident in HBM before the timed region.  Refs are sharded over ranks with no data-path
 collective (weak scaling); metrics are all-gathered once at the end.
@@ -29,14 +30,25 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0   # dense; AMD's 5 PF headline includes 2:1 spars
 PEAK_HBM_GBS = 8000.0
 
 
-def algorithmic_flops_per_ref(N=64, n_strings=9, sam=True):
+def gem_flops_per_image(S=785, D=768, layers=12, gem_blocks=6, patch_k=768, embed=512):
+    """GEM ViT-B/16 at 448x448, computed ONCE per image: per block 2*S*D*12D of GEMMs + 4*S^2*D of attention;
+    a GEM block adds 3 sets x 2 self-self attentions (4*S^2*D each) and one more out-projection; the MLP and the
+    original attention of the last block are dead."""
+    gemm = 2.0 * S * D * 12 * D
+    attn = 4.0 * S * S * D
+    plain = layers * (gemm + attn) - (2.0 * S * D * 8 * D + 2.0 * S * D * D + attn)
+    ss = gem_blocks * (6 * attn + 2.0 * S * D * D)
+    return plain + ss + 2.0 * (S - 1) * patch_k * D + 2.0 * S * D * embed
+
+
+def algorithmic_flops_per_ref(N=64, n_strings=9, sam=True, gem=False):
     """SURVEY.md 8d, minimal variant (dead final-block streams removed), ViT-B/16 G2L;
-    SAM ViT-H encoder 5.961 TFLOP + decoder 3.62 GFLOP x 64 prompts."""
+    SAM ViT-H encoder 5.961 TFLOP + decoder 3.62 GFLOP x 64 prompts; + the GEM heat-map stage when it runs here."""
     blk = 2.908e9          # per sequence per block (qkv .697, proj .232, mlp 1.859, attn .119)
     patch = 0.231e9        # patch embed per sequence
     clip = 2 * N * patch + 23 * N * blk
-    text = 5.96e9 * n_strings
-    return clip + text + ((5.961e12 + 64 * 3.62e9) if sam else 0.0)
+    text = 5.96e9 * (n_strings + (3 if gem else 0))
+    return clip + text + ((5.961e12 + 64 * 3.62e9) if sam else 0.0) + (gem_flops_per_image() if gem else 0.0)
 
 
 def roofline(precision, nprof, g, x, a, traffic, whole_tflops, xg=(0, 0.0, 0.0)):
@@ -126,7 +138,7 @@ def cpu_baseline_sam():
                    f"decoder on 2 of 64 prompts {t5 - t4:.1f}s x32, post-process 6 of 192 {t6 - t5:.1f}s x32")
 
 
-def cpu_baseline(fusion_mode, n_sample=8, with_sam=True):
+def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False):
     """Oracle (numpy port of the reference algorithm, oracle/clip_oracle.py) timed on the host
     cores for a bounded sample of the same workload; extrapolated to one ref."""
     from hybridgl_amd import synth, weights
@@ -158,6 +170,18 @@ def cpu_baseline(fusion_mode, n_sample=8, with_sam=True):
     t4 = time.perf_counter()
     scale = 64 / n_sample
     t_ref = (t1 - t0) * scale + (t2 - t1) * scale + (t3 - t2) + (t4 - t3)
+    gem_note = ""
+    if with_gem:
+        from hybridgl_amd.gem import get_gem_img_transform
+        from oracle import gem_oracle as GO
+        timg = get_gem_img_transform()(img).numpy()
+        t5 = time.perf_counter()
+        feat, _ = GO.gem_vit_forward(sd, timg[None])
+        heat = GO.gem_heatmap(feat[0], text[:3], 448)
+        GO.resize_bilinear_aa(heat, H, W)
+        t6 = time.perf_counter()
+        t_ref += (t6 - t5) + (t3 - t2) / 3.0
+        gem_note = f"; GEM heat-maps: 1 image encode at 448 + 3 maps ({t6 - t5:.1f}s; the reference re-encodes per sentence) + 3 prompts"
     sam_note = ""
     if with_sam:
         t_sam, sam_note = cpu_baseline_sam()
@@ -166,7 +190,7 @@ def cpu_baseline(fusion_mode, n_sample=8, with_sam=True):
     return {"value": 1.0 / t_ref, "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"numpy oracle: views+CLIP hybrid {fusion_mode} on {n_sample} of 64 masks "
                       f"({t2 - t0:.1f}s, scaled x{scale:g}), 9 text strings ({t3 - t2:.1f}s), "
-                      f"3-sentence tail on 64 masks ({t4 - t3:.1f}s){sam_note}; numpy BLAS threads = host default"}
+                      f"3-sentence tail on 64 masks ({t4 - t3:.1f}s){gem_note}{sam_note}; numpy BLAS threads = host default"}
 
 
 def main():
@@ -181,6 +205,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="scope B: run the SAM stage and the CLIP stage back to back on one stream instead of "
                          "overlapping ref i's CLIP stage with ref i+1's SAM stage on two streams")
+    ap.add_argument("--heatmap", default="device", choices=["device", "given"],
+                    help="device: the GEM heat-map stage (ViT-B/16 at 448x448 with self-self attention, 3 prompts) runs "
+                         "inside the step; given: seeded heat-maps are inputs (the stage is then outside the timed work)")
     ap.add_argument("--scope", default="B", choices=["A", "B"],
                     help="A: proposals given (CLIP + scoring only); B: + SAM ViT-H proposal stage (full path)")
     args = ap.parse_args()
@@ -214,11 +241,17 @@ def main():
         gen = SamAutomaticMaskGenerator(sam, points_per_side=8, pred_iou_thresh=-1e30, stability_score_thresh=0.0,
                                         box_nms_thresh=2.0, crop_n_layers=0, crop_n_points_downscale_factor=1,
                                         min_mask_region_area=800)
+    use_gem = args.heatmap == "device"
+    gem_model = None
+    if use_gem:
+        # Hybridgl_main.py:36-38: the same OpenAI ViT-B/16 checkpoint as the CLIP stage -> shared device weights
+        from hybridgl_amd.gem import create_gem_model
+        gem_model = create_gem_model("ViT-B/16", clip=model)
     # the CLIP stage scores the 64 seeded proposals (fixed N, meaningful shapes)
     pipe = HybridGLPipeline(model, fusion_mode=args.fusion, masking_block=9, mask_generator=gen, use_sam_masks=False,
-                            fixed_proposals=None, cleanup_given_masks=gen is not None)
+                            fixed_proposals=None, cleanup_given_masks=gen is not None, gem_model=gem_model)
     # rank r owns refs i = r (mod world) of the shuffle=False order
-    refs = [synthetic_ref(rank + world * j, dev, N=args.masks, sam_img_size=1024 if gen else 0)[0]
+    refs = [synthetic_ref(rank + world * j, dev, N=args.masks, sam_img_size=1024 if gen else 0, gem=use_gem)[0]
             for j in range(args.pool)]
 
     def barrier():
@@ -308,7 +341,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if precision == "f32" else "f32 via fp16x3 split MFMA (fp32 accumulate)",
-            "data": "synthetic (seeded images/masks/tokens/heat-maps; seeded random weights)",
+            "data": ("synthetic (seeded images/masks/tokens; seeded random weights)" if use_gem else
+                     "synthetic (seeded images/masks/tokens/heat-maps; seeded random weights)"),
             "config": {
                 "workload": (f"RefCOCO-shaped ref (BASELINE configs[1]): 640x640 image, 3 queries x (sentence+noun "
                              f"phrase+1 other noun); "
@@ -318,20 +352,25 @@ def main():
                                 "seeded proposal-shaped masks; the Pillow-exact resize to 1024 runs on the device inside "
                                 "the step) + " if args.scope == "B" else "proposals given (scope A) + ")
                              + f"view synthesis + CLIP ViT-B/16 hybrid {args.fusion} (masking_block 9) on "
-                             f"{args.masks} seeded proposals + text encoder (9 strings) + scoring tail + IoU"),
+                             f"{args.masks} seeded proposals + text encoder ({12 if use_gem else 9} strings) + "
+                             + ("GEM heat-map stage (ViT-B/16 at 448x448, self-self attention in the last 6 blocks, once "
+                                "per image; 3 prompts -> 3 maps, antialiased resize to the image) + " if use_gem else
+                                "heat-maps given + ")
+                             + "scoring tail + IoU"),
                 "scope": args.scope,
+                "heatmap": args.heatmap,
                 "stage_overlap": bool(overlap),
                 "fusion_mode": args.fusion, "proposals": args.masks, "image": "640x640", "queries": 3,
                 "parallelism": f"image-parallel x{world}",
             },
             "roofline": roofline(precision, nprof, (g_n, g_ms, g_fl), (x_n, x_ms, x_fl), (a_n, a_ms, a_fl), traffic,
-                                 algorithmic_flops_per_ref(args.masks, sam=args.scope == "B") / (dt / args.steps) / 1e12,
+                                 algorithmic_flops_per_ref(args.masks, sam=args.scope == "B", gem=use_gem) / (dt / args.steps) / 1e12,
                                  xg=(xg_n, xg_ms, xg_fl)),
             "precision": precision,
             "metrics": m,
         }
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(args.fusion, with_sam=args.scope == "B")
+            rec["cpu_baseline"] = cpu_baseline(args.fusion, with_sam=args.scope == "B", with_gem=use_gem)
         print(json.dumps(rec))
     if world > 1:
         dist.destroy_process_group()

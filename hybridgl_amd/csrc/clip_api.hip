@@ -10,17 +10,11 @@
 #include "hgl_common.h"
 #include <math.h>
 
-namespace {
-
-struct BlockBufs {
-  float* H;    // [M, D]   LN output / attention output
-  float* QKV;  // [M, 3D]
-  float* F;    // [M, 4D]
-};
+typedef HglBlockBufs BlockBufs;
 
 // x <- x + attn(ln_1 x) ; x <- x + mlp(ln_2 x)      (clip/model.py:244-257)
-int run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, const BlockBufs& bf,
-              int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st) {
+int hgl_clip_run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, const HglBlockBufs& bf,
+                       int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st) {
   const int M = B * S;
   const int hd = D / heads;
   const long long sQKV = (long long)S * 3 * D;
@@ -66,6 +60,26 @@ int run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, c
   return HGL_OK;
 }
 
+// patch embedding + cls + pos + ln_pre for `n_img` images -> X [n_img, S, D]; cols holds the im2col matrix
+// (n_img*P*3p^2 floats), tok the patch tokens (n_img*P*D floats)
+int hgl_clip_embed_images(const HglClipVisionW* w, const float* imgs, int n_img, float* X, float* cols, float* tok,
+                          hipStream_t st) {
+  const int D = w->width, g = w->grid, P = g * g, S = P + 1, kd = 3 * w->patch * w->patch;
+  HGL_TRY(hgl_launch_im2col_patch(imgs, n_img, g * w->patch, w->patch, cols, st));
+  HGL_TRY(hgl_launch_gemm(cols, w->conv1_w, nullptr, nullptr, tok, n_img * P, D, kd, kd, kd, 0, D, 1,
+                          0, 0, 0, 0, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_assemble_lnpre(tok, w->class_embedding, w->positional_embedding, w->ln_pre_w,
+                                    w->ln_pre_b, X, n_img, S, D, st));
+  return HGL_OK;
+}
+
+namespace {
+
+inline int run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, const BlockBufs& bf,
+                     int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st) {
+  return hgl_clip_run_block(w, X, B, S, D, heads, bf, mask_kind, keep, keep_b0, keep_n, st);
+}
+
 int n_streams(int mode) {
   switch (mode) {
     case HGL_FUSION_G2L:
@@ -99,18 +113,9 @@ bool carve(HglArena& ar, const HglClipVisionW* w, int N, int mode, ClipPlan& p) 
   return ar.ok();
 }
 
-// patch embedding + cls + pos + ln_pre for `n_img` images -> X [n_img, S, D]
 int embed_images(const HglClipVisionW* w, const float* imgs, int n_img, float* X, const ClipPlan& p,
                  hipStream_t st) {
-  const int D = w->width, g = w->grid, P = g * g, S = P + 1, kd = 3 * w->patch * w->patch;
-  float* cols = p.F;
-  float* tok = p.QKV;
-  HGL_TRY(hgl_launch_im2col_patch(imgs, n_img, g * w->patch, w->patch, cols, st));
-  HGL_TRY(hgl_launch_gemm(cols, w->conv1_w, nullptr, nullptr, tok, n_img * P, D, kd, kd, kd, 0, D, 1,
-                          0, 0, 0, 0, HGL_ACT_NONE, st));
-  HGL_TRY(hgl_launch_assemble_lnpre(tok, w->class_embedding, w->positional_embedding, w->ln_pre_w,
-                                    w->ln_pre_b, X, n_img, S, D, st));
-  return HGL_OK;
+  return hgl_clip_embed_images(w, imgs, n_img, X, p.F, p.QKV, st);
 }
 
 // ln_post(x[:,0]) @ proj  (+ R)   (model/backbone.py:254-260)

@@ -97,6 +97,17 @@ int hgl_launch_text_embed(const int32_t* tokens, const float* emb, const float* 
 int hgl_launch_gather_eot(const float* x, const int32_t* eot, int B, int S, int D, float* y,
                           hipStream_t st);
 
+// CLIP transformer pieces shared by clip_api.hip and gem_api.hip
+struct HglBlockBufs {
+  float* H;    // [M, D]   LN output / attention output
+  float* QKV;  // [M, 3D]
+  float* F;    // [M, 4D]
+};
+int hgl_clip_run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, const HglBlockBufs& bf,
+                       int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st);
+int hgl_clip_embed_images(const HglClipVisionW* w, const float* imgs, int n_img, float* X, float* cols, float* tok,
+                          hipStream_t st);
+
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench roofline) ----
 enum HglProfClass { HGL_PROF_GEMM = 0, HGL_PROF_ATTN = 1, HGL_PROF_OTHER = 2, HGL_PROF_GEMM_X3 = 3, HGL_PROF_GEMM_X3G = 4, HGL_PROF_NCLASS = 5 };
 struct HglProfScope {

@@ -1,13 +1,16 @@
 """Per-ref evaluation step of Hybridgl_main.main (Hybridgl_main.py:79-230) on the GPU.
 
 One `RefBatch` = one dataset item: an image, its mask proposals, its sentences (already
-tokenised; spaCy parse records and the GEM heat-map are inputs -- both are external
-packages in the reference).  `HybridGLPipeline.step` runs, without any host
-synchronisation, the reference's per-ref work:
+tokenised; the spaCy parse records are inputs -- an external package in the reference,
+SURVEY.md 8c).  `HybridGLPipeline.step` runs, without any host synchronisation, the
+reference's per-ref work:
 
     views   Hybridgl_main.py:93-125   hgl_synthesize_views
     hybrid  Hybridgl_main.py:128      hgl_clip_hybrid_forward
     text    Hybridgl_main.py:146-161  hgl_clip_encode_text (all strings of the ref in one batch)
+    heat    Hybridgl_main.py:200-201  hgl_gem_image_features (once per image), hgl_gem_heatmap and
+                                      hgl_resize_bilinear_aa (all sentences in one call) when a gem model is
+                                      given; otherwise Sentence.imgattn is an input
     tail    Hybridgl_main.py:153-230  hgl_coherence_scores, hgl_score_sentence, hgl_iou_select
 
 and accumulates cum_I/cum_U and the per-sentence IoUs on the device (Hybridgl_main.py:52-55,
@@ -33,6 +36,7 @@ class Sentence:
     relaflag: str = "none"         # extract_rela_word  (utils.py:206-238)
     n_nouns: int = 0               # len(nouns) of extract_nouns (Hybridgl_main.py:184)
     imgattn: Optional[torch.Tensor] = None  # [H,W] fp32: gem_model(...) resized to the image (:200-202)
+    gem_row: Optional[int] = None  # token row of "a photo of a {noun_phrase}." (the GEM prompt) when the heat-map is computed here
     target: Optional[torch.Tensor] = None   # [H,W] per-phrase ground truth (Hybridgl_main_PhraseCut.py:117-119); else RefBatch.target
 
 
@@ -48,6 +52,7 @@ class RefBatch:
     sentences: List[Sentence] = field(default_factory=list)
     sam_resized: Optional[torch.Tensor] = None  # [h,w,3] uint8: sam_img after ResizeLongestSide (PIL, host)
     image_id: Optional[int] = None  # COCO image id: consecutive refs of one image reuse proposals + hybrid features
+    tensor_img: Optional[torch.Tensor] = None   # [3,448,448] fp32: image['tensor_img'] = gem.get_gem_img_transform()(img)
 
 
 class EmptyProposals(RuntimeError):
@@ -70,12 +75,14 @@ def black_for(relaflag):
 
 class HybridGLPipeline:
     def __init__(self, model, fusion_mode="G2L", masking_block=9, r=0.5, alpha=0.6, k1=3, k2=6, res=224,
-                 mask_generator=None, use_sam_masks=False, fixed_proposals=None, cleanup_given_masks=False):
+                 mask_generator=None, use_sam_masks=False, fixed_proposals=None, cleanup_given_masks=False,
+                 gem_model=None):
         """mask_generator: a hybridgl_amd.sam.SamAutomaticMaskGenerator; when given, every step runs the
         SAM proposal stage (encoder, decoder, post-processing, NMS) on ref.sam_img first.
         use_sam_masks=False keeps ref.masks for the CLIP stage (fixed N; synthetic benchmark, where
         random SAM weights give an arbitrary number of proposals); True feeds the SAM proposals."""
         self.model = model
+        self.gem_model = gem_model              # hybridgl_amd.gem.GEMWrapper: heat-maps computed on the device
         self.mask_generator = mask_generator
         self.use_sam_masks = use_sam_masks
         self.fixed_proposals = fixed_proposals
@@ -134,8 +141,26 @@ class HybridGLPipeline:
         ev_in, ev_text = torch.cuda.Event(), torch.cuda.Event()
         ev_in.record(cur)
         self._s_text.wait_event(ev_in)
+        heat = None
         with torch.cuda.stream(self._s_text):
             text = m.model.encode_text(ref.tokens)
+            gem_rows = [s.gem_row for s in ref.sentences if s.imgattn is None]
+            if gem_rows:
+                # Hybridgl_main.py:200-201: gem_model(tensor_img, [noun_phrase])[0] -> T.Resize((h, w), antialias=True).
+                # The image tower depends on the image only (the reference re-runs it for every sentence); the
+                # prompts' text features come out of the same text-encoder batch.
+                from . import gem as G
+                if self.gem_model is None or ref.tensor_img is None or any(r is None for r in gem_rows):
+                    raise ValueError("a sentence without imgattn needs gem_model, RefBatch.tensor_img and Sentence.gem_row")
+                if ref.image_id is not None and getattr(self, "_gem_cache_id", None) == ref.image_id:
+                    gfeat = self._gem_cache_feat
+                else:
+                    gfeat = self.gem_model.image_features(ref.tensor_img)
+                    if ref.image_id is not None:
+                        self._gem_cache_id, self._gem_cache_feat = ref.image_id, gfeat
+                maps = self.gem_model.heatmap(gfeat, _rows(text, gem_rows), ref.tensor_img.shape[-1])
+                heat = G.resize_antialias(maps, ref.sam_img.shape[:2])
+                heat.record_stream(cur)
             ev_text.record(self._s_text)
         text.record_stream(cur)
         # Per-image caching: the dataset yields one item per REF and the same image backs
@@ -175,8 +200,13 @@ class HybridGLPipeline:
         self.k1 = min(self.k1, hybrid.shape[0])
         self.k2 = min(self.k2, hybrid.shape[0])
         last = None
+        n_heat = 0
         for s in ref.sentences:
-            gem = ops.coherence_scores(s.imgattn, ref.masks, s.dirflag, black_for(s.relaflag))
+            imgattn = s.imgattn
+            if imgattn is None:
+                imgattn = heat[n_heat]
+                n_heat += 1
+            gem = ops.coherence_scores(imgattn, ref.masks, s.dirflag, black_for(s.relaflag))
             others = _rows(text, s.other_noun_rows)
             idx, sc, sn = ops.score_sentence(hybrid, text[s.sentence_row], text[s.noun_phrase_row], others,
                                              ref.boxes, gem, m.model._logit_scale_exp, self.r, self.k1,
@@ -205,15 +235,22 @@ class HybridGLPipeline:
         }
 
 
-def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=49408, sam_img_size=0):
+def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=49408, sam_img_size=0, gem=False, gem_size=448):
     """The benchmark item of SURVEY.md 8d: 640x640 image, 64 proposals, 3 queries, each with a
-    sentence, a noun phrase and one other noun (9 token rows).  Returns (RefBatch, numpy dict)."""
+    sentence, a noun phrase and one other noun (9 token rows).  Returns (RefBatch, numpy dict).
+    gem=True: the heat-map is NOT an input; the ref carries tensor_img [3,gem_size,gem_size] and one more token
+    row per sentence (the GEM prompt), and the pipeline computes the heat-maps on the device."""
     img = synth.synth_image(H, W, 1000 + i)
     blur = synth.box_blur_u8(img)
     norm = synth.imagenet_normalize(img)
     masks = synth.synth_masks(N, H, W, 2000 + i)
     boxes = synth.boxes_from_masks(masks)
     tokens = synth.synth_tokens(3 * n_sent, context, vocab, 3000 + i)
+    tensor_img = None
+    if gem:
+        from .gem import get_gem_img_transform
+        tokens = np.concatenate([tokens, synth.synth_tokens(n_sent, context, vocab, 5000 + i)], axis=0)
+        tensor_img = get_gem_img_transform(gem_size)(img).numpy()
     gt = masks[(7 * i) % N]
     sents, attn_np = [], []
     for j in range(n_sent):
@@ -221,9 +258,11 @@ def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=494
         attn = synth.synth_heatmap(H, W, 4000 + 10 * i + j)
         attn_np.append(attn)
         sents.append(Sentence(3 * j, 3 * j + 1, [3 * j + 2], dirflag, relaflag, n_nouns,
-                              torch.from_numpy(attn).to(device)))
+                              None if gem else torch.from_numpy(attn).to(device), 3 * n_sent + j if gem else None))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     resized = None   # ResizeLongestSide runs on the device (hgl_resize_pil_bilinear), inside the step
-    ref = RefBatch(t(img), t(blur), t(norm), t(masks), t(boxes), t(tokens), t(gt), sents, resized)
-    host = dict(img=img, blur=blur, norm=norm, masks=masks, boxes=boxes, tokens=tokens, gt=gt, attn=attn_np)
+    ref = RefBatch(t(img), t(blur), t(norm), t(masks), t(boxes), t(tokens), t(gt), sents, resized,
+                   tensor_img=t(tensor_img) if gem else None)
+    host = dict(img=img, blur=blur, norm=norm, masks=masks, boxes=boxes, tokens=tokens, gt=gt, attn=attn_np,
+                tensor_img=tensor_img)
     return ref, host

@@ -176,6 +176,35 @@ size_t hgl_clip_text_workspace_bytes(const HglClipTextW* w, int B);
 int hgl_clip_encode_text(const HglClipTextW* w, const int32_t* tokens, int B, float* out,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Text-conditioned heat-map: the GEM call of Hybridgl_main.py:36-39,200-201
+ * (`gem.create_gem_model('ViT-B/16','openai')`, `gem_model(tensor_img, [noun_phrase])`).
+ * gem_torch 1.0.1 is an external package (environment.yaml:206): the published
+ * algorithm is restated, parity unpinned (oracle/gem_oracle.py).
+ * --------------------------------------------------------------------- */
+
+/* GEMViT.forward on ONE image.  w: the CLIP vision tower with grid = res/patch and
+ * positional_embedding already interpolated to that grid ([grid*grid+1, width]).
+ * img [3,res,res] fp32 (gem.get_gem_img_transform output).  The last gem_blocks
+ * blocks are GEM blocks (gem_depth - 1 = 6 by default); ss_attn_iter self-self
+ * iterations (1); ss_attn_temp <= 0 selects the adaptive temperature.
+ * feat_gem [grid*grid+1, embed] = proj(ln_post(gem stream)), row 0 = CLS;
+ * feat_ori (may be NULL) = the same for the original stream (return_ori=True). */
+size_t hgl_gem_workspace_bytes(const HglClipVisionW* w);
+int hgl_gem_image_features(const HglClipVisionW* w, const float* img, int gem_blocks, int ss_attn_iter,
+                           float ss_attn_temp, float* feat_gem, float* feat_ori,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* GEMWrapper.forward after the encoders: heat[t] = minmax(bilinear_up(100*cos(feat[1:], text[t])))
+ * feat [grid*grid+1,E]; text [T,E] (normalised or not); heat [T,res,res]; normalize=0 skips min-max. */
+size_t hgl_gem_heatmap_workspace_bytes(int grid, int T, int res);
+int hgl_gem_heatmap(const float* feat, int grid, int E, const float* text, int T, int res, int normalize,
+                    float* heat, void* workspace, size_t workspace_bytes, void* stream);
+
+/* T.Resize((H,W), antialias=True) on a float tensor (Hybridgl_main.py:201):
+ * F.interpolate(bilinear, antialias=True, align_corners=False); in [C,h,w] -> out [C,H,W]. */
+int hgl_resize_bilinear_aa(const float* in, int C, int h, int w, float* out, int H, int W, void* stream);
+
 /* TF.resize(pred_masks.float(), (g,g)) bilinear, align_corners=False, no
  * antialias (model/backbone.py:160): masks [N,Hm,Wm] uint8 -> pm [N,g*g] f32. */
 int hgl_mask_resize(const uint8_t* masks, int N, int Hm, int Wm, int g, float* pm, void* stream);
