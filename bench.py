@@ -147,11 +147,13 @@ def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False):
     sd = weights.clip_state_dict("ViT-B/16", 0)
     H = W = 640
     img = synth.synth_image(H, W, 1000)
-    blur = synth.box_blur_u8(img)
+    from oracle import cv_oracle as CV
     norm = synth.imagenet_normalize(img)
     masks = synth.synth_masks(64, H, W, 2000)
     boxes = synth.boxes_from_masks(masks)
     tokens = synth.synth_tokens(9, 77, 49408, 3000)
+    tb = time.perf_counter()
+    blur = CV.gaussian_blur_u8(img, 15)
     t0 = time.perf_counter()
     loc, glo = O.synthesize_views(img, blur, norm, masks[:n_sample], 224)
     t1 = time.perf_counter()
@@ -169,7 +171,7 @@ def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False):
         O.compute_iou(masks[ip], masks[0]); O.compute_iou(masks[ifin], masks[0])
     t4 = time.perf_counter()
     scale = 64 / n_sample
-    t_ref = (t1 - t0) * scale + (t2 - t1) * scale + (t3 - t2) + (t4 - t3)
+    t_ref = (t0 - tb) + (t1 - t0) * scale + (t2 - t1) * scale + (t3 - t2) + (t4 - t3)
     gem_note = ""
     if with_gem:
         from hybridgl_amd.gem import get_gem_img_transform
@@ -208,6 +210,8 @@ def main():
     ap.add_argument("--heatmap", default="device", choices=["device", "given"],
                     help="device: the GEM heat-map stage (ViT-B/16 at 448x448 with self-self attention, 3 prompts) runs "
                          "inside the step; given: seeded heat-maps are inputs (the stage is then outside the timed work)")
+    ap.add_argument("--blur", default="device", choices=["device", "given"],
+                    help="device: cv2.GaussianBlur's fixed-point filter runs inside the step; given: the blurred image is an input")
     ap.add_argument("--scope", default="B", choices=["A", "B"],
                     help="A: proposals given (CLIP + scoring only); B: + SAM ViT-H proposal stage (full path)")
     args = ap.parse_args()
@@ -251,7 +255,8 @@ def main():
     pipe = HybridGLPipeline(model, fusion_mode=args.fusion, masking_block=9, mask_generator=gen, use_sam_masks=False,
                             fixed_proposals=None, cleanup_given_masks=gen is not None, gem_model=gem_model)
     # rank r owns refs i = r (mod world) of the shuffle=False order
-    refs = [synthetic_ref(rank + world * j, dev, N=args.masks, sam_img_size=1024 if gen else 0, gem=use_gem)[0]
+    refs = [synthetic_ref(rank + world * j, dev, N=args.masks, sam_img_size=1024 if gen else 0, gem=use_gem,
+                          device_blur=args.blur == "device")[0]
             for j in range(args.pool)]
 
     def barrier():
@@ -351,7 +356,7 @@ def main():
                                 "discarded; connected-component clean-up (min area 800) + second NMS run on the 64 "
                                 "seeded proposal-shaped masks; the Pillow-exact resize to 1024 runs on the device inside "
                                 "the step) + " if args.scope == "B" else "proposals given (scope A) + ")
-                             + f"view synthesis + CLIP ViT-B/16 hybrid {args.fusion} (masking_block 9) on "
+                             + ("15x15 Gaussian blur (cv2 fixed-point) + " if args.blur == "device" else "") + f"view synthesis + CLIP ViT-B/16 hybrid {args.fusion} (masking_block 9) on "
                              f"{args.masks} seeded proposals + text encoder ({12 if use_gem else 9} strings) + "
                              + ("GEM heat-map stage (ViT-B/16 at 448x448, self-self attention in the last 6 blocks, once "
                                 "per image; 3 prompts -> 3 maps, antialiased resize to the image) + " if use_gem else

@@ -150,6 +150,8 @@ PROTOTYPES = {
     "hgl_relation_boxes": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
     "hgl_gaussian_blur_u8_workspace_bytes": (_SZ, [_I, _I, _I]),
     "hgl_gaussian_blur_u8": (_I, [_VP, _I, _I, _I, C.POINTER(C.c_double), _I, _VP, _VP, _SZ, _VP]),
+    "hgl_cv_gaussian_kernel_q8": (_I, [_I, C.c_double, C.POINTER(C.c_uint16)]),
+    "hgl_gaussian_blur_u8_q8": (_I, [_VP, _I, _I, _I, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), _I, _VP, _VP, _SZ, _VP]),
     "hgl_gt_mask_from_polygons": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP]),
     "hgl_gt_mask_from_rle_counts": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "hgl_gt_mask_from_rle_string": (_I, [C.c_char_p, _I, _I, _VP, _VP]),

@@ -9,28 +9,48 @@
 // final-block output is never consumed (SURVEY.md section 3.3 "dead work") are not computed.
 #include "hgl_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 typedef HglBlockBufs BlockBufs;
 
-// x <- x + attn(ln_1 x) ; x <- x + mlp(ln_2 x)      (clip/model.py:244-257)
-int hgl_clip_run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, const HglBlockBufs& bf,
-                       int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st) {
+// The split-fp16 matrix-core path of a block: every GEMM operand activation exists only as fp16 (hi, lo) halves.
+// Rows <= 512 (tiny batches) go through hgl_launch_gemm instead, which hands GEMMs with a registered weight to the
+// small-tile f16x3 kernel.  Between 512 and ~1500 rows the large tilings are latency-bound when run alone (a 128x128
+// tile per CU), but they cost a third of the small-tile kernel's CU-time, which is what matters for work that runs
+// on a side stream underneath the SAM / CLIP kernels (text encoder: 12 x 77 rows, GEM: 785 rows): measured
+// 49.05 -> 47.8 ms per benchmark step.
+bool hgl_clip_block_uses_x3(const HglResBlockW& w, int M, int D) {
+  static const int min_m = getenv("HGL_X3_MIN_M") ? atoi(getenv("HGL_X3_MIN_M")) : 512;
+  return M > min_m && hgl_use_x3(w.in_proj_w, D) && hgl_use_x3(w.out_proj_w, D) && hgl_use_x3(w.fc_w, D) &&
+         hgl_use_x3(w.proj_w, 4 * D) && (D % 256) == 0;
+}
+
+// first half of a block: H = ln_1(X) (fp32, or the fp16 hi+lo pair aliasing bf.H on the split path), QKV = H W_in + b
+int hgl_clip_block_qkv(const HglResBlockW& w, const float* X, int M, int D, const HglBlockBufs& bf, hipStream_t st) {
+  if (hgl_clip_block_uses_x3(w, M, D)) {
+    uint16_t* Hh = (uint16_t*)bf.H;
+    uint16_t* Hl = Hh + (size_t)M * D;
+    HGL_TRY(hgl_launch_layernorm_split(X, w.ln1_w, w.ln1_b, Hh, Hl, M, D, 1e-5f, st));
+    return hgl_launch_gemm_f16x3(Hh, Hl, D, w.in_proj_w, w.in_proj_b, nullptr, 0, bf.QKV, nullptr, nullptr, 3 * D, M, 3 * D, D,
+                                 HGL_ACT_NONE, st);
+  }
+  HGL_TRY(hgl_launch_layernorm(X, w.ln1_w, w.ln1_b, bf.H, M, D, 1e-5f, st));
+  return hgl_launch_gemm(bf.H, w.in_proj_w, w.in_proj_b, nullptr, bf.QKV, M, 3 * D, D, D, D, 0, 3 * D, 1, 0, 0, 0, 0,
+                         HGL_ACT_NONE, st);
+}
+
+// second half: x <- x + out_proj(attention(QKV)) ; x <- x + mlp(ln_2 x)
+int hgl_clip_block_rest(const HglResBlockW& w, float* X, int B, int S, int D, int heads, const HglBlockBufs& bf,
+                        int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st) {
   const int M = B * S;
   const int hd = D / heads;
   const long long sQKV = (long long)S * 3 * D;
-  // (M <= 1024 -- the text encoder, tiny batches -- goes through hgl_launch_gemm below, which hands GEMMs with a
-  // registered weight to the small-tile f16x3 kernel: a handful of 128x128 tiles would be latency-bound)
-  if (M > 1024 && hgl_use_x3(w.in_proj_w, D) && hgl_use_x3(w.out_proj_w, D) && hgl_use_x3(w.fc_w, D) &&
-      hgl_use_x3(w.proj_w, 4 * D) && (D % 256) == 0) {
-    // split-fp16 matrix-core path: activations feeding a GEMM exist only as fp16 (hi, lo) halves,
-    // which alias the fp32 scratch buffers (same byte size).
+  if (hgl_clip_block_uses_x3(w, M, D)) {
+    // activations feeding a GEMM alias the fp32 scratch buffers (same byte size)
     uint16_t* Hh = (uint16_t*)bf.H;
     uint16_t* Hl = Hh + (size_t)M * D;
     uint16_t* Fh = (uint16_t*)bf.F;
     uint16_t* Fl = Fh + (size_t)M * 4 * D;
-    HGL_TRY(hgl_launch_layernorm_split(X, w.ln1_w, w.ln1_b, Hh, Hl, M, D, 1e-5f, st));
-    HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, w.in_proj_w, w.in_proj_b, nullptr, 0, bf.QKV, nullptr, nullptr, 3 * D, M,
-                                  3 * D, D, HGL_ACT_NONE, st));
     // the attention writes its output as the fp16 hi+lo pair the out-projection reads
     HGL_TRY(hgl_launch_attention_split(bf.QKV, bf.QKV + D, bf.QKV + 2 * D, nullptr, Hh, Hl, B, heads, S, S, hd, 3 * D, 3 * D,
                                        3 * D, D, sQKV, sQKV, sQKV, (long long)S * D, 1.0f / sqrtf((float)hd), mask_kind, keep,
@@ -44,9 +64,6 @@ int hgl_clip_run_block(const HglResBlockW& w, float* X, int B, int S, int D, int
                                   HGL_ACT_NONE, st));
     return HGL_OK;
   }
-  HGL_TRY(hgl_launch_layernorm(X, w.ln1_w, w.ln1_b, bf.H, M, D, 1e-5f, st));
-  HGL_TRY(hgl_launch_gemm(bf.H, w.in_proj_w, w.in_proj_b, nullptr, bf.QKV, M, 3 * D, D, D, D, 0,
-                          3 * D, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
   HGL_TRY(hgl_launch_attention(bf.QKV, bf.QKV + D, bf.QKV + 2 * D, bf.H, B, heads, S, S, hd, 3 * D,
                                3 * D, 3 * D, D, sQKV, sQKV, sQKV, (long long)S * D, 1.0f / sqrtf((float)hd),
                                mask_kind, keep, keep_b0, keep_n, nullptr, nullptr, 0, 0, st));
@@ -58,6 +75,13 @@ int hgl_clip_run_block(const HglResBlockW& w, float* X, int B, int S, int D, int
   HGL_TRY(hgl_launch_gemm(bf.F, w.proj_w, w.proj_b, X, X, M, D, 4 * D, 4 * D, 4 * D, D, D, 1, 0, 0,
                           0, 0, HGL_ACT_NONE, st));
   return HGL_OK;
+}
+
+// x <- x + attn(ln_1 x) ; x <- x + mlp(ln_2 x)      (clip/model.py:244-257)
+int hgl_clip_run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, const HglBlockBufs& bf,
+                       int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st) {
+  HGL_TRY(hgl_clip_block_qkv(w, X, B * S, D, bf, st));
+  return hgl_clip_block_rest(w, X, B, S, D, heads, bf, mask_kind, keep, keep_b0, keep_n, st);
 }
 
 // patch embedding + cls + pos + ln_pre for `n_img` images -> X [n_img, S, D]; cols holds the im2col matrix

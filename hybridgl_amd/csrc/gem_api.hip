@@ -34,6 +34,23 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__
   if (lane == 0) norms[row] = sqrtf(s);
 }
 
+// the same from the fp16 (hi, lo) pair of the split path: x = hi + lo
+__global__ __launch_bounds__(256) void row_norm_split_kernel(const _Float16* __restrict__ Hh, const _Float16* __restrict__ Hl, int S,
+                                                             int D, float* __restrict__ norms) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= S) return;
+  const _Float16* h = Hh + (long long)row * D;
+  const _Float16* l = Hl + (long long)row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) {
+    const float x = (float)h[i] + (float)l[i];
+    s += x * x;
+  }
+  s = wave_sum(s);
+  if (lane == 0) norms[row] = sqrtf(s);
+}
+
 // t = mean(norms) * scale  (fixed order: one work-group, strided partials, tree in LDS)
 __global__ __launch_bounds__(256) void temp_kernel(const float* __restrict__ norms, int S, float scale, float* __restrict__ t) {
   __shared__ float part[256];
@@ -84,6 +101,19 @@ __global__ __launch_bounds__(256) void normalize_heads_kernel(const float* __res
 __global__ __launch_bounds__(256) void mean3_kernel(const float* __restrict__ a, long long stride, long long n, float* __restrict__ out) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = (a[i] + a[i + stride] + a[i + 2 * stride]) / 3.0f;
+}
+
+// the same, written as the fp16 (hi, lo) pair the split out-projection reads
+__global__ __launch_bounds__(256) void mean3_split_kernel(const float* __restrict__ a, long long stride, long long n,
+                                                          _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float m = (a[i] + a[i + stride] + a[i + 2 * stride]) / 3.0f;
+    _Float16 h, l;
+    hgl_split_hi_lo(m, h, l);
+    hi[i] = h;
+    lo[i] = l;
+  }
 }
 
 // logits[t, p] = 100 * <f_p / |f_p|, x_t / |x_t|>; feat rows 1..P (row 0 = CLS). One wave per (p, t).
@@ -249,13 +279,17 @@ int gem_block(const HglResBlockW& w, const GemPlan& p, int S, int D, int heads, 
   const int hd = D / heads;
   const float scale = 1.0f / sqrtf((float)hd);
   const long long SD = (long long)S * D;
-  HGL_TRY(hgl_launch_layernorm(p.X, w.ln1_w, w.ln1_b, p.H, S, D, 1e-5f, st));
-  HGL_TRY(hgl_launch_gemm(p.H, w.in_proj_w, w.in_proj_b, nullptr, p.QKV, S, 3 * D, D, D, D, 0, 3 * D, 1, 0, 0, 0, 0,
-                          HGL_ACT_NONE, st));
+  const HglBlockBufs bf{p.H, p.QKV, p.F};
+  const bool x3 = hgl_clip_block_uses_x3(w, S, D);
+  HGL_TRY(hgl_clip_block_qkv(w, p.X, S, D, bf, st));          // p.H = ln_1(x) (fp32 or the hi+lo pair), p.QKV
   if (ss_temp > 0.f) {
     hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, p.t, ss_temp);
   } else {
-    hipLaunchKernelGGL(row_norm_kernel, dim3((S + 3) / 4), dim3(256), 0, st, p.H, S, D, p.norms);
+    if (x3)
+      hipLaunchKernelGGL(row_norm_split_kernel, dim3((S + 3) / 4), dim3(256), 0, st, (const _Float16*)p.H,
+                         (const _Float16*)p.H + SD, S, D, p.norms);
+    else
+      hipLaunchKernelGGL(row_norm_kernel, dim3((S + 3) / 4), dim3(256), 0, st, p.H, S, D, p.norms);
     hipLaunchKernelGGL(temp_kernel, dim3(1), dim3(256), 0, st, p.norms, S, scale, p.t);
   }
   HGL_TRY(hgl_check_launch("gem_temperature"));
@@ -270,19 +304,21 @@ int gem_block(const HglResBlockW& w, const GemPlan& p, int S, int D, int heads, 
   // assignment to v: the value operand is the block's v for all three sets (batch stride 0)
   HGL_TRY(hgl_launch_attention(p.N3s, p.N3, V, p.X1, 3, heads, S, S, hd, D, D, 3 * D, D, SD, SD, 0, SD, 1.0f, HGL_MASK_NONE,
                                nullptr, 0, 0, nullptr, nullptr, 0, 0, st));
-  hipLaunchKernelGGL(mean3_kernel, dim3((unsigned)((SD + 255) / 256)), dim3(256), 0, st, p.X1, SD, SD, p.N3);
-  HGL_TRY(hgl_check_launch("gem_mean3"));
-  HGL_TRY(hgl_launch_gemm(p.N3, w.out_proj_w, w.out_proj_b, p.Xg, p.Xg, S, D, D, D, D, D, D, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
+  if (x3) {
+    _Float16* Mh = (_Float16*)p.N3;
+    _Float16* Ml = Mh + SD;
+    hipLaunchKernelGGL(mean3_split_kernel, dim3((unsigned)((SD + 255) / 256)), dim3(256), 0, st, p.X1, SD, SD, Mh, Ml);
+    HGL_TRY(hgl_check_launch("gem_mean3"));
+    HGL_TRY(hgl_launch_gemm_f16x3(Mh, Ml, D, w.out_proj_w, w.out_proj_b, p.Xg, D, p.Xg, nullptr, nullptr, D, S, D, D,
+                                  HGL_ACT_NONE, st));
+  } else {
+    hipLaunchKernelGGL(mean3_kernel, dim3((unsigned)((SD + 255) / 256)), dim3(256), 0, st, p.X1, SD, SD, p.N3);
+    HGL_TRY(hgl_check_launch("gem_mean3"));
+    HGL_TRY(hgl_launch_gemm(p.N3, w.out_proj_w, w.out_proj_b, p.Xg, p.Xg, S, D, D, D, D, D, D, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
+  }
   if (!need_ori) return HGL_OK;
-  // original stream (clip/model.py:244-257), re-using QKV
-  const long long sQKV = (long long)S * 3 * D;
-  HGL_TRY(hgl_launch_attention(p.QKV, p.QKV + D, V, p.H, 1, heads, S, S, hd, 3 * D, 3 * D, 3 * D, D, sQKV, sQKV, sQKV, SD, scale,
-                               HGL_MASK_NONE, nullptr, 0, 0, nullptr, nullptr, 0, 0, st));
-  HGL_TRY(hgl_launch_gemm(p.H, w.out_proj_w, w.out_proj_b, p.X, p.X, S, D, D, D, D, D, D, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
-  HGL_TRY(hgl_launch_layernorm(p.X, w.ln2_w, w.ln2_b, p.H, S, D, 1e-5f, st));
-  HGL_TRY(hgl_launch_gemm(p.H, w.fc_w, w.fc_b, nullptr, p.F, S, 4 * D, D, D, D, 0, 4 * D, 1, 0, 0, 0, 0, HGL_ACT_QUICKGELU, st));
-  HGL_TRY(hgl_launch_gemm(p.F, w.proj_w, w.proj_b, p.X, p.X, S, D, 4 * D, 4 * D, 4 * D, D, D, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
-  return HGL_OK;
+  // original stream (clip/model.py:244-257): the plain block on the same QKV
+  return hgl_clip_block_rest(w, p.X, 1, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st);
 }
 
 bool valid_vision(const HglClipVisionW* w) {

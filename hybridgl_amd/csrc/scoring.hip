@@ -567,6 +567,40 @@ __global__ __launch_bounds__(256) void blur_h_kernel(const double* __restrict__ 
   out[i] = (uint8_t)v;
 }
 
+// ---- cv2.GaussianBlur on uint8 (OpenCV 4.x bit-exact path, smooth.simd.hpp fixedSmoothInvoker): both passes in
+// integer arithmetic with 8.8 fixed-point taps that sum to 256 -- the row pass gives sum(src * kx) <= 255 * 256 in 16
+// bits, the column pass sum(ky * row) in 32 bits, rounded once: (v + 2^15) >> 16.  Reflect-101 borders.
+struct BlurTapsQ8 { uint16_t x[31], y[31]; int k; };
+
+__global__ __launch_bounds__(256) void blur_q8_h_kernel(const uint8_t* __restrict__ img, int H, int W, int C, BlurTapsQ8 t,
+                                                        uint16_t* __restrict__ tmp) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  const long long total = (long long)H * W * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int x = (int)((i / C) % W);
+  const long long y = i / ((long long)W * C);
+  const int r = t.k / 2;
+  unsigned a = 0;
+  for (int j = 0; j < t.k; ++j) a += (unsigned)t.x[j] * img[(y * W + reflect101(x + j - r, W)) * C + c];
+  tmp[i] = (uint16_t)a;
+}
+
+__global__ __launch_bounds__(256) void blur_q8_v_kernel(const uint16_t* __restrict__ tmp, int H, int W, int C, BlurTapsQ8 t,
+                                                        uint8_t* __restrict__ out) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  const long long total = (long long)H * W * C;
+  if (i >= total) return;
+  const long long wc = (long long)W * C;
+  const int y = (int)(i / wc);
+  const long long rest = i - (long long)y * wc;
+  const int r = t.k / 2;
+  unsigned a = 0;
+  for (int j = 0; j < t.k; ++j) a += (unsigned)t.y[j] * tmp[(long long)reflect101(y + j - r, H) * wc + rest];
+  const unsigned v = (a + 32768u) >> 16;
+  out[i] = (uint8_t)(v > 255u ? 255u : v);
+}
+
 }  // namespace
 
 extern "C" {
@@ -713,6 +747,33 @@ int hgl_gaussian_blur_u8(const uint8_t* img, int H, int W, int C, const double* 
   hipLaunchKernelGGL(blur_v_kernel, dim3(blocks), dim3(256), 0, st, img, H, W, C, t, (double*)workspace);
   hipLaunchKernelGGL(blur_h_kernel, dim3(blocks), dim3(256), 0, st, (const double*)workspace, H, W, C, t, out);
   return hgl_check_launch("gaussian_blur_u8");
+}
+
+int hgl_gaussian_blur_u8_q8(const uint8_t* img, int H, int W, int C, const uint16_t* taps_x, const uint16_t* taps_y, int k,
+                            uint8_t* out, void* workspace, size_t workspace_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(img && out && taps_x && taps_y && H > 0 && W > 0 && C > 0, "gaussian_blur_u8_q8: bad arguments");
+  HGL_REQUIRE(k >= 1 && k <= 31 && (k & 1) && k / 2 < H && k / 2 < W, "gaussian_blur_u8_q8: kernel size %d unsupported for %dx%d", k, H, W);
+  if (!workspace || workspace_bytes < (size_t)H * W * C * sizeof(uint16_t)) {
+    hgl_set_error("gaussian_blur_u8_q8: workspace too small");
+    return HGL_EWORKSPACE;
+  }
+  BlurTapsQ8 t;
+  t.k = k;
+  unsigned sx = 0, sy = 0;
+  for (int i = 0; i < 31; ++i) {
+    t.x[i] = i < k ? taps_x[i] : 0;
+    t.y[i] = i < k ? taps_y[i] : 0;
+    sx += t.x[i];
+    sy += t.y[i];
+  }
+  HGL_REQUIRE(sx == 256 && sy == 256, "gaussian_blur_u8_q8: the 8.8 fixed-point taps must sum to 256 (got %u, %u)", sx, sy);
+  const long long total = (long long)H * W * C;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(blur_q8_h_kernel, dim3(blocks), dim3(256), 0, st, img, H, W, C, t, (uint16_t*)workspace);
+  hipLaunchKernelGGL(blur_q8_v_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)workspace, H, W, C, t, out);
+  return hgl_check_launch("gaussian_blur_u8_q8");
 }
 
 int hgl_synthesize_views(const uint8_t* sam_img, const uint8_t* blurred, const float* image_norm,

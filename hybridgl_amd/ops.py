@@ -266,21 +266,36 @@ def synthesize_views(sam_img, blurred, image_norm, masks, res=224):
     return loc, glo
 
 
-def gaussian_blur_u8(img, k=15):
-    """Device version of synth.box_blur_u8 (the stand-in for cv2.GaussianBlur(img,(k,k),0)), bit-identical to it.
-    img: [H,W,C] uint8 device tensor -> blurred [H,W,C] uint8."""
+def cv_gaussian_kernel_q8(k=15, sigma=0.0):
+    """the k 8.8 fixed-point taps of cv2.GaussianBlur on uint8 (sum 256) -> ctypes uint16 array (host)"""
+    import ctypes as C
+    taps = (C.c_uint16 * k)()
+    check(_lib.load().hgl_cv_gaussian_kernel_q8(k, float(sigma), taps), "hgl_cv_gaussian_kernel_q8")
+    return taps
+
+
+def gaussian_blur_u8(img, k=15, sigma=0.0, mode="cv2"):
+    """cv2.GaussianBlur(img, (k, k), sigma) on a [H,W,C] uint8 device tensor (Hybridgl_main.py:99).
+    mode="cv2": OpenCV's 8-bit fixed-point path restated (integer arithmetic; parity with the package unpinned);
+    mode="float": the double-precision separable Gaussian of synth.box_blur_u8, bit-identical to it."""
     import ctypes as C
     import numpy as np
     lib = _lib.load()
     H, W, Cc = img.shape
-    sigma = 0.3 * ((k - 1) * 0.5 - 1) + 0.8
+    out = torch.empty_like(img)
+    ws = workspace(lib.hgl_gaussian_blur_u8_workspace_bytes(H, W, Cc), img.device, "blur")
+    if mode == "cv2":
+        taps = cv_gaussian_kernel_q8(k, sigma)
+        check(lib.hgl_gaussian_blur_u8_q8(_dev(img, torch.uint8, "img"), H, W, Cc, taps, taps, k, out.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _stream()), "hgl_gaussian_blur_u8_q8")
+        return out
+    assert mode == "float"
+    sigma = sigma if sigma > 0 else 0.3 * ((k - 1) * 0.5 - 1) + 0.8
     r = k // 2
     x = np.arange(-r, r + 1, dtype=np.float64)
     g = np.exp(-(x * x) / (2 * sigma * sigma))
     g /= g.sum()
     taps = (C.c_double * k)(*[float(v) for v in g])
-    out = torch.empty_like(img)
-    ws = workspace(lib.hgl_gaussian_blur_u8_workspace_bytes(H, W, Cc), img.device, "blur")
     check(lib.hgl_gaussian_blur_u8(_dev(img, torch.uint8, "img"), H, W, Cc, taps, k, out.data_ptr(), ws.data_ptr(),
                                    ws.numel(), _stream()), "hgl_gaussian_blur_u8")
     return out

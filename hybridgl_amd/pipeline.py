@@ -36,14 +36,14 @@ class Sentence:
     relaflag: str = "none"         # extract_rela_word  (utils.py:206-238)
     n_nouns: int = 0               # len(nouns) of extract_nouns (Hybridgl_main.py:184)
     imgattn: Optional[torch.Tensor] = None  # [H,W] fp32: gem_model(...) resized to the image (:200-202)
-    gem_row: Optional[int] = None  # token row of "a photo of a {noun_phrase}." (the GEM prompt) when the heat-map is computed here
     target: Optional[torch.Tensor] = None   # [H,W] per-phrase ground truth (Hybridgl_main_PhraseCut.py:117-119); else RefBatch.target
+    gem_row: Optional[int] = None  # token row of "a photo of a {noun_phrase}." (the GEM prompt) when the heat-map is computed here
 
 
 @dataclass
 class RefBatch:
     sam_img: torch.Tensor      # [H,W,3] uint8   image['sam_img']
-    blurred: torch.Tensor      # [H,W,3] uint8   cv2.GaussianBlur(sam_img,(15,15),0)  (:99)
+    blurred: Optional[torch.Tensor]  # [H,W,3] uint8   cv2.GaussianBlur(sam_img,(15,15),0)  (:99); None = computed in the step
     image_norm: torch.Tensor   # [3,H,W] fp32    image['image'] (ImageNet-normalised)
     masks: torch.Tensor        # [N,H,W] bool    SAM proposals (:86-87)
     boxes: torch.Tensor        # [N,4] int64     XYWH (:89-90)
@@ -191,7 +191,8 @@ class HybridGLPipeline:
                     # (random-weight SAM logits are pixel noise, which is not what the clean-up sees in practice)
                     cm, _ = self.mask_generator.cleanup_fixed(ref.masks.view(torch.uint8))
                     ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
-            local, glob = ops.synthesize_views(ref.sam_img, ref.blurred, ref.image_norm, ref.masks, self.res)
+            blurred = ref.blurred if ref.blurred is not None else ops.gaussian_blur_u8(ref.sam_img, 15)   # :99
+            local, glob = ops.synthesize_views(ref.sam_img, blurred, ref.image_norm, ref.masks, self.res)
             hybrid = m(local, glob, ref.masks, masking_block=self.masking_block, fusion_mode=self.fusion_mode)
             if ref.image_id is not None:
                 self._cache_id, self._cache_ref, self._cache_hybrid = ref.image_id, ref, hybrid
@@ -235,11 +236,13 @@ class HybridGLPipeline:
         }
 
 
-def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=49408, sam_img_size=0, gem=False, gem_size=448):
+def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=49408, sam_img_size=0, gem=False, gem_size=448,
+                  device_blur=False):
     """The benchmark item of SURVEY.md 8d: 640x640 image, 64 proposals, 3 queries, each with a
     sentence, a noun phrase and one other noun (9 token rows).  Returns (RefBatch, numpy dict).
     gem=True: the heat-map is NOT an input; the ref carries tensor_img [3,gem_size,gem_size] and one more token
-    row per sentence (the GEM prompt), and the pipeline computes the heat-maps on the device."""
+    row per sentence (the GEM prompt), and the pipeline computes the heat-maps on the device.
+    device_blur=True: RefBatch.blurred is None and the step runs cv2.GaussianBlur's fixed-point filter itself."""
     img = synth.synth_image(H, W, 1000 + i)
     blur = synth.box_blur_u8(img)
     norm = synth.imagenet_normalize(img)
@@ -258,10 +261,10 @@ def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=494
         attn = synth.synth_heatmap(H, W, 4000 + 10 * i + j)
         attn_np.append(attn)
         sents.append(Sentence(3 * j, 3 * j + 1, [3 * j + 2], dirflag, relaflag, n_nouns,
-                              None if gem else torch.from_numpy(attn).to(device), 3 * n_sent + j if gem else None))
+                              None if gem else torch.from_numpy(attn).to(device), gem_row=3 * n_sent + j if gem else None))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     resized = None   # ResizeLongestSide runs on the device (hgl_resize_pil_bilinear), inside the step
-    ref = RefBatch(t(img), t(blur), t(norm), t(masks), t(boxes), t(tokens), t(gt), sents, resized,
+    ref = RefBatch(t(img), None if device_blur else t(blur), t(norm), t(masks), t(boxes), t(tokens), t(gt), sents, resized,
                    tensor_img=t(tensor_img) if gem else None)
     host = dict(img=img, blur=blur, norm=norm, masks=masks, boxes=boxes, tokens=tokens, gt=gt, attn=attn_np,
                 tensor_img=tensor_img)

@@ -273,6 +273,14 @@ size_t hgl_gaussian_blur_u8_workspace_bytes(int H, int W, int C);
 int hgl_gaussian_blur_u8(const uint8_t* img, int H, int W, int C, const double* taps, int k, uint8_t* out, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* cv2.GaussianBlur(img, (k,k), sigma) on uint8 (Hybridgl_main.py:99), OpenCV 4.x bit-exact path restated
+ * (opencv-python is external: parity unpinned).  hgl_cv_gaussian_kernel_q8 (HOST) fills the k 8.8 fixed-point
+ * taps (sum 256; sigma <= 0 selects OpenCV's 0.15 k + 0.35).  hgl_gaussian_blur_u8_q8 filters rows then columns in
+ * integer arithmetic, reflect-101 borders, one rounding (v + 2^15) >> 16.  Workspace: the size query above. */
+int hgl_cv_gaussian_kernel_q8(int k, double sigma, uint16_t* taps);
+int hgl_gaussian_blur_u8_q8(const uint8_t* img, int H, int W, int C, const uint16_t* taps_x, const uint16_t* taps_y, int k,
+                            uint8_t* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Image synthesis (Hybridgl_main.py:93-125): per mask, the blurred-background
  * "global" view and mean-filled "local" view, bilinear (no antialias) to res x res.

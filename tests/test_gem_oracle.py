@@ -91,3 +91,32 @@ def test_gem_heatmap_properties():
     for kw in (dict(ss_attn_iter=2), dict(ss_attn_temp=3.0), dict(ss_attn_iter=0)):
         g2, _ = GO.gem_vit_forward(sd, img, **kw)
         assert np.isfinite(g2).all() and np.abs(g2 - gem).max() > 1e-4
+
+
+# ----------------------------------------------------------------------------- cv2.GaussianBlur fixed-point taps (host code)
+@pytest.mark.parametrize("sigma", [0.0, 0.8, 2.6, 5.0])
+def test_cv_gaussian_taps_host_vs_oracle(sigma):
+    """hgl_cv_gaussian_kernel_q8 (host C++ in libhybridgl.so) == oracle/cv_oracle.py for every odd size: 8.8 fixed
+    point, symmetric, sum exactly 256; OpenCV's tabulated small kernels for sigma <= 0."""
+    from hybridgl_amd import ops
+    from oracle import cv_oracle as CV
+    for k in range(1, 32, 2):
+        taps = list(ops.cv_gaussian_kernel_q8(k, sigma))
+        assert taps == CV.gaussian_kernel_q8(k, sigma), (k, sigma)
+        assert sum(taps) == 256 and taps == taps[::-1]
+    if sigma == 0.0:
+        assert list(ops.cv_gaussian_kernel_q8(3)) == [64, 128, 64]
+        assert list(ops.cv_gaussian_kernel_q8(5)) == [16, 64, 96, 64, 16]
+        assert list(ops.cv_gaussian_kernel_q8(7)) == [8, 28, 56, 72, 56, 28, 8]
+        assert list(ops.cv_gaussian_kernel_q8(15)) == [1, 3, 6, 12, 20, 30, 36, 40, 36, 30, 20, 12, 6, 3, 1]
+
+
+def test_cv_blur_oracle_properties():
+    from oracle import cv_oracle as CV
+    flat = np.full((20, 30, 3), 200, dtype=np.uint8)
+    assert np.array_equal(CV.gaussian_blur_u8(flat), flat)
+    img = np.zeros((31, 31, 1), dtype=np.uint8)
+    img[15, 15] = 255
+    b = CV.gaussian_blur_u8(img).astype(np.int64)
+    t = np.asarray(CV.gaussian_kernel_q8(15), dtype=np.int64)
+    assert np.array_equal(b[8:23, 8:23, 0], (np.outer(t, t) * 255 + 32768) >> 16)      # impulse response = tap outer product

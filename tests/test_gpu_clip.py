@@ -156,8 +156,25 @@ def test_gaussian_blur_device_matches_host_definition(cuda, H, W):
     rng = np.random.default_rng(H)
     img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
     img[: H // 3] = synth.synth_image(H, W, 1)[: H // 3]
-    got = ops.gaussian_blur_u8(torch.from_numpy(img).to(cuda)).cpu().numpy()
+    got = ops.gaussian_blur_u8(torch.from_numpy(img).to(cuda), mode="float").cpu().numpy()
     assert np.array_equal(got, synth.box_blur_u8(img))
+
+
+@pytest.mark.parametrize("H,W,k", [(40, 56, 15), (157, 203, 15), (480, 640, 15), (64, 48, 5), (33, 47, 9), (64, 64, 31)])
+def test_cv2_fixed_point_blur_bit_exact_vs_oracle(cuda, H, W, k):
+    """hgl_cv_gaussian_kernel_q8 + hgl_gaussian_blur_u8_q8 == the integer restatement of OpenCV's 8-bit GaussianBlur
+    (oracle/cv_oracle.py; parity with the cv2 package itself unpinned), bit for bit: taps and pixels."""
+    from hybridgl_amd import ops, synth
+    from oracle import cv_oracle as CV
+    assert list(ops.cv_gaussian_kernel_q8(k)) == CV.gaussian_kernel_q8(k)
+    rng = np.random.default_rng(H * k)
+    img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    img[: H // 3] = synth.synth_image(H, W, 1)[: H // 3]
+    img[-2:] = 255                                    # saturated border rows: the 16-bit row sums peak at 255 * 256
+    got = ops.gaussian_blur_u8(torch.from_numpy(img).to(cuda), k).cpu().numpy()
+    assert np.array_equal(got, CV.gaussian_blur_u8(img, k))
+    flat = np.full((H, W, 3), 77, dtype=np.uint8)     # the taps sum to 256: a constant image is a fixed point
+    assert np.array_equal(ops.gaussian_blur_u8(torch.from_numpy(flat).to(cuda), k).cpu().numpy(), flat)
 
 
 def test_reference_named_helpers_vs_golden(cuda, golden_dir):

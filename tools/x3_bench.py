@@ -34,6 +34,20 @@ SHAPES = [  # (name, M, N, K, act, residual)
 ]
 
 
+GEM_SHAPES = [  # the GEM ViT-B/16 at 448x448 (785 tokens) and the text encoder with the GEM prompts (12 x 77)
+    ("gem qkv", 785, 2304, 768, "none", False),
+    ("gem out", 785, 768, 768, "none", True),
+    ("gem fc1", 785, 3072, 768, "quickgelu", False),
+    ("gem fc2", 785, 768, 3072, "none", True),
+    ("text qkv", 924, 1536, 512, "none", False),
+    ("text out", 924, 512, 512, "none", True),
+    ("text fc1", 924, 2048, 512, "quickgelu", False),
+    ("text fc2", 924, 512, 2048, "none", True),
+]
+if os.environ.get("X3_SHAPES") == "gem":
+    SHAPES = GEM_SHAPES
+
+
 def main():
     dev = torch.device("cuda:0")
     lib = _lib.load()
