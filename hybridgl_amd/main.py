@@ -7,10 +7,10 @@ and prints/appends the reference's two result lines.
 `--real` walks the REFER annotations under --refer_data_root (hybridgl_amd/refer_io.py: refs(<splitBy>).p,
 instances.json, COCO images; ground truth from the native polygon/RLE codec) with real checkpoints
 (HYBRIDGL_CLIP_CHECKPOINT / HYBRIDGL_SAM_CHECKPOINT / HYBRIDGL_BPE_VOCAB).  The two external models of the
-reference stay inputs: the spaCy parse (--parse_json: {sent_id: {"noun_phrase", "other_nouns", "dirflag",
-"relaflag"}}, default = whole sentence, no relation words) and the GEM heat-map (--heatmap_dir/<sent_id>.npy,
-default = uniform, i.e. no spatial guidance); the blurred background uses this package's own Gaussian (cv2 parity
-is unpinned).
+spaCy parse of the reference stays an input (--parse_json: {sent_id: {"noun_phrase", "other_nouns", "dirflag",
+"relaflag"}}, default = whole sentence, no relation words).  The GEM heat-map of the noun phrase is computed on the
+device (hybridgl_amd/gem.py, Hybridgl_main.py:200-201) unless --heatmap_dir/<sent_id>.npy supplies it; the blurred
+background is OpenCV's fixed-point GaussianBlur restated on the device (Hybridgl_main.py:99).
 
     python -m hybridgl_amd.main --dataset refcocog --split val --fusion_mode G2L --synthetic 8
     python -m hybridgl_amd.main --dataset refcoco --split testA --real --refer_data_root ./refer/data
@@ -35,6 +35,8 @@ def default_argument_parser():
     p.add_argument("--real", action="store_true", help="evaluate the REFER refs under --refer_data_root")
     p.add_argument("--parse_json", default="", help="pre-computed parse records keyed by sent_id")
     p.add_argument("--heatmap_dir", default="", help="pre-computed heat-maps <sent_id>.npy ([H,W] or any size, fp32)")
+    p.add_argument("--heatmap", default="device", choices=["device", "given"],
+                   help="device: GEM heat-maps computed here; given: --heatmap_dir files (real) / seeded maps (synthetic)")
     p.add_argument("--max_refs", type=int, default=0, help="stop after this many refs (0 = all)")
     p.add_argument("--clip_model", default="ViT-B/16")
     p.add_argument("--sam_model", default="default")
@@ -55,8 +57,10 @@ def real_refs(args, dev, splitBy, context_length):
     from .pipeline import RefBatch, Sentence
     from .refer_io import ReferDataset
     from .tokenizer import SimpleTokenizer, tokenize
+    from .gem import GEMWrapper, get_gem_img_transform
     ds = ReferDataset(args.refer_data_root, args.dataset, splitBy, args.split)
     tk = SimpleTokenizer(args.bpe_vocab or None)
+    preprocess = get_gem_img_transform()                                       # Hybridgl_main.py:39
     parse = json.load(open(args.parse_json)) if args.parse_json else {}
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     n = len(ds) if args.max_refs <= 0 else min(len(ds), args.max_refs)
@@ -76,15 +80,19 @@ def real_refs(args, dev, splitBy, context_length):
                 if tuple(a.shape) != (H, W):     # Hybridgl_main.py:201-202: bilinear to the image size
                     a = torch.nn.functional.interpolate(a[None, None], size=(H, W), mode="bilinear", align_corners=False)[0, 0]
                 attn = a.to(dev).contiguous()
-            if attn is None:
-                attn = torch.ones((H, W), dtype=torch.float32, device=dev)
+            gem_row = None
+            if attn is None and args.heatmap == "device":
+                gem_row = len(strings)                                         # Hybridgl_main.py:200 gem_model(tensor_img, [noun_phrase])
+                strings += GEMWrapper.prompts([rec.get("noun_phrase", raw)])
+            elif attn is None:
+                attn = torch.ones((H, W), dtype=torch.float32, device=dev)     # uniform: no spatial guidance
             sents.append(Sentence(row, row + 1, list(range(row + 2, row + 2 + len(others))), rec.get("dirflag", "none"),
-                                  rec.get("relaflag", "none"), len(others), attn))
+                                  rec.get("relaflag", "none"), len(others), attn, gem_row=gem_row))
         tokens = tokenize(strings, context_length=context_length, tokenizer=tk)   # raises on over-long text, as clip.tokenize
         placeholder = torch.zeros((1, H, W), dtype=torch.bool, device=dev)
-        yield RefBatch(t(img), ops.gaussian_blur_u8(t(img)), t(synth.imagenet_normalize(img)), placeholder,
+        yield RefBatch(t(img), None, t(synth.imagenet_normalize(img)), placeholder,
                        torch.zeros((1, 4), dtype=torch.int64, device=dev), t(tokens), t(annot), sents, None,
-                       int(data["img_id"][0]))
+                       int(data["img_id"][0]), tensor_img=preprocess(img).to(dev) if args.heatmap == "device" else None)
 
 
 def main(args):
@@ -103,8 +111,12 @@ def main(args):
         gen = SamAutomaticMaskGenerator(sam, points_per_side=args.points_per_side, pred_iou_thresh=args.pred_iou_thresh,
                                         stability_score_thresh=args.stability_score_thresh, crop_n_layers=0,
                                         crop_n_points_downscale_factor=1, min_mask_region_area=args.min_mask_region_area)
+    gem_model = None
+    if args.heatmap == "device":
+        from .gem import create_gem_model
+        gem_model = create_gem_model(args.clip_model, clip=model)          # Hybridgl_main.py:36-38 (same checkpoint: shared weights)
     pipe = HybridGLPipeline(model, fusion_mode=args.fusion_mode, masking_block=9, mask_generator=gen,
-                            use_sam_masks=args.real)
+                            use_sam_masks=args.real, gem_model=gem_model)
     print(f"fusion mode={args.fusion_mode}")
     if args.real:
         from .weights import CLIP_CONFIGS
@@ -118,7 +130,8 @@ def main(args):
             print(f"{skipped} refs skipped: the proposal stage returned no mask")
     else:
         for i in range(args.synthetic):
-            ref, _ = synthetic_ref(i, dev, N=args.proposals, sam_img_size=1024 if gen else 0)
+            ref, _ = synthetic_ref(i, dev, N=args.proposals, sam_img_size=1024 if gen else 0, gem=gem_model is not None,
+                                   device_blur=True)
             pipe.step(ref)
     m = pipe.metrics()
     text = (f"\n\n fusion_mode={args.fusion_mode} "

@@ -39,7 +39,8 @@ def _dataset(root):
     return refs
 
 
-def test_driver_runs_refer_data_end_to_end(cuda, golden_dir, tmp_path):
+@pytest.mark.parametrize("heatmap", ["device", "given"])
+def test_driver_runs_refer_data_end_to_end(cuda, golden_dir, tmp_path, heatmap):
     from hybridgl_amd import main as drv
     root = tmp_path / "refer_data"
     refs = _dataset(root)
@@ -47,7 +48,7 @@ def test_driver_runs_refer_data_end_to_end(cuda, golden_dir, tmp_path):
         "--real", "--refer_data_root", str(root), "--dataset", "refcoco", "--split", "val", "--sam_model", "tiny",
         "--bpe_vocab", os.path.join(golden_dir, "tiny_bpe_vocab.txt.gz"), "--parse_json", str(root / "parse.json"),
         "--pred_iou_thresh", "-1", "--stability_score_thresh", "0", "--min_mask_region_area", "20",
-        "--points_per_side", "4", "--result_dir", str(tmp_path / "log")])
+        "--points_per_side", "4", "--result_dir", str(tmp_path / "log"), "--heatmap", heatmap])
     m = drv.main(args)
     assert m["n_sentences"] == 2 * len(refs)
     assert m["cum"][1] > 0 and 0.0 <= m["oIoU"] <= 100.0 and 0.0 <= m["oIoU_final"] <= 100.0
