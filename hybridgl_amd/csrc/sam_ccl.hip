@@ -48,9 +48,73 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
   }
 }
 
-// Pass A -- horizontal runs, one wave per image row: L[p] = index of the first pixel of p's run
-// (no atomics: a prefix-max of "last non-working column" across the row), -1 outside the working
-// set (working pixel = (mask != 0) XOR holes).  area[] is zeroed.
+// ---- All passes walk the MASK BYTES, one wave per image row and 64 consecutive pixels per step (coalesced); the
+// run structure of a row is recovered on the fly from wave ballots (working pixel = (mask != 0) XOR holes), so the
+// int arrays are touched only at run starts: L[start] = parent link of the run (a union-find over runs, not over
+// pixels), area[root] = pixels of the component.  (A first version kept a label per pixel and spent ~700 us per call
+// at 64 x 640 x 640 moving 105 MB int arrays through six passes; the byte passes take a fifth of that.)
+constexpr int CCL_STEPS = 16;     // steps of 64 pixels whose bytes are fetched up front (independent loads: one latency)
+struct RowScan {
+  const uint8_t* row;     // mask bytes of this image row
+  int W, holes;
+  int carry;              // last non-working column of the steps done so far
+  bool prev_last;         // working bit of the column just left of the current step
+  int prev_last_start;    // its run start (valid when prev_last)
+  uint8_t v[CCL_STEPS + 1];   // working flags of this lane's pixel in each step of the group (+ the first of the next group)
+  unsigned lo_mask, hi_mask;  // bits of the lanes below this one, per 32-bit half of a ballot
+  // per step
+  bool work;              // this lane's pixel is a working pixel
+  unsigned long long wb;  // ballot of `work`
+  int start;              // run start column of this lane's pixel (valid when work)
+  bool left, right;       // working bits of the columns just left / right of this lane's pixel
+
+  __device__ __forceinline__ void init(const uint8_t* r, int W_, int holes_, int lane) {
+    row = r; W = W_; holes = holes_; carry = -1; prev_last = false; prev_last_start = 0;
+    lo_mask = lane < 32 ? (1u << lane) - 1u : 0xffffffffu;
+    hi_mask = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
+  }
+  // fetch the group of steps that begins at column g0
+  __device__ __forceinline__ void load(int g0, int lane) {
+#pragma unroll
+    for (int k = 0; k <= CCL_STEPS; ++k) {
+      const int x = g0 + 64 * k + (k < CCL_STEPS ? lane : 0);
+      v[k] = x < W ? row[x] : (uint8_t)(holes ? 1 : 0);       // beyond the row: a non-working value
+    }
+  }
+  // step k of the group (columns x0 .. x0+63).  Needs the whole wave (ballot, neighbour exchange): 32-bit VALU
+  // work only -- the first version shifted 64-bit masks per lane and was bound by exactly that.
+  __device__ __forceinline__ void step(int k, int x0, int lane) {
+    work = (v[k] != 0) != (holes != 0);
+    wb = __ballot(work);
+    const unsigned blo = ~(unsigned)wb & lo_mask, bhi = ~(unsigned)(wb >> 32) & hi_mask;
+    int last = carry;
+    if (blo) last = x0 + 31 - __clz(blo);
+    if (bhi) last = x0 + 63 - __clz(bhi);
+    start = last + 1;
+    const int wi = work ? 1 : 0;
+    const int up = __shfl_up(wi, 1), dn = __shfl_down(wi, 1);
+    const bool next0 = (__shfl((int)v[k + 1], 0) != 0) != (holes != 0);   // lane 0 of the next step (or the look-ahead byte)
+    left = lane > 0 ? up != 0 : prev_last;
+    right = lane < 63 ? dn != 0 : next0;
+  }
+  __device__ __forceinline__ void advance(int x0) {
+    const unsigned long long nb = ~wb;
+    prev_last = (wb >> 63) != 0;
+    prev_last_start = __shfl(start, 63);
+    if (nb) carry = x0 + 63 - __clzll(nb);                 // (all 64 working: the carry stays)
+  }
+};
+#define CCL_FOR_STEPS(scan_load, ...)                                    \
+  for (int g0 = 0; g0 < W; g0 += 64 * CCL_STEPS) {                        \
+    scan_load;                                                            \
+    _Pragma("unroll") for (int k = 0; k < CCL_STEPS; ++k) {               \
+      const int x0 = g0 + 64 * k;                                         \
+      if (x0 >= W) break;                                                 \
+      __VA_ARGS__                                                         \
+    }                                                                     \
+  }
+
+// Pass A -- every run start becomes its own parent and gets a zero area.
 __global__ __launch_bounds__(256) void ccl_rows_kernel(const uint8_t* __restrict__ masks, int holes, int W,
                                                        long long rows, int* __restrict__ L,
                                                        int* __restrict__ area) {
@@ -58,137 +122,139 @@ __global__ __launch_bounds__(256) void ccl_rows_kernel(const uint8_t* __restrict
   const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
   if (row >= rows) return;
   const long long base = row * W;
-  const int ppl = (W + 63) / 64;                 // pixels per lane
-  const int x0 = lane * ppl;
-  int last = -1;                                 // last non-working column inside this lane's span
-  for (int i = 0; i < ppl; ++i) {
-    const int x = x0 + i;
-    if (x < W && ((masks[base + x] != 0) == (holes != 0))) last = x;   // non-working pixel
-  }
-  int pre = last;                                // inclusive prefix max over lanes
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(pre, o);
-    if (lane >= o) pre = max(pre, v);
-  }
-  int cur = __shfl_up(pre, 1);                   // exclusive: everything left of this lane
-  if (lane == 0) cur = -1;
-  for (int i = 0; i < ppl; ++i) {
-    const int x = x0 + i;
-    if (x >= W) break;
-    const bool work = (masks[base + x] != 0) != (holes != 0);
-    if (!work) cur = x;
-    L[base + x] = work ? (int)(base + cur + 1) : -1;
-    area[base + x] = 0;
-  }
+  RowScan c;
+  c.init(masks + base, W, holes, lane);
+  CCL_FOR_STEPS(c.load(g0, lane), {
+    c.step(k, x0, lane);
+    if (c.work && !c.left) {
+      L[base + x0 + lane] = (int)(base + x0 + lane);
+      area[base + x0 + lane] = 0;
+    }
+    c.advance(x0);
+  })
 }
 
-// Pass B -- vertical / diagonal links between runs of adjacent rows.  A link is issued only where it
-// is not implied by a link one column to the left or by run membership, so a blob costs O(1) unions
-// per row instead of one per pixel.
-__global__ __launch_bounds__(256) void ccl_merge_kernel(int* __restrict__ L, int H, int W, long long total) {
-  const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i >= total) return;
-  const int me = L[i];
-  if (me < 0) return;
-  const long long HW = (long long)H * W;
-  const int p = (int)(i % HW);
-  const int y = p / W, x = p % W;
-  if (y + 1 >= H) return;
-  const int s = L[i + W];                                   // below
-  const int sw = x > 0 ? L[i + W - 1] : -1;                 // below-left
-  const int se = x + 1 < W ? L[i + W + 1] : -1;             // below-right
-  const int w = x > 0 ? L[i - 1] : -1;                      // left (same run when >= 0)
-  const int e = x + 1 < W ? L[i + 1] : -1;                  // right (same run when >= 0)
-  if (s >= 0 && !(w >= 0 && sw >= 0)) uf_union(L, me, s);   // first column where the two runs touch
-  if (s < 0) {
-    if (sw >= 0 && w < 0) uf_union(L, me, sw);              // isolated diagonal contacts
-    if (se >= 0 && e < 0) uf_union(L, me, se);
-  }
+// Pass B -- links between the runs of adjacent rows (8-connectivity).  A link is issued only at the first column
+// where two runs touch (not implied by a contact one column to the left), so a blob costs O(1) unions per row.
+__global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t* __restrict__ masks, int holes, int* __restrict__ L, int H,
+                                                        int W, long long rows) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (row >= rows || (int)(row % H) + 1 >= H) return;
+  const long long base = row * W;
+  RowScan c, d;
+  c.init(masks + base, W, holes, lane);
+  d.init(masks + base + W, W, holes, lane);
+  CCL_FOR_STEPS(c.load(g0, lane); d.load(g0, lane), {
+    c.step(k, x0, lane);
+    d.step(k, x0, lane);
+    const int d_up = __shfl_up(d.start, 1);                                // (every lane takes part in the shuffle)
+    const int d_left_start = lane > 0 ? d_up : d.prev_last_start;           // run start of the below-left pixel
+    if (c.work) {
+      const int me = (int)(base + c.start);
+      const bool s = d.work, sw = d.left, se = d.right, w = c.left, e = c.right;
+      if (s && !(w && sw)) uf_union(L, me, (int)(base + W + d.start));
+      if (!s) {
+        if (sw && !w) uf_union(L, me, (int)(base + W + d_left_start));
+        if (se && !e) uf_union(L, me, (int)(base + W + x0 + lane + 1));   // below is not working: the run starts there
+      }
+    }
+    c.advance(x0);
+    d.advance(x0);
+  })
 }
 
-// Pass C -- per run: compress the run start's link to its root and add the run length to the
-// component's area (one atomic per run, issued by the run's last pixel).
-__global__ __launch_bounds__(256) void ccl_count_kernel(int* __restrict__ L, int* __restrict__ area, int W,
-                                                        long long total) {
-  const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i >= total) return;
-  const int me = L[i];
-  if (me < 0) return;
-  const int x = (int)(i % W);
-  const bool is_end = (x + 1 == W) || L[i + 1] < 0;
-  if (!is_end) return;
-  const bool is_start = (x == 0) || L[i - 1] < 0;
-  const int start = is_start ? (int)i : me;                 // non-start pixels still hold their run start
-  const int r = uf_find(L, start);
-  atomicAdd(&area[r], (int)i - start + 1);
-}
-__global__ __launch_bounds__(256) void ccl_compress_kernel(int* __restrict__ L, int W, long long total) {
-  const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i >= total || L[i] < 0) return;
-  const int x = (int)(i % W);
-  if ((x == 0) || L[i - 1] < 0) L[i] = uf_find(L, (int)i);  // run starts point at the root
+// Pass C -- per run (its last pixel): add the run length to the component's area.
+__global__ __launch_bounds__(256) void ccl_count_kernel(const uint8_t* __restrict__ masks, int holes, const int* __restrict__ L,
+                                                        int* __restrict__ area, int W, long long rows) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long long base = row * W;
+  RowScan c;
+  c.init(masks + base, W, holes, lane);
+  CCL_FOR_STEPS(c.load(g0, lane), {
+    c.step(k, x0, lane);
+    if (c.work && !c.right) {
+      const int r = uf_find(L, (int)(base + c.start));
+      atomicAdd(&area[r], x0 + lane - c.start + 1);
+    }
+    c.advance(x0);
+  })
 }
 
-// root of the component of working pixel i after ccl_compress_kernel
-__device__ __forceinline__ int ccl_root(const int* __restrict__ L, long long i, int W) {
-  const int me = L[i];
-  const int x = (int)(i % W);
-  const bool is_start = (x == 0) || L[i - 1] < 0;
-  return is_start ? me : L[me];
-}
-
-// per mask: stats[n*4+0] = number of small components, [1] = number of large ones,
-// [2] = max area, [3] = smallest root among the components of max area
-__global__ __launch_bounds__(256) void ccl_stats_kernel(const int* __restrict__ L, const int* __restrict__ area,
-                                                        long long HW, long long total, int thresh,
-                                                        int* __restrict__ stats) {
-  const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i >= total || L[i] != (int)i) return;   // one thread per root
-  const int n = (int)(i / HW), a = area[i];
-  atomicAdd(&stats[n * 4 + (a < thresh ? 0 : 1)], 1);
-  atomicMax(&stats[n * 4 + 2], a);
-}
-__global__ __launch_bounds__(256) void ccl_argmax_kernel(const int* __restrict__ L, const int* __restrict__ area,
-                                                         long long HW, long long total, int* __restrict__ stats) {
-  const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i >= total || L[i] != (int)i) return;
-  const int n = (int)(i / HW);
-  if (area[i] == stats[n * 4 + 2]) atomicMin(&stats[n * 4 + 3], (int)i);
+// Pass D -- run starts are pointed at their root; the lane that finds a root (L[i] == i) also files the component
+// into its mask's statistics: stats[n*4+0] = number of small components, [1] = number of large ones, ([3]:[2]) =
+// one 64-bit key (area << 32 | 0x7fffffff - root) maximised atomically, i.e. the largest area and, among equals,
+// the smallest root -- the reference's "first largest" component (label order = raster order of first pixels).
+__global__ __launch_bounds__(256) void ccl_compress_kernel(const uint8_t* __restrict__ masks, int holes, int* __restrict__ L,
+                                                           const int* __restrict__ area, int W, long long HW, long long rows,
+                                                           int thresh, int* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long long base = row * W;
+  RowScan c;
+  c.init(masks + base, W, holes, lane);
+  CCL_FOR_STEPS(c.load(g0, lane), {
+    c.step(k, x0, lane);
+    if (c.work && !c.left) {
+      const int i = (int)(base + x0 + lane);
+      const int r = uf_find(L, i);
+      if (r == i) {
+        const int n = (int)(i / HW), a = area[i];
+        atomicAdd(&stats[n * 4 + (a < thresh ? 0 : 1)], 1);
+        const unsigned long long key = ((unsigned long long)(unsigned)a << 32) | (unsigned)(0x7fffffff - i);
+        atomicMax((unsigned long long*)(stats + n * 4 + 2), key);
+      } else {
+        L[i] = r;
+      }
+    }
+    c.advance(x0);
+  })
 }
 
 __global__ void ccl_stats_init_kernel(int* stats, int N) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  stats[n * 4 + 0] = 0; stats[n * 4 + 1] = 0; stats[n * 4 + 2] = 0; stats[n * 4 + 3] = 0x7fffffff;
+  stats[n * 4 + 0] = 0; stats[n * 4 + 1] = 0; stats[n * 4 + 2] = 0; stats[n * 4 + 3] = 0;
 }
 
-// holes:   out = mask | (working && area < thresh)                      (fill small holes)
-// islands: out = working && area >= thresh ; if no component is large, keep the (first) largest
+// Pass E -- holes:   out = mask | (working && area < thresh)                      (fill small holes)
+//           islands: out = working && area >= thresh ; if no component is large, keep the (first) largest
 __global__ __launch_bounds__(256) void ccl_apply_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ L,
                                                         const int* __restrict__ area, const int* __restrict__ stats,
-                                                        int holes, int W, long long HW, long long total, int thresh,
+                                                        int holes, int H, int W, long long rows, int thresh,
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ changed) {
-  const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i >= total) return;
-  const int n = (int)(i / HW);
-  const bool m = masks[i] != 0;
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long long base = row * W;
+  const int n = (int)(row / H);
   const int n_small = stats[n * 4 + 0];
+  if (row % H == 0 && lane == 0) changed[n] = n_small != 0;
   if (n_small == 0) {            // nothing below the threshold: mask unchanged (utils/amg.py:281-282)
-    out[i] = m ? 1 : 0;
-    if (i % HW == 0) changed[n] = 0;
+    for (int x = lane; x < W; x += 64) out[base + x] = masks[base + x] != 0 ? 1 : 0;
     return;
   }
-  if (i % HW == 0) changed[n] = 1;
-  const int r = L[i] >= 0 ? ccl_root(L, i, W) : -1;
-  bool o;
-  if (holes) {
-    o = m || (r >= 0 && area[r] < thresh);
-  } else {
-    const bool any_large = stats[n * 4 + 1] > 0;
-    o = r >= 0 && (any_large ? area[r] >= thresh : r == stats[n * 4 + 3]);
-  }
-  out[i] = o ? 1 : 0;
+  const bool any_large = stats[n * 4 + 1] > 0;
+  const int best = 0x7fffffff - stats[n * 4 + 2];
+  RowScan c;
+  c.init(masks + base, W, holes, lane);
+  CCL_FOR_STEPS(c.load(g0, lane), {
+    c.step(k, x0, lane);
+    const int x = x0 + lane;
+    if (x < W) {
+      const bool m = c.v[k] != 0;
+      int r = -1;
+      if (c.work) r = L[base + c.start];     // the run start holds the root (or is the root)
+      bool o;
+      if (holes) o = m || (r >= 0 && area[r] < thresh);
+      else o = r >= 0 && (any_large ? area[r] >= thresh : r == best);
+      out[base + x] = o ? 1 : 0;
+    }
+    c.advance(x0);
+  })
 }
 
 // batched_mask_to_box: counters [N,4] = minx, miny, maxx, maxy
@@ -213,11 +279,12 @@ __global__ __launch_bounds__(256) void box_kernel(const uint8_t* __restrict__ ma
       for (int e = 0; e < 16 && p0 + e < HW; ++e) w4[e >> 2] |= (unsigned)(m[p0 + e] != 0) << (8 * (e & 3));
     }
     if ((w4[0] | w4[1] | w4[2] | w4[3]) == 0) continue;
+    const int y0 = (int)(p0 / W), xs = (int)(p0 - (long long)y0 * W);   // one division per 16 pixels
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       if ((w4[e >> 2] >> (8 * (e & 3))) & 0xff) {
-        const long long p = p0 + e;
-        const int x = (int)(p % W), y = (int)(p / W);
+        int x = xs + e, y = y0;
+        while (x >= W) { x -= W; ++y; }
         minx = min(minx, x); maxx = max(maxx, x); miny = min(miny, y); maxy = max(maxy, y);
       }
     }
@@ -265,16 +332,16 @@ int hgl_remove_small_regions(const uint8_t* masks, int N, int H, int W, int area
   int* area = ar.take<int>((size_t)total);
   int* stats = ar.take<int>((size_t)N * 4);
   const long long HW = (long long)H * W;
-  hipLaunchKernelGGL(ccl_rows_kernel, dim3((unsigned)(((long long)N * H + 3) / 4)), dim3(256), 0, st, masks, holes, W,
-                     (long long)N * H, L, area);
+  const long long rows = (long long)N * H;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  hipLaunchKernelGGL(ccl_rows_kernel, grid, dim3(256), 0, st, masks, holes, W, rows, L, area);
   hipLaunchKernelGGL(ccl_stats_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stats, N);
-  hipLaunchKernelGGL(ccl_merge_kernel, dim3(g1(total)), dim3(256), 0, st, L, H, W, total);
-  hipLaunchKernelGGL(ccl_count_kernel, dim3(g1(total)), dim3(256), 0, st, L, area, W, total);
-  hipLaunchKernelGGL(ccl_compress_kernel, dim3(g1(total)), dim3(256), 0, st, L, W, total);
-  hipLaunchKernelGGL(ccl_stats_kernel, dim3(g1(total)), dim3(256), 0, st, L, area, HW, total, area_thresh, stats);
-  hipLaunchKernelGGL(ccl_argmax_kernel, dim3(g1(total)), dim3(256), 0, st, L, area, HW, total, stats);
-  hipLaunchKernelGGL(ccl_apply_kernel, dim3(g1(total)), dim3(256), 0, st, masks, L, area, stats, holes, W, HW, total,
-                     area_thresh, out, changed);
+  hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, st, masks, holes, L, H, W, rows);
+  hipLaunchKernelGGL(ccl_count_kernel, grid, dim3(256), 0, st, masks, holes, (const int*)L, area, W, rows);
+  hipLaunchKernelGGL(ccl_compress_kernel, grid, dim3(256), 0, st, masks, holes, L, (const int*)area, W, HW, rows, area_thresh,
+                     stats);
+  hipLaunchKernelGGL(ccl_apply_kernel, grid, dim3(256), 0, st, masks, (const int*)L, (const int*)area, (const int*)stats, holes,
+                     H, W, rows, area_thresh, out, changed);
   return hgl_check_launch("remove_small_regions");
 }
 

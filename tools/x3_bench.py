@@ -44,8 +44,18 @@ GEM_SHAPES = [  # the GEM ViT-B/16 at 448x448 (785 tokens) and the text encoder 
     ("text fc1", 924, 2048, 512, "quickgelu", False),
     ("text fc2", 924, 512, 2048, "none", True),
 ]
+SAM2_SHAPES = [  # the SAM ViT-H encoder GEMMs for one image and for two images stacked along M
+    ("qkv win x1", 4900, 3840, 1280, "none", False), ("qkv win x2", 9800, 3840, 1280, "none", False),
+    ("proj win x1", 4900, 1280, 1280, "none", False), ("proj win x2", 9800, 1280, 1280, "none", False),
+    ("lin1 x1", 4096, 5120, 1280, "gelu", False), ("lin1 x2", 8192, 5120, 1280, "gelu", False),
+    ("lin2 x1", 4096, 1280, 5120, "none", True), ("lin2 x2", 8192, 1280, 5120, "none", True),
+    ("qkv glob x1", 4096, 3840, 1280, "none", False), ("qkv glob x2", 8192, 3840, 1280, "none", False),
+    ("proj glob x1", 4096, 1280, 1280, "none", False), ("proj glob x2", 8192, 1280, 1280, "none", False),
+]
 if os.environ.get("X3_SHAPES") == "gem":
     SHAPES = GEM_SHAPES
+if os.environ.get("X3_SHAPES") == "sam2":
+    SHAPES = SAM2_SHAPES
 
 
 def main():
