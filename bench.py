@@ -51,7 +51,7 @@ def algorithmic_flops_per_ref(N=64, n_strings=9, sam=True, gem=False):
     return clip + text + ((5.961e12 + 64 * 3.62e9) if sam else 0.0) + (gem_flops_per_image() if gem else 0.0)
 
 
-def roofline(precision, nprof, g, x, a, traffic, whole_tflops, xg=(0, 0.0, 0.0)):
+def roofline(precision, nprof, g, x, a, traffic, whole_tflops, xg=(0, 0.0, 0.0), few=(0, 0.0, 0.0)):
     """roofline object for the kernel that dominates the step (by summed launch time)."""
     g_n, g_ms, g_fl = g
     x_n, x_ms, x_fl = x
@@ -93,6 +93,10 @@ def roofline(precision, nprof, g, x, a, traffic, whole_tflops, xg=(0, 0.0, 0.0))
         "gemm_x3g_kernel": members["gemm_x3g_kernel"],
         "attn_f32_kernel": {"achieved": tf(a_fl, a_ms), "launches_per_step": a_n / nprof, "ms_per_step": a_ms / nprof},
     }
+    main["other_kernels"]["f16x3_gemm_few_tile_launches"] = {
+        "achieved": tf(few[2], few[1]), "launches_per_step": few[0] / nprof, "ms_per_step": few[1] / nprof,
+        "note": "launches of the f16x3 kernels with < 256 output tiles (GEM heat-map tower at 785 rows, text encoder at 924 "
+                "rows): latency-bound when timed alone, they run on a side stream underneath the SAM / CLIP kernels"}
     main["whole_step_algorithmic_tflops"] = whole_tflops
     return main
 
@@ -297,6 +301,7 @@ def main():
     a_n, a_ms, a_fl, a_by = prof_read(lib, 1)
     x_n, x_ms, x_fl, x_by = prof_read(lib, 3)
     xg_n, xg_ms, xg_fl, xg_by = prof_read(lib, 4)
+    fw_n, fw_ms, fw_fl, fw_by = prof_read(lib, 5)
     precision = "f16x3" if lib.hgl_get_precision() == 1 else "f32"
 
     m = pipe.metrics()
@@ -370,7 +375,7 @@ def main():
             },
             "roofline": roofline(precision, nprof, (g_n, g_ms, g_fl), (x_n, x_ms, x_fl), (a_n, a_ms, a_fl), traffic,
                                  algorithmic_flops_per_ref(args.masks, sam=args.scope == "B", gem=use_gem) / (dt / args.steps) / 1e12,
-                                 xg=(xg_n, xg_ms, xg_fl)),
+                                 xg=(xg_n, xg_ms, xg_fl), few=(fw_n, fw_ms, fw_fl)),
             "precision": precision,
             "metrics": m,
         }

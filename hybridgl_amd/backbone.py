@@ -93,6 +93,8 @@ class _ClipModel:
             "ln_post_b": _to_dev(sd["visual.ln_post.bias"], device),
             "proj_t": _to_dev(np.ascontiguousarray(np.asarray(sd["visual.proj"]).T), device),
         }
+        if precision == "f16x3" and self._vt["conv1"].shape[1] % 64 == 0:
+            ops.register_split_weight(self._vt["conv1"])     # patch embedding as a split-fp16 GEMM
         v = HglClipVisionW()
         v.width, v.layers, v.heads, v.patch, v.grid, v.embed = vw, vl, vw // 64, p, grid, cfg["embed_dim"]
         v.conv1_w = self._vt["conv1"].data_ptr()

@@ -89,9 +89,18 @@ int hgl_clip_run_block(const HglResBlockW& w, float* X, int B, int S, int D, int
 int hgl_clip_embed_images(const HglClipVisionW* w, const float* imgs, int n_img, float* X, float* cols, float* tok,
                           hipStream_t st) {
   const int D = w->width, g = w->grid, P = g * g, S = P + 1, kd = 3 * w->patch * w->patch;
-  HGL_TRY(hgl_launch_im2col_patch(imgs, n_img, g * w->patch, w->patch, cols, st));
-  HGL_TRY(hgl_launch_gemm(cols, w->conv1_w, nullptr, nullptr, tok, n_img * P, D, kd, kd, kd, 0, D, 1,
-                          0, 0, 0, 0, HGL_ACT_NONE, st));
+  if (n_img * P > 512 && (w->patch & 3) == 0 && hgl_use_x3(w->conv1_w, kd)) {
+    // split-fp16 path: the im2col matrix is written directly as fp16 hi | lo planes (same bytes as the fp32 matrix)
+    uint16_t* ch = (uint16_t*)cols;
+    uint16_t* cl = ch + (size_t)n_img * P * kd;
+    HGL_TRY(hgl_launch_im2col_patch_split(imgs, n_img, g * w->patch, w->patch, ch, cl, st));
+    HGL_TRY(hgl_launch_gemm_f16x3(ch, cl, kd, w->conv1_w, nullptr, nullptr, 0, tok, nullptr, nullptr, D, n_img * P, D, kd,
+                                  HGL_ACT_NONE, st));
+  } else {
+    HGL_TRY(hgl_launch_im2col_patch(imgs, n_img, g * w->patch, w->patch, cols, st));
+    HGL_TRY(hgl_launch_gemm(cols, w->conv1_w, nullptr, nullptr, tok, n_img * P, D, kd, kd, kd, 0, D, 1,
+                            0, 0, 0, 0, HGL_ACT_NONE, st));
+  }
   HGL_TRY(hgl_launch_assemble_lnpre(tok, w->class_embedding, w->positional_embedding, w->ln_pre_w,
                                     w->ln_pre_b, X, n_img, S, D, st));
   return HGL_OK;

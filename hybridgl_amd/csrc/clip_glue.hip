@@ -105,6 +105,35 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restri
   }
 }
 
+// the same, written as the fp16 (hi, lo) pair the split-fp16 patch-embedding GEMM reads (patch side % 4 == 0)
+typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void im2col_patch_split_kernel(const float* __restrict__ img, _Float16* __restrict__ hi,
+                                                                 _Float16* __restrict__ lo, int N, int res, int p,
+                                                                 long long total4) {
+  const int g = res / p;
+  const int kdim = 3 * p * p;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    const int col = (int)(e % kdim);
+    const long long rowi = e / kdim;
+    const int kx = col % p, ky = (col / p) % p, c = col / (p * p);
+    const int px = (int)(rowi % g), py = (int)((rowi / g) % g);
+    const int n = (int)(rowi / ((long long)g * g));
+    const f32x4 v = *(const f32x4*)(img + (((long long)n * 3 + c) * res + (py * p + ky)) * res + px * p + kx);
+    h16x4_t a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      _Float16 h0, l0;
+      hgl_split_hi_lo(v[j], h0, l0);
+      a[j] = h0;
+      b[j] = l0;
+    }
+    *(h16x4_t*)(hi + e) = a;
+    *(h16x4_t*)(lo + e) = b;
+  }
+}
+
 // ---- assemble tokens + LN (one wave per row; generic D via loops over LDS-free passes) ----
 __global__ __launch_bounds__(256) void assemble_lnpre_kernel(
     const float* __restrict__ tok, const float* __restrict__ cls, const float* __restrict__ pos,
@@ -270,6 +299,15 @@ int hgl_launch_im2col_patch(const float* img, int N, int res, int patch, float* 
   else
     hipLaunchKernelGGL(im2col_patch_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, img, cols, N, res, patch, total);
   return hgl_check_launch("im2col_patch");
+}
+
+int hgl_launch_im2col_patch_split(const float* img, int N, int res, int patch, void* hi, void* lo, hipStream_t st) {
+  HGL_REQUIRE(img && hi && lo && N > 0 && res > 0 && patch > 0 && res % patch == 0 && patch % 4 == 0,
+              "im2col_split: bad arguments (res=%d patch=%d)", res, patch);
+  const long long total = (long long)N * 3 * res * res;
+  hipLaunchKernelGGL(im2col_patch_split_kernel, dim3(grid_for(total / 4)), dim3(256), 0, st, img, (_Float16*)hi, (_Float16*)lo, N,
+                     res, patch, total / 4);
+  return hgl_check_launch("im2col_patch_split");
 }
 
 int hgl_launch_assemble_lnpre(const float* tok, const float* cls, const float* pos, const float* lw,

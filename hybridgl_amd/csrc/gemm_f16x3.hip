@@ -818,7 +818,10 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
   const bool small_offsets = (double)M * lda * (amap ? 4.0 : 2.0) < 4.0e9 && (double)N * K * 2.0 < 4.0e9;   // gathered rows: <= 2M
   int kind = g_x3_kernel >= 0 ? g_x3_kernel : pick_x3_kernel(M, N, K);
   if (!small_offsets) kind = HGL_X3_V1;
-  HglProfScope prof(kind == HGL_X3_V1 ? HGL_PROF_GEMM_X3 : HGL_PROF_GEMM_X3G, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
+  // launches that cannot fill the 256 CUs once (GEM at 785 rows, text encoder: a 128x128 tile per CU is latency-bound
+  // when run alone) are accounted separately from the throughput-bound ones
+  const long long few_tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  HglProfScope prof(few_tiles < 256 ? HGL_PROF_GEMM_X3_FEW : kind == HGL_X3_V1 ? HGL_PROF_GEMM_X3 : HGL_PROF_GEMM_X3G, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
 #define HGL_X3_LAUNCH(ACT_, BK_, OCC_)                                                                        \
   do {                                                                                                        \
     g.tiles_m = (M + BM - 1) / BM;                                                                            \

@@ -82,6 +82,7 @@ int hgl_launch_attention(const float* q, const float* k, const float* v, float* 
 
 // CLIP glue (clip_glue.hip)
 int hgl_launch_im2col_patch(const float* img, int N, int res, int patch, float* cols, hipStream_t st);
+int hgl_launch_im2col_patch_split(const float* img, int N, int res, int patch, void* hi, void* lo, hipStream_t st);
 int hgl_launch_assemble_lnpre(const float* tok, const float* cls, const float* pos, const float* lw,
                               const float* lb, float* x, int B, int S, int D, hipStream_t st);
 int hgl_launch_mask_resize(const uint8_t* masks, int N, int Hm, int Wm, int g, float* pm,
@@ -113,7 +114,7 @@ int hgl_clip_embed_images(const HglClipVisionW* w, const float* imgs, int n_img,
                           hipStream_t st);
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench roofline) ----
-enum HglProfClass { HGL_PROF_GEMM = 0, HGL_PROF_ATTN = 1, HGL_PROF_OTHER = 2, HGL_PROF_GEMM_X3 = 3, HGL_PROF_GEMM_X3G = 4, HGL_PROF_NCLASS = 5 };
+enum HglProfClass { HGL_PROF_GEMM = 0, HGL_PROF_ATTN = 1, HGL_PROF_OTHER = 2, HGL_PROF_GEMM_X3 = 3, HGL_PROF_GEMM_X3G = 4, HGL_PROF_GEMM_X3_FEW = 5, HGL_PROF_NCLASS = 6 };
 struct HglProfScope {
   int slot;
   hipStream_t st;

@@ -344,10 +344,18 @@ int hgl_sam_encode(const HglSamEncoderW* w, const uint8_t* resized_img, int in_h
   const int D = w->embed_dim, S = w->img_size, g = S / w->patch, C = w->out_chans, T = g * g;
   const int kd = 3 * w->patch * w->patch;
   HGL_TRY(hgl_launch_sam_preprocess(resized_img, in_h, in_w, S, p.img, st));
-  HGL_TRY(hgl_launch_im2col_patch(p.img, 1, S, w->patch, p.cols, st));
   // patch embedding + bias + absolute position embedding (image_encoder.py:107-109)
-  HGL_TRY(hgl_launch_gemm(p.cols, w->patch_w, w->patch_b, w->pos_embed, p.X, T, D, kd, kd, kd, D, D, 1, 0, 0, 0, 0,
-                          HGL_ACT_NONE, st));
+  if ((w->patch & 3) == 0 && hgl_use_x3(w->patch_w, kd)) {
+    uint16_t* ch = (uint16_t*)p.cols;            // im2col written as fp16 hi | lo planes (same bytes as fp32)
+    uint16_t* cl = ch + (size_t)T * kd;
+    HGL_TRY(hgl_launch_im2col_patch_split(p.img, 1, S, w->patch, ch, cl, st));
+    HGL_TRY(hgl_launch_gemm_f16x3(ch, cl, kd, w->patch_w, w->patch_b, w->pos_embed, D, p.X, nullptr, nullptr, D, T, D, kd,
+                                  HGL_ACT_NONE, st));
+  } else {
+    HGL_TRY(hgl_launch_im2col_patch(p.img, 1, S, w->patch, p.cols, st));
+    HGL_TRY(hgl_launch_gemm(p.cols, w->patch_w, w->patch_b, w->pos_embed, p.X, T, D, kd, kd, kd, D, D, 1, 0, 0, 0, 0,
+                            HGL_ACT_NONE, st));
+  }
   for (int i = 0; i < w->depth; ++i) {
     const int ws = w->blocks[i].window;
     if (ws > 0) {   // every windowed block shares one window size (build_sam.py:55-101)
@@ -357,12 +365,29 @@ int hgl_sam_encode(const HglSamEncoderW* w, const uint8_t* resized_img, int in_h
   }
   for (int i = 0; i < w->depth; ++i) HGL_TRY(enc_block(w, w->blocks[i], p, st));
   // neck: conv1x1 -> LayerNorm2d -> conv3x3(pad 1) -> LayerNorm2d, all on NHWC rows
-  HGL_TRY(hgl_launch_gemm(p.X, w->neck0_w, nullptr, nullptr, p.neckA, T, C, D, D, D, 0, C, 1, 0, 0, 0, 0,
-                          HGL_ACT_NONE, st));
+  const bool neck_x3 = hgl_use_x3(w->neck0_w, D) && hgl_use_x3(w->neck2_w, C * 9);
+  if (neck_x3) {   // operands split into the (dead) MLP buffers: H holds T*D, F holds T*4D floats
+    uint16_t* xh = (uint16_t*)p.H;
+    uint16_t* xl = xh + (size_t)T * D;
+    HGL_TRY(hgl_launch_split_f16(p.X, 1.0f, xh, xl, (long long)T * D, st));
+    HGL_TRY(hgl_launch_gemm_f16x3(xh, xl, D, w->neck0_w, nullptr, nullptr, 0, p.neckA, nullptr, nullptr, C, T, C, D,
+                                  HGL_ACT_NONE, st));
+  } else {
+    HGL_TRY(hgl_launch_gemm(p.X, w->neck0_w, nullptr, nullptr, p.neckA, T, C, D, D, D, 0, C, 1, 0, 0, 0, 0,
+                            HGL_ACT_NONE, st));
+  }
   HGL_TRY(hgl_launch_layernorm(p.neckA, w->neck1_w, w->neck1_b, p.neckB, T, C, 1e-6f, st));
   HGL_TRY(hgl_launch_im2col3x3(p.neckB, g, C, p.cols3, st));
-  HGL_TRY(hgl_launch_gemm(p.cols3, w->neck2_w, nullptr, nullptr, p.neckA, T, C, C * 9, C * 9, C * 9, 0, C, 1, 0, 0,
-                          0, 0, HGL_ACT_NONE, st));
+  if (neck_x3 && (size_t)C * 9 <= (size_t)4 * D) {
+    uint16_t* ch = (uint16_t*)p.F;
+    uint16_t* cl = ch + (size_t)T * C * 9;
+    HGL_TRY(hgl_launch_split_f16(p.cols3, 1.0f, ch, cl, (long long)T * C * 9, st));
+    HGL_TRY(hgl_launch_gemm_f16x3(ch, cl, C * 9, w->neck2_w, nullptr, nullptr, 0, p.neckA, nullptr, nullptr, C, T, C, C * 9,
+                                  HGL_ACT_NONE, st));
+  } else {
+    HGL_TRY(hgl_launch_gemm(p.cols3, w->neck2_w, nullptr, nullptr, p.neckA, T, C, C * 9, C * 9, C * 9, 0, C, 1, 0, 0,
+                            0, 0, HGL_ACT_NONE, st));
+  }
   HGL_TRY(hgl_launch_layernorm(p.neckA, w->neck3_w, w->neck3_b, emb, T, C, 1e-6f, st));
   return HGL_OK;
 }

@@ -83,6 +83,10 @@ class Sam:
         enc.neck1_w, enc.neck1_b = t(sd[f"{e}.neck.1.weight"]), t(sd[f"{e}.neck.1.bias"])
         enc.neck2_w = t(np.asarray(sd[f"{e}.neck.2.weight"]).reshape(Cc, Cc * 9))
         enc.neck3_w, enc.neck3_b = t(sd[f"{e}.neck.3.weight"]), t(sd[f"{e}.neck.3.bias"])
+        if precision == "f16x3":     # patch embedding and neck convolutions as split-fp16 GEMMs (K % 64 == 0 permitting)
+            for x in self._t:
+                if x.data_ptr() in (enc.patch_w, enc.neck0_w, enc.neck2_w) and x.shape[1] % 64 == 0:
+                    ops.register_split_weight(x)
         self.enc_w = enc
 
         m, pe = "mask_decoder", "prompt_encoder"

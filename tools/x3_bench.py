@@ -87,6 +87,8 @@ def main():
         lib.hgl_prof_read(3, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))   # register-staged kernel
         if n.value == 0:
             lib.hgl_prof_read(4, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))   # LDS-DMA kernels
+        if n.value == 0:
+            lib.hgl_prof_read(5, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))   # launches with < 256 tiles
         tf = fl.value / ms.value / 1e9
         if not name.startswith(("text", "ragged", "k", "h")):
             tot_ms += ms.value / n.value
