@@ -660,15 +660,19 @@ __device__ __forceinline__ float wsum(float v) {
 }
 
 // LayerNorm writing the split form directly (one wave per row, D % 256 == 0)
+// Optional row maps: row r is read at x[smap[r]] and written at row dmap[r] (the SAM window partition of the real
+// tokens, image_encoder.py:243-266, folded into the norm1 pass).
 template <int VEC>
 __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ b, _Float16* __restrict__ hi,
-                                                              _Float16* __restrict__ lo, int rows, float eps) {
+                                                              _Float16* __restrict__ lo, int rows, float eps,
+                                                              const int* __restrict__ smap, const int* __restrict__ dmap) {
   constexpr int D = VEC * 256;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const f32x4* xr = (const f32x4*)(x + (long long)row * D);
+  const int srow = smap ? smap[row] : row, drow = dmap ? dmap[row] : row;
+  const f32x4* xr = (const f32x4*)(x + (long long)srow * D);
   f32x4 v[VEC];
   float s = 0.f;
 #pragma unroll
@@ -686,8 +690,8 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
       q += d * d;
     }
   const float rstd = rsqrtf(wsum(q) * (1.0f / D) + eps);
-  f16x4* hr = (f16x4*)(hi + (long long)row * D);
-  f16x4* lr = (f16x4*)(lo + (long long)row * D);
+  f16x4* hr = (f16x4*)(hi + (long long)drow * D);
+  f16x4* lr = (f16x4*)(lo + (long long)drow * D);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     const f32x4 wv = ((const f32x4*)w)[lane + 64 * i];
@@ -753,14 +757,19 @@ int hgl_launch_split_f16(const float* x, float scale, void* hi, void* lo, long l
 
 int hgl_launch_layernorm_split(const float* x, const float* w, const float* b, void* hi, void* lo, int rows, int D,
                                float eps, hipStream_t st) {
+  return hgl_launch_layernorm_split_maps(x, w, b, hi, lo, rows, D, eps, nullptr, nullptr, st);
+}
+
+int hgl_launch_layernorm_split_maps(const float* x, const float* w, const float* b, void* hi, void* lo, int rows, int D,
+                                    float eps, const int* smap, const int* dmap, hipStream_t st) {
   const unsigned grid = (unsigned)((rows + 3) / 4);
   _Float16 *h = (_Float16*)hi, *l = (_Float16*)lo;
   switch (D) {
-    case 256: hipLaunchKernelGGL(layernorm_split_kernel<1>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps); break;
-    case 512: hipLaunchKernelGGL(layernorm_split_kernel<2>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps); break;
-    case 768: hipLaunchKernelGGL(layernorm_split_kernel<3>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps); break;
-    case 1024: hipLaunchKernelGGL(layernorm_split_kernel<4>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps); break;
-    case 1280: hipLaunchKernelGGL(layernorm_split_kernel<5>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps); break;
+    case 256: hipLaunchKernelGGL(layernorm_split_kernel<1>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps, smap, dmap); break;
+    case 512: hipLaunchKernelGGL(layernorm_split_kernel<2>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps, smap, dmap); break;
+    case 768: hipLaunchKernelGGL(layernorm_split_kernel<3>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps, smap, dmap); break;
+    case 1024: hipLaunchKernelGGL(layernorm_split_kernel<4>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps, smap, dmap); break;
+    case 1280: hipLaunchKernelGGL(layernorm_split_kernel<5>, dim3(grid), dim3(256), 0, st, x, w, b, h, l, rows, eps, smap, dmap); break;
     default: hgl_set_error("layernorm_split: unsupported D=%d", D); return HGL_EINVAL;
   }
   return hgl_check_launch("layernorm_split");

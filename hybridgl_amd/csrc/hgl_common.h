@@ -152,6 +152,8 @@ bool hgl_has_split_weight(const float* W);
 int hgl_launch_split_f16(const float* x, float scale, void* hi, void* lo, long long n, hipStream_t st);
 int hgl_launch_layernorm_split(const float* x, const float* w, const float* b, void* hi, void* lo, int rows, int D,
                                float eps, hipStream_t st);
+int hgl_launch_layernorm_split_maps(const float* x, const float* w, const float* b, void* hi, void* lo, int rows, int D,
+                                    float eps, const int* smap, const int* dmap, hipStream_t st);
 bool hgl_gemm_skinny_applicable(const float* W32, int M, int N, int K, int lda, int ldw, int batch);
 int hgl_launch_gemm_x3_skinny(const float* A, int lda, const float* W32, const float* bias, const float* R, int ldr,
                               float* C, int ldc, int M, int N, int K, int act, hipStream_t st);

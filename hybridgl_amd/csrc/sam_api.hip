@@ -86,7 +86,11 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
   uint16_t* Fh = (uint16_t*)p.F;
   uint16_t* Fl = Fh + (size_t)T * 4 * D;
   if (x3) {
-    if (ws > 0) {
+    if (ws > 0 && M > T && padskip) {
+      // norm1 of the real tokens written straight to their rows of the padded window layout (the pad rows are never
+      // read: the GEMMs below gather the real tokens only)
+      HGL_TRY(hgl_launch_layernorm_split_maps(p.X, b.norm1_w, b.norm1_b, Ah, Al, T, D, 1e-6f, p.tok_of, p.pad_of, st));
+    } else if (ws > 0) {
       HGL_TRY(hgl_launch_layernorm(p.X, b.norm1_w, b.norm1_b, p.H, T, D, 1e-6f, st));
       HGL_TRY(hgl_launch_win_partition_split(p.H, g, ws, nw, D, Ah, Al, st));
     } else {

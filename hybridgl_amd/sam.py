@@ -500,7 +500,11 @@ class SamAutomaticMaskGenerator:
         tp = pts.copy()
         tp[:, 0] *= nw / W                                                       # apply_coords, utils/transforms.py:33-45
         tp[:, 1] *= nh / H
-        p01 = torch.from_numpy(((tp + 0.5) / float(m.img_size)).astype(np.float32)).to(m.device)
+        key = (H, W, layer_idx)
+        if getattr(self, "_p01_key", None) != key:      # the prompt grid depends on the image size only: upload it once
+            self._p01_key = key
+            self._p01 = torch.from_numpy(((tp + 0.5) / float(m.img_size)).astype(np.float32)).to(m.device)
+        p01 = self._p01
         lows, ious = [], []
         for s in range(0, len(pts), self.points_per_batch):
             low, iou = m.decode_points(emb, p01[s:s + self.points_per_batch].contiguous())
