@@ -60,8 +60,18 @@ int hgl_clip_block_rest(const HglResBlockW& w, float* X, int B, int S, int D, in
     HGL_TRY(hgl_launch_layernorm_split(X, w.ln2_w, w.ln2_b, Hh, Hl, M, D, 1e-5f, st));
     HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, w.fc_w, w.fc_b, nullptr, 0, nullptr, Fh, Fl, 4 * D, M, 4 * D, D,
                                   HGL_ACT_QUICKGELU, st));
-    HGL_TRY(hgl_launch_gemm_f16x3(Fh, Fl, 4 * D, w.proj_w, w.proj_b, X, D, X, nullptr, nullptr, D, M, D, 4 * D,
-                                  HGL_ACT_NONE, st));
+    // mlp.c_proj with few output tiles and K = 4D (GEM at 785 rows, the text encoder, small batches): split-K over the
+    // idle CUs; the partial sums borrow the qkv buffer (dead after the attention; it holds three slices)
+    static const int splitk_on = getenv("HGL_CLIP_SPLITK") ? atoi(getenv("HGL_CLIP_SPLITK")) : 1;
+    int ks = splitk_on ? hgl_gemm_f16x3_splitk_factor(M, D, 4 * D) : 1;
+    if (ks > 3) ks = 3;
+    if (ks > 1) {
+      HGL_TRY(hgl_launch_gemm_f16x3_splitk(Fh, Fl, 4 * D, nullptr, w.proj_w, w.proj_b, X, D, nullptr, X, D, M, D, 4 * D,
+                                           HGL_ACT_NONE, ks, bf.QKV, (size_t)M * 3 * D * sizeof(float), st));
+    } else {
+      HGL_TRY(hgl_launch_gemm_f16x3(Fh, Fl, 4 * D, w.proj_w, w.proj_b, X, D, X, nullptr, nullptr, D, M, D, 4 * D,
+                                    HGL_ACT_NONE, st));
+    }
     return HGL_OK;
   }
   HGL_TRY(hgl_launch_attention(bf.QKV, bf.QKV + D, bf.QKV + 2 * D, bf.H, B, heads, S, S, hd, 3 * D,

@@ -937,7 +937,9 @@ int hgl_launch_gemm_f16x3_splitk(const void* Ah, const void* Al, int lda, const 
   g.gm = 8;
   g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
   {
-    HglProfScope prof(HGL_PROF_GEMM_X3G, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
+    const long long few_tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    HglProfScope prof(few_tiles < 256 ? HGL_PROF_GEMM_X3_FEW : HGL_PROF_GEMM_X3G, 2.0 * M * (double)N * K,
+                      4.0 * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);
     const size_t lds = (size_t)4 * (256 + 256) * 64;
     static bool set = false;
     if (!set) {
