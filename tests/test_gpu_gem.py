@@ -70,6 +70,19 @@ def test_b16_448_heatmap_vs_oracle(cuda, b16):
     assert torch.equal(gm.image_features(torch.from_numpy(img).to(cuda)), feat)
 
 
+def test_b32_geometry_vs_oracle(cuda):
+    """another checkpoint geometry: ViT-B/32 at 448 x 448 (7x7 position grid interpolated to 14x14, 197 tokens)"""
+    sd = weights.clip_state_dict("ViT-B/32", 0)
+    gm = G.create_gem_model("ViT-B/32", state_dict=sd, device=cuda)
+    img = np.random.default_rng(31).standard_normal((3, 448, 448)).astype(np.float32)
+    feat = gm.image_features(torch.from_numpy(img).to(cuda)).cpu().numpy()
+    rg, _ = GO.gem_vit_forward(sd, img[None])
+    assert feat.shape == (197, 512)
+    np.testing.assert_allclose(feat, rg[0], rtol=0, atol=2e-4)
+    del gm
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("h,w,H,W", [(448, 448, 480, 640), (448, 448, 300, 400), (448, 448, 640, 427), (64, 64, 37, 91),
                                      (448, 448, 448, 448), (32, 32, 5, 200)])
 def test_resize_antialias_vs_torch(cuda, h, w, H, W):
