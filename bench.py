@@ -30,6 +30,15 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0   # dense; AMD's 5 PF headline includes 2:1 spars
 PEAK_HBM_GBS = 8000.0
 
 
+# CLIP geometries: ViT-B/16 is the reference's configuration (Hybridgl_main.py:37,47); ViT-L/14 is the extension named by
+# BASELINE.json (no oracle in the reference: model/backbone.py:16-21 defines neither last_layer nor heads for it;
+# SURVEY.md note 2: last_layer = layers - 2, masking_block = layers - 3)
+CLIP_GEOM = {
+    "ViT-B/16": dict(D=768, layers=12, S=197, patch_k=768, embed=512, masking_block=9, last_layer=10, text_D=512, gem_S=785),
+    "ViT-L/14": dict(D=1024, layers=24, S=257, patch_k=588, embed=768, masking_block=21, last_layer=22, text_D=768, gem_S=1025),
+}
+
+
 def gem_flops_per_image(S=785, D=768, layers=12, gem_blocks=6, patch_k=768, embed=512):
     """GEM ViT-B/16 at 448x448, computed ONCE per image: per block 2*S*D*12D of GEMMs + 4*S^2*D of attention;
     a GEM block adds 3 sets x 2 self-self attentions (4*S^2*D each) and one more out-projection; the MLP and the
@@ -41,14 +50,21 @@ def gem_flops_per_image(S=785, D=768, layers=12, gem_blocks=6, patch_k=768, embe
     return plain + ss + 2.0 * (S - 1) * patch_k * D + 2.0 * S * D * embed
 
 
-def algorithmic_flops_per_ref(N=64, n_strings=9, sam=True, gem=False):
-    """SURVEY.md 8d, minimal variant (dead final-block streams removed), ViT-B/16 G2L;
-    SAM ViT-H encoder 5.961 TFLOP + decoder 3.62 GFLOP x 64 prompts; + the GEM heat-map stage when it runs here."""
-    blk = 2.908e9          # per sequence per block (qkv .697, proj .232, mlp 1.859, attn .119)
-    patch = 0.231e9        # patch embed per sequence
-    clip = 2 * N * patch + 23 * N * blk
-    text = 5.96e9 * (n_strings + (3 if gem else 0))
-    return clip + text + ((5.961e12 + 64 * 3.62e9) if sam else 0.0) + (gem_flops_per_image() if gem else 0.0)
+def algorithmic_flops_per_ref(N=64, n_strings=9, sam=True, gem=False, clip_name="ViT-B/16"):
+    """SURVEY.md 8d, minimal variant (dead final-block streams removed), G2L: the two streams run through the blocks
+    below the masking block and the two-stream blocks, the returning block on one stream (ViT-B/16: 23 N block
+    evaluations of 2.908 GFLOP; ViT-L/14: 47 N of 6.738 GFLOP).  SAM ViT-H encoder 5.961 TFLOP + decoder 3.62 GFLOP
+    x 64 prompts; + the GEM heat-map stage when it runs here."""
+    g = CLIP_GEOM[clip_name]
+    S, D = g["S"], g["D"]
+    blk = 2.0 * S * D * 12 * D + 4.0 * S * S * D          # ViT-B/16: 2.908e9 (qkv .697, proj .232, mlp 1.859, attn .119)
+    patch = 2.0 * (S - 1) * g["patch_k"] * D               # ViT-B/16: 0.231e9
+    n_blk = 2 * g["last_layer"] + 3                        # 2 * masking_block + 2 * (last_layer + 1 - masking_block) + 1
+    clip = 2 * N * patch + n_blk * N * blk
+    tD = g["text_D"]
+    text = (12 * (2.0 * 77 * tD * 12 * tD + 4.0 * 77 * 77 * tD) + 2.0 * tD * g["embed"]) * (n_strings + (3 if gem else 0))
+    gem_fl = gem_flops_per_image(g["gem_S"], D, g["layers"], 6, g["patch_k"], g["embed"]) if gem else 0.0
+    return clip + text + ((5.961e12 + 64 * 3.62e9) if sam else 0.0) + gem_fl
 
 
 def roofline(precision, nprof, g, x, a, traffic, whole_tflops, xg=(0, 0.0, 0.0), few=(0, 0.0, 0.0)):
@@ -142,13 +158,14 @@ def cpu_baseline_sam():
                    f"decoder on 2 of 64 prompts {t5 - t4:.1f}s x32, post-process 6 of 192 {t6 - t5:.1f}s x32")
 
 
-def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False):
+def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False, clip_name="ViT-B/16"):
     """Oracle (numpy port of the reference algorithm, oracle/clip_oracle.py) timed on the host
     cores for a bounded sample of the same workload; extrapolated to one ref."""
     from hybridgl_amd import synth, weights
     from oracle import clip_oracle as O
     threads = os.cpu_count() or 1
-    sd = weights.clip_state_dict("ViT-B/16", 0)
+    geom = CLIP_GEOM[clip_name]
+    sd = weights.clip_state_dict(clip_name, 0)
     H = W = 640
     img = synth.synth_image(H, W, 1000)
     from oracle import cv_oracle as CV
@@ -161,9 +178,9 @@ def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False):
     t0 = time.perf_counter()
     loc, glo = O.synthesize_views(img, blur, norm, masks[:n_sample], 224)
     t1 = time.perf_counter()
-    feats = O.clip_hybrid_forward(sd, loc, glo, masks[:n_sample], 9, fusion_mode, 10)
+    feats = O.clip_hybrid_forward(sd, loc, glo, masks[:n_sample], geom["masking_block"], fusion_mode, geom["last_layer"])
     t2 = time.perf_counter()
-    text = O.encode_text(sd, tokens, heads=8)
+    text = O.encode_text(sd, tokens, heads=geom["text_D"] // 64)
     t3 = time.perf_counter()
     hyb = np.concatenate([feats] * (64 // n_sample), 0)
     for j in range(3):
@@ -205,6 +222,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--fusion", default="G2L", choices=["G2L", "L2G", "G2L&L2G"])
+    ap.add_argument("--clip", default="ViT-B/16", choices=list(CLIP_GEOM),
+                    help="CLIP geometry: ViT-B/16 = the reference's configuration; ViT-L/14 = the extension BASELINE.json names")
     ap.add_argument("--masks", type=int, default=64)
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic refs resident per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -243,7 +262,8 @@ def main():
     from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
 
     lib = _lib.load()
-    model = CLIPViTFM("ViT-B/16", seed=0, device=dev)
+    geom = CLIP_GEOM[args.clip]
+    model = CLIPViTFM(args.clip, seed=0, device=dev)
     gen = None
     if args.scope == "B":
         from hybridgl_amd.sam import SamAutomaticMaskGenerator, sam_model_registry
@@ -261,9 +281,9 @@ def main():
     if use_gem:
         # Hybridgl_main.py:36-38: the same OpenAI ViT-B/16 checkpoint as the CLIP stage -> shared device weights
         from hybridgl_amd.gem import create_gem_model
-        gem_model = create_gem_model("ViT-B/16", clip=model)
+        gem_model = create_gem_model(args.clip, clip=model)
     # the CLIP stage scores the 64 seeded proposals (fixed N, meaningful shapes)
-    pipe = HybridGLPipeline(model, fusion_mode=args.fusion, masking_block=9, mask_generator=gen, use_sam_masks=False,
+    pipe = HybridGLPipeline(model, fusion_mode=args.fusion, masking_block=geom["masking_block"], mask_generator=gen, use_sam_masks=False,
                             fixed_proposals=None, cleanup_given_masks=gen is not None, gem_model=gem_model)
     # rank r owns refs i = r (mod world) of the shuffle=False order
     refs = [synthetic_ref(rank + world * j, dev, N=args.masks, sam_img_size=1024 if gen else 0, gem=use_gem,
@@ -368,26 +388,27 @@ def main():
                                 "discarded; connected-component clean-up (min area 800) + second NMS run on the 64 "
                                 "seeded proposal-shaped masks; the Pillow-exact resize to 1024 runs on the device inside "
                                 "the step) + " if args.scope == "B" else "proposals given (scope A) + ")
-                             + ("15x15 Gaussian blur (cv2 fixed-point) + " if args.blur == "device" else "") + f"view synthesis + CLIP ViT-B/16 hybrid {args.fusion} (masking_block 9) on "
+                             + ("15x15 Gaussian blur (cv2 fixed-point) + " if args.blur == "device" else "") + f"view synthesis + CLIP {args.clip} hybrid {args.fusion} (masking_block {geom['masking_block']}) on "
                              f"{args.masks} seeded proposals + text encoder ({12 if use_gem else 9} strings) + "
-                             + ("GEM heat-map stage (ViT-B/16 at 448x448, self-self attention in the last 6 blocks, once "
+                             + (f"GEM heat-map stage ({args.clip} at 448x448, self-self attention in the last 6 blocks, once "
                                 "per image; 3 prompts -> 3 maps, antialiased resize to the image) + " if use_gem else
                                 "heat-maps given + ")
                              + "scoring tail + IoU"),
                 "scope": args.scope,
                 "heatmap": args.heatmap,
                 "stage_overlap": bool(overlap),
+                "clip": args.clip,
                 "fusion_mode": args.fusion, "proposals": args.masks, "image": "640x640", "queries": 3,
                 "parallelism": f"image-parallel x{world}",
             },
             "roofline": roofline(precision, nprof, (g_n, g_ms, g_fl), (x_n, x_ms, x_fl), (a_n, a_ms, a_fl), traffic,
-                                 algorithmic_flops_per_ref(args.masks, sam=args.scope == "B", gem=use_gem) / (dt / args.steps) / 1e12,
+                                 algorithmic_flops_per_ref(args.masks, sam=args.scope == "B", gem=use_gem, clip_name=args.clip) / (dt / args.steps) / 1e12,
                                  xg=(xg_n, xg_ms, xg_fl), few=(fw_n, fw_ms, fw_fl)),
             "precision": precision,
             "metrics": m,
         }
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(args.fusion, with_sam=args.scope == "B", with_gem=use_gem)
+            rec["cpu_baseline"] = cpu_baseline(args.fusion, with_sam=args.scope == "B", with_gem=use_gem, clip_name=args.clip)
         print(json.dumps(rec))
     if world > 1:
         dist.destroy_process_group()
