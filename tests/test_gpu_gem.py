@@ -83,6 +83,20 @@ def test_b32_geometry_vs_oracle(cuda):
     torch.cuda.empty_cache()
 
 
+def test_l14_geometry_vs_oracle(cuda):
+    """the extension geometry BASELINE.json names: ViT-L/14 (width 1024, 24 layers, 16 heads, patch 14 -> the
+    patch-embedding GEMM stays fp32: K = 588), at 280 x 280 (16x16 position grid interpolated to 20x20, 401 tokens)"""
+    sd = weights.clip_state_dict("ViT-L/14", 0)
+    gm = G.create_gem_model("ViT-L/14", state_dict=sd, device=cuda)
+    img = np.random.default_rng(41).standard_normal((3, 280, 280)).astype(np.float32)
+    feat = gm.image_features(torch.from_numpy(img).to(cuda)).cpu().numpy()
+    rg, _ = GO.gem_vit_forward(sd, img[None])
+    assert feat.shape == (401, 768)
+    np.testing.assert_allclose(feat, rg[0], rtol=0, atol=3e-4)
+    del gm
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("h,w,H,W", [(448, 448, 480, 640), (448, 448, 300, 400), (448, 448, 640, 427), (64, 64, 37, 91),
                                      (448, 448, 448, 448), (32, 32, 5, 200)])
 def test_resize_antialias_vs_torch(cuda, h, w, H, W):
