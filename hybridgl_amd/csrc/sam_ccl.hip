@@ -305,8 +305,6 @@ __global__ void box_final_kernel(int* b, int N) {
   if (b[n * 4 + 2] < 0) { b[n * 4 + 0] = 0; b[n * 4 + 1] = 0; b[n * 4 + 2] = 0; b[n * 4 + 3] = 0; }
 }
 
-inline unsigned g1(long long n) { return (unsigned)((n + 255) / 256); }
-
 }  // namespace
 
 extern "C" {
