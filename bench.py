@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 path on a box "
                          "with fewer GPUs than ranks)")
+    ap.add_argument("--sam-batch", type=int, default=2, choices=[1, 2],
+                    help="images per SAM encoder pass in the overlapped pipeline (2: the proposal stage of refs i+1 and i+2 "
+                         "shares one encoder pass; steps are then taken two at a time)")
     ap.add_argument("--scope", default="B", choices=["A", "B"],
                     help="A: proposals given (CLIP + scoring only); B: + SAM ViT-H proposal stage (full path)")
     args = ap.parse_args()
@@ -296,6 +299,8 @@ def main():
 
     overlap = gen is not None and not args.no_overlap
 
+    pair = overlap and args.sam_batch == 2
+
     def do_step(i):
         # one step = one ref completed: its SAM stage + its CLIP/scoring stage.  With overlap the two
         # stages of consecutive refs run concurrently on two streams (software pipeline over refs).
@@ -304,14 +309,24 @@ def main():
         else:
             pipe.step(refs[i % len(refs)])
 
-    for i in range(args.warmup):
-        do_step(i)
+    def do_steps(k):
+        # k steps = k refs completed (k SAM stages + k CLIP stages).  In pair mode two refs are taken per call: one
+        # SAM encoder pass over both prefetched images, the two CLIP stages back to back; an odd k ends with a single.
+        i = 0
+        while pair and i + 1 < k:
+            pipe.step_overlapped_pair([refs[i % len(refs)], refs[(i + 1) % len(refs)]],
+                                      [refs[(i + 2) % len(refs)], refs[(i + 3) % len(refs)]])
+            i += 2
+        while i < k:
+            do_step(i)
+            i += 1
+
+    do_steps(args.warmup)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        do_step(i)
+    do_steps(args.steps)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -397,6 +412,7 @@ def main():
                 "scope": args.scope,
                 "heatmap": args.heatmap,
                 "stage_overlap": bool(overlap),
+                "sam_images_per_encoder_pass": 2 if pair else 1,
                 "clip": args.clip,
                 "fusion_mode": args.fusion, "proposals": args.masks, "image": "640x640", "queries": 3,
                 "parallelism": f"image-parallel x{world}",

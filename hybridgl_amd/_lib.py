@@ -132,6 +132,9 @@ PROTOTYPES = {
     "hgl_resize_pil_bilinear": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _SZ, _VP]),
     "hgl_sam_encode_workspace_bytes": (_SZ, [C.POINTER(HglSamEncoderW)]),
     "hgl_sam_encode": (_I, [C.POINTER(HglSamEncoderW), _VP, _I, _I, _VP, _VP, _SZ, _VP]),
+    "hgl_sam_encode_batch_workspace_bytes": (_SZ, [C.POINTER(HglSamEncoderW), _I]),
+    "hgl_sam_encode_batch": (_I, [C.POINTER(HglSamEncoderW), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), _I,
+                                  _VP, _VP, _SZ, _VP]),
     "hgl_sam_dense_pe": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _VP]),
     "hgl_sam_decode_workspace_bytes": (_SZ, [C.POINTER(HglSamDecoderW), _I]),
     "hgl_sam_decode_points": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _I, _VP, _VP, _VP, _SZ, _VP]),

@@ -137,7 +137,7 @@ int hgl_launch_pe(const float* coords01, const float* G, int n, int F, int mode,
                   const float* not_a_point, float* out, hipStream_t st);
 int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const float* sparse, int P, int C,
                             float* tokens, hipStream_t st);
-int hgl_launch_win_maps(int g, int ws, int nw, int* pad_of, int* tok_of, int* pad_list, int* pad_count, hipStream_t st);
+int hgl_launch_win_maps(int g, int ws, int nw, int nb, int* pad_of, int* tok_of, int* pad_list, int* pad_count, hipStream_t st);
 int hgl_launch_fill_rows(float* dst, int ld, const int* rows, const int* nrows, int max_rows, const float* v, int N,
                          hipStream_t st);
 int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long rows, float eps, void* hi, void* lo,

@@ -15,11 +15,12 @@ struct EncPlan {
   float *img, *cols, *X, *H, *Hw, *QKV, *O, *P, *F, *Th, *Tw, *relh, *relw, *neckA, *neckB, *cols3;
   int *pad_of, *tok_of, *pad_list, *pad_count;   // row maps of the padded window partition (win_maps_kernel)
   int n_pad_max;
+  int nb;                                         // images stacked along the token rows
 };
 
-bool carve_enc(HglArena& ar, const HglSamEncoderW* w, EncPlan& p) {
+bool carve_enc(HglArena& ar, const HglSamEncoderW* w, int nb, EncPlan& p) {
   const int D = w->embed_dim, S = w->img_size, g = S / w->patch, C = w->out_chans;
-  const size_t T = (size_t)g * g;
+  const size_t T = (size_t)nb * g * g;
   // windowed blocks pad the grid up to a multiple of the window size
   size_t Tw_max = T;
   int rl_max = 0;
@@ -27,11 +28,12 @@ bool carve_enc(HglArena& ar, const HglSamEncoderW* w, EncPlan& p) {
     const int ws = w->blocks[i].window;
     if (ws > 0) {
       const size_t nw = (g + ws - 1) / ws;
-      Tw_max = Tw_max > nw * nw * ws * ws ? Tw_max : nw * nw * ws * ws;
+      Tw_max = Tw_max > nb * nw * nw * ws * ws ? Tw_max : nb * nw * nw * ws * ws;
     }
     rl_max = rl_max > w->blocks[i].rel_len ? rl_max : w->blocks[i].rel_len;
   }
-  p.img = ar.take<float>((size_t)3 * S * S);
+  p.nb = nb;
+  p.img = ar.take<float>((size_t)nb * 3 * S * S);
   p.cols = ar.take<float>(T * 3 * w->patch * w->patch);
   p.X = ar.take<float>(T * D);
   p.H = ar.take<float>(T * D);
@@ -65,12 +67,15 @@ bool valid_enc(const HglSamEncoderW* w) {
 // Block.forward (modeling/image_encoder.py:166-182)
 int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, hipStream_t st) {
   const int D = w->embed_dim, g = w->img_size / w->patch, heads = w->heads, hd = D / heads;
-  const int T = g * g;
+  const int T1 = g * g;                   // tokens of one image
+  const int T = p.nb * T1;                // token rows of the batch (images stacked along the rows)
   const int ws = b.window;
   const int size = ws > 0 ? ws : g;       // attention grid side
   const int nw = ws > 0 ? (g + ws - 1) / ws : 1;
-  const int B = nw * nw;                  // windows (1 for global attention)
+  const int B1 = nw * nw;                 // windows of one image (1 for global attention)
+  const int B = p.nb * B1;
   const int S = size * size;              // tokens per window
+  const int M1 = B1 * S;                  // padded rows of one image
   const int M = B * S;
   const int L = b.rel_len;
   HGL_REQUIRE(L == 2 * size - 1, "sam_encode: rel_pos length %d does not match attention size %d", L, size);
@@ -92,7 +97,9 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
       HGL_TRY(hgl_launch_layernorm_split_maps(p.X, b.norm1_w, b.norm1_b, Ah, Al, T, D, 1e-6f, p.tok_of, p.pad_of, st));
     } else if (ws > 0) {
       HGL_TRY(hgl_launch_layernorm(p.X, b.norm1_w, b.norm1_b, p.H, T, D, 1e-6f, st));
-      HGL_TRY(hgl_launch_win_partition_split(p.H, g, ws, nw, D, Ah, Al, st));
+      for (int i = 0; i < p.nb; ++i)
+        HGL_TRY(hgl_launch_win_partition_split(p.H + (size_t)i * T1 * D, g, ws, nw, D, Ah + (size_t)i * M1 * D,
+                                               Al + (size_t)i * M1 * D, st));
     } else {
       HGL_TRY(hgl_launch_layernorm_split(p.X, b.norm1_w, b.norm1_b, Ah, Al, T, D, 1e-6f, st));
     }
@@ -109,7 +116,8 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
     HGL_TRY(hgl_launch_layernorm(p.X, b.norm1_w, b.norm1_b, p.H, T, D, 1e-6f, st));
     const float* A = p.H;
     if (ws > 0) {
-      HGL_TRY(hgl_launch_win_partition(p.H, g, ws, nw, D, p.Hw, st));
+      for (int i = 0; i < p.nb; ++i)
+        HGL_TRY(hgl_launch_win_partition(p.H + (size_t)i * T1 * D, g, ws, nw, D, p.Hw + (size_t)i * M1 * D, st));
       A = p.Hw;
     }
     HGL_TRY(hgl_launch_gemm(A, b.qkv_w, b.qkv_b, nullptr, p.QKV, M, 3 * D, D, D, D, 0, 3 * D, 1, 0, 0, 0, 0,
@@ -149,7 +157,8 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
     } else if (ws > 0) {
       HGL_TRY(hgl_launch_gemm_f16x3(Ah, Al, D, b.proj_w, b.proj_b, nullptr, 0, p.P, nullptr, nullptr, D, M, D, D,
                                     HGL_ACT_NONE, st));
-      HGL_TRY(hgl_launch_win_unpartition_add(p.X, g, ws, nw, D, p.P, st));
+      for (int i = 0; i < p.nb; ++i)
+        HGL_TRY(hgl_launch_win_unpartition_add(p.X + (size_t)i * T1 * D, g, ws, nw, D, p.P + (size_t)i * M1 * D, st));
     } else {
       HGL_TRY(hgl_launch_gemm_f16x3(Ah, Al, D, b.proj_w, b.proj_b, p.X, D, p.X, nullptr, nullptr, D, T, D, D,
                                     HGL_ACT_NONE, st));
@@ -174,7 +183,8 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
   if (ws > 0) {
     HGL_TRY(hgl_launch_gemm(p.O, b.proj_w, b.proj_b, nullptr, p.P, M, D, D, D, D, 0, D, 1, 0, 0, 0, 0,
                             HGL_ACT_NONE, st));
-    HGL_TRY(hgl_launch_win_unpartition_add(p.X, g, ws, nw, D, p.P, st));
+    for (int i = 0; i < p.nb; ++i)
+      HGL_TRY(hgl_launch_win_unpartition_add(p.X + (size_t)i * T1 * D, g, ws, nw, D, p.P + (size_t)i * M1 * D, st));
   } else {
     HGL_TRY(hgl_launch_gemm(p.O, b.proj_w, b.proj_b, p.X, p.X, T, D, D, D, D, D, D, 1, 0, 0, 0, 0,
                             HGL_ACT_NONE, st));
@@ -324,46 +334,54 @@ int dec_t2i_x3(const HglSamDecoderW* w, const HglSamAttnW& a, const float* qpe, 
 
 extern "C" {
 
-size_t hgl_sam_encode_workspace_bytes(const HglSamEncoderW* w) {
-  if (!valid_enc(w)) return 0;
+size_t hgl_sam_encode_batch_workspace_bytes(const HglSamEncoderW* w, int nb) {
+  if (!valid_enc(w) || nb < 1) return 0;
   HglArena ar(nullptr, 0);
   EncPlan p;
-  carve_enc(ar, w, p);
+  carve_enc(ar, w, nb, p);
   return ar.off;
 }
 
-int hgl_sam_encode(const HglSamEncoderW* w, const uint8_t* resized_img, int in_h, int in_w, float* emb,
-                   void* workspace, size_t workspace_bytes, void* stream) {
+size_t hgl_sam_encode_workspace_bytes(const HglSamEncoderW* w) { return hgl_sam_encode_batch_workspace_bytes(w, 1); }
+
+// nb images through the encoder at once: the token rows of the images are stacked, so every GEMM / LayerNorm / window
+// attention launch covers all of them (weights read once, M = nb * 4096: the tilings fill the chip better and mlp.lin2
+// needs no split-K).  Each image's result is what the single-image call gives up to the summation order of split-K.
+int hgl_sam_encode_batch(const HglSamEncoderW* w, const uint8_t* const* resized_imgs, const int* in_h, const int* in_w, int nb,
+                         float* emb, void* workspace, size_t workspace_bytes, void* stream) {
   HGL_TRY(hgl_require_device());
   HGL_REQUIRE(valid_enc(w), "sam_encode: invalid weight struct");
-  HGL_REQUIRE(resized_img && emb && in_h > 0 && in_w > 0 && in_h <= w->img_size && in_w <= w->img_size,
-              "sam_encode: bad image (%dx%d for img_size %d)", in_h, in_w, w->img_size);
+  HGL_REQUIRE(resized_imgs && in_h && in_w && emb && nb >= 1 && nb <= 64, "sam_encode: bad arguments (nb %d)", nb);
+  for (int i = 0; i < nb; ++i)
+    HGL_REQUIRE(resized_imgs[i] && in_h[i] > 0 && in_w[i] > 0 && in_h[i] <= w->img_size && in_w[i] <= w->img_size,
+                "sam_encode: bad image %d (%dx%d for img_size %d)", i, in_h[i], in_w[i], w->img_size);
   HglArena ar(workspace, workspace_bytes);
   EncPlan p;
-  if (!workspace || !carve_enc(ar, w, p)) {
+  if (!workspace || !carve_enc(ar, w, nb, p)) {
     hgl_set_error("sam_encode: workspace too small (%zu bytes given)", workspace_bytes);
     return HGL_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int D = w->embed_dim, S = w->img_size, g = S / w->patch, C = w->out_chans, T = g * g;
+  const int D = w->embed_dim, S = w->img_size, g = S / w->patch, C = w->out_chans, T1 = g * g, T = nb * T1;
   const int kd = 3 * w->patch * w->patch;
-  HGL_TRY(hgl_launch_sam_preprocess(resized_img, in_h, in_w, S, p.img, st));
-  // patch embedding + bias + absolute position embedding (image_encoder.py:107-109)
+  for (int i = 0; i < nb; ++i)
+    HGL_TRY(hgl_launch_sam_preprocess(resized_imgs[i], in_h[i], in_w[i], S, p.img + (size_t)i * 3 * S * S, st));
+  // patch embedding + bias + absolute position embedding (image_encoder.py:107-109); the position rows repeat per image
   if ((w->patch & 3) == 0 && hgl_use_x3(w->patch_w, kd)) {
     uint16_t* ch = (uint16_t*)p.cols;            // im2col written as fp16 hi | lo planes (same bytes as fp32)
     uint16_t* cl = ch + (size_t)T * kd;
-    HGL_TRY(hgl_launch_im2col_patch_split(p.img, 1, S, w->patch, ch, cl, st));
-    HGL_TRY(hgl_launch_gemm_f16x3(ch, cl, kd, w->patch_w, w->patch_b, w->pos_embed, D, p.X, nullptr, nullptr, D, T, D, kd,
-                                  HGL_ACT_NONE, st));
+    HGL_TRY(hgl_launch_im2col_patch_split(p.img, nb, S, w->patch, ch, cl, st));
+    HGL_TRY(hgl_launch_gemm_f16x3_rmod(ch, cl, kd, w->patch_w, w->patch_b, w->pos_embed, D, nb > 1 ? T1 : 0, p.X, nullptr,
+                                       nullptr, D, T, D, kd, HGL_ACT_NONE, st));
   } else {
-    HGL_TRY(hgl_launch_im2col_patch(p.img, 1, S, w->patch, p.cols, st));
-    HGL_TRY(hgl_launch_gemm(p.cols, w->patch_w, w->patch_b, w->pos_embed, p.X, T, D, kd, kd, kd, D, D, 1, 0, 0, 0, 0,
-                            HGL_ACT_NONE, st));
+    HGL_TRY(hgl_launch_im2col_patch(p.img, nb, S, w->patch, p.cols, st));
+    HGL_TRY(hgl_launch_gemm(p.cols, w->patch_w, w->patch_b, w->pos_embed, p.X, T1, D, kd, kd, kd, D, D, nb,
+                            (long long)T1 * kd, 0, 0, (long long)T1 * D, HGL_ACT_NONE, st));
   }
   for (int i = 0; i < w->depth; ++i) {
     const int ws = w->blocks[i].window;
     if (ws > 0) {   // every windowed block shares one window size (build_sam.py:55-101)
-      HGL_TRY(hgl_launch_win_maps(g, ws, (g + ws - 1) / ws, p.pad_of, p.tok_of, p.pad_list, p.pad_count, st));
+      HGL_TRY(hgl_launch_win_maps(g, ws, (g + ws - 1) / ws, nb, p.pad_of, p.tok_of, p.pad_list, p.pad_count, st));
       break;
     }
   }
@@ -381,7 +399,8 @@ int hgl_sam_encode(const HglSamEncoderW* w, const uint8_t* resized_img, int in_h
                             HGL_ACT_NONE, st));
   }
   HGL_TRY(hgl_launch_layernorm(p.neckA, w->neck1_w, w->neck1_b, p.neckB, T, C, 1e-6f, st));
-  HGL_TRY(hgl_launch_im2col3x3(p.neckB, g, C, p.cols3, st));
+  for (int i = 0; i < nb; ++i)
+    HGL_TRY(hgl_launch_im2col3x3(p.neckB + (size_t)i * T1 * C, g, C, p.cols3 + (size_t)i * T1 * C * 9, st));
   if (neck_x3 && (size_t)C * 9 <= (size_t)4 * D) {
     uint16_t* ch = (uint16_t*)p.F;
     uint16_t* cl = ch + (size_t)T * C * 9;
@@ -394,6 +413,11 @@ int hgl_sam_encode(const HglSamEncoderW* w, const uint8_t* resized_img, int in_h
   }
   HGL_TRY(hgl_launch_layernorm(p.neckA, w->neck3_w, w->neck3_b, emb, T, C, 1e-6f, st));
   return HGL_OK;
+}
+
+int hgl_sam_encode(const HglSamEncoderW* w, const uint8_t* resized_img, int in_h, int in_w, float* emb,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  return hgl_sam_encode_batch(w, &resized_img, &in_h, &in_w, 1, emb, workspace, workspace_bytes, stream);
 }
 
 int hgl_sam_dense_pe(const HglSamDecoderW* w, const float* grid_coords01, float* dense_pe, void* stream) {

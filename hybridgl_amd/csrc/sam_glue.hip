@@ -155,21 +155,24 @@ __global__ __launch_bounds__(256) void relpos_direct_kernel(const float* __restr
 // at padded row pad_of[r] = window*ws*ws + position and at token-order row tok_of[r] = y*g + x; pad_list collects
 // the padded rows that hold no token.  The f16x3 GEMMs of a windowed block run over the real tokens only: the pad
 // rows of qkv are the bias (filled by fill_rows_kernel) and the pad rows of the projection are never needed.
-__global__ __launch_bounds__(256) void win_maps_kernel(int g, int ws, int nw, int* __restrict__ pad_of,
+__global__ __launch_bounds__(256) void win_maps_kernel(int g, int ws, int nw, int nb, int* __restrict__ pad_of,
                                                        int* __restrict__ tok_of, int* __restrict__ pad_list,
                                                        int* __restrict__ pad_count) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= nw * nw * ws * ws) return;
+  // nb images stacked along the rows: image i owns token rows [i*g*g, (i+1)*g*g) and padded rows [i*Tw, (i+1)*Tw)
+  const int Tw = nw * nw * ws * ws;
+  const int gidx = blockIdx.x * 256 + threadIdx.x;
+  if (gidx >= nb * Tw) return;
+  const int img = gidx / Tw, idx = gidx - img * Tw;
   const int w = idx / (ws * ws), p = idx - w * ws * ws;
   const int wy = w / nw, wx = w - wy * nw, py = p / ws, px = p - py * ws;
   const int y = wy * ws + py, x = wx * ws + px;
   if (y < g && x < g) {
     const int rh = min(ws, g - wy * ws), rw = min(ws, g - wx * ws);
-    const int r = wy * ws * g + rh * (wx * ws) + py * rw + px;
-    pad_of[r] = idx;
-    tok_of[r] = y * g + x;
+    const int r = img * g * g + wy * ws * g + rh * (wx * ws) + py * rw + px;
+    pad_of[r] = gidx;
+    tok_of[r] = img * g * g + y * g + x;
   } else {
-    pad_list[atomicAdd(pad_count, 1)] = idx;
+    pad_list[atomicAdd(pad_count, 1)] = gidx;
   }
 }
 
@@ -771,13 +774,13 @@ int hgl_launch_relpos_direct(const float* qkv, int ldq, int B, int heads, int S,
   else hipLaunchKernelGGL(relpos_direct_kernel<64>, grid, dim3(256), lds, st, qkv, ldq, heads, S, size, Rh, Rw, rel_h, rel_w);
   return hgl_check_launch("relpos_direct");
 }
-int hgl_launch_win_maps(int g, int ws, int nw, int* pad_of, int* tok_of, int* pad_list, int* pad_count, hipStream_t st) {
+int hgl_launch_win_maps(int g, int ws, int nw, int nb, int* pad_of, int* tok_of, int* pad_list, int* pad_count, hipStream_t st) {
   if (hipMemsetAsync(pad_count, 0, sizeof(int), st) != hipSuccess) {
     hgl_set_error("win_maps: memset failed");
     return HGL_ELAUNCH;
   }
-  hipLaunchKernelGGL(win_maps_kernel, dim3(grid1((long long)nw * nw * ws * ws)), dim3(256), 0, st, g, ws, nw, pad_of, tok_of,
-                     pad_list, pad_count);
+  hipLaunchKernelGGL(win_maps_kernel, dim3(grid1((long long)nb * nw * nw * ws * ws)), dim3(256), 0, st, g, ws, nw, nb, pad_of,
+                     tok_of, pad_list, pad_count);
   return hgl_check_launch("win_maps");
 }
 int hgl_launch_fill_rows(float* dst, int ld, const int* rows, const int* nrows, int max_rows, const float* v, int N,

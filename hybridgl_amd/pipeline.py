@@ -129,6 +129,40 @@ class HybridGLPipeline:
         cur.wait_event(e2)
         return out
 
+    def step_overlapped_pair(self, refs, next_refs):
+        """step_overlapped for two refs at a time: ONE SAM encoder pass over the images of both `next_refs`
+        (Sam.encode_batch: token rows stacked, weights read once, GEMMs at M = 8192) runs on the SAM stream while
+        the CLIP + scoring stages of the two `refs` run back to back on the CLIP stream.  Same work and same
+        results per ref as two step_overlapped calls (up to the summation order of the encoder's split-K)."""
+        if not hasattr(self, "_s_sam"):
+            self._s_sam, self._s_clip = torch.cuda.Stream(), torch.cuda.Stream()
+            self._ev = torch.cuda.Event()
+        cur = torch.cuda.current_stream()
+        self._ev.record(cur)
+        self._s_sam.wait_event(self._ev)
+        self._s_clip.wait_event(self._ev)
+        gen = self.mask_generator
+        with torch.cuda.stream(self._s_sam):
+            self.last_proposals = gen.propose_batch([r.sam_img for r in next_refs])[-1]
+        outs = []
+        with torch.cuda.stream(self._s_clip):
+            self.mask_generator = None          # the CLIP stage below must not re-run the SAM stage
+            try:
+                for ref in refs:
+                    if self.cleanup_given_masks:
+                        import dataclasses
+                        cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
+                        ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
+                    outs.append(self.step(ref))
+            finally:
+                self.mask_generator = gen
+        e1, e2 = torch.cuda.Event(), torch.cuda.Event()
+        e1.record(self._s_sam)
+        e2.record(self._s_clip)
+        cur.wait_event(e1)
+        cur.wait_event(e2)
+        return outs
+
     def step(self, ref: RefBatch):
         """One dataset item; returns the device tensors of the last sentence (idx, scores)."""
         import dataclasses

@@ -169,6 +169,23 @@ class Sam:
                                  emb.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "hgl_sam_encode")
         return emb
 
+    def encode_batch(self, resized_list):
+        """several images through the encoder at once (token rows stacked: weights read once, better-filled GEMMs).
+        resized_list: [h_i,w_i,3] uint8 device tensors -> emb [nb, g*g, C]; each slice equals encode() of that image
+        up to the summation order of split-K."""
+        lib = _lib.load()
+        nb = len(resized_list)
+        imgs = [r.contiguous() for r in resized_list]
+        ptrs = (C.c_void_p * nb)(*[ops._dev(r, torch.uint8, "resized_img") for r in imgs])
+        hs = (C.c_int * nb)(*[int(r.shape[0]) for r in imgs])
+        wsz = (C.c_int * nb)(*[int(r.shape[1]) for r in imgs])
+        need = lib.hgl_sam_encode_batch_workspace_bytes(C.byref(self.enc_w), nb)
+        ws = ops.workspace(need, self.device, "sam_encode")
+        emb = torch.empty((nb, self.grid * self.grid, self.cfg["out_chans"]), dtype=torch.float32, device=self.device)
+        check(lib.hgl_sam_encode_batch(C.byref(self.enc_w), ptrs, hs, wsz, nb, emb.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       ops._stream()), "hgl_sam_encode_batch")
+        return emb
+
     def decode_points(self, emb, points01):
         """points01: [P,2] fp32 device ((point+0.5)/img_size) -> (low_res [P,3,4g,4g], iou [P,3])."""
         lib = _lib.load()
@@ -496,6 +513,23 @@ class SamAutomaticMaskGenerator:
             dev_img = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image)).to(m.device)
             resized = resize_longest_side(dev_img.contiguous(), m.img_size)
         emb = m.encode(resized)
+        return self._propose_from_embedding(emb, H, W, nh, nw, layer_idx, crop_box, orig_size)
+
+    def propose_batch(self, images):
+        """propose() for several whole images with ONE encoder pass over all of them (Sam.encode_batch); decoder,
+        post-processing and NMS per image.  Returns the list of propose() tuples."""
+        m = self.model
+        sizes, resized = [], []
+        for image in images:
+            H, W = image.shape[:2]
+            dev_img = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image)).to(m.device)
+            sizes.append((H, W) + get_preprocess_shape(H, W, m.img_size))
+            resized.append(resize_longest_side(dev_img.contiguous(), m.img_size))
+        emb = m.encode_batch(resized)
+        return [self._propose_from_embedding(emb[i], *sizes[i], 0, None, None) for i in range(len(images))]
+
+    def _propose_from_embedding(self, emb, H, W, nh, nw, layer_idx, crop_box, orig_size):
+        m = self.model
         pts = self.point_grids[layer_idx] * np.array([[W, H]], dtype=np.float64)   # automatic_mask_generator.py:240-241
         tp = pts.copy()
         tp[:, 0] *= nw / W                                                       # apply_coords, utils/transforms.py:33-45

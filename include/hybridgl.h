@@ -357,6 +357,12 @@ size_t hgl_sam_encode_workspace_bytes(const HglSamEncoderW* w);
 int hgl_sam_encode(const HglSamEncoderW* w, const uint8_t* resized_img, int in_h, int in_w, float* emb,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same for nb images at once (token rows stacked: every launch covers all images, weights read once).
+ * resized_imgs / in_h / in_w: HOST arrays of nb device pointers / sizes; emb [nb, g*g, out_chans]. */
+size_t hgl_sam_encode_batch_workspace_bytes(const HglSamEncoderW* w, int nb);
+int hgl_sam_encode_batch(const HglSamEncoderW* w, const uint8_t* const* resized_imgs, const int* in_h, const int* in_w,
+                         int nb, float* emb, void* workspace, size_t workspace_bytes, void* stream);
+
 /* get_dense_pe() (prompt_encoder.py:194-205): grid_coords01 [grid*grid,2] fp32 = ((x+1)-0.5)/grid,
  * ((y+1)-0.5)/grid; fills dense_pe [grid*grid, C]; call once per model. */
 int hgl_sam_dense_pe(const HglSamDecoderW* w, const float* grid_coords01, float* dense_pe, void* stream);

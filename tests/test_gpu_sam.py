@@ -386,3 +386,25 @@ def test_resize_longest_side_bit_exact_vs_pillow(cuda, shape):
     ref = np.array(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
     got = hsam.resize_longest_side(T(img, cuda), L).cpu().numpy()
     assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_encoder_batch_of_two_equals_single_images(cuda):
+    """hgl_sam_encode_batch: two images stacked along the token rows (windows of both images in one attention launch,
+    row maps with per-image offsets, position embedding shared through the residual modulo) == two single-image
+    passes.  Tiny geometry (fp32 GEMMs, windowed + global blocks) and the ViT-B width with 2 blocks (split-fp16 path,
+    pad-row skipping, split-K in the single-image pass only)."""
+    from hybridgl_amd.synth import synth_image
+    for name, tol in [("tiny", 1e-5), ("vit_b_d2", 2e-4)]:
+        cfg = weights.SAM_CONFIGS[name]
+        m = hsam.Sam(weights.sam_state_dict(name, 0), cfg, cuda)
+        S = cfg["img_size"]
+        a = T(synth_image(S, S, 3), cuda)
+        b = T(synth_image(S * 3 // 4, S, 4), cuda)          # a shorter image: zero-padded rows in its preprocess
+        ea, eb = m.encode(a), m.encode(b)
+        both = m.encode_batch([a, b])
+        assert both.shape == (2,) + tuple(ea.shape)
+        np.testing.assert_allclose(both[0].cpu().numpy(), ea.cpu().numpy(), rtol=0, atol=tol)
+        np.testing.assert_allclose(both[1].cpu().numpy(), eb.cpu().numpy(), rtol=0, atol=tol)
+        np.testing.assert_allclose(m.encode_batch([b])[0].cpu().numpy(), eb.cpu().numpy(), rtol=0, atol=0)
+        del m
+        torch.cuda.empty_cache()
