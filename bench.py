@@ -238,9 +238,12 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 path on a box "
                          "with fewer GPUs than ranks)")
-    ap.add_argument("--sam-batch", type=int, default=2, choices=[1, 2],
-                    help="images per SAM encoder pass in the overlapped pipeline (2: the proposal stage of refs i+1 and i+2 "
-                         "shares one encoder pass; steps are then taken two at a time)")
+    ap.add_argument("--sam-batch", type=int, default=8, choices=[1, 2, 4, 8],
+                    help="largest group of refs the overlapped pipeline takes at a time: ONE SAM encoder pass over the images "
+                         "of the next group (token rows stacked, weights read once) under ONE text-encoder batch + ONE hybrid "
+                         "forward over the masks of the current group; same work and same results per ref (1: ref by ref)")
+    ap.add_argument("--no-clip-group", action="store_true",
+                    help="grouped steps: one text-encoder batch + one hybrid forward per ref instead of one for the group")
     ap.add_argument("--scope", default="B", choices=["A", "B"],
                     help="A: proposals given (CLIP + scoring only); B: + SAM ViT-H proposal stage (full path)")
     args = ap.parse_args()
@@ -288,6 +291,7 @@ def main():
     # the CLIP stage scores the 64 seeded proposals (fixed N, meaningful shapes)
     pipe = HybridGLPipeline(model, fusion_mode=args.fusion, masking_block=geom["masking_block"], mask_generator=gen, use_sam_masks=False,
                             fixed_proposals=None, cleanup_given_masks=gen is not None, gem_model=gem_model)
+    pipe.group_clip = not args.no_clip_group
     # rank r owns refs i = r (mod world) of the shuffle=False order
     refs = [synthetic_ref(rank + world * j, dev, N=args.masks, sam_img_size=1024 if gen else 0, gem=use_gem,
                           device_blur=args.blur == "device")[0]
@@ -299,7 +303,8 @@ def main():
 
     overlap = gen is not None and not args.no_overlap
 
-    pair = overlap and args.sam_batch == 2
+    pair = overlap and args.sam_batch >= 2
+    nbatch = args.sam_batch
 
     def do_step(i):
         # one step = one ref completed: its SAM stage + its CLIP/scoring stage.  With overlap the two
@@ -310,13 +315,15 @@ def main():
             pipe.step(refs[i % len(refs)])
 
     def do_steps(k):
-        # k steps = k refs completed (k SAM stages + k CLIP stages).  In pair mode two refs are taken per call: one
-        # SAM encoder pass over both prefetched images, the two CLIP stages back to back; an odd k ends with a single.
+        # k steps = k refs completed (k SAM stages + k CLIP stages), taken in groups of up to --sam-batch refs: one
+        # SAM encoder pass over the group's prefetched images, one text batch + one hybrid forward for the group;
+        # what does not fill a group of two ends ref by ref.
         i = 0
-        while pair and i + 1 < k:
-            pipe.step_overlapped_pair([refs[i % len(refs)], refs[(i + 1) % len(refs)]],
-                                      [refs[(i + 2) % len(refs)], refs[(i + 3) % len(refs)]])
-            i += 2
+        while pair and k - i >= 2:
+            g = max(c for c in (2, 4, 8) if c <= min(nbatch, k - i))
+            pipe.step_overlapped_pair([refs[(i + j) % len(refs)] for j in range(g)],
+                                      [refs[(i + g + j) % len(refs)] for j in range(g)])
+            i += g
         while i < k:
             do_step(i)
             i += 1
@@ -412,7 +419,8 @@ def main():
                 "scope": args.scope,
                 "heatmap": args.heatmap,
                 "stage_overlap": bool(overlap),
-                "sam_images_per_encoder_pass": 2 if pair else 1,
+                "sam_images_per_encoder_pass": nbatch if pair else 1,
+                "refs_per_clip_forward": nbatch if pair and pipe.group_clip else 1,
                 "clip": args.clip,
                 "fusion_mode": args.fusion, "proposals": args.masks, "image": "640x640", "queries": 3,
                 "parallelism": f"image-parallel x{world}",

@@ -252,14 +252,18 @@ def score_sentence(hybrid, sentence_feat, noun_phrase_feat, other_noun_feats, bo
     return idx, sc, sn
 
 
-def synthesize_views(sam_img, blurred, image_norm, masks, res=224):
-    """Hybridgl_main.py:93-125 -> (local_imgs, global_imgs) [N,3,res,res] fp32."""
+def synthesize_views(sam_img, blurred, image_norm, masks, res=224, out=None):
+    """Hybridgl_main.py:93-125 -> (local_imgs, global_imgs) [N,3,res,res] fp32 (written into `out` when given)."""
     lib = _lib.load()
     N, H, W = masks.shape
     mp, masks = _u8(masks, "masks")
     dev = masks.device
-    loc = torch.empty((N, 3, res, res), dtype=torch.float32, device=dev)
-    glo = torch.empty((N, 3, res, res), dtype=torch.float32, device=dev)
+    if out is not None:
+        loc, glo = out
+        assert tuple(loc.shape) == (N, 3, res, res) == tuple(glo.shape) and loc.is_contiguous() and glo.is_contiguous()
+    else:
+        loc = torch.empty((N, 3, res, res), dtype=torch.float32, device=dev)
+        glo = torch.empty((N, 3, res, res), dtype=torch.float32, device=dev)
     check(lib.hgl_synthesize_views(_dev(sam_img, torch.uint8, "sam_img"), _dev(blurred, torch.uint8, "blurred"),
                                    _dev(image_norm, torch.float32, "image_norm"), mp, N, H, W, res,
                                    loc.data_ptr(), glo.data_ptr(), _stream()), "hgl_synthesize_views")

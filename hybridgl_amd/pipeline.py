@@ -83,6 +83,7 @@ class HybridGLPipeline:
         random SAM weights give an arbitrary number of proposals); True feeds the SAM proposals."""
         self.model = model
         self.gem_model = gem_model              # hybridgl_amd.gem.GEMWrapper: heat-maps computed on the device
+        self.group_clip = True                  # step_overlapped_pair: one text batch + one hybrid forward for its refs
         self.mask_generator = mask_generator
         self.use_sam_masks = use_sam_masks
         self.fixed_proposals = fixed_proposals
@@ -130,10 +131,11 @@ class HybridGLPipeline:
         return out
 
     def step_overlapped_pair(self, refs, next_refs):
-        """step_overlapped for two refs at a time: ONE SAM encoder pass over the images of both `next_refs`
-        (Sam.encode_batch: token rows stacked, weights read once, GEMMs at M = 8192) runs on the SAM stream while
-        the CLIP + scoring stages of the two `refs` run back to back on the CLIP stream.  Same work and same
-        results per ref as two step_overlapped calls (up to the summation order of the encoder's split-K)."""
+        """step_overlapped for a group of refs (2, 4, 8 ...) at a time: ONE SAM encoder pass over the images of all
+        `next_refs` (Sam.encode_batch: token rows stacked, weights read once, GEMMs at M = 4096 * group) runs on the
+        SAM stream while the CLIP + scoring stage of the `refs` runs on the CLIP stream (step_group: one text batch,
+        one hybrid forward).  Same work and same results per ref as step_overlapped ref by ref (up to the summation
+        order of the encoder's split-K)."""
         if not hasattr(self, "_s_sam"):
             self._s_sam, self._s_clip = torch.cuda.Stream(), torch.cuda.Stream()
             self._ev = torch.cuda.Event()
@@ -148,12 +150,14 @@ class HybridGLPipeline:
         with torch.cuda.stream(self._s_clip):
             self.mask_generator = None          # the CLIP stage below must not re-run the SAM stage
             try:
+                group = []
                 for ref in refs:
                     if self.cleanup_given_masks:
                         import dataclasses
                         cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
                         ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
-                    outs.append(self.step(ref))
+                    group.append(ref)
+                outs = self.step_group(group) if self.group_clip else [self.step(r) for r in group]
             finally:
                 self.mask_generator = gen
         e1, e2 = torch.cuda.Event(), torch.cuda.Event()
@@ -231,6 +235,11 @@ class HybridGLPipeline:
             if ref.image_id is not None:
                 self._cache_id, self._cache_ref, self._cache_hybrid = ref.image_id, ref, hybrid
         cur.wait_event(ev_text)
+        return hybrid, text, self._score_ref(ref, hybrid, text, heat)
+
+    def _score_ref(self, ref, hybrid, text, heat):
+        """the per-sentence tail of Hybridgl_main.py:153-230 for one ref; returns the tensors of its last sentence"""
+        m = self.model
         # the k1/k2 clamp of Hybridgl_main.py:178-181 persists across refs in the reference
         self.k1 = min(self.k1, hybrid.shape[0])
         self.k2 = min(self.k2, hybrid.shape[0])
@@ -253,7 +262,62 @@ class HybridGLPipeline:
             self.cum[2:4] += iu1
             self.iu_log.append((iu0, iu1))
             last = (idx, sc, sn, gem)
-        return hybrid, text, last
+        return last
+
+    def step_group(self, refs):
+        """Several refs whose proposals are given, with ONE text-encoder batch over the strings of all refs and ONE
+        hybrid forward over the masks of all refs (every mask row of CLIPViTFM.forward is independent, so the
+        concatenation changes nothing but the GEMM sizes: 2 x 64 masks -> M = 50432 rows, tile counts that fill
+        the chip evenly).  Falls back to step() per ref where that does not apply (in-step SAM, per-image cache,
+        refs of different mask sizes)."""
+        import dataclasses
+        m = self.model
+        same = all(r.masks.shape[1:] == refs[0].masks.shape[1:] and r.tokens.shape[1] == refs[0].tokens.shape[1] for r in refs)
+        if len(refs) == 1 or self.mask_generator is not None or not same or any(r.image_id is not None for r in refs):
+            return [self.step(r) for r in refs]
+        cur = torch.cuda.current_stream()
+        if not hasattr(self, "_s_text"):
+            self._s_text = torch.cuda.Stream()
+        ev_in, ev_text = torch.cuda.Event(), torch.cuda.Event()
+        ev_in.record(cur)
+        self._s_text.wait_event(ev_in)
+        offs = np.cumsum([0] + [r.tokens.shape[0] for r in refs])
+        heats = []
+        with torch.cuda.stream(self._s_text):
+            text_all = m.model.encode_text(torch.cat([r.tokens for r in refs], dim=0))
+            for i, ref in enumerate(refs):
+                text = text_all[offs[i]:offs[i + 1]]
+                gem_rows = [s.gem_row for s in ref.sentences if s.imgattn is None]
+                heat = None
+                if gem_rows:
+                    from . import gem as G
+                    if self.gem_model is None or ref.tensor_img is None or any(r is None for r in gem_rows):
+                        raise ValueError("a sentence without imgattn needs gem_model, RefBatch.tensor_img and Sentence.gem_row")
+                    gfeat = self.gem_model.image_features(ref.tensor_img)
+                    maps = self.gem_model.heatmap(gfeat, _rows(text, gem_rows), ref.tensor_img.shape[-1])
+                    heat = G.resize_antialias(maps, ref.sam_img.shape[:2])
+                    heat.record_stream(cur)
+                heats.append(heat)
+            ev_text.record(self._s_text)
+        text_all.record_stream(cur)
+        ns = [r.masks.shape[0] for r in refs]
+        moff = np.cumsum([0] + ns)
+        dev = refs[0].masks.device
+        local = torch.empty((int(moff[-1]), 3, self.res, self.res), dtype=torch.float32, device=dev)
+        glob = torch.empty_like(local)
+        for i, ref in enumerate(refs):
+            blurred = ref.blurred if ref.blurred is not None else ops.gaussian_blur_u8(ref.sam_img, 15)   # :99
+            ops.synthesize_views(ref.sam_img, blurred, ref.image_norm, ref.masks, self.res,
+                                 out=(local[moff[i]:moff[i + 1]], glob[moff[i]:moff[i + 1]]))
+        masks_all = torch.cat([r.masks for r in refs], dim=0)
+        hybrid_all = m(local, glob, masks_all, masking_block=self.masking_block, fusion_mode=self.fusion_mode)
+        cur.wait_event(ev_text)
+        outs = []
+        for i, ref in enumerate(refs):
+            hybrid = hybrid_all[moff[i]:moff[i + 1]]
+            text = text_all[offs[i]:offs[i + 1]]
+            outs.append((hybrid, text, self._score_ref(ref, hybrid, text, heats[i])))
+        return outs
 
     def metrics(self):
         """Hybridgl_main.py:240-247: overall IoU and mean IoU, pure and with spatial guidance."""

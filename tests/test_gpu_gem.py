@@ -171,6 +171,24 @@ def test_pipeline_computes_heatmaps_like_the_reference_sequence(cuda, b16):
         HybridGLPipeline(clip, "G2L", 9).step(ref)        # no gem model and no heat-map
 
 
+def test_step_group_equals_per_ref_steps(cuda, b16):
+    """HybridGLPipeline.step_group: one text-encoder batch and one hybrid forward over the masks of several refs ==
+    the refs stepped one by one (every mask row and every string is independent)."""
+    from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
+    _, clip = b16
+    gm = G.create_gem_model("ViT-B/16", clip=clip)
+    refs = [synthetic_ref(i, cuda, N=8, H=320, W=480, gem=True, device_blur=True)[0] for i in range(3)]
+    p1 = HybridGLPipeline(clip, "G2L", 9, gem_model=gm)
+    outs1 = [p1.step(r) for r in refs]
+    p2 = HybridGLPipeline(clip, "G2L", 9, gem_model=gm)
+    outs2 = p2.step_group(refs)
+    assert p1.metrics()["cum"] == p2.metrics()["cum"] and p1.metrics()["n_sentences"] == p2.metrics()["n_sentences"] == 9
+    for a, b in zip(outs1, outs2):
+        np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), rtol=0, atol=2e-5)      # hybrid features
+        np.testing.assert_allclose(a[1].cpu().numpy(), b[1].cpu().numpy(), rtol=0, atol=2e-5)      # text features
+        assert torch.equal(a[2][0], b[2][0])                                                      # winning indices
+
+
 def test_errors(cuda, tiny):
     import ctypes as C
     from hybridgl_amd import _lib
