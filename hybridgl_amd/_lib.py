@@ -115,6 +115,8 @@ PROTOTYPES = {
     "hgl_clip_encode_text": (_I, [C.POINTER(HglClipTextW), _VP, _I, _VP, _VP, _SZ, _VP]),
     "hgl_gem_workspace_bytes": (_SZ, [C.POINTER(HglClipVisionW)]),
     "hgl_gem_image_features": (_I, [C.POINTER(HglClipVisionW), _VP, _I, _I, _F, _VP, _VP, _VP, _SZ, _VP]),
+    "hgl_gem_batch_workspace_bytes": (_SZ, [C.POINTER(HglClipVisionW), _I]),
+    "hgl_gem_image_features_batch": (_I, [C.POINTER(HglClipVisionW), _VP, _I, _I, _I, _F, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_gem_heatmap_workspace_bytes": (_SZ, [_I, _I, _I]),
     "hgl_gem_heatmap": (_I, [_VP, _I, _I, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "hgl_resize_bilinear_aa": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _VP]),

@@ -51,45 +51,46 @@ __global__ __launch_bounds__(256) void row_norm_split_kernel(const _Float16* __r
   if (lane == 0) norms[row] = sqrtf(s);
 }
 
-// t = mean(norms) * scale  (fixed order: one work-group, strided partials, tree in LDS)
+// t[img] = mean(norms of image img) * scale  (fixed order: one work-group per image, strided partials, tree in LDS)
 __global__ __launch_bounds__(256) void temp_kernel(const float* __restrict__ norms, int S, float scale, float* __restrict__ t) {
   __shared__ float part[256];
+  const float* nr = norms + (long long)blockIdx.x * S;
   float s = 0.f;
-  for (int i = threadIdx.x; i < S; i += 256) s += norms[i];
+  for (int i = threadIdx.x; i < S; i += 256) s += nr[i];
   part[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) t[0] = part[0] / (float)S * scale;
+  if (threadIdx.x == 0) t[blockIdx.x] = part[0] / (float)S * scale;
 }
 
-__global__ void set_scalar_kernel(float* t, float v) { t[0] = v; }
+__global__ void set_scalar_kernel(float* t, float v, int n) { if ((int)threadIdx.x < n) t[threadIdx.x] = v; }
 
-// per (set, token, head): n = x / max(||x||, 1e-12) -> nrm, n * t -> nrm_s.   src set j at src + j*set_stride,
-// row stride ld; outputs [3, S, heads*hd] contiguous.  One 16-lane group per (set, token, head).
+// per (set, row, head): n = x / max(||x||, 1e-12) -> nrm, n * t[row / S] -> nrm_s.   src set j at src + j*set_stride,
+// row stride ld; `rows` = images * S token rows; outputs [3, rows, heads*hd] contiguous.  One 16-lane group per item.
 __global__ __launch_bounds__(256) void normalize_heads_kernel(const float* __restrict__ src, long long set_stride, int ld,
-                                                              int S, int heads, int hd, const float* __restrict__ t,
+                                                              int rows, int S, int heads, int hd, const float* __restrict__ t,
                                                               float* __restrict__ nrm, float* __restrict__ nrm_s) {
   const int sub = threadIdx.x & 15;
   const long long item = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-  const long long total = 3LL * S * heads;
+  const long long total = 3LL * rows * heads;
   if (item >= total) return;
   const int h = (int)(item % heads);
   const long long rs = item / heads;
-  const int s = (int)(rs % S);
-  const int set = (int)(rs / S);
+  const int s = (int)(rs % rows);
+  const int set = (int)(rs / rows);
   const float* x = src + set * set_stride + (long long)s * ld + h * hd;
   float q = 0.f;
   for (int i = sub; i < hd; i += 16) q += x[i] * x[i];
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o);
   const float inv = 1.0f / fmaxf(sqrtf(q), 1e-12f);
-  const float tt = t[0];
+  const float tt = t[s / S];
   const long long D = (long long)heads * hd;
-  float* o1 = nrm + ((long long)set * S + s) * D + h * hd;
-  float* o2 = nrm_s + ((long long)set * S + s) * D + h * hd;
+  float* o1 = nrm + ((long long)set * rows + s) * D + h * hd;
+  float* o2 = nrm_s + ((long long)set * rows + s) * D + h * hd;
   for (int i = sub; i < hd; i += 16) {
     const float n = x[i] * inv;
     o1[i] = n;
@@ -247,78 +248,89 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(const float* __restrict_
 
 struct GemPlan {
   float *X, *Xg, *H, *QKV, *F, *N3, *N3s, *X1, *norms, *t;
+  int nb;   // images stacked along the token rows
 };
 
-bool carve(HglArena& ar, const HglClipVisionW* w, GemPlan& p) {
+bool carve(HglArena& ar, const HglClipVisionW* w, int nb, GemPlan& p) {
   const size_t S = (size_t)w->grid * w->grid + 1, D = w->width;
-  const size_t act = S * D;
+  const size_t act = (size_t)nb * S * D;
+  p.nb = nb;
   p.X = ar.take<float>(act);
   p.Xg = ar.take<float>(act);
   p.H = ar.take<float>(act);
   p.QKV = ar.take<float>(3 * act);
-  const size_t cols = (S - 1) * 3 * w->patch * w->patch;
+  const size_t cols = (size_t)nb * (S - 1) * 3 * w->patch * w->patch;
   p.F = ar.take<float>(4 * act > cols ? 4 * act : cols);
   p.N3 = ar.take<float>(3 * act);
   p.N3s = ar.take<float>(3 * act);
   p.X1 = ar.take<float>(3 * act);
-  p.norms = ar.take<float>(S);
+  p.norms = ar.take<float>((size_t)nb * S);
   p.t = ar.take<float>(64);
   return ar.ok();
 }
 
-int normalize_heads(const float* src, long long set_stride, int ld, int S, int heads, int hd, const GemPlan& p, hipStream_t st) {
-  const long long items = 3LL * S * heads;
-  hipLaunchKernelGGL(normalize_heads_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st, src, set_stride, ld, S,
+int normalize_heads(const float* src, long long set_stride, int ld, int rows, int S, int heads, int hd, const GemPlan& p,
+                    hipStream_t st) {
+  const long long items = 3LL * rows * heads;
+  hipLaunchKernelGGL(normalize_heads_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st, src, set_stride, ld, rows, S,
                      heads, hd, p.t, p.N3, p.N3s);
   return hgl_check_launch("gem_normalize_heads");
 }
 
-// One GEM block: the gem stream gets proj(self-self attention(ln_1 x)); the original stream is the plain block.
+// One GEM block over the stacked token rows of p.nb images: the gem stream gets proj(self-self attention(ln_1 x)); the
+// original stream is the plain block.
 int gem_block(const HglResBlockW& w, const GemPlan& p, int S, int D, int heads, int ss_iter, float ss_temp, bool need_ori,
               hipStream_t st) {
-  const int hd = D / heads;
+  const int hd = D / heads, nb = p.nb, M = nb * S;
   const float scale = 1.0f / sqrtf((float)hd);
-  const long long SD = (long long)S * D;
+  const long long SD = (long long)S * D, MD = (long long)M * D;
   const HglBlockBufs bf{p.H, p.QKV, p.F};
-  const bool x3 = hgl_clip_block_uses_x3(w, S, D);
-  HGL_TRY(hgl_clip_block_qkv(w, p.X, S, D, bf, st));          // p.H = ln_1(x) (fp32 or the hi+lo pair), p.QKV
+  const bool x3 = hgl_clip_block_uses_x3(w, M, D);
+  HGL_TRY(hgl_clip_block_qkv(w, p.X, M, D, bf, st));          // p.H = ln_1(x) (fp32 or the hi+lo pair), p.QKV
   if (ss_temp > 0.f) {
-    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, p.t, ss_temp);
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(64), 0, st, p.t, ss_temp, nb);
   } else {
     if (x3)
-      hipLaunchKernelGGL(row_norm_split_kernel, dim3((S + 3) / 4), dim3(256), 0, st, (const _Float16*)p.H,
-                         (const _Float16*)p.H + SD, S, D, p.norms);
+      hipLaunchKernelGGL(row_norm_split_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const _Float16*)p.H,
+                         (const _Float16*)p.H + MD, M, D, p.norms);
     else
-      hipLaunchKernelGGL(row_norm_kernel, dim3((S + 3) / 4), dim3(256), 0, st, p.H, S, D, p.norms);
-    hipLaunchKernelGGL(temp_kernel, dim3(1), dim3(256), 0, st, p.norms, S, scale, p.t);
+      hipLaunchKernelGGL(row_norm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, p.H, M, D, p.norms);
+    hipLaunchKernelGGL(temp_kernel, dim3(nb), dim3(256), 0, st, p.norms, S, scale, p.t);   // one temperature per image
   }
   HGL_TRY(hgl_check_launch("gem_temperature"));
-  // sets in the order (v, k, q): QKV + 2D, + D, + 0
+  // sets in the order (v, k, q): QKV + 2D, + D, + 0.  Attention batches = (set, image): 3 * nb sequences of S tokens.
   const float* V = p.QKV + 2 * D;
-  HGL_TRY(normalize_heads(V, -(long long)D, 3 * D, S, heads, hd, p, st));
+  HGL_TRY(normalize_heads(V, -(long long)D, 3 * D, M, S, heads, hd, p, st));
   for (int it = 0; it < ss_iter; ++it) {
-    HGL_TRY(hgl_launch_attention(p.N3s, p.N3, p.N3, p.X1, 3, heads, S, S, hd, D, D, D, D, SD, SD, SD, SD, 1.0f,
+    HGL_TRY(hgl_launch_attention(p.N3s, p.N3, p.N3, p.X1, 3 * nb, heads, S, S, hd, D, D, D, D, SD, SD, SD, SD, 1.0f,
                                  HGL_MASK_NONE, nullptr, 0, 0, nullptr, nullptr, 0, 0, st));
-    HGL_TRY(normalize_heads(p.X1, SD, D, S, heads, hd, p, st));
+    HGL_TRY(normalize_heads(p.X1, MD, D, M, S, heads, hd, p, st));
   }
-  // assignment to v: the value operand is the block's v for all three sets (batch stride 0)
-  HGL_TRY(hgl_launch_attention(p.N3s, p.N3, V, p.X1, 3, heads, S, S, hd, D, D, 3 * D, D, SD, SD, 0, SD, 1.0f, HGL_MASK_NONE,
-                               nullptr, 0, 0, nullptr, nullptr, 0, 0, st));
+  // assignment to v: the value operand is the block's v for all three sets -- one launch when a batch stride of 0
+  // expresses that (one image), else one launch per set over the images
+  if (nb == 1) {
+    HGL_TRY(hgl_launch_attention(p.N3s, p.N3, V, p.X1, 3, heads, S, S, hd, D, D, 3 * D, D, SD, SD, 0, SD, 1.0f, HGL_MASK_NONE,
+                                 nullptr, 0, 0, nullptr, nullptr, 0, 0, st));
+  } else {
+    for (int set = 0; set < 3; ++set)
+      HGL_TRY(hgl_launch_attention(p.N3s + set * MD, p.N3 + set * MD, V, p.X1 + set * MD, nb, heads, S, S, hd, D, D, 3 * D, D,
+                                   SD, SD, 3 * SD, SD, 1.0f, HGL_MASK_NONE, nullptr, 0, 0, nullptr, nullptr, 0, 0, st));
+  }
   if (x3) {
     _Float16* Mh = (_Float16*)p.N3;
-    _Float16* Ml = Mh + SD;
-    hipLaunchKernelGGL(mean3_split_kernel, dim3((unsigned)((SD + 255) / 256)), dim3(256), 0, st, p.X1, SD, SD, Mh, Ml);
+    _Float16* Ml = Mh + MD;
+    hipLaunchKernelGGL(mean3_split_kernel, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, p.X1, MD, MD, Mh, Ml);
     HGL_TRY(hgl_check_launch("gem_mean3"));
-    HGL_TRY(hgl_launch_gemm_f16x3(Mh, Ml, D, w.out_proj_w, w.out_proj_b, p.Xg, D, p.Xg, nullptr, nullptr, D, S, D, D,
+    HGL_TRY(hgl_launch_gemm_f16x3(Mh, Ml, D, w.out_proj_w, w.out_proj_b, p.Xg, D, p.Xg, nullptr, nullptr, D, M, D, D,
                                   HGL_ACT_NONE, st));
   } else {
-    hipLaunchKernelGGL(mean3_kernel, dim3((unsigned)((SD + 255) / 256)), dim3(256), 0, st, p.X1, SD, SD, p.N3);
+    hipLaunchKernelGGL(mean3_kernel, dim3((unsigned)((MD + 255) / 256)), dim3(256), 0, st, p.X1, MD, MD, p.N3);
     HGL_TRY(hgl_check_launch("gem_mean3"));
-    HGL_TRY(hgl_launch_gemm(p.N3, w.out_proj_w, w.out_proj_b, p.Xg, p.Xg, S, D, D, D, D, D, D, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
+    HGL_TRY(hgl_launch_gemm(p.N3, w.out_proj_w, w.out_proj_b, p.Xg, p.Xg, M, D, D, D, D, D, D, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
   }
   if (!need_ori) return HGL_OK;
   // original stream (clip/model.py:244-257): the plain block on the same QKV
-  return hgl_clip_block_rest(w, p.X, 1, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st);
+  return hgl_clip_block_rest(w, p.X, nb, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st);
 }
 
 bool valid_vision(const HglClipVisionW* w) {
@@ -331,37 +343,40 @@ bool valid_vision(const HglClipVisionW* w) {
 
 extern "C" {
 
-size_t hgl_gem_workspace_bytes(const HglClipVisionW* w) {
-  if (!valid_vision(w)) return 0;
+size_t hgl_gem_batch_workspace_bytes(const HglClipVisionW* w, int nb) {
+  if (!valid_vision(w) || nb < 1) return 0;
   HglArena ar(nullptr, 0);
   GemPlan p;
-  carve(ar, w, p);
+  carve(ar, w, nb, p);
   return ar.off;
 }
 
-int hgl_gem_image_features(const HglClipVisionW* w, const float* img, int gem_blocks, int ss_attn_iter, float ss_attn_temp,
-                           float* feat_gem, float* feat_ori, void* workspace, size_t workspace_bytes, void* stream) {
+size_t hgl_gem_workspace_bytes(const HglClipVisionW* w) { return hgl_gem_batch_workspace_bytes(w, 1); }
+
+int hgl_gem_image_features_batch(const HglClipVisionW* w, const float* imgs, int nb, int gem_blocks, int ss_attn_iter,
+                                 float ss_attn_temp, float* feat_gem, float* feat_ori, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
   HGL_TRY(hgl_require_device());
   HGL_REQUIRE(valid_vision(w), "gem_image_features: invalid weight struct");
-  HGL_REQUIRE(img && feat_gem, "gem_image_features: null input");
+  HGL_REQUIRE(imgs && feat_gem && nb >= 1 && nb <= 64, "gem_image_features: bad arguments (nb %d)", nb);
   HGL_REQUIRE(gem_blocks >= 0 && gem_blocks <= w->layers, "gem_image_features: gem_blocks %d outside 0..%d", gem_blocks, w->layers);
   HGL_REQUIRE(ss_attn_iter >= 0 && ss_attn_iter <= 16, "gem_image_features: bad ss_attn_iter %d", ss_attn_iter);
   HglArena ar(workspace, workspace_bytes);
   GemPlan p;
-  if (!workspace || !carve(ar, w, p)) {
+  if (!workspace || !carve(ar, w, nb, p)) {
     hgl_set_error("gem_image_features: workspace too small (%zu bytes given)", workspace_bytes);
     return HGL_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int D = w->width, S = w->grid * w->grid + 1, heads = w->heads, E = w->embed;
+  const int D = w->width, S = w->grid * w->grid + 1, heads = w->heads, E = w->embed, M = nb * S;
   HglBlockBufs bf{p.H, p.QKV, p.F};
-  HGL_TRY(hgl_clip_embed_images(w, img, 1, p.X, p.F, p.QKV, st));
+  HGL_TRY(hgl_clip_embed_images(w, imgs, nb, p.X, p.F, p.QKV, st));
   const int first_gem = w->layers - gem_blocks;
   for (int l = 0; l < first_gem; ++l)
-    HGL_TRY(hgl_clip_run_block(w->blocks[l], p.X, 1, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
+    HGL_TRY(hgl_clip_run_block(w->blocks[l], p.X, nb, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
   const float* gem_stream = p.X;
   if (gem_blocks > 0) {
-    (void)hipMemcpyAsync(p.Xg, p.X, sizeof(float) * (size_t)S * D, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(p.Xg, p.X, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
     gem_stream = p.Xg;
     for (int l = first_gem; l < w->layers; ++l) {
       // the original stream of the last block only feeds feat_ori
@@ -370,13 +385,19 @@ int hgl_gem_image_features(const HglClipVisionW* w, const float* img, int gem_bl
     }
   }
   // ln_post + proj on every token of the stream(s)
-  HGL_TRY(hgl_launch_layernorm(gem_stream, w->ln_post_w, w->ln_post_b, p.H, S, D, 1e-5f, st));
-  HGL_TRY(hgl_launch_gemm(p.H, w->proj_t, nullptr, nullptr, feat_gem, S, E, D, D, D, 0, E, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_layernorm(gem_stream, w->ln_post_w, w->ln_post_b, p.H, M, D, 1e-5f, st));
+  HGL_TRY(hgl_launch_gemm(p.H, w->proj_t, nullptr, nullptr, feat_gem, M, E, D, D, D, 0, E, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
   if (feat_ori) {
-    HGL_TRY(hgl_launch_layernorm(p.X, w->ln_post_w, w->ln_post_b, p.H, S, D, 1e-5f, st));
-    HGL_TRY(hgl_launch_gemm(p.H, w->proj_t, nullptr, nullptr, feat_ori, S, E, D, D, D, 0, E, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
+    HGL_TRY(hgl_launch_layernorm(p.X, w->ln_post_w, w->ln_post_b, p.H, M, D, 1e-5f, st));
+    HGL_TRY(hgl_launch_gemm(p.H, w->proj_t, nullptr, nullptr, feat_ori, M, E, D, D, D, 0, E, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
   }
   return HGL_OK;
+}
+
+int hgl_gem_image_features(const HglClipVisionW* w, const float* img, int gem_blocks, int ss_attn_iter, float ss_attn_temp,
+                           float* feat_gem, float* feat_ori, void* workspace, size_t workspace_bytes, void* stream) {
+  return hgl_gem_image_features_batch(w, img, 1, gem_blocks, ss_attn_iter, ss_attn_temp, feat_gem, feat_ori, workspace,
+                                      workspace_bytes, stream);
 }
 
 size_t hgl_gem_heatmap_workspace_bytes(int grid, int T, int res) {

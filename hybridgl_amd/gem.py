@@ -138,6 +138,28 @@ class GEMWrapper:
               "hgl_gem_image_features")
         return ori if return_ori else feat
 
+    def image_features_batch(self, images, return_ori=False):
+        """GEMViT.forward on several images at once [B, 3, R, R] -> [B, 1 + g*g, embed]: the token rows of the images are
+        stacked, so every GEMM / LayerNorm launch covers all of them (one self-self temperature per image)."""
+        lib = _lib.load()
+        assert images.dim() == 4 and images.shape[1] == 3 and images.shape[2] == images.shape[3], "images must be [B,3,R,R]"
+        nb, R = images.shape[0], images.shape[-1]
+        assert R % self.patch_size == 0, "image side must be a multiple of the patch size"
+        grid = R // self.patch_size
+        v = self._vision(grid)
+        imgs = images.contiguous()
+        E = self.model.cfg["embed_dim"]
+        S = grid * grid + 1
+        feat = torch.empty((nb, S, E), dtype=torch.float32, device=imgs.device)
+        ori = torch.empty((nb, S, E), dtype=torch.float32, device=imgs.device) if return_ori else None
+        need = lib.hgl_gem_batch_workspace_bytes(C.byref(v), nb)
+        ws = ops.workspace(need, imgs.device, "gem")
+        check(lib.hgl_gem_image_features_batch(C.byref(v), ops._dev(imgs, torch.float32, "images"), nb, self.gem_blocks,
+                                               self.ss_attn_iter, float(self.ss_attn_temp) if self.ss_attn_temp else 0.0,
+                                               feat.data_ptr(), ori.data_ptr() if return_ori else None, ws.data_ptr(),
+                                               ws.numel(), ops._stream()), "hgl_gem_image_features_batch")
+        return ori if return_ori else feat
+
     def heatmap(self, feat, text_feats, res, normalize=True):
         """feat [1+g*g, E], text_feats [T, E] -> [T, res, res]"""
         lib = _lib.load()
@@ -168,8 +190,8 @@ class GEMWrapper:
     def forward(self, image, text, normalize=True, return_ori=False):
         assert image.dim() == 4, "image must be [B,3,W,H]"
         txt = self.encode_text(text)[0]
-        maps = [self.heatmap(self.image_features(image[b], return_ori), txt, image.shape[-1], normalize)
-                for b in range(image.shape[0])]
+        feats = self.image_features_batch(image, return_ori)
+        maps = [self.heatmap(feats[b], txt, image.shape[-1], normalize) for b in range(image.shape[0])]
         return torch.stack(maps, dim=0)
 
     __call__ = forward

@@ -285,15 +285,26 @@ class HybridGLPipeline:
         heats = []
         with torch.cuda.stream(self._s_text):
             text_all = m.model.encode_text(torch.cat([r.tokens for r in refs], dim=0))
+            # GEM image towers of the refs that need a heat-map: one pass over all of them when their sizes agree
+            need = [i for i, r in enumerate(refs) if any(s.imgattn is None for s in r.sentences)]
+            gfeats = {}
+            if need:
+                if self.gem_model is None or any(refs[i].tensor_img is None for i in need):
+                    raise ValueError("a sentence without imgattn needs gem_model, RefBatch.tensor_img and Sentence.gem_row")
+                if len(need) > 1 and all(refs[i].tensor_img.shape == refs[need[0]].tensor_img.shape for i in need):
+                    fb = self.gem_model.image_features_batch(torch.stack([refs[i].tensor_img for i in need], dim=0))
+                    gfeats = {i: fb[j] for j, i in enumerate(need)}
+                else:
+                    gfeats = {i: self.gem_model.image_features(refs[i].tensor_img) for i in need}
             for i, ref in enumerate(refs):
                 text = text_all[offs[i]:offs[i + 1]]
                 gem_rows = [s.gem_row for s in ref.sentences if s.imgattn is None]
                 heat = None
                 if gem_rows:
                     from . import gem as G
-                    if self.gem_model is None or ref.tensor_img is None or any(r is None for r in gem_rows):
+                    if any(r is None for r in gem_rows):
                         raise ValueError("a sentence without imgattn needs gem_model, RefBatch.tensor_img and Sentence.gem_row")
-                    gfeat = self.gem_model.image_features(ref.tensor_img)
+                    gfeat = gfeats[i]
                     maps = self.gem_model.heatmap(gfeat, _rows(text, gem_rows), ref.tensor_img.shape[-1])
                     heat = G.resize_antialias(maps, ref.sam_img.shape[:2])
                     heat.record_stream(cur)

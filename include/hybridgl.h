@@ -196,6 +196,13 @@ int hgl_gem_image_features(const HglClipVisionW* w, const float* img, int gem_bl
                            float ss_attn_temp, float* feat_gem, float* feat_ori,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same for nb images at once ([nb,3,res,res] contiguous; token rows stacked: every GEMM covers all images, one
+ * temperature per image); feat_gem / feat_ori [nb, grid*grid+1, embed]. */
+size_t hgl_gem_batch_workspace_bytes(const HglClipVisionW* w, int nb);
+int hgl_gem_image_features_batch(const HglClipVisionW* w, const float* imgs, int nb, int gem_blocks, int ss_attn_iter,
+                                 float ss_attn_temp, float* feat_gem, float* feat_ori,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* GEMWrapper.forward after the encoders: heat[t] = minmax(bilinear_up(100*cos(feat[1:], text[t])))
  * feat [grid*grid+1,E]; text [T,E] (normalised or not); heat [T,res,res]; normalize=0 skips min-max. */
 size_t hgl_gem_heatmap_workspace_bytes(int grid, int T, int res);

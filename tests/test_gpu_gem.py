@@ -171,6 +171,21 @@ def test_pipeline_computes_heatmaps_like_the_reference_sequence(cuda, b16):
         HybridGLPipeline(clip, "G2L", 9).step(ref)        # no gem model and no heat-map
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(ss_attn_temp=3.0), dict(ss_attn_iter=2)])
+def test_image_features_batch_equals_single_images(cuda, tiny, b16, kw):
+    """hgl_gem_image_features_batch: token rows of several images stacked (one temperature per image, the final
+    assignment to v per set over the images) == the images one by one; both residual streams."""
+    for (sd, clip), name, R, tol in [(tiny, "tiny", 128, 1e-5), (b16, "ViT-B/16", 224, 1e-4)]:
+        gm = G.create_gem_model(name, clip=clip, **kw)
+        imgs = torch.from_numpy(np.random.default_rng(R).standard_normal((3, 3, R, R)).astype(np.float32)).to(cuda)
+        imgs[1] *= 3.0                                    # different token norms -> different temperatures
+        fb = gm.image_features_batch(imgs)
+        ob = gm.image_features_batch(imgs, return_ori=True)
+        for b in range(3):
+            np.testing.assert_allclose(fb[b].cpu().numpy(), gm.image_features(imgs[b]).cpu().numpy(), rtol=0, atol=tol)
+            np.testing.assert_allclose(ob[b].cpu().numpy(), gm.image_features(imgs[b], return_ori=True).cpu().numpy(), rtol=0, atol=tol)
+
+
 def test_step_group_equals_per_ref_steps(cuda, b16):
     """HybridGLPipeline.step_group: one text-encoder batch and one hybrid forward over the masks of several refs ==
     the refs stepped one by one (every mask row and every string is independent)."""
