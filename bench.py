@@ -341,9 +341,13 @@ def main():
 
     # ---- roofline leg: the same steps with HIP events around every launch of the dominant kernel
     lib.hgl_prof_enable(1)
-    nprof = 2
-    for i in range(nprof):
-        pipe.step(refs[i % len(refs)])   # serial on one stream: per-kernel event times are not overlapped
+    if pair:   # one group of the timed size, its stages back to back on one stream
+        nprof = nbatch
+        pipe.step_serial_group([refs[j % len(refs)] for j in range(nprof)])
+    else:
+        nprof = 2
+        for i in range(nprof):
+            pipe.step(refs[i % len(refs)])   # serial on one stream: per-kernel event times are not overlapped
     torch.cuda.synchronize()
     lib.hgl_prof_enable(0)
     g_n, g_ms, g_fl, g_by = prof_read(lib, 0)

@@ -167,6 +167,25 @@ class HybridGLPipeline:
         cur.wait_event(e2)
         return outs
 
+    def step_serial_group(self, refs):
+        """The work of step_overlapped_pair for one group on the CURRENT stream, stages back to back (no overlap): SAM
+        proposal stage of the group's own images in one encoder pass, then the grouped CLIP + scoring stage.  Used for
+        per-kernel timing (events on one stream)."""
+        gen = self.mask_generator
+        self.last_proposals = gen.propose_batch([r.sam_img for r in refs])[-1]
+        self.mask_generator = None
+        try:
+            group = []
+            for ref in refs:
+                if self.cleanup_given_masks:
+                    import dataclasses
+                    cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
+                    ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
+                group.append(ref)
+            return self.step_group(group) if self.group_clip else [self.step(r) for r in group]
+        finally:
+            self.mask_generator = gen
+
     def step(self, ref: RefBatch):
         """One dataset item; returns the device tensors of the last sentence (idx, scores)."""
         import dataclasses
