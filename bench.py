@@ -319,10 +319,13 @@ def main():
         # SAM encoder pass over the group's prefetched images, one text batch + one hybrid forward for the group;
         # what does not fill a group of two ends ref by ref.
         i = 0
-        while pair and k - i >= 2:
+        while (pair or (gen is None and nbatch >= 2)) and k - i >= 2:
             g = max(c for c in (2, 4, 8) if c <= min(nbatch, k - i))
-            pipe.step_overlapped_pair([refs[(i + j) % len(refs)] for j in range(g)],
-                                      [refs[(i + g + j) % len(refs)] for j in range(g)])
+            group = [refs[(i + j) % len(refs)] for j in range(g)]
+            if pair:
+                pipe.step_overlapped_pair(group, [refs[(i + g + j) % len(refs)] for j in range(g)])
+            else:   # scope A: proposals given, the grouped CLIP + scoring stage alone
+                pipe.step_group(group)
             i += g
         while i < k:
             do_step(i)
