@@ -52,6 +52,16 @@ SAM2_SHAPES = [  # the SAM ViT-H encoder GEMMs for one image and for two images 
     ("qkv glob x1", 4096, 3840, 1280, "none", False), ("qkv glob x2", 8192, 3840, 1280, "none", False),
     ("proj glob x1", 4096, 1280, 1280, "none", False), ("proj glob x2", 8192, 1280, 1280, "none", False),
 ]
+GROUP8_SHAPES = [  # the GEMMs of the grouped pipeline (8 refs per group)
+    ("clip qkv", 201728, 2304, 768, "none", False), ("clip out", 201728, 768, 768, "none", True),
+    ("clip fc1", 201728, 3072, 768, "quickgelu", False), ("clip fc2", 201728, 768, 3072, "none", True),
+    ("sam qkv", 32768, 3840, 1280, "none", False), ("sam proj", 32768, 1280, 1280, "none", True),
+    ("sam lin1", 32768, 5120, 1280, "gelu", False), ("sam lin2", 32768, 1280, 5120, "none", True),
+    ("text qkv", 7392, 1536, 512, "none", False), ("text fc1", 7392, 2048, 512, "quickgelu", False),
+    ("gem qkv", 6280, 2304, 768, "none", False), ("gem fc2", 6280, 768, 3072, "none", True),
+]
+if os.environ.get("X3_SHAPES") == "group8":
+    SHAPES = GROUP8_SHAPES
 if os.environ.get("X3_SHAPES") == "gem":
     SHAPES = GEM_SHAPES
 if os.environ.get("X3_SHAPES") == "sam2":
