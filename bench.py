@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 path on a box "
                          "with fewer GPUs than ranks)")
-    ap.add_argument("--sam-batch", type=int, default=8, choices=[1, 2, 4, 8],
+    ap.add_argument("--sam-batch", type=int, default=8, choices=[1, 2, 4, 8, 16],
                     help="largest group of refs the overlapped pipeline takes at a time: ONE SAM encoder pass over the images "
                          "of the next group (token rows stacked, weights read once) under ONE text-encoder batch + ONE hybrid "
                          "forward over the masks of the current group; same work and same results per ref (1: ref by ref)")
@@ -320,7 +320,7 @@ def main():
         # what does not fill a group of two ends ref by ref.
         i = 0
         while (pair or (gen is None and nbatch >= 2)) and k - i >= 2:
-            g = max(c for c in (2, 4, 8) if c <= min(nbatch, k - i))
+            g = max(c for c in (2, 4, 8, 16) if c <= min(nbatch, k - i))
             group = [refs[(i + j) % len(refs)] for j in range(g)]
             if pair:
                 pipe.step_overlapped_pair(group, [refs[(i + g + j) % len(refs)] for j in range(g)])
