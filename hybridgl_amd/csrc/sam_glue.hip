@@ -151,6 +151,101 @@ __global__ __launch_bounds__(256) void relpos_direct_kernel(const float* __restr
   }
 }
 
+// The same tables on the matrix cores (f16x3 mode): T^T = R . Q^T per (batch, head, axis) with the split-fp16 scheme
+// of the GEMMs -- A operand = the (2*size-1) table rows (zero-padded to NT*32, split to fp16 hi | lo in LDS once per
+// workgroup), B operand = the wave's 32 query vectors (split in registers), 3 MFMAs per 16-wide k step.  The
+// accumulator (lane = query, 16 of 32 table indices per lane) goes through an LDS patch from which every query reads
+// its `size` consecutive entries T[q][qc + size-1 - k].  The VALU version above is bound by its LDS reads (one
+// 16-byte read per 4 fmas): 30 us per windowed block against ~10 for the bytes this one moves.
+typedef _Float16 rp_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rp_h4 __attribute__((ext_vector_type(4)));
+template <int HD, int NT>
+__global__ __launch_bounds__(256) void relpos_mfma_kernel(const float* __restrict__ qkv, int ldq, int heads, int S, int size,
+                                                          const float* __restrict__ Rh, const float* __restrict__ Rw,
+                                                          float* __restrict__ rel_h, float* __restrict__ rel_w) {
+  constexpr int KS = HD / 16;          // k steps
+  constexpr int TP = HD + 8;           // halfs per staged table row (16-byte aligned, odd multiple of 16 B)
+  constexpr int GP = NT * 32 + 1;      // floats per query row of the gather patch
+  extern __shared__ __attribute__((aligned(16))) unsigned char rp_smem[];
+  _Float16* Th = (_Float16*)rp_smem;                       // [NT*32][TP] hi
+  _Float16* Tl = Th + NT * 32 * TP;                        // [NT*32][TP] lo
+  float* G = (float*)(Tl + NT * 32 * TP);                  // [4 waves][32 queries][GP]
+  const int axis = blockIdx.z, bh = blockIdx.y;
+  const int b = bh / heads, hh = bh % heads;
+  const float* R = axis ? Rw : Rh;
+  const int nrow = 2 * size - 1;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  for (int i = t; i < NT * 32 * (HD / 4); i += 256) {
+    const int rr = i / (HD / 4), c = i % (HD / 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (rr < nrow) v = *(const f32x4*)(R + (long long)rr * HD + 4 * c);
+    rp_h4 a, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 h0, l0;
+      hgl_split_hi_lo(v[e], h0, l0);
+      a[e] = h0;
+      l[e] = l0;
+    }
+    *(rp_h4*)(Th + rr * TP + 4 * c) = a;
+    *(rp_h4*)(Tl + rr * TP + 4 * c) = l;
+  }
+  __syncthreads();
+  const int q = (blockIdx.x * 4 + wave) * 32 + r;
+  const bool qvalid = q < S;
+  const float* qp = qkv + ((long long)b * S + (qvalid ? q : 0)) * ldq + hh * HD;
+  rp_h8 qh[KS], ql[KS];
+#pragma unroll
+  for (int c = 0; c < KS; ++c) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const f32x4 v = qvalid ? *(const f32x4*)(qp + 16 * c + 8 * h + 4 * half) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        _Float16 h0, l0;
+        hgl_split_hi_lo(v[e], h0, l0);
+        qh[c][4 * half + e] = h0;
+        ql[c][4 * half + e] = l0;
+      }
+    }
+  }
+  float* Gw = G + (wave * 32 + r) * GP;
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const _Float16* trow = Th + (tt * 32 + r) * TP + 8 * h;
+    const _Float16* lrow = Tl + (tt * 32 + r) * TP + 8 * h;
+#pragma unroll
+    for (int c = 0; c < KS; ++c) {
+      const rp_h8 ah = *(const rp_h8*)(trow + 16 * c);
+      const rp_h8 al = *(const rp_h8*)(lrow + 16 * c);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[c], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[c], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[c], acc, 0, 0, 0);
+    }
+    // acc[e] = T[table index tt*32 + (e&3) + 8*(e>>2) + 4*h][query r]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Gw[tt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[e];
+  }
+  __syncthreads();
+  if (!qvalid) return;
+  const int qc = axis ? q % size : q / size;
+  float* out = (axis ? rel_w : rel_h) + ((long long)bh * S + q) * size;
+  // the two lanes of a query share its row: k in [0, sp) and [sp, size), sp even so that both write aligned pairs
+  const int sp = (size / 2 + 1) & ~1;
+  const int k0 = h ? sp : 0, k1 = h ? size : sp;
+  const float* src = Gw + qc + size - 1;                  // entry of k = 0; the index falls by one per k
+  for (int k = k0; k < k1; k += 2) {
+    f32x2 o;
+    o[0] = src[-k];
+    o[1] = src[-k - 1];
+    *(f32x2*)(out + k) = o;
+  }
+}
+
 // Row maps of the zero-padded window partition (image_encoder.py:244-283): the r-th REAL token in window order lives
 // at padded row pad_of[r] = window*ws*ws + position and at token-order row tok_of[r] = y*g + x; pad_list collects
 // the padded rows that hold no token.  The f16x3 GEMMs of a windowed block run over the real tokens only: the pad
@@ -768,6 +863,27 @@ int hgl_launch_relpos_direct(const float* qkv, int ldq, int B, int heads, int S,
                              const float* Rh, const float* Rw, float* rel_h, float* rel_w, hipStream_t st) {
   HGL_REQUIRE(hd == 80 || hd == 64, "relpos_direct: head dim %d unsupported", hd);
   HGL_REQUIRE((size & 1) == 0 && size > 0 && size <= 64, "relpos_direct: window size %d unsupported (even, <= 64)", size);
+  // f16x3 mode: the matrix-core version (table of 2*size-1 rows padded to 32 / 128)
+  if (hgl_precision() == HGL_PREC_F16X3 && (size == 14 || size == 64)) {
+    const int NT = size == 14 ? 1 : 4;
+    const dim3 gridm((unsigned)((S + 127) / 128), (unsigned)(B * heads), 2);
+    const size_t ldsm = (size_t)2 * NT * 32 * (hd + 8) * sizeof(_Float16) + (size_t)4 * 32 * (NT * 32 + 1) * sizeof(float);
+#define HGL_RP_LAUNCH(HD_, NT_)                                                                                          \
+  do {                                                                                                                 \
+    static bool set_ = false;                                                                                          \
+    if (!set_) {                                                                                                       \
+      (void)hipFuncSetAttribute((const void*)relpos_mfma_kernel<HD_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm); \
+      set_ = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((relpos_mfma_kernel<HD_, NT_>), gridm, dim3(256), ldsm, st, qkv, ldq, heads, S, size, Rh, Rw, rel_h, rel_w); \
+  } while (0)
+    if (hd == 80 && NT == 1) HGL_RP_LAUNCH(80, 1);
+    else if (hd == 80) HGL_RP_LAUNCH(80, 4);
+    else if (NT == 1) HGL_RP_LAUNCH(64, 1);
+    else HGL_RP_LAUNCH(64, 4);
+#undef HGL_RP_LAUNCH
+    return hgl_check_launch("relpos_mfma");
+  }
   const dim3 grid((unsigned)((S + 255) / 256), (unsigned)(B * heads), 2);
   const size_t lds = (size_t)(2 * size - 1) * (hd + 4) * sizeof(float);
   if (hd == 80) hipLaunchKernelGGL(relpos_direct_kernel<80>, grid, dim3(256), lds, st, qkv, ldq, heads, S, size, Rh, Rw, rel_h, rel_w);
