@@ -51,16 +51,19 @@ def gem_flops_per_image(S=785, D=768, layers=12, gem_blocks=6, patch_k=768, embe
 
 
 def algorithmic_flops_per_ref(N=64, n_strings=9, sam=True, gem=False, clip_name="ViT-B/16"):
-    """SURVEY.md 8d, minimal variant (dead final-block streams removed), G2L: the two streams run through the blocks
-    below the masking block and the two-stream blocks, the returning block on one stream (ViT-B/16: 23 N block
-    evaluations of 2.908 GFLOP; ViT-L/14: 47 N of 6.738 GFLOP).  SAM ViT-H encoder 5.961 TFLOP + decoder 3.62 GFLOP
+    """SURVEY.md 8d, minimal variant (dead work removed), G2L: the two streams run through the blocks below the masking
+    block and the two-stream blocks (ViT-B/16: 22 N block evaluations of 2.908 GFLOP; ViT-L/14: 46 N of 6.738 GFLOP); the
+    returning block runs on one stream and only as far as its CLS row needs (0.70 instead of 2.908 GFLOP per mask).  SAM ViT-H encoder 5.961 TFLOP + decoder 3.62 GFLOP
     x 64 prompts; + the GEM heat-map stage when it runs here."""
     g = CLIP_GEOM[clip_name]
     S, D = g["S"], g["D"]
     blk = 2.0 * S * D * 12 * D + 4.0 * S * S * D          # ViT-B/16: 2.908e9 (qkv .697, proj .232, mlp 1.859, attn .119)
     patch = 2.0 * (S - 1) * g["patch_k"] * D               # ViT-B/16: 0.231e9
-    n_blk = 2 * g["last_layer"] + 3                        # 2 * masking_block + 2 * (last_layer + 1 - masking_block) + 1
-    clip = 2 * N * patch + n_blk * N * blk
+    # full blocks: both streams below the returning block (2 * (last_layer + 1) evaluations per mask); the returning block
+    # itself feeds only its CLS row to the head: ln_1 + qkv on every token, everything after on one row per sequence
+    n_full = 2 * g["last_layer"] + 2
+    ret = 2.0 * S * D * 3 * D + 4.0 * S * D + 2.0 * D * 9 * D
+    clip = 2 * N * patch + n_full * N * blk + N * ret
     tD = g["text_D"]
     text = (12 * (2.0 * 77 * tD * 12 * tD + 4.0 * 77 * 77 * tD) + 2.0 * tD * g["embed"]) * (n_strings + (3 if gem else 0))
     gem_fl = gem_flops_per_image(g["gem_S"], D, g["layers"], 6, g["patch_k"], g["embed"]) if gem else 0.0

@@ -161,14 +161,35 @@ int embed_images(const HglClipVisionW* w, const float* imgs, int n_img, float* X
   return hgl_clip_embed_images(w, imgs, n_img, X, p.F, p.QKV, st);
 }
 
-// ln_post(x[:,0]) @ proj  (+ R)   (model/backbone.py:254-260)
-int head(const HglClipVisionW* w, const float* X, int N, float* out, const float* R,
-         const ClipPlan& p, hipStream_t st) {
-  const int D = w->width, S = w->grid * w->grid + 1, E = w->embed;
-  HGL_TRY(hgl_launch_gather_rows(X, (long long)S * D, N, D, p.cls_rows, st));
+// The RETURNING block: only the CLS row of its output is consumed (ln_post(x[:, 0]) @ proj, model/backbone.py:254-260),
+// so only that row is computed past the attention: ln_1 + the qkv projection run on every token (the keys and values
+// of all tokens are needed), the attention on one query per sequence, the out-projection and the MLP on one row per
+// sequence.  2.2 of the block's 2.9 GFLOP per sequence are dead rows.  Leaves the CLS rows [B, D] in p.cls_rows.
+int run_block_cls(const HglResBlockW& w, const float* X, int B, int S, int D, int heads, const BlockBufs& bf, int mask_kind,
+                  const uint8_t* keep, int keep_b0, int keep_n, const ClipPlan& p, hipStream_t st) {
+  const int M = B * S, hd = D / heads;
+  const long long sQKV = (long long)S * 3 * D;
+  HGL_TRY(hgl_clip_block_qkv(w, X, M, D, bf, st));
+  float* att = bf.H;            // [B, D]: the ln_1 output is dead after the qkv projection
+  float* xcls = p.cls_rows;     // [B, D]
+  float* h = p.cls_ln;          // [B, D]
+  HGL_TRY(hgl_launch_attention(bf.QKV, bf.QKV + D, bf.QKV + 2 * D, att, B, heads, 1, S, hd, 3 * D, 3 * D, 3 * D, D, sQKV, sQKV,
+                               sQKV, (long long)D, 1.0f / sqrtf((float)hd), mask_kind, keep, keep_b0, keep_n, nullptr, nullptr,
+                               0, 0, st));
+  HGL_TRY(hgl_launch_gather_rows(X, (long long)S * D, B, D, xcls, st));
+  HGL_TRY(hgl_launch_gemm(att, w.out_proj_w, w.out_proj_b, xcls, xcls, B, D, D, D, D, D, D, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_layernorm(xcls, w.ln2_w, w.ln2_b, h, B, D, 1e-5f, st));
+  HGL_TRY(hgl_launch_gemm(h, w.fc_w, w.fc_b, nullptr, bf.F, B, 4 * D, D, D, D, 0, 4 * D, 1, 0, 0, 0, 0, HGL_ACT_QUICKGELU, st));
+  HGL_TRY(hgl_launch_gemm(bf.F, w.proj_w, w.proj_b, xcls, xcls, B, D, 4 * D, 4 * D, 4 * D, D, D, 1, 0, 0, 0, 0, HGL_ACT_NONE,
+                          st));
+  return HGL_OK;
+}
+
+// ln_post(rows) @ proj (+ R) on CLS rows that are already gathered (p.cls_rows)
+int head_rows(const HglClipVisionW* w, int N, float* out, const float* R, const ClipPlan& p, hipStream_t st) {
+  const int D = w->width, E = w->embed;
   HGL_TRY(hgl_launch_layernorm(p.cls_rows, w->ln_post_w, w->ln_post_b, p.cls_ln, N, D, 1e-5f, st));
-  HGL_TRY(hgl_launch_gemm(p.cls_ln, w->proj_t, nullptr, R, out, N, E, D, D, D, E, E, 1, 0, 0, 0, 0,
-                          HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_gemm(p.cls_ln, w->proj_t, nullptr, R, out, N, E, D, D, D, E, E, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
   return HGL_OK;
 }
 
@@ -229,9 +250,10 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
   if (need_masks) HGL_TRY(hgl_launch_mask_resize(masks, N, Hm, Wm, g, p.pm, p.keep, st));
 
   if (fusion_mode == HGL_FUSION_CROP) {
-    for (int l = 0; l < w->layers; ++l)
+    for (int l = 0; l + 1 < w->layers; ++l)
       HGL_TRY(run_block(w->blocks[l], p.X, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
-    return head(w, p.X, N, out, nullptr, p, st);
+    HGL_TRY(run_block_cls(w->blocks[w->layers - 1], p.X, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, p, st));
+    return head_rows(w, N, out, nullptr, p, st);
   }
 
   const int nb0 = two_stream ? 2 * N : N;
@@ -245,14 +267,16 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
       for (int l = masking_block; l <= ret_block; ++l) {
         // x = cat(cls, x*pm)  (model/backbone.py:163-176)
         HGL_TRY(hgl_launch_mix(X, nullptr, 0.f, X, 1.f, p.pm, N, S, D, st));
-        HGL_TRY(run_block(w->blocks[l], X, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
+        if (l < ret_block) HGL_TRY(run_block(w->blocks[l], X, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
+        else HGL_TRY(run_block_cls(w->blocks[l], X, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, p, st));
       }
-      return head(w, X, N, out, nullptr, p, st);
+      return head_rows(w, N, out, nullptr, p, st);
     }
     case HGL_FUSION_ATTN_MASKING: {
-      for (int l = masking_block; l <= ret_block; ++l)
+      for (int l = masking_block; l < ret_block; ++l)
         HGL_TRY(run_block(w->blocks[l], X, N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 0, N, st));
-      return head(w, X, N, out, nullptr, p, st);
+      HGL_TRY(run_block_cls(w->blocks[ret_block], X, N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 0, N, p, st));
+      return head_rows(w, N, out, nullptr, p, st);
     }
     case HGL_FUSION_G2L: {
       // streams: [local | global].  local' = blk(local + 2*tokmask(global)); global' = blk(global, keep)
@@ -261,12 +285,12 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
         if (l < ret_block) {
           (void)hipMemcpyAsync(Y + sN, X + sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
           HGL_TRY(run_block(w->blocks[l], Y, 2 * N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, N, N, st));
-        } else {  // the global stream of the returning block is dead
-          HGL_TRY(run_block(w->blocks[l], Y, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
+        } else {  // the global stream of the returning block is dead, and so are the non-CLS rows of the local one
+          HGL_TRY(run_block_cls(w->blocks[l], Y, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, p, st));
         }
         float* t = X; X = Y; Y = t;
       }
-      return head(w, X, N, out, nullptr, p, st);
+      return head_rows(w, N, out, nullptr, p, st);
     }
     case HGL_FUSION_L2G: {
       // local' = blk(local); global' = blk(local + 2*global, keep)
@@ -275,12 +299,12 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
         if (l < ret_block) {
           (void)hipMemcpyAsync(Y, X, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
           HGL_TRY(run_block(w->blocks[l], Y, 2 * N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, N, N, st));
-        } else {  // the local stream of the returning block is dead
-          HGL_TRY(run_block(w->blocks[l], Y + sN, N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 0, N, st));
+        } else {  // the local stream of the returning block is dead, and so are the non-CLS rows of the global one
+          HGL_TRY(run_block_cls(w->blocks[l], Y + sN, N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 0, N, p, st));
         }
         float* t = X; X = Y; Y = t;
       }
-      return head(w, X + sN, N, out, nullptr, p, st);
+      return head_rows(w, N, out, nullptr, p, st);
     }
     case HGL_FUSION_G2L_L2G: {
       // stream order here: [xl | hl | xg | hg]  (keep applies to the last two)
@@ -296,15 +320,16 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
           (void)hipMemcpyAsync(Y, X, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
           (void)hipMemcpyAsync(Y + 2 * sN, X + 2 * sN, sizeof(float) * sN, hipMemcpyDeviceToDevice, st);
           HGL_TRY(run_block(w->blocks[l], Y, 4 * N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 2 * N, N, st));
-        } else {  // plain xl / xg streams of the returning block are dead
-          HGL_TRY(run_block(w->blocks[l], Y + sN, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, st));
-          HGL_TRY(run_block(w->blocks[l], Y + 3 * sN, N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 0, N, st));
+        } else {  // plain xl / xg streams of the returning block are dead; of hl / hg only the CLS rows are consumed
+          HGL_TRY(run_block_cls(w->blocks[l], Y + sN, N, S, D, heads, bf, HGL_MASK_NONE, nullptr, 0, 0, p, st));
+          HGL_TRY(head_rows(w, N, out, nullptr, p, st));
+          HGL_TRY(run_block_cls(w->blocks[l], Y + 3 * sN, N, S, D, heads, bf, HGL_MASK_CLS_KEEP, p.keep, 0, N, p, st));
+          // out = head(hl) + head(hg): the second projection accumulates onto the first
+          return head_rows(w, N, out, out, p, st);
         }
         float* t = X; X = Y; Y = t;
       }
-      HGL_TRY(head(w, X + sN, N, out, nullptr, p, st));
-      // out = head(hl) + head(hg): the second projection accumulates onto the first
-      return head(w, X + 3 * sN, N, out, out, p, st);
+      break;   // not reached: the loop returns at the returning block
     }
   }
   hgl_set_error("clip_hybrid_forward: unreachable");
