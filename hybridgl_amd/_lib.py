@@ -113,6 +113,7 @@ PROTOTYPES = {
                                      _VP, _SZ, _VP]),
     "hgl_clip_text_workspace_bytes": (_SZ, [C.POINTER(HglClipTextW), _I]),
     "hgl_clip_encode_text": (_I, [C.POINTER(HglClipTextW), _VP, _I, _VP, _VP, _SZ, _VP]),
+    "hgl_clip_encode_text_prefix": (_I, [C.POINTER(HglClipTextW), _VP, _I, _I, _VP, _VP, _SZ, _VP]),
     "hgl_gem_workspace_bytes": (_SZ, [C.POINTER(HglClipVisionW)]),
     "hgl_gem_image_features": (_I, [C.POINTER(HglClipVisionW), _VP, _I, _I, _F, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_gem_batch_workspace_bytes": (_SZ, [C.POINTER(HglClipVisionW), _I]),

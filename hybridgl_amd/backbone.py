@@ -128,8 +128,10 @@ class _ClipModel:
         self._logit_scale_exp = float(np.exp(np.float32(np.asarray(sd["logit_scale"]))))
         self.context_length = cfg["context_length"]
 
-    def encode_text(self, text, target_noun_index=None):
-        """CLIP.encode_text (clip/model.py:414-431). text: [B, context] integer tokens."""
+    def encode_text(self, text, target_noun_index=None, seq_len=None):
+        """CLIP.encode_text (clip/model.py:414-431). text: [B, context] integer tokens.  seq_len (not in the
+        reference): compute only the first seq_len positions -- exact under the causal mask when every EOT token lies
+        inside that prefix (the caller's promise; the tokenizer knows the lengths)."""
         if target_noun_index:
             raise NotImplementedError("target_noun_index pooling is not on the Hybridgl_main path")
         lib = _lib.load()
@@ -141,8 +143,9 @@ class _ClipModel:
         need = lib.hgl_clip_text_workspace_bytes(C.byref(self.text_w), B)
         ws = ops.workspace(need, tok.device, "clip_text")
         out = torch.empty((B, self.cfg["embed_dim"]), dtype=torch.float32, device=tok.device)
-        check(lib.hgl_clip_encode_text(C.byref(self.text_w), tok.data_ptr(), B, out.data_ptr(),
-                                       ws.data_ptr(), ws.numel(), ops._stream()), "hgl_clip_encode_text")
+        S = self.context_length if seq_len is None else max(1, min(int(seq_len), self.context_length))
+        check(lib.hgl_clip_encode_text_prefix(C.byref(self.text_w), tok.data_ptr(), B, S, out.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), ops._stream()), "hgl_clip_encode_text")
         return out
 
 

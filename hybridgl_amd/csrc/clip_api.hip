@@ -366,11 +366,15 @@ size_t hgl_clip_text_workspace_bytes(const HglClipTextW* w, int B) {
   return ar.off;
 }
 
-int hgl_clip_encode_text(const HglClipTextW* w, const int32_t* tokens, int B, float* out,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+// seq_len <= context: only the first seq_len positions of every string are computed.  Under the causal mask a
+// position never sees later ones, so the pooled EOT feature is unchanged as long as every EOT lies inside the prefix
+// (the caller's promise; an EOT beyond it yields NaN rows rather than a wrong feature).
+int hgl_clip_encode_text_prefix(const HglClipTextW* w, const int32_t* tokens, int B, int seq_len, float* out,
+                                void* workspace, size_t workspace_bytes, void* stream) {
   HGL_TRY(hgl_require_device());
   HGL_REQUIRE(valid_text(w), "clip_encode_text: invalid weight struct");
   HGL_REQUIRE(tokens && out && B > 0, "clip_encode_text: null input");
+  HGL_REQUIRE(seq_len >= 1 && seq_len <= w->context, "clip_encode_text: prefix length %d outside 1..%d", seq_len, w->context);
   HglArena ar(workspace, workspace_bytes);
   TextPlan p;
   if (!workspace || !carve_text(ar, w, B, p)) {
@@ -378,8 +382,8 @@ int hgl_clip_encode_text(const HglClipTextW* w, const int32_t* tokens, int B, fl
     return HGL_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int D = w->width, S = w->context;
-  HGL_TRY(hgl_launch_text_embed(tokens, w->token_embedding, w->positional_embedding, p.X, B, S, D,
+  const int D = w->width, S = seq_len;
+  HGL_TRY(hgl_launch_text_embed(tokens, w->token_embedding, w->positional_embedding, p.X, B, S, w->context, D,
                                 w->vocab, p.eot, st));
   BlockBufs bf{p.H, p.QKV, p.F};
   for (int l = 0; l < w->layers; ++l)
@@ -390,6 +394,11 @@ int hgl_clip_encode_text(const HglClipTextW* w, const int32_t* tokens, int B, fl
   HGL_TRY(hgl_launch_gemm(p.rows_ln, w->text_projection_t, nullptr, nullptr, out, B, w->embed, D, D, D,
                           0, w->embed, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
   return HGL_OK;
+}
+
+int hgl_clip_encode_text(const HglClipTextW* w, const int32_t* tokens, int B, float* out,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  return hgl_clip_encode_text_prefix(w, tokens, B, w ? w->context : 0, out, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

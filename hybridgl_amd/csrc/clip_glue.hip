@@ -232,39 +232,42 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ y,
 }
 
 // one wave per (b,s) row; also finds the EOT position = first argmax of token ids per sequence
+// S <= ctx positions of every token row are embedded (row stride ctx); the EOT index is the arg-max over the whole row
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ tokens,
                                                          const float* __restrict__ emb,
                                                          const float* __restrict__ pos,
-                                                         float* __restrict__ x, int B, int S, int D,
+                                                         float* __restrict__ x, int B, int S, int ctx, int D,
                                                          int vocab, int32_t* __restrict__ eot) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
   if (row >= (long long)B * S) return;
   const int s = (int)(row % S);
   const int bidx = (int)(row / S);
-  int tk = tokens[row];
+  int tk = tokens[(long long)bidx * ctx + s];
   tk = tk < 0 ? 0 : (tk >= vocab ? vocab - 1 : tk);
   const float* er = emb + (long long)tk * D;
   const float* pr = pos + (long long)s * D;
   float* xr = x + row * D;
   for (int i = lane; i < D; i += 64) xr[i] = er[i] + pr[i];
   if (s == 0 && lane == 0) {
-    int best = 0, bv = tokens[(long long)bidx * S];
-    for (int j = 1; j < S; ++j) {
-      const int v = tokens[(long long)bidx * S + j];
+    int best = 0, bv = tokens[(long long)bidx * ctx];
+    for (int j = 1; j < ctx; ++j) {
+      const int v = tokens[(long long)bidx * ctx + j];
       if (v > bv) { bv = v; best = j; }
     }
     eot[bidx] = best;
   }
 }
 
+// y[b] = x[b, eot[b]]; an EOT beyond the computed prefix (a caller that passed too short a prefix) gives NaN rows
 __global__ __launch_bounds__(256) void gather_eot_kernel(const float* __restrict__ x,
                                                          const int32_t* __restrict__ eot, int B,
                                                          int S, int D, float* __restrict__ y) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= (long long)B * D) return;
   const int bidx = (int)(i / D), d = (int)(i % D);
-  y[i] = x[((long long)bidx * S + eot[bidx]) * D + d];
+  const int e = eot[bidx];
+  y[i] = e < S ? x[((long long)bidx * S + e) * D + d] : __int_as_float(0x7fc00000);
 }
 
 inline unsigned grid_for(long long n, int block = 256, unsigned cap = 256u * 16u) {
@@ -346,9 +349,9 @@ int hgl_launch_add_inplace(float* y, const float* x, long long n, hipStream_t st
 }
 
 int hgl_launch_text_embed(const int32_t* tokens, const float* emb, const float* pos, float* x, int B,
-                          int S, int D, int vocab, int32_t* eot, hipStream_t st) {
+                          int S, int ctx, int D, int vocab, int32_t* eot, hipStream_t st) {
   const long long rows = (long long)B * S;
-  hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, tokens, emb, pos, x, B, S, D, vocab, eot);
+  hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, tokens, emb, pos, x, B, S, ctx, D, vocab, eot);
   return hgl_check_launch("text_embed");
 }
 

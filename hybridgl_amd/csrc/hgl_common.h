@@ -94,7 +94,7 @@ int hgl_launch_gather_rows(const float* x, long long row_stride, int rows, int D
                            hipStream_t st);
 int hgl_launch_add_inplace(float* y, const float* x, long long n, hipStream_t st);
 int hgl_launch_text_embed(const int32_t* tokens, const float* emb, const float* pos, float* x, int B,
-                          int S, int D, int vocab, int32_t* eot, hipStream_t st);
+                          int S, int ctx, int D, int vocab, int32_t* eot, hipStream_t st);
 int hgl_launch_gather_eot(const float* x, const int32_t* eot, int B, int S, int D, float* y,
                           hipStream_t st);
 

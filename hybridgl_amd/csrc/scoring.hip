@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void score_sentence_kernel(
     for (int w = 1; w < 4; ++w)
       if (red[w] > gmx || (red[w] == gmx && redi[w] < gmi)) { gmx = red[w]; gmi = redi[w]; }
     __syncthreads();
-    if (which == 0 && t == 0) idx[0] = gmi;
+    if (which == 0 && t == 0) idx[0] = gmi == 0x7fffffff ? 0 : gmi;   // all-NaN logits (a NaN text feature): a valid index, NaN scores
     float se = 0.f;
     for (int n = t; n < N; n += 256) se += expf(lg[n] - gmx);
     se = wave_sum_f(se);

@@ -92,7 +92,8 @@ def real_refs(args, dev, splitBy, context_length):
         placeholder = torch.zeros((1, H, W), dtype=torch.bool, device=dev)
         yield RefBatch(t(img), None, t(synth.imagenet_normalize(img)), placeholder,
                        torch.zeros((1, 4), dtype=torch.int64, device=dev), t(tokens), t(annot), sents, None,
-                       int(data["img_id"][0]), tensor_img=preprocess(img).to(dev) if args.heatmap == "device" else None)
+                       int(data["img_id"][0]), tensor_img=preprocess(img).to(dev) if args.heatmap == "device" else None,
+                       token_len=int(tokens.argmax(axis=1).max()) + 1)
 
 
 def main(args):

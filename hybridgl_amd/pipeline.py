@@ -53,6 +53,8 @@ class RefBatch:
     sam_resized: Optional[torch.Tensor] = None  # [h,w,3] uint8: sam_img after ResizeLongestSide (PIL, host)
     image_id: Optional[int] = None  # COCO image id: consecutive refs of one image reuse proposals + hybrid features
     tensor_img: Optional[torch.Tensor] = None   # [3,448,448] fp32: image['tensor_img'] = gem.get_gem_img_transform()(img)
+    token_len: Optional[int] = None   # 1 + the largest EOT position of `tokens` (host knowledge of the tokenizer): the text
+                                      # encoder then computes only that prefix of the 77 positions (exact: causal mask)
 
 
 class EmptyProposals(RuntimeError):
@@ -200,7 +202,7 @@ class HybridGLPipeline:
         self._s_text.wait_event(ev_in)
         heat = None
         with torch.cuda.stream(self._s_text):
-            text = m.model.encode_text(ref.tokens)
+            text = m.model.encode_text(ref.tokens, seq_len=ref.token_len)
             gem_rows = [s.gem_row for s in ref.sentences if s.imgattn is None]
             if gem_rows:
                 # Hybridgl_main.py:200-201: gem_model(tensor_img, [noun_phrase])[0] -> T.Resize((h, w), antialias=True).
@@ -225,7 +227,8 @@ class HybridGLPipeline:
         # image only, so they are computed once per image.  Results are identical.
         if ref.image_id is not None and getattr(self, "_cache_id", None) == ref.image_id:
             hybrid = self._cache_hybrid
-            ref = dataclasses.replace(self._cache_ref, tokens=ref.tokens, sentences=ref.sentences, target=ref.target)
+            ref = dataclasses.replace(self._cache_ref, tokens=ref.tokens, token_len=ref.token_len, sentences=ref.sentences,
+                                      target=ref.target)
         else:
             if self.mask_generator is not None:
                 # Hybridgl_main.py:85 mask_generator.generate(sam_img), kept on the device
@@ -303,7 +306,9 @@ class HybridGLPipeline:
         offs = np.cumsum([0] + [r.tokens.shape[0] for r in refs])
         heats = []
         with torch.cuda.stream(self._s_text):
-            text_all = m.model.encode_text(torch.cat([r.tokens for r in refs], dim=0))
+            lens = [r.token_len for r in refs]
+            text_all = m.model.encode_text(torch.cat([r.tokens for r in refs], dim=0),
+                                           seq_len=None if any(v is None for v in lens) else max(lens))
             # GEM image towers of the refs that need a heat-map: one pass over all of them when their sizes agree
             need = [i for i, r in enumerate(refs) if any(s.imgattn is None for s in r.sentences)]
             gfeats = {}
@@ -393,7 +398,7 @@ def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=494
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     resized = None   # ResizeLongestSide runs on the device (hgl_resize_pil_bilinear), inside the step
     ref = RefBatch(t(img), None if device_blur else t(blur), t(norm), t(masks), t(boxes), t(tokens), t(gt), sents, resized,
-                   tensor_img=t(tensor_img) if gem else None)
+                   tensor_img=t(tensor_img) if gem else None, token_len=int(tokens.argmax(axis=1).max()) + 1)
     host = dict(img=img, blur=blur, norm=norm, masks=masks, boxes=boxes, tokens=tokens, gt=gt, attn=attn_np,
                 tensor_img=tensor_img)
     return ref, host

@@ -176,6 +176,10 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
 size_t hgl_clip_text_workspace_bytes(const HglClipTextW* w, int B);
 int hgl_clip_encode_text(const HglClipTextW* w, const int32_t* tokens, int B, float* out,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same on the first seq_len <= context positions only: exact under the causal mask as long as every EOT token
+ * lies inside the prefix (referring expressions use a dozen of the 77 positions); an EOT beyond it yields NaN rows. */
+int hgl_clip_encode_text_prefix(const HglClipTextW* w, const int32_t* tokens, int B, int seq_len, float* out,
+                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Text-conditioned heat-map: the GEM call of Hybridgl_main.py:36-39,200-201

@@ -111,6 +111,26 @@ def test_encode_text_vs_reference_golden(cuda, golden_dir, tiny, b16, name, cfg)
     np.testing.assert_allclose(y, g["out"], rtol=0, atol=5e-5)
 
 
+def test_encode_text_prefix_is_exact(cuda, b16):
+    """encode_text(seq_len=L): only the first L of the 77 positions are computed; under the causal mask the EOT feature
+    does not depend on later positions, so the result equals the full computation when every EOT lies inside the
+    prefix -- and is NaN (not a wrong feature) for a string whose EOT lies beyond it."""
+    from hybridgl_amd.synth import synth_tokens
+    _, model = b16
+    tok = synth_tokens(12, 77, 49408, 21)
+    L = int(tok.argmax(axis=1).max()) + 1
+    assert L <= 14
+    t = torch.from_numpy(tok).to(cuda)
+    full = model.model.encode_text(t)
+    pre = model.model.encode_text(t, seq_len=L)
+    np.testing.assert_allclose(pre.cpu().numpy(), full.cpu().numpy(), rtol=0, atol=1e-5)   # different GEMM kernels at 168 vs 924 rows
+    np.testing.assert_allclose(model.model.encode_text(t, seq_len=L + 9).cpu().numpy(), full.cpu().numpy(), rtol=0, atol=1e-5)
+    short = model.model.encode_text(t, seq_len=L - 1).cpu().numpy()
+    late = tok.argmax(axis=1) >= L - 1
+    assert late.any() and np.isnan(short[late]).all() and np.isfinite(short[~late]).all()
+    np.testing.assert_allclose(short[~late], full.cpu().numpy()[~late], rtol=0, atol=1e-5)
+
+
 def test_linearity_of_head_and_determinism(cuda, b16):
     """size-independent properties at the BASELINE size (N=64): the result does not depend on the
     batch composition (each mask row is independent) and repeated runs are bit-identical."""
@@ -138,7 +158,7 @@ def test_pipeline_image_cache_identical(cuda, b16):
     ref0, _ = synthetic_ref(0, cuda, N=8)
     ref1, _ = synthetic_ref(1, cuda, N=8)
     # second ref: same image/masks as ref0, its own sentences
-    ref_b = dataclasses.replace(ref0, tokens=ref1.tokens, sentences=ref1.sentences, target=ref0.target)
+    ref_b = dataclasses.replace(ref0, tokens=ref1.tokens, token_len=ref1.token_len, sentences=ref1.sentences, target=ref0.target)
     p1 = HybridGLPipeline(model, "G2L", 9)
     p1.step(ref0); out_plain = p1.step(ref_b)
     p2 = HybridGLPipeline(model, "G2L", 9)

@@ -148,7 +148,7 @@ def test_pipeline_computes_heatmaps_like_the_reference_sequence(cuda, b16):
     p1 = HybridGLPipeline(clip, "G2L", 9, gem_model=gm)
     out1 = p1.step(ref)
     # the same ref with the heat-maps produced up front through the package-style call surface
-    text = clip.model.encode_text(ref.tokens)
+    text = clip.model.encode_text(ref.tokens, seq_len=ref.token_len)     # the pipeline computes the EOT prefix only
     sents = []
     for s in ref.sentences:
         m = gm.heatmap(gm.image_features(ref.tensor_img), text[s.gem_row:s.gem_row + 1], 448)      # gem_model(...)[0]
