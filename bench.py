@@ -50,7 +50,7 @@ def gem_flops_per_image(S=785, D=768, layers=12, gem_blocks=6, patch_k=768, embe
     return plain + ss + 2.0 * (S - 1) * patch_k * D + 2.0 * S * D * embed
 
 
-def algorithmic_flops_per_ref(N=64, n_strings=9, sam=True, gem=False, clip_name="ViT-B/16"):
+def algorithmic_flops_per_ref(N=64, n_strings=9, sam=True, gem=False, clip_name="ViT-B/16", text_S=77):
     """SURVEY.md 8d, minimal variant (dead work removed), G2L: the two streams run through the blocks below the masking
     block and the two-stream blocks (ViT-B/16: 22 N block evaluations of 2.908 GFLOP; ViT-L/14: 46 N of 6.738 GFLOP); the
     returning block runs on one stream and only as far as its CLS row needs (0.70 instead of 2.908 GFLOP per mask).  SAM ViT-H encoder 5.961 TFLOP + decoder 3.62 GFLOP
@@ -65,7 +65,8 @@ def algorithmic_flops_per_ref(N=64, n_strings=9, sam=True, gem=False, clip_name=
     ret = 2.0 * S * D * 3 * D + 4.0 * S * D + 2.0 * D * 9 * D
     clip = 2 * N * patch + n_full * N * blk + N * ret
     tD = g["text_D"]
-    text = (12 * (2.0 * 77 * tD * 12 * tD + 4.0 * 77 * 77 * tD) + 2.0 * tD * g["embed"]) * (n_strings + (3 if gem else 0))
+    # text_S: positions the text encoder computes (77 = the full context; the pipeline computes the EOT prefix only)
+    text = (12 * (2.0 * text_S * tD * 12 * tD + 4.0 * text_S * text_S * tD) + 2.0 * tD * g["embed"]) * (n_strings + (3 if gem else 0))
     gem_fl = gem_flops_per_image(g["gem_S"], D, g["layers"], 6, g["patch_k"], g["embed"]) if gem else 0.0
     return clip + text + ((5.961e12 + 64 * 3.62e9) if sam else 0.0) + gem_fl
 
@@ -436,7 +437,8 @@ def main():
                 "parallelism": f"image-parallel x{world}",
             },
             "roofline": roofline(precision, nprof, (g_n, g_ms, g_fl), (x_n, x_ms, x_fl), (a_n, a_ms, a_fl), traffic,
-                                 algorithmic_flops_per_ref(args.masks, sam=args.scope == "B", gem=use_gem, clip_name=args.clip) / (dt / args.steps) / 1e12,
+                                 algorithmic_flops_per_ref(args.masks, sam=args.scope == "B", gem=use_gem, clip_name=args.clip,
+                                                           text_S=max(r.token_len or 77 for r in refs)) / (dt / args.steps) / 1e12,
                                  xg=(xg_n, xg_ms, xg_fl), few=(fw_n, fw_ms, fw_fl)),
             "precision": precision,
             "metrics": m,
