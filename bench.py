@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--clip", default="ViT-B/16", choices=list(CLIP_GEOM),
                     help="CLIP geometry: ViT-B/16 = the reference's configuration; ViT-L/14 = the extension BASELINE.json names")
     ap.add_argument("--masks", type=int, default=64)
-    ap.add_argument("--pool", type=int, default=2, help="distinct synthetic refs resident per rank")
+    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic refs resident per rank (a group of 8 = 8 different images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="scope B: run the SAM stage and the CLIP stage back to back on one stream instead of "
