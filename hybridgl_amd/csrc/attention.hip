@@ -17,6 +17,7 @@
 //     ds_read_b128 fragment reads are conflict free; V read as ds_read_b32 rows).
 //   * everything fp32: exact products, fp32 accumulation -> matches the fp32 reference.
 #include "hgl_common.h"
+#include <stdlib.h>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -272,8 +273,12 @@ __device__ __forceinline__ h16x4 lds_tr4(const _Float16* p) {
 // indicator of (key / RELW, RELW + key % RELW).  E is appended to the staged K rows, so the bias costs two more
 // k-steps (4 MFMAs) per key tile and no index arithmetic.  (The generic path divides and issues two dependent
 // global loads per score; on the windowed blocks that made the kernel 3x slower than its MFMA work.)
-template <int HD, int RELW>
-__global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
+// NW waves per workgroup, 32 queries each: 4 (two workgroups per CU) or 8 (one workgroup per CU, 256 queries: a
+// 14 x 14 window or a 197-token CLIP sequence is then ONE workgroup that stages the keys and values once instead of
+// two workgroups that each stage all of them).
+template <int HD, int RELW, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnArgs a) {
+  constexpr int NT = NW * 64;
   constexpr int KS = HD / 16;                 // k-steps of the QK^T contraction
   constexpr int EW = RELW > 0 ? 32 : 0;       // indicator columns appended to a K row
   constexpr int KROW = 2 * HD + EW + 8;       // halfs per staged K row: hi | lo | E | pad (odd multiple of 16 B)
@@ -285,9 +290,10 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   // four rows of a block then fall on four different 64-byte bank groups.
   constexpr int VP = HD <= 32 ? 32 : 96;      // halfs per staged V row (>= DT*32)
   constexpr int F4 = HD / 4;
-  constexpr int NLK = KV_CHUNK * F4 / 256;    // K float4 per thread per chunk
+  constexpr int NLK = (KV_CHUNK * F4 + NT - 1) / NT;    // K float4 per thread per chunk (the last one guarded)
   constexpr int NLV = NLK;                    // V float4 per thread per chunk (same row-major walk as K)
-  static_assert(HD % 16 == 0 && KV_CHUNK * F4 % 256 == 0, "unsupported head dim");
+  static_assert(HD % 16 == 0, "unsupported head dim");
+  constexpr bool EXACT = KV_CHUNK * F4 % NT == 0;   // every thread has NLK elements
   __shared__ __attribute__((aligned(16))) _Float16 Ks[KV_CHUNK * KROW];
   static_assert(VP >= DT * 32, "V row pitch");
   __shared__ __attribute__((aligned(16))) _Float16 Vh[KV_CHUNK * VP];
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   const int r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y;
   const int b = bh / a.H, hh = bh - b * a.H;
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int q0 = (blockIdx.x * NW + wave) * 32;
   const int qi = q0 + r;
   const bool qvalid = qi < a.Sq;
   // a wave whose 32 queries all lie beyond the sequence (e.g. the 4th wave of the second 128-query block at S = 197)
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   const float* relh = a.rel_h ? a.rel_h + ((long long)bh * a.Sq + (qvalid ? qi : 0)) * a.kh : nullptr;
   const float* relw = a.rel_w ? a.rel_w + ((long long)bh * a.Sq + (qvalid ? qi : 0)) * a.kw : nullptr;
   int sk_eff = a.Sk;
-  if (a.mask_kind == HGL_MASK_CAUSAL) sk_eff = min(a.Sk, (int)(blockIdx.x * 4 + 4) * 32);
+  if (a.mask_kind == HGL_MASK_CAUSAL) sk_eff = min(a.Sk, (int)(blockIdx.x * NW + NW) * 32);
   // R fragments of the MFMA bias: lane (r,h) element j of step c = R[q][16c + 8h + j]
   h16x8 rbh[2], rbl[2];
   if constexpr (RELW > 0) {
@@ -369,13 +375,15 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   auto load_chunk = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NLK; ++i) {
-      const int idx = t + 256 * i;
+      const int idx = t + NT * i;
+      if (!EXACT && idx >= KV_CHUNK * F4) break;
       const int row = idx / F4, c4 = idx - row * F4;
       pk[i] = *(const f32x4*)(kp + (long long)min(kc + row, a.Sk - 1) * a.ldk + c4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < NLV; ++i) {
-      const int idx = t + 256 * i;
+      const int idx = t + NT * i;
+      if (!EXACT && idx >= KV_CHUNK * F4) break;
       const int row = idx / F4, c4 = idx - row * F4;
       pv[i] = *(const f32x4*)(vp + (long long)min(kc + row, a.Sk - 1) * a.ldv + c4 * 4);
     }
@@ -383,14 +391,15 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   auto store_chunk = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NLK; ++i) {
-      const int idx = t + 256 * i;
+      const int idx = t + NT * i;
+      if (!EXACT && idx >= KV_CHUNK * F4) break;
       const int row = idx / F4, c4 = idx - row * F4;
       h16x4 hi, lo;
       split4(pk[i], hi, lo);
       *(h16x4*)(Ks + row * KROW + c4 * 4) = hi;
       *(h16x4*)(Ks + row * KROW + HD + c4 * 4) = lo;
     }
-    if constexpr (RELW > 0) {   // indicator columns: thread -> (key row t/4, 8 of the 32 columns)
+    if (RELW > 0 && t < 256) {   // indicator columns: thread -> (key row t/4, 8 of the 32 columns)
       const int row = t >> 2, j0 = 8 * (t & 3), kg = kc + row;
       const int ih = kg / RELW, iw = RELW + kg - ih * RELW;
       h16x8 e;
@@ -400,7 +409,8 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NLV; ++i) {
-      const int idx = t + 256 * i;
+      const int idx = t + NT * i;
+      if (!EXACT && idx >= KV_CHUNK * F4) break;
       const int row = idx / F4, c4 = idx - row * F4;
       h16x4 hi, lo;
       split4(pv[i], hi, lo);
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(AttnArgs a) {
   };
   if (VP > HD) {  // zero the d padding of every row once (it feeds output rows that are never stored)
     constexpr int PADW = VP - HD > 0 ? VP - HD : 1;
-    for (int i = t; i < KV_CHUNK * PADW; i += 256) {
+    for (int i = t; i < KV_CHUNK * PADW; i += NT) {
       const int row = i / PADW, c = i - row * PADW;
       Vh[row * VP + HD + c] = (_Float16)0.f;
       Vl[row * VP + HD + c] = (_Float16)0.f;
@@ -806,10 +816,20 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
   HglProfScope prof(HGL_PROF_ATTN, 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD,
                     4.0 * a.B * a.H * HD * (2.0 * a.Sq + 2.0 * a.Sk), st);
   if (hgl_precision() == HGL_PREC_F16X3) {
-    if (HD == 80 && a.rel_h && a.kh == 14 && a.kw == 14 && a.Sk == 196 && a.mask_kind == HGL_MASK_NONE)
-      hipLaunchKernelGGL((attn_x3_kernel<HD, HD == 80 ? 14 : 0>), grid, dim3(256), 0, st, a);
-    else
+    // sequences of 129..256 queries (a 14 x 14 window, a 197-token CLIP sequence): one 8-wave workgroup per (batch, head)
+    static const int wide = getenv("HGL_ATTN_WIDE") ? atoi(getenv("HGL_ATTN_WIDE")) : 1;
+    // (longer sequences measured neutral for 785 queries, slower for the 4096-query global blocks: two independent
+    // 4-wave workgroups per CU interleave their phases, one 8-wave workgroup meets at every barrier)
+    const bool w8 = wide && HD >= 64 && a.Sq > 128 && a.Sq <= 256 && a.mask_kind != HGL_MASK_CAUSAL;
+    const dim3 grid8((a.Sq + 255) / 256, a.B * a.H);
+    if (HD == 80 && a.rel_h && a.kh == 14 && a.kw == 14 && a.Sk == 196 && a.mask_kind == HGL_MASK_NONE) {
+      if (w8) hipLaunchKernelGGL((attn_x3_kernel<HD, HD == 80 ? 14 : 0, 8>), grid8, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((attn_x3_kernel<HD, HD == 80 ? 14 : 0>), grid, dim3(256), 0, st, a);
+    } else if (w8 && !a.rel_h) {
+      hipLaunchKernelGGL((attn_x3_kernel<HD, 0, 8>), grid8, dim3(512), 0, st, a);
+    } else {
       hipLaunchKernelGGL((attn_x3_kernel<HD, 0>), grid, dim3(256), 0, st, a);
+    }
   }
   else hipLaunchKernelGGL(attn_f32_kernel<HD>, grid, dim3(256), 0, st, a);
   return hgl_check_launch("attention");
