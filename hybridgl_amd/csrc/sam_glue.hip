@@ -170,28 +170,12 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const float* __restric
   _Float16* Th = (_Float16*)rp_smem;                       // [NT*32][TP] hi
   _Float16* Tl = Th + NT * 32 * TP;                        // [NT*32][TP] lo
   float* G = (float*)(Tl + NT * 32 * TP);                  // [4 waves][32 queries][GP]
-  const int axis = blockIdx.z, bh = blockIdx.y;
+  const int bh = blockIdx.y;
   const int b = bh / heads, hh = bh % heads;
-  const float* R = axis ? Rw : Rh;
   const int nrow = 2 * size - 1;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
-  for (int i = t; i < NT * 32 * (HD / 4); i += 256) {
-    const int rr = i / (HD / 4), c = i % (HD / 4);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (rr < nrow) v = *(const f32x4*)(R + (long long)rr * HD + 4 * c);
-    rp_h4 a, l;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      _Float16 h0, l0;
-      hgl_split_hi_lo(v[e], h0, l0);
-      a[e] = h0;
-      l[e] = l0;
-    }
-    *(rp_h4*)(Th + rr * TP + 4 * c) = a;
-    *(rp_h4*)(Tl + rr * TP + 4 * c) = l;
-  }
-  __syncthreads();
+  // the wave's 32 query vectors, split once and used for both axes
   const int q = (blockIdx.x * 4 + wave) * 32 + r;
   const bool qvalid = q < S;
   const float* qp = qkv + ((long long)b * S + (qvalid ? q : 0)) * ldq + hh * HD;
@@ -211,38 +195,59 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const float* __restric
     }
   }
   float* Gw = G + (wave * 32 + r) * GP;
+  for (int axis = 0; axis < 2; ++axis) {
+    const float* R = axis ? Rw : Rh;
+    if (axis) __syncthreads();                             // every wave has gathered from its patch / read the table
+    for (int i = t; i < NT * 32 * (HD / 4); i += 256) {
+      const int rr = i / (HD / 4), c = i % (HD / 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (rr < nrow) v = *(const f32x4*)(R + (long long)rr * HD + 4 * c);
+      rp_h4 a, l;
 #pragma unroll
-  for (int tt = 0; tt < NT; ++tt) {
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const _Float16* trow = Th + (tt * 32 + r) * TP + 8 * h;
-    const _Float16* lrow = Tl + (tt * 32 + r) * TP + 8 * h;
-#pragma unroll
-    for (int c = 0; c < KS; ++c) {
-      const rp_h8 ah = *(const rp_h8*)(trow + 16 * c);
-      const rp_h8 al = *(const rp_h8*)(lrow + 16 * c);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[c], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[c], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[c], acc, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) {
+        _Float16 h0, l0;
+        hgl_split_hi_lo(v[e], h0, l0);
+        a[e] = h0;
+        l[e] = l0;
+      }
+      *(rp_h4*)(Th + rr * TP + 4 * c) = a;
+      *(rp_h4*)(Tl + rr * TP + 4 * c) = l;
     }
-    // acc[e] = T[table index tt*32 + (e&3) + 8*(e>>2) + 4*h][query r]
+    __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) Gw[tt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[e];
-  }
-  __syncthreads();
-  if (!qvalid) return;
-  const int qc = axis ? q % size : q / size;
-  float* out = (axis ? rel_w : rel_h) + ((long long)bh * S + q) * size;
-  // the two lanes of a query share its row: k in [0, sp) and [sp, size), sp even so that both write aligned pairs
-  const int sp = (size / 2 + 1) & ~1;
-  const int k0 = h ? sp : 0, k1 = h ? size : sp;
-  const float* src = Gw + qc + size - 1;                  // entry of k = 0; the index falls by one per k
-  for (int k = k0; k < k1; k += 2) {
-    f32x2 o;
-    o[0] = src[-k];
-    o[1] = src[-k - 1];
-    *(f32x2*)(out + k) = o;
+    for (int tt = 0; tt < NT; ++tt) {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      const _Float16* trow = Th + (tt * 32 + r) * TP + 8 * h;
+      const _Float16* lrow = Tl + (tt * 32 + r) * TP + 8 * h;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        const rp_h8 ah = *(const rp_h8*)(trow + 16 * c);
+        const rp_h8 al = *(const rp_h8*)(lrow + 16 * c);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[c], acc, 0, 0, 0);
+      }
+      // acc[e] = T[table index tt*32 + (e&3) + 8*(e>>2) + 4*h][query r]
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Gw[tt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[e];
+    }
+    __syncthreads();
+    if (qvalid) {
+      const int qc = axis ? q % size : q / size;
+      float* out = (axis ? rel_w : rel_h) + ((long long)bh * S + q) * size;
+      // the two lanes of a query share its row: k in [0, sp) and [sp, size), sp even so that both write aligned pairs
+      const int sp = (size / 2 + 1) & ~1;
+      const int k0 = h ? sp : 0, k1 = h ? size : sp;
+      const float* src = Gw + qc + size - 1;                // entry of k = 0; the index falls by one per k
+      for (int k = k0; k < k1; k += 2) {
+        f32x2 o;
+        o[0] = src[-k];
+        o[1] = src[-k - 1];
+        *(f32x2*)(out + k) = o;
+      }
+    }
   }
 }
 
@@ -866,7 +871,7 @@ int hgl_launch_relpos_direct(const float* qkv, int ldq, int B, int heads, int S,
   // f16x3 mode: the matrix-core version (table of 2*size-1 rows padded to 32 / 128)
   if (hgl_precision() == HGL_PREC_F16X3 && (size == 14 || size == 64)) {
     const int NT = size == 14 ? 1 : 4;
-    const dim3 gridm((unsigned)((S + 127) / 128), (unsigned)(B * heads), 2);
+    const dim3 gridm((unsigned)((S + 127) / 128), (unsigned)(B * heads), 1);   // both axes in one workgroup: q is read once
     const size_t ldsm = (size_t)2 * NT * 32 * (hd + 8) * sizeof(_Float16) + (size_t)4 * 32 * (NT * 32 + 1) * sizeof(float);
 #define HGL_RP_LAUNCH(HD_, NT_)                                                                                          \
   do {                                                                                                                 \
