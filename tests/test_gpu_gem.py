@@ -192,7 +192,8 @@ def test_step_group_equals_per_ref_steps(cuda, b16):
     from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
     _, clip = b16
     gm = G.create_gem_model("ViT-B/16", clip=clip)
-    refs = [synthetic_ref(i, cuda, N=8, H=320, W=480, gem=True, device_blur=True)[0] for i in range(3)]
+    # ragged group: the refs bring different numbers of proposals
+    refs = [synthetic_ref(i, cuda, N=n, H=320, W=480, gem=True, device_blur=True)[0] for i, n in enumerate((8, 5, 11))]
     p1 = HybridGLPipeline(clip, "G2L", 9, gem_model=gm)
     outs1 = [p1.step(r) for r in refs]
     p2 = HybridGLPipeline(clip, "G2L", 9, gem_model=gm)
