@@ -426,7 +426,10 @@ def main():
                              + (f"GEM heat-map stage ({args.clip} at 448x448, self-self attention in the last 6 blocks, once "
                                 "per image; 3 prompts -> 3 maps, antialiased resize to the image) + " if use_gem else
                                 "heat-maps given + ")
-                             + "scoring tail + IoU"),
+                             + "scoring tail + IoU"
+                             + (f"; refs are taken in groups of up to {nbatch} (one SAM encoder pass over the group's images, one "
+                                "text-encoder batch, one GEM tower pass and one hybrid forward over the group's masks; same work "
+                                "and results per ref)" if (pair or (gen is None and nbatch >= 2)) else "")),
                 "scope": args.scope,
                 "heatmap": args.heatmap,
                 "stage_overlap": bool(overlap),
