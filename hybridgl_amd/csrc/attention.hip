@@ -38,6 +38,7 @@ struct AttnArgs {
   int keep_b0, keep_n;
   const float *rel_h, *rel_w;
   int kh, kw;
+  const float *tab_h, *tab_w;  // RELW kernels: the rel-pos TABLES [2*RELW-1, HD]; rel_h / rel_w are then computed in the kernel
   _Float16 *out_hi, *out_lo;   // f16x3 kernels: when out == nullptr the result is written as the fp16 hi+lo pair
 };
 
@@ -298,6 +299,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
   static_assert(VP >= DT * 32, "V row pitch");
   __shared__ __attribute__((aligned(16))) _Float16 Vh[KV_CHUNK * VP];
   __shared__ __attribute__((aligned(16))) _Float16 Vl[KV_CHUNK * VP];
+  // per wave: T[query][table index] of the two axes when the decomposed rel-pos terms are computed here
+  constexpr int RPP = 33;
+  __shared__ float RPatch[(RELW > 0 && NW == 8) ? NW * 2 * 32 * RPP : 1];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -355,19 +359,94 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
   // R fragments of the MFMA bias: lane (r,h) element j of step c = R[q][16c + 8h + j]
   h16x8 rbh[2], rbl[2];
   if constexpr (RELW > 0) {
+    bool from_tables = false;
+    if constexpr (NW == 8) from_tables = a.tab_h != nullptr;
+    if constexpr (NW == 8) {
+      if (from_tables && wave_active) {
+        // rel_h[q][k] = q . Rh[qy - k + RELW-1] (image_encoder.py:325-361, UNSCALED q): T^T = R . Q^T on the matrix cores
+        // with the same split-fp16 scheme and summation order as relpos_mfma_kernel, per wave, through an LDS patch
+        h16x8 uh[KS], ul[KS];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+        for (int sx = 0; sx < KS; ++sx) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int idx = 16 * c + 8 * h + j;
-        float x = 0.f;
-        if (idx < RELW) x = relh[idx];
-        else if (idx < 2 * RELW) x = relw[idx - RELW];
-        _Float16 hi, lo;
-        hgl_split_hi_lo(x, hi, lo);
-        rbh[c][j] = hi;
-        rbl[c][j] = lo;
+          for (int half = 0; half < 2; ++half) {
+            const f32x4 v = qvalid ? *(const f32x4*)(qp + 16 * sx + 8 * h + 4 * half) : f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              _Float16 hi, lo;
+              hgl_split_hi_lo(v[e], hi, lo);
+              uh[sx][4 * half + e] = hi;
+              ul[sx][4 * half + e] = lo;
+            }
+          }
+        }
+        float* P0 = RPatch + wave * 2 * 32 * RPP;
+#pragma unroll
+        for (int axis = 0; axis < 2; ++axis) {
+          const float* Rt = axis ? a.tab_w : a.tab_h;
+          f32x16 acc;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+          for (int sx = 0; sx < KS; ++sx) {
+            h16x8 th, tl;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              f32x4 v = {0, 0, 0, 0};
+              if (r < 2 * RELW - 1) v = *(const f32x4*)(Rt + (long long)r * HD + 16 * sx + 8 * h + 4 * half);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                _Float16 hi, lo;
+                hgl_split_hi_lo(v[e], hi, lo);
+                th[4 * half + e] = hi;
+                tl[4 * half + e] = lo;
+              }
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, uh[sx], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, ul[sx], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, uh[sx], acc, 0, 0, 0);
+          }
+          // acc[e] = T[table index (e&3) + 8*(e>>2) + 4*h][query r]
+          float* Pw = P0 + axis * 32 * RPP + r * RPP;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) Pw[(e & 3) + 8 * (e >> 2) + 4 * h] = acc[e];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const int qq = qvalid ? qi : 0;
+        const int qy = qq / RELW, qx = qq - qy * RELW;
+        const float* Ph = P0 + r * RPP + qy + RELW - 1;               // entry of k = 0; the index falls by one per k
+        const float* Pv = P0 + 32 * RPP + r * RPP + qx + RELW - 1;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int idx = 16 * c + 8 * h + j;
+            float x = 0.f;
+            if (idx < RELW) x = Ph[-idx];
+            else if (idx < 2 * RELW) x = Pv[-(idx - RELW)];
+            _Float16 hi, lo;
+            hgl_split_hi_lo(x, hi, lo);
+            rbh[c][j] = hi;
+            rbl[c][j] = lo;
+          }
       }
+    }
+    if (!from_tables) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int idx = 16 * c + 8 * h + j;
+          float x = 0.f;
+          if (idx < RELW) x = relh[idx];
+          else if (idx < 2 * RELW) x = relw[idx - RELW];
+          _Float16 hi, lo;
+          hgl_split_hi_lo(x, hi, lo);
+          rbh[c][j] = hi;
+          rbl[c][j] = lo;
+        }
+    }
   }
 
   // ---- staging (software pipelined through registers) ----
@@ -837,6 +916,30 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// Windowed attention of the SAM encoder (14 x 14 windows, head dim 80, f16x3 mode) with the decomposed rel-pos terms
+// computed INSIDE the kernel from the tables Rh / Rw [27, 80] (no rel_h / rel_w tensors, no separate table kernel).
+// Returns HGL_EINVAL-free "not applicable" (1) when the shape is not the one this path serves.
+int hgl_launch_attention_win14(const float* q, const float* k, const float* v, void* out_hi, void* out_lo, int B, int H, int hd,
+                               int ldq, int ldk, int ldv, int ldo, long long sqb, long long skb, long long svb, long long sob,
+                               float scale, const float* Rh, const float* Rw, hipStream_t st) {
+  static const int wide = getenv("HGL_ATTN_WIDE") ? atoi(getenv("HGL_ATTN_WIDE")) : 1;
+  static const int fused = getenv("HGL_ATTN_RELPOS_FUSED") ? atoi(getenv("HGL_ATTN_RELPOS_FUSED")) : 1;
+  if (!wide || !fused || hd != 80 || hgl_precision() != HGL_PREC_F16X3 || !out_hi || !out_lo || !Rh || !Rw) return 1;
+  HGL_REQUIRE(q && k && v && B > 0 && H > 0 && (long long)B * H <= 65535, "attention_win14: bad arguments");
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.out = nullptr;
+  a.B = B; a.H = H; a.Sq = 196; a.Sk = 196;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.sqb = sqb; a.skb = skb; a.svb = svb; a.sob = sob;
+  a.scale = scale; a.mask_kind = HGL_MASK_NONE; a.keep = nullptr; a.keep_b0 = 0; a.keep_n = B;
+  a.rel_h = nullptr; a.rel_w = nullptr; a.kh = 14; a.kw = 14;
+  a.tab_h = Rh; a.tab_w = Rw;
+  a.out_hi = (_Float16*)out_hi; a.out_lo = (_Float16*)out_lo;
+  HglProfScope prof(HGL_PROF_ATTN, 4.0 * B * H * 196.0 * 196.0 * 80, 0.0, st);
+  hipLaunchKernelGGL((attn_x3_kernel<80, 14, 8>), dim3(1, (unsigned)(B * H)), dim3(512), 0, st, a);
+  return hgl_check_launch("attention_win14");
+}
+
 // few-key attention (Sk <= 8, head dim 16): output fp32 (out) or the fp16 split pair (out == nullptr)
 int hgl_launch_attention_smallk(const float* q, const float* k, const float* v, float* out, void* out_hi, void* out_lo,
                                 int B, int H, int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
@@ -909,6 +1012,7 @@ int hgl_launch_attention_split(const float* q, const float* k, const float* v, f
   a.sqb = sqb; a.skb = skb; a.svb = svb; a.sob = sob;
   a.scale = scale; a.mask_kind = mask_kind; a.keep = keep; a.keep_b0 = keep_b0; a.keep_n = keep_n > 0 ? keep_n : B;
   a.rel_h = rel_h; a.rel_w = rel_w; a.kh = kh; a.kw = kw;
+  a.tab_h = nullptr; a.tab_w = nullptr;
   a.out_hi = (_Float16*)out_hi; a.out_lo = (_Float16*)out_lo;
   switch (hd) {
     case 16: return launch_hd<16>(a, st);

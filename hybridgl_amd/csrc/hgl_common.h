@@ -71,6 +71,9 @@ int hgl_launch_attention_split(const float* q, const float* k, const float* v, f
                                long long skb, long long svb, long long sob, float scale, int mask_kind,
                                const uint8_t* keep, int keep_b0, int keep_n, const float* rel_h,
                                const float* rel_w, int kh, int kw, hipStream_t st);
+int hgl_launch_attention_win14(const float* q, const float* k, const float* v, void* out_hi, void* out_lo, int B, int H, int hd,
+                               int ldq, int ldk, int ldv, int ldo, long long sqb, long long skb, long long svb, long long sob,
+                               float scale, const float* Rh, const float* Rw, hipStream_t st);
 int hgl_launch_attention_smallk(const float* q, const float* k, const float* v, float* out, void* out_hi, void* out_lo,
                                 int B, int H, int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
                                 long long skb, long long svb, long long sob, float scale, hipStream_t st);

@@ -123,6 +123,14 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
     HGL_TRY(hgl_launch_gemm(A, b.qkv_w, b.qkv_b, nullptr, p.QKV, M, 3 * D, D, D, D, 0, 3 * D, 1, 0, 0, 0, 0,
                             HGL_ACT_NONE, st));
   }
+  // 14 x 14 windows at head dim 80 in f16x3 mode: the attention kernel computes the decomposed rel-pos terms itself
+  if (x3 && ws == 14 && hd == 80) {
+    const int rc = hgl_launch_attention_win14(p.QKV, p.QKV + D, p.QKV + 2 * D, Ah, Al, B, heads, hd, 3 * D, 3 * D, 3 * D, D,
+                                              (long long)S * 3 * D, (long long)S * 3 * D, (long long)S * 3 * D, (long long)S * D,
+                                              1.0f / sqrtf((float)hd), b.rel_pos_h, b.rel_pos_w, st);
+    if (rc < 0) return rc;
+    if (rc == 0) goto attention_done;
+  }
   // decomposed rel-pos tables rel_h/rel_w [B*heads, S, size] from the UNSCALED q (image_encoder.py:351-354)
   if (hd == 80 || hd == 64) {
     HGL_TRY(hgl_launch_relpos_direct(p.QKV, 3 * D, B, heads, S, size, hd, b.rel_pos_h, b.rel_pos_w, p.relh, p.relw, st));
@@ -139,6 +147,7 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
                                      3 * D, 3 * D, D, (long long)S * 3 * D, (long long)S * 3 * D, (long long)S * 3 * D,
                                      (long long)S * D, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, p.relh,
                                      p.relw, size, size, st));
+attention_done:
   if (x3) {
     static int splitk_proj = -1;   // HGL_SAM_SPLITK_PROJ=1 enables split-K for the projection too (measured neutral: K is short)
     if (splitk_proj < 0) { const char* v = getenv("HGL_SAM_SPLITK_PROJ"); splitk_proj = (v && v[0] == '1') ? 1 : 0; }
