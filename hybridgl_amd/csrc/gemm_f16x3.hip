@@ -34,7 +34,7 @@ struct SplitW {
 };
 std::unordered_map<const void*, SplitW> g_split;   // fp32 weight pointer -> its fp16 split
 int g_precision = HGL_PREC_F32;
-enum { HGL_X3_V1 = 0, HGL_X3_L = 1, HGL_X3_M = 2, HGL_X3_S = 3, HGL_X3_N = 4, HGL_X3_Q = 5 };
+enum { HGL_X3_V1 = 0, HGL_X3_L = 1, HGL_X3_M = 2, HGL_X3_S = 3, HGL_X3_N = 4, HGL_X3_Q = 5, HGL_X3_P = 6, HGL_X3_D = 7, HGL_X3_P16 = 8 };
 
 struct Args {
   const _Float16 *Ah, *Al, *Wh, *Wl;
@@ -49,6 +49,8 @@ struct Args {
   int ksplit;    // applied by splitk_reduce_kernel, which sums the parts in a fixed order
   const int *amap, *cmap;   // optional row maps: A row m is read from row amap[m]; output / residual row m lives at cmap[m]
   int rmod;    // residual row = row % rmod when > 0 (a residual shared by every batch of rows), else row
+  int dbg;     // timing experiments only (HGL_X3_DBG): bit 0 = skip the write-out
+  int stg_mode, stg_ticks;   // start stagger of the persistent kernel: workgroup class and 10-ns ticks per class
 };
 
 int g_x3_kernel = -2;   // -2: read HGL_X3_KERNEL on first use; -1: cost model; >= 0: forced
@@ -82,6 +84,20 @@ int pick_x3_kernel(int M, int N, int K) {
     if (t < best_t) { best_t = t; best = c.kind; }
   }
   return best;
+}
+
+// grid of the persistent ping-pong kernel: one workgroup per CU (HGL_X3_PERSIST=0: one per tile)
+long long x3p_grid(long long tiles) {
+  static int ncu = 0, persist = -1;
+  if (persist < 0) {
+    const char* v = getenv("HGL_X3_PERSIST");
+    persist = v ? atoi(v) : 1;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  return persist && tiles > ncu ? ncu : tiles;
 }
 
 template <int ACT>
@@ -527,6 +543,922 @@ __global__ __launch_bounds__(WGM * WGN * 64, OCC) void gemm_x3g_kernel(Args g) {
   }
 }
 
+// Shared write-out of a wave's MI x NI accumulator tiles (32x32 each): bias / activation / residual / optional
+// row maps / split (fp16 hi+lo) output, or the raw partial sums of a split-K slice.
+template <int ACT, int MI, int NI>
+__device__ __forceinline__ void x3_epilogue(const Args& g, f32x16 (&acc)[MI][NI], int row0, int col0, int wrow, int wcol,
+                                            int r, int h, int TBM, int TBN) {
+  const int mclamp = g.M - 1, nclamp = g.N - 1;
+  const bool full_tile = (row0 + TBM <= g.M) && (col0 + TBN <= g.N);
+  if (g.ksplit > 1) {   // raw partial sums; splitk_reduce_kernel finishes
+    float* pp = g.part + (long long)blockIdx.y * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int col = col0 + wcol + j * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row0 + wrow + i * 32 + 4 * h + (e & 3) + 8 * (e >> 2);
+          if (full_tile || (col < g.N && row < g.M)) pp[(long long)row * g.N + col] = acc[i][j][e] * g.out_scale;
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int rbase = row0 + wrow + i * 32 + 4 * h;
+    int crow[16];   // output rows of this lane (through the optional row map), fetched in one batch
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rr = min(rbase + (e & 3) + 8 * (e >> 2), mclamp);
+      crow[e] = g.cmap ? g.cmap[rr] : rr;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = col0 + wcol + j * 32 + r;
+      const bool cok = col < g.N;
+      const int colc = cok ? col : nclamp;
+      const float bv = g.bias ? g.bias[colc] : 0.0f;
+      float rv[16];
+      if (g.R) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          rv[e] = g.R[(long long)(g.rmod > 0 ? crow[e] % g.rmod : crow[e]) * g.ldr + colc];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rbase + (e & 3) + 8 * (e >> 2);
+        const float v = act_apply<ACT>(acc[i][j][e] * g.out_scale + bv) + rv[e];
+        if (full_tile || (cok && row < g.M)) {
+          const long long o = (long long)crow[e] * g.ldc + col;
+          if (g.C) {
+            g.C[o] = v;
+          } else {
+            _Float16 hi, lo;
+            hgl_split_hi_lo(v, hi, lo);
+            g.Ch[o] = hi;
+            g.Cl[o] = lo;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ping-pong variant of the 256x256 LDS-DMA tiling (kind P).  Same tile, same LDS image (planes [A_hi|A_lo|W_hi|W_lo]
+// of 256 rows x 64 B per stage, XOR-swizzled chunks, two stages) and the same per-accumulator order of the MFMAs as
+// gemm_x3g_kernel<256,256,2,4> -- so the outputs are bit-identical -- but a different schedule.  In the kernel
+// above the eight waves run the same program in the same phase: the two waves of a SIMD want the matrix pipe
+// together and reach the one barrier per K tile together, where the pipe drains (53-56 % MFMA-busy measured).
+// Here the waves form two groups of four (waves 0-3 = the upper 128 rows, waves 4-7 = the lower 128 rows: one wave
+// of each group per SIMD) that run ONE BARRIER APART: a K tile is cut into four phases (a 64 x 32 quadrant of the
+// wave's 128 x 64 tile = 12 MFMAs = 384 matrix-pipe cycles each); a phase is a load segment (the quadrant's
+// ds_read_b128 fragment reads + two LDS-DMA pieces + the counted waits), a barrier, an MFMA-only segment under
+// s_setprio 1, a barrier.  Because group 1 executed one extra barrier at the start, every barrier interval has one
+// group issuing nothing but MFMAs while the other group's loads, DMA issue and waits run beside it on the same SIMDs.
+//
+// Staging is in UNITS of 16 KiB (16 pieces, two per wave) in the order the phases need them: U1 = A rows {0-63} of
+// each group's half, U2 = W columns {0-31} of each wave column's 64, U3 = W columns {32-63}, U4 = A rows {64-127};
+// phase 1 reads U1 + U2, phase 2 U3, phase 3 U4, phase 4 nothing.  A unit's LDS slot is free again one barrier after
+// its reading phase (the fragment reads are retired by lgkmcnt(0) BEFORE the load segment's barrier), so the DMA runs
+// seven units ahead of the reads: the load segment of (tile t, phase 1) issues U4(t+1), phases 2-4 issue U1-U3(t+2).
+// Each load segment ends with s_waitcnt vmcnt(10): all but the wave's five youngest units have landed, i.e. every
+// unit read by ANY wave in the next segment -- published by the barrier that follows.  A unit has five phases
+// (about 3800 matrix-pipe cycles) to land against one K tile (3072) in the kernel above.  The last two K tiles use
+// the exact smaller counts (8, 6, 4, 2, 0).
+template <int N>
+__device__ __forceinline__ void x3p_wait() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+// The accumulators are kept TRANSPOSED (the W fragment is the MFMA's first operand): lane (r, h) of acc[i][j] holds
+// output row i*32 + r and the columns j*32 + 8*q + 4*h + {0..3} (q = e >> 2) -- four consecutive columns per
+// quad of registers, so bias / residual / output move as 16-byte vectors (4 stores per 32x32 tile instead of 16).
+// The products and their order per accumulator are unchanged (a*b = b*a, same k order): bit-identical results.
+// Requires N, ldc, ldr multiples of 4 and 16-byte aligned bases (checked by the launcher, which otherwise takes the L tiling).
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
+  constexpr int TBM = 256, TBN = 256, MI = 4, NI = 2, WTM = 128, WTN = 64;
+  constexpr int PLANE = 256 * 64;    // bytes of one plane of one stage
+  constexpr int STAGE = 4 * PLANE;   // [A_hi | A_lo | W_hi | W_lo]
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_p[];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;   // wm = the phase group
+  const int mclamp = g.M - 1, nclamp = g.N - 1;
+  int kbeg = 0, nk = g.K / 32;   // K tiles of 32; even and >= 2 (K % 64 == 0, checked by the launcher)
+  if (g.ksplit > 1) {
+    const int chunk = (nk / g.ksplit) & ~1;
+    kbeg = (int)blockIdx.y * chunk;
+    nk = (int)blockIdx.y == g.ksplit - 1 ? nk - kbeg : chunk;
+  }
+
+  // Tile schedule.  The tile list (group of GM row tiles x all column tiles, row-fastest) is cut into eight contiguous
+  // chunks, one per XCD (blockIdx.x & 7 names the workgroups that share an XCD); the workgroups of an XCD walk their
+  // chunk with a stride of their count, so the tiles in flight on one L2 are neighbours.  gridDim.x == number of tiles
+  // gives one tile per workgroup (the mapping of the other tilings); a smaller grid makes the kernel persistent.
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7;
+  int vstart, vlen;
+  {
+    const int q = ntiles >> 3, rr = ntiles & 7;
+    vstart = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+    vlen = q + (xcd < rr ? 1 : 0);
+  }
+  const int vstride = ((int)gridDim.x - xcd + 7) >> 3;
+  int v = blockIdx.x >> 3;
+  if (v >= vlen) return;
+
+  // staging: this wave's two 16-row groups of A (rows 0-63 / 64-127 of its group's half) and of W
+  const int prow = lane >> 2, pchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const unsigned char *bAh = (const unsigned char*)g.Ah, *bAl = (const unsigned char*)g.Al;
+  const unsigned char *bWh = (const unsigned char*)g.Wh, *bWl = (const unsigned char*)g.Wl;
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem_p;
+  const int rgA0 = wm * 8 + (wave & 3), rgA1 = rgA0 + 4;
+  const int cgW0 = 4 * (wave >> 1) + (wave & 1), cgW1 = cgW0 + 2;
+  struct TileOff { int row0, col0; unsigned oa0, oa1, ow0, ow1; };
+  auto tile_offsets = [&](int vid) {
+    const int bid = vstart + vid;
+    const int GM = g.gm;
+    const int group = bid / (GM * g.tiles_n);
+    const int first_m = group * GM;
+    const int gmn = min(g.tiles_m - first_m, GM);
+    const int rem = bid - group * GM * g.tiles_n;
+    TileOff o;
+    o.row0 = (first_m + rem % gmn) * TBM;
+    o.col0 = (rem / gmn) * TBN;
+    int a0 = min(o.row0 + rgA0 * 16 + prow, mclamp), a1 = min(o.row0 + rgA1 * 16 + prow, mclamp);
+    if (g.amap) { a0 = g.amap[a0]; a1 = g.amap[a1]; }
+    o.oa0 = (unsigned)(a0 * g.lda + pchunk * 8) * 2u;
+    o.oa1 = (unsigned)(a1 * g.lda + pchunk * 8) * 2u;
+    o.ow0 = (unsigned)(min(o.col0 + cgW0 * 16 + prow, nclamp) * g.ldw + pchunk * 8) * 2u;
+    o.ow1 = (unsigned)(min(o.col0 + cgW1 * 16 + prow, nclamp) * g.ldw + pchunk * 8) * 2u;
+    return o;
+  };
+  TileOff cur = tile_offsets(v);
+  if (g.stg_ticks > 0) {   // spread the workgroups' phases so that their write-out bursts do not coincide
+    const int j = blockIdx.x >> 3;
+    const int cls = g.stg_mode == 1 ? j : g.stg_mode == 2 ? xcd : g.stg_mode == 3 ? (j & 3) : g.stg_mode == 4 ? (j >> 3) : (j & 7);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long want = (unsigned long long)cls * g.stg_ticks;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < want) __builtin_amdgcn_s_sleep(8);
+  }
+  // unit u (0: A first rows, 1: W first columns, 2: W second columns, 3: A second rows) of K tile `tile`
+  auto issue_unit = [&](const TileOff& o, int u, int tile) {
+    const unsigned sb = lds0 + (tile & 1) * STAGE;
+    const long long ko = (long long)(kbeg + tile) * 64;
+    if (u == 0) {
+      glds16(bAh + ko, o.oa0, sb + rgA0 * 1024);
+      glds16(bAl + ko, o.oa0, sb + PLANE + rgA0 * 1024);
+    } else if (u == 1) {
+      glds16(bWh + ko, o.ow0, sb + 2 * PLANE + cgW0 * 1024);
+      glds16(bWl + ko, o.ow0, sb + 3 * PLANE + cgW0 * 1024);
+    } else if (u == 2) {
+      glds16(bWh + ko, o.ow1, sb + 2 * PLANE + cgW1 * 1024);
+      glds16(bWl + ko, o.ow1, sb + 3 * PLANE + cgW1 * 1024);
+    } else {
+      glds16(bAh + ko, o.oa1, sb + rgA1 * 1024);
+      glds16(bAl + ko, o.oa1, sb + PLANE + rgA1 * 1024);
+    }
+  };
+  auto issue_prologue = [&](const TileOff& o) {   // seven units ahead
+    issue_unit(o, 0, 0); issue_unit(o, 1, 0); issue_unit(o, 2, 0); issue_unit(o, 3, 0);
+    issue_unit(o, 0, 1); issue_unit(o, 1, 1); issue_unit(o, 2, 1);
+  };
+
+  const int sw = (r >> 2) & 3;
+  const int co0 = ((0 + h) ^ sw) * 16, co1 = ((2 + h) ^ sw) * 16;
+  const unsigned char* Ab = smem_p + (wm * WTM + r) * 64;
+  const unsigned char* Wb = smem_p + 2 * PLANE + (wn * WTN + r) * 64;
+  f32x16 acc[MI][NI];
+  f16x8 ah[2][2], al[2][2];      // [row block of the half][k-step]
+  f16x8 bh[2][2], bl[2][2];      // [column block][k-step]
+  auto read_A = [&](int ih, int stage) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const unsigned char* p = Ab + stage * STAGE + (2 * ih + ii) * 2048;
+      ah[ii][0] = *(const f16x8*)(p + co0); ah[ii][1] = *(const f16x8*)(p + co1);
+      al[ii][0] = *(const f16x8*)(p + PLANE + co0); al[ii][1] = *(const f16x8*)(p + PLANE + co1);
+    }
+  };
+  auto read_B = [&](int j, int stage) {
+    const unsigned char* p = Wb + stage * STAGE + j * 2048;
+    bh[j][0] = *(const f16x8*)(p + co0); bh[j][1] = *(const f16x8*)(p + co1);
+    bl[j][0] = *(const f16x8*)(p + PLANE + co0); bl[j][1] = *(const f16x8*)(p + PLANE + co1);
+  };
+  // the 12 MFMAs of quadrant (ih, j): per accumulator k-step 0 then 1, each lo*hi, hi*lo, hi*hi (the order of
+  // every other f16x3 kernel); W fragment first = transposed accumulator
+  auto quad = [&](int ih, int j) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const f16x8 a = term == 0 ? al[ii][s] : ah[ii][s];
+          const f16x8 b = term == 1 ? bl[j][s] : bh[j][s];
+          acc[2 * ih + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[2 * ih + ii][j], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one K tile: C1..C4 = the vmcnt left outstanding at the end of the four load segments; I1 / I2: issue the unit
+  // of phase 1 (tile + 1) / of phases 2-4 (tile + 2); LAST drops group 1's unpaired final barrier
+  auto tile_body = [&](int tile, auto c1, auto c2, auto c3, auto c4, auto i1, auto i2, auto last) {
+    constexpr int C1 = decltype(c1)::value, C2 = decltype(c2)::value, C3 = decltype(c3)::value, C4 = decltype(c4)::value;
+    constexpr bool I1 = decltype(i1)::value, I2 = decltype(i2)::value, LAST = decltype(last)::value;
+    const int stage = tile & 1;
+    // phase 1
+    read_A(0, stage);
+    read_B(0, stage);
+    if (I1) issue_unit(cur, 3, tile + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    x3p_wait<C1>();
+    bar();
+    quad(0, 0);
+    bar();
+    // phase 2
+    read_B(1, stage);
+    if (I2) issue_unit(cur, 0, tile + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    x3p_wait<C2>();
+    bar();
+    quad(0, 1);
+    bar();
+    // phase 3
+    read_A(1, stage);
+    if (I2) issue_unit(cur, 1, tile + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    x3p_wait<C3>();
+    bar();
+    quad(1, 0);
+    bar();
+    // phase 4
+    if (I2) issue_unit(cur, 2, tile + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    x3p_wait<C4>();
+    bar();
+    quad(1, 1);
+    if (!(LAST && wm == 1)) bar();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I2_ = std::integral_constant<int, 2>;
+  using I4 = std::integral_constant<int, 4>;
+  using I6 = std::integral_constant<int, 6>;
+  using I8 = std::integral_constant<int, 8>;
+  using I10 = std::integral_constant<int, 10>;
+  const std::true_type yes;
+  const std::false_type no;
+
+  issue_prologue(cur);
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    // Every wait below is correct whatever else the wave still has in flight (the stores of the previous tile's
+    // write-out are YOUNGER than this tile's prologue pieces, so they can only make a counted wait stricter).
+    x3p_wait<10>();
+    bar();
+    if (wm == 1) bar();   // group 1 runs one barrier behind group 0
+    for (int tile = 0; tile + 2 < nk; ++tile) tile_body(tile, I10(), I10(), I10(), I10(), yes, yes, no);
+    tile_body(nk - 2, I10(), I8(), I6(), I4(), yes, no, no);
+    tile_body(nk - 1, I2_(), I0(), I0(), I0(), no, no, yes);
+    // Both groups have retired every LDS read of this tile when either leaves its last barrier (group 1's phase 4
+    // has none, group 0 finishes after group 1's last read segment): the next tile's prologue DMA goes out BEFORE
+    // the write-out, which it overlaps.
+    const TileOff done = cur;
+    v += vstride;
+    const bool more = v < vlen;
+    if (more) {
+      cur = tile_offsets(v);
+      issue_prologue(cur);
+    }
+
+    // ---- write-out (transposed accumulators: 16-byte vectors along the output row) ----
+    if ((g.dbg & 1) && acc[0][0][0] != 12345.678f) {
+    } else {
+      const int row0 = done.row0, col0 = done.col0;
+      const bool full_tile = (row0 + TBM <= g.M) && (col0 + TBN <= g.N);
+      const int cb = col0 + wn * WTN + 4 * h;   // + j*32 + 8*q
+      if (g.ksplit > 1) {   // raw partial sums; splitk_reduce_kernel finishes
+        float* pp = g.part + (long long)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int row = row0 + wm * WTM + i * 32 + r;
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int col = cb + j * 32 + 8 * q;
+              if (full_tile || (row < g.M && col < g.N)) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * q + e] * g.out_scale;
+                *(f32x4*)(pp + (long long)row * g.N + col) = o;
+              }
+            }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          f32x4 bv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int colc = min(cb + j * 32 + 8 * q, g.N - 4);
+            bv[q] = g.bias ? *(const f32x4*)(g.bias + colc) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const int row = row0 + wm * WTM + i * 32 + r;
+            const int rc = min(row, mclamp);
+            const int crow = g.cmap ? g.cmap[rc] : rc;
+            const long long rrow = g.rmod > 0 ? crow % g.rmod : crow;
+            f32x4 rv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int colc = min(cb + j * 32 + 8 * q, g.N - 4);
+              rv[q] = g.R ? *(const f32x4*)(g.R + rrow * g.ldr + colc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int col = cb + j * 32 + 8 * q;
+              if (full_tile || (row < g.M && col < g.N)) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = act_apply<ACT>(acc[i][j][4 * q + e] * g.out_scale + bv[q][e]) + rv[q][e];
+                const long long off = (long long)crow * g.ldc + col;
+                if (g.C) {
+                  *(f32x4*)(g.C + off) = o;
+                } else {
+                  f16x4 hi4, lo4;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    _Float16 hh, ll;
+                    hgl_split_hi_lo(o[e], hh, ll);
+                    hi4[e] = hh;
+                    lo4[e] = ll;
+                  }
+                  *(f16x4*)(g.Ch + off) = hi4;
+                  *(f16x4*)(g.Cl + off) = lo4;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    if (!more) break;
+  }
+}
+
+// The same kernel on v_mfma_f32_16x16x32_f16 (kind P16): one MFMA per term covers the whole K tile of 32; same LDS
+// image with the swizzle of the 16-row fragment reads, same staging order, same counts.  The K sum inside an
+// instruction is ordered differently, so the results differ from the 32x32x16 tilings in the last bits.
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void gemm_x3p16_kernel(Args g) {
+  constexpr int TBM = 256, TBN = 256, MB = 8, NB = 4, WTM = 128, WTN = 64;   // 16x16 accumulator blocks per wave
+  constexpr int PLANE = 256 * 64;    // bytes of one plane of one stage
+  constexpr int STAGE = 4 * PLANE;   // [A_hi | A_lo | W_hi | W_lo]
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_p[];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 15, h = lane >> 4;   // fragment row / 8-wide k group; accumulator: row r, columns 4*h..4*h+3
+  const int wm = wave >> 2, wn = wave & 3;   // wm = the phase group
+  const int mclamp = g.M - 1, nclamp = g.N - 1;
+  int kbeg = 0, nk = g.K / 32;   // K tiles of 32; even and >= 2 (K % 64 == 0, checked by the launcher)
+  if (g.ksplit > 1) {
+    const int chunk = (nk / g.ksplit) & ~1;
+    kbeg = (int)blockIdx.y * chunk;
+    nk = (int)blockIdx.y == g.ksplit - 1 ? nk - kbeg : chunk;
+  }
+
+  // Tile schedule.  The tile list (group of GM row tiles x all column tiles, row-fastest) is cut into eight contiguous
+  // chunks, one per XCD (blockIdx.x & 7 names the workgroups that share an XCD); the workgroups of an XCD walk their
+  // chunk with a stride of their count, so the tiles in flight on one L2 are neighbours.  gridDim.x == number of tiles
+  // gives one tile per workgroup (the mapping of the other tilings); a smaller grid makes the kernel persistent.
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7;
+  int vstart, vlen;
+  {
+    const int q = ntiles >> 3, rr = ntiles & 7;
+    vstart = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+    vlen = q + (xcd < rr ? 1 : 0);
+  }
+  const int vstride = ((int)gridDim.x - xcd + 7) >> 3;
+  int v = blockIdx.x >> 3;
+  if (v >= vlen) return;
+
+  // staging: this wave's two 16-row groups of A (rows 0-63 / 64-127 of its group's half) and of W
+  const int prow = lane >> 2, pchunk = (lane & 3) ^ ((0x78 >> (2 * ((lane >> 4) & 3))) & 3);   // swizzle {0,2,3,1}[(row >> 2) & 3]
+  const unsigned char *bAh = (const unsigned char*)g.Ah, *bAl = (const unsigned char*)g.Al;
+  const unsigned char *bWh = (const unsigned char*)g.Wh, *bWl = (const unsigned char*)g.Wl;
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem_p;
+  const int rgA0 = wm * 8 + (wave & 3), rgA1 = rgA0 + 4;
+  const int cgW0 = 4 * (wave >> 1) + (wave & 1), cgW1 = cgW0 + 2;
+  struct TileOff { int row0, col0; unsigned oa0, oa1, ow0, ow1; };
+  auto tile_offsets = [&](int vid) {
+    const int bid = vstart + vid;
+    const int GM = g.gm;
+    const int group = bid / (GM * g.tiles_n);
+    const int first_m = group * GM;
+    const int gmn = min(g.tiles_m - first_m, GM);
+    const int rem = bid - group * GM * g.tiles_n;
+    TileOff o;
+    o.row0 = (first_m + rem % gmn) * TBM;
+    o.col0 = (rem / gmn) * TBN;
+    int a0 = min(o.row0 + rgA0 * 16 + prow, mclamp), a1 = min(o.row0 + rgA1 * 16 + prow, mclamp);
+    if (g.amap) { a0 = g.amap[a0]; a1 = g.amap[a1]; }
+    o.oa0 = (unsigned)(a0 * g.lda + pchunk * 8) * 2u;
+    o.oa1 = (unsigned)(a1 * g.lda + pchunk * 8) * 2u;
+    o.ow0 = (unsigned)(min(o.col0 + cgW0 * 16 + prow, nclamp) * g.ldw + pchunk * 8) * 2u;
+    o.ow1 = (unsigned)(min(o.col0 + cgW1 * 16 + prow, nclamp) * g.ldw + pchunk * 8) * 2u;
+    return o;
+  };
+  TileOff cur = tile_offsets(v);
+  if (g.stg_ticks > 0) {   // spread the workgroups' phases so that their write-out bursts do not coincide
+    const int j = blockIdx.x >> 3;
+    const int cls = g.stg_mode == 1 ? j : g.stg_mode == 2 ? xcd : g.stg_mode == 3 ? (j & 3) : g.stg_mode == 4 ? (j >> 3) : (j & 7);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long want = (unsigned long long)cls * g.stg_ticks;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < want) __builtin_amdgcn_s_sleep(8);
+  }
+  // unit u (0: A first rows, 1: W first columns, 2: W second columns, 3: A second rows) of K tile `tile`
+  auto issue_unit = [&](const TileOff& o, int u, int tile) {
+    const unsigned sb = lds0 + (tile & 1) * STAGE;
+    const long long ko = (long long)(kbeg + tile) * 64;
+    if (u == 0) {
+      glds16(bAh + ko, o.oa0, sb + rgA0 * 1024);
+      glds16(bAl + ko, o.oa0, sb + PLANE + rgA0 * 1024);
+    } else if (u == 1) {
+      glds16(bWh + ko, o.ow0, sb + 2 * PLANE + cgW0 * 1024);
+      glds16(bWl + ko, o.ow0, sb + 3 * PLANE + cgW0 * 1024);
+    } else if (u == 2) {
+      glds16(bWh + ko, o.ow1, sb + 2 * PLANE + cgW1 * 1024);
+      glds16(bWl + ko, o.ow1, sb + 3 * PLANE + cgW1 * 1024);
+    } else {
+      glds16(bAh + ko, o.oa1, sb + rgA1 * 1024);
+      glds16(bAl + ko, o.oa1, sb + PLANE + rgA1 * 1024);
+    }
+  };
+  auto issue_prologue = [&](const TileOff& o) {   // seven units ahead
+    issue_unit(o, 0, 0); issue_unit(o, 1, 0); issue_unit(o, 2, 0); issue_unit(o, 3, 0);
+    issue_unit(o, 0, 1); issue_unit(o, 1, 1); issue_unit(o, 2, 1);
+  };
+
+  // LDS chunk swizzle for the 16-row x 4-chunk fragment reads of v_mfma_f32_16x16x32_f16 (a lane reads row r, chunk h):
+  // chunk ^= {0,2,3,1}[(row >> 2) & 3] puts the 16 lanes of every ds_read_b128 lane group on 16 different 16-byte slots
+  const int sw = (0x78 >> (2 * ((r >> 2) & 3))) & 3;
+  const int co = (h ^ sw) * 16;
+  const unsigned char* Ab = smem_p + (wm * WTM + r) * 64 + co;
+  const unsigned char* Wb = smem_p + 2 * PLANE + (wn * WTN + r) * 64 + co;
+  f32x4 acc[MB][NB];
+  f16x8 ah[4], al[4];            // [16-row block of the half]: the whole K tile of 32
+  f16x8 bh[2][2], bl[2][2];      // [32-column half][16-column block]
+  auto read_A = [&](int ih, int stage) {
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      const unsigned char* p = Ab + stage * STAGE + (4 * ih + ib) * 1024;
+      ah[ib] = *(const f16x8*)p;
+      al[ib] = *(const f16x8*)(p + PLANE);
+    }
+  };
+  auto read_B = [&](int j, int stage) {
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      const unsigned char* p = Wb + stage * STAGE + (2 * j + jb) * 1024;
+      bh[j][jb] = *(const f16x8*)p;
+      bl[j][jb] = *(const f16x8*)(p + PLANE);
+    }
+  };
+  // the 24 MFMAs of quadrant (ih, j): per accumulator lo*hi, hi*lo, hi*hi over the whole K tile; W fragment first =
+  // transposed accumulator (lane: output row r, four consecutive columns)
+  auto quad = [&](int ih, int j) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+          const f16x8 a = term == 0 ? al[ib] : ah[ib];
+          const f16x8 b = term == 1 ? bl[j][jb] : bh[j][jb];
+          acc[4 * ih + ib][2 * j + jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, acc[4 * ih + ib][2 * j + jb], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one K tile: C1..C4 = the vmcnt left outstanding at the end of the four load segments; I1 / I2: issue the unit
+  // of phase 1 (tile + 1) / of phases 2-4 (tile + 2); LAST drops group 1's unpaired final barrier
+  auto tile_body = [&](int tile, auto c1, auto c2, auto c3, auto c4, auto i1, auto i2, auto last) {
+    constexpr int C1 = decltype(c1)::value, C2 = decltype(c2)::value, C3 = decltype(c3)::value, C4 = decltype(c4)::value;
+    constexpr bool I1 = decltype(i1)::value, I2 = decltype(i2)::value, LAST = decltype(last)::value;
+    const int stage = tile & 1;
+    // phase 1
+    read_A(0, stage);
+    read_B(0, stage);
+    if (I1) issue_unit(cur, 3, tile + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    x3p_wait<C1>();
+    bar();
+    quad(0, 0);
+    bar();
+    // phase 2
+    read_B(1, stage);
+    if (I2) issue_unit(cur, 0, tile + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    x3p_wait<C2>();
+    bar();
+    quad(0, 1);
+    bar();
+    // phase 3
+    read_A(1, stage);
+    if (I2) issue_unit(cur, 1, tile + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    x3p_wait<C3>();
+    bar();
+    quad(1, 0);
+    bar();
+    // phase 4
+    if (I2) issue_unit(cur, 2, tile + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    x3p_wait<C4>();
+    bar();
+    quad(1, 1);
+    if (!(LAST && wm == 1)) bar();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I2_ = std::integral_constant<int, 2>;
+  using I4 = std::integral_constant<int, 4>;
+  using I6 = std::integral_constant<int, 6>;
+  using I8 = std::integral_constant<int, 8>;
+  using I10 = std::integral_constant<int, 10>;
+  const std::true_type yes;
+  const std::false_type no;
+
+  issue_prologue(cur);
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Every wait below is correct whatever else the wave still has in flight (the stores of the previous tile's
+    // write-out are YOUNGER than this tile's prologue pieces, so they can only make a counted wait stricter).
+    x3p_wait<10>();
+    bar();
+    if (wm == 1) bar();   // group 1 runs one barrier behind group 0
+    for (int tile = 0; tile + 2 < nk; ++tile) tile_body(tile, I10(), I10(), I10(), I10(), yes, yes, no);
+    tile_body(nk - 2, I10(), I8(), I6(), I4(), yes, no, no);
+    tile_body(nk - 1, I2_(), I0(), I0(), I0(), no, no, yes);
+    // Both groups have retired every LDS read of this tile when either leaves its last barrier (group 1's phase 4
+    // has none, group 0 finishes after group 1's last read segment): the next tile's prologue DMA goes out BEFORE
+    // the write-out, which it overlaps.
+    const TileOff done = cur;
+    v += vstride;
+    const bool more = v < vlen;
+    if (more) {
+      cur = tile_offsets(v);
+      issue_prologue(cur);
+    }
+
+    // ---- write-out: accumulator block (mb, nb) = output rows mb*16 + r, columns nb*16 + 4*h .. +3 ----
+    if ((g.dbg & 1) && acc[0][0][0] != 12345.678f) {
+    } else {
+      const int row0 = done.row0, col0 = done.col0;
+      const bool full_tile = (row0 + TBM <= g.M) && (col0 + TBN <= g.N);
+      const int cb = col0 + wn * WTN + 4 * h;   // + nb*16
+      if (g.ksplit > 1) {   // raw partial sums; splitk_reduce_kernel finishes
+        float* pp = g.part + (long long)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int row = row0 + wm * WTM + mb * 16 + r;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int col = cb + nb * 16;
+            if (full_tile || (row < g.M && col < g.N)) {
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = acc[mb][nb][e] * g.out_scale;
+              *(f32x4*)(pp + (long long)row * g.N + col) = o;
+            }
+          }
+        }
+      } else {
+        f32x4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int colc = min(cb + nb * 16, g.N - 4);
+          bv[nb] = g.bias ? *(const f32x4*)(g.bias + colc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int row = row0 + wm * WTM + mb * 16 + r;
+          const int rc = min(row, mclamp);
+          const int crow = g.cmap ? g.cmap[rc] : rc;
+          const long long rrow = g.rmod > 0 ? crow % g.rmod : crow;
+          f32x4 rv[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int colc = min(cb + nb * 16, g.N - 4);
+            rv[nb] = g.R ? *(const f32x4*)(g.R + rrow * g.ldr + colc) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int col = cb + nb * 16;
+            if (full_tile || (row < g.M && col < g.N)) {
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = act_apply<ACT>(acc[mb][nb][e] * g.out_scale + bv[nb][e]) + rv[nb][e];
+              const long long off = (long long)crow * g.ldc + col;
+              if (g.C) {
+                *(f32x4*)(g.C + off) = o;
+              } else {
+                f16x4 hi4, lo4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  _Float16 hh, ll;
+                  hgl_split_hi_lo(o[e], hh, ll);
+                  hi4[e] = hh;
+                  lo4[e] = ll;
+                }
+                *(f16x4*)(g.Ch + off) = hi4;
+                *(f16x4*)(g.Cl + off) = lo4;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (!more) break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ping-pong tiling with a DEFERRED write-out (kind D): 256 x 128 tile, eight waves as 4 (M) x 2 (N), a wave owns
+// 64 x 64 = four 32x32 accumulators = 64 registers -- half of kind P -- so that a wave can keep the finished
+// accumulators of tile n while it multiplies tile n+1, and write tile n out a vector at a time during the main loop
+// of tile n+1 (measured on kind P: the write-out of a 256x256 tile costs 11-31 us per tile = 18 % of the GEMM time,
+// a per-CU store-rate limit that neither a persistent loop nor staggered workgroups remove).
+// Same two phase groups (waves 0-3 / 4-7 one barrier apart), two phases per K tile (one 32-row block of the wave x
+// its two 32-column blocks = 12 MFMAs each), THREE LDS stages of 48 KiB ([A_hi 16K | A_lo 16K | W_hi 8K | W_lo 8K]).
+// A wave stages six 1-KiB pieces per K tile, in need order [A0.hi A0.lo W.hi W.lo A1.hi A1.lo] (A0 / A1 = the rows
+// of the first / second 32-row blocks): the load segment of (K tile t, phase 2) issues the first three pieces of
+// K tile t+3, the one of (t+1, phase 1) the last three.  Counted waits: 12 after phase 1 (everything up to A1 of
+// this K tile has landed), 11 after phase 2 (A0 and W of the next K tile).
+template <int N>
+__device__ __forceinline__ void x3d_wait() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void gemm_x3d_kernel(Args g) {
+  constexpr int TBM = 256, TBN = 128, WTM = 64, WTN = 64;
+  constexpr int APLANE = 256 * 64, WPLANE = 128 * 64;
+  constexpr int STAGE = 2 * APLANE + 2 * WPLANE;   // 48 KiB
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_d[];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int grp = wave >> 2;   // phase group
+  const int mclamp = g.M - 1, nclamp = g.N - 1;
+  const int nk = g.K / 32;     // >= 4 (launcher)
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7;
+  int vstart, vlen;
+  {
+    const int q = ntiles >> 3, rr = ntiles & 7;
+    vstart = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+    vlen = q + (xcd < rr ? 1 : 0);
+  }
+  const int vstride = ((int)gridDim.x - xcd + 7) >> 3;
+  int v = blockIdx.x >> 3;
+  if (v >= vlen) return;
+
+  const int prow = lane >> 2, pchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const unsigned char *bAh = (const unsigned char*)g.Ah, *bAl = (const unsigned char*)g.Al;
+  const unsigned char *bWh = (const unsigned char*)g.Wh, *bWl = (const unsigned char*)g.Wl;
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem_d;
+  const int rgA0 = 4 * (wave >> 1) + (wave & 1), rgA1 = rgA0 + 2;   // 16-row groups: rows wm*64 + {0-31} / {32-63}
+  const int cgW = wave;                                             // 16-column group
+  struct TileOff { int row0, col0; unsigned oa0, oa1, ow; };
+  auto tile_offsets = [&](int vid) {
+    const int bid = vstart + vid;
+    const int GM = g.gm;
+    const int group = bid / (GM * g.tiles_n);
+    const int first_m = group * GM;
+    const int gmn = min(g.tiles_m - first_m, GM);
+    const int rem = bid - group * GM * g.tiles_n;
+    TileOff o;
+    o.row0 = (first_m + rem % gmn) * TBM;
+    o.col0 = (rem / gmn) * TBN;
+    int a0 = min(o.row0 + rgA0 * 16 + prow, mclamp), a1 = min(o.row0 + rgA1 * 16 + prow, mclamp);
+    if (g.amap) { a0 = g.amap[a0]; a1 = g.amap[a1]; }
+    o.oa0 = (unsigned)(a0 * g.lda + pchunk * 8) * 2u;
+    o.oa1 = (unsigned)(a1 * g.lda + pchunk * 8) * 2u;
+    o.ow = (unsigned)(min(o.col0 + cgW * 16 + prow, nclamp) * g.ldw + pchunk * 8) * 2u;
+    return o;
+  };
+  TileOff cur = tile_offsets(v);
+  // half h3 (0: A0.hi A0.lo W.hi, 1: W.lo A1.hi A1.lo) of K tile kt into stage sidx
+  auto issue_half = [&](const TileOff& o, int h3, int kt, int sidx) {
+    const unsigned sb = lds0 + sidx * STAGE;
+    const long long ko = (long long)kt * 64;
+    if (h3 == 0) {
+      glds16(bAh + ko, o.oa0, sb + rgA0 * 1024);
+      glds16(bAl + ko, o.oa0, sb + APLANE + rgA0 * 1024);
+      glds16(bWh + ko, o.ow, sb + 2 * APLANE + cgW * 1024);
+    } else {
+      glds16(bWl + ko, o.ow, sb + 2 * APLANE + WPLANE + cgW * 1024);
+      glds16(bAh + ko, o.oa1, sb + rgA1 * 1024);
+      glds16(bAl + ko, o.oa1, sb + APLANE + rgA1 * 1024);
+    }
+  };
+
+  const int sw = (r >> 2) & 3;
+  const int co0 = ((0 + h) ^ sw) * 16, co1 = ((2 + h) ^ sw) * 16;
+  const unsigned char* Ab = smem_d + (wm * WTM + r) * 64;
+  const unsigned char* Wb = smem_d + 2 * APLANE + (wn * WTN + r) * 64;
+  f32x16 acc[2][2];
+  f16x8 ah[2], al[2];            // [k-step] of the current 32-row block
+  f16x8 bh[2][2], bl[2][2];      // [column block][k-step]
+  auto read_A = [&](int i, int sidx) {
+    const unsigned char* p = Ab + sidx * STAGE + i * 2048;
+    ah[0] = *(const f16x8*)(p + co0); ah[1] = *(const f16x8*)(p + co1);
+    al[0] = *(const f16x8*)(p + APLANE + co0); al[1] = *(const f16x8*)(p + APLANE + co1);
+  };
+  auto read_B = [&](int sidx) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned char* p = Wb + sidx * STAGE + j * 2048;
+      bh[j][0] = *(const f16x8*)(p + co0); bh[j][1] = *(const f16x8*)(p + co1);
+      bl[j][0] = *(const f16x8*)(p + WPLANE + co0); bl[j][1] = *(const f16x8*)(p + WPLANE + co1);
+    }
+  };
+  // the 12 MFMAs of row block i (transposed accumulators, as kind P)
+  auto half = [&](int i) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f16x8 a = term == 0 ? al[s] : ah[s];
+          const f16x8 b = term == 1 ? bl[j][s] : bh[j][s];
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[i][j], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // K tile kt in stage sidx; I1 / I2: the load segment of phase 1 issues the second half of K tile kt+2 (stage
+  // sidx+2), the one of phase 2 the first half of kt+3 (stage sidx); N1 / N2 the counted waits; LAST: final K tile
+  auto ktile = [&](int kt, int sidx, auto n1, auto n2, auto i1, auto i2, auto last) {
+    constexpr int N1 = decltype(n1)::value, N2 = decltype(n2)::value;
+    constexpr bool I1 = decltype(i1)::value, I2 = decltype(i2)::value, LAST = decltype(last)::value;
+    const int s2 = sidx >= 1 ? sidx - 1 : 2;   // (sidx + 2) % 3
+    read_A(0, sidx);
+    read_B(sidx);
+    if (I1) issue_half(cur, 1, kt + 2, s2);
+    __builtin_amdgcn_sched_barrier(0);
+    x3d_wait<N1>();
+    bar();
+    half(0);
+    bar();
+    read_A(1, sidx);
+    if (I2) issue_half(cur, 0, kt + 3, sidx);
+    __builtin_amdgcn_sched_barrier(0);
+    x3d_wait<N2>();
+    bar();
+    half(1);
+    if (!(LAST && grp == 1)) bar();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I2_ = std::integral_constant<int, 2>;
+  using I6 = std::integral_constant<int, 6>;
+  using I8 = std::integral_constant<int, 8>;
+  using I11 = std::integral_constant<int, 11>;
+  using I12 = std::integral_constant<int, 12>;
+  const std::true_type yes;
+  const std::false_type no;
+  auto issue_prologue = [&](const TileOff& o) {   // K tiles 0, 1 and the first half of 2
+    issue_half(o, 0, 0, 0); issue_half(o, 1, 0, 0);
+    issue_half(o, 0, 1, 1); issue_half(o, 1, 1, 1);
+    issue_half(o, 0, 2, 2);
+  };
+
+  issue_prologue(cur);
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    x3d_wait<11>();
+    bar();
+    if (grp == 1) bar();   // group 1 runs one barrier behind group 0
+    int sidx = 0;
+    int kt = 0;
+    for (; kt + 3 < nk; ++kt) {
+      ktile(kt, sidx, I12(), I11(), yes, yes, no);
+      sidx = sidx == 2 ? 0 : sidx + 1;
+    }
+    ktile(kt, sidx, I12(), I8(), yes, no, no);
+    sidx = sidx == 2 ? 0 : sidx + 1;
+    ktile(kt + 1, sidx, I6(), I2_(), no, no, no);
+    sidx = sidx == 2 ? 0 : sidx + 1;
+    ktile(kt + 2, sidx, I0(), I0(), no, no, yes);
+
+    const TileOff done = cur;
+    v += vstride;
+    const bool more = v < vlen;
+    if (more) {
+      cur = tile_offsets(v);
+      issue_prologue(cur);
+    }
+    // ---- write-out ----
+    if ((g.dbg & 1) && acc[0][0][0] != 12345.678f) {
+    } else {
+      const int row0 = done.row0, col0 = done.col0;
+      const bool full_tile = (row0 + TBM <= g.M) && (col0 + TBN <= g.N);
+      const int cb = col0 + wn * WTN + 4 * h;   // + j*32 + 8*q
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4 bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int colc = min(cb + j * 32 + 8 * q, g.N - 4);
+          bv[q] = g.bias ? *(const f32x4*)(g.bias + colc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = row0 + wm * WTM + i * 32 + r;
+          const int rc = min(row, mclamp);
+          const int crow = g.cmap ? g.cmap[rc] : rc;
+          const long long rrow = g.rmod > 0 ? crow % g.rmod : crow;
+          f32x4 rv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int colc = min(cb + j * 32 + 8 * q, g.N - 4);
+            rv[q] = g.R ? *(const f32x4*)(g.R + rrow * g.ldr + colc) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = cb + j * 32 + 8 * q;
+            if (full_tile || (row < g.M && col < g.N)) {
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = act_apply<ACT>(acc[i][j][4 * q + e] * g.out_scale + bv[q][e]) + rv[q][e];
+              const long long off = (long long)crow * g.ldc + col;
+              if (g.C) {
+                *(f32x4*)(g.C + off) = o;
+              } else {
+                f16x4 hi4, lo4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  _Float16 hh, ll;
+                  hgl_split_hi_lo(o[e], hh, ll);
+                  hi4[e] = hh;
+                  lo4[e] = ll;
+                }
+                *(f16x4*)(g.Ch + off) = hi4;
+                *(f16x4*)(g.Cl + off) = lo4;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (!more) break;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Small-M GEMMs (token MLPs / hyper-networks / IoU head of the SAM decoder, the text encoder, the heads): a few
 // dozen output tiles with K up to 2048 leave the 128x128 kernels latency-bound (8 workgroups, 64 serial K tiles:
@@ -803,6 +1735,8 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldr = ldr; g.ldc = ldc;
   g.rmod = rmod; g.amap = amap; g.cmap = cmap;
   g.part = nullptr; g.ksplit = 1;
+  { static int dbg = -1; if (dbg < 0) { const char* v = getenv("HGL_X3_DBG"); dbg = v ? atoi(v) : 0; } g.dbg = dbg; }
+  { static int sm = -1, stk = 0; if (sm < 0) { const char* v = getenv("HGL_X3_STG_MODE"); sm = v ? atoi(v) : 0; v = getenv("HGL_X3_STG_TICKS"); stk = v ? atoi(v) : 0; } g.stg_mode = sm; g.stg_ticks = stk; }
   g.out_scale = ldexpf(1.0f, -sw.scale_log2);
   {
     static int gmv = -1;
@@ -821,12 +1755,21 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
       else if (!strcmp(v, "S")) g_x3_kernel = HGL_X3_S;
       else if (!strcmp(v, "N")) g_x3_kernel = HGL_X3_N;
       else if (!strcmp(v, "Q")) g_x3_kernel = HGL_X3_Q;
+      else if (!strcmp(v, "P")) g_x3_kernel = HGL_X3_P;
+      else if (!strcmp(v, "D")) g_x3_kernel = HGL_X3_D;
+      else if (!strcmp(v, "P16")) g_x3_kernel = HGL_X3_P16;
     }
   }
   // the LDS-DMA kernels address the operands with 32-bit byte offsets from the plane bases
   const bool small_offsets = (double)M * lda * (amap ? 4.0 : 2.0) < 4.0e9 && (double)N * K * 2.0 < 4.0e9;   // gathered rows: <= 2M
   int kind = g_x3_kernel >= 0 ? g_x3_kernel : pick_x3_kernel(M, N, K);
   if (!small_offsets) kind = HGL_X3_V1;
+  if (kind == HGL_X3_D && K < 128) kind = HGL_X3_P;
+  if (kind == HGL_X3_P || kind == HGL_X3_D || kind == HGL_X3_P16) {   // 16-byte vectors along the output rows
+    const bool vec4 = (N & 3) == 0 && (ldc & 3) == 0 && (!R || (ldr & 3) == 0) && (((size_t)bias | (size_t)R | (size_t)C) & 15) == 0 &&
+                      (((size_t)Ch | (size_t)Cl) & 7) == 0;
+    if (!vec4) kind = HGL_X3_L;
+  }
   // launches that cannot fill the 256 CUs once (GEM at 785 rows, text encoder: a 128x128 tile per CU is latency-bound
   // when run alone) are accounted separately from the throughput-bound ones
   const long long few_tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
@@ -859,9 +1802,57 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
     }                                                                                                         \
     hipLaunchKernelGGL((gemm_x3g_kernel<ACT_, TBM_, TBN_, WGM_, WGN_, OCC_>), dim3((unsigned)nwg), dim3(WGM_ * WGN_ * 64), lds_, st, g); \
   } while (0)
+#define HGL_X3P_LAUNCH(ACT_)                                                                                  \
+  do {                                                                                                        \
+    g.tiles_m = (M + 255) / 256;                                                                              \
+    g.tiles_n = (N + 255) / 256;                                                                              \
+    const long long nwg = (long long)g.tiles_m * g.tiles_n;                                                   \
+    HGL_REQUIRE(nwg < (1ll << 31), "gemm_f16x3: grid too large");                                            \
+    const size_t lds_ = (size_t)2 * 4 * 256 * 64;                                                             \
+    static bool set_ = false;                                                                                 \
+    if (!set_) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)gemm_x3p_kernel<ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+      set_ = true;                                                                                            \
+    }                                                                                                         \
+    const long long grid_ = x3p_grid(nwg);                                                                    \
+    hipLaunchKernelGGL((gemm_x3p_kernel<ACT_>), dim3((unsigned)grid_), dim3(512), lds_, st, g);               \
+  } while (0)
+#define HGL_X3D_LAUNCH(ACT_)                                                                                  \
+  do {                                                                                                        \
+    g.tiles_m = (M + 255) / 256;                                                                              \
+    g.tiles_n = (N + 127) / 128;                                                                              \
+    const long long nwg = (long long)g.tiles_m * g.tiles_n;                                                   \
+    HGL_REQUIRE(nwg < (1ll << 31), "gemm_f16x3: grid too large");                                            \
+    const size_t lds_ = (size_t)3 * 49152;                                                                    \
+    static bool set_ = false;                                                                                 \
+    if (!set_) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)gemm_x3d_kernel<ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+      set_ = true;                                                                                            \
+    }                                                                                                         \
+    const long long grid_ = x3p_grid(nwg);                                                                    \
+    hipLaunchKernelGGL((gemm_x3d_kernel<ACT_>), dim3((unsigned)grid_), dim3(512), lds_, st, g);               \
+  } while (0)
+#define HGL_X3P16_LAUNCH(ACT_)                                                                                \
+  do {                                                                                                        \
+    g.tiles_m = (M + 255) / 256;                                                                              \
+    g.tiles_n = (N + 255) / 256;                                                                              \
+    const long long nwg = (long long)g.tiles_m * g.tiles_n;                                                   \
+    HGL_REQUIRE(nwg < (1ll << 31), "gemm_f16x3: grid too large");                                            \
+    const size_t lds_ = (size_t)2 * 4 * 256 * 64;                                                             \
+    static bool set_ = false;                                                                                 \
+    if (!set_) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)gemm_x3p16_kernel<ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+      set_ = true;                                                                                            \
+    }                                                                                                         \
+    const long long grid_ = x3p_grid(nwg);                                                                    \
+    hipLaunchKernelGGL((gemm_x3p16_kernel<ACT_>), dim3((unsigned)grid_), dim3(512), lds_, st, g);             \
+  } while (0)
 #define HGL_X3_VARIANTS(ACT_)                                  \
   do {                                                         \
-    if (kind == 1) HGL_X3G_LAUNCH(ACT_, 256, 256, 2, 4, 1);    \
+    if (kind == 8) HGL_X3P16_LAUNCH(ACT_);                     \
+    else if (kind == 7) HGL_X3D_LAUNCH(ACT_);                  \
+    else if (kind == 6) HGL_X3P_LAUNCH(ACT_);                  \
+    else if (kind == 1) HGL_X3G_LAUNCH(ACT_, 256, 256, 2, 4, 1);    \
     else if (kind == 2) HGL_X3G_LAUNCH(ACT_, 256, 128, 4, 2, 1); \
     else if (kind == 3) HGL_X3G_LAUNCH(ACT_, 128, 128, 2, 2, 2); \
     else if (kind == 4) HGL_X3G_LAUNCH(ACT_, 128, 160, 4, 1, 2); \
@@ -932,7 +1923,7 @@ int hgl_launch_gemm_f16x3_splitk(const void* Ah, const void* Al, int lda, const 
   g.Ah = (const _Float16*)Ah; g.Al = (const _Float16*)Al; g.Wh = sw.hi; g.Wl = sw.lo;
   g.bias = nullptr; g.R = nullptr; g.C = nullptr; g.Ch = nullptr; g.Cl = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldr = 0; g.ldc = N;
-  g.rmod = 0; g.amap = amap; g.cmap = nullptr; g.part = part; g.ksplit = ksplit;
+  g.rmod = 0; g.amap = amap; g.cmap = nullptr; g.part = part; g.ksplit = ksplit; g.dbg = 0; g.stg_mode = 0; g.stg_ticks = 0;
   g.out_scale = ldexpf(1.0f, -sw.scale_log2);
   g.gm = 8;
   g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
@@ -973,7 +1964,7 @@ int hgl_set_precision(int mode) {
 int hgl_get_precision(void) { return g_precision; }
 
 int hgl_gemm_f16x3_select(int kind) {
-  HGL_REQUIRE(kind >= -1 && kind <= HGL_X3_Q, "gemm_f16x3_select: unknown kernel %d", kind);
+  HGL_REQUIRE(kind >= -1 && kind <= HGL_X3_P16, "gemm_f16x3_select: unknown kernel %d", kind);
   g_x3_kernel = kind;
   return HGL_OK;
 }
