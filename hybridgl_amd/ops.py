@@ -86,7 +86,7 @@ def set_precision(mode):
     check(_lib.load().hgl_set_precision({"f32": 0, "f16x3": 1}[mode]), "hgl_set_precision")
 
 
-X3_KERNELS = {"auto": -1, "v1": 0, "L": 1, "M": 2, "S": 3, "N": 4, "Q": 5, "P": 6, "D": 7, "P16": 8}
+X3_KERNELS = {"auto": -1, "v1": 0, "P": 1}
 
 
 def select_x3_kernel(kind="auto"):

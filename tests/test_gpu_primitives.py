@@ -79,12 +79,12 @@ def test_gemm_f16x3_tilings_bit_identical(cuda, M, N, K):
     r = T(rng.standard_normal((M, N)).astype(np.float32), cuda)
     try:
         outs = {}
-        for kind in ("v1", "L", "M", "S", "N", "Q", "P", "D", "auto"):
+        for kind in ("v1", "P", "auto"):
             ops.select_x3_kernel(kind)
             outs[kind] = ops.gemm_f16x3(a, w, b, r, "gelu").cpu().numpy()
     finally:
         ops.select_x3_kernel("auto")
-    for kind in ("L", "M", "S", "N", "Q", "P", "D", "auto"):
+    for kind in ("P", "auto"):
         assert np.array_equal(outs[kind], outs["v1"]), kind
     z = a.cpu().numpy().astype(np.float64) @ w.cpu().numpy().astype(np.float64).T + b.cpu().numpy()
     from scipy.special import erf
@@ -101,7 +101,7 @@ def test_gemm_f16x3_inplace_residual(cuda):
     c0 = rng.standard_normal((M, N)).astype(np.float32)
     try:
         ref = None
-        for kind in ("v1", "L", "M", "S", "N", "Q", "P", "D"):
+        for kind in ("v1", "P"):
             ops.select_x3_kernel(kind)
             c = T(c0, cuda)
             ops.gemm_f16x3(a, w, None, c, "none", out=c)
