@@ -9,7 +9,9 @@ encoder, text encoder (9 strings + 3 GEM prompts), the GEM heat-map stage (ViT-B
 per-sentence scoring tail with IoU.  All inputs are synthetic
 (hybridgl_amd/synth.py), weights are seeded random (no checkpoints offline), and every input is
 resident in HBM before the timed region.  Refs are sharded over ranks with no data-path
-collective (weak scaling); metrics are all-gathered once at the end.
+collective (weak scaling); the per-sentence metric rows are all-gathered once at the end (hybridgl_amd/dist.py).
+
+`--gpus N` without a launcher (WORLD_SIZE unset) starts N ranks itself, before this process touches the GPU.
 """
 import argparse
 import ctypes as C
@@ -80,16 +82,16 @@ def roofline(precision, nprof, g, x, a, traffic, whole_tflops, xg=(0, 0.0, 0.0),
     tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     members = {
         "gemm_f16x3_kernel": {"achieved": tf(x_fl, x_ms), "launches_per_step": x_n / nprof, "ms_per_step": x_ms / nprof},
-        "gemm_x3g_kernel": {"achieved": tf(xg_fl, xg_ms), "launches_per_step": xg_n / nprof, "ms_per_step": xg_ms / nprof},
+        "gemm_x3p_kernel": {"achieved": tf(xg_fl, xg_ms), "launches_per_step": xg_n / nprof, "ms_per_step": xg_ms / nprof},
     }
     if max(x_ms, xg_ms) > g_ms:
         name = "gemm_f16x3_kernel (register-staged 128x128 tiling)"
         if xg_ms > x_ms:   # the LDS-DMA family dominates: report it, keep the other under other_kernels
-            name = "gemm_x3g_kernel (LDS-DMA tilings)"
+            name = "gemm_x3p_kernel (256x256 LDS-DMA ping-pong tiling, persistent)"
             (x_n, x_ms, x_fl), (xg_n, xg_ms, xg_fl) = (xg_n, xg_ms, xg_fl), (x_n, x_ms, x_fl)
         ach = tf(x_fl, x_ms)
-        main = {"bound": "mfma", "kernel": name + ": fp32 operands split in fp16 hi+lo; 3 x v_mfma_f32_32x32x16_f16 "
-                "per product step, fp32 accumulate",
+        main = {"bound": "mfma", "kernel": name + ": fp32 operands split in fp16 hi+lo; 3 x v_mfma_f32_16x16x32_f16 "
+                "per 32-deep product step, fp32 accumulate",
                 "f16x3_gemm_family": {"achieved": tf(x_fl + xg_fl, x_ms + xg_ms), "ms_per_step": (x_ms + xg_ms) / nprof,
                                       "launches_per_step": (x_n + xg_n) / nprof,
                                       "other_member": {"achieved": tf(xg_fl, xg_ms), "ms_per_step": xg_ms / nprof,
@@ -110,8 +112,8 @@ def roofline(precision, nprof, g, x, a, traffic, whole_tflops, xg=(0, 0.0, 0.0),
     main["other_kernels"] = {
         "gemm_f32_kernel": {"achieved": tf(g_fl, g_ms), "launches_per_step": g_n / nprof, "ms_per_step": g_ms / nprof},
         "gemm_f16x3_kernel": members["gemm_f16x3_kernel"],
-        "gemm_x3g_kernel": members["gemm_x3g_kernel"],
-        "attn_f32_kernel": {"achieved": tf(a_fl, a_ms), "launches_per_step": a_n / nprof, "ms_per_step": a_ms / nprof},
+        "gemm_x3p_kernel": members["gemm_x3p_kernel"],
+        "attention_kernels": {"achieved": tf(a_fl, a_ms), "launches_per_step": a_n / nprof, "ms_per_step": a_ms / nprof},
     }
     main["other_kernels"]["f16x3_gemm_few_tile_launches"] = {
         "achieved": tf(few[2], few[1]), "launches_per_step": few[0] / nprof, "ms_per_step": few[1] / nprof,
@@ -250,22 +252,33 @@ def main():
                     help="grouped steps: one text-encoder batch + one hybrid forward per ref instead of one for the group")
     ap.add_argument("--scope", default="B", choices=["A", "B"],
                     help="A: proposals given (CLIP + scoring only); B: + SAM ViT-H proposal stage (full path)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the short secondary timings (G2L&L2G, ViT-L/14) that are attached under the `also` key at N = 1")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from hybridgl_amd import dist as D
+    rank, local_rank, world = D.env_rank()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # No launcher: start the N ranks here.  Nothing above has touched the GPU (importing torch and counting devices
+        # does not create a context); the children are fresh interpreters, rank 0 prints the one JSON line.
+        ngpu = D.visible_gpu_count()
+        argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+        if ngpu < args.gpus and args.backend == "nccl":
+            # RCCL cannot put two ranks on one device; gloo can (exercises the N > 1 path on a box with fewer GPUs)
+            print(f"bench.py: {args.gpus} ranks on {ngpu} visible GPU(s): ranks share devices, metric exchange over gloo",
+                  file=sys.stderr)
+            argv += ["--backend", "gloo"]
+        sys.exit(D.spawn_local_ranks(args.gpus, argv))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists)"
-    local_dev = local_rank % torch.cuda.device_count()      # identity on a node with one GPU per rank
+    ngpu = torch.cuda.device_count()
+    local_dev = local_rank % ngpu      # identity on a node with one GPU per rank
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
+    dist = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist = D.init_process_group(args.backend, dev)
 
     from hybridgl_amd import _lib
     from hybridgl_amd.backbone import CLIPViTFM
@@ -297,7 +310,7 @@ def main():
                             fixed_proposals=None, cleanup_given_masks=gen is not None, gem_model=gem_model)
     pipe.group_clip = not args.no_clip_group
     # rank r owns refs i = r (mod world) of the shuffle=False order
-    refs = [synthetic_ref(rank + world * j, dev, N=args.masks, sam_img_size=1024 if gen else 0, gem=use_gem,
+    refs = [synthetic_ref(D.owned_index(j, rank, world), dev, N=args.masks, sam_img_size=1024 if gen else 0, gem=use_gem,
                           device_blur=args.blur == "device")[0]
             for j in range(args.pool)]
 
@@ -337,6 +350,8 @@ def main():
 
     do_steps(args.warmup)
     torch.cuda.synchronize()
+    # the metric rows of the report are those of the timed steps only
+    pipe.cum.zero_(); pipe.iu_log.clear(); pipe.iu_owner.clear()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -345,6 +360,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    rows = pipe.partial_rows()
 
     # ---- roofline leg: the same steps with HIP events around every launch of the dominant kernel
     lib.hgl_prof_enable(1)
@@ -364,19 +380,50 @@ def main():
     fw_n, fw_ms, fw_fl, fw_by = prof_read(lib, 5)
     precision = "f16x3" if lib.hgl_get_precision() == 1 else "f32"
 
-    m = pipe.metrics()
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        # the only collective of the path: one all-gather of the metric vector (RCCL over xGMI)
-        vec = torch.tensor(m["cum"] + [m["n_sentences"]], dtype=torch.int64, device=dev)
-        out = [torch.zeros_like(vec) for _ in range(world)]
-        dist.all_gather(out, vec)
-        tot = torch.stack(out).sum(0).cpu().numpy()
-        m["cum"] = [int(v) for v in tot[:4]]
-        m["oIoU"] = tot[0] * 100.0 / max(int(tot[1]), 1)
-        m["oIoU_final"] = tot[2] * 100.0 / max(int(tot[3]), 1)
+    dt = D.max_over_ranks(dt, dist, dev)
+    # the only exchange of the path: one all-gather of the per-sentence metric rows (RCCL over xGMI; hybridgl_amd/dist.py)
+    m = D.gather_metrics(rows, dist, dev)
+
+    # ---- short secondary timings in the same process (N = 1 only): the other fusion mode and the ViT-L/14 geometry
+    also = None
+    if world == 1 and not args.no_also and args.scope == "B" and args.fusion == "G2L" and args.clip == "ViT-B/16" and pair:
+        also = {}
+
+        def timed(p2, n_steps=8):
+            nonlocal pipe
+            keep, pipe = pipe, p2
+            try:
+                do_steps(n_steps)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                do_steps(n_steps)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / n_steps
+            finally:
+                pipe = keep
+        p2 = HybridGLPipeline(model, fusion_mode="G2L&L2G", masking_block=geom["masking_block"], mask_generator=gen,
+                              use_sam_masks=False, fixed_proposals=None, cleanup_given_masks=True, gem_model=gem_model)
+        t = timed(p2)
+        also["G2L&L2G"] = {"ms_per_step": t * 1e3, "value": 1.0 / t, "unit": "images/s", "steps": 8,
+                           "config": "the headline workload with fusion_mode G2L&L2G (BASELINE configs[3] per GPU)",
+                           "whole_step_algorithmic_tflops": None}
+        del p2
+        gl = CLIP_GEOM["ViT-L/14"]
+        model_l = CLIPViTFM("ViT-L/14", seed=0, device=dev)
+        gem_l = None
+        if use_gem:
+            from hybridgl_amd.gem import create_gem_model
+            gem_l = create_gem_model("ViT-L/14", clip=model_l)
+        p3 = HybridGLPipeline(model_l, fusion_mode="G2L", masking_block=gl["masking_block"], mask_generator=gen,
+                              use_sam_masks=False, fixed_proposals=None, cleanup_given_masks=True, gem_model=gem_l)
+        t = timed(p3)
+        fl = algorithmic_flops_per_ref(args.masks, sam=True, gem=use_gem, clip_name="ViT-L/14",
+                                       text_S=max(r.token_len or 77 for r in refs))
+        also["ViT-L/14"] = {"ms_per_step": t * 1e3, "value": 1.0 / t, "unit": "images/s", "steps": 8,
+                            "config": "the headline workload with the CLIP / GEM ViT-L/14 geometry north_star names (masking_block 21)",
+                            "whole_step_algorithmic_tflops": fl / t / 1e12}
+        del p3, model_l, gem_l
+        torch.cuda.empty_cache()
 
     if rank == 0:
         total_refs = args.steps * world
@@ -387,7 +434,7 @@ def main():
                 tj = json.load(open(tpath))
                 # launch-weighted mean over the template instantiations of the dominant kernel
                 if precision == "f16x3":
-                    prefix = "gemm_x3g_kernel<" if xg_ms > x_ms else "gemm_f16x3_kernel<"
+                    prefix = "gemm_x3p_kernel<" if xg_ms > x_ms else "gemm_f16x3_kernel<"
                 else:
                     prefix = "gemm_f32_kernel<"
                 num = den = 0.0
@@ -404,6 +451,9 @@ def main():
             "value": total_refs / dt,
             "unit": "images/s",
             "n_gpus": world,
+            "world_size_seen": dist.get_world_size() if dist is not None else 1,
+            "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
+            "ranks_per_gpu": max(1, -(-world // max(ngpu, 1))),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -446,6 +496,8 @@ def main():
             "precision": precision,
             "metrics": m,
         }
+        if also is not None:
+            rec["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.fusion, with_sam=args.scope == "B", with_gem=use_gem, clip_name=args.clip)
         print(json.dumps(rec))

@@ -14,6 +14,10 @@ background is OpenCV's fixed-point GaussianBlur restated on the device (Hybridgl
 
     python -m hybridgl_amd.main --dataset refcocog --split val --fusion_mode G2L --synthetic 8
     python -m hybridgl_amd.main --dataset refcoco --split testA --real --refer_data_root ./refer/data
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m hybridgl_amd.main --real ...
+
+Under a launcher (WORLD_SIZE > 1) rank r evaluates the items i = r (mod R) of the loader's order and the metric rows
+are gathered once at the end (hybridgl_amd/dist.py); rank 0 writes the report.
 """
 import argparse
 import os
@@ -49,8 +53,19 @@ def default_argument_parser():
     return p
 
 
-def real_refs(args, dev, splitBy, context_length):
-    """RefBatch per dataset item, in the loader's order (Hybridgl_main.py:40-45,79-146)."""
+OTHER_NOUN_PREFIX = "a photo of "   # Hybridgl_main.py:160: clip.tokenize('a photo of ' + other_noun)
+
+
+def sentence_strings(raw, rec):
+    """The strings the reference tokenises for one sentence (Hybridgl_main.py:146-161), in the row order of
+    pipeline.Sentence: [sentence, noun phrase, 'a photo of ' + other noun ...].  `rec` is the sentence's parse record
+    ({"noun_phrase", "other_nouns": bare phrases as extract_nouns returns them, ...}); missing -> whole sentence, no nouns."""
+    others = list(rec.get("other_nouns", []))
+    return [raw, rec.get("noun_phrase", raw)] + [OTHER_NOUN_PREFIX + o for o in others]
+
+
+def real_refs(args, dev, splitBy, context_length, rank=0, world=1):
+    """RefBatch per dataset item of this rank, in the loader's order (Hybridgl_main.py:40-45,79-146)."""
     import json
     import numpy as np
     from . import ops, synth
@@ -64,7 +79,9 @@ def real_refs(args, dev, splitBy, context_length):
     parse = json.load(open(args.parse_json)) if args.parse_json else {}
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     n = len(ds) if args.max_refs <= 0 else min(len(ds), args.max_refs)
-    for i in range(n):
+    from .dist import shard_by_groups
+    image_ids = [ds.refer.Refs[r]["image_id"] for r in ds.ref_ids[:n]]
+    for i in shard_by_groups(image_ids, rank, world):   # refs of one image stay on one rank (per-image cache)
         data, annot, sentences = ds[i]
         img = data["sam_img"]
         H, W = img.shape[:2]
@@ -72,8 +89,8 @@ def real_refs(args, dev, splitBy, context_length):
         for sent_id, raw in zip(data["sent_ids"], sentences):
             rec = parse.get(str(sent_id), {})
             row = len(strings)
-            others = list(rec.get("other_nouns", []))
-            strings += [raw, rec.get("noun_phrase", raw)] + others
+            others = list(rec.get("other_nouns", []))   # extract_nouns' phrases, bare (utils.py:82-98)
+            strings += sentence_strings(raw, rec)
             attn = None
             if args.heatmap_dir and os.path.exists(os.path.join(args.heatmap_dir, f"{sent_id}.npy")):
                 a = torch.from_numpy(np.load(os.path.join(args.heatmap_dir, f"{sent_id}.npy")).astype(np.float32))
@@ -93,15 +110,18 @@ def real_refs(args, dev, splitBy, context_length):
         yield RefBatch(t(img), None, t(synth.imagenet_normalize(img)), placeholder,
                        torch.zeros((1, 4), dtype=torch.int64, device=dev), t(tokens), t(annot), sents, None,
                        int(data["img_id"][0]), tensor_img=preprocess(img).to(dev) if args.heatmap == "device" else None,
-                       token_len=int(tokens.argmax(axis=1).max()) + 1)
+                       token_len=int(tokens.argmax(axis=1).max()) + 1, index=i)
 
 
 def main(args):
     from .backbone import CLIPViTFM
     from .pipeline import EmptyProposals, HybridGLPipeline, synthetic_ref
+    from . import dist as D
     assert torch.cuda.is_available(), "hybridgl_amd has no CPU path"
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    rank, local_rank, world = D.env_rank()
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    dist = D.init_process_group(os.environ.get("HYBRIDGL_DIST_BACKEND", "nccl"), dev) if world > 1 else None
     splitBy = "umd" if args.dataset == "refcocog" else "unc"          # Hybridgl_main.py:26-29
     model = CLIPViTFM(model_name=args.clip_model, device=dev).eval()
     gen = None
@@ -118,11 +138,12 @@ def main(args):
         gem_model = create_gem_model(args.clip_model, clip=model)          # Hybridgl_main.py:36-38 (same checkpoint: shared weights)
     pipe = HybridGLPipeline(model, fusion_mode=args.fusion_mode, masking_block=9, mask_generator=gen,
                             use_sam_masks=args.real, gem_model=gem_model)
-    print(f"fusion mode={args.fusion_mode}")
+    if rank == 0:
+        print(f"fusion mode={args.fusion_mode}")
     if args.real:
         from .weights import CLIP_CONFIGS
         skipped = 0
-        for ref in real_refs(args, dev, splitBy, CLIP_CONFIGS[args.clip_model]["context_length"]):
+        for ref in real_refs(args, dev, splitBy, CLIP_CONFIGS[args.clip_model]["context_length"], rank, world):
             try:
                 pipe.step(ref)
             except EmptyProposals:
@@ -130,11 +151,15 @@ def main(args):
         if skipped:
             print(f"{skipped} refs skipped: the proposal stage returned no mask")
     else:
-        for i in range(args.synthetic):
+        for i in D.shard_indices(args.synthetic, rank, world):
             ref, _ = synthetic_ref(i, dev, N=args.proposals, sam_img_size=1024 if gen else 0, gem=gem_model is not None,
                                    device_blur=True)
             pipe.step(ref)
-    m = pipe.metrics()
+    m = pipe.metrics(dist)      # one all-gather of the metric rows; identical on every rank
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank != 0:
+        return m
     text = (f"\n\n fusion_mode={args.fusion_mode} "
             f"\nDataset: {args.dataset} / {args.split} / {splitBy}"
             f"\nOverall IoU / mean IoU"

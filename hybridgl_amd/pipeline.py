@@ -55,6 +55,8 @@ class RefBatch:
     tensor_img: Optional[torch.Tensor] = None   # [3,448,448] fp32: image['tensor_img'] = gem.get_gem_img_transform()(img)
     token_len: Optional[int] = None   # 1 + the largest EOT position of `tokens` (host knowledge of the tokenizer): the text
                                       # encoder then computes only that prefix of the 77 positions (exact: causal mask)
+    index: Optional[int] = None       # position in the loader's order (Hybridgl_main.py:45,79); under sharding the metric rows
+                                      # of all ranks are put back into this order (hybridgl_amd/dist.py)
 
 
 class EmptyProposals(RuntimeError):
@@ -78,11 +80,19 @@ def black_for(relaflag):
 class HybridGLPipeline:
     def __init__(self, model, fusion_mode="G2L", masking_block=9, r=0.5, alpha=0.6, k1=3, k2=6, res=224,
                  mask_generator=None, use_sam_masks=False, fixed_proposals=None, cleanup_given_masks=False,
-                 gem_model=None):
+                 gem_model=None, k_clamp="persistent"):
         """mask_generator: a hybridgl_amd.sam.SamAutomaticMaskGenerator; when given, every step runs the
         SAM proposal stage (encoder, decoder, post-processing, NMS) on ref.sam_img first.
         use_sam_masks=False keeps ref.masks for the CLIP stage (fixed N; synthetic benchmark, where
-        random SAM weights give an arbitrary number of proposals); True feeds the SAM proposals."""
+        random SAM weights give an arbitrary number of proposals); True feeds the SAM proposals.
+        k_clamp: "persistent" = the reference's quirk (Hybridgl_main.py:178-181: once an image yields fewer than k1 / k2
+        proposals, k1 / k2 stay clamped for every LATER item of the process -- under sharding "later" means later on the
+        same rank, so a run that meets such an image depends on the number of ranks); "per_ref" = the clamp applies
+        to that item only (order- and sharding-independent; differs from the reference after such an image)."""
+        if k_clamp not in ("persistent", "per_ref"):
+            raise ValueError("k_clamp must be 'persistent' or 'per_ref'")
+        self.k_clamp = k_clamp
+        self._k0 = (k1, k2)
         self.model = model
         self.gem_model = gem_model              # hybridgl_amd.gem.GEMWrapper: heat-maps computed on the device
         self.group_clip = True                  # step_overlapped_pair: one text batch + one hybrid forward for its refs
@@ -98,6 +108,8 @@ class HybridGLPipeline:
         # metric accumulators stay on the device: [cum_I, cum_U, cum_I_final, cum_U_final]
         self.cum = torch.zeros(4, dtype=torch.int64, device=dev)
         self.iu_log = []  # per sentence (IU_pure, IU_final) device tensors
+        self.iu_owner = []  # per sentence (dataset position of its ref, sentence number)
+        self._n_refs = 0
 
     def step_overlapped(self, ref: RefBatch, next_ref: RefBatch):
         """Two-stage software pipeline over refs on two HIP streams: the SAM proposal stage of
@@ -116,21 +128,32 @@ class HybridGLPipeline:
         with torch.cuda.stream(self._s_sam):
             self.last_proposals = gen.propose(next_ref.sam_img, resized=next_ref.sam_resized)
         with torch.cuda.stream(self._s_clip):
-            self.mask_generator = None          # the CLIP stage below must not re-run the SAM stage
-            try:
-                if self.cleanup_given_masks:
-                    import dataclasses
-                    cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
-                    ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
-                out = self.step(ref)
-            finally:
-                self.mask_generator = gen
+            if self.cleanup_given_masks:
+                import dataclasses
+                cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
+                ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
+            out = self.step(ref, run_sam=False)   # the SAM stage of this ref ran one call earlier
+        self._join_side_streams(cur, [out])
+        return out
+
+    def _join_side_streams(self, cur, outs):
+        """The caller's stream waits for both side streams; every tensor that leaves them is recorded on the caller's
+        stream so that the caching allocator does not hand its block to later side-stream work while the caller reads it."""
         e1, e2 = torch.cuda.Event(), torch.cuda.Event()
         e1.record(self._s_sam)
         e2.record(self._s_clip)
         cur.wait_event(e1)
         cur.wait_event(e2)
-        return out
+
+        def rec(x):
+            if isinstance(x, torch.Tensor):
+                if x.is_cuda:
+                    x.record_stream(cur)
+            elif isinstance(x, (tuple, list)):
+                for y in x:
+                    rec(y)
+        rec(outs)
+        rec(getattr(self, "last_proposals", None))
 
     def step_overlapped_pair(self, refs, next_refs):
         """step_overlapped for a group of refs (2, 4, 8 ...) at a time: ONE SAM encoder pass over the images of all
@@ -150,23 +173,15 @@ class HybridGLPipeline:
             self.last_proposals = gen.propose_batch([r.sam_img for r in next_refs])[-1]
         outs = []
         with torch.cuda.stream(self._s_clip):
-            self.mask_generator = None          # the CLIP stage below must not re-run the SAM stage
-            try:
-                group = []
-                for ref in refs:
-                    if self.cleanup_given_masks:
-                        import dataclasses
-                        cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
-                        ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
-                    group.append(ref)
-                outs = self.step_group(group) if self.group_clip else [self.step(r) for r in group]
-            finally:
-                self.mask_generator = gen
-        e1, e2 = torch.cuda.Event(), torch.cuda.Event()
-        e1.record(self._s_sam)
-        e2.record(self._s_clip)
-        cur.wait_event(e1)
-        cur.wait_event(e2)
+            group = []
+            for ref in refs:
+                if self.cleanup_given_masks:
+                    import dataclasses
+                    cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
+                    ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
+                group.append(ref)
+            outs = self.step_group(group, run_sam=False) if self.group_clip else [self.step(r, run_sam=False) for r in group]
+        self._join_side_streams(cur, outs)
         return outs
 
     def step_serial_group(self, refs):
@@ -175,23 +190,21 @@ class HybridGLPipeline:
         per-kernel timing (events on one stream)."""
         gen = self.mask_generator
         self.last_proposals = gen.propose_batch([r.sam_img for r in refs])[-1]
-        self.mask_generator = None
-        try:
-            group = []
-            for ref in refs:
-                if self.cleanup_given_masks:
-                    import dataclasses
-                    cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
-                    ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
-                group.append(ref)
-            return self.step_group(group) if self.group_clip else [self.step(r) for r in group]
-        finally:
-            self.mask_generator = gen
+        group = []
+        for ref in refs:
+            if self.cleanup_given_masks:
+                import dataclasses
+                cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
+                ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
+            group.append(ref)
+        return self.step_group(group, run_sam=False) if self.group_clip else [self.step(r, run_sam=False) for r in group]
 
-    def step(self, ref: RefBatch):
-        """One dataset item; returns the device tensors of the last sentence (idx, scores)."""
+    def step(self, ref: RefBatch, run_sam=True):
+        """One dataset item; returns the device tensors of the last sentence (idx, scores).
+        run_sam=False: the proposal stage of this ref is not part of this call (it ran earlier / on another stream)."""
         import dataclasses
         m = self.model
+        gen_here = self.mask_generator if run_sam else None
         # The text encoder (9 strings: small, latency-bound kernels) is independent of the image path: it runs on its
         # own stream underneath the SAM / CLIP image kernels and is joined before the scoring tail.
         cur = torch.cuda.current_stream()
@@ -230,16 +243,16 @@ class HybridGLPipeline:
             ref = dataclasses.replace(self._cache_ref, tokens=ref.tokens, token_len=ref.token_len, sentences=ref.sentences,
                                       target=ref.target)
         else:
-            if self.mask_generator is not None:
+            if gen_here is not None:
                 # Hybridgl_main.py:85 mask_generator.generate(sam_img), kept on the device
-                if self.use_sam_masks and getattr(self.mask_generator, "crop_n_layers", 0) > 0:
+                if self.use_sam_masks and getattr(gen_here, "crop_n_layers", 0) > 0:
                     # PhraseCut configuration (Hybridgl_main_PhraseCut.py:56-62): crop layers, cross-crop NMS
-                    prop = self.mask_generator.generate_device_crops(ref.sam_img)[:4]
+                    prop = gen_here.generate_device_crops(ref.sam_img)[:4]
                 elif self.use_sam_masks or self.fixed_proposals is not None:
-                    prop = self.mask_generator.generate_device(ref.sam_img, resized=ref.sam_resized,
-                                                               fixed_n=self.fixed_proposals)
+                    prop = gen_here.generate_device(ref.sam_img, resized=ref.sam_resized,
+                                                    fixed_n=self.fixed_proposals)
                 else:  # proposal kernels only, nothing read back
-                    prop = self.mask_generator.propose(ref.sam_img, resized=ref.sam_resized)
+                    prop = gen_here.propose(ref.sam_img, resized=ref.sam_resized)
                 if self.use_sam_masks:
                     if prop[0].shape[0] == 0:
                         raise EmptyProposals("no proposals")
@@ -249,7 +262,7 @@ class HybridGLPipeline:
                 if self.cleanup_given_masks and not self.use_sam_masks:
                     # synthetic benchmark: the small-region clean-up runs on the proposal-shaped seeded masks
                     # (random-weight SAM logits are pixel noise, which is not what the clean-up sees in practice)
-                    cm, _ = self.mask_generator.cleanup_fixed(ref.masks.view(torch.uint8))
+                    cm, _ = gen_here.cleanup_fixed(ref.masks.view(torch.uint8))
                     ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
             blurred = ref.blurred if ref.blurred is not None else ops.gaussian_blur_u8(ref.sam_img, 15)   # :99
             local, glob = ops.synthesize_views(ref.sam_img, blurred, ref.image_norm, ref.masks, self.res)
@@ -263,11 +276,15 @@ class HybridGLPipeline:
         """the per-sentence tail of Hybridgl_main.py:153-230 for one ref; returns the tensors of its last sentence"""
         m = self.model
         # the k1/k2 clamp of Hybridgl_main.py:178-181 persists across refs in the reference
+        if self.k_clamp == "per_ref":
+            self.k1, self.k2 = self._k0
         self.k1 = min(self.k1, hybrid.shape[0])
         self.k2 = min(self.k2, hybrid.shape[0])
+        ref_index = ref.index if ref.index is not None else self._n_refs
+        self._n_refs += 1
         last = None
         n_heat = 0
-        for s in ref.sentences:
+        for sent_no, s in enumerate(ref.sentences):
             imgattn = s.imgattn
             if imgattn is None:
                 imgattn = heat[n_heat]
@@ -283,10 +300,11 @@ class HybridGLPipeline:
             self.cum[0:2] += iu0
             self.cum[2:4] += iu1
             self.iu_log.append((iu0, iu1))
+            self.iu_owner.append((ref_index, sent_no))
             last = (idx, sc, sn, gem)
         return last
 
-    def step_group(self, refs):
+    def step_group(self, refs, run_sam=True):
         """Several refs whose proposals are given, with ONE text-encoder batch over the strings of all refs and ONE
         hybrid forward over the masks of all refs (every mask row of CLIPViTFM.forward is independent, so the
         concatenation changes nothing but the GEMM sizes: 2 x 64 masks -> M = 50432 rows, tile counts that fill
@@ -295,8 +313,8 @@ class HybridGLPipeline:
         import dataclasses
         m = self.model
         same = all(r.masks.shape[1:] == refs[0].masks.shape[1:] and r.tokens.shape[1] == refs[0].tokens.shape[1] for r in refs)
-        if len(refs) == 1 or self.mask_generator is not None or not same or any(r.image_id is not None for r in refs):
-            return [self.step(r) for r in refs]
+        if len(refs) == 1 or (run_sam and self.mask_generator is not None) or not same or any(r.image_id is not None for r in refs):
+            return [self.step(r, run_sam=run_sam) for r in refs]
         cur = torch.cuda.current_stream()
         if not hasattr(self, "_s_text"):
             self._s_text = torch.cuda.Stream()
@@ -354,19 +372,19 @@ class HybridGLPipeline:
             outs.append((hybrid, text, self._score_ref(ref, hybrid, text, heats[i])))
         return outs
 
-    def metrics(self):
-        """Hybridgl_main.py:240-247: overall IoU and mean IoU, pure and with spatial guidance."""
-        cum = self.cum.cpu().numpy().astype(np.float64)
-        ious = np.array([[float(a[0]) / float(a[1]) if int(a[1]) else 0.0, float(b[0]) / float(b[1]) if int(b[1]) else 0.0]
-                         for a, b in ((x.cpu().numpy(), y.cpu().numpy()) for x, y in self.iu_log)]).reshape(-1, 2)
-        return {
-            "cum": [int(v) for v in cum],
-            "oIoU": cum[0] * 100.0 / cum[1] if cum[1] else 0.0,
-            "mIoU": float(ious[:, 0].mean() * 100.0) if len(ious) else 0.0,
-            "oIoU_final": cum[2] * 100.0 / cum[3] if cum[3] else 0.0,
-            "mIoU_final": float(ious[:, 1].mean() * 100.0) if len(ious) else 0.0,
-            "n_sentences": len(ious),
-        }
+    def partial_rows(self):
+        """This process's per-sentence rows [n, 6] int64 = (dataset position, sentence, I, U, I_final, U_final)
+        (hybridgl_amd.dist.ROW_FIELDS): the unit that ranks exchange.  One device->host copy."""
+        if not self.iu_log:
+            return np.zeros((0, 6), dtype=np.int64)
+        iu = torch.stack([torch.cat([a.reshape(2), b.reshape(2)]) for a, b in self.iu_log]).cpu().numpy().astype(np.int64)
+        return np.concatenate([np.asarray(self.iu_owner, dtype=np.int64).reshape(-1, 2), iu], axis=1)
+
+    def metrics(self, dist=None):
+        """Hybridgl_main.py:240-247: overall IoU and mean IoU, pure and with spatial guidance; with an initialised
+        torch.distributed (`dist`) the rows of all ranks are gathered first (the job's metrics, on every rank)."""
+        from . import dist as D
+        return D.gather_metrics(self.partial_rows(), dist, self.model.device)
 
 
 def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=49408, sam_img_size=0, gem=False, gem_size=448,
@@ -398,7 +416,7 @@ def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=494
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     resized = None   # ResizeLongestSide runs on the device (hgl_resize_pil_bilinear), inside the step
     ref = RefBatch(t(img), None if device_blur else t(blur), t(norm), t(masks), t(boxes), t(tokens), t(gt), sents, resized,
-                   tensor_img=t(tensor_img) if gem else None, token_len=int(tokens.argmax(axis=1).max()) + 1)
+                   tensor_img=t(tensor_img) if gem else None, token_len=int(tokens.argmax(axis=1).max()) + 1, index=i)
     host = dict(img=img, blur=blur, norm=norm, masks=masks, boxes=boxes, tokens=tokens, gt=gt, attn=attn_np,
                 tensor_img=tensor_img)
     return ref, host

@@ -193,8 +193,8 @@ def phrasecut_item(sam_img, phrases, gt_polygons, device, tokenizer, parse=None,
     for i, phrase in enumerate(phrases):
         rec = (parse or {}).get(phrase, {})
         row = len(strings)
-        others = list(rec.get("other_nouns", []))
-        strings += [phrase, rec.get("noun_phrase", phrase)] + others
+        others = list(rec.get("other_nouns", []))   # bare phrases; Hybridgl_main_PhraseCut.py:147 encodes 'a photo of ' + other_noun
+        strings += [phrase, rec.get("noun_phrase", phrase)] + ["a photo of " + o for o in others]
         flat = [p for inst in gt_polygons[i] for p in inst]
         gt = phrasecut_polygons_to_mask(flat, W, H)
         attn = t(np.asarray(heatmaps[i], np.float32)) if heatmaps is not None else torch.ones((H, W), dtype=torch.float32, device=device)

@@ -1,82 +1,134 @@
-"""CPU, world_size 2 over gloo: the sharding rule and the metric all-gather of the N>1 path
-(bench.py / SURVEY.md 8e) -- refs i = r (mod R), one all_gather of [cum_I, cum_U, cum_I_f, cum_U_f, n]."""
+"""The N > 1 path of the product (hybridgl_amd/dist.py: sharding rule, metric-row exchange, report) on CPU over gloo,
+world_size 2 -- the code bench.py and hybridgl_amd.main run, not a copy of it.  The oracle only plays the checker:
+it produces per-sentence (I, U) rows for seeded tail cases; the product code shards, gathers and reports them."""
+import json
 import os
-import socket
+import subprocess
 import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
+import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from hybridgl_amd import dist as D   # noqa: E402
 
 
-def shard(n_items, rank, world):
-    return list(range(rank, n_items, world))
+def _rows_for(indices, k_of=None):
+    """oracle-made metric rows of the given dataset positions (two sentences per ref)"""
+    from oracle import clip_oracle as O
+    from oracle.cases import tail_case
+    rows = []
+    for i in indices:
+        hybrid, t_pos, t_neg, masks, boxes, attn, gt = tail_case(i % 8)
+        for s, (d, rel) in enumerate((("none", "none"), ("left", "big"))):
+            gem = O.coherence_scores(attn, masks, d, 1.8)
+            ip, ifin, _, _ = O.score_sentence(hybrid, t_pos, t_neg, boxes, gem, 100.0, 3, 6, 0.6, rel, s == 1)
+            rows.append([i, s, *O.compute_iou(masks[ip], gt), *O.compute_iou(masks[ifin], gt)])
+    return np.asarray(rows, dtype=np.int64).reshape(-1, 6)
 
 
 def _worker(rank, world, port, n_items, q):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle import clip_oracle as O
-    from oracle.cases import tail_case
-    cum = np.zeros(5, dtype=np.int64)
-    for i in shard(n_items, rank, world):
-        hybrid, t_pos, t_neg, masks, boxes, attn, gt = tail_case(i % 8)
-        gem = O.coherence_scores(attn, masks, "none", 1.8)
-        ip, ifin, _, _ = O.score_sentence(hybrid, t_pos, t_neg, boxes, gem, 100.0, 3, 6, 0.6, "none", False)
-        I0, U0 = O.compute_iou(masks[ip], gt)
-        I1, U1 = O.compute_iou(masks[ifin], gt)
-        cum += np.array([I0, U0, I1, U1, 1])
-    vec = torch.from_numpy(cum)
-    out = [torch.zeros_like(vec) for _ in range(world)]
-    dist.all_gather(out, vec)
-    tmax = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    from hybridgl_amd import dist as DD
+    dist = DD.init_process_group("gloo")
+    r, _, w = DD.env_rank()
+    mine = DD.shard_indices(n_items, r, w)
+    rows = _rows_for(mine)
+    # rank 1 holds one row fewer than rank 0 when n_items is odd: the padded exchange must cope
+    m = DD.gather_metrics(rows, dist)
+    t = DD.max_over_ranks(float(rank + 1), dist)
     dist.barrier()
-    if rank == 0:
-        q.put((torch.stack(out).numpy(), float(tmax.item())))
+    q.put((rank, m, t, len(rows)))
     dist.destroy_process_group()
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def test_sharding_is_a_partition():
-    for n, w in [(10, 2), (7, 4), (64, 8), (3, 8)]:
-        parts = [shard(n, r, w) for r in range(w)]
+    for n, w in [(10, 2), (7, 4), (64, 8), (3, 8), (0, 2)]:
+        parts = [D.shard_indices(n, r, w) for r in range(w)]
         assert sorted(sum(parts, [])) == list(range(n))
+        assert all(p == sorted(p) for p in parts)
+    with pytest.raises(ValueError):
+        D.shard_indices(4, 2, 2)
+    assert [D.owned_index(j, 1, 4) for j in range(3)] == [1, 5, 9]
 
 
-def test_two_ranks_gather_equals_single_process():
-    sys.path.insert(0, ROOT)
-    from oracle import clip_oracle as O
-    from oracle.cases import tail_case
-    n_items, world = 6, 2
+def test_group_sharding_keeps_an_image_on_one_rank():
+    keys = [7, 7, 7, 3, 3, 9, 7, 7, 1]          # image ids in loader order (the second run of 7 is a new group)
+    parts = [D.shard_by_groups(keys, r, 2) for r in range(2)]
+    assert sorted(parts[0] + parts[1]) == list(range(len(keys)))
+    assert parts[0] == [0, 1, 2, 5, 8] and parts[1] == [3, 4, 6, 7]
+    assert D.shard_by_groups(keys, 0, 1) == list(range(len(keys)))
+
+
+def test_report_matches_the_reference_formulas():
+    """metrics_from_rows restates Hybridgl_main.py:240-247 / utils.py:365-384: float32 per-sentence IoU (0 where U == 0),
+    torch.mean in the loader's order, cumulative I * 100 / U."""
+    import torch
+    rows = np.array([[1, 0, 10, 40, 0, 0], [0, 1, 3, 9, 9, 9], [0, 0, 5, 7, 1, 3]], dtype=np.int64)
+    m = D.metrics_from_rows(rows)
+    assert m["cum"] == [18, 56, 10, 12] and m["n_sentences"] == 3
+    assert m["oIoU"] == 18 * 100.0 / 56 and m["oIoU_final"] == 10 * 100.0 / 12
+    ordered = [(5, 7), (3, 9), (10, 40)]            # (ref 0, s0), (ref 0, s1), (ref 1, s0)
+    ref = torch.mean(torch.tensor([torch.tensor(i) * 1.0 / torch.tensor(u) for i, u in ordered])) * 100.0
+    assert m["mIoU"] == float(ref)
+    ref_f = torch.mean(torch.tensor([torch.tensor(1) * 1.0 / torch.tensor(3), torch.tensor(1.0), torch.tensor(0.0)])) * 100.0
+    assert m["mIoU_final"] == float(ref_f)
+    assert D.metrics_from_rows(np.zeros((0, 6), np.int64))["oIoU"] == 0.0
+
+
+def test_two_ranks_report_equals_single_process():
+    n_items, world = 5, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    port = D.free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
     for p in procs:
         p.start()
-    gathered, tmax = q.get(timeout=300)
+    got = sorted(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    ref = np.zeros(5, dtype=np.int64)
-    for i in range(n_items):
-        hybrid, t_pos, t_neg, masks, boxes, attn, gt = tail_case(i % 8)
-        gem = O.coherence_scores(attn, masks, "none", 1.8)
-        ip, ifin, _, _ = O.score_sentence(hybrid, t_pos, t_neg, boxes, gem, 100.0, 3, 6, 0.6, "none", False)
-        ref += np.array([*O.compute_iou(masks[ip], gt), *O.compute_iou(masks[ifin], gt), 1])
-    assert gathered.shape == (2, 5)
-    assert np.array_equal(gathered.sum(0), ref)          # oIoU numerators/denominators are additive
-    assert tmax == 2.0                                    # MAX over ranks, as bench.py times the job
+    single = D.metrics_from_rows(_rows_for(range(n_items)))
+    for rank, m, tmax, n_rows in got:
+        assert m == single, (rank, m, single)       # every rank holds the job's report, bit for bit
+        assert tmax == 2.0                           # MAX over ranks, as bench.py times the job
+    assert [g[3] for g in got] == [6, 4]             # ragged row counts went through the padded all-gather
+
+
+def test_spawn_local_ranks_sets_the_launcher_environment(tmp_path):
+    """bench.py --gpus N without a launcher: N fresh interpreters with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*,
+    a failing rank makes the job fail."""
+    out = tmp_path / "r"
+    code = ("import os, sys; open(sys.argv[1] + os.environ['RANK'], 'w').write(' '.join(os.environ[k] for k in "
+            "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR'))); sys.exit(3 if os.environ['RANK'] == '1' and len(sys.argv) > 2 else 0)")
+    assert D.spawn_local_ranks(3, [sys.executable, "-c", code, str(out)]) == 0
+    assert [open(f"{out}{r}").read() for r in range(3)] == [f"{r} {r} 3 127.0.0.1" for r in range(3)]
+    assert D.spawn_local_ranks(2, [sys.executable, "-c", code, str(out), "fail"]) == 3
+
+
+def test_bench_spawns_before_touching_the_gpu():
+    """`python bench.py --gpus 2` with no launcher must reach spawn_local_ranks without a GPU call: in this GPU-less
+    container the children then stop at bench.py's own 'needs a GPU' assertion -- not the parent."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--backend", "gloo"], env=env, capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_driver.py::test_bench_two_ranks")
+    assert r.returncode != 0
+    assert "bench.py needs a GPU" in r.stderr and "spawn_local_ranks" not in r.stderr
+
+
+def test_other_nouns_carry_the_reference_prefix():
+    """Hybridgl_main.py:160 / Hybridgl_main_PhraseCut.py:147: clip.tokenize('a photo of ' + other_noun)"""
+    from hybridgl_amd.main import sentence_strings
+    rec = {"noun_phrase": "the cat", "other_nouns": ["a dog", "sofa"]}
+    assert sentence_strings("the cat left of a dog on the sofa", rec) == [
+        "the cat left of a dog on the sofa", "the cat", "a photo of a dog", "a photo of sofa"]
+    assert sentence_strings("cat", {}) == ["cat", "cat"]
