@@ -101,6 +101,7 @@ PROTOTYPES = {
     "hgl_set_precision": (_I, [_I]),
     "hgl_get_precision": (_I, []),
     "hgl_gemm_f16x3_select": (_I, [_I]),
+    "hgl_split_overflow_count": (_I, [_I, C.POINTER(C.c_ulonglong)]),
     "hgl_register_split_weight": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP]),
     "hgl_unregister_split_weight": (_I, [_VP]),
     "hgl_gemm_f16x3": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _SZ, _VP]),
@@ -114,6 +115,7 @@ PROTOTYPES = {
     "hgl_clip_text_workspace_bytes": (_SZ, [C.POINTER(HglClipTextW), _I]),
     "hgl_clip_encode_text": (_I, [C.POINTER(HglClipTextW), _VP, _I, _VP, _VP, _SZ, _VP]),
     "hgl_clip_encode_text_prefix": (_I, [C.POINTER(HglClipTextW), _VP, _I, _I, _VP, _VP, _SZ, _VP]),
+    "hgl_clip_encode_text_ex": (_I, [C.POINTER(HglClipTextW), _VP, _I, _I, _VP, _VP, _I, _I, _VP, _VP, _SZ, _VP]),
     "hgl_gem_workspace_bytes": (_SZ, [C.POINTER(HglClipVisionW)]),
     "hgl_gem_image_features": (_I, [C.POINTER(HglClipVisionW), _VP, _I, _I, _F, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_gem_batch_workspace_bytes": (_SZ, [C.POINTER(HglClipVisionW), _I]),

@@ -75,9 +75,11 @@ class _ClipModel:
     """The `.model` attribute: what the reference reaches as Model.model.* (clip/model.py:340-431)."""
 
     def __init__(self, sd, cfg, device, precision="f32"):
+        import weakref
         self.cfg = cfg
         self.precision = precision
         self.device = torch.device(device)
+        _before = set(ops._split_cache)
         self.dtype = torch.float32  # convert_weights is disabled in the reference (clip/model.py:509)
         vw, vl = cfg["vision_width"], cfg["vision_layers"]
         p = cfg["vision_patch_size"]
@@ -127,25 +129,50 @@ class _ClipModel:
         self.logit_scale = _to_dev(np.asarray(sd["logit_scale"], dtype=np.float32).reshape(()), device)
         self._logit_scale_exp = float(np.exp(np.float32(np.asarray(sd["logit_scale"]))))
         self.context_length = cfg["context_length"]
+        # the fp16 splits registered above die with this model (library registry + hi/lo tensors)
+        self._split_keys = ops.split_weight_keys_since(_before)
+        weakref.finalize(self, ops.release_split_weights, list(self._split_keys))
 
-    def encode_text(self, text, target_noun_index=None, seq_len=None):
-        """CLIP.encode_text (clip/model.py:414-431). text: [B, context] integer tokens.  seq_len (not in the
-        reference): compute only the first seq_len positions -- exact under the causal mask when every EOT token lies
-        inside that prefix (the caller's promise; the tokenizer knows the lengths)."""
-        if target_noun_index:
-            raise NotImplementedError("target_noun_index pooling is not on the Hybridgl_main path")
+    def encode_text(self, text, target_noun_index=None, seq_len=None, masking_index=(), masking_block=None):
+        """CLIP.encode_text (clip/model.py:414-431). text: [B, context] integer tokens.
+        target_noun_index: the projected row is position target_noun_index + 1 of every string instead of its EOT
+        (clip/model.py:426-428); like the reference's `if target_noun_index:` a None or 0 pools the EOT.  A tensor /
+        sequence of one index per string is accepted as well (the reference's truth test only admits one element).
+        seq_len (not in the reference): compute only the first seq_len positions -- exact under the causal mask when
+        every pooled position lies inside that prefix (the caller's promise; the tokenizer knows the lengths).
+        masking_index / masking_block: CLIPViTFM.text_masking_feature (see there)."""
         lib = _lib.load()
+        ops.use_precision(self.precision)
         if not text.is_cuda:
             raise _lib.HybridGLError("encode_text: tokens must be on the GPU (no CPU path exists)")
         tok = text.to(torch.int32).contiguous()
         B = tok.shape[0]
         assert tok.shape[1] == self.context_length
+        pool = None
+        if target_noun_index is not None:
+            if isinstance(target_noun_index, torch.Tensor):
+                tni = target_noun_index.reshape(-1).to(torch.int64).cpu()
+            else:
+                tni = torch.as_tensor(target_noun_index, dtype=torch.int64).reshape(-1)
+            if tni.numel() not in (1, B):
+                raise ValueError(f"target_noun_index: expected 1 or {B} indices, got {tni.numel()}")
+            if bool((tni != 0).any()) or tni.numel() > 1:      # a lone 0 is falsy in the reference -> EOT pooling
+                pos = (tni + 1).expand(B) if tni.numel() == 1 else tni + 1
+                if int(pos.min()) < 0 or int(pos.max()) >= self.context_length:
+                    raise IndexError("target_noun_index + 1 outside the context")
+                pool = pos.to(torch.int32).contiguous().to(tok.device)
+        zero = None
+        if len(masking_index):
+            zero = torch.as_tensor([int(i) + 1 for i in masking_index], dtype=torch.int32).to(tok.device)   # + start token
         need = lib.hgl_clip_text_workspace_bytes(C.byref(self.text_w), B)
         ws = ops.workspace(need, tok.device, "clip_text")
         out = torch.empty((B, self.cfg["embed_dim"]), dtype=torch.float32, device=tok.device)
         S = self.context_length if seq_len is None else max(1, min(int(seq_len), self.context_length))
-        check(lib.hgl_clip_encode_text_prefix(C.byref(self.text_w), tok.data_ptr(), B, S, out.data_ptr(),
-                                              ws.data_ptr(), ws.numel(), ops._stream()), "hgl_clip_encode_text")
+        check(lib.hgl_clip_encode_text_ex(C.byref(self.text_w), tok.data_ptr(), B, S,
+                                          pool.data_ptr() if pool is not None else None,
+                                          zero.data_ptr() if zero is not None else None, 0 if zero is None else zero.numel(),
+                                          0 if masking_block is None else int(masking_block), out.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), ops._stream()), "hgl_clip_encode_text")
         return out
 
 
@@ -163,7 +190,7 @@ class CLIPViTFM:
         faster GEMMs); default from HYBRIDGL_PRECISION (ops.default_precision)."""
         _lib.load()
         precision = precision or ops.default_precision()
-        ops.set_precision(precision)
+        ops.use_precision(precision)
         # model/backbone.py:16-21 (+ the ViT-L/14 extension of SURVEY.md note 2)
         if model_name in ("ViT-B/32", "ViT-B/16", "tiny"):
             self.last_layer, self.num_heads = 10, 12
@@ -203,11 +230,9 @@ class CLIPViTFM:
         return self.model.encode_text(text)
 
     def text_masking_feature(self, text, masking_index=[], masking_block=11):   # noqa: B006 -- reference signature
-        """model/backbone.py:34-56.  Not called anywhere in the reference's drivers; without masked tokens it is
-        text_feature, and the token-zeroing variant is not built."""
-        if masking_index:
-            raise NotImplementedError("text_masking_feature with masked tokens is not on the reference's path")
-        return self.model.encode_text(text)
+        """model/backbone.py:34-56: the text tower with the token positions masking_index (+1 for the start token) of
+        every string zeroed before each block >= masking_block; EOT pooling and projection as text_feature."""
+        return self.model.encode_text(text, masking_index=list(masking_index), masking_block=masking_block)
 
     def calculate_score(self, image_features, text_features, visual_norm_dim=1):
         """model/backbone.py:74-87 -> [N, T] logits."""
@@ -218,6 +243,7 @@ class CLIPViTFM:
     def forward(self, local_imgs, global_imgs, pred_masks, masking_block=None, fusion_mode="G2L"):
         """model/backbone.py:117 -> [N, embed_dim]."""
         lib = _lib.load()
+        ops.use_precision(self.model.precision)
         if fusion_mode not in FUSION:
             raise ValueError(f"unknown fusion_mode {fusion_mode!r}")
         mode = FUSION[fusion_mode]

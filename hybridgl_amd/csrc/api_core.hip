@@ -86,6 +86,16 @@ int hgl_prof_read(int cls, long long* launches, double* ms, double* flops, doubl
   return HGL_OK;
 }
 
+// Number of fp32 values beyond the fp16 range that the split-fp16 (f16x3) path has saturated since the last reset,
+// summed over the library's kernels.  Blocking device reads: synchronise the streams that ran the work first.
+int hgl_split_overflow_count(int reset, unsigned long long* count) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(count != nullptr, "split_overflow_count: null argument");
+  *count = hgl_split_overflow_gemm(reset) + hgl_split_overflow_attention(reset) + hgl_split_overflow_clip_glue(reset) +
+           hgl_split_overflow_gem(reset) + hgl_split_overflow_sam_glue(reset);
+  return HGL_OK;
+}
+
 int hgl_abi_version(void) { return HGL_ABI_VERSION; }
 const char* hgl_last_error(void) { return g_err; }
 

@@ -1024,3 +1024,5 @@ int hgl_launch_attention_split(const float* q, const float* k, const float* v, f
       return HGL_EINVAL;
   }
 }
+
+HGL_DEFINE_SPLIT_OVERFLOW_READER(hgl_split_overflow_attention)

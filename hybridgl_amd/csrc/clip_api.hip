@@ -369,12 +369,14 @@ size_t hgl_clip_text_workspace_bytes(const HglClipTextW* w, int B) {
 // seq_len <= context: only the first seq_len positions of every string are computed.  Under the causal mask a
 // position never sees later ones, so the pooled EOT feature is unchanged as long as every EOT lies inside the prefix
 // (the caller's promise; an EOT beyond it yields NaN rows rather than a wrong feature).
-int hgl_clip_encode_text_prefix(const HglClipTextW* w, const int32_t* tokens, int B, int seq_len, float* out,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+int hgl_clip_encode_text_ex(const HglClipTextW* w, const int32_t* tokens, int B, int seq_len, const int32_t* pool_pos,
+                            const int32_t* zero_pos, int n_zero, int masking_block, float* out,
+                            void* workspace, size_t workspace_bytes, void* stream) {
   HGL_TRY(hgl_require_device());
   HGL_REQUIRE(valid_text(w), "clip_encode_text: invalid weight struct");
   HGL_REQUIRE(tokens && out && B > 0, "clip_encode_text: null input");
   HGL_REQUIRE(seq_len >= 1 && seq_len <= w->context, "clip_encode_text: prefix length %d outside 1..%d", seq_len, w->context);
+  HGL_REQUIRE(n_zero >= 0 && (n_zero == 0 || zero_pos), "clip_encode_text: %d masked positions without a list", n_zero);
   HglArena ar(workspace, workspace_bytes);
   TextPlan p;
   if (!workspace || !carve_text(ar, w, B, p)) {
@@ -385,15 +387,27 @@ int hgl_clip_encode_text_prefix(const HglClipTextW* w, const int32_t* tokens, in
   const int D = w->width, S = seq_len;
   HGL_TRY(hgl_launch_text_embed(tokens, w->token_embedding, w->positional_embedding, p.X, B, S, w->context, D,
                                 w->vocab, p.eot, st));
+  if (pool_pos)   // clip/model.py:426-428: the pooled row is chosen by the caller
+    if (hipMemcpyAsync(p.eot, pool_pos, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      hgl_set_error("clip_encode_text: copying pool_pos failed");
+      return HGL_ELAUNCH;
+    }
   BlockBufs bf{p.H, p.QKV, p.F};
-  for (int l = 0; l < w->layers; ++l)
+  for (int l = 0; l < w->layers; ++l) {
+    if (n_zero > 0 && l >= masking_block) HGL_TRY(hgl_launch_zero_positions(p.X, B, S, D, zero_pos, n_zero, st));   // backbone.py:44-46
     HGL_TRY(run_block(w->blocks[l], p.X, B, S, D, w->heads, bf, HGL_MASK_CAUSAL, nullptr, 0, 0, st));
-  // ln_final is row-wise: normalise only the EOT rows, then project (clip/model.py:424-429)
+  }
+  // ln_final is row-wise: normalise only the pooled rows, then project (clip/model.py:424-429)
   HGL_TRY(hgl_launch_gather_eot(p.X, p.eot, B, S, D, p.rows, st));
   HGL_TRY(hgl_launch_layernorm(p.rows, w->ln_final_w, w->ln_final_b, p.rows_ln, B, D, 1e-5f, st));
   HGL_TRY(hgl_launch_gemm(p.rows_ln, w->text_projection_t, nullptr, nullptr, out, B, w->embed, D, D, D,
                           0, w->embed, 1, 0, 0, 0, 0, HGL_ACT_NONE, st));
   return HGL_OK;
+}
+
+int hgl_clip_encode_text_prefix(const HglClipTextW* w, const int32_t* tokens, int B, int seq_len, float* out,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  return hgl_clip_encode_text_ex(w, tokens, B, seq_len, nullptr, nullptr, 0, 0, out, workspace, workspace_bytes, stream);
 }
 
 int hgl_clip_encode_text(const HglClipTextW* w, const int32_t* tokens, int B, float* out,

@@ -270,6 +270,18 @@ __global__ __launch_bounds__(256) void gather_eot_kernel(const float* __restrict
   y[i] = e < S ? x[((long long)bidx * S + e) * D + d] : __int_as_float(0x7fc00000);
 }
 
+// x[b, pos[z], :] = 0 for every string b and listed position (model/backbone.py:44-46: x[masking_index] = 0 on [S,B,D])
+__global__ __launch_bounds__(256) void zero_positions_kernel(float* __restrict__ x, int B, int S, int D,
+                                                             const int32_t* __restrict__ pos, int n) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)B * n * D) return;
+  const int d = (int)(i % D);
+  const int z = (int)((i / D) % n);
+  const int b = (int)(i / ((long long)D * n));
+  const int p = pos[z];
+  if (p >= 0 && p < S) x[((long long)b * S + p) * D + d] = 0.0f;
+}
+
 inline unsigned grid_for(long long n, int block = 256, unsigned cap = 256u * 16u) {
   long long g = (n + block - 1) / block;
   if (g < 1) g = 1;
@@ -355,9 +367,17 @@ int hgl_launch_text_embed(const int32_t* tokens, const float* emb, const float* 
   return hgl_check_launch("text_embed");
 }
 
+int hgl_launch_zero_positions(float* x, int B, int S, int D, const int32_t* pos, int n, hipStream_t st) {
+  const long long total = (long long)B * n * D;
+  hipLaunchKernelGGL(zero_positions_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, B, S, D, pos, n);
+  return hgl_check_launch("zero_positions");
+}
+
 int hgl_launch_gather_eot(const float* x, const int32_t* eot, int B, int S, int D, float* y,
                           hipStream_t st) {
   const long long n = (long long)B * D;
   hipLaunchKernelGGL(gather_eot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, eot, B, S, D, y);
   return hgl_check_launch("gather_eot");
 }
+
+HGL_DEFINE_SPLIT_OVERFLOW_READER(hgl_split_overflow_clip_glue)

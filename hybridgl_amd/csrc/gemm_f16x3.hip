@@ -1088,3 +1088,5 @@ int hgl_gemm_f16x3(const float* A, const float* W, const float* bias, const floa
 }
 
 }  // extern "C"
+
+HGL_DEFINE_SPLIT_OVERFLOW_READER(hgl_split_overflow_gemm)

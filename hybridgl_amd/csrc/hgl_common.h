@@ -14,12 +14,39 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // arithmetic into one of the conversions (single rounding from the exact product) and not the other, so that on
 // ties the stored hi and the hi subtracted for lo are different fp16 neighbours and hi + lo misses x by 2*|lo|
 // (measured: 0.1 % of attention rows off by up to 8e-5 relative).  The empty asm makes x opaque.
+//
+// Range: |x| > 65504 does not fit fp16 (hi would be inf, lo = x - inf = -inf and the MFMA sum NaN).  Such a value is
+// SATURATED to +-65504 and COUNTED in a per-translation-unit device counter that hgl_split_overflow_count() sums:
+// the result is then wrong but finite, and the host is told (hybridgl_amd raises and points at HYBRIDGL_PRECISION=f32).
+// Weights are pre-scaled by a power of two and cannot overflow; activations of the trained CLIP / SAM models stay two
+// to three orders of magnitude below the limit.  A NaN stays a NaN.
+static __device__ __attribute__((unused)) unsigned int hgl_tu_split_overflow;
 __device__ __forceinline__ void hgl_split_hi_lo(float x, _Float16& hi, _Float16& lo) {
   asm volatile("" : "+v"(x));
+  if (__builtin_expect(fabsf(x) > 65504.0f, 0)) {
+    atomicAdd(&hgl_tu_split_overflow, 1u);
+    x = copysignf(65504.0f, x);
+  }
   hi = (_Float16)x;
   lo = (_Float16)(x - (float)hi);
 }
+// host-side reader of this translation unit's counter (define once in every .hip that splits)
+#define HGL_DEFINE_SPLIT_OVERFLOW_READER(name)                                                        \
+  unsigned long long name(int reset) {                                                                \
+    unsigned int v = 0;                                                                               \
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(hgl_tu_split_overflow), sizeof(v)) != hipSuccess) return 0; \
+    if (reset && v) {                                                                                 \
+      const unsigned int z = 0;                                                                       \
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(hgl_tu_split_overflow), &z, sizeof(z));                      \
+    }                                                                                                 \
+    return v;                                                                                         \
+  }
 #endif
+unsigned long long hgl_split_overflow_gemm(int reset);
+unsigned long long hgl_split_overflow_attention(int reset);
+unsigned long long hgl_split_overflow_clip_glue(int reset);
+unsigned long long hgl_split_overflow_gem(int reset);
+unsigned long long hgl_split_overflow_sam_glue(int reset);
 
 void hgl_set_error(const char* fmt, ...);
 int hgl_check_launch(const char* what);  // hipGetLastError -> HGL_ELAUNCH
@@ -100,6 +127,7 @@ int hgl_launch_text_embed(const int32_t* tokens, const float* emb, const float* 
                           int S, int ctx, int D, int vocab, int32_t* eot, hipStream_t st);
 int hgl_launch_gather_eot(const float* x, const int32_t* eot, int B, int S, int D, float* y,
                           hipStream_t st);
+int hgl_launch_zero_positions(float* x, int B, int S, int D, const int32_t* pos, int n, hipStream_t st);
 
 // CLIP transformer pieces shared by clip_api.hip and gem_api.hip
 struct HglBlockBufs {

@@ -119,6 +119,7 @@ class GEMWrapper:
     def image_features(self, image, return_ori=False):
         """GEMViT.forward on one image [3, R, R] -> [1 + g*g, embed] (ln_post + proj of every token)."""
         lib = _lib.load()
+        ops.use_precision(self.model.precision)
         assert image.dim() == 3 and image.shape[0] == 3 and image.shape[1] == image.shape[2], "image must be [3,R,R]"
         R = image.shape[-1]
         assert R % self.patch_size == 0, "image side must be a multiple of the patch size"
@@ -142,6 +143,7 @@ class GEMWrapper:
         """GEMViT.forward on several images at once [B, 3, R, R] -> [B, 1 + g*g, embed]: the token rows of the images are
         stacked, so every GEMM / LayerNorm launch covers all of them (one self-self temperature per image)."""
         lib = _lib.load()
+        ops.use_precision(self.model.precision)
         assert images.dim() == 4 and images.shape[1] == 3 and images.shape[2] == images.shape[3], "images must be [B,3,R,R]"
         nb, R = images.shape[0], images.shape[-1]
         assert R % self.patch_size == 0, "image side must be a multiple of the patch size"
@@ -163,6 +165,7 @@ class GEMWrapper:
     def heatmap(self, feat, text_feats, res, normalize=True):
         """feat [1+g*g, E], text_feats [T, E] -> [T, res, res]"""
         lib = _lib.load()
+        ops.use_precision(self.model.precision)
         T, E = text_feats.shape
         grid = int(round(math.sqrt(feat.shape[0] - 1)))
         tf = text_feats.contiguous()

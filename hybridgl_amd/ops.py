@@ -3,6 +3,8 @@
 Every function validates device/dtype/contiguity, then passes raw pointers to
 libhybridgl.so.  Nothing here computes: a missing library or a CPU tensor raises.
 """
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -54,17 +56,18 @@ def gemm(a, w, bias=None, residual=None, act="none", out=None):
     return out
 
 
-_split_cache = {}  # fp32 weight data_ptr -> (weight, hi, lo): keeps the registered halves alive
+_split_cache = {}  # fp32 weight data_ptr -> (weight, hi, lo): keeps the registered halves alive while a model owns them
 
 
 def register_split_weight(w):
     """Register the fp16 hi/lo split of a [N,K] fp32 weight for the HGL_PREC_F16X3 GEMM path.
-    The power-of-two scale puts max|w| at <= 2^14 (lo halves stay normal fp16)."""
+    The power-of-two scale puts max|w| at <= 2^14 (lo halves stay normal fp16).  Returns the registry key; the owner
+    hands its keys to release_split_weights when it dies (the models do that through weakref.finalize)."""
     import math
     lib = _lib.load()
     key = w.data_ptr()
     if key in _split_cache:
-        return
+        return key
     N, K = w.shape
     amax = float(w.abs().max().item())
     s = 0 if amax == 0 else max(-24, min(24, 14 - math.ceil(math.log2(amax))))
@@ -73,6 +76,23 @@ def register_split_weight(w):
     check(lib.hgl_register_split_weight(_dev(w, torch.float32, "w"), N, K, s, hi.data_ptr(), lo.data_ptr(),
                                         _stream()), "hgl_register_split_weight")
     _split_cache[key] = (w, hi, lo)
+    return key
+
+
+def release_split_weights(keys):
+    """Drop the registered splits of `keys` (library registry + the hi/lo tensors): called when their model dies."""
+    try:
+        lib = _lib.load()
+    except Exception:   # interpreter shutdown
+        return
+    for key in keys:
+        if _split_cache.pop(key, None) is not None:
+            lib.hgl_unregister_split_weight(key)
+
+
+def split_weight_keys_since(before):
+    """keys registered after the snapshot `before` (= set(_split_cache)): what a constructor has added"""
+    return [k for k in _split_cache if k not in before]
 
 
 def default_precision():
@@ -81,9 +101,41 @@ def default_precision():
     return os.environ.get("HYBRIDGL_PRECISION", "f16x3")
 
 
+_precision_now = None
+
+
 def set_precision(mode):
-    """'f32' (exact fp32 MFMA) or 'f16x3' (split-fp16 MFMA, fp32-class accuracy)."""
+    """'f32' (exact fp32 MFMA) or 'f16x3' (split-fp16 MFMA, fp32-class accuracy).  The library keeps ONE current mode;
+    every model carries its own and re-asserts it on entry (use_precision), so models of different precision can live
+    in one process."""
+    global _precision_now
     check(_lib.load().hgl_set_precision({"f32": 0, "f16x3": 1}[mode]), "hgl_set_precision")
+    _precision_now = mode
+
+
+def use_precision(mode):
+    """make `mode` the library's current precision if it is not already (called on entry by every model method)"""
+    if mode != _precision_now:
+        set_precision(mode)
+
+
+def split_overflow_count(reset=True, sync=True):
+    """Number of activations beyond the fp16 range that the f16x3 path saturated since the last reset
+    (hgl_split_overflow_count).  Synchronises the device first unless sync=False."""
+    if sync:
+        torch.cuda.synchronize()
+    n = C.c_ulonglong(0)
+    check(_lib.load().hgl_split_overflow_count(1 if reset else 0, C.byref(n)), "hgl_split_overflow_count")
+    return int(n.value)
+
+
+def check_split_overflow():
+    """raise if the f16x3 path met a value it cannot represent (the results since the last check are then not
+    fp32-class); the cure is HYBRIDGL_PRECISION=f32"""
+    n = split_overflow_count(reset=True)
+    if n:
+        raise _lib.HybridGLError(f"{n} activation value(s) exceeded the fp16 range (|x| > 65504) in f16x3 mode and were "
+                                 "saturated: rerun with HYBRIDGL_PRECISION=f32 (or precision='f32')")
 
 
 X3_KERNELS = {"auto": -1, "v1": 0, "P": 1}

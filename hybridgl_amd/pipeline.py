@@ -384,7 +384,10 @@ class HybridGLPipeline:
         """Hybridgl_main.py:240-247: overall IoU and mean IoU, pure and with spatial guidance; with an initialised
         torch.distributed (`dist`) the rows of all ranks are gathered first (the job's metrics, on every rank)."""
         from . import dist as D
-        return D.gather_metrics(self.partial_rows(), dist, self.model.device)
+        rows = self.partial_rows()
+        if getattr(self.model.model, "precision", "f32") == "f16x3":
+            ops.check_split_overflow()     # an activation beyond the fp16 range voids the run: raise, do not report
+        return D.gather_metrics(rows, dist, self.model.device)
 
 
 def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=49408, sam_img_size=0, gem=False, gem_size=448,

@@ -42,9 +42,11 @@ class Sam:
 
     def __init__(self, state_dict, cfg, device="cuda", precision=None):
         _lib.load()
+        import weakref
         precision = precision or ops.default_precision()
-        ops.set_precision(precision)
+        ops.use_precision(precision)
         self.precision = precision
+        _before = set(ops._split_cache)
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         self._t = []  # keep every device tensor alive
@@ -148,6 +150,9 @@ class Sam:
               "hgl_sam_dense_pe")
         torch.cuda.current_stream().synchronize()
         self.dec_w = dec
+        # the fp16 splits registered above die with this model (library registry + hi/lo tensors)
+        self._split_keys = ops.split_weight_keys_since(_before)
+        weakref.finalize(self, ops.release_split_weights, list(self._split_keys))
 
     def to(self, device):
         if torch.device(device).type != "cuda":
@@ -161,6 +166,7 @@ class Sam:
     def encode(self, resized_u8):
         """resized_u8: [h,w,3] uint8 device tensor (long side == img_size) -> emb [g*g, C]."""
         lib = _lib.load()
+        ops.use_precision(self.precision)
         h, w = resized_u8.shape[:2]
         need = lib.hgl_sam_encode_workspace_bytes(C.byref(self.enc_w))
         ws = ops.workspace(need, self.device, "sam_encode")
@@ -174,6 +180,7 @@ class Sam:
         resized_list: [h_i,w_i,3] uint8 device tensors -> emb [nb, g*g, C]; each slice equals encode() of that image
         up to the summation order of split-K."""
         lib = _lib.load()
+        ops.use_precision(self.precision)
         nb = len(resized_list)
         imgs = [r.contiguous() for r in resized_list]
         ptrs = (C.c_void_p * nb)(*[ops._dev(r, torch.uint8, "resized_img") for r in imgs])
@@ -189,6 +196,7 @@ class Sam:
     def decode_points(self, emb, points01):
         """points01: [P,2] fp32 device ((point+0.5)/img_size) -> (low_res [P,3,4g,4g], iou [P,3])."""
         lib = _lib.load()
+        ops.use_precision(self.precision)
         P = points01.shape[0]
         need = lib.hgl_sam_decode_workspace_bytes(C.byref(self.dec_w), P)
         ws = ops.workspace(need, self.device, "sam_decode")
@@ -351,29 +359,26 @@ def build_all_layer_point_grids(n_per_side, n_layers, scale_per_layer):
 
 
 def generate_crop_boxes(im_size, n_layers, overlap_ratio):
-    """utils/amg.py:201-238 -> (crop boxes XYXY, layer index of each); the first box is the whole image."""
+    """Crop windows of the crop-layer generator (what utils/amg.py:201-238 produces; pinned by the known answers in
+    tests/golden/sam_crops.npz) -> (XYXY boxes, layer index of each).  Layer 0 is the whole image; layer L tiles the
+    image with a 2^L x 2^L grid of equal windows that overlap by int(overlap_ratio * short_side * 2 / 2^L) pixels,
+    window size = ceil((overlap * (n - 1) + side) / n), origins = int((size - overlap) * k), enumerated x-major,
+    clipped to the image."""
     import math
-    from itertools import product
-    crop_boxes, layer_idxs = [], []
-    im_h, im_w = im_size
-    short_side = min(im_h, im_w)
-    crop_boxes.append([0, 0, im_w, im_h])
-    layer_idxs.append(0)
-
-    def crop_len(orig_len, n_crops, overlap):
-        return int(math.ceil((overlap * (n_crops - 1) + orig_len) / n_crops))
-
-    for i_layer in range(n_layers):
-        n_crops_per_side = 2 ** (i_layer + 1)
-        overlap = int(overlap_ratio * short_side * (2 / n_crops_per_side))
-        crop_w = crop_len(im_w, n_crops_per_side, overlap)
-        crop_h = crop_len(im_h, n_crops_per_side, overlap)
-        crop_box_x0 = [int((crop_w - overlap) * i) for i in range(n_crops_per_side)]
-        crop_box_y0 = [int((crop_h - overlap) * i) for i in range(n_crops_per_side)]
-        for x0, y0 in product(crop_box_x0, crop_box_y0):
-            crop_boxes.append([x0, y0, min(x0 + crop_w, im_w), min(y0 + crop_h, im_h)])
-            layer_idxs.append(i_layer + 1)
-    return crop_boxes, layer_idxs
+    height, width = im_size
+    boxes, layers = [[0, 0, width, height]], [0]
+    for layer in range(1, n_layers + 1):
+        n = 1 << layer
+        overlap = int(overlap_ratio * min(height, width) * (2 / n))
+        win_w = int(math.ceil((overlap * (n - 1) + width) / n))
+        win_h = int(math.ceil((overlap * (n - 1) + height) / n))
+        for kx in range(n):
+            x0 = int((win_w - overlap) * kx)
+            for ky in range(n):
+                y0 = int((win_h - overlap) * ky)
+                boxes.append([x0, y0, min(x0 + win_w, width), min(y0 + win_h, height)])
+                layers.append(layer)
+    return boxes, layers
 
 
 def get_preprocess_shape(oldh, oldw, long_side):

@@ -76,10 +76,15 @@ int hgl_prof_read(int cls, long long* launches, double* ms, double* flops, doubl
 #define HGL_PREC_F16X3 1
 int hgl_set_precision(int mode);
 int hgl_get_precision(void);
-/* Pins the tiling of the f16x3 GEMM: -1 = cost model (default), 0 = register-staged 128x128,
- * 1..5 = LDS-DMA 256x256 / 256x128 / 128x128 / 128x160 / 160x160.  All tilings give bit-identical results; the
- * switch exists for the parity tests and micro-benchmarks. */
+/* Pins the tiling of the f16x3 GEMM: -1 = cost model (default), 0 = register-staged 128x128 (two workgroups per
+ * CU), 1 = LDS-DMA 256x256 ping-pong (persistent).  Both tilings give bit-identical results; the switch exists for
+ * the parity tests and micro-benchmarks. */
 int hgl_gemm_f16x3_select(int kind);
+/* f16x3 mode splits every fp32 operand into fp16 hi + lo; an activation beyond the fp16 range (|x| > 65504) is
+ * saturated and counted instead of becoming inf / NaN.  *count = values saturated since the last reset, over all
+ * kernels of the library (a blocking device read: synchronise the producing streams first).  Non-zero means the
+ * results of that run are not trustworthy in this mode: rerun with hgl_set_precision(HGL_PREC_F32). */
+int hgl_split_overflow_count(int reset, unsigned long long* count);
 /* Splits w_fp32 [N,K] * 2^scale_log2 into caller-owned fp16 arrays hi, lo ([N,K] each) and
  * records them under the fp32 pointer (scale_log2 keeps the lo half in the fp16 normal range;
  * choose max|w| * 2^scale_log2 <= 2^14). */
@@ -180,6 +185,16 @@ int hgl_clip_encode_text(const HglClipTextW* w, const int32_t* tokens, int B, fl
  * lies inside the prefix (referring expressions use a dozen of the 77 positions); an EOT beyond it yields NaN rows. */
 int hgl_clip_encode_text_prefix(const HglClipTextW* w, const int32_t* tokens, int B, int seq_len, float* out,
                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* The two text-tower variants off the Hybridgl_main path (kept for API completeness):
+ *  - pool_pos (device int32 [B], nullable): the projected row of string b is position pool_pos[b] instead of its EOT --
+ *    CLIP.encode_text(text, target_noun_index) with pool_pos = target_noun_index + 1 (clip/model.py:426-428);
+ *  - zero_pos (device int32 [n_zero], nullable) + masking_block: before every block l >= masking_block the positions
+ *    zero_pos[*] of EVERY string are set to zero -- CLIPViTFM.text_masking_feature with zero_pos = masking_index + 1
+ *    (model/backbone.py:34-56).  Positions >= seq_len are ignored. */
+int hgl_clip_encode_text_ex(const HglClipTextW* w, const int32_t* tokens, int B, int seq_len, const int32_t* pool_pos,
+                            const int32_t* zero_pos, int n_zero, int masking_block, float* out,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Text-conditioned heat-map: the GEM call of Hybridgl_main.py:36-39,200-201

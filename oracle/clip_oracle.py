@@ -225,8 +225,11 @@ def clip_hybrid_forward(sd, local_imgs, global_imgs, pred_masks, masking_block=N
 
 
 # ----------------------------------------------------------------------------- CLIP text
-def encode_text(sd, tokens, heads=None):
-    """CLIP.encode_text (clip/model.py:414-431); causal mask from build_attention_mask (:396-402)."""
+def encode_text(sd, tokens, heads=None, target_noun_index=None, masking_index=(), masking_block=None):
+    """CLIP.encode_text (clip/model.py:414-431); causal mask from build_attention_mask (:396-402).
+    target_noun_index: the pooled position is target_noun_index + 1 instead of the EOT (:426-428; None and 0 are
+    falsy there and fall through to the EOT).  masking_index / masking_block: CLIPViTFM.text_masking_feature
+    (model/backbone.py:34-56): positions masking_index + 1 of every sequence are zeroed before each block >= masking_block."""
     tokens = np.asarray(tokens)
     B, S = tokens.shape
     D = sd["ln_final.weight"].shape[0]
@@ -235,10 +238,16 @@ def encode_text(sd, tokens, heads=None):
     layers = len(set(k.split(".")[2] for k in sd if k.startswith("transformer.resblocks")))
     x = (sd["token_embedding.weight"][tokens] + sd["positional_embedding"]).astype(F32)
     causal = np.triu(np.full((S, S), -np.inf, dtype=F32), 1)[None, None]
+    zero = [int(i) + 1 for i in masking_index]
     for i in range(layers):
+        if zero and masking_block is not None and i >= masking_block:
+            x = x.copy()
+            x[:, zero] = 0
         x = resblock(x, sd, f"transformer.resblocks.{i}", heads, causal)
     x = layer_norm(x, sd["ln_final.weight"], sd["ln_final.bias"])
     eot = tokens.argmax(axis=-1)
+    if target_noun_index:
+        eot = np.full(B, int(target_noun_index) + 1)
     return (x[np.arange(B), eot] @ sd["text_projection"]).astype(F32)
 
 

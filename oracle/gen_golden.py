@@ -144,6 +144,35 @@ def gen_text(cfg_name, seed, tag):
     print(tag, y.shape)
 
 
+def gen_text_pool(cfg_name, seed, tag, masking_blocks):
+    """The two text-tower variants off the Hybridgl_main path: CLIP.encode_text(text, target_noun_index)
+    (clip/model.py:426-428: pooled at target_noun_index + 1; 0 / None fall through to the EOT) and
+    CLIPViTFM.text_masking_feature (model/backbone.py:34-56: positions masking_index + 1 zeroed before every block
+    >= masking_block)."""
+    model = build_ref_clip(cfg_name, seed)
+    bb = build_ref_backbone(cfg_name, seed)
+    cfg = weights.CLIP_CONFIGS[cfg_name]
+    rng = np.random.default_rng(17)
+    B, S, V = 5, cfg["context_length"], cfg["vocab_size"]
+    tok = np.zeros((B, S), dtype=np.int64)
+    for b in range(B):
+        n = int(rng.integers(5, min(S - 2, 12)))
+        tok[b, 0] = V - 2
+        tok[b, 1:1 + n] = rng.integers(1, V - 2, size=n)
+        tok[b, 1 + n] = V - 1
+    out = {"tokens": tok.astype(np.int32), "masking_blocks": np.array(masking_blocks, dtype=np.int64)}
+    t = torch.from_numpy(tok)
+    with torch.no_grad():
+        for k in (0, 1, 3):
+            out[f"pool_{k}"] = model.encode_text(t, target_noun_index=k).numpy().astype(np.float32)
+        for mb in masking_blocks:
+            out[f"mask_{mb}_idx12"] = bb.text_masking_feature(t, masking_index=[1, 2], masking_block=mb).numpy().astype(np.float32)
+            out[f"mask_{mb}_idx0"] = bb.text_masking_feature(t, masking_index=[0], masking_block=mb).numpy().astype(np.float32)
+        out["mask_none"] = bb.text_masking_feature(t, masking_index=[], masking_block=masking_blocks[0]).numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+    print(tag, {k: v.shape for k, v in out.items()})
+
+
 def gen_scoring():
     """utils.py functions + CLIPViTFM.calculate_score + the inline tail of Hybridgl_main.py:153-230
     driven through the reference's own helpers (relation_boxes, gen_dir_mask, Compute_IoU)."""
@@ -454,6 +483,10 @@ if __name__ == "__main__":
         gen_text("tiny", 0, "text_tiny")
     if want("text_b16"):
         gen_text("ViT-B/16", 0, "text_b16")
+    if want("text_pool_tiny"):
+        gen_text_pool("tiny", 0, "text_pool_tiny", [1, 2])
+    if want("text_pool_b16"):
+        gen_text_pool("ViT-B/16", 0, "text_pool_b16", [11, 9])
     if want("scoring"):
         gen_scoring()
     if want("resize"):

@@ -111,6 +111,30 @@ def test_encode_text_vs_reference_golden(cuda, golden_dir, tiny, b16, name, cfg)
     np.testing.assert_allclose(y, g["out"], rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("name,cfg", [("text_pool_tiny.npz", "tiny"), ("text_pool_b16.npz", "ViT-B/16")])
+def test_text_pooling_and_token_masking_vs_reference_golden(cuda, golden_dir, tiny, b16, name, cfg):
+    """CLIP.encode_text(text, target_noun_index) (clip/model.py:426-428) and CLIPViTFM.text_masking_feature
+    (model/backbone.py:34-56) on the device vs outputs of the imported reference"""
+    g = np.load(os.path.join(golden_dir, name))
+    model = tiny[1] if cfg == "tiny" else b16[1]
+    tok = torch.from_numpy(g["tokens"]).to(cuda)
+    for k in (0, 1, 3):
+        y = model.model.encode_text(tok, target_noun_index=k).cpu().numpy()
+        np.testing.assert_allclose(y, g[f"pool_{k}"], rtol=0, atol=5e-5)
+    # one index per string (the reference's truth test admits a single element only): row-wise the same
+    per_row = model.model.encode_text(tok, target_noun_index=torch.tensor([1, 3, 1, 3, 1])).cpu().numpy()
+    np.testing.assert_allclose(per_row[0::2], g["pool_1"][0::2], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(per_row[1::2], g["pool_3"][1::2], rtol=0, atol=5e-5)
+    for mb in g["masking_blocks"]:
+        for tag, idx in (("idx12", [1, 2]), ("idx0", [0])):
+            y = model.text_masking_feature(tok, masking_index=idx, masking_block=int(mb)).cpu().numpy()
+            np.testing.assert_allclose(y, g[f"mask_{int(mb)}_{tag}"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(model.text_masking_feature(tok).cpu().numpy(), g["mask_none"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(model.text_feature(tok).cpu().numpy(), g["mask_none"], rtol=0, atol=5e-5)
+    with pytest.raises(IndexError):
+        model.model.encode_text(tok, target_noun_index=model.model.context_length)
+
+
 def test_encode_text_prefix_is_exact(cuda, b16):
     """encode_text(seq_len=L): only the first L of the 77 positions are computed; under the causal mask the EOT feature
     does not depend on later positions, so the result equals the full computation when every EOT lies inside the

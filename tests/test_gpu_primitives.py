@@ -362,3 +362,62 @@ def test_errors_are_loud(cuda):
         ops.layernorm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8))  # CPU tensor
     with pytest.raises(HybridGLError):
         ops.attention(*(torch.zeros(1, 8, 24, device=cuda) for _ in range(3)), heads=1)  # hd=24
+
+
+def test_split_overflow_is_saturated_and_counted(cuda):
+    """f16x3 mode: an activation beyond the fp16 range (|x| > 65504) must never turn into inf / NaN silently: the split
+    saturates it, counts it (hgl_split_overflow_count) and the Python layer raises.  A NaN input stays a NaN."""
+    from hybridgl_amd._lib import HybridGLError
+    rng = np.random.default_rng(3)
+    M, N, K = 256, 128, 128
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    ops.split_overflow_count(reset=True)
+    y = ops.gemm_f16x3(T(a, cuda), T(w, cuda)).cpu().numpy()
+    assert ops.split_overflow_count(reset=True) == 0 and np.isfinite(y).all()
+    a2 = a.copy()
+    a2[3, 5] = 1.0e6
+    a2[7, 9] = -3.0e5
+    y2 = ops.gemm_f16x3(T(a2, cuda), T(w, cuda)).cpu().numpy()
+    assert np.isfinite(y2).all()                                  # saturated, not inf - inf
+    assert np.array_equal(y2[[0, 1, 2, 4]], y[[0, 1, 2, 4]])      # other rows untouched
+    assert ops.split_overflow_count(reset=False) == 2
+    with pytest.raises(HybridGLError, match="fp16 range"):
+        ops.check_split_overflow()
+    assert ops.split_overflow_count() == 0                        # the check resets
+    a3 = a.copy()
+    a3[2, 2] = np.nan
+    y3 = ops.gemm_f16x3(T(a3, cuda), T(w, cuda)).cpu().numpy()
+    assert np.isnan(y3[2]).all() and np.isfinite(y3[3]).all() and ops.split_overflow_count() == 0
+    # values up to the fp16 maximum are exact members of the split
+    a4 = a.copy()
+    a4[1, 1] = 65504.0
+    ops.gemm_f16x3(T(a4, cuda), T(w, cuda))
+    assert ops.split_overflow_count() == 0
+
+
+def test_models_release_their_split_weights_and_keep_their_precision(cuda):
+    """Each model carries its precision (re-asserted on entry) and its registered fp16 splits die with it."""
+    import gc
+    from hybridgl_amd import weights
+    from hybridgl_amd.backbone import CLIPViTFM
+    from oracle.cases import views_for_case
+    sd = weights.clip_state_dict("tiny", 0)
+    n0 = len(ops._split_cache)
+    m16 = CLIPViTFM("tiny", state_dict=sd, device=cuda, precision="f16x3")
+    n1 = len(ops._split_cache)
+    assert n1 > n0
+    m32 = CLIPViTFM("tiny", state_dict=sd, device=cuda, precision="f32")     # registers nothing, flips the library mode
+    assert len(ops._split_cache) == n1
+    loc, glo, masks = views_for_case(5, 64, 97, 130)
+    args = (T(loc, cuda), T(glo, cuda), T(masks, cuda))
+    y32 = m32(*args, masking_block=9, fusion_mode="G2L").cpu().numpy()
+    y16 = m16(*args, masking_block=9, fusion_mode="G2L").cpu().numpy()           # must run in ITS mode again
+    assert ops._precision_now == "f16x3"
+    y32b = m32(*args, masking_block=9, fusion_mode="G2L").cpu().numpy()
+    assert np.array_equal(y32, y32b) and np.abs(y16 - y32).max() < 1e-4
+    solo = CLIPViTFM("tiny", state_dict=sd, device=cuda, precision="f16x3")
+    assert np.array_equal(solo(*args, masking_block=9, fusion_mode="G2L").cpu().numpy(), y16)
+    del m16, solo
+    gc.collect()
+    assert len(ops._split_cache) == n0

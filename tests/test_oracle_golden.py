@@ -56,6 +56,24 @@ def test_encode_text(golden_dir, name, cfg):
     np.testing.assert_allclose(y, g["out"], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("name,cfg", [("text_pool_tiny.npz", "tiny"), ("text_pool_b16.npz", "ViT-B/16")])
+def test_encode_text_pooling_and_token_masking(golden_dir, name, cfg):
+    """CLIP.encode_text(text, target_noun_index) (clip/model.py:426-428) and CLIPViTFM.text_masking_feature
+    (model/backbone.py:34-56) of the reference vs the oracle's restatement"""
+    g = _load(golden_dir, name)
+    sd = weights.clip_state_dict(cfg, 0)
+    heads = weights.CLIP_CONFIGS[cfg]["transformer_heads"]
+    for k in (0, 1, 3):
+        y = O.encode_text(sd, g["tokens"], heads=heads, target_noun_index=k)
+        np.testing.assert_allclose(y, g[f"pool_{k}"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(g["pool_0"], O.encode_text(sd, g["tokens"], heads=heads), rtol=0, atol=2e-5)   # 0 -> EOT
+    for mb in g["masking_blocks"]:
+        for tag, idx in (("idx12", [1, 2]), ("idx0", [0])):
+            y = O.encode_text(sd, g["tokens"], heads=heads, masking_index=idx, masking_block=int(mb))
+            np.testing.assert_allclose(y, g[f"mask_{int(mb)}_{tag}"], rtol=0, atol=2e-5)
+    assert np.abs(g[f"mask_{int(g['masking_blocks'][0])}_idx12"] - g["mask_none"]).max() > 1e-3    # the masking does something
+
+
 @pytest.mark.parametrize("i", range(len(RESIZE_CASES)))
 def test_bilinear_resize(golden_dir, i):
     g = _load(golden_dir, "resize.npz")
