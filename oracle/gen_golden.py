@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from hybridgl_amd import weights  # noqa: E402
 from hybridgl_amd.synth import synth_masks, synth_image  # noqa: E402
-from oracle.cases import views_for_case, resize_case, RESIZE_CASES, tail_case  # noqa: E402
+from oracle.cases import edge_masks, views_for_case, resize_case, RESIZE_CASES, tail_case  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -261,6 +261,112 @@ def gen_scoring():
     np.savez_compressed(os.path.join(GOLD, "scoring.npz"), **out)
 
 
+def ref_tail(bb, utils, hybrid, t_pos, t_neg, masks, boxes, attn, gt, rela, dirflag, has_other, k1=3, k2=6):
+    """One sentence of the tail of Hybridgl_main.py:153-230, glue restated, every helper the reference's own
+    (calculate_score, relation_boxes, gen_dir_mask, Compute_IoU).  Returns (idx_pure, idx_final, (I, U), k1, k2) with the
+    k1 / k2 the reference would carry on to the next sentence (:178-181)."""
+    softmax0 = torch.nn.Softmax(0)
+    H, W = masks.shape[1:]
+    with torch.no_grad():
+        vf = torch.from_numpy(hybrid)
+        score_clip = bb.calculate_score(vf, torch.from_numpy(t_pos))
+        score_neg = bb.calculate_score(vf, torch.from_numpy(t_neg))
+        idx_pure = int(torch.argmax(score_clip))
+        score_clip, score_neg = softmax0(score_clip), softmax0(score_neg)
+        if k1 > len(score_clip):
+            k1 = len(score_clip)
+        if k2 > len(score_neg):
+            k2 = len(score_neg)
+        _, maxidxs = torch.topk(score_clip.view(-1), k=k1)
+        _, maxneg = torch.topk(score_neg.view(-1), k=k2)
+        bx = torch.from_numpy(boxes)
+        topscores = np.zeros(k1)
+        for i in range(k1):
+            for j in (maxidxs if not has_other else maxneg):
+                sj = score_clip[j][0] if not has_other else score_neg[j][0]
+                topscores[i] = topscores[i] + utils.relation_boxes(bx[maxidxs[i]], bx[j], score_clip[maxidxs[i]][0], sj, rela)
+        topscores = softmax0(torch.Tensor(topscores))
+        a = torch.from_numpy(attn)
+        a = (a - a.min()) / (a.max() - a.min())
+        a = a * utils.gen_dir_mask(dirflag, H, W, None)
+        a = a / a.mean()
+        black = 1.95 if rela == "big" else (1.5 if rela == "small" else 1.8)
+        gem = []
+        for pm_ in torch.from_numpy(masks):
+            pm_ = pm_.type(torch.uint8)
+            gem.append(float((a * (2 - black) * pm_ / (pm_.sum())).sum() - (a * black * (1 - pm_) / ((1 - pm_).sum())).sum()))
+        gem = np.array(gem, dtype=np.float32)
+        for i in range(k1):
+            topscores[i] = topscores[i] * (1 - 0.6) + 0.6 * float(gem[maxidxs[i]])
+        idx_final = int(maxidxs[torch.argmax(topscores)])
+        _, _, cI, cU = utils.Compute_IoU(torch.from_numpy(masks[idx_final]), torch.from_numpy(gt[None].astype(np.uint8)), 0, 0, [])
+    return idx_pure, idx_final, (int(cI), int(cU)), k1, k2, gem
+
+
+def gen_scoring_small():
+    """Tail goldens with FEWER proposals than k1 = 3 / k2 = 6 (Hybridgl_main.py:178-181: the clamp, which the reference
+    never undoes): a sequence of refs with N = 12, 5, 12, 2, 12 proposals run with the k1 / k2 carried from ref to ref,
+    exactly as the reference's loop does."""
+    sys.path.insert(0, REF)
+    utils = _load("ref_utils", os.path.join(REF, "utils.py"))
+    bb = build_ref_backbone("tiny", 0)
+    out = {}
+    plan = [(0, 12, "none", "none", False), (1, 5, "left", "left", True), (2, 12, "big", "middle", True),
+            (3, 2, "within", "right", True), (4, 12, "small", "none", False), (5, 2, "none", "left", False)]
+    k1, k2 = 3, 6
+    for step, (ci, N, rela, dirflag, has_other) in enumerate(plan):
+        hybrid, t_pos, t_neg, masks, boxes, attn, gt = tail_case(ci, N, 32, 96, 128)
+        ip, ifin, iu, k1, k2, gem = ref_tail(bb, utils, hybrid, t_pos, t_neg, masks, boxes, attn, gt, rela, dirflag, has_other, k1, k2)
+        out[f"s{step}_idx"] = np.array([ip, ifin], dtype=np.int64)
+        out[f"s{step}_IU"] = np.array(iu, dtype=np.int64)
+        out[f"s{step}_k"] = np.array([k1, k2], dtype=np.int64)
+        out[f"s{step}_gem"] = gem
+        print("small tail", step, N, rela, dirflag, has_other, ip, ifin, k1, k2)
+    out["plan"] = np.array([f"{ci},{N},{rela},{dirflag},{int(h)}" for ci, N, rela, dirflag, h in plan])
+    np.savez_compressed(os.path.join(GOLD, "scoring_small.npz"), **out)
+
+
+def gen_views():
+    """Hybridgl_main.py:93-125 (the per-mask local / global view loop) with everything that CAN be pinned offline pinned:
+    the loop's statements are kept one for one; cv2.bitwise_and / cv2.add are their documented uint8 semantics in numpy
+    (masked copy, saturating add); T.ToTensor / T.Resize(antialias=None) / T.Normalize are torch arithmetic
+    (torchvision 0.15 tensor path = F.interpolate bilinear, align_corners=False, no antialias).  Only the Gaussian blur
+    itself is an INPUT here (cv2 is absent; its restatement is pinned separately as integer arithmetic, oracle/cv_oracle.py)."""
+    from hybridgl_amd import synth
+    from oracle import cv_oracle as CV
+    out = {}
+    for tag, (H, W, N, res) in {"a": (97, 130, 4, 64), "b": (120, 88, 3, 56)}.items():
+        img = synth.synth_image(H, W, 900 + N)
+        masks_np = edge_masks(N, H, W, 910 + N)
+        blurred = CV.gaussian_blur_u8(img, 15)
+        imagesrc = torch.from_numpy(img)[None]
+        original_img = torch.from_numpy(synth.imagenet_normalize(img))[None]       # image['image'] (dataset_refer_bert.py:155)
+        masks = torch.from_numpy(masks_np)
+        pixel_mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).reshape(1, 3, 1, 1)
+        to_tensor = lambda a: torch.from_numpy(a).permute(2, 0, 1).float().div(255)
+        resize = lambda x: F.interpolate(x[None] if x.dim() == 3 else x, size=(res, res), mode="bilinear", align_corners=False)[0]
+        normalize = lambda x: (x - torch.tensor([0.485, 0.456, 0.406])[:, None, None]) / torch.tensor([0.229, 0.224, 0.225])[:, None, None]
+        global_imgs, local_imgs = [], []
+        for pred_mask in masks:
+            pred_mask = pred_mask.type(torch.uint8)
+            global_img = imagesrc[0].numpy()
+            mask = pred_mask.cpu().numpy()
+            sharp_region = np.where(np.clip(mask, 0, 255).astype(np.uint8)[:, :, None] != 0, global_img, 0).astype(np.uint8)  # cv2.bitwise_and(img, img, mask=)
+            inv_mask = 1 - mask
+            blurred_region = (blurred * inv_mask[:, :, None]).astype(np.uint8)
+            global_img = np.clip(sharp_region.astype(np.int32) + blurred_region.astype(np.int32), 0, 255).astype(np.uint8)  # cv2.add (saturating)
+            global_img = normalize(resize(to_tensor(global_img)))
+            global_imgs.append(global_img)
+            masked_image = original_img * pred_mask[None, None, ...] + (1 - pred_mask[None, None, ...]) * pixel_mean
+            masked_image = resize(masked_image.squeeze(0))
+            local_imgs.append(masked_image.squeeze(0))
+        out[f"{tag}_meta"] = np.array([H, W, N, res, 900 + N, 910 + N], dtype=np.int64)
+        out[f"{tag}_global"] = torch.stack(global_imgs).numpy().astype(np.float32)
+        out[f"{tag}_local"] = torch.stack(local_imgs).numpy().astype(np.float32)
+        print("views", tag, out[f"{tag}_global"].shape)
+    np.savez_compressed(os.path.join(GOLD, "views.npz"), **out)
+
+
 def gen_resize():
     """bilinear no-antialias resize vs the real torch F.interpolate (mask down-sample and 224 views).
     Inputs are regenerated from the seed by the tests (oracle/cases.py:resize_case)."""
@@ -483,6 +589,10 @@ if __name__ == "__main__":
         gen_text("tiny", 0, "text_tiny")
     if want("text_b16"):
         gen_text("ViT-B/16", 0, "text_b16")
+    if want("views"):
+        gen_views()
+    if want("scoring_small"):
+        gen_scoring_small()
     if want("text_pool_tiny"):
         gen_text_pool("tiny", 0, "text_pool_tiny", [1, 2])
     if want("text_pool_b16"):

@@ -68,6 +68,28 @@ def test_k_clamp_with_few_proposals(cuda, k_clamp):
         assert [int(v) for v in last[0].cpu()] == list(want[-1])
 
 
+def test_persistent_clamp_sequence_vs_reference_golden(cuda, golden_dir):
+    """tests/golden/scoring_small.npz: the reference's own tail run over refs with 12, 5, 12, 2, 12, 2 proposals with the
+    k1 / k2 it carries from ref to ref.  The pipeline's scoring stage (k_clamp="persistent") must pick the same masks,
+    count the same I / U and end every ref with the same k1 / k2."""
+    from hybridgl_amd.pipeline import RefBatch, Sentence
+    g = np.load(os.path.join(golden_dir, "scoring_small.npz"))
+    from oracle.cases import tail_case
+    pipe = _tiny(cuda, k_clamp="persistent")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    for step, rec in enumerate(g["plan"]):
+        ci, N, rela, dirflag, has_other = str(rec).split(",")
+        ci, N, has_other = int(ci), int(N), bool(int(has_other))
+        hybrid, t_pos, t_neg, masks, boxes, attn, gt = tail_case(ci, N, 32, 96, 128)
+        text = t(np.concatenate([t_pos, t_pos, t_neg], axis=0))       # sentence == noun phrase makes the r-ensemble exact
+        sent = Sentence(0, 1, [2], dirflag, rela, 1 if has_other else 0, t(attn))
+        ref = RefBatch(None, None, None, t(masks), t(boxes), None, t(gt), [sent], index=step)
+        idx = pipe._score_ref(ref, t(hybrid), text, None)[0]
+        assert [int(v) for v in idx.cpu()] == [int(v) for v in g[f"s{step}_idx"]], step
+        assert [pipe.k1, pipe.k2] == [int(v) for v in g[f"s{step}_k"]], step
+        assert [int(v) for v in pipe.partial_rows()[-1][4:6]] == [int(v) for v in g[f"s{step}_IU"]], step
+
+
 def test_clamp_is_per_rank_under_sharding(cuda):
     """Documented deviation: with k_clamp="persistent" the quirk acts on the items of ONE process in its
     own order.  Two 'ranks' that split [12, 2, 12, 12] proposals as (0, 2) / (1, 3) clamp only rank 1's later item; the

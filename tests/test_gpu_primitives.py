@@ -354,6 +354,23 @@ def test_synthesize_views(cuda):
         np.testing.assert_allclose(glo.cpu().numpy(), rg, rtol=0, atol=5e-6)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_synthesize_views_vs_reference_loop_golden(cuda, golden_dir, tag):
+    """device view synthesis (with the device's own fixed-point blur in front) vs tests/golden/views.npz, the loop of
+    Hybridgl_main.py:93-125 with its torch arithmetic pinned (ragged masks: single pixel, full, thin line, empty)"""
+    import os
+    from hybridgl_amd.synth import imagenet_normalize, synth_image
+    from oracle.cases import edge_masks
+    g = np.load(os.path.join(golden_dir, "views.npz"))
+    H, W, N, res, s_img, s_mask = (int(v) for v in g[f"{tag}_meta"])
+    img = synth_image(H, W, s_img)
+    masks = edge_masks(N, H, W, s_mask)
+    blur = ops.gaussian_blur_u8(T(img, cuda), 15)
+    loc, glo = ops.synthesize_views(T(img, cuda), blur, T(imagenet_normalize(img), cuda), T(masks, cuda), res)
+    np.testing.assert_allclose(glo.cpu().numpy(), g[f"{tag}_global"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(loc.cpu().numpy(), g[f"{tag}_local"], rtol=0, atol=2e-6)
+
+
 def test_errors_are_loud(cuda):
     from hybridgl_amd._lib import HybridGLError
     with pytest.raises(HybridGLError):

@@ -138,3 +138,39 @@ def test_scoring_tail(golden_dir, ci):
     np.testing.assert_allclose(sn, g[f"tail{ci}_sn"], rtol=0, atol=2e-5)
     assert [ip, ifin] == [int(v) for v in g[f"tail{ci}_idx"]]
     assert O.compute_iou(masks[ifin], gt) == tuple(int(v) for v in g[f"tail{ci}_IU"])
+
+
+def test_scoring_tail_with_fewer_proposals_than_k(golden_dir):
+    """refs with 5 and 2 proposals clamp k2 / k1 (Hybridgl_main.py:178-181) and the clamp persists to the later refs:
+    the reference's winners for the whole sequence vs the oracle run with the carried k1 / k2"""
+    g = _load(golden_dir, "scoring_small.npz")
+    k1, k2 = 3, 6
+    for step, rec in enumerate(g["plan"]):
+        ci, N, rela, dirflag, has_other = str(rec).split(",")
+        ci, N, has_other = int(ci), int(N), bool(int(has_other))
+        hybrid, t_pos, t_neg, masks, boxes, attn, gt = tail_case(ci, N, 32, 96, 128)
+        black = 1.95 if rela == "big" else (1.5 if rela == "small" else 1.8)
+        gem = O.coherence_scores(attn, masks, dirflag, black)
+        np.testing.assert_allclose(gem, g[f"s{step}_gem"], rtol=2e-5, atol=2e-5)
+        k1, k2 = min(k1, N), min(k2, N)
+        assert [k1, k2] == [int(v) for v in g[f"s{step}_k"]]
+        ip, ifin, _, _ = O.score_sentence(hybrid, t_pos, t_neg, boxes, gem, float(_load(golden_dir, "scoring.npz")["cs_logit_scale"]),
+                                          k1, k2, 0.6, rela, has_other)
+        assert [ip, ifin] == [int(v) for v in g[f"s{step}_idx"]], step
+        assert O.compute_iou(masks[ifin], gt) == tuple(int(v) for v in g[f"s{step}_IU"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_view_synthesis_vs_reference_loop(golden_dir, tag):
+    """tests/golden/views.npz = the loop of Hybridgl_main.py:93-125 with its torch arithmetic (ToTensor / Resize / Normalize)
+    and the uint8 compositing pinned; the blurred image is an input (ragged masks: single pixel, full, thin, empty)."""
+    from hybridgl_amd import synth
+    from oracle import cv_oracle as CV
+    from oracle.cases import edge_masks
+    g = _load(golden_dir, "views.npz")
+    H, W, N, res, s_img, s_mask = (int(v) for v in g[f"{tag}_meta"])
+    img = synth.synth_image(H, W, s_img)
+    masks = edge_masks(N, H, W, s_mask)
+    loc, glo = O.synthesize_views(img, CV.gaussian_blur_u8(img, 15), synth.imagenet_normalize(img), masks, res)
+    np.testing.assert_allclose(glo, g[f"{tag}_global"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(loc, g[f"{tag}_local"], rtol=0, atol=2e-6)
