@@ -6,11 +6,12 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import torch
 
 from hybridgl_amd import ops, weights
-from hybridgl_amd.stress import stress_clip_state_dict, stress_sam_state_dict
+from stress_weights import stress_clip_state_dict, stress_sam_state_dict
 
 dev = torch.device("cuda:0")
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)

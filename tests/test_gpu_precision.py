@@ -1,9 +1,9 @@
 """Precision of the split-fp16 (f16x3) path where seeded Gaussian weights do not reach: the FULL 32-block ViT-H
-encoder at 1024 x 1024, and weights rescaled to trained-checkpoint statistics (hybridgl_amd/stress.py: LayerNorm gains up
+encoder at 1024 x 1024, and weights rescaled to trained-checkpoint statistics (tests/stress_weights.py: LayerNorm gains up
 to 10, massive residual channels x300, MLP pre-activations of several tens).  The yardstick is the numpy fp32 oracle;
 the library's exact-fp32 MFMA mode is run beside it to show what fp32 arithmetic in a different summation order costs.
 
-Measured (tools/precision_probe.py, MI355X): ViT-H x32 blocks max|err| 1.0e-5 (f16x3) / 1.4e-5 (f32 mode) on O(1)
+Measured (tests/precision_probe.py, MI355X): ViT-H x32 blocks max|err| 1.0e-5 (f16x3) / 1.4e-5 (f32 mode) on O(1)
 embeddings; stressed CLIP ViT-B/16 logits 4.2e-4..6.6e-4 (f16x3) / 4.6e-4..5.1e-4 (f32 mode); stressed ViT-H x2
 3.0e-4 / 2.3e-4; no value leaves the fp16 range."""
 import numpy as np
@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from hybridgl_amd import ops, weights
-from hybridgl_amd.stress import stress_clip_state_dict, stress_sam_state_dict
+from stress_weights import stress_clip_state_dict, stress_sam_state_dict
 
 pytestmark = pytest.mark.gpu
 

@@ -408,3 +408,17 @@ def test_encoder_batch_of_two_equals_single_images(cuda):
         np.testing.assert_allclose(m.encode_batch([b])[0].cpu().numpy(), eb.cpu().numpy(), rtol=0, atol=0)
         del m
         torch.cuda.empty_cache()
+
+
+def test_encoder_batch_of_eight_equals_single_images(cuda):
+    """the benchmark's encoder pass: EIGHT images stacked along the token rows (M = 8 x 4096 at the ViT-H width, two
+    blocks: one windowed, one global) == eight single-image passes, image by image"""
+    from hybridgl_amd.synth import synth_image
+    cfg = weights.SAM_CONFIGS["vit_h_d2"]
+    m = hsam.Sam(weights.sam_state_dict("vit_h_d2", 0), cfg, cuda)
+    imgs = [T(synth_image(1024 if i % 3 else 683, 1024, 20 + i), cuda) for i in range(8)]
+    both = m.encode_batch(imgs)
+    assert both.shape == (8, 4096, 256) and torch.isfinite(both).all()
+    for i in (0, 3, 7):
+        np.testing.assert_allclose(both[i].cpu().numpy(), m.encode(imgs[i]).cpu().numpy(), rtol=0, atol=2e-4)
+    assert torch.equal(both, m.encode_batch(imgs))          # run-to-run bit reproducible
