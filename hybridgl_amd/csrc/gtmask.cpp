@@ -126,6 +126,8 @@ int hgl_gt_mask_from_polygons(const double* xy, const int32_t* n_points, int n_p
   for (int i = 0; i < n_polys; ++i) {
     const int k = n_points[i];
     HGL_REQUIRE(k >= 1, "gt_mask_from_polygons: polygon %d has %d points", i, k);
+    for (int j = 0; j < 2 * k; ++j)      // the boundary walk is 5 steps per pixel: keep it finite and the int casts defined
+      HGL_REQUIRE(p[j] == p[j] && p[j] > -1.0e5 && p[j] < 1.0e5, "gt_mask_from_polygons: coordinate %d of polygon %d out of range", j, i);
     pos.clear();
     polygon_crossings(p, k, H, W, pos);
     total += fill_toggles(pos, H, W, mask);
@@ -147,23 +149,28 @@ int hgl_gt_mask_from_rle_string(const char* s, int H, int W, uint8_t* mask, int6
   HGL_REQUIRE(s && mask && H > 0 && W > 0, "gt_mask_from_rle_string: bad arguments");
   // LEB128-like, 5 payload bits + continuation bit per character (offset 48), every count after the third stored
   // as a difference to the count two places earlier (maskApi.c:217-230)
+  // The string comes from an annotation file: every shift below is on unsigned 64-bit values with a bounded count
+  // (a count takes at most 7 characters = 35 bits; maskApi.c itself shifts 32-bit ints, so longer groups never occur in
+  // valid data), a group cut off by the end of the string or longer than that is an error, never undefined behaviour.
   std::vector<unsigned> cnts;
   size_t p = 0;
   while (s[p]) {
-    long x = 0;
+    unsigned long long ux = 0;
     int k = 0;
     bool more = true;
     while (more) {
       HGL_REQUIRE(s[p] != 0, "gt_mask_from_rle_string: truncated string");
-      const char c = (char)(s[p] - 48);
-      x |= (long)(c & 0x1f) << (5 * k);
-      more = (c & 0x20) != 0;
+      HGL_REQUIRE(k < 7, "gt_mask_from_rle_string: malformed count (more than 7 characters)");
+      const unsigned c = (unsigned)(unsigned char)(s[p] - 48);
+      ux |= (unsigned long long)(c & 0x1fu) << (5 * k);
+      more = (c & 0x20u) != 0;
       ++p;
       ++k;
-      if (!more && (c & 0x10)) x |= -1L << (5 * k);
+      if (!more && (c & 0x10u)) ux |= ~0ULL << (5 * k);      // sign extension (maskApi.c: x |= -1 << 5*k)
     }
-    if (cnts.size() > 2) x += (long)cnts[cnts.size() - 2];
-    cnts.push_back((unsigned)x);
+    long long x = (long long)ux;
+    if (cnts.size() > 2) x += (long long)cnts[cnts.size() - 2];
+    cnts.push_back((unsigned)(unsigned long long)x);
   }
   std::fill(mask, mask + (size_t)H * W, (uint8_t)0);
   const long long a = fill_counts(cnts.data(), (long long)cnts.size(), H, W, mask);
