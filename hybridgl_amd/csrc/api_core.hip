@@ -86,13 +86,12 @@ int hgl_prof_read(int cls, long long* launches, double* ms, double* flops, doubl
   return HGL_OK;
 }
 
-// Number of fp32 values beyond the fp16 range that the split-fp16 (f16x3) path has saturated since the last reset,
-// summed over the library's kernels.  Blocking device reads: synchronise the streams that ran the work first.
+// Number of GPU threads of the split-fp16 (f16x3) path that met a value beyond the fp16 range since the last reset
+// (GEMM split epilogues / operand splits, attention staging).  Blocking device reads: synchronise the streams that ran the work first.
 int hgl_split_overflow_count(int reset, unsigned long long* count) {
   HGL_TRY(hgl_require_device());
   HGL_REQUIRE(count != nullptr, "split_overflow_count: null argument");
-  *count = hgl_split_overflow_gemm(reset) + hgl_split_overflow_attention(reset) + hgl_split_overflow_clip_glue(reset) +
-           hgl_split_overflow_gem(reset) + hgl_split_overflow_sam_glue(reset);
+  *count = hgl_split_overflow_gemm(reset) + hgl_split_overflow_attention(reset);
   return HGL_OK;
 }
 

@@ -247,11 +247,11 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(AttnArgs a) {
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void split4(const f32x4 v, h16x4& hi, h16x4& lo) {
+__device__ __forceinline__ void split4(const f32x4 v, h16x4& hi, h16x4& lo, float& amax) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     _Float16 a, c;
-    hgl_split_hi_lo(v[e], a, c);
+    hgl_split_hi_lo(v[e], a, c, amax);
     hi[e] = a;
     lo[e] = c;
   }
@@ -324,6 +324,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
   // against 33 MFMAs per key tile).
   constexpr float LOG2E = 1.4426950408889634f;
   const float qscale = a.scale;
+  float amax = 0.f;   // of the Q / K / V values this thread splits (fp16 range guard, hgl_common.h)
   h16x8 qh[KS], ql[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
       for (int e = 0; e < 4; ++e) {
         const float x = v[e] * qscale;
         _Float16 hi, lo;
-        hgl_split_hi_lo(x, hi, lo);
+        hgl_split_hi_lo(x, hi, lo, amax);
         qh[s][4 * half + e] = hi;
         ql[s][4 * half + e] = lo;
       }
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
       if (!EXACT && idx >= KV_CHUNK * F4) break;
       const int row = idx / F4, c4 = idx - row * F4;
       h16x4 hi, lo;
-      split4(pk[i], hi, lo);
+      split4(pk[i], hi, lo, amax);
       *(h16x4*)(Ks + row * KROW + c4 * 4) = hi;
       *(h16x4*)(Ks + row * KROW + HD + c4 * 4) = lo;
     }
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
       if (!EXACT && idx >= KV_CHUNK * F4) break;
       const int row = idx / F4, c4 = idx - row * F4;
       h16x4 hi, lo;
-      split4(pv[i], hi, lo);
+      split4(pv[i], hi, lo, amax);
       *(h16x4*)(Vh + row * VP + c4 * 4) = hi;
       *(h16x4*)(Vl + row * VP + c4 * 4) = lo;
     }
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
     }
   }
 
+  hgl_split_commit(amax);
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   if (qvalid) {

@@ -379,5 +379,3 @@ int hgl_launch_gather_eot(const float* x, const int32_t* eot, int B, int S, int 
   hipLaunchKernelGGL(gather_eot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, eot, B, S, D, y);
   return hgl_check_launch("gather_eot");
 }
-
-HGL_DEFINE_SPLIT_OVERFLOW_READER(hgl_split_overflow_clip_glue)

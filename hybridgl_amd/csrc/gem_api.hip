@@ -444,5 +444,3 @@ int hgl_resize_bilinear_aa(const float* in, int C, int h, int w, float* out, int
 }
 
 }  // extern "C"
-
-HGL_DEFINE_SPLIT_OVERFLOW_READER(hgl_split_overflow_gem)

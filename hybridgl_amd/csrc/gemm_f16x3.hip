@@ -119,7 +119,7 @@ __device__ __forceinline__ float act_apply(float x) {
 // col .. col+3.  vec: 16-byte accesses (g.vec4); otherwise element by element with bounds checks.
 template <int ACT>
 __device__ __forceinline__ void x3_store_block(const Args& g, const f32x4 acc, int row, int crow, long long rrow, int col,
-                                               bool inside) {
+                                               bool inside, float& amax) {
   if (g.vec4) {
     if (!(inside || (row < g.M && col < g.N))) return;
     const f32x4 bv = g.bias ? *(const f32x4*)(g.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -135,7 +135,7 @@ __device__ __forceinline__ void x3_store_block(const Args& g, const f32x4 acc, i
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         _Float16 hh, ll;
-        hgl_split_hi_lo(o[e], hh, ll);
+        hgl_split_hi_lo(o[e], hh, ll, amax);
         hi4[e] = hh;
         lo4[e] = ll;
       }
@@ -156,7 +156,7 @@ __device__ __forceinline__ void x3_store_block(const Args& g, const f32x4 acc, i
           g.C[off] = v;
         } else {
           _Float16 hh, ll;
-          hgl_split_hi_lo(v, hh, ll);
+          hgl_split_hi_lo(v, hh, ll, amax);
           g.Ch[off] = hh;
           g.Cl[off] = ll;
         }
@@ -272,6 +272,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
 
   // ---- write-out ----
   const bool full_tile = (row0 + BM <= g.M) && (col0 + BN <= g.N);
+  float amax = 0.f;   // of the values split in the write-out
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = row0 + wm * 64 + i * 16 + r;
@@ -279,8 +280,9 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
     const int crow = g.cmap ? g.cmap[rc] : rc;
     const long long rrow = g.rmod > 0 ? crow % g.rmod : crow;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x3_store_block<ACT>(g, acc[i][j], row, crow, rrow, col0 + wn * 64 + j * 16 + 4 * h, full_tile);
+    for (int j = 0; j < 4; ++j) x3_store_block<ACT>(g, acc[i][j], row, crow, rrow, col0 + wn * 64 + j * 16 + 4 * h, full_tile, amax);
   }
+  hgl_split_commit(amax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -511,6 +513,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
   const std::true_type yes;
   const std::false_type no;
 
+  float amax = 0.f;   // of the values split in the write-outs
   issue_prologue(cur);
   for (;;) {
 #pragma unroll
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   _Float16 hh, ll;
-                  hgl_split_hi_lo(o[e], hh, ll);
+                  hgl_split_hi_lo(o[e], hh, ll, amax);
                   hi4[e] = hh;
                   lo4[e] = ll;
                 }
@@ -605,6 +608,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
     }
     if (!more) break;
   }
+  hgl_split_commit(amax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -635,13 +639,14 @@ __global__ __launch_bounds__(256) void gemm_x3_skinny_kernel(SkinnyArgs g) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   const int nks = g.K >> 4;
+  float amax = 0.f;
   auto step = [&](const f32x4 a0, const f32x4 a1, const f16x8 wh, const f16x8 wl) {
     f16x8 ah, al;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       _Float16 h0, l0, h1, l1;
-      hgl_split_hi_lo(a0[e], h0, l0);
-      hgl_split_hi_lo(a1[e], h1, l1);
+      hgl_split_hi_lo(a0[e], h0, l0, amax);
+      hgl_split_hi_lo(a1[e], h1, l1, amax);
       ah[e] = h0; ah[4 + e] = h1;
       al[e] = l0; al[4 + e] = l1;
     }
@@ -666,6 +671,7 @@ __global__ __launch_bounds__(256) void gemm_x3_skinny_kernel(SkinnyArgs g) {
     const int k = 16 * ks;
     step(*(const f32x4*)(ap + k), *(const f32x4*)(ap + k + 4), *(const f16x8*)(whp + k), *(const f16x8*)(wlp + k));
   }
+  hgl_split_commit(amax);
   if (wave > 0) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[wave - 1][e][lane] = acc[e];
@@ -718,19 +724,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, float scale,
                                                         _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                         long long n4) {
+  float amax = 0.f;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const f32x4 v = ((const f32x4*)x)[i];
     f16x4 a, b;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       _Float16 h0, l0;
-      hgl_split_hi_lo(v[e] * scale, h0, l0);
+      hgl_split_hi_lo(v[e] * scale, h0, l0, amax);
       a[e] = h0;
       b[e] = l0;
     }
     ((f16x4*)hi)[i] = a;
     ((f16x4*)lo)[i] = b;
   }
+  hgl_split_commit(amax);
 }
 
 __device__ __forceinline__ float wsum(float v) {

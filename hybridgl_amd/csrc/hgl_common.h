@@ -15,22 +15,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ties the stored hi and the hi subtracted for lo are different fp16 neighbours and hi + lo misses x by 2*|lo|
 // (measured: 0.1 % of attention rows off by up to 8e-5 relative).  The empty asm makes x opaque.
 //
-// Range: |x| > 65504 does not fit fp16 (hi would be inf, lo = x - inf = -inf and the MFMA sum NaN).  Such a value is
-// SATURATED to +-65504 and COUNTED in a per-translation-unit device counter that hgl_split_overflow_count() sums:
-// the result is then wrong but finite, and the host is told (hybridgl_amd raises and points at HYBRIDGL_PRECISION=f32).
-// Weights are pre-scaled by a power of two and cannot overflow; activations of the trained CLIP / SAM models stay two
-// to three orders of magnitude below the limit.  A NaN stays a NaN.
+// Range: |x| > 65504 does not fit fp16 (hi = inf, lo = x - inf = -inf, and the MFMA sum is NaN).  The splits of values
+// that are not bounded by construction -- GEMM outputs (epilogues with a split output, the attention's Q / K / V staging,
+// the skinny kernel's A operand, the generic split kernel) -- go through the 4-argument form, which also folds |x| into a
+// per-thread running maximum (one v_max per element, no branch); hgl_split_commit() at the end of the thread counts the
+// thread in a per-translation-unit device counter when that maximum left the range.  hgl_split_overflow_count() sums the
+// counters: the run then contains inf / NaN AND the host is told (hybridgl_amd raises and points at HYBRIDGL_PRECISION=f32)
+// -- never silently.  LayerNorm outputs (|y| <= sqrt(D) |w| + |b|), normalised pixels, probabilities and convex
+// combinations of already-checked values use the 3-argument form.  Weights are pre-scaled by a power of two and cannot
+// overflow; activations of the trained CLIP / SAM models stay two to three orders of magnitude below the limit.
 static __device__ __attribute__((unused)) unsigned int hgl_tu_split_overflow;
 __device__ __forceinline__ void hgl_split_hi_lo(float x, _Float16& hi, _Float16& lo) {
   asm volatile("" : "+v"(x));
-  if (__builtin_expect(fabsf(x) > 65504.0f, 0)) {
-    atomicAdd(&hgl_tu_split_overflow, 1u);
-    x = copysignf(65504.0f, x);
-  }
   hi = (_Float16)x;
   lo = (_Float16)(x - (float)hi);
 }
-// host-side reader of this translation unit's counter (define once in every .hip that splits)
+__device__ __forceinline__ void hgl_split_hi_lo(float x, _Float16& hi, _Float16& lo, float& amax) {
+  asm volatile("" : "+v"(x));
+  amax = fmaxf(amax, fabsf(x));      // a NaN is ignored here (maxNum) and stays a NaN in hi / lo
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
+__device__ __forceinline__ void hgl_split_commit(float amax) {
+  if (__builtin_expect(amax > 65504.0f, 0)) atomicAdd(&hgl_tu_split_overflow, 1u);
+}
+// host-side reader of this translation unit's counter (define once in every .hip that commits)
 #define HGL_DEFINE_SPLIT_OVERFLOW_READER(name)                                                        \
   unsigned long long name(int reset) {                                                                \
     unsigned int v = 0;                                                                               \
@@ -44,9 +53,6 @@ __device__ __forceinline__ void hgl_split_hi_lo(float x, _Float16& hi, _Float16&
 #endif
 unsigned long long hgl_split_overflow_gemm(int reset);
 unsigned long long hgl_split_overflow_attention(int reset);
-unsigned long long hgl_split_overflow_clip_glue(int reset);
-unsigned long long hgl_split_overflow_gem(int reset);
-unsigned long long hgl_split_overflow_sam_glue(int reset);
 
 void hgl_set_error(const char* fmt, ...);
 int hgl_check_launch(const char* what);  // hipGetLastError -> HGL_ELAUNCH

@@ -1069,5 +1069,3 @@ int hgl_gather_masks(const uint8_t* masks, const int32_t* idx, const int32_t* n,
 }
 
 }  // extern "C"
-
-HGL_DEFINE_SPLIT_OVERFLOW_READER(hgl_split_overflow_sam_glue)

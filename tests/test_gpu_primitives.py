@@ -381,9 +381,10 @@ def test_errors_are_loud(cuda):
         ops.attention(*(torch.zeros(1, 8, 24, device=cuda) for _ in range(3)), heads=1)  # hd=24
 
 
-def test_split_overflow_is_saturated_and_counted(cuda):
-    """f16x3 mode: an activation beyond the fp16 range (|x| > 65504) must never turn into inf / NaN silently: the split
-    saturates it, counts it (hgl_split_overflow_count) and the Python layer raises.  A NaN input stays a NaN."""
+def test_split_overflow_is_counted_and_raised(cuda):
+    """f16x3 mode: an activation beyond the fp16 range (|x| > 65504) cannot be split; the kernels fold |x| into a
+    per-thread running maximum and count the thread (hgl_split_overflow_count), the Python layer raises -- inf / NaN
+    never leaves the library silently.  A NaN input stays a NaN and is not an overflow."""
     from hybridgl_amd._lib import HybridGLError
     rng = np.random.default_rng(3)
     M, N, K = 256, 128, 128
@@ -396,9 +397,9 @@ def test_split_overflow_is_saturated_and_counted(cuda):
     a2[3, 5] = 1.0e6
     a2[7, 9] = -3.0e5
     y2 = ops.gemm_f16x3(T(a2, cuda), T(w, cuda)).cpu().numpy()
-    assert np.isfinite(y2).all()                                  # saturated, not inf - inf
-    assert np.array_equal(y2[[0, 1, 2, 4]], y[[0, 1, 2, 4]])      # other rows untouched
-    assert ops.split_overflow_count(reset=False) == 2
+    assert not np.isfinite(y2[[3, 7]]).any()                      # inf - inf inside the split: the rows are lost ...
+    assert np.array_equal(y2[[0, 1, 2, 4]], y[[0, 1, 2, 4]])      # ... the other rows untouched ...
+    assert ops.split_overflow_count(reset=False) == 2             # ... and the two offending threads are counted
     with pytest.raises(HybridGLError, match="fp16 range"):
         ops.check_split_overflow()
     assert ops.split_overflow_count() == 0                        # the check resets
@@ -406,11 +407,13 @@ def test_split_overflow_is_saturated_and_counted(cuda):
     a3[2, 2] = np.nan
     y3 = ops.gemm_f16x3(T(a3, cuda), T(w, cuda)).cpu().numpy()
     assert np.isnan(y3[2]).all() and np.isfinite(y3[3]).all() and ops.split_overflow_count() == 0
-    # values up to the fp16 maximum are exact members of the split
     a4 = a.copy()
-    a4[1, 1] = 65504.0
-    ops.gemm_f16x3(T(a4, cuda), T(w, cuda))
+    a4[1, 1] = 65504.0                                            # the fp16 maximum itself is a member of the split
+    assert np.isfinite(ops.gemm_f16x3(T(a4, cuda), T(w, cuda)).cpu().numpy()).all()
     assert ops.split_overflow_count() == 0
+    q = torch.randn(1, 64, 64, device=cuda) * 1.0e5                # the attention's Q / K / V staging sees GEMM outputs: counted too
+    ops.attention(q, q, q, 1)
+    assert ops.split_overflow_count() > 0
 
 
 def test_models_release_their_split_weights_and_keep_their_precision(cuda):
