@@ -510,22 +510,37 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
   using I6 = std::integral_constant<int, 6>;
   using I8 = std::integral_constant<int, 8>;
   using I10 = std::integral_constant<int, 10>;
+  using I42 = std::integral_constant<int, 42>;
   const std::true_type yes;
   const std::false_type no;
 
   float amax = 0.f;   // of the values split in the write-outs
+  bool prev_full = false;   // the previous tile of this workgroup was written out in full (see the waits below)
   issue_prologue(cur);
   for (;;) {
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // Every wait below is correct whatever else the wave still has in flight (the stores of the previous tile's
-    // write-out are YOUNGER than this tile's prologue pieces, so they can only make a counted wait stricter).
-    x3p_wait<10>();
-    bar();
-    if (wm == 1) bar();   // group 1 runs one barrier behind group 0
-    for (int tile = 0; tile + 2 < nk; ++tile) tile_body(tile, I10(), I10(), I10(), I10(), yes, yes, no);
+    // The write-out of the previous tile was issued AFTER this tile's seven-unit prologue, so its loads / stores are
+    // YOUNGER than the prologue pieces on the wave's in-order vmcnt.  A counted wait that ignores them is always correct
+    // (stricter) but drains the stores before the tile can start.  When the previous tile was a full one its write-out
+    // issued at least 32 vector-memory operations (one store per accumulator block, never predicated off), so the waits
+    // that only need prologue units may leave 32 more operations outstanding: the stores then drain under the first
+    // five phases of this tile.  From phase 2 of K tile 1 on the needed units are younger than the stores (count 10).
+    if (prev_full && nk >= 4) {
+      x3p_wait<42>();
+      bar();
+      if (wm == 1) bar();   // group 1 runs one barrier behind group 0
+      tile_body(0, I42(), I42(), I42(), I42(), yes, yes, no);
+      tile_body(1, I42(), I10(), I10(), I10(), yes, yes, no);
+      for (int tile = 2; tile + 2 < nk; ++tile) tile_body(tile, I10(), I10(), I10(), I10(), yes, yes, no);
+    } else {
+      x3p_wait<10>();
+      bar();
+      if (wm == 1) bar();   // group 1 runs one barrier behind group 0
+      for (int tile = 0; tile + 2 < nk; ++tile) tile_body(tile, I10(), I10(), I10(), I10(), yes, yes, no);
+    }
     tile_body(nk - 2, I10(), I8(), I6(), I4(), yes, no, no);
     tile_body(nk - 1, I2_(), I0(), I0(), I0(), no, no, yes);
     // Both groups have retired every LDS read of this tile when either leaves its last barrier (group 1's phase 4
@@ -607,6 +622,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
       }
     }
     if (!more) break;
+    prev_full = (done.row0 + TBM <= g.M) && (done.col0 + TBN <= g.N) && g.ksplit <= 1;
   }
   hgl_split_commit(amax);
 }
