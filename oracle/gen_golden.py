@@ -488,6 +488,30 @@ def gen_sam_tiny():
             out["amg_area"] = np.array([a["area"] for a in anns], dtype=np.int64)
         print("sam_tiny: emb", out["emb_nhwc"].shape, "low", low.shape, "iou range", float(iou.min()), float(iou.max()),
               "logit range", float(full.min()), float(full.max()), "amg masks", len(anns))
+        # the same generator with thresholds that DECIDE (Hybridgl_main.py:67-73 runs 0.7 / 0.7 / NMS 0.7 on trained weights;
+        # with seeded weights the predicted-IoU and stability values live elsewhere, so the two thresholds are put at
+        # quantiles of what the relaxed run produced; box_nms_thresh is the reference's 0.7): a 6 x 6 grid, every filter live
+        # (mask threshold raised to a high logit quantile, as in gen_sam_crops: a mask is then a handful of pixels and the
+        # boxes differ from mask to mask, so the NMS has real decisions to take)
+        sam.mask_threshold = float(np.quantile(full.numpy(), 0.9995))
+        out["dec_mask_threshold"] = np.array([sam.mask_threshold], dtype=np.float64)
+        gen6 = SamAutomaticMaskGenerator(sam, points_per_side=6, pred_iou_thresh=-1e9, stability_score_thresh=0.0,
+                                         stability_score_offset=0.25, crop_n_layers=0, min_mask_region_area=0, box_nms_thresh=1.5)
+        a6 = gen6.generate(c["image"])
+        iou_thr = float(np.quantile([a["predicted_iou"] for a in a6], 0.45))
+        stab_thr = float(np.nanquantile([a["stability_score"] for a in a6], 0.35))
+        gen_d = SamAutomaticMaskGenerator(sam, points_per_side=6, pred_iou_thresh=iou_thr, stability_score_thresh=stab_thr,
+                                          stability_score_offset=0.25, crop_n_layers=0, min_mask_region_area=20, box_nms_thresh=0.7)
+        ad = gen_d.generate(c["image"])
+        out["dec_thr"] = np.array([iou_thr, stab_thr, 0.7], dtype=np.float64)
+        out["dec_n_open"] = np.array([len(a6)])
+        out["dec_masks"] = np.packbits(np.stack([a["segmentation"] for a in ad]), axis=-1)
+        out["dec_bbox"] = np.array([a["bbox"] for a in ad], dtype=np.int64)
+        out["dec_iou"] = np.array([a["predicted_iou"] for a in ad], dtype=np.float32)
+        out["dec_stab"] = np.array([a["stability_score"] for a in ad], dtype=np.float32)
+        out["dec_points"] = np.array([a["point_coords"][0] for a in ad], dtype=np.float64)
+        sam.mask_threshold = 0.0
+        print("sam_tiny deciding thresholds", out["dec_thr"], "kept", len(ad), "of", len(a6))
     np.savez_compressed(os.path.join(GOLD, "sam_tiny.npz"), **out)
 
 

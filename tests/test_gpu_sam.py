@@ -194,6 +194,41 @@ def test_tiny_generate_vs_reference(cuda, g, tiny):
     assert all(a["crop_box"] == [0, 0, 200, 160] for a in anns)
 
 
+def test_tiny_generate_with_deciding_thresholds_vs_reference(cuda, g, tiny):
+    """The generator with filters that DECIDE (Hybridgl_main.py:67-73 runs pred_iou 0.7 / NMS 0.7 on trained weights): a
+    6 x 6 grid, pred_iou_thresh at the 45 % quantile of the predicted IoUs, box_nms_thresh = 0.7 on sparse masks (mask
+    threshold at a high logit quantile, so that boxes differ), min_mask_region_area = 20.  The reference keeps 44 of 108
+    candidates; the same records must come out here (a record within 1e-3 of a threshold may flip)."""
+    c = sam_tiny_case()
+    iou_thr, stab_thr, nms_thr = (float(v) for v in g["dec_thr"])
+    m = tiny[1]
+    old = m.mask_threshold
+    m.mask_threshold = float(g["dec_mask_threshold"][0])
+    try:
+        gen = hsam.SamAutomaticMaskGenerator(m, points_per_side=6, pred_iou_thresh=iou_thr, stability_score_thresh=stab_thr,
+                                             stability_score_offset=0.25, crop_n_layers=0, min_mask_region_area=20,
+                                             box_nms_thresh=nms_thr)
+        anns = gen.generate(c["image"])
+    finally:
+        m.mask_threshold = old
+    n_ref = len(g["dec_iou"])
+    assert 0 < n_ref < int(g["dec_n_open"][0]) // 2          # the filters removed more than half
+    ref_masks = np.unpackbits(g["dec_masks"], axis=-1)[..., :200].astype(bool)
+    near = int((np.abs(g["dec_iou"] - iou_thr) < 1e-3).sum())
+    assert abs(len(anns) - n_ref) <= 2 + near, (len(anns), n_ref)
+    matched = same_pos = 0
+    for i in range(n_ref):
+        for j, a in enumerate(anns):
+            if np.abs(np.array(a["point_coords"][0]) - g["dec_points"][i]).max() < 1e-9 and \
+                    abs(a["predicted_iou"] - g["dec_iou"][i]) < 1e-4 and (a["segmentation"] != ref_masks[i]).mean() < 2e-3:
+                assert np.abs(np.array(a["bbox"]) - g["dec_bbox"][i]).max() <= 2
+                matched += 1
+                same_pos += int(i == j)
+                break
+    assert matched >= n_ref - 2 - near, (matched, n_ref)
+    assert same_pos >= n_ref - 6, (same_pos, n_ref)          # output order (NMS order) agrees
+
+
 def test_nms_large_vs_oracle_and_small(cuda):
     """the bit-matrix NMS (any K) against the oracle's greedy NMS and, for K <= 1024, against the one-workgroup
     kernel: identical kept lists (score ties and duplicates included)."""
