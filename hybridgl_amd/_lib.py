@@ -177,6 +177,9 @@ def load():
         raise HybridGLError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C hybridgl_amd/csrc). There is no CPU fallback.")
+    # torch first: its wheel bundles the HIP runtime it was built with, and the process must hold ONE libamdhip64 -- loading
+    # this library before torch pulls in the system copy as well, after which no device is visible to it
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
