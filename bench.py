@@ -217,6 +217,10 @@ def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False, clip_na
         t_ref += t_sam
         sam_note = "; " + sam_note
     return {"value": 1.0 / t_ref, "unit": "images/s", "cores": threads, "kind": "port",
+            "reference_torch_cpu": {"value": 0.014, "unit": "images/s", "cores": 8,
+                                    "note": "the reference's own torch CPU path (imported, seeded weights) measured in the build "
+                                            "container on 8 vCPU, BASELINE.md section 2 / SURVEY.md section 6: ~73 s per ref; the reference "
+                                            "cannot travel to the GPU box, so this number is quoted, not re-measured there"},
             "sample": f"numpy oracle: views+CLIP hybrid {fusion_mode} on {n_sample} of 64 masks "
                       f"({t2 - t0:.1f}s, scaled x{scale:g}), 9 text strings ({t3 - t2:.1f}s), "
                       f"3-sentence tail on 64 masks ({t4 - t3:.1f}s){gem_note}{sam_note}; numpy BLAS threads = host default"}
