@@ -334,7 +334,7 @@ __device__ __forceinline__ void x3p_wait() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int ACT>
+template <int ACT, bool WLOADS>
 __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
   constexpr int TBM = 256, TBN = 256, MB = 8, NB = 4, WTM = 128, WTN = 64;   // 16x16 accumulator blocks per wave
   constexpr int PLANE = 256 * 64;    // bytes of one plane of one stage
@@ -542,7 +542,13 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
       for (int tile = 0; tile + 2 < nk; ++tile) tile_body(tile, I10(), I10(), I10(), I10(), yes, yes, no);
     }
     tile_body(nk - 2, I10(), I8(), I6(), I4(), yes, no, no);
+    // the tile's bias vector (row-contiguous write-out: ONE 16-byte vector per lane) is fetched under the last K tile and
+    // waited for BEFORE the next tile's prologue goes out: a compiler-counted wait placed after the prologue would have to
+    // be vmcnt(0) and drain the DMA it cannot see
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && g.ksplit <= 1) bv = *(const f32x4*)(g.bias + min(cur.col0 + wn * WTN + 4 * (lane & 15), g.N - 4));
     tile_body(nk - 1, I2_(), I0(), I0(), I0(), no, no, yes);
+    asm volatile("" : "+v"(bv));
     // Both groups have retired every LDS read of this tile when either leaves its last barrier (group 1's phase 4
     // has none, group 0 finishes after group 1's last read segment): the next tile's prologue DMA goes out BEFORE
     // the write-out, which it overlaps.
@@ -576,32 +582,62 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
           }
         }
       } else {
-        f32x4 bv[NB];
+        // Row-contiguous write-out.  In the accumulator layout adjacent lanes hold DIFFERENT rows (lane = 16*h + r), and a
+        // store instruction whose adjacent lanes are not contiguous costs ~260 cycles to issue whatever else the chip
+        // does (tools/micro/store_rate.hip: 8.4k cycles per 256 KB tile for a LONE workgroup; 2.4k with 4 rows x 256 B per
+        // instruction).  So every 16-row block goes through a wave-private 4 KiB patch of the 32 KiB of LDS the two
+        // stages leave free: written as it lies in the registers (element (row r, 16-byte chunk c) at r*256 +
+        // ((c ^ r) & 15)*16: both directions conflict-free), read back with lane = 16*(row & 3) + chunk.  Residual rows
+        // are then loaded in the same row-contiguous form and a lane needs ONE bias vector.  LDS operations of a wave
+        // execute in order, the patch is private: no barrier, no wait between the writes and the reads.
+        unsigned char* const tp = smem_p + 2 * STAGE + wave * 4096;
+        const int rl = lane >> 4, cl = lane & 15;
+        const int col = col0 + wn * WTN + 4 * cl;
+        const bool cok = col < g.N;
+        const int colc = min(col, g.N - 4);
+        // WLOADS = the write-out reads something (residual rows, a row map).  Without loads nothing in the loop waits on
+        // vmcnt and the stores stream out back to back; with a runtime `R ? load : 0` the compiler put an s_waitcnt
+        // vmcnt(0) into every row block -- every block then waited for all earlier stores AND for the next tile's
+        // prologue DMA (in-kernel stamps: ~500 cycles per store instruction).  With loads, the rows of block mb+1 are
+        // fetched before block mb is finished (compiler-counted partial waits).
+        int crow[2][4];
+        f32x4 rv[2][4];
+        auto fetch = [&](int mb, int (&cr)[4], f32x4 (&rr)[4]) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const int colc = min(cb + nb * 16, g.N - 4);
-          bv[nb] = g.bias ? *(const f32x4*)(g.bias + colc) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const int row = row0 + wm * WTM + mb * 16 + r;
-          const int rc = min(row, mclamp);
-          const int crow = g.cmap ? g.cmap[rc] : rc;
-          const long long rrow = g.rmod > 0 ? crow % g.rmod : crow;
-          f32x4 rv[NB];
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            const int colc = min(cb + nb * 16, g.N - 4);
-            rv[nb] = g.R ? *(const f32x4*)(g.R + rrow * g.ldr + colc) : f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int i = 0; i < 4; ++i) {
+            const int rc = min(row0 + wm * WTM + mb * 16 + 4 * i + rl, mclamp);
+            cr[i] = rc;
+            if constexpr (WLOADS) if (g.cmap) cr[i] = g.cmap[rc];
           }
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            const int col = cb + nb * 16;
-            if (full_tile || (row < g.M && col < g.N)) {
+          for (int i = 0; i < 4; ++i) {
+            rr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (WLOADS) {
+              const long long rrow = g.rmod > 0 ? cr[i] % g.rmod : cr[i];
+              if (g.R) rr[i] = *(const f32x4*)(g.R + rrow * g.ldr + colc);
+            }
+          }
+        };
+        fetch(0, crow[0], rv[0]);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) *(f32x4*)(tp + r * 256 + (((4 * nb + h) ^ r) & 15) * 16) = acc[mb][nb];
+          f32x4 v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int rho = 4 * i + rl;
+            v[i] = *(const f32x4*)(tp + rho * 256 + ((cl ^ rho) & 15) * 16);
+          }
+          if (mb + 1 < MB) fetch(mb + 1, crow[(mb + 1) & 1], rv[(mb + 1) & 1]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = row0 + wm * WTM + mb * 16 + 4 * i + rl;
+            if (full_tile || (row < g.M && cok)) {
               f32x4 o;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = act_apply<ACT>(acc[mb][nb][e] * g.out_scale + bv[nb][e]) + rv[nb][e];
-              const long long off = (long long)crow * g.ldc + col;
+              for (int e = 0; e < 4; ++e) o[e] = act_apply<ACT>(v[i][e] * g.out_scale + bv[e]) + rv[mb & 1][i][e];
+              const long long off = (long long)crow[mb & 1][i] * g.ldc + col;
               if (g.C) {
                 *(f32x4*)(g.C + off) = o;
               } else {
@@ -916,21 +952,26 @@ int launch_x3_v1(Args& g, hipStream_t st) {
   return HGL_OK;
 }
 
-template <int ACT>
-int launch_x3_p(Args& g, hipStream_t st) {
+template <int ACT, bool WLOADS>
+int launch_x3_p2(Args& g, hipStream_t st) {
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
   const long long nwg = (long long)g.tiles_m * g.tiles_n;
   HGL_REQUIRE(nwg < (1ll << 31), "gemm_f16x3: grid too large");
-  const size_t lds = (size_t)2 * 4 * 256 * 64;
+  const size_t lds = (size_t)2 * 4 * 256 * 64 + 8 * 4096;   // two stages + the write-out patches: all 160 KiB
   static bool set = false;
   if (!set) {
-    (void)hipFuncSetAttribute((const void*)gemm_x3p_kernel<ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_x3p_kernel<ACT, WLOADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     set = true;
   }
   const long long grid = g.ksplit > 1 ? nwg : x3p_grid(nwg);
-  hipLaunchKernelGGL((gemm_x3p_kernel<ACT>), dim3((unsigned)grid, (unsigned)(g.ksplit > 1 ? g.ksplit : 1)), dim3(512), lds, st, g);
+  hipLaunchKernelGGL((gemm_x3p_kernel<ACT, WLOADS>), dim3((unsigned)grid, (unsigned)(g.ksplit > 1 ? g.ksplit : 1)), dim3(512), lds, st, g);
   return HGL_OK;
+}
+
+template <int ACT>
+int launch_x3_p(Args& g, hipStream_t st) {
+  return (g.R || g.cmap) ? launch_x3_p2<ACT, true>(g, st) : launch_x3_p2<ACT, false>(g, st);
 }
 
 template <int ACT>
