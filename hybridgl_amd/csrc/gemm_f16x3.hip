@@ -329,6 +329,15 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
                : "memory");
 }
 
+// one dword per lane: LDS[lds_addr + 4*lane] = *(sbase + voff)
+__device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void x3p_wait() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
@@ -377,7 +386,8 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
   const int rgA0 = wm * 8 + (wave & 3), rgA1 = rgA0 + 4;
   const int cgW0 = 4 * (wave >> 1) + (wave & 1), cgW1 = cgW0 + 2;
   struct TileOff { int row0, col0; unsigned oa0, oa1, ow0, ow1; };
-  auto tile_offsets = [&](int vid) {
+  // rows of A this lane stages (a0, a1: clamped, before the row map) and its two W offsets
+  auto tile_rows = [&](int vid, int& a0, int& a1) {
     const int bid = vstart + vid;
     const int GM = g.gm;
     const int group = bid / (GM * g.tiles_n);
@@ -387,31 +397,47 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
     TileOff o;
     o.row0 = (first_m + rem % gmn) * TBM;
     o.col0 = (rem / gmn) * TBN;
-    int a0 = min(o.row0 + rgA0 * 16 + prow, mclamp), a1 = min(o.row0 + rgA1 * 16 + prow, mclamp);
-    if (g.amap) { a0 = g.amap[a0]; a1 = g.amap[a1]; }
-    o.oa0 = (unsigned)(a0 * g.lda + pchunk * 8) * 2u;
-    o.oa1 = (unsigned)(a1 * g.lda + pchunk * 8) * 2u;
+    a0 = min(o.row0 + rgA0 * 16 + prow, mclamp);
+    a1 = min(o.row0 + rgA1 * 16 + prow, mclamp);
+    o.oa0 = o.oa1 = 0;
     o.ow0 = (unsigned)(min(o.col0 + cgW0 * 16 + prow, nclamp) * g.ldw + pchunk * 8) * 2u;
     o.ow1 = (unsigned)(min(o.col0 + cgW1 * 16 + prow, nclamp) * g.ldw + pchunk * 8) * 2u;
     return o;
   };
+  auto a_offset = [&](int arow) { return (unsigned)(arow * g.lda + pchunk * 8) * 2u; };
+  auto tile_offsets = [&](int vid) {
+    int a0, a1;
+    TileOff o = tile_rows(vid, a0, a1);
+    if (g.amap) { a0 = g.amap[a0]; a1 = g.amap[a1]; }
+    o.oa0 = a_offset(a0);
+    o.oa1 = a_offset(a1);
+    return o;
+  };
   TileOff cur = tile_offsets(v);
-  // unit u (0: A first rows, 1: W first columns, 2: W second columns, 3: A second rows) of K tile `tile`
-  auto issue_unit = [&](const TileOff& o, int u, int tile) {
+  // unit u (0: A first rows, 1: W first columns, 2: W second columns, 3: A second rows) of K tile `tile`; a K tile index
+  // >= nk means K tile (tile - nk) of the NEXT output tile of this workgroup (nk is even, so the stage parity carries on):
+  // the DMA stream runs seven units ahead straight across the boundary between two output tiles
+  auto issue_unit = [&](const TileOff& o0, int u, int tile, bool wrap = false) {
     const unsigned sb = lds0 + (tile & 1) * STAGE;
-    const long long ko = (long long)(kbeg + tile) * 64;
+    const long long ko = (long long)(kbeg + (wrap ? tile - nk : tile)) * 64;
+    // the next tile's four per-lane offsets wait in the wave's write-out patch (idle during the main loop), not in VGPRs
+    const unsigned* nx = (const unsigned*)(smem_p + 2 * STAGE + wave * 4096) + lane * 4;
     if (u == 0) {
-      glds16(bAh + ko, o.oa0, sb + rgA0 * 1024);
-      glds16(bAl + ko, o.oa0, sb + PLANE + rgA0 * 1024);
+      const unsigned off = wrap ? nx[0] : o0.oa0;
+      glds16(bAh + ko, off, sb + rgA0 * 1024);
+      glds16(bAl + ko, off, sb + PLANE + rgA0 * 1024);
     } else if (u == 1) {
-      glds16(bWh + ko, o.ow0, sb + 2 * PLANE + cgW0 * 1024);
-      glds16(bWl + ko, o.ow0, sb + 3 * PLANE + cgW0 * 1024);
+      const unsigned off = wrap ? nx[2] : o0.ow0;
+      glds16(bWh + ko, off, sb + 2 * PLANE + cgW0 * 1024);
+      glds16(bWl + ko, off, sb + 3 * PLANE + cgW0 * 1024);
     } else if (u == 2) {
-      glds16(bWh + ko, o.ow1, sb + 2 * PLANE + cgW1 * 1024);
-      glds16(bWl + ko, o.ow1, sb + 3 * PLANE + cgW1 * 1024);
+      const unsigned off = wrap ? nx[3] : o0.ow1;
+      glds16(bWh + ko, off, sb + 2 * PLANE + cgW1 * 1024);
+      glds16(bWl + ko, off, sb + 3 * PLANE + cgW1 * 1024);
     } else {
-      glds16(bAh + ko, o.oa1, sb + rgA1 * 1024);
-      glds16(bAl + ko, o.oa1, sb + PLANE + rgA1 * 1024);
+      const unsigned off = wrap ? nx[1] : o0.oa1;
+      glds16(bAh + ko, off, sb + rgA1 * 1024);
+      glds16(bAl + ko, off, sb + PLANE + rgA1 * 1024);
     }
   };
   auto issue_prologue = [&](const TileOff& o) {   // seven units ahead
@@ -467,39 +493,47 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
   };
   // one K tile: C1..C4 = the vmcnt left outstanding at the end of the four load segments; I1 / I2: issue the unit
   // of phase 1 (tile + 1) / of phases 2-4 (tile + 2); LAST drops group 1's unpaired final barrier
-  auto tile_body = [&](int tile, auto c1, auto c2, auto c3, auto c4, auto i1, auto i2, auto last) {
-    constexpr int C1 = decltype(c1)::value, C2 = decltype(c2)::value, C3 = decltype(c3)::value, C4 = decltype(c4)::value;
+  // `go` (runtime, uniform): the workgroup has another output tile after this one -- the K tile then issues whatever I1 / I2
+  // say and waits with the steady count of 10 (ONE code path for the accumulators: two instantiations behind an
+  // if / else made the register allocator rename the accumulators and spill)
+  auto tile_body = [&](int tile, auto c1, auto c2, auto c3, auto c4, auto i1, auto i2, auto last, bool go) {
     constexpr bool I1 = decltype(i1)::value, I2 = decltype(i2)::value, LAST = decltype(last)::value;
     const int stage = tile & 1;
+    auto wait = [&](auto c) {
+      constexpr int CC = decltype(c)::value;
+      if constexpr (CC == 10 || CC == 42) x3p_wait<CC>();
+      else if (go) x3p_wait<10>();
+      else x3p_wait<CC>();
+    };
     // phase 1
     read_A(0, stage);
     read_B(0, stage);
-    if (I1) issue_unit(cur, 3, tile + 1);
+    if (I1 || go) issue_unit(cur, 3, tile + 1, go && tile + 1 >= nk);
     __builtin_amdgcn_sched_barrier(0);
-    x3p_wait<C1>();
+    wait(c1);
     bar();
     quad(0, 0);
     bar();
     // phase 2
     read_B(1, stage);
-    if (I2) issue_unit(cur, 0, tile + 2);
+    if (I2 || go) issue_unit(cur, 0, tile + 2, go);
     __builtin_amdgcn_sched_barrier(0);
-    x3p_wait<C2>();
+    wait(c2);
     bar();
     quad(0, 1);
     bar();
     // phase 3
     read_A(1, stage);
-    if (I2) issue_unit(cur, 1, tile + 2);
+    if (I2 || go) issue_unit(cur, 1, tile + 2, go);
     __builtin_amdgcn_sched_barrier(0);
-    x3p_wait<C3>();
+    wait(c3);
     bar();
     quad(1, 0);
     bar();
     // phase 4
-    if (I2) issue_unit(cur, 2, tile + 2);
+    if (I2 || go) issue_unit(cur, 2, tile + 2, go);
     __builtin_amdgcn_sched_barrier(0);
-    x3p_wait<C4>();
+    wait(c4);
     bar();
     quad(1, 1);
     if (!(LAST && wm == 1)) bar();
@@ -518,48 +552,73 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
   bool prev_full = false;   // the previous tile of this workgroup was written out in full (see the waits below)
   issue_prologue(cur);
   for (;;) {
+    const bool more = v + vstride < vlen;
+    int nrow0 = 0, ncol0 = 0;
+    unsigned char* const nxp = smem_p + 2 * STAGE + wave * 4096;   // the wave's write-out patch, idle until the write-out
+    if (more) {
+      // the next tile's offsets, parked in the patch.  With a row map the two A rows are map LOADS: a compiler-counted
+      // wait for them here would be vmcnt(0) in the middle of the DMA stream and of the previous tile's stores, so
+      // they go to the patch by DMA too and are turned into offsets before the last two K tiles
+      int a0, a1;
+      const TileOff nn = tile_rows(v + vstride, a0, a1);
+      nrow0 = nn.row0; ncol0 = nn.col0;
+      *(u32x4*)(nxp + lane * 16) = u32x4{a_offset(a0), a_offset(a1), nn.ow0, nn.ow1};
+      if (g.amap) {
+        const unsigned pl = lds0 + 2 * STAGE + wave * 4096 + 1024;
+        glds4(g.amap, (unsigned)a0 * 4u, pl);
+        glds4(g.amap, (unsigned)a1 * 4u, pl + 256);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
       for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // The write-out of the previous tile was issued AFTER this tile's seven-unit prologue, so its loads / stores are
-    // YOUNGER than the prologue pieces on the wave's in-order vmcnt.  A counted wait that ignores them is always correct
-    // (stricter) but drains the stores before the tile can start.  When the previous tile was a full one its write-out
-    // issued at least 32 vector-memory operations (one store per accumulator block, never predicated off), so the waits
-    // that only need prologue units may leave 32 more operations outstanding: the stores then drain under the first
-    // five phases of this tile.  From phase 2 of K tile 1 on the needed units are younger than the stores (count 10).
+    // The write-out of the previous tile was issued AFTER the seven units that were in flight at the tile boundary, so its
+    // loads / stores are YOUNGER than those units on the wave's in-order vmcnt.  A counted wait that ignores them is
+    // always correct (stricter) but drains the stores before the tile can go on.  When the previous tile was a full one
+    // its write-out issued at least 32 vector-memory operations (one store per row group, never predicated off), so the
+    // waits that only need units older than the write-out may leave 32 more operations outstanding: the stores then
+    // drain under the first five phases of this tile.  From phase 2 of K tile 1 on the needed units are younger than the
+    // stores (count 10).
     if (prev_full && nk >= 4) {
       x3p_wait<42>();
       bar();
       if (wm == 1) bar();   // group 1 runs one barrier behind group 0
-      tile_body(0, I42(), I42(), I42(), I42(), yes, yes, no);
-      tile_body(1, I42(), I10(), I10(), I10(), yes, yes, no);
-      for (int tile = 2; tile + 2 < nk; ++tile) tile_body(tile, I10(), I10(), I10(), I10(), yes, yes, no);
+      tile_body(0, I42(), I42(), I42(), I42(), yes, yes, no, false);
+      tile_body(1, I42(), I10(), I10(), I10(), yes, yes, no, false);
+      for (int tile = 2; tile + 2 < nk; ++tile) tile_body(tile, I10(), I10(), I10(), I10(), yes, yes, no, false);
     } else {
       x3p_wait<10>();
       bar();
       if (wm == 1) bar();   // group 1 runs one barrier behind group 0
-      for (int tile = 0; tile + 2 < nk; ++tile) tile_body(tile, I10(), I10(), I10(), I10(), yes, yes, no);
+      for (int tile = 0; tile + 2 < nk; ++tile) tile_body(tile, I10(), I10(), I10(), I10(), yes, yes, no, false);
     }
-    tile_body(nk - 2, I10(), I8(), I6(), I4(), yes, no, no);
     // the tile's bias vector (row-contiguous write-out: ONE 16-byte vector per lane) is fetched under the last K tile and
-    // waited for BEFORE the next tile's prologue goes out: a compiler-counted wait placed after the prologue would have to
-    // be vmcnt(0) and drain the DMA it cannot see
+    // waited for BEFORE the write-out: a compiler-counted wait in the middle of the DMA stream would have to be vmcnt(0)
+    // (loaded by asm so that the compiler does not count it; vmcnt(8) = the four units K tile nk-1 issues when the stream
+    // goes on, and the drained tail otherwise)
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && g.ksplit <= 1) bv = *(const f32x4*)(g.bias + min(cur.col0 + wn * WTN + 4 * (lane & 15), g.N - 4));
-    tile_body(nk - 1, I2_(), I0(), I0(), I0(), no, no, yes);
-    asm volatile("" : "+v"(bv));
-    // Both groups have retired every LDS read of this tile when either leaves its last barrier (group 1's phase 4
-    // has none, group 0 finishes after group 1's last read segment): the next tile's prologue DMA goes out BEFORE
-    // the write-out, which it overlaps.
+    if (more && g.amap) {
+      // the two map DMAs are older than the 16 operations of the last two K tiles issued so far (none if nk == 2)
+      if (nk >= 4) x3p_wait<10>(); else x3p_wait<0>();
+      const int m0 = *(const int*)(nxp + 1024 + lane * 4), m1 = *(const int*)(nxp + 1280 + lane * 4);
+      *(unsigned*)(nxp + lane * 16) = a_offset(m0);
+      *(unsigned*)(nxp + lane * 16 + 4) = a_offset(m1);
+    }
+    tile_body(nk - 2, I10(), I8(), I6(), I4(), yes, no, no, more);
+    const bool has_bias = g.bias && g.ksplit <= 1;
+    if (has_bias) {
+      const float* bp = g.bias + min(cur.col0 + wn * WTN + 4 * (lane & 15), g.N - 4);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bv) : "v"(bp) : "memory");
+    }
+    tile_body(nk - 1, I2_(), I0(), I0(), I0(), no, no, yes, more);
+    if (has_bias) asm volatile("s_waitcnt vmcnt(8)" : "+v"(bv)::"memory");
     const TileOff done = cur;
     v += vstride;
-    const bool more = v < vlen;
     if (more) {
-      cur = tile_offsets(v);
-      issue_prologue(cur);
+      const unsigned* nx = (const unsigned*)(smem_p + 2 * STAGE + wave * 4096) + lane * 4;
+      cur.row0 = nrow0; cur.col0 = ncol0; cur.oa0 = nx[0]; cur.oa1 = nx[1]; cur.ow0 = nx[2]; cur.ow1 = nx[3];
     }
-
     // ---- write-out: accumulator block (mb, nb) = output rows mb*16 + r, columns nb*16 + 4*h .. +3 ----
     {
       const int row0 = done.row0, col0 = done.col0;
