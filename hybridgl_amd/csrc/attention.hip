@@ -686,6 +686,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
 //   * the output rows are stored fire-and-forget under the next item's prologue.
 // The arithmetic of a tile (QK^T on split operands, lazy-rescaled online softmax, PV through transposing LDS reads, the
 // rel-pos bias of a 14 x 14 window as two extra k-steps against indicator columns) is that of attn_x3_kernel.
+// In-kernel cycle stamps (tools/attn_stamps.py; compiled in with -DHGL_ATTN_STAMPS only): workgroup 0, one wave
+#ifdef HGL_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[2048];
+__device__ int g_attn_stamp_wave = 0;
+#define STAMP(id) do { if (blockIdx.x == 0 && t == 64 * g_attn_stamp_wave && nst < 2040) { g_attn_stamps[nst++] = ((unsigned long long)(id) << 48) | ((unsigned long long)clock64() & 0xffffffffffffull); } } while (0)
+#else
+#define STAMP(id) do {} while (0)
+#endif
+
 template <int HD, int RELW>
 __global__ __launch_bounds__(512, 1) void attn_x3w_kernel(AttnArgs a) {
   constexpr int NW = 8, NT = NW * 64;
@@ -706,6 +715,7 @@ __global__ __launch_bounds__(512, 1) void attn_x3w_kernel(AttnArgs a) {
   static_assert(RELW == 0 || (size_t)NW * 2 * 32 * RPP * 4 <= (size_t)2 * BUF_H * 2, "rel-pos patch must fit the two buffers");
   extern __shared__ __attribute__((aligned(16))) _Float16 smem_w[];
   float* const RPatch = (float*)smem_w;                  // prologue only: aliases the (then idle) K/V buffers
+  uint8_t* const keepL = (uint8_t*)(smem_w + 2 * BUF_H);   // [256]: keepL[key - 1] = the item's CLS-keep row
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -793,16 +803,32 @@ __global__ __launch_bounds__(512, 1) void attn_x3w_kernel(AttnArgs a) {
     }
   };
 
+  // CLS-keep row of an item (make_attn_mask: only query 0 is masked): one byte per thread, prefetched with the item's first
+  // K/V chunk and parked in LDS.  Per-score global byte loads (the generic kernel) serialise 16 load + wait pairs per key
+  // tile on the one wave that owns query 0 while the other seven wait for it at the chunk barrier.
+  unsigned pkeep = 1;
+  auto keep_ptr = [&](int it) -> const uint8_t* {
+    const int bb = it / a.H;
+    return (a.mask_kind == HGL_MASK_CLS_KEEP && bb >= a.keep_b0) ? a.keep + (long long)((bb - a.keep_b0) % a.keep_n) * (a.Sk - 1) : nullptr;
+  };
+  auto load_keep = [&](int it) {
+    const uint8_t* kr = keep_ptr(it);
+    if (kr && t < a.Sk - 1) pkeep = kr[t];
+  };
+
   int item = blockIdx.x;
   if (item >= nitems) return;
+  int nst = 0; (void)nst;
   if constexpr (PREQ) load_q(item);
   load_chunk(item, 0);
+  load_keep(item);
   __syncthreads();   // the padding zeros
 
   for (;;) {
     const int b = item / a.H, hh = item - b * a.H;
     const int next = item + (int)gridDim.x;
     const bool has_next = next < nitems;
+    STAMP(1);
 
     // ---- Q fragments (pre-scaled in fp32, then split: see attn_x3_kernel) from the prefetched rows ----
     if constexpr (!PREQ) {
@@ -898,22 +924,25 @@ __global__ __launch_bounds__(512, 1) void attn_x3w_kernel(AttnArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
     float m_run = NEG_INF, l_run = 0.f;
-    const uint8_t* keep_row = nullptr;
-    if (a.mask_kind == HGL_MASK_CLS_KEEP && b >= a.keep_b0)
-      keep_row = a.keep + (long long)((b - a.keep_b0) % a.keep_n) * (a.Sk - 1);
+    const bool has_keep = keep_ptr(item) != nullptr;
+    STAMP(2);
 
     if constexpr (PREQ || RELW > 0) store_chunk(0, 0);
+    if (has_keep && t < a.Sk - 1) keepL[t] = (uint8_t)pkeep;
     if (nch > 1) load_chunk(item, KV_CHUNK);
-    else if (has_next) { if constexpr (PREQ) load_q(next); load_chunk(next, 0); }
+    else if (has_next) { if constexpr (PREQ) load_q(next); load_chunk(next, 0); load_keep(next); }
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
 
     for (int c = 0; c < nch; ++c) {
       const int kc = c * KV_CHUNK;
       if (c + 1 < nch) {
         store_chunk(kc + KV_CHUNK, (c + 1) & 1);     // its buffer was released by the barrier that ended iteration c-1
         if (c + 2 < nch) load_chunk(item, kc + 2 * KV_CHUNK);
-        else if (has_next) { if constexpr (PREQ) load_q(next); load_chunk(next, 0); }
+        else if (has_next) { if constexpr (PREQ) load_q(next); load_chunk(next, 0); load_keep(next); }
       }
+      STAMP(5);
       const _Float16* Ks = smem_w + (c & 1) * BUF_H;
       const _Float16* Vh = Ks + KV_CHUNK * KROW;
       const _Float16* Vl = Vh + KV_CHUNK * VP;
@@ -941,22 +970,29 @@ __global__ __launch_bounds__(512, 1) void attn_x3w_kernel(AttnArgs a) {
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(e8, rbh[cc], s, 0, 0, 0);
           }
         }
+        STAMP(6);
         float mx = NEG_INF;
-        if (kbase + 32 > a.Sk || keep_row) {   // uniform: the tile that crosses the end of the sequence, CLS-keep batches
+        if (kbase + 32 > a.Sk) {   // uniform: the tile that crosses the end of the sequence
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-            float sv = s[e];
-            bool masked = kg >= a.Sk;
-            if (keep_row && qi == 0 && kg >= 1 && kg < a.Sk) masked |= keep_row[kg - 1] == 0;
-            sv = masked ? NEG_INF : sv;
-            s[e] = sv;
-            mx = fmaxf(mx, sv);
+            s[e] = kg >= a.Sk ? NEG_INF : s[e];
           }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
         }
+        if (has_keep && wave == 0) {   // uniform: the wave that owns query 0 of a CLS-keep batch
+          // the tile's 32 keep bytes as one bit mask (a ballot over one byte read per lane), bit c = key kbase + c; the
+          // CLS key itself (key 0) is always kept.  A lane's element e is key kbase + 4h + (e & 3) + 8 (e >> 2).
+          const int kk = kbase + (lane & 31);
+          const unsigned kb = kk >= 1 && kk < a.Sk ? keepL[kk - 1] : 1u;
+          const unsigned bits = (unsigned)__builtin_amdgcn_ballot_w64(kb != 0) >> (4 * h);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const bool kept = (bits >> ((e & 3) + 8 * (e >> 2))) & 1u;
+            s[e] = (qi == 0 && !kept) ? NEG_INF : s[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_cand = fmaxf(m_run, mx);
         float m_new = m_run;
@@ -986,6 +1022,7 @@ __global__ __launch_bounds__(512, 1) void attn_x3w_kernel(AttnArgs a) {
           pl[e >> 3][(e & 7) + 1] = (_Float16)(p1 - (float)hi2[1]);
         }
         l_run += rs;
+        STAMP(7);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           if (kbase + 16 * s2 >= a.Sk) break;   // uniform: the keys of this k-step are all beyond the sequence (P = 0)
@@ -1003,7 +1040,9 @@ __global__ __launch_bounds__(512, 1) void attn_x3w_kernel(AttnArgs a) {
           }
         }
       }
+      STAMP(12);
       __syncthreads();
+      STAMP(13);
     }
 
     // ---- output rows of this item (the stores drain under the next item's prologue) ----
@@ -1038,6 +1077,7 @@ __global__ __launch_bounds__(512, 1) void attn_x3w_kernel(AttnArgs a) {
         }
       }
     }
+    STAMP(14);
     if (!has_next) break;
     item = next;
   }
@@ -1267,7 +1307,7 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(FewQArgs a) {
 template <int HD, int RELW>
 void launch_wide(const AttnArgs& a, hipStream_t st) {
   constexpr int KROW = 2 * HD + (RELW > 0 ? 32 : 0) + 8, VP = HD <= 32 ? 32 : 96;
-  constexpr size_t lds = (size_t)2 * KV_CHUNK * (KROW + 2 * VP) * sizeof(_Float16);
+  constexpr size_t lds = (size_t)2 * KV_CHUNK * (KROW + 2 * VP) * sizeof(_Float16) + 256;   // + the CLS-keep row
   static bool set = false;
   static int ncu = 0;
   if (!set) {
@@ -1308,6 +1348,16 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef HGL_ATTN_STAMPS
+extern "C" int hgl_debug_attn_stamps(unsigned long long* out, int n, int wave) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
+  unsigned long long z[2048] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), z, sizeof(z));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp_wave), &wave, sizeof(int));
+  return 0;
+}
+#endif
 
 // Windowed attention of the SAM encoder (14 x 14 windows, head dim 80, f16x3 mode) with the decomposed rel-pos terms
 // computed INSIDE the kernel from the tables Rh / Rw [27, 80] (no rel_h / rel_w tensors, no separate table kernel).

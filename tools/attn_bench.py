@@ -36,6 +36,16 @@ def plain(B, H, S, hd, name, mask="none"):
 
 plain(1024, 12, 197, 64, "clip 1024x12 S197 hd64")
 plain(128, 12, 197, 64, "clip 128x12 S197 hd64")
+
+
+def cls_keep(B, H, S, hd, name):
+    q, k, v = (torch.randn(B, S, H * hd, device=dev) for _ in range(3))
+    keep = (torch.rand(B, S - 1, device=dev) < 0.3).to(torch.uint8)
+    timed(lambda: ops.attention(q, k, v, H, mask="cls_keep", keep=keep, keep_b0=0, keep_n=B), 4.0 * B * H * S * S * hd, name)
+
+
+cls_keep(1024, 12, 197, 64, "clip 1024x12 S197 CLS-keep")
+
 plain(8, 12, 785, 64, "gem 8x12 S785 hd64")
 plain(8, 16, 4096, 80, "sam global 8x16 S4096 hd80")
 plain(96, 8, 77, 64, "text 96x8 S77 hd64 causal", mask="causal")
@@ -52,3 +62,6 @@ lib.hgl_prof_enable(0)
 n, ms, fl, by = C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
 lib.hgl_prof_read(1, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
 print(f"sam vit_h_d2 x8 attention class: {n.value} launches {ms.value * 1e3:.1f} us total, {fl.value / ms.value / 1e9:.1f} TF/s (1 windowed 200 windows + 1 global)")
+# layout probe: the same 12288 items with every (batch, head) slice CONTIGUOUS (rows of 256 B instead of 256-B pieces of
+# 9 KB rows): what the access pattern costs
+plain(1024 * 12, 1, 197, 64, "12288x1 S197 fp32, head-major")
