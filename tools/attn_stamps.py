@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""In-kernel cycle stamps of the persistent wide attention kernel (attention.hip compiled with -DHGL_ATTN_STAMPS):
+"""In-kernel cycle stamps of the persistent wide attention kernel.  Needs attention.hip compiled with the stamps in:
+    touch hybridgl_amd/csrc/attention.hip && make -C hybridgl_amd/csrc EXTRA=-DHGL_ATTN_STAMPS      (and again without EXTRA afterwards)
+
 where the cycles of an item go, for workgroup 0, wave argv[1] (default 0).  CLIP shape 1024 x 12 x 197 x 64."""
 import ctypes as C
 import os
