@@ -92,6 +92,35 @@ def test_gemm_f16x3_tilings_bit_identical(cuda, M, N, K):
     assert np.abs(outs["v1"] - z).max() < 3e-5
 
 
+def test_gemm_f16x3_tilings_fuzz_many_tiles(cuda):
+    """The ping-pong kernel counts its waits by hand (LDS-DMA units that run across output-tile boundaries, write-out
+    stores, the bias load -- all on one in-order counter); the register-staged kernel's waits are the compiler's.  An
+    under-count would read stale data: random shapes with MANY tiles per persistent workgroup, each repeated, must
+    match bit for bit (tools/x3_fuzz.py is the long form: 2 500 cases)."""
+    rng = np.random.default_rng(11)
+    try:
+        for c in range(40):
+            K = 64 * int(rng.integers(1, 33))
+            N = 4 * int(rng.integers(16, 700))
+            M = int(rng.integers(2000, 120000))
+            if M * (N + K) > 200e6:
+                M = int(200e6 // (N + K))
+            act = ("none", "quickgelu", "gelu", "relu")[int(rng.integers(0, 4))]
+            a = torch.randn(M, K, device=cuda)
+            w = torch.randn(N, K, device=cuda) / K ** 0.5
+            b = torch.randn(N, device=cuda) if rng.random() < 0.7 else None
+            r = torch.randn(M, N, device=cuda) if rng.random() < 0.5 else None
+            ops.select_x3_kernel("v1")
+            ref = ops.gemm_f16x3(a, w, b, r, act)
+            ops.select_x3_kernel("P")
+            for rep in range(2):
+                assert torch.equal(ops.gemm_f16x3(a, w, b, r, act), ref), (c, rep, M, N, K, act)
+            torch.cuda.synchronize()
+            ops.release_split_weights([w.data_ptr()])
+    finally:
+        ops.select_x3_kernel("auto")
+
+
 def test_gemm_f16x3_inplace_residual(cuda):
     """residual aliasing the output (x += proj(...)) on every tiling"""
     rng = np.random.default_rng(5)
