@@ -60,7 +60,7 @@ int hgl_device_count(void);
 
 /* Per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg).
  * cls: 0 = fp32 MFMA GEMM, 1 = fused attention, 2 = other, 3 = split-fp16 (f16x3) GEMM, register-staged kernel
- * (gemm_f16x3_kernel), 4 = f16x3 GEMM, LDS-DMA kernels (gemm_x3g_kernel), 5 = launches of either f16x3 kernel with
+ * (gemm_f16x3_kernel), 4 = f16x3 GEMM, LDS-DMA ping-pong kernel (gemm_x3p_kernel), 5 = launches of either f16x3 kernel with
  * fewer than 256 output tiles (latency-bound side-stream work: GEM at 785 rows, text encoder).  hgl_prof_read synchronises,
  * returns and clears the records of one class: launches, summed event ms, and the summed
  * ALGORITHMIC flops / bytes of those launches (2*M*N*K per GEMM; 4*B*H*Sq*Sk*hd per attention). */

@@ -70,7 +70,7 @@ def test_gemm_f16x3(cuda, M, N, K, act):
 
 @pytest.mark.parametrize("M,N,K", [(300, 200, 64), (777, 1000, 192), (1031, 520, 1280), (64, 3000, 128)])
 def test_gemm_f16x3_tilings_bit_identical(cuda, M, N, K):
-    """Every tiling of the f16x3 GEMM (register-staged, LDS-DMA 256x256 / 256x128 / 128x128) accumulates in the
+    """Every tiling of the f16x3 GEMM (register-staged 128x128, LDS-DMA ping-pong 256x256) accumulates in the
     same order: outputs must be bit-identical, ragged edges included, and the cost model must pick one of them."""
     rng = np.random.default_rng(M + N + K)
     a = T(rng.standard_normal((M, K)).astype(np.float32), cuda)
