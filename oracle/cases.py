@@ -88,3 +88,18 @@ def sam_crops_case():
     from hybridgl_amd.synth import synth_image
     return dict(image=synth_image(240, 320, 77), points_per_side=8, crop_n_layers=1, downscale=2,
                 box_nms_thresh=0.7, crop_nms_thresh=0.7, logit_quantile=0.9995)
+
+
+def tie_case(ci, dup):
+    """tail_case(ci) with proposals `dup[1:]` made exact copies of proposal dup[0] (feature row, mask, box): their scores
+    tie exactly in both soft-maxes, so the winners depend on how argmax / topk order equal values"""
+    hybrid, t_pos, t_neg, masks, boxes, attn, gt = tail_case(ci, 12, 32, 96, 128)
+    for j in dup[1:]:
+        hybrid[j] = hybrid[dup[0]]
+        masks[j] = masks[dup[0]]
+        boxes[j] = boxes[dup[0]]
+    return hybrid, t_pos, t_neg, masks, boxes, attn, gt
+
+
+TIE_PLAN = [(0, (2, 5), "none", "none", False), (1, (0, 7, 9), "left", "left", True), (2, (4, 1), "big", "middle", True),
+            (3, (11, 3, 6), "within", "right", False), (4, (8, 10), "small", "none", True), (5, (1, 2, 3, 4), "up", "left", False)]

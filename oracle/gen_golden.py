@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from hybridgl_amd import weights  # noqa: E402
 from hybridgl_amd.synth import synth_masks, synth_image  # noqa: E402
-from oracle.cases import edge_masks, views_for_case, resize_case, RESIZE_CASES, tail_case  # noqa: E402
+from oracle.cases import edge_masks, views_for_case, resize_case, RESIZE_CASES, tail_case, tie_case, TIE_PLAN  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -326,6 +326,22 @@ def gen_scoring_small():
     np.savez_compressed(os.path.join(GOLD, "scoring_small.npz"), **out)
 
 
+def gen_scoring_ties():
+    """Tail goldens with EXACT score ties (duplicated proposals): pins which of the equal candidates torch.argmax /
+    torch.topk (Hybridgl_main.py:163-183) return, and with them the winning index."""
+    sys.path.insert(0, REF)
+    utils = _load("ref_utils", os.path.join(REF, "utils.py"))
+    bb = build_ref_backbone("tiny", 0)
+    out = {}
+    for step, (ci, dup, rela, dirflag, has_other) in enumerate(TIE_PLAN):
+        hybrid, t_pos, t_neg, masks, boxes, attn, gt = tie_case(ci, dup)
+        ip, ifin, iu, _, _, gem = ref_tail(bb, utils, hybrid, t_pos, t_neg, masks, boxes, attn, gt, rela, dirflag, has_other, 3, 6)
+        out[f"t{step}_idx"] = np.array([ip, ifin], dtype=np.int64)
+        out[f"t{step}_IU"] = np.array(iu, dtype=np.int64)
+        print("tie tail", step, dup, rela, dirflag, has_other, ip, ifin)
+    np.savez_compressed(os.path.join(GOLD, "scoring_ties.npz"), **out)
+
+
 def gen_views():
     """Hybridgl_main.py:93-125 (the per-mask local / global view loop) with everything that CAN be pinned offline pinned:
     the loop's statements are kept one for one; cv2.bitwise_and / cv2.add are their documented uint8 semantics in numpy
@@ -617,6 +633,8 @@ if __name__ == "__main__":
         gen_views()
     if want("scoring_small"):
         gen_scoring_small()
+    if want("scoring_ties"):
+        gen_scoring_ties()
     if want("text_pool_tiny"):
         gen_text_pool("tiny", 0, "text_pool_tiny", [1, 2])
     if want("text_pool_b16"):

@@ -160,6 +160,21 @@ def test_scoring_tail_with_fewer_proposals_than_k(golden_dir):
         assert O.compute_iou(masks[ifin], gt) == tuple(int(v) for v in g[f"s{step}_IU"])
 
 
+def test_scoring_tail_with_exact_ties(golden_dir):
+    """tests/golden/scoring_ties.npz: the reference's tail on refs whose proposals contain exact copies (2-4 identical
+    feature rows / masks / boxes): pins which of the equal candidates torch.argmax / torch.topk return"""
+    from oracle.cases import TIE_PLAN, tie_case
+    g = _load(golden_dir, "scoring_ties.npz")
+    ls = float(_load(golden_dir, "scoring.npz")["cs_logit_scale"])
+    for step, (ci, dup, rela, dirflag, has_other) in enumerate(TIE_PLAN):
+        hybrid, t_pos, t_neg, masks, boxes, attn, gt = tie_case(ci, dup)
+        black = 1.95 if rela == "big" else (1.5 if rela == "small" else 1.8)
+        gem = O.coherence_scores(attn, masks, dirflag, black)
+        ip, ifin, _, _ = O.score_sentence(hybrid, t_pos, t_neg, boxes, gem, ls, 3, 6, 0.6, rela, has_other)
+        assert [ip, ifin] == [int(v) for v in g[f"t{step}_idx"]], step
+        assert O.compute_iou(masks[ifin], gt) == tuple(int(v) for v in g[f"t{step}_IU"])
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_view_synthesis_vs_reference_loop(golden_dir, tag):
     """tests/golden/views.npz = the loop of Hybridgl_main.py:93-125 with its torch arithmetic (ToTensor / Resize / Normalize)
