@@ -449,11 +449,14 @@ __global__ __launch_bounds__(256) void score_sentence_kernel(
     for (int i = 0; i < k1; ++i) { tf[i] = ts[i]; mx = fmaxf(mx, tf[i]); }
     float den = 0.f;
     for (int i = 0; i < k1; ++i) { tf[i] = expf(tf[i] - mx); den += tf[i]; }
+    // torch.argmax's order: a NaN is larger than every number and the FIRST of equal maxima (or NaNs) wins -- a NaN coherence
+    // score (an empty or full proposal mask, a constant heat-map: 0/0 in Hybridgl_main.py:203-223) among the top-k decides
+    // the reference's answer (tests/golden/scoring_nan.npz)
     int best = 0;
-    float bv = -INFINITY;
+    float bv = 0.f;
     for (int i = 0; i < k1; ++i) {
       const float v = (tf[i] / den) * (1.f - alpha) + alpha * gem[top1[i]];
-      if (v > bv) { bv = v; best = i; }
+      if (i == 0 || v > bv || (v != v && bv == bv)) { bv = v; best = i; }
     }
     idx[1] = top1[best];
   }

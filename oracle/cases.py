@@ -103,3 +103,31 @@ def tie_case(ci, dup):
 
 TIE_PLAN = [(0, (2, 5), "none", "none", False), (1, (0, 7, 9), "left", "left", True), (2, (4, 1), "big", "middle", True),
             (3, (11, 3, 6), "within", "right", False), (4, (8, 10), "small", "none", True), (5, (1, 2, 3, 4), "up", "left", False)]
+
+
+def nan_case(kind):
+    """tail_case(0) pushed into the divisions by zero of Hybridgl_main.py:203-223: a constant heat-map (min-max = 0/0: every
+    coherence score NaN), a proposal with an EMPTY mask (sum = 0) or a FULL mask ((1 - m).sum() = 0) -- also as the
+    proposal with the best CLIP score, so that the NaN reaches the blended top-k scores and torch.argmax's NaN rule decides"""
+    import numpy as np
+    hybrid, t_pos, t_neg, masks, boxes, attn, gt = tail_case(0, 12, 32, 96, 128)
+    masks = masks.copy()
+    hn = hybrid / np.linalg.norm(hybrid, axis=1, keepdims=True)
+    top = int(np.argmax(hn @ (t_pos[0] / np.linalg.norm(t_pos[0]))))
+    if kind == "const_attn":
+        attn = np.full_like(attn, 0.5)
+    elif kind == "empty_mask":
+        masks[3] = 0
+    elif kind == "full_mask":
+        masks[4] = 1
+    elif kind == "empty_top":
+        masks[top] = 0
+    elif kind == "full_top":
+        masks[top] = 1
+    else:
+        raise ValueError(kind)
+    return hybrid, t_pos, t_neg, masks, boxes, attn, gt
+
+
+NAN_PLAN = [("const_attn", "none", "none", False), ("empty_mask", "none", "none", False), ("full_mask", "big", "middle", True),
+            ("empty_top", "none", "none", False), ("empty_top", "left", "left", True), ("full_top", "small", "right", False)]

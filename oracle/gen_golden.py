@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from hybridgl_amd import weights  # noqa: E402
 from hybridgl_amd.synth import synth_masks, synth_image  # noqa: E402
-from oracle.cases import edge_masks, views_for_case, resize_case, RESIZE_CASES, tail_case, tie_case, TIE_PLAN  # noqa: E402
+from oracle.cases import edge_masks, views_for_case, resize_case, RESIZE_CASES, tail_case, tie_case, TIE_PLAN, nan_case, NAN_PLAN  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -342,6 +342,26 @@ def gen_scoring_ties():
     np.savez_compressed(os.path.join(GOLD, "scoring_ties.npz"), **out)
 
 
+def gen_scoring_nan():
+    """Tail goldens for the divisions by zero of Hybridgl_main.py:203-223 (constant heat-map, empty / full proposal masks,
+    also as the best-scoring proposal): which index the reference reports when NaNs reach its soft-max / arg-max."""
+    sys.path.insert(0, REF)
+    utils = _load("ref_utils", os.path.join(REF, "utils.py"))
+    bb = build_ref_backbone("tiny", 0)
+    out = {}
+    import warnings
+    for step, (kind, rela, dirflag, has_other) in enumerate(NAN_PLAN):
+        hybrid, t_pos, t_neg, masks, boxes, attn, gt = nan_case(kind)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ip, ifin, iu, _, _, gem = ref_tail(bb, utils, hybrid, t_pos, t_neg, masks, boxes, attn, gt, rela, dirflag, has_other, 3, 6)
+        out[f"n{step}_idx"] = np.array([ip, ifin], dtype=np.int64)
+        out[f"n{step}_IU"] = np.array(iu, dtype=np.int64)
+        out[f"n{step}_gem_nan"] = np.isnan(gem)
+        print("nan tail", step, kind, rela, dirflag, has_other, ip, ifin, int(np.isnan(gem).sum()))
+    np.savez_compressed(os.path.join(GOLD, "scoring_nan.npz"), **out)
+
+
 def gen_views():
     """Hybridgl_main.py:93-125 (the per-mask local / global view loop) with everything that CAN be pinned offline pinned:
     the loop's statements are kept one for one; cv2.bitwise_and / cv2.add are their documented uint8 semantics in numpy
@@ -635,6 +655,8 @@ if __name__ == "__main__":
         gen_scoring_small()
     if want("scoring_ties"):
         gen_scoring_ties()
+    if want("scoring_nan"):
+        gen_scoring_nan()
     if want("text_pool_tiny"):
         gen_text_pool("tiny", 0, "text_pool_tiny", [1, 2])
     if want("text_pool_b16"):

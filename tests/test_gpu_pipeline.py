@@ -109,6 +109,24 @@ def test_exact_score_ties_vs_reference_golden(cuda, golden_dir):
         assert [int(v) for v in pipe.partial_rows()[-1][4:6]] == [int(v) for v in g[f"t{step}_IU"]], step
 
 
+def test_divisions_by_zero_vs_reference_golden(cuda, golden_dir):
+    """tests/golden/scoring_nan.npz: constant heat-map, empty / full proposal masks (also as the best-scoring proposal): the
+    device's fused coherence + scoring kernels must report the indices the reference reports when NaNs reach its arg-max"""
+    from hybridgl_amd.pipeline import RefBatch, Sentence
+    from oracle.cases import NAN_PLAN, nan_case
+    g = np.load(os.path.join(golden_dir, "scoring_nan.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    for step, (kind, rela, dirflag, has_other) in enumerate(NAN_PLAN):
+        pipe = _tiny(cuda, k_clamp="per_ref")
+        hybrid, t_pos, t_neg, masks, boxes, attn, gt = nan_case(kind)
+        text = t(np.concatenate([t_pos, t_pos, t_neg], axis=0))
+        sent = Sentence(0, 1, [2], dirflag, rela, 1 if has_other else 0, t(attn))
+        ref = RefBatch(None, None, None, t(masks), t(boxes), None, t(gt), [sent], index=step)
+        idx = pipe._score_ref(ref, t(hybrid), text, None)[0]
+        assert [int(v) for v in idx.cpu()] == [int(v) for v in g[f"n{step}_idx"]], (step, kind)
+        assert [int(v) for v in pipe.partial_rows()[-1][4:6]] == [int(v) for v in g[f"n{step}_IU"]], (step, kind)
+
+
 def test_clamp_is_per_rank_under_sharding(cuda):
     """Documented deviation: with k_clamp="persistent" the quirk acts on the items of ONE process in its
     own order.  Two 'ranks' that split [12, 2, 12, 12] proposals as (0, 2) / (1, 3) clamp only rank 1's later item; the

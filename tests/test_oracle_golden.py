@@ -175,6 +175,25 @@ def test_scoring_tail_with_exact_ties(golden_dir):
         assert O.compute_iou(masks[ifin], gt) == tuple(int(v) for v in g[f"t{step}_IU"])
 
 
+def test_scoring_tail_divisions_by_zero(golden_dir):
+    """tests/golden/scoring_nan.npz: constant heat-map (0/0 in the min-max), empty and full proposal masks (x/0 in the
+    coherence terms), also as the best-scoring proposal: the reference's winners when NaNs reach its arg-max"""
+    import warnings
+    from oracle.cases import NAN_PLAN, nan_case
+    g = _load(golden_dir, "scoring_nan.npz")
+    ls = float(_load(golden_dir, "scoring.npz")["cs_logit_scale"])
+    for step, (kind, rela, dirflag, has_other) in enumerate(NAN_PLAN):
+        hybrid, t_pos, t_neg, masks, boxes, attn, gt = nan_case(kind)
+        black = 1.95 if rela == "big" else (1.5 if rela == "small" else 1.8)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            gem = O.coherence_scores(attn, masks, dirflag, black)
+            ip, ifin, _, _ = O.score_sentence(hybrid, t_pos, t_neg, boxes, gem, ls, 3, 6, 0.6, rela, has_other)
+        assert np.array_equal(np.isnan(gem), g[f"n{step}_gem_nan"]), (step, kind)
+        assert [ip, ifin] == [int(v) for v in g[f"n{step}_idx"]], (step, kind)
+        assert O.compute_iou(masks[ifin], gt) == tuple(int(v) for v in g[f"n{step}_IU"])
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_view_synthesis_vs_reference_loop(golden_dir, tag):
     """tests/golden/views.npz = the loop of Hybridgl_main.py:93-125 with its torch arithmetic (ToTensor / Resize / Normalize)
