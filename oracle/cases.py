@@ -124,10 +124,19 @@ def nan_case(kind):
         masks[top] = 0
     elif kind == "full_top":
         masks[top] = 1
+    elif kind == "zero_box_top":      # relation "within" divides by the area of box i (utils.py:262): 0/0 or x/0
+        boxes = boxes.copy()
+        boxes[top, 2:] = 0
+    elif kind == "zero_box_other":
+        boxes = boxes.copy()
+        boxes[(top + 1) % len(boxes), 2] = 0
+        boxes[(top + 5) % len(boxes), 3] = 0
     else:
         raise ValueError(kind)
     return hybrid, t_pos, t_neg, masks, boxes, attn, gt
 
 
 NAN_PLAN = [("const_attn", "none", "none", False), ("empty_mask", "none", "none", False), ("full_mask", "big", "middle", True),
-            ("empty_top", "none", "none", False), ("empty_top", "left", "left", True), ("full_top", "small", "right", False)]
+            ("empty_top", "none", "none", False), ("empty_top", "left", "left", True), ("full_top", "small", "right", False),
+            ("zero_box_top", "within", "none", False), ("zero_box_top", "within", "left", True), ("zero_box_other", "within", "none", True),
+            ("zero_box_top", "big", "none", False)]
