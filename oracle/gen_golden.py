@@ -305,14 +305,15 @@ def ref_tail(bb, utils, hybrid, t_pos, t_neg, masks, boxes, attn, gt, rela, dirf
 
 def gen_scoring_small():
     """Tail goldens with FEWER proposals than k1 = 3 / k2 = 6 (Hybridgl_main.py:178-181: the clamp, which the reference
-    never undoes): a sequence of refs with N = 12, 5, 12, 2, 12 proposals run with the k1 / k2 carried from ref to ref,
+    never undoes): a sequence of refs with N = 12, 5, 12, 2, 12, 2, 1, 12, 1 proposals run with the k1 / k2 carried from ref to ref,
     exactly as the reference's loop does."""
     sys.path.insert(0, REF)
     utils = _load("ref_utils", os.path.join(REF, "utils.py"))
     bb = build_ref_backbone("tiny", 0)
     out = {}
     plan = [(0, 12, "none", "none", False), (1, 5, "left", "left", True), (2, 12, "big", "middle", True),
-            (3, 2, "within", "right", True), (4, 12, "small", "none", False), (5, 2, "none", "left", False)]
+            (3, 2, "within", "right", True), (4, 12, "small", "none", False), (5, 2, "none", "left", False),
+            (6, 1, "left", "left", True), (7, 12, "within", "middle", True), (8, 1, "none", "none", False)]
     k1, k2 = 3, 6
     for step, (ci, N, rela, dirflag, has_other) in enumerate(plan):
         hybrid, t_pos, t_neg, masks, boxes, attn, gt = tail_case(ci, N, 32, 96, 128)
