@@ -126,6 +126,26 @@ def gen_clip(cfg_name, seed, Ns, H, W, modes, tag):
     np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
 
 
+MB_PLAN = [(None, MODES), (0, MODES), (1, MODES), (10, MODES), (11, ["G2L", "L2G", "G2L&L2G", "token_masking", "crop"])]
+
+
+def gen_clip_mb(tag="clip_tiny_mb"):
+    """CLIPViTFM.forward on the tiny geometry (12 blocks, last_layer 10) with masking_block at the ends of its range: None
+    (= last_layer), 0, 1, last_layer and last_layer + 1 (where the reference still returns features: not attn_masking,
+    whose return sits at block last_layer, model/backbone.py:197-203)."""
+    model = build_ref_backbone("tiny", 0)
+    loc, glo, masks = views_for_case(3, 64, 97, 130)
+    out = {"last_layer": np.array([model.last_layer], dtype=np.int64)}
+    for mb, modes in MB_PLAN:
+        for mode in modes:
+            with torch.no_grad():
+                y = model(local_imgs=torch.from_numpy(loc), global_imgs=torch.from_numpy(glo), pred_masks=torch.from_numpy(masks),
+                          fusion_mode=mode, masking_block=mb)
+            out[f"mb{mb}_{mode}"] = y.numpy().astype(np.float32)
+            print(tag, mb, mode, y.shape)
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+
+
 def gen_text(cfg_name, seed, tag):
     model = build_ref_clip(cfg_name, seed)
     cfg = weights.CLIP_CONFIGS[cfg_name]
@@ -644,6 +664,8 @@ if __name__ == "__main__":
     want = lambda k: sel is None or k in sel
     if want("clip_tiny"):
         gen_clip("tiny", 0, [1, 3, 5], 97, 130, MODES, "clip_tiny")
+    if want("clip_tiny_mb"):
+        gen_clip_mb()
     if want("clip_b16"):
         gen_clip("ViT-B/16", 0, [4], 640, 640, ["G2L", "L2G", "G2L&L2G"], "clip_b16")
     if want("text_tiny"):

@@ -76,6 +76,22 @@ def test_other_clip_geometries_vs_oracle(cuda, name, last_layer, mb):
     torch.cuda.empty_cache()
 
 
+def test_tiny_masking_block_range_vs_reference_golden(cuda, golden_dir, tiny):
+    """tests/golden/clip_tiny_mb.npz: masking_block None (= last_layer), 0, 1, last_layer, last_layer + 1 in every mode in
+    which the reference returns features; beyond that range the library refuses (the reference returns un-normalised
+    tokens or crashes there)."""
+    g = np.load(os.path.join(golden_dir, "clip_tiny_mb.npz"))
+    loc, glo, masks = views_for_case(3, 64, 97, 130)
+    for k in [k for k in g.files if k.startswith("mb")]:
+        mb, mode = k[2:].split("_", 1)
+        y = _run(tiny[1], loc, glo, masks, mode, cuda, None if mb == "None" else int(mb))
+        np.testing.assert_allclose(y, g[k], rtol=0, atol=5e-5, err_msg=k)
+    from hybridgl_amd._lib import HybridGLError
+    for mb, mode in ((12, "G2L"), (11, "attn_masking"), (13, "token_masking")):
+        with pytest.raises(HybridGLError):
+            _run(tiny[1], loc, glo, masks, mode, cuda, mb)
+
+
 @pytest.mark.parametrize("mb", [0, 5, 11])
 def test_tiny_other_masking_blocks_vs_oracle(cuda, tiny, mb):
     loc, glo, masks = views_for_case(3, 64, 97, 130)

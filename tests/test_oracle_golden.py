@@ -38,6 +38,22 @@ def test_clip_tiny_all_modes(golden_dir, N, mode):
     np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5)
 
 
+def test_clip_tiny_masking_block_range(golden_dir):
+    """tests/golden/clip_tiny_mb.npz: the reference's forward with masking_block None (= last_layer), 0, 1, last_layer and
+    last_layer + 1 in every mode in which it returns features"""
+    g = _load(golden_dir, "clip_tiny_mb.npz")
+    last = int(g["last_layer"][0])
+    sd = weights.clip_state_dict("tiny", 0)
+    loc, glo, masks = views_for_case(3, 64, 97, 130)
+    keys = [k for k in g.files if k.startswith("mb")]
+    assert len(keys) == 29
+    for k in keys:
+        mb, mode = k[2:].split("_", 1)
+        mb = last if mb == "None" else int(mb)
+        y = O.clip_hybrid_forward(sd, loc, glo, masks, masking_block=mb, fusion_mode=mode, last_layer=last)
+        np.testing.assert_allclose(y, g[k], rtol=0, atol=2e-5, err_msg=k)
+
+
 @pytest.mark.parametrize("mode", ["G2L", "L2G", "G2L&L2G"])
 def test_clip_b16(golden_dir, mode):
     g = _load(golden_dir, "clip_b16.npz")
