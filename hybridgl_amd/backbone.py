@@ -250,16 +250,16 @@ class CLIPViTFM:
         N = local_imgs.shape[0]
         res = self.model.cfg["image_resolution"]
         assert tuple(local_imgs.shape[1:]) == (3, res, res), "local_imgs must be [N,3,res,res]"
-        local_imgs = local_imgs.contiguous()
+        local_imgs = local_imgs.to(torch.float32).contiguous()      # x.type(self.model.dtype), model/backbone.py:123
         lp = ops._dev(local_imgs, torch.float32, "local_imgs")
         gp = None
         if global_imgs is not None:
-            assert global_imgs.shape == local_imgs.shape
-            global_imgs = global_imgs.contiguous()
+            assert global_imgs.shape == local_imgs.shape, "global_imgs must have the shape of local_imgs"
+            global_imgs = global_imgs.to(torch.float32).contiguous()
             gp = ops._dev(global_imgs, torch.float32, "global_imgs")
         mp, Hm, Wm = None, 0, 0
         if pred_masks is not None:
-            assert pred_masks.shape[0] == N
+            assert pred_masks.shape[0] == N, "one mask per image row"
             Hm, Wm = pred_masks.shape[1:]
             pm = pred_masks if pred_masks.dtype in (torch.bool, torch.uint8) else (pred_masks != 0)
             mp, pm = ops._u8(pm.contiguous(), "pred_masks")

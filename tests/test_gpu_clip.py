@@ -267,6 +267,30 @@ def test_cv2_fixed_point_blur_bit_exact_vs_oracle(cuda, H, W, k):
     assert np.array_equal(ops.gaussian_blur_u8(torch.from_numpy(flat).to(cuda), k).cpu().numpy(), flat)
 
 
+def test_forward_accepts_what_the_reference_accepts(cuda, tiny):
+    """model/backbone.py:123,160 cast whatever comes in (`x.type(self.model.dtype)`, `pred_masks.type(torch.float32)`): image
+    tensors of another float type, non-contiguous views, masks as bool / uint8 / int64 / float {0, 1} give the same features;
+    host tensors and unknown modes are refused with a message (no CPU path exists)."""
+    from hybridgl_amd._lib import HybridGLError
+    loc, glo, masks = views_for_case(3, 64, 97, 130)
+    L, G, M = T(loc, cuda), T(glo, cuda), T(masks, cuda)
+    base = tiny[1](L, G, M, masking_block=9, fusion_mode="G2L")
+    for Mx in (M.bool(), M.to(torch.uint8), M.long(), M.float()):
+        assert torch.equal(tiny[1](L, G, Mx, masking_block=9, fusion_mode="G2L"), base)
+    Ln = L.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    assert not Ln.is_contiguous() and torch.equal(tiny[1](Ln, G, M, masking_block=9, fusion_mode="G2L"), base)
+    assert torch.equal(tiny[1](L.double(), G.double(), M, masking_block=9, fusion_mode="G2L"), base)
+    y16 = tiny[1](L.half(), G.half(), M, masking_block=9, fusion_mode="G2L")      # the inputs were rounded to fp16 by the caller
+    assert torch.isfinite(y16).all() and float((y16 - base).abs().max()) < 0.05
+    with pytest.raises(HybridGLError):
+        tiny[1](L.cpu(), G.cpu(), M.cpu(), masking_block=9, fusion_mode="G2L")
+    with pytest.raises(HybridGLError):
+        tiny[1](L, None, M, masking_block=9, fusion_mode="G2L")
+    with pytest.raises(ValueError):
+        tiny[1](L, G, M, masking_block=9, fusion_mode="nope")
+    assert tiny[1](L, None, M, fusion_mode="crop").shape == base.shape
+
+
 def test_reference_named_helpers_vs_golden(cuda, golden_dir):
     """hybridgl_amd.utils.{gen_dir_mask, relation_boxes, Compute_IoU}: the reference's utils.py names, device
     arithmetic, against the vectors captured from the reference (tests/golden/scoring.npz)."""
