@@ -388,6 +388,10 @@ def test_remove_small_regions_vs_oracle(cuda, mode):
     masks[4] = True                                    # full
     masks[5] = False; masks[5, 10:13, 10:13] = True; masks[5, 40:43, 40:43] = True   # tie: equal areas
     masks[6, ::2, ::2] = False                         # checkerboard holes inside the blob (diagonal links)
+    # the threshold is strict (amg.py: `s < area_thresh`): a component of EXACTLY 20 pixels stays, one of 19 goes
+    masks[7] = False; masks[7, 20:70, 20:90] = True
+    masks[7, 2:6, 2:7] = True; masks[7, 2:6, 100:105] = True; masks[7, 5, 104] = False          # islands of 20 and 19
+    masks[7, 30:34, 30:35] = False; masks[7, 50:54, 60:65] = False; masks[7, 53, 64] = True     # holes of 20 and 19
     out, changed = hsam.remove_small_regions(T(masks.astype(np.uint8), cuda), 20, mode)
     out, changed = out.cpu().numpy().astype(bool), changed.cpu().numpy()
     for i in range(len(masks)):
