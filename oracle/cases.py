@@ -140,3 +140,13 @@ NAN_PLAN = [("const_attn", "none", "none", False), ("empty_mask", "none", "none"
             ("empty_top", "none", "none", False), ("empty_top", "left", "left", True), ("full_top", "small", "right", False),
             ("zero_box_top", "within", "none", False), ("zero_box_top", "within", "left", True), ("zero_box_other", "within", "none", True),
             ("zero_box_top", "big", "none", False)]
+
+
+# (case id, number of other nouns, relation word, direction flag): the text glue of Hybridgl_main.py:146-165 --
+# r * sentence + (1 - r) * noun phrase, the MEAN of the other nouns' features (zeros when there are none)
+GLUE_PLAN = [(20, 0, "none", "none"), (21, 1, "left", "left"), (22, 2, "big", "middle"), (23, 3, "within", "right"), (24, 1, "small", "none")]
+
+
+def glue_tokens(ci, n_other):
+    from hybridgl_amd import synth
+    return synth.synth_tokens(2 + n_other, 16, 512, 7000 + ci)

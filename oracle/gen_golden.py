@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from hybridgl_amd import weights  # noqa: E402
 from hybridgl_amd.synth import synth_masks, synth_image  # noqa: E402
-from oracle.cases import edge_masks, views_for_case, resize_case, RESIZE_CASES, tail_case, tie_case, TIE_PLAN, nan_case, NAN_PLAN  # noqa: E402
+from oracle.cases import edge_masks, views_for_case, resize_case, RESIZE_CASES, tail_case, tie_case, TIE_PLAN, nan_case, NAN_PLAN, GLUE_PLAN, glue_tokens  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -363,6 +363,44 @@ def gen_scoring_ties():
     np.savez_compressed(os.path.join(GOLD, "scoring_ties.npz"), **out)
 
 
+def gen_tail_glue():
+    """The text glue in front of the tail, statement for statement (Hybridgl_main.py:146-165): sentence and noun phrase
+    encoded separately and mixed with r, every other noun encoded and AVERAGED into one negative feature (zeros when the
+    sentence has none), then the tail as in ref_tail.  Pins the device kernel's own ensemble / mean against the reference's."""
+    sys.path.insert(0, REF)
+    utils = _load("ref_utils", os.path.join(REF, "utils.py"))
+    bb = build_ref_backbone("tiny", 0)
+    r = 0.5
+    out = {"r": np.array([r], dtype=np.float32)}
+    for ci, n_other, rela, dirflag in GLUE_PLAN:
+        hybrid, _, _, masks, boxes, attn, gt = tail_case(ci, 12, 32, 96, 128)
+        tok = torch.from_numpy(glue_tokens(ci, n_other).astype(np.int64))
+        with torch.no_grad():
+            sentence_features = bb.model.encode_text(tok[0:1])
+            noun_phrase_features = bb.model.encode_text(tok[1:2])
+            text_ensemble = r * sentence_features + (1 - r) * noun_phrase_features
+            other_noun_features = torch.zeros(1, sentence_features.shape[1])
+            cnt = 0
+            for j in range(n_other):
+                other_noun_features += bb.model.encode_text(tok[2 + j:3 + j])
+                cnt += 1
+            if cnt != 0:
+                other_noun_features = other_noun_features / cnt
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ip, ifin, iu, _, _, gem = ref_tail(bb, utils, hybrid, text_ensemble.numpy(), other_noun_features.numpy(), masks, boxes, attn,
+                                                   gt, rela, dirflag, n_other > 0, 3, 6)
+                sc = torch.nn.Softmax(0)(bb.calculate_score(torch.from_numpy(hybrid), text_ensemble)).numpy()
+        out[f"g{ci}_idx"] = np.array([ip, ifin], dtype=np.int64)
+        out[f"g{ci}_IU"] = np.array(iu, dtype=np.int64)
+        out[f"g{ci}_score_clip"] = sc.astype(np.float32)
+        out[f"g{ci}_ensemble"] = text_ensemble.numpy().astype(np.float32)
+        out[f"g{ci}_other"] = other_noun_features.numpy().astype(np.float32)
+        print("tail glue", ci, n_other, rela, dirflag, ip, ifin)
+    np.savez_compressed(os.path.join(GOLD, "tail_glue.npz"), **out)
+
+
 def gen_scoring_nan():
     """Tail goldens for the divisions by zero of Hybridgl_main.py:203-223 (constant heat-map, empty / full proposal masks,
     also as the best-scoring proposal): which index the reference reports when NaNs reach its soft-max / arg-max."""
@@ -680,6 +718,8 @@ if __name__ == "__main__":
         gen_scoring_ties()
     if want("scoring_nan"):
         gen_scoring_nan()
+    if want("tail_glue"):
+        gen_tail_glue()
     if want("text_pool_tiny"):
         gen_text_pool("tiny", 0, "text_pool_tiny", [1, 2])
     if want("text_pool_b16"):

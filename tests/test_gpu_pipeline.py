@@ -109,6 +109,27 @@ def test_exact_score_ties_vs_reference_golden(cuda, golden_dir):
         assert [int(v) for v in pipe.partial_rows()[-1][4:6]] == [int(v) for v in g[f"t{step}_IU"]], step
 
 
+def test_text_glue_vs_reference_golden(cuda, golden_dir):
+    """tests/golden/tail_glue.npz: sentence / noun phrase / 0..3 other nouns as TOKENS; the reference encodes them, mixes
+    r * sentence + (1 - r) * noun phrase, averages the other nouns (Hybridgl_main.py:146-165) and runs its tail.  The
+    device text encoder + score_sentence_kernel (which does the mix and the mean itself) must pick the same masks and
+    agree on the soft-maxed scores."""
+    from hybridgl_amd.pipeline import RefBatch, Sentence
+    from oracle.cases import GLUE_PLAN, glue_tokens, tail_case
+    g = np.load(os.path.join(golden_dir, "tail_glue.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    for ci, n_other, rela, dirflag in GLUE_PLAN:
+        pipe = _tiny(cuda, k_clamp="per_ref", r=float(g["r"][0]))
+        hybrid, _, _, masks, boxes, attn, gt = tail_case(ci, 12, 32, 96, 128)
+        text = pipe.model.model.encode_text(t(glue_tokens(ci, n_other)))
+        sent = Sentence(0, 1, list(range(2, 2 + n_other)), dirflag, rela, n_other, t(attn))
+        ref = RefBatch(None, None, None, t(masks), t(boxes), None, t(gt), [sent], index=ci)
+        idx, sc, _, _ = pipe._score_ref(ref, t(hybrid), text, None)
+        assert [int(v) for v in idx.cpu()] == [int(v) for v in g[f"g{ci}_idx"]], ci
+        np.testing.assert_allclose(torch.softmax(sc.reshape(-1), 0).cpu().numpy(), g[f"g{ci}_score_clip"][:, 0], rtol=0, atol=2e-6)   # sc: logits
+        assert [int(v) for v in pipe.partial_rows()[-1][4:6]] == [int(v) for v in g[f"g{ci}_IU"]], ci
+
+
 def test_divisions_by_zero_vs_reference_golden(cuda, golden_dir):
     """tests/golden/scoring_nan.npz: constant heat-map, empty / full proposal masks (also as the best-scoring proposal): the
     device's fused coherence + scoring kernels must report the indices the reference reports when NaNs reach its arg-max"""

@@ -191,6 +191,37 @@ def test_scoring_tail_with_exact_ties(golden_dir):
         assert O.compute_iou(masks[ifin], gt) == tuple(int(v) for v in g[f"t{step}_IU"])
 
 
+def test_tail_text_glue(golden_dir):
+    """tests/golden/tail_glue.npz: the statements in front of the tail (Hybridgl_main.py:146-165) run by the reference --
+    r * sentence + (1 - r) * noun phrase, the mean of 0..3 other-noun features -- then its tail: the oracle's text encoder +
+    the same glue + score_sentence"""
+    import warnings
+    from oracle.cases import GLUE_PLAN, glue_tokens
+    g = _load(golden_dir, "tail_glue.npz")
+    r = float(g["r"][0])
+    sd = weights.clip_state_dict("tiny", 0)
+    ls = float(np.exp(sd["logit_scale"]))
+    for ci, n_other, rela, dirflag in GLUE_PLAN:
+        hybrid, _, _, masks, boxes, attn, gt = tail_case(ci, 12, 32, 96, 128)
+        feats = O.encode_text(sd, glue_tokens(ci, n_other))
+        ens = (np.float32(r) * feats[0:1] + np.float32(1 - r) * feats[1:2]).astype(np.float32)
+        other = np.zeros((1, feats.shape[1]), dtype=np.float32)
+        for j in range(n_other):
+            other = other + feats[2 + j:3 + j]
+        if n_other:
+            other = other / np.float32(n_other)
+        np.testing.assert_allclose(ens, g[f"g{ci}_ensemble"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(other, g[f"g{ci}_other"], rtol=0, atol=2e-5)
+        black = 1.95 if rela == "big" else (1.5 if rela == "small" else 1.8)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            gem = O.coherence_scores(attn, masks, dirflag, black)
+            ip, ifin, sc, _ = O.score_sentence(hybrid, ens, other, boxes, gem, ls, 3, 6, 0.6, rela, n_other > 0)
+        np.testing.assert_allclose(O.softmax(sc, 0), g[f"g{ci}_score_clip"][:, 0], rtol=0, atol=2e-6)   # sc: the logits
+        assert [ip, ifin] == [int(v) for v in g[f"g{ci}_idx"]], ci
+        assert O.compute_iou(masks[ifin], gt) == tuple(int(v) for v in g[f"g{ci}_IU"])
+
+
 def test_scoring_tail_divisions_by_zero(golden_dir):
     """tests/golden/scoring_nan.npz: constant heat-map (0/0 in the min-max), empty and full proposal masks (x/0 in the
     coherence terms), also as the best-scoring proposal: the reference's winners when NaNs reach its arg-max"""
