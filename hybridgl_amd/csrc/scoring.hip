@@ -359,27 +359,34 @@ __global__ __launch_bounds__(256) void score_sentence_kernel(
   __syncthreads();
   __threadfence_block();
 
-  // softmax over masks of both logit vectors + argmax of score_clip
+  // softmax over masks of both logit vectors + argmax of score_clip.  torch.argmax's order: a NaN is larger than every
+  // number, the first of equal maxima (or NaNs) wins; a NaN maximum then makes the whole soft-max NaN, as torch's does.
+  auto better = [](float v, int n, float mx, int mi) {
+    const bool vn = v != v, mn = mx != mx;
+    if (vn != mn) return vn;
+    if (vn) return n < mi;
+    return v > mx || (v == mx && n < mi);
+  };
   for (int which = 0; which < 2; ++which) {
     const float* lg = which == 0 ? score_clip : score_neg;
     float mx = -INFINITY;
     int mi = 0x7fffffff;
     for (int n = t; n < N; n += 256) {
       const float v = lg[n];
-      if (v > mx || (v == mx && n < mi)) { mx = v; mi = n; }
+      if (better(v, n, mx, mi)) { mx = v; mi = n; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(mx, o);
       const int oi = __shfl_xor(mi, o);
-      if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+      if (better(ov, oi, mx, mi)) { mx = ov; mi = oi; }
     }
     if (lane == 0) { red[wave] = mx; redi[wave] = mi; }
     __syncthreads();
     float gmx = red[0];
     int gmi = redi[0];
     for (int w = 1; w < 4; ++w)
-      if (red[w] > gmx || (red[w] == gmx && redi[w] < gmi)) { gmx = red[w]; gmi = redi[w]; }
+      if (better(red[w], redi[w], gmx, gmi)) { gmx = red[w]; gmi = redi[w]; }
     __syncthreads();
     if (which == 0 && t == 0) idx[0] = gmi == 0x7fffffff ? 0 : gmi;   // all-NaN logits (a NaN text feature): a valid index, NaN scores
     float se = 0.f;

@@ -127,6 +127,13 @@ def nan_case(kind):
     elif kind == "zero_box_top":      # relation "within" divides by the area of box i (utils.py:262): 0/0 or x/0
         boxes = boxes.copy()
         boxes[top, 2:] = 0
+    elif kind == "nan_row":           # one proposal's feature row is NaN: torch.argmax answers with that proposal
+        hybrid = hybrid.copy()
+        hybrid[5, 4] = np.nan
+    elif kind == "nan_rows2":
+        hybrid = hybrid.copy()
+        hybrid[7, 2] = np.nan
+        hybrid[2, 9] = np.nan
     elif kind == "zero_box_other":
         boxes = boxes.copy()
         boxes[(top + 1) % len(boxes), 2] = 0
@@ -139,7 +146,10 @@ def nan_case(kind):
 NAN_PLAN = [("const_attn", "none", "none", False), ("empty_mask", "none", "none", False), ("full_mask", "big", "middle", True),
             ("empty_top", "none", "none", False), ("empty_top", "left", "left", True), ("full_top", "small", "right", False),
             ("zero_box_top", "within", "none", False), ("zero_box_top", "within", "left", True), ("zero_box_other", "within", "none", True),
-            ("zero_box_top", "big", "none", False)]
+            ("zero_box_top", "big", "none", False),
+            # NaN FEATURES: only the pure-CLIP index is defined (first NaN); every soft-maxed score is NaN after that and
+            # which entries torch.topk returns for an all-NaN vector is an implementation detail -- tests compare idx[0] only
+            ("nan_row", "none", "none", False), ("nan_rows2", "left", "left", True)]
 
 
 # (case id, number of other nouns, relation word, direction flag): the text glue of Hybridgl_main.py:146-165 --

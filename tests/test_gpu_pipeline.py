@@ -144,6 +144,9 @@ def test_divisions_by_zero_vs_reference_golden(cuda, golden_dir):
         sent = Sentence(0, 1, [2], dirflag, rela, 1 if has_other else 0, t(attn))
         ref = RefBatch(None, None, None, t(masks), t(boxes), None, t(gt), [sent], index=step)
         idx = pipe._score_ref(ref, t(hybrid), text, None)[0]
+        if kind.startswith("nan_row"):      # NaN features: only the pure-CLIP index is defined (oracle/cases.py)
+            assert int(idx.cpu()[0]) == int(g[f"n{step}_idx"][0]), (step, kind)
+            continue
         assert [int(v) for v in idx.cpu()] == [int(v) for v in g[f"n{step}_idx"]], (step, kind)
         assert [int(v) for v in pipe.partial_rows()[-1][4:6]] == [int(v) for v in g[f"n{step}_IU"]], (step, kind)
 
