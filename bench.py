@@ -229,8 +229,9 @@ def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False, clip_na
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=24,
+                    help="timed steps (refs); the default is a whole number of groups of --sam-batch refs")
+    ap.add_argument("--warmup", type=int, default=8, help="untimed steps (refs); the default is one full group")
     ap.add_argument("--fusion", default="G2L", choices=["G2L", "L2G", "G2L&L2G"])
     ap.add_argument("--clip", default="ViT-B/16", choices=list(CLIP_GEOM),
                     help="CLIP geometry: ViT-B/16 = the reference's configuration; ViT-L/14 = the extension BASELINE.json names")
