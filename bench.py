@@ -229,9 +229,9 @@ def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False, clip_na
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24,
-                    help="timed steps (refs); the default is a whole number of groups of --sam-batch refs")
-    ap.add_argument("--warmup", type=int, default=8, help="untimed steps (refs); the default is one full group")
+    ap.add_argument("--steps", type=int, default=64,
+                    help="timed steps (refs); the default is a whole number of groups of --sam-batch images")
+    ap.add_argument("--warmup", type=int, default=16, help="untimed steps (refs); the default is two full groups")
     ap.add_argument("--fusion", default="G2L", choices=["G2L", "L2G", "G2L&L2G"])
     ap.add_argument("--clip", default="ViT-B/16", choices=list(CLIP_GEOM),
                     help="CLIP geometry: ViT-B/16 = the reference's configuration; ViT-L/14 = the extension BASELINE.json names")
@@ -239,8 +239,8 @@ def main():
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic refs resident per rank (a group of 8 = 8 different images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="scope B: run the SAM stage and the CLIP stage back to back on one stream instead of "
-                         "overlapping ref i's CLIP stage with ref i+1's SAM stage on two streams")
+                    help="run the SAM stage and the CLIP stage of the loop back to back on one stream (HybridGLPipeline.run(serial=True)) "
+                         "instead of the SAM stage of group g+1 beside the CLIP stage of group g on two streams")
     ap.add_argument("--heatmap", default="device", choices=["device", "given"],
                     help="device: the GEM heat-map stage (ViT-B/16 at 448x448 with self-self attention, 3 prompts) runs "
                          "inside the step; given: seeded heat-maps are inputs (the stage is then outside the timed work)")
@@ -250,15 +250,21 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 path on a box "
                          "with fewer GPUs than ranks)")
     ap.add_argument("--sam-batch", type=int, default=8, choices=[1, 2, 4, 8, 16],
-                    help="largest group of refs the overlapped pipeline takes at a time: ONE SAM encoder pass over the images "
-                         "of the next group (token rows stacked, weights read once) under ONE text-encoder batch + ONE hybrid "
-                         "forward over the masks of the current group; same work and same results per ref (1: ref by ref)")
-    ap.add_argument("--no-clip-group", action="store_true",
-                    help="grouped steps: one text-encoder batch + one hybrid forward per ref instead of one for the group")
+                    help="images per group of the evaluation loop (HybridGLPipeline.run): ONE SAM encoder pass over the images of "
+                         "group g+1 (token rows stacked, weights read once) beside ONE text-encoder batch + ONE hybrid forward "
+                         "over the proposals of group g; same work and same results per ref (1: ref by ref, HybridGLPipeline.step)")
+    ap.add_argument("--proposals-from", default="sam", choices=["sam", "seeded"],
+                    help="sam (default): the CLIP stage scores SAM's OWN masks -- the first --masks survivors of the first NMS of "
+                         "every image go through the small-region clean-up and the second NMS into view synthesis and the hybrid "
+                         "forward, their counts are read back (two device->host copies per group); seeded: rounds 1-2's workload -- "
+                         "the SAM proposal kernels run and their output is discarded, the clean-up + CLIP stages take the items' "
+                         "seeded proposal-shaped masks (no count read-back)")
     ap.add_argument("--scope", default="B", choices=["A", "B"],
                     help="A: proposals given (CLIP + scoring only); B: + SAM ViT-H proposal stage (full path)")
     ap.add_argument("--no-also", action="store_true",
-                    help="skip the short secondary timings (G2L&L2G, ViT-L/14) that are attached under the `also` key at N = 1")
+                    help="skip the short secondary timings (seeded masks, L2G, G2L&L2G, strict fp32, ViT-L/14, PhraseCut) that are "
+                         "attached under the `also` key at N = 1")
+    ap.add_argument("--timeout", type=float, default=3600.0, help="--gpus N without a launcher: seconds before the ranks are killed")
     args = ap.parse_args()
 
     from hybridgl_amd import dist as D
@@ -273,47 +279,55 @@ def main():
             print(f"bench.py: {args.gpus} ranks on {ngpu} visible GPU(s): ranks share devices, metric exchange over gloo",
                   file=sys.stderr)
             argv += ["--backend", "gloo"]
-        sys.exit(D.spawn_local_ranks(args.gpus, argv))
+        sys.exit(D.spawn_local_ranks(args.gpus, argv, timeout=args.timeout))
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists)"
     ngpu = torch.cuda.device_count()
     local_dev = local_rank % ngpu      # identity on a node with one GPU per rank
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    cores = D.pin_rank_to_cores(local_rank, local_world)    # each rank's launch thread on its own share of the host cores
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         dist = D.init_process_group(args.backend, dev)
 
-    from hybridgl_amd import _lib
+    from hybridgl_amd import _lib, ops
     from hybridgl_amd.backbone import CLIPViTFM
     from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
 
     lib = _lib.load()
     geom = CLIP_GEOM[args.clip]
     model = CLIPViTFM(args.clip, seed=0, device=dev)
-    gen = None
+    gen = sam = None
+    dependent = args.scope == "B" and args.proposals_from == "sam"
+
+    def make_gen(sam_model):
+        from hybridgl_amd.sam import SamAutomaticMaskGenerator
+        # Hybridgl_main.py:67-73 (8x8 grid, no crops, min_mask_region_area=800).  With random weights the reference
+        # thresholds (0.7 / 0.7 / NMS 0.7) would keep an arbitrary number of proposals, so the benchmark opens the three
+        # filters ("AMG filters forced to keep a fixed 64", SURVEY.md 8d scope B): every candidate reaches the first NMS,
+        # the first --masks of its order go on.
+        return SamAutomaticMaskGenerator(sam_model, points_per_side=8, pred_iou_thresh=-1e30, stability_score_thresh=0.0,
+                                         box_nms_thresh=2.0, crop_n_layers=0, crop_n_points_downscale_factor=1,
+                                         min_mask_region_area=800)
     if args.scope == "B":
-        from hybridgl_amd.sam import SamAutomaticMaskGenerator, sam_model_registry
+        from hybridgl_amd.sam import sam_model_registry
         sam = sam_model_registry["default"](seed=0, device=dev)
-        # Hybridgl_main.py:67-73
-        # Hybridgl_main.py:67-73 (8x8 grid, no crops, min_mask_region_area=800).  With random weights the
-        # reference thresholds (0.7 / 0.7 / NMS 0.7) would keep an arbitrary number of proposals, so the
-        # benchmark opens the three filters and cleans up a FIXED 64 survivors (scope B):
-        # every kernel of the stage runs on the full-size work, with no host sync.
-        gen = SamAutomaticMaskGenerator(sam, points_per_side=8, pred_iou_thresh=-1e30, stability_score_thresh=0.0,
-                                        box_nms_thresh=2.0, crop_n_layers=0, crop_n_points_downscale_factor=1,
-                                        min_mask_region_area=800)
+        gen = make_gen(sam)
     use_gem = args.heatmap == "device"
     gem_model = None
     if use_gem:
         # Hybridgl_main.py:36-38: the same OpenAI ViT-B/16 checkpoint as the CLIP stage -> shared device weights
         from hybridgl_amd.gem import create_gem_model
         gem_model = create_gem_model(args.clip, clip=model)
-    # the CLIP stage scores the 64 seeded proposals (fixed N, meaningful shapes)
-    pipe = HybridGLPipeline(model, fusion_mode=args.fusion, masking_block=geom["masking_block"], mask_generator=gen, use_sam_masks=False,
-                            fixed_proposals=None, cleanup_given_masks=gen is not None, gem_model=gem_model)
-    pipe.group_clip = not args.no_clip_group
+
+    def make_pipe(m=model, g=gen, gm=gem_model, fusion=args.fusion, mb=geom["masking_block"], dep=dependent):
+        return HybridGLPipeline(m, fusion_mode=fusion, masking_block=mb, mask_generator=g, use_sam_masks=dep,
+                                fixed_proposals=args.masks if (dep and args.sam_batch == 1) else None,
+                                cleanup_given_masks=g is not None and not dep, gem_model=gm)
+    pipe = make_pipe()
     # rank r owns refs i = r (mod world) of the shuffle=False order
     refs = [synthetic_ref(D.owned_index(j, rank, world), dev, N=args.masks, sam_img_size=1024 if gen else 0, gem=use_gem,
                           device_blur=args.blur == "device")[0]
@@ -323,40 +337,27 @@ def main():
         if world > 1:
             dist.barrier()
 
-    overlap = gen is not None and not args.no_overlap
-
-    pair = overlap and args.sam_batch >= 2
     nbatch = args.sam_batch
 
-    def do_step(i):
-        # one step = one ref completed: its SAM stage + its CLIP/scoring stage.  With overlap the two
-        # stages of consecutive refs run concurrently on two streams (software pipeline over refs).
-        if overlap:
-            pipe.step_overlapped(refs[i % len(refs)], refs[(i + 1) % len(refs)])
-        else:
-            pipe.step(refs[i % len(refs)])
-
-    def do_steps(k):
-        # k steps = k refs completed (k SAM stages + k CLIP stages), taken in groups of up to --sam-batch refs: one
-        # SAM encoder pass over the group's prefetched images, one text batch + one hybrid forward for the group;
-        # what does not fill a group of two ends ref by ref.
-        i = 0
-        while (pair or (gen is None and nbatch >= 2)) and k - i >= 2:
-            g = max(c for c in (2, 4, 8, 16) if c <= min(nbatch, k - i))
-            group = [refs[(i + j) % len(refs)] for j in range(g)]
-            if pair:
-                pipe.step_overlapped_pair(group, [refs[(i + g + j) % len(refs)] for j in range(g)])
-            else:   # scope A: proposals given, the grouped CLIP + scoring stage alone
-                pipe.step_group(group)
-            i += g
-        while i < k:
-            do_step(i)
-            i += 1
+    def do_steps(k, p=None, cap=args.masks, pool=None):
+        """k steps = k refs completed, start to finish (proposal stage + CLIP/scoring stage of each), through the PRODUCT's
+        loop: HybridGLPipeline.run over a loader that yields k resident refs (hybridgl_amd.main runs the same call over a
+        Prefetcher)."""
+        p = p or pipe
+        pool = pool or refs
+        if nbatch == 1:
+            for i in range(k):
+                p.step(pool[i % len(pool)])
+            return
+        n = p.run((pool[i % len(pool)] for i in range(k)), group=nbatch, proposal_cap=cap if p.use_sam_masks else None,
+                  serial=args.no_overlap)
+        assert n == k, f"{k - n} refs were skipped (no proposals)"
 
     do_steps(args.warmup)
     torch.cuda.synchronize()
     # the metric rows of the report are those of the timed steps only
     pipe.cum.zero_(); pipe.iu_log.clear(); pipe.iu_owner.clear()
+    ops.split_overflow_count(reset=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -366,18 +367,22 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rows = pipe.partial_rows()
+    # fp16 range guard of the f16x3 mode (ops.check_split_overflow): GPU threads that met |x| > 65504 in the timed steps
+    overflow = ops.split_overflow_count(reset=True)
 
-    # ---- roofline leg: the same steps with HIP events around every launch of the dominant kernel
+    # ---- roofline leg: one group of the same loop with every stage on ONE stream, HIP events around every launch
     lib.hgl_prof_enable(1)
-    if pair:   # one group of the timed size, its stages back to back on one stream
-        nprof = nbatch
-        pipe.step_serial_group([refs[j % len(refs)] for j in range(nprof)])
-    else:
-        nprof = 2
+    nprof = max(nbatch, 2)
+    keep_rows = (pipe.cum.clone(), list(pipe.iu_log), list(pipe.iu_owner))
+    if nbatch == 1:
         for i in range(nprof):
-            pipe.step(refs[i % len(refs)])   # serial on one stream: per-kernel event times are not overlapped
+            pipe.step(refs[i % len(refs)])
+    else:
+        pipe.run((refs[i % len(refs)] for i in range(nprof)), group=nbatch, proposal_cap=args.masks if pipe.use_sam_masks else None,
+                 serial=True)
     torch.cuda.synchronize()
     lib.hgl_prof_enable(0)
+    pipe.cum.copy_(keep_rows[0]); pipe.iu_log[:] = keep_rows[1]; pipe.iu_owner[:] = keep_rows[2]
     g_n, g_ms, g_fl, g_by = prof_read(lib, 0)
     a_n, a_ms, a_fl, a_by = prof_read(lib, 1)
     x_n, x_ms, x_fl, x_by = prof_read(lib, 3)
@@ -388,52 +393,81 @@ def main():
     dt = D.max_over_ranks(dt, dist, dev)
     # the only exchange of the path: one all-gather of the per-sentence metric rows (RCCL over xGMI; hybridgl_amd/dist.py)
     m = D.gather_metrics(rows, dist, dev)
+    overflow = int(D.max_over_ranks(float(overflow), dist, dev))
 
-    # ---- short secondary timings in the same process (N = 1 only): the other fusion mode and the ViT-L/14 geometry
+    # ---- short secondary timings in the same process (N = 1 only)
     also = None
-    if world == 1 and not args.no_also and args.scope == "B" and args.fusion == "G2L" and args.clip == "ViT-B/16" and pair:
+    if world == 1 and not args.no_also and args.scope == "B" and args.fusion == "G2L" and args.clip == "ViT-B/16" and nbatch >= 2 \
+            and dependent:
         also = {}
 
-        def timed(p2, n_steps=8):
-            nonlocal pipe
-            keep, pipe = pipe, p2
-            try:
-                do_steps(n_steps)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                do_steps(n_steps)
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t1) / n_steps
-            finally:
-                pipe = keep
-        p2 = HybridGLPipeline(model, fusion_mode="G2L&L2G", masking_block=geom["masking_block"], mask_generator=gen,
-                              use_sam_masks=False, fixed_proposals=None, cleanup_given_masks=True, gem_model=gem_model)
-        t = timed(p2)
-        also["G2L&L2G"] = {"ms_per_step": t * 1e3, "value": 1.0 / t, "unit": "images/s", "steps": 8,
-                           "config": "the headline workload with fusion_mode G2L&L2G (BASELINE configs[3] per GPU)",
-                           "whole_step_algorithmic_tflops": None}
-        del p2
+        def timed(p2, n_steps=16, **kw):
+            do_steps(n_steps, p2, **kw)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            do_steps(n_steps, p2, **kw)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / n_steps
+
+        def entry(t, n_steps, config, fl=None):
+            return {"ms_per_step": t * 1e3, "value": 1.0 / t, "unit": "images/s", "steps": n_steps, "config": config,
+                    "whole_step_algorithmic_tflops": None if fl is None else fl / t / 1e12}
+        text_S = max(r.token_len or 77 for r in refs)
+        t = timed(make_pipe(dep=False))
+        also["seeded_masks"] = entry(t, 16, "rounds 1-2's headline workload (--proposals-from seeded): the SAM proposal kernels run, their "
+                                     "masks are discarded, clean-up + CLIP take the 64 seeded masks; no count read-back")
+        t = timed(make_pipe(fusion="L2G"))
+        also["L2G"] = entry(t, 16, "the headline workload with fusion_mode L2G (BASELINE configs[2] per GPU)")
+        t = timed(make_pipe(fusion="G2L&L2G"))
+        also["G2L&L2G"] = entry(t, 16, "the headline workload with fusion_mode G2L&L2G (BASELINE configs[3] per GPU)")
+        # strict fp32: every product an exact fp32 MFMA (v_mfma_f32_32x32x2_f32), own model objects
+        model_f = CLIPViTFM(args.clip, seed=0, device=dev, precision="f32")
+        from hybridgl_amd.sam import sam_model_registry
+        sam_f = sam_model_registry["default"](seed=0, device=dev, precision="f32")
+        gem_f = None
+        if use_gem:
+            from hybridgl_amd.gem import create_gem_model
+            gem_f = create_gem_model(args.clip, clip=model_f)
+        t = timed(make_pipe(m=model_f, g=make_gen(sam_f), gm=gem_f), n_steps=8)
+        also["f32"] = entry(t, 8, "the headline workload with HYBRIDGL_PRECISION=f32 semantics (exact fp32 MFMA products in every "
+                                  "GEMM and attention; roofline denominator 157.3 TFLOP/s)",
+                            algorithmic_flops_per_ref(args.masks, sam=True, gem=use_gem, clip_name=args.clip, text_S=text_S))
+        del model_f, sam_f, gem_f
+        torch.cuda.empty_cache()
         gl = CLIP_GEOM["ViT-L/14"]
         model_l = CLIPViTFM("ViT-L/14", seed=0, device=dev)
         gem_l = None
         if use_gem:
             from hybridgl_amd.gem import create_gem_model
             gem_l = create_gem_model("ViT-L/14", clip=model_l)
-        p3 = HybridGLPipeline(model_l, fusion_mode="G2L", masking_block=gl["masking_block"], mask_generator=gen,
-                              use_sam_masks=False, fixed_proposals=None, cleanup_given_masks=True, gem_model=gem_l)
-        t = timed(p3)
-        fl = algorithmic_flops_per_ref(args.masks, sam=True, gem=use_gem, clip_name="ViT-L/14",
-                                       text_S=max(r.token_len or 77 for r in refs))
-        also["ViT-L/14"] = {"ms_per_step": t * 1e3, "value": 1.0 / t, "unit": "images/s", "steps": 8,
-                            "config": "the headline workload with the CLIP / GEM ViT-L/14 geometry north_star names (masking_block 21)",
-                            "whole_step_algorithmic_tflops": fl / t / 1e12}
-        del p3, model_l, gem_l
+        t = timed(make_pipe(m=model_l, gm=gem_l, mb=gl["masking_block"]), n_steps=8)
+        also["ViT-L/14"] = entry(t, 8, "the headline workload with the CLIP / GEM ViT-L/14 geometry north_star names (masking_block 21)",
+                                 algorithmic_flops_per_ref(args.masks, sam=True, gem=use_gem, clip_name="ViT-L/14", text_S=text_S))
+        del model_l, gem_l
+        torch.cuda.empty_cache()
+        # PhraseCut-shaped items (BASELINE configs[4] per GPU; Hybridgl_main_PhraseCut.py:56-62): 64x64 points + one crop
+        # layer (5 encoder passes, 128 decoder batches, per-crop + cross-crop NMS over 12288 + 4 x 3072 candidates), 8 phrases
+        # per image scored against one hybrid forward; at most 256 proposals per image go on (random weights: noise masks)
+        from hybridgl_amd.sam import SamAutomaticMaskGenerator
+        gen_pc = SamAutomaticMaskGenerator(sam, points_per_side=64, pred_iou_thresh=-1e30, stability_score_thresh=0.0,
+                                           crop_n_layers=1, crop_n_points_downscale_factor=2, min_mask_region_area=100)
+        pc_refs = [synthetic_ref(100 + j, dev, N=args.masks, H=480, W=640, n_sent=8, sam_img_size=1024, gem=use_gem,
+                                 device_blur=True)[0] for j in range(2)]
+        t = timed(make_pipe(g=gen_pc, fusion="G2L&L2G"), n_steps=2, cap=256, pool=pc_refs)
+        also["PhraseCut"] = entry(t, 2, "PhraseCut-shaped item: 480x640 image, heavy AMG (64x64 points, 1 crop layer, downscale 2, min "
+                                        "area 100, thresholds open), <= 256 of SAM's masks into CLIP G2L&L2G, 8 phrases x (sentence + noun "
+                                        "phrase + 1 other noun) + 8 GEM prompts")
+        also["PhraseCut"]["unit"] = "images/s (8 phrases each)"
+        del gen_pc, pc_refs
         torch.cuda.empty_cache()
 
     if rank == 0:
         total_refs = args.steps * world
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        traffic, traffic_src = None, None
+        for cand in ("r03_pmc_traffic.json", "pmc_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(tpath):
+                break
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
@@ -449,16 +483,37 @@ def main():
                         num += n_l * float(v.get("hbm_bytes_per_launch", 0.0))
                         den += n_l
                 traffic = num / den if den > 0 else None
+                traffic_src = (f"profiles/{os.path.basename(tpath)}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                               "command on an earlier box (tools/profile_round.sh), replayed here -- not measured in this run")
             except Exception:
                 traffic = None
+        workload = (f"RefCOCO-shaped ref (BASELINE configs[1]): 640x640 image, 3 queries x (sentence+noun phrase+1 other noun); "
+                    + (("SAM ViT-H proposal stage (Pillow-exact resize to 1024 on the device, encoder, 8x8 point grid = 64 prompts x 3 "
+                        "masks, fused post-processing of the 192 candidates, NMS; filters open) whose OWN masks feed the rest: the "
+                        f"first {args.masks} survivors of every image -> connected-component clean-up (min area 800) + second NMS -> "
+                        "counts read back (two device->host copies per group) -> " if dependent else
+                        "SAM ViT-H proposal stage (encoder, 64 prompts x 3 masks, fused post-processing, NMS) whose noise masks "
+                        "(random weights) are discarded; connected-component clean-up (min area 800) + second NMS run on the 64 "
+                        "seeded proposal-shaped masks + ") if args.scope == "B" else "proposals given (scope A) + ")
+                    + ("15x15 Gaussian blur (cv2 fixed-point) + " if args.blur == "device" else "")
+                    + f"view synthesis + CLIP {args.clip} hybrid {args.fusion} (masking_block {geom['masking_block']}) on "
+                    f"{args.masks} proposals + text encoder ({12 if use_gem else 9} strings) + "
+                    + (f"GEM heat-map stage ({args.clip} at 448x448, self-self attention in the last 6 blocks, once "
+                       "per image; 3 prompts -> 3 maps, antialiased resize to the image) + " if use_gem else "heat-maps given + ")
+                    + "scoring tail + IoU"
+                    + (f"; timed through HybridGLPipeline.run (the evaluator's loop, hybridgl_amd/main.py) in groups of {nbatch} "
+                       "images: one SAM encoder pass over the images of group g+1 beside one text-encoder batch, one GEM tower "
+                       "pass and one hybrid forward over the proposals of group g; pipeline fill and drain are inside the timed "
+                       "region" if nbatch >= 2 else "; ref by ref (HybridGLPipeline.step)"))
         rec = {
             "metric": "images/sec (whole node)",
             "value": total_refs / dt,
             "unit": "images/s",
-            "n_gpus": world,
+            "n_gpus": min(world, ngpu) if world > 1 else 1,
             "world_size_seen": dist.get_world_size() if dist is not None else 1,
             "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
             "ranks_per_gpu": max(1, -(-world // max(ngpu, 1))),
+            "host_cores_per_rank": len(cores) if cores else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -466,30 +521,17 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if precision == "f32" else "f32 via fp16x3 split MFMA (fp32 accumulate)",
-            "data": ("synthetic (seeded images/masks/tokens; seeded random weights)" if use_gem else
-                     "synthetic (seeded images/masks/tokens/heat-maps; seeded random weights)"),
+            "data": ("synthetic (seeded images/tokens; seeded random weights; proposals = SAM's own masks)" if dependent else
+                     "synthetic (seeded images/masks/tokens; seeded random weights)"),
             "config": {
-                "workload": (f"RefCOCO-shaped ref (BASELINE configs[1]): 640x640 image, 3 queries x (sentence+noun "
-                             f"phrase+1 other noun); "
-                             + ("SAM ViT-H proposal stage (encoder, 8x8 point grid = 64 prompts x 3 masks, fused "
-                                "post-processing of the 192 candidates, NMS) whose noise masks (random weights) are "
-                                "discarded; connected-component clean-up (min area 800) + second NMS run on the 64 "
-                                "seeded proposal-shaped masks; the Pillow-exact resize to 1024 runs on the device inside "
-                                "the step) + " if args.scope == "B" else "proposals given (scope A) + ")
-                             + ("15x15 Gaussian blur (cv2 fixed-point) + " if args.blur == "device" else "") + f"view synthesis + CLIP {args.clip} hybrid {args.fusion} (masking_block {geom['masking_block']}) on "
-                             f"{args.masks} seeded proposals + text encoder ({12 if use_gem else 9} strings) + "
-                             + (f"GEM heat-map stage ({args.clip} at 448x448, self-self attention in the last 6 blocks, once "
-                                "per image; 3 prompts -> 3 maps, antialiased resize to the image) + " if use_gem else
-                                "heat-maps given + ")
-                             + "scoring tail + IoU"
-                             + (f"; refs are taken in groups of up to {nbatch} (one SAM encoder pass over the group's images, one "
-                                "text-encoder batch, one GEM tower pass and one hybrid forward over the group's masks; same work "
-                                "and results per ref)" if (pair or (gen is None and nbatch >= 2)) else "")),
+                "workload": workload,
                 "scope": args.scope,
+                "proposals_from": args.proposals_from if args.scope == "B" else "given",
                 "heatmap": args.heatmap,
-                "stage_overlap": bool(overlap),
-                "sam_images_per_encoder_pass": nbatch if pair else 1,
-                "refs_per_clip_forward": nbatch if pair and pipe.group_clip else 1,
+                "stage_overlap": bool(gen is not None and not args.no_overlap and nbatch >= 2),
+                "sam_images_per_encoder_pass": nbatch,
+                "refs_per_clip_forward": nbatch,
+                "host_syncs_per_group": (2 if dependent else 0) if nbatch >= 2 else None,
                 "clip": args.clip,
                 "fusion_mode": args.fusion, "proposals": args.masks, "image": "640x640", "queries": 3,
                 "parallelism": f"image-parallel x{world}",
@@ -499,8 +541,10 @@ def main():
                                                            text_S=max(r.token_len or 77 for r in refs)) / (dt / args.steps) / 1e12,
                                  xg=(xg_n, xg_ms, xg_fl), few=(fw_n, fw_ms, fw_fl)),
             "precision": precision,
+            "split_overflow_count": overflow,
             "metrics": m,
         }
+        rec["roofline"]["traffic_source"] = traffic_src
         if also is not None:
             rec["also"] = also
         if world == 1 and not args.no_cpu_baseline:
@@ -508,6 +552,9 @@ def main():
         print(json.dumps(rec))
     if world > 1:
         dist.destroy_process_group()
+    if overflow:
+        raise SystemExit(f"bench.py: {overflow} GPU threads met activations beyond the fp16 range in f16x3 mode: the numbers above "
+                         "are void; rerun with HYBRIDGL_PRECISION=f32")
 
 
 if __name__ == "__main__":

@@ -112,6 +112,8 @@ PROTOTYPES = {
     "hgl_clip_hybrid_workspace_bytes": (_SZ, [C.POINTER(HglClipVisionW), _I, _I, _I, _I]),
     "hgl_clip_hybrid_forward": (_I, [C.POINTER(HglClipVisionW), _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP,
                                      _VP, _SZ, _VP]),
+    "hgl_clip_hybrid_forward_segments": (_I, [C.POINTER(HglClipVisionW), _VP, _VP, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                              C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "hgl_clip_text_workspace_bytes": (_SZ, [C.POINTER(HglClipTextW), _I]),
     "hgl_clip_encode_text": (_I, [C.POINTER(HglClipTextW), _VP, _I, _VP, _VP, _SZ, _VP]),
     "hgl_clip_encode_text_prefix": (_I, [C.POINTER(HglClipTextW), _VP, _I, _I, _VP, _VP, _SZ, _VP]),
@@ -166,9 +168,11 @@ PROTOTYPES = {
 }
 
 _lib = None
+ABI_VERSION = 2   # include/hybridgl.h HGL_ABI_VERSION
 
 
 def load():
+
     """Load libhybridgl.so (once). Raises HybridGLError when it has not been built."""
     global _lib
     if _lib is not None:
@@ -181,12 +185,14 @@ def load():
     # this library before torch pulls in the system copy as well, after which no device is visible to it
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    lib.hgl_abi_version.restype = C.c_int
+    if lib.hgl_abi_version() != ABI_VERSION:    # before any symbol lookup: a stale library fails with this message
+        raise HybridGLError(f"{LIB_PATH} has ABI version {lib.hgl_abi_version()}, this package binds version {ABI_VERSION}: "
+                            "rebuild it (make -C hybridgl_amd/csrc)")
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.hgl_abi_version() != 1:
-        raise HybridGLError("libhybridgl ABI version mismatch")
     _lib = lib
     return lib
 

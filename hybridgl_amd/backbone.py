@@ -257,18 +257,35 @@ class CLIPViTFM:
             assert global_imgs.shape == local_imgs.shape, "global_imgs must have the shape of local_imgs"
             global_imgs = global_imgs.to(torch.float32).contiguous()
             gp = ops._dev(global_imgs, torch.float32, "global_imgs")
+        v = self.model.visual_w
+        out = torch.empty((N, self.model.cfg["embed_dim"]), dtype=torch.float32, device=local_imgs.device)
+        mb = -1 if masking_block is None else int(masking_block)
+        if isinstance(pred_masks, (list, tuple)):
+            # (not in the reference) the proposals of several images, each [n_i, H_i, W_i] with its own size: one forward
+            # over all rows (a group of dataset items; every row is independent)
+            segs = [pm if pm.dtype in (torch.bool, torch.uint8) else (pm != 0) for pm in pred_masks]
+            segs = [ops._u8(pm.contiguous(), "pred_masks")[1] for pm in segs]
+            assert sum(int(pm.shape[0]) for pm in segs) == N, "one mask per image row"
+            ns = len(segs)
+            ptrs = (C.c_void_p * ns)(*[pm.data_ptr() for pm in segs])
+            sn = (C.c_int * ns)(*[int(pm.shape[0]) for pm in segs])
+            sh = (C.c_int * ns)(*[int(pm.shape[1]) for pm in segs])
+            sw = (C.c_int * ns)(*[int(pm.shape[2]) for pm in segs])
+            need = lib.hgl_clip_hybrid_workspace_bytes(C.byref(v), N, 0, 0, mode)
+            ws = ops.workspace(need, local_imgs.device, "clip_hybrid")
+            check(lib.hgl_clip_hybrid_forward_segments(C.byref(v), lp, gp, ptrs, sn, sh, sw, ns, N, mode, mb, self.last_layer,
+                                                       out.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()),
+                  "hgl_clip_hybrid_forward_segments")
+            return out
         mp, Hm, Wm = None, 0, 0
         if pred_masks is not None:
             assert pred_masks.shape[0] == N, "one mask per image row"
             Hm, Wm = pred_masks.shape[1:]
             pm = pred_masks if pred_masks.dtype in (torch.bool, torch.uint8) else (pred_masks != 0)
             mp, pm = ops._u8(pm.contiguous(), "pred_masks")
-        v = self.model.visual_w
         need = lib.hgl_clip_hybrid_workspace_bytes(C.byref(v), N, Hm, Wm, mode)
         ws = ops.workspace(need, local_imgs.device, "clip_hybrid")
-        out = torch.empty((N, self.model.cfg["embed_dim"]), dtype=torch.float32, device=local_imgs.device)
-        check(lib.hgl_clip_hybrid_forward(C.byref(v), lp, gp, mp, N, Hm, Wm, mode,
-                                          -1 if masking_block is None else int(masking_block),
+        check(lib.hgl_clip_hybrid_forward(C.byref(v), lp, gp, mp, N, Hm, Wm, mode, mb,
                                           self.last_layer, out.data_ptr(), ws.data_ptr(), ws.numel(),
                                           ops._stream()), "hgl_clip_hybrid_forward")
         return out

@@ -1332,7 +1332,9 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
     static const int wide = getenv("HGL_ATTN_WIDE") ? atoi(getenv("HGL_ATTN_WIDE")) : 1;
     // (longer sequences measured neutral for 785 queries, slower for the 4096-query global blocks: two independent
     // 4-wave workgroups per CU interleave their phases, one 8-wave workgroup meets at every barrier)
-    const bool w8 = wide && HD >= 64 && a.Sq > 128 && a.Sq <= 256 && a.mask_kind != HGL_MASK_CAUSAL;
+    // the persistent kernel parks the CLS-keep row of an item in a 256-byte LDS tail: keys beyond 257 do not fit there
+    const bool w8 = wide && HD >= 64 && a.Sq > 128 && a.Sq <= 256 && a.mask_kind != HGL_MASK_CAUSAL &&
+                    (a.mask_kind != HGL_MASK_CLS_KEEP || a.Sk <= 257);
     if (HD == 80 && a.rel_h && a.kh == 14 && a.kw == 14 && a.Sk == 196 && a.mask_kind == HGL_MASK_NONE) {
       hipLaunchKernelGGL((attn_x3_kernel<HD, HD == 80 ? 14 : 0>), grid, dim3(256), 0, st, a);   // rel_h / rel_w given as tensors
     } else if (w8 && !a.rel_h && wide == 2) {   // A/B: the one-item-per-workgroup wide kernel

@@ -213,10 +213,18 @@ size_t hgl_clip_hybrid_workspace_bytes(const HglClipVisionW* w, int N, int Hm, i
   return ar.off;
 }
 
-int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, const float* global_imgs,
-                            const uint8_t* masks, int N, int Hm, int Wm, int fusion_mode,
-                            int masking_block, int last_layer, float* out, void* workspace,
-                            size_t workspace_bytes, void* stream) {
+// The masks of one hybrid forward: n_seg runs of rows, run s = seg_n[s] masks of seg_h[s] x seg_w[s] pixels at seg_masks[s]
+// (one run = the proposals of one image; a group of refs brings images of different sizes).
+struct MaskSegs {
+  const uint8_t* const* masks;
+  const int *n, *h, *w;
+  int n_seg;
+};
+
+static int hybrid_forward_impl(const HglClipVisionW* w, const float* local_imgs, const float* global_imgs,
+                               const MaskSegs& segs, int N, int fusion_mode,
+                               int masking_block, int last_layer, float* out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   HGL_TRY(hgl_require_device());
   HGL_REQUIRE(valid_vision(w), "clip_hybrid_forward: invalid weight struct");
   HGL_REQUIRE(local_imgs && out && N > 0, "clip_hybrid_forward: null input");
@@ -224,7 +232,16 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
   const bool two_stream = n_streams(fusion_mode) >= 2;
   HGL_REQUIRE(!two_stream || global_imgs, "clip_hybrid_forward: global_imgs required for this fusion mode");
   const bool need_masks = fusion_mode != HGL_FUSION_CROP;
-  HGL_REQUIRE(!need_masks || (masks && Hm > 0 && Wm > 0), "clip_hybrid_forward: masks required");
+  if (need_masks) {
+    HGL_REQUIRE(segs.masks && segs.n && segs.h && segs.w && segs.n_seg > 0, "clip_hybrid_forward: masks required");
+    long long rows = 0;
+    for (int s = 0; s < segs.n_seg; ++s) {
+      HGL_REQUIRE(segs.masks[s] && segs.n[s] > 0 && segs.h[s] > 0 && segs.w[s] > 0,
+                  "clip_hybrid_forward: mask run %d is empty (n %d, %d x %d)", s, segs.n[s], segs.h[s], segs.w[s]);
+      rows += segs.n[s];
+    }
+    HGL_REQUIRE(rows == N, "clip_hybrid_forward: the mask runs hold %lld masks for %d image rows", rows, N);
+  }
   if (masking_block < 0) masking_block = last_layer;
   HGL_REQUIRE(last_layer >= 0 && last_layer + 1 < w->layers + 1, "clip_hybrid_forward: bad last_layer %d", last_layer);
   // the reference's return sits inside the per-block loop: the returning block must exist and be
@@ -247,7 +264,13 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
   // ---- patch embedding of the streams ----
   HGL_TRY(embed_images(w, local_imgs, N, p.X, p, st));
   if (two_stream) HGL_TRY(embed_images(w, global_imgs, N, p.X + sN, p, st));
-  if (need_masks) HGL_TRY(hgl_launch_mask_resize(masks, N, Hm, Wm, g, p.pm, p.keep, st));
+  if (need_masks) {
+    size_t r0 = 0;
+    for (int s = 0; s < segs.n_seg; ++s) {
+      HGL_TRY(hgl_launch_mask_resize(segs.masks[s], segs.n[s], segs.h[s], segs.w[s], g, p.pm + r0 * (S - 1), p.keep + r0 * (S - 1), st));
+      r0 += segs.n[s];
+    }
+  }
 
   if (fusion_mode == HGL_FUSION_CROP) {
     for (int l = 0; l + 1 < w->layers; ++l)
@@ -334,6 +357,24 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
   }
   hgl_set_error("clip_hybrid_forward: unreachable");
   return HGL_EINVAL;
+}
+
+int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, const float* global_imgs,
+                            const uint8_t* masks, int N, int Hm, int Wm, int fusion_mode,
+                            int masking_block, int last_layer, float* out, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  MaskSegs one{&masks, &N, &Hm, &Wm, masks ? 1 : 0};
+  return hybrid_forward_impl(w, local_imgs, global_imgs, one, N, fusion_mode, masking_block, last_layer, out, workspace,
+                             workspace_bytes, stream);
+}
+
+int hgl_clip_hybrid_forward_segments(const HglClipVisionW* w, const float* local_imgs, const float* global_imgs,
+                                     const uint8_t* const* seg_masks, const int* seg_n, const int* seg_h, const int* seg_w,
+                                     int n_seg, int N, int fusion_mode, int masking_block, int last_layer, float* out,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  MaskSegs segs{seg_masks, seg_n, seg_h, seg_w, n_seg};
+  return hybrid_forward_impl(w, local_imgs, global_imgs, segs, N, fusion_mode, masking_block, last_layer, out, workspace,
+                             workspace_bytes, stream);
 }
 
 static bool valid_text(const HglClipTextW* w) {

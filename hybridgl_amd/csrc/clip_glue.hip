@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void gather_eot_kernel(const float* __restrict
   if (i >= (long long)B * D) return;
   const int bidx = (int)(i / D), d = (int)(i % D);
   const int e = eot[bidx];
-  y[i] = e < S ? x[((long long)bidx * S + e) * D + d] : __int_as_float(0x7fc00000);
+  y[i] = (e >= 0 && e < S) ? x[((long long)bidx * S + e) * D + d] : __int_as_float(0x7fc00000);   // a negative caller-chosen position is outside too
 }
 
 // x[b, pos[z], :] = 0 for every string b and listed position (model/backbone.py:44-46: x[masking_index] = 0 on [S,B,D])

@@ -147,11 +147,38 @@ def free_port():
     return p
 
 
-def spawn_local_ranks(n, argv, extra_env=None, timeout=None):
+def rank_cpu_affinity(local_rank, local_world, cpus=None):
+    """The host cores of one rank: an even contiguous share of the cores this process may run on (each rank keeps a
+    launch thread + loader threads busy; eight ranks that roam over all cores evict each other's caches).  Returns the
+    sorted core list; [] when there are fewer cores than ranks (no pinning then)."""
+    cpus = sorted(cpus if cpus is not None else os.sched_getaffinity(0))
+    per = len(cpus) // max(local_world, 1)
+    if per < 1:
+        return []
+    return cpus[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """os.sched_setaffinity of this process to rank_cpu_affinity (HYBRIDGL_PIN_CORES=0 disables); returns the cores."""
+    if os.environ.get("HYBRIDGL_PIN_CORES", "1") == "0" or local_world <= 1:
+        return []
+    cores = rank_cpu_affinity(local_rank, local_world)
+    if cores:
+        try:
+            os.sched_setaffinity(0, cores)
+        except OSError:
+            return []
+    return cores
+
+
+def spawn_local_ranks(n, argv, extra_env=None, timeout=None, poll_s=0.05):
     """Start `n` fresh processes of `argv` (one rank each) with the launcher's environment (RANK, LOCAL_RANK, WORLD_SIZE,
     MASTER_ADDR = 127.0.0.1, MASTER_PORT = a free port) and wait for them.  Must be called BEFORE the calling process
     touches the GPU (it only forks interpreters; nothing is exec'ed over an initialised device).  Rank 0 inherits
-    stdout; returns the largest exit code (a rank that dies takes the others down after `timeout`)."""
+    stdout.  ALL ranks are polled: the first rank that exits non-zero -- whichever it is -- ends the job at once (the
+    others may be parked in a collective waiting for it: they are terminated, then killed) and ITS exit code is returned;
+    `timeout` seconds without completion kill every rank and return 124.  0 when every rank exits 0."""
+    import time
     port = free_port()
     procs = []
     for r in range(n):
@@ -162,21 +189,39 @@ def spawn_local_ranks(n, argv, extra_env=None, timeout=None):
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen(argv, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    try:
-        for p in procs:
-            p.wait(timeout=timeout)
-            rc = max(rc, abs(p.returncode))
-            if p.returncode != 0:   # do not leave the other ranks waiting in a collective
-                for q in procs:
-                    if q.poll() is None:
-                        q.terminate()
-    except subprocess.TimeoutExpired:
+
+    def stop_all():
         for q in procs:
             if q.poll() is None:
+                q.terminate()
+        t_end = time.monotonic() + 5.0
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
                 q.kill()
-        rc = max(rc, 124)
-    return rc
+                q.wait()
+
+    deadline = None if timeout is None else time.monotonic() + timeout
+    try:
+        while True:
+            running = 0
+            for p in procs:
+                rc = p.poll()
+                if rc is None:
+                    running += 1
+                elif rc != 0:
+                    stop_all()
+                    return rc if rc > 0 else 128 - rc     # killed by signal s -> 128 + s, as a shell reports it
+            if running == 0:
+                return 0
+            if deadline is not None and time.monotonic() > deadline:
+                stop_all()
+                return 124
+            time.sleep(poll_s)
+    except BaseException:
+        stop_all()
+        raise
 
 
 def visible_gpu_count():

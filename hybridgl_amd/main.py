@@ -50,6 +50,9 @@ def default_argument_parser():
     p.add_argument("--pred_iou_thresh", type=float, default=0.7)
     p.add_argument("--stability_score_thresh", type=float, default=0.7)
     p.add_argument("--min_mask_region_area", type=int, default=800)
+    p.add_argument("--group", type=int, default=8,
+                   help="images taken at a time by the two-stream loop (HybridGLPipeline.run); 1 = ref by ref on one stream")
+    p.add_argument("--workers", type=int, default=4, help="loader threads (Hybridgl_main.py:45 num_workers)")
     return p
 
 
@@ -64,30 +67,44 @@ def sentence_strings(raw, rec):
     return [raw, rec.get("noun_phrase", raw)] + [OTHER_NOUN_PREFIX + o for o in others]
 
 
-def real_refs(args, dev, splitBy, context_length, rank=0, world=1):
-    """RefBatch per dataset item of this rank, in the loader's order (Hybridgl_main.py:40-45,79-146)."""
-    import json
-    import numpy as np
-    from . import ops, synth
-    from .pipeline import RefBatch, Sentence
-    from .refer_io import ReferDataset
-    from .tokenizer import SimpleTokenizer, tokenize
-    from .gem import GEMWrapper, get_gem_img_transform
-    ds = ReferDataset(args.refer_data_root, args.dataset, splitBy, args.split)
-    tk = SimpleTokenizer(args.bpe_vocab or None)
-    preprocess = get_gem_img_transform()                                       # Hybridgl_main.py:39
-    parse = json.load(open(args.parse_json)) if args.parse_json else {}
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    n = len(ds) if args.max_refs <= 0 else min(len(ds), args.max_refs)
-    from .dist import shard_by_groups
-    image_ids = [ds.refer.Refs[r]["image_id"] for r in ds.ref_ids[:n]]
-    for i in shard_by_groups(image_ids, rank, world):   # refs of one image stay on one rank (per-image cache)
-        data, annot, sentences = ds[i]
+class RealRefs:
+    """The dataset side of the loop (Hybridgl_main.py:40-45,79-146): `jobs(rank, world)` = the dataset positions of this
+    rank in the loader's order, `load(i)` = one RefBatch (image decode, GEM transform, strings, tokens, ground truth on the
+    host; uploads on the calling thread's current stream).  `load` is what hybridgl_amd.loader.Prefetcher runs on its
+    background threads."""
+
+    def __init__(self, args, dev, splitBy, context_length):
+        import json
+        from .refer_io import ReferDataset
+        from .tokenizer import SimpleTokenizer
+        from .gem import get_gem_img_transform
+        self.args, self.dev, self.context_length = args, dev, context_length
+        self.ds = ReferDataset(args.refer_data_root, args.dataset, splitBy, args.split)
+        self.tk = SimpleTokenizer(args.bpe_vocab or None)
+        self.preprocess = get_gem_img_transform()                                       # Hybridgl_main.py:39
+        self.parse = json.load(open(args.parse_json)) if args.parse_json else {}
+        self.n = len(self.ds) if args.max_refs <= 0 else min(len(self.ds), args.max_refs)
+
+    def jobs(self, rank=0, world=1):
+        from .dist import shard_by_groups
+        image_ids = [self.ds.refer.Refs[r]["image_id"] for r in self.ds.ref_ids[:self.n]]
+        return shard_by_groups(image_ids, rank, world)   # refs of one image stay on one rank (per-image cache)
+
+    def load(self, i):
+        import numpy as np
+        from . import synth
+        from .gem import GEMWrapper
+        from .loader import pin_upload
+        from .pipeline import RefBatch, Sentence
+        from .tokenizer import tokenize
+        args, dev = self.args, self.dev
+        data, annot, sentences = self.ds[i]
         img = data["sam_img"]
         H, W = img.shape[:2]
         strings, sents = [], []
+        t = lambda a: pin_upload(a, dev)
         for sent_id, raw in zip(data["sent_ids"], sentences):
-            rec = parse.get(str(sent_id), {})
+            rec = self.parse.get(str(sent_id), {})
             row = len(strings)
             others = list(rec.get("other_nouns", []))   # extract_nouns' phrases, bare (utils.py:82-98)
             strings += sentence_strings(raw, rec)
@@ -96,7 +113,7 @@ def real_refs(args, dev, splitBy, context_length, rank=0, world=1):
                 a = torch.from_numpy(np.load(os.path.join(args.heatmap_dir, f"{sent_id}.npy")).astype(np.float32))
                 if tuple(a.shape) != (H, W):     # Hybridgl_main.py:201-202: bilinear to the image size
                     a = torch.nn.functional.interpolate(a[None, None], size=(H, W), mode="bilinear", align_corners=False)[0, 0]
-                attn = a.to(dev).contiguous()
+                attn = t(a)
             gem_row = None
             if attn is None and args.heatmap == "device":
                 gem_row = len(strings)                                         # Hybridgl_main.py:200 gem_model(tensor_img, [noun_phrase])
@@ -105,12 +122,19 @@ def real_refs(args, dev, splitBy, context_length, rank=0, world=1):
                 attn = torch.ones((H, W), dtype=torch.float32, device=dev)     # uniform: no spatial guidance
             sents.append(Sentence(row, row + 1, list(range(row + 2, row + 2 + len(others))), rec.get("dirflag", "none"),
                                   rec.get("relaflag", "none"), len(others), attn, gem_row=gem_row))
-        tokens = tokenize(strings, context_length=context_length, tokenizer=tk)   # raises on over-long text, as clip.tokenize
+        tokens = tokenize(strings, context_length=self.context_length, tokenizer=self.tk)   # raises on over-long text, as clip.tokenize
         placeholder = torch.zeros((1, H, W), dtype=torch.bool, device=dev)
-        yield RefBatch(t(img), None, t(synth.imagenet_normalize(img)), placeholder,
-                       torch.zeros((1, 4), dtype=torch.int64, device=dev), t(tokens), t(annot), sents, None,
-                       int(data["img_id"][0]), tensor_img=preprocess(img).to(dev) if args.heatmap == "device" else None,
-                       token_len=int(tokens.argmax(axis=1).max()) + 1, index=i)
+        return RefBatch(t(img), None, t(synth.imagenet_normalize(img)), placeholder,
+                        torch.zeros((1, 4), dtype=torch.int64, device=dev), t(tokens), t(annot), sents, None,
+                        int(data["img_id"][0]), tensor_img=t(self.preprocess(img)) if args.heatmap == "device" else None,
+                        token_len=int(tokens.argmax(axis=1).max()) + 1, index=i)
+
+
+def real_refs(args, dev, splitBy, context_length, rank=0, world=1):
+    """RefBatch per dataset item of this rank, in the loader's order, prepared on the calling thread (no prefetching)."""
+    rr = RealRefs(args, dev, splitBy, context_length)
+    for i in rr.jobs(rank, world):
+        yield rr.load(i)
 
 
 def main(args):
@@ -140,21 +164,28 @@ def main(args):
                             use_sam_masks=args.real, gem_model=gem_model)
     if rank == 0:
         print(f"fusion mode={args.fusion_mode}")
+    from .loader import Prefetcher
     if args.real:
         from .weights import CLIP_CONFIGS
-        skipped = 0
-        for ref in real_refs(args, dev, splitBy, CLIP_CONFIGS[args.clip_model]["context_length"], rank, world):
+        rr = RealRefs(args, dev, splitBy, CLIP_CONFIGS[args.clip_model]["context_length"])
+        jobs, make = rr.jobs(rank, world), rr.load
+    else:
+        jobs = D.shard_indices(args.synthetic, rank, world)
+        make = lambda i: synthetic_ref(i, dev, N=args.proposals, sam_img_size=1024 if gen else 0, gem=gem_model is not None,
+                                       device_blur=True)[0]
+    # Hybridgl_main.py:45,79: DataLoader(num_workers=4) feeding the loop; here loader threads feed the grouped loop
+    loader = Prefetcher(jobs, make, workers=args.workers, depth=2 * args.group + 2, device=dev)
+    if args.group <= 1:      # ref by ref on one stream (Hybridgl_main.py:79-230 as written)
+        for ref in loader:
             try:
                 pipe.step(ref)
             except EmptyProposals:
-                skipped += 1      # the reference would fail on an image without proposals; count and go on
-        if skipped:
-            print(f"{skipped} refs skipped: the proposal stage returned no mask")
+                pipe.skipped = getattr(pipe, "skipped", 0) + 1
     else:
-        for i in D.shard_indices(args.synthetic, rank, world):
-            ref, _ = synthetic_ref(i, dev, N=args.proposals, sam_img_size=1024 if gen else 0, gem=gem_model is not None,
-                                   device_blur=True)
-            pipe.step(ref)
+        pipe.run(loader, group=args.group)
+    if getattr(pipe, "skipped", 0):
+        # the reference would fail on an image without proposals; count and go on
+        print(f"{pipe.skipped} refs skipped: the proposal stage returned no mask")
     m = pipe.metrics(dist)      # one all-gather of the metric rows; identical on every rank
     if dist is not None:
         dist.destroy_process_group()

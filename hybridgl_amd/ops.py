@@ -226,8 +226,11 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, tag="default"):
-    """Grow-only device workspace (allocated outside the timed/hot path, reused)."""
-    key = (str(device), tag)
+    """Grow-only device workspace (allocated outside the timed/hot path, reused).  One buffer per (tag, stream): the
+    stages of the evaluation loop run on their own streams, and a buffer that grows (a larger image, more proposals)
+    is replaced while kernels of ANOTHER stream could still be using the old one -- the caching allocator only orders
+    reuse within the allocating stream."""
+    key = (str(device), tag, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

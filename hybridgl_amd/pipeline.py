@@ -57,10 +57,28 @@ class RefBatch:
                                       # encoder then computes only that prefix of the 77 positions (exact: causal mask)
     index: Optional[int] = None       # position in the loader's order (Hybridgl_main.py:45,79); under sharding the metric rows
                                       # of all ranks are put back into this order (hybridgl_amd/dist.py)
+    ready: Optional[object] = None    # torch.cuda.Event recorded behind the uploads of this item (hybridgl_amd/loader.py: the
+                                      # copies run on a loader thread's stream); consumers make their stream wait for it
 
 
 class EmptyProposals(RuntimeError):
     """the proposal stage kept no mask for this image"""
+
+
+def _adopt(ref, streams):
+    """An item uploaded on a loader thread's stream (RefBatch.ready): the consuming streams wait for its copies, and its
+    tensors are recorded on them so that the caching allocator does not hand their blocks to the next upload while a
+    consumer still reads them."""
+    if ref.ready is None:
+        return
+    ts = [ref.sam_img, ref.blurred, ref.image_norm, ref.masks, ref.boxes, ref.tokens, ref.target, ref.sam_resized, ref.tensor_img]
+    for s in ref.sentences:
+        ts += [s.imgattn, s.target]
+    for st in streams:
+        st.wait_event(ref.ready)
+        for t in ts:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(st)
 
 
 def _rows(text, rows):
@@ -95,7 +113,6 @@ class HybridGLPipeline:
         self._k0 = (k1, k2)
         self.model = model
         self.gem_model = gem_model              # hybridgl_amd.gem.GEMWrapper: heat-maps computed on the device
-        self.group_clip = True                  # step_overlapped_pair: one text batch + one hybrid forward for its refs
         self.mask_generator = mask_generator
         self.use_sam_masks = use_sam_masks
         self.fixed_proposals = fixed_proposals
@@ -110,31 +127,6 @@ class HybridGLPipeline:
         self.iu_log = []  # per sentence (IU_pure, IU_final) device tensors
         self.iu_owner = []  # per sentence (dataset position of its ref, sentence number)
         self._n_refs = 0
-
-    def step_overlapped(self, ref: RefBatch, next_ref: RefBatch):
-        """Two-stage software pipeline over refs on two HIP streams: the SAM proposal stage of
-        `next_ref` runs concurrently with the CLIP + scoring stage of `ref` (whose proposals were
-        produced one call earlier).  Fills the CUs that SAM's small-M kernels leave idle.  Only for
-        flows where the CLIP stage does not consume this call's SAM output (benchmark / prefetching
-        driver); results are identical to step()."""
-        if not hasattr(self, "_s_sam"):
-            self._s_sam, self._s_clip = torch.cuda.Stream(), torch.cuda.Stream()
-            self._ev = torch.cuda.Event()
-        cur = torch.cuda.current_stream()
-        self._ev.record(cur)
-        self._s_sam.wait_event(self._ev)
-        self._s_clip.wait_event(self._ev)
-        gen = self.mask_generator
-        with torch.cuda.stream(self._s_sam):
-            self.last_proposals = gen.propose(next_ref.sam_img, resized=next_ref.sam_resized)
-        with torch.cuda.stream(self._s_clip):
-            if self.cleanup_given_masks:
-                import dataclasses
-                cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
-                ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
-            out = self.step(ref, run_sam=False)   # the SAM stage of this ref ran one call earlier
-        self._join_side_streams(cur, [out])
-        return out
 
     def _join_side_streams(self, cur, outs):
         """The caller's stream waits for both side streams; every tensor that leaves them is recorded on the caller's
@@ -155,55 +147,12 @@ class HybridGLPipeline:
         rec(outs)
         rec(getattr(self, "last_proposals", None))
 
-    def step_overlapped_pair(self, refs, next_refs):
-        """step_overlapped for a group of refs (2, 4, 8 ...) at a time: ONE SAM encoder pass over the images of all
-        `next_refs` (Sam.encode_batch: token rows stacked, weights read once, GEMMs at M = 4096 * group) runs on the
-        SAM stream while the CLIP + scoring stage of the `refs` runs on the CLIP stream (step_group: one text batch,
-        one hybrid forward).  Same work and same results per ref as step_overlapped ref by ref (up to the summation
-        order of the encoder's split-K)."""
-        if not hasattr(self, "_s_sam"):
-            self._s_sam, self._s_clip = torch.cuda.Stream(), torch.cuda.Stream()
-            self._ev = torch.cuda.Event()
-        cur = torch.cuda.current_stream()
-        self._ev.record(cur)
-        self._s_sam.wait_event(self._ev)
-        self._s_clip.wait_event(self._ev)
-        gen = self.mask_generator
-        with torch.cuda.stream(self._s_sam):
-            self.last_proposals = gen.propose_batch([r.sam_img for r in next_refs])[-1]
-        outs = []
-        with torch.cuda.stream(self._s_clip):
-            group = []
-            for ref in refs:
-                if self.cleanup_given_masks:
-                    import dataclasses
-                    cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
-                    ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
-                group.append(ref)
-            outs = self.step_group(group, run_sam=False) if self.group_clip else [self.step(r, run_sam=False) for r in group]
-        self._join_side_streams(cur, outs)
-        return outs
-
-    def step_serial_group(self, refs):
-        """The work of step_overlapped_pair for one group on the CURRENT stream, stages back to back (no overlap): SAM
-        proposal stage of the group's own images in one encoder pass, then the grouped CLIP + scoring stage.  Used for
-        per-kernel timing (events on one stream)."""
-        gen = self.mask_generator
-        self.last_proposals = gen.propose_batch([r.sam_img for r in refs])[-1]
-        group = []
-        for ref in refs:
-            if self.cleanup_given_masks:
-                import dataclasses
-                cm, _ = gen.cleanup_fixed(ref.masks.view(torch.uint8))
-                ref = dataclasses.replace(ref, masks=cm.view(torch.bool))
-            group.append(ref)
-        return self.step_group(group, run_sam=False) if self.group_clip else [self.step(r, run_sam=False) for r in group]
-
     def step(self, ref: RefBatch, run_sam=True):
         """One dataset item; returns the device tensors of the last sentence (idx, scores).
         run_sam=False: the proposal stage of this ref is not part of this call (it ran earlier / on another stream)."""
         import dataclasses
         m = self.model
+        _adopt(ref, (torch.cuda.current_stream(),))
         gen_here = self.mask_generator if run_sam else None
         # The text encoder (9 strings: small, latency-bound kernels) is independent of the image path: it runs on its
         # own stream underneath the SAM / CLIP image kernels and is joined before the scoring tail.
@@ -241,7 +190,7 @@ class HybridGLPipeline:
         if ref.image_id is not None and getattr(self, "_cache_id", None) == ref.image_id:
             hybrid = self._cache_hybrid
             ref = dataclasses.replace(self._cache_ref, tokens=ref.tokens, token_len=ref.token_len, sentences=ref.sentences,
-                                      target=ref.target)
+                                      target=ref.target, index=ref.index)
         else:
             if gen_here is not None:
                 # Hybridgl_main.py:85 mask_generator.generate(sam_img), kept on the device
@@ -304,73 +253,193 @@ class HybridGLPipeline:
             last = (idx, sc, sn, gem)
         return last
 
-    def step_group(self, refs, run_sam=True):
-        """Several refs whose proposals are given, with ONE text-encoder batch over the strings of all refs and ONE
-        hybrid forward over the masks of all refs (every mask row of CLIPViTFM.forward is independent, so the
-        concatenation changes nothing but the GEMM sizes: 2 x 64 masks -> M = 50432 rows, tile counts that fill
-        the chip evenly).  Falls back to step() per ref where that does not apply (in-step SAM, per-image cache,
-        refs of different mask sizes)."""
+    # ---- the evaluation loop at the grouped rate ----------------------------------------------------------------------
+    def _streams(self):
+        if not hasattr(self, "_s_sam"):
+            self._s_sam, self._s_clip = torch.cuda.Stream(), torch.cuda.Stream()
+            self._ev = torch.cuda.Event()
+        return self._s_sam, self._s_clip
+
+    @staticmethod
+    def _units(loader, group):
+        """Groups of up to `group` IMAGE UNITS in the loader's order; a unit = the consecutive items that share an
+        image_id (the dataset yields one item per ref, Hybridgl_main.py:79; proposals, views and hybrid features depend on
+        the image only).  Items without an image_id are units of their own."""
+        units, cur = [], None
+        for ref in loader:
+            if cur is not None and ref.image_id is not None and ref.image_id == cur[0].image_id:
+                cur.append(ref)
+                continue
+            if cur is not None:
+                units.append(cur)
+                if len(units) == group:
+                    yield units
+                    units = []
+            cur = [ref]
+        if cur is not None:
+            units.append(cur)
+        if units:
+            yield units
+
+    def run(self, loader, group=8, proposal_cap=None, collect=False, serial=False):
+        """The loop of Hybridgl_main.py:79-230 over a whole loader, taken `group` images at a time on two streams:
+
+            SAM stream   group g+1: ONE encoder pass over its images, per image decoder + post-processing + NMS, small-region
+                         clean-up + second NMS (SamAutomaticMaskGenerator.group_begin / group_cleanup / group_finish: the
+                         survivor counts of the whole group are read back in TWO device->host copies, not 2 per image)
+            CLIP stream  group g: one text-encoder batch over the strings of all its refs, one GEM tower pass over its
+                         images, one hybrid forward over the ACTUAL proposals of all its images (ragged counts, images of
+                         different sizes), then the per-sentence tail of every ref in the loader's order
+
+        The CLIP stage of group g is enqueued before the host waits for the counts of group g+1, so the device always has
+        work.  `loader` yields RefBatch items (device tensors; hybridgl_amd.loader.Prefetcher prepares them on background
+        threads, Hybridgl_main.py:45).  Results per ref are those of step() -- every mask row, string and image is
+        independent -- up to the summation order of the SAM encoder's split-K, which only a single-image pass uses.
+        Without a mask generator (or with run_sam=False semantics: use_sam_masks=False and no generator) the proposals are
+        RefBatch.masks / boxes.  Images for which the generator keeps no mask are skipped and counted (self.skipped; the
+        reference would fail on them).  Returns the number of refs scored; collect=True also keeps step()'s per-ref
+        return values in self.collected.  serial=True: the same work with every stage on the CURRENT stream, back to back
+        (per-kernel timing with events on one stream)."""
+        gen = self.mask_generator
+        cur = torch.cuda.current_stream()
+        self._serial = bool(serial)
+        if serial:
+            s_sam = s_clip = cur
+        else:
+            s_sam, s_clip = self._streams()
+            self._ev.record(cur)
+            s_sam.wait_event(self._ev)
+            s_clip.wait_event(self._ev)
+        self.collected = [] if collect else None
+        self.skipped = getattr(self, "skipped", 0)
+        done = 0
+        pending = None
+        for units in self._units(loader, group):
+            for u in units:
+                for r in u:
+                    _adopt(r, (s_sam, s_clip))
+            state = None
+            if gen is not None:
+                with torch.cuda.stream(s_sam):
+                    imgs = [u[0].sam_img for u in units]
+                    if self.use_sam_masks:
+                        if getattr(gen, "crop_n_layers", 0) > 0:   # PhraseCut configuration: crop layers, image by image
+                            state = ("crops", [tuple(t[:proposal_cap] if proposal_cap is not None else t
+                                                     for t in gen.generate_device_crops(im)[:2]) for im in imgs])
+                        else:
+                            state = ("group", gen.group_begin(imgs, proposal_cap))
+                    else:    # proposal kernels only; their output is not consumed (synthetic benchmark, seeded masks)
+                        self.last_proposals = gen.propose_batch(imgs)[-1]
+            if pending is not None:
+                with torch.cuda.stream(s_clip):
+                    done += self._clip_group(*pending)
+            props, ready = None, None
+            if state is not None:
+                with torch.cuda.stream(s_sam):
+                    if state[0] == "group":
+                        props = [p[:2] for p in gen.group_finish(gen.group_cleanup(state[1]))]
+                    else:
+                        props = state[1]
+                    ready = torch.cuda.Event()
+                    ready.record(s_sam)
+            pending = (units, props, ready)
+        if pending is not None:
+            with torch.cuda.stream(s_clip):
+                done += self._clip_group(*pending)
+        if not serial:
+            self._join_side_streams(cur, self.collected)
+        return done
+
+    def _clip_group(self, units, props, ready):
+        """CLIP + scoring stage of one group on the current stream; props[i] = (masks u8 [n,H,W], boxes XYWH) of unit i from
+        the proposal stage (None: the items' own masks / boxes).  Returns the number of refs scored."""
         import dataclasses
         m = self.model
-        same = all(r.masks.shape[1:] == refs[0].masks.shape[1:] and r.tokens.shape[1] == refs[0].tokens.shape[1] for r in refs)
-        if len(refs) == 1 or (run_sam and self.mask_generator is not None) or not same or any(r.image_id is not None for r in refs):
-            return [self.step(r, run_sam=run_sam) for r in refs]
         cur = torch.cuda.current_stream()
+        if ready is not None:
+            cur.wait_event(ready)
+        gen = self.mask_generator
+        live = []     # (refs of the unit, masks bool [n,H,W], boxes)
+        for i, refs in enumerate(units):
+            if props is not None:
+                mk, bx = props[i]
+                if mk.shape[0] == 0:
+                    self.skipped += len(refs)
+                    continue
+                mk.record_stream(cur)
+                bx.record_stream(cur)
+                live.append((refs, mk.view(torch.bool) if mk.dtype == torch.uint8 else mk, bx.contiguous()))
+            else:
+                mk = refs[0].masks
+                if self.cleanup_given_masks and gen is not None:
+                    mk = gen.cleanup_fixed(mk.view(torch.uint8))[0].view(torch.bool)
+                live.append((refs, mk, refs[0].boxes))
+        if not live:
+            return 0
         if not hasattr(self, "_s_text"):
             self._s_text = torch.cuda.Stream()
+        s_text = cur if getattr(self, "_serial", False) else self._s_text
         ev_in, ev_text = torch.cuda.Event(), torch.cuda.Event()
         ev_in.record(cur)
-        self._s_text.wait_event(ev_in)
-        offs = np.cumsum([0] + [r.tokens.shape[0] for r in refs])
+        s_text.wait_event(ev_in)
+        all_refs = [r for refs, _, _ in live for r in refs]
+        offs = np.cumsum([0] + [r.tokens.shape[0] for r in all_refs])
         heats = []
-        with torch.cuda.stream(self._s_text):
-            lens = [r.token_len for r in refs]
-            text_all = m.model.encode_text(torch.cat([r.tokens for r in refs], dim=0),
+        with torch.cuda.stream(s_text):
+            lens = [r.token_len for r in all_refs]
+            text_all = m.model.encode_text(torch.cat([r.tokens for r in all_refs], dim=0) if len(all_refs) > 1 else all_refs[0].tokens,
                                            seq_len=None if any(v is None for v in lens) else max(lens))
-            # GEM image towers of the refs that need a heat-map: one pass over all of them when their sizes agree
-            need = [i for i, r in enumerate(refs) if any(s.imgattn is None for s in r.sentences)]
+            # GEM image tower once per IMAGE that has a sentence without a given heat-map
+            need = [i for i, (refs, _, _) in enumerate(live) if any(s.imgattn is None for r in refs for s in r.sentences)]
             gfeats = {}
             if need:
-                if self.gem_model is None or any(refs[i].tensor_img is None for i in need):
+                if self.gem_model is None or any(live[i][0][0].tensor_img is None for i in need):
                     raise ValueError("a sentence without imgattn needs gem_model, RefBatch.tensor_img and Sentence.gem_row")
-                if len(need) > 1 and all(refs[i].tensor_img.shape == refs[need[0]].tensor_img.shape for i in need):
-                    fb = self.gem_model.image_features_batch(torch.stack([refs[i].tensor_img for i in need], dim=0))
+                timgs = [live[i][0][0].tensor_img for i in need]
+                if len(need) > 1 and all(t.shape == timgs[0].shape for t in timgs):
+                    fb = self.gem_model.image_features_batch(torch.stack(timgs, dim=0))
                     gfeats = {i: fb[j] for j, i in enumerate(need)}
                 else:
-                    gfeats = {i: self.gem_model.image_features(refs[i].tensor_img) for i in need}
-            for i, ref in enumerate(refs):
-                text = text_all[offs[i]:offs[i + 1]]
-                gem_rows = [s.gem_row for s in ref.sentences if s.imgattn is None]
-                heat = None
-                if gem_rows:
-                    from . import gem as G
-                    if any(r is None for r in gem_rows):
-                        raise ValueError("a sentence without imgattn needs gem_model, RefBatch.tensor_img and Sentence.gem_row")
-                    gfeat = gfeats[i]
-                    maps = self.gem_model.heatmap(gfeat, _rows(text, gem_rows), ref.tensor_img.shape[-1])
-                    heat = G.resize_antialias(maps, ref.sam_img.shape[:2])
-                    heat.record_stream(cur)
-                heats.append(heat)
-            ev_text.record(self._s_text)
+                    gfeats = {i: self.gem_model.image_features(t) for i, t in zip(need, timgs)}
+            k = 0
+            for i, (refs, _, _) in enumerate(live):
+                for ref in refs:
+                    text = text_all[offs[k]:offs[k + 1]]
+                    k += 1
+                    gem_rows = [s.gem_row for s in ref.sentences if s.imgattn is None]
+                    heat = None
+                    if gem_rows:
+                        from . import gem as G
+                        if any(r is None for r in gem_rows):
+                            raise ValueError("a sentence without imgattn needs gem_model, RefBatch.tensor_img and Sentence.gem_row")
+                        maps = self.gem_model.heatmap(gfeats[i], _rows(text, gem_rows), ref.tensor_img.shape[-1])
+                        heat = G.resize_antialias(maps, ref.sam_img.shape[:2])     # Hybridgl_main.py:201
+                        heat.record_stream(cur)
+                    heats.append(heat)
+            ev_text.record(s_text)
         text_all.record_stream(cur)
-        ns = [r.masks.shape[0] for r in refs]
+        ns = [mk.shape[0] for _, mk, _ in live]
         moff = np.cumsum([0] + ns)
-        dev = refs[0].masks.device
+        dev = live[0][1].device
         local = torch.empty((int(moff[-1]), 3, self.res, self.res), dtype=torch.float32, device=dev)
         glob = torch.empty_like(local)
-        for i, ref in enumerate(refs):
-            blurred = ref.blurred if ref.blurred is not None else ops.gaussian_blur_u8(ref.sam_img, 15)   # :99
-            ops.synthesize_views(ref.sam_img, blurred, ref.image_norm, ref.masks, self.res,
+        for i, (refs, mk, _) in enumerate(live):
+            r0 = refs[0]
+            blurred = r0.blurred if r0.blurred is not None else ops.gaussian_blur_u8(r0.sam_img, 15)   # :99
+            ops.synthesize_views(r0.sam_img, blurred, r0.image_norm, mk, self.res,
                                  out=(local[moff[i]:moff[i + 1]], glob[moff[i]:moff[i + 1]]))
-        masks_all = torch.cat([r.masks for r in refs], dim=0)
-        hybrid_all = m(local, glob, masks_all, masking_block=self.masking_block, fusion_mode=self.fusion_mode)
+        hybrid_all = m(local, glob, [mk for _, mk, _ in live], masking_block=self.masking_block, fusion_mode=self.fusion_mode)
         cur.wait_event(ev_text)
-        outs = []
-        for i, ref in enumerate(refs):
+        k = 0
+        for i, (refs, mk, bx) in enumerate(live):
             hybrid = hybrid_all[moff[i]:moff[i + 1]]
-            text = text_all[offs[i]:offs[i + 1]]
-            outs.append((hybrid, text, self._score_ref(ref, hybrid, text, heats[i])))
-        return outs
+            for ref in refs:
+                text = text_all[offs[k]:offs[k + 1]]
+                out = self._score_ref(dataclasses.replace(ref, masks=mk, boxes=bx), hybrid, text, heats[k])
+                k += 1
+                if self.collected is not None:
+                    self.collected.append((hybrid, text, out))
+        return len(all_refs)
 
     def partial_rows(self):
         """This process's per-sentence rows [n, 6] int64 = (dataset position, sentence, I, U, I_final, U_final)

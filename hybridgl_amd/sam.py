@@ -473,6 +473,11 @@ class SamPredictor:
         return m[0].cpu().numpy(), iou[0].cpu().numpy(), low[0].cpu().numpy()
 
 
+class _GroupState:
+    """a group of images on its way through SamAutomaticMaskGenerator.group_begin / group_cleanup / group_finish"""
+    __slots__ = ("sizes", "cap", "cand", "n1_dev", "n1", "ev1", "n1_list", "stage", "n2", "ev2")
+
+
 class SamAutomaticMaskGenerator:
     """automatic_mask_generator.py:35-372: the Hybridgl_main.py:67-73 configuration (one crop, 8x8 points) runs
     entirely on the device with two host syncs; crop layers / dense grids (Hybridgl_main_PhraseCut.py) add one
@@ -643,6 +648,99 @@ class SamAutomaticMaskGenerator:
         b = bx.long()
         xywh = torch.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1) if n > 0 else b
         return m, xywh, iou.index_select(0, idx), stab.index_select(0, idx), idx
+
+    # ---- a GROUP of images through the generator: one encoder pass, two host syncs for the whole group ------------
+    def group_begin(self, images, cap=None):
+        """Stage A of generate() for several whole images (no crop layers) on the current stream: Pillow-exact resize,
+        ONE encoder pass over all of them (Sam.encode_batch), then per image decoder + fused post-processing + first NMS.
+        The survivor counts of all images leave in ONE device->host copy (pinned), marked by an event: nothing is waited for
+        here, so the caller can enqueue other work (the CLIP stage of the previous group) before group_cleanup().
+        cap: keep at most this many survivors per image (first NMS order; not in the reference -- synthetic benchmark:
+        'AMG forced to keep a fixed 64')."""
+        assert self.crop_n_layers == 0, "crop layers take generate_device_crops (one crop at a time)"
+        st = _GroupState()
+        st.cap = cap
+        st.sizes = [tuple(int(v) for v in im.shape[:2]) for im in images]
+        st.cand = self.propose_batch(images)
+        dev = self.model.device
+        st.n1_dev = torch.cat([c[5] for c in st.cand])
+        st.n1 = torch.empty(len(images), dtype=torch.int32).pin_memory()
+        st.n1.copy_(st.n1_dev, non_blocking=True)
+        st.ev1 = torch.cuda.Event()
+        st.ev1.record(torch.cuda.current_stream(dev))
+        return st
+
+    def group_cleanup(self, st):
+        """Stage B: waits for the counts of group_begin (host sync 1 of 2), gathers each image's survivors and runs
+        postprocess_small_regions' kernels on them (holes, islands, boxes, second NMS; automatic_mask_generator.py:324-372).
+        The second NMS counts leave in one copy again."""
+        st.ev1.synchronize()
+        dev = self.model.device
+        n1 = [int(v) for v in st.n1.tolist()]
+        if st.cap is not None:
+            n1 = [min(v, st.cap) for v in n1]
+        st.n1_list = n1
+        st.stage = []
+        n2_dev = []
+        for (masks, boxes, iou, stab, order, _n, _pts), n in zip(st.cand, n1):
+            if n == 0:
+                st.stage.append(None)
+                n2_dev.append(torch.zeros(1, dtype=torch.int32, device=dev))
+                continue
+            idx = order[:n].long()
+            m = masks.index_select(0, idx)
+            bx = boxes.index_select(0, idx)
+            if self.min_mask_region_area > 0:
+                m1, c1 = remove_small_regions(m, self.min_mask_region_area, "holes")
+                m2, c2 = remove_small_regions(m1, self.min_mask_region_area, "islands")
+                unchanged = ((c1 | c2) == 0).to(torch.float32)           # score 1 for untouched masks
+                nb = mask_boxes(m2)
+                order2, n2 = nms(nb, unchanged, torch.ones(n, dtype=torch.uint8, device=dev),
+                                 max(self.box_nms_thresh, self.crop_nms_thresh))
+                st.stage.append((m2, nb, idx, order2, iou, stab))
+                n2_dev.append(n2)
+            else:
+                st.stage.append((m, bx, idx, None, iou, stab))
+                n2_dev.append(torch.full((1,), n, dtype=torch.int32, device=dev))
+        st.cand = None     # the candidate tensors (192 full-size masks per image) can go back to the allocator
+        st.n2 = None
+        if self.min_mask_region_area > 0:
+            st.n2 = torch.empty(len(n1), dtype=torch.int32).pin_memory()
+            st.n2.copy_(torch.cat(n2_dev), non_blocking=True)
+            st.ev2 = torch.cuda.Event()
+            st.ev2.record(torch.cuda.current_stream(dev))
+        return st
+
+    def group_finish(self, st):
+        """Stage C: host sync 2 of 2 (none without the small-region clean-up), the final gathers.  Returns per image what
+        generate_device returns: (masks [n,H,W] uint8, boxes_xywh [n,4] int64, iou [n], stability [n], cand [n] int64);
+        n may be 0."""
+        if st.n2 is not None:
+            st.ev2.synchronize()
+            n2 = [int(v) for v in st.n2.tolist()]
+        else:
+            n2 = list(st.n1_list)
+        out = []
+        dev = self.model.device
+        for stg, n, hw in zip(st.stage, n2, st.sizes):
+            if stg is None or n == 0:
+                e = torch.empty
+                out.append((e((0,) + hw, dtype=torch.uint8, device=dev), e((0, 4), dtype=torch.int64, device=dev),
+                            e((0,), device=dev), e((0,), device=dev), e((0,), dtype=torch.int64, device=dev)))
+                continue
+            m, bx, idx, order2, iou, stab = stg
+            if order2 is not None:
+                k = order2[:n].long()
+                m, bx, idx = m.index_select(0, k), bx.index_select(0, k), idx.index_select(0, k)
+            b = bx.long()
+            xywh = torch.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1)
+            out.append((m, xywh, iou.index_select(0, idx), stab.index_select(0, idx), idx))
+        st.stage = None
+        return out
+
+    def generate_group(self, images, cap=None):
+        """generate_device() for several images with one encoder pass and two host syncs in all (one without clean-up)."""
+        return self.group_finish(self.group_cleanup(self.group_begin(images, cap)))
 
     def cleanup_fixed(self, m):
         """postprocess_small_regions kernels on a fixed batch of masks [n,H,W] uint8 without reading any

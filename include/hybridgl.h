@@ -32,7 +32,9 @@ extern "C" {
 #define HGL_EWORKSPACE (-3)/* workspace too small */
 #define HGL_ELAUNCH (-4)   /* kernel launch failed */
 
-#define HGL_ABI_VERSION 1
+/* 2: + hgl_clip_hybrid_forward_segments, hgl_split_overflow_count, hgl_clip_encode_text_ex; hgl_gemm_f16x3_select
+ * knows kinds -1, 0, 1 only */
+#define HGL_ABI_VERSION 2
 
 /* activation codes for hgl_gemm_f32 */
 #define HGL_ACT_NONE 0
@@ -175,6 +177,15 @@ int hgl_clip_hybrid_forward(const HglClipVisionW* w, const float* local_imgs, co
                             const uint8_t* masks, int N, int Hm, int Wm,
                             int fusion_mode, int masking_block, int last_layer,
                             float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* The same over the proposals of SEVERAL images in one call (a group of dataset items, Hybridgl_main.py:79-128 taken
+ * several at a time): rows of local/global are the masks of image 0, then image 1, ...; run s = seg_n[s] masks of
+ * seg_h[s] x seg_w[s] pixels at the device pointer seg_masks[s] (the three arrays and the pointer array are HOST
+ * memory); sum(seg_n) == N.  Every row is independent, so out equals the per-image calls stacked.  Workspace: the
+ * size query above with the total N. */
+int hgl_clip_hybrid_forward_segments(const HglClipVisionW* w, const float* local_imgs, const float* global_imgs,
+                                     const uint8_t* const* seg_masks, const int* seg_n, const int* seg_h, const int* seg_w,
+                                     int n_seg, int N, int fusion_mode, int masking_block, int last_layer,
+                                     float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* CLIP.encode_text(text) (clip/model.py:414-431): tokens [B,context] int32
  * -> out [B,embed]; pooled at argmax(token id) (the EOT token). */

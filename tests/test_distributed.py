@@ -111,16 +111,79 @@ def test_spawn_local_ranks_sets_the_launcher_environment(tmp_path):
     assert D.spawn_local_ranks(2, [sys.executable, "-c", code, str(out), "fail"]) == 3
 
 
+def test_a_late_rank_that_dies_ends_the_job_at_once(tmp_path):
+    """Rank 2 of 3 fails while ranks 0 and 1 sit in a (simulated) collective: the spawner polls ALL ranks, stops the
+    others and returns rank 2's code -- it does not block on rank 0 first."""
+    import time
+    code = ("import os, sys, time\n"
+            "if os.environ['RANK'] == '2':\n    time.sleep(0.3); sys.exit(7)\n"
+            "time.sleep(600)\n")
+    t0 = time.monotonic()
+    assert D.spawn_local_ranks(3, [sys.executable, "-c", code]) == 7
+    assert time.monotonic() - t0 < 30
+    # a rank killed by a signal reports 128 + signal; a job that never finishes hits the timeout (124)
+    code = "import os, signal, time\nif os.environ['RANK'] == '1':\n    os.kill(os.getpid(), signal.SIGKILL)\ntime.sleep(600)\n"
+    assert D.spawn_local_ranks(2, [sys.executable, "-c", code]) == 128 + 9
+    assert D.spawn_local_ranks(2, [sys.executable, "-c", "import time; time.sleep(600)"], timeout=1.0) == 124
+
+
+def _worker8(rank, world, port, counts, q):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    sys.path.insert(0, ROOT)
+    from hybridgl_amd import dist as DD
+    dist = DD.init_process_group("gloo")
+    # rank r holds counts[r] seeded rows (some ranks none at all); ref_index encodes the owner so the report order is checkable
+    rng = np.random.default_rng(100 + rank)
+    rows = np.stack([np.array([rank + world * j, 0, *sorted(rng.integers(1, 1000, 2)), *sorted(rng.integers(1, 1000, 2))])
+                     for j in range(counts[rank])]).astype(np.int64) if counts[rank] else np.zeros((0, 6), np.int64)
+    all_rows = DD.gather_rows(rows, dist)
+    m = DD.metrics_from_rows(all_rows)
+    q.put((rank, m, all_rows.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_with_ragged_and_empty_shares():
+    """world 8 over gloo: row counts 3, 0, 1, 0, 0, 5, 2, 0 -- ranks WITHOUT a single row (a dataset tail shorter than the
+    node, images without proposals) go through the padded all-gather; every rank ends with the same rows and report."""
+    world, counts = 8, [3, 0, 1, 0, 0, 5, 2, 0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = D.free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, counts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rows0 = got[0][2]
+    assert len(rows0) == sum(counts)
+    assert [r[0] % world for r in rows0] == [r for r, c in enumerate(counts) for _ in range(c)]   # rank-major, each rank in order
+    for rank, m, rows in got:
+        assert rows == rows0 and m == got[0][1]
+    assert got[0][1] == D.metrics_from_rows(np.asarray(rows0))
+
+
+def test_rank_core_shares_are_disjoint():
+    cpus = list(range(3, 67))                      # 64 cores the process may use
+    parts = [D.rank_cpu_affinity(r, 8, cpus) for r in range(8)]
+    assert all(len(p) == 8 for p in parts) and sorted(sum(parts, [])) == cpus
+    assert D.rank_cpu_affinity(0, 8, list(range(4))) == []        # fewer cores than ranks: no pinning
+    assert D.rank_cpu_affinity(2, 3, list(range(8))) == [4, 5]
+
+
 def test_bench_spawns_before_touching_the_gpu():
     """`python bench.py --gpus 2` with no launcher must reach spawn_local_ranks without a GPU call: in this GPU-less
     container the children then stop at bench.py's own 'needs a GPU' assertion -- not the parent."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_driver.py::test_bench_two_ranks")
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--backend", "gloo"], env=env, capture_output=True, text=True, timeout=600)
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("GPU present: covered by tests/test_gpu_driver.py::test_bench_two_ranks")
     assert r.returncode != 0
     assert "bench.py needs a GPU" in r.stderr and "spawn_local_ranks" not in r.stderr
 

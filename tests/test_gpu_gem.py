@@ -186,8 +186,8 @@ def test_image_features_batch_equals_single_images(cuda, tiny, b16, kw):
             np.testing.assert_allclose(ob[b].cpu().numpy(), gm.image_features(imgs[b], return_ori=True).cpu().numpy(), rtol=0, atol=tol)
 
 
-def test_step_group_equals_per_ref_steps(cuda, b16):
-    """HybridGLPipeline.step_group: one text-encoder batch and one hybrid forward over the masks of several refs ==
+def test_grouped_run_equals_per_ref_steps(cuda, b16):
+    """HybridGLPipeline.run on given proposals: one text-encoder batch and one hybrid forward over the masks of several refs ==
     the refs stepped one by one (every mask row and every string is independent)."""
     from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
     _, clip = b16
@@ -197,7 +197,8 @@ def test_step_group_equals_per_ref_steps(cuda, b16):
     p1 = HybridGLPipeline(clip, "G2L", 9, gem_model=gm)
     outs1 = [p1.step(r) for r in refs]
     p2 = HybridGLPipeline(clip, "G2L", 9, gem_model=gm)
-    outs2 = p2.step_group(refs)
+    assert p2.run(iter(refs), group=len(refs), collect=True) == len(refs)
+    outs2 = p2.collected
     assert p1.metrics()["cum"] == p2.metrics()["cum"] and p1.metrics()["n_sentences"] == p2.metrics()["n_sentences"] == 9
     for a, b in zip(outs1, outs2):
         np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), rtol=0, atol=2e-5)      # hybrid features

@@ -175,14 +175,15 @@ def test_clamp_is_per_rank_under_sharding(cuda):
     assert D.metrics_from_rows(np.concatenate([a, b])) == D.metrics_from_rows(whole)
 
 
-def test_group_and_overlapped_steps_equal_ref_by_ref(cuda):
-    """step_group (one text batch + one hybrid forward for 8 refs) and the metric rows it files are identical to eight
-    step() calls: every mask row and every string is independent of its batch."""
+def test_grouped_run_equals_ref_by_ref(cuda):
+    """run() on given proposals (one text batch + one hybrid forward for 8 refs) and the metric rows it files are identical
+    to eight step() calls: every mask row and every string is independent of its batch."""
     refs = [_ref(i, cuda, 12)[0] for i in range(8)]
     a, b = _tiny(cuda), _tiny(cuda)
     for r in refs:
         a.step(r)
-    outs = b.step_group(refs)
+    assert b.run(iter(refs), group=8, collect=True) == 8
+    outs = b.collected
     assert len(outs) == 8
     assert np.array_equal(a.partial_rows(), b.partial_rows())
     assert a.metrics() == b.metrics()
@@ -194,9 +195,10 @@ def test_group_and_overlapped_steps_equal_ref_by_ref(cuda):
         assert torch.equal(l1[0], last[0])
 
 
-def test_overlapped_pair_equals_serial_on_full_size_models(cuda):
-    """The benchmark's step (SAM stage of the next group under the CLIP stage of this one, three streams, groups of 2)
-    files the same metric rows as plain step() calls on the same refs (ViT-B/16 + SAM at the tiny geometry)."""
+def test_two_stream_run_with_discarded_proposals_equals_serial(cuda):
+    """--proposals-from seeded (rounds 1-2's benchmark workload): the SAM proposal kernels of group g+1 run beside the CLIP
+    stage of group g and their output is discarded; the rows are those of plain step() calls on the same refs (ViT-B/16 +
+    SAM at the tiny geometry), on two streams and on one."""
     from hybridgl_amd.backbone import CLIPViTFM
     from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
     from hybridgl_amd.sam import SamAutomaticMaskGenerator, sam_model_registry
@@ -205,13 +207,13 @@ def test_overlapped_pair_equals_serial_on_full_size_models(cuda):
                                     stability_score_thresh=0.0, box_nms_thresh=2.0, min_mask_region_area=50)
     refs = [synthetic_ref(i, cuda, N=8, H=160, W=200, sam_img_size=256)[0] for i in range(4)]
     mk = lambda: HybridGLPipeline(model, mask_generator=gen, use_sam_masks=False, cleanup_given_masks=True)
-    a, b = mk(), mk()
+    a, b, c = mk(), mk(), mk()
     for r in refs:
         a.step(r)
-    b.step_overlapped_pair(refs[0:2], refs[2:4])
-    b.step_overlapped_pair(refs[2:4], refs[0:2])
+    b.run(iter(refs), group=2)
+    c.run(iter(refs), group=2, serial=True)
     torch.cuda.synchronize()
-    assert np.array_equal(a.partial_rows(), b.partial_rows())
+    assert np.array_equal(a.partial_rows(), b.partial_rows()) and np.array_equal(a.partial_rows(), c.partial_rows())
     assert b.mask_generator is gen          # the generator is never swapped out to steer the step
 
 
@@ -255,7 +257,8 @@ def test_bench_two_ranks(cuda):
     common = ["--scope", "A", "--warmup", "0", "--no-cpu-baseline", "--no-also", "--masks", "16"]
     two = _bench(["--gpus", "2", "--steps", "8", "--pool", "8"] + common)
     one = _bench(["--gpus", "1", "--steps", "16", "--pool", "16"] + common)
-    assert two["n_gpus"] == 2 and two["world_size_seen"] == 2 and one["n_gpus"] == 1
+    # two ranks on ONE device: n_gpus is the hardware (1), the ranks show in world_size_seen / ranks_per_gpu
+    assert two["n_gpus"] == 1 and two["ranks_per_gpu"] == 2 and two["world_size_seen"] == 2 and one["n_gpus"] == 1
     assert two["metrics"]["n_sentences"] == one["metrics"]["n_sentences"] == 48
     assert two["metrics"] == one["metrics"]
     assert two["value"] > 0 and two["scaling"] == "weak"

@@ -230,6 +230,24 @@ def test_attention_cls_keep_with_offsets(cuda, precision):
     np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5, add), rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("Sk", [300, 600])
+def test_attention_cls_keep_more_keys_than_queries(cuda, precision, Sk):
+    """197 queries (the 8-wave kernels' range) against more than 257 keys under the CLS keep mask: the persistent wide
+    kernel parks an item's keep row in a 256-byte LDS tail and must not be chosen here (reachable through hgl_attention_f32)."""
+    rng = np.random.default_rng(14)
+    B, heads, Sq, hd, n = 3, 2, 197, 64, 3
+    D = heads * hd
+    q = rng.standard_normal((B, Sq, D)).astype(np.float32)
+    k, v = (rng.standard_normal((B, Sk, D)).astype(np.float32) for _ in range(2))
+    keep = rng.random((n, Sk - 1)) > 0.5
+    add = np.zeros((B, 1, Sq, Sk))
+    for b in range(B):
+        add[b, 0, 0, 1:] = np.where(keep[b % n], 0, -np.inf)
+    y = ops.attention(T(q, cuda), T(k, cuda), T(v, cuda), heads, mask="cls_keep", keep=T(keep, cuda),
+                      keep_b0=0, keep_n=n).cpu().numpy()
+    np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5, add), rtol=0, atol=2e-5)
+
+
 def test_attention_spiked_scores_online_softmax(cuda, precision):
     """force the running max to jump at a late key tile (rescale branch of the online softmax)."""
     rng = np.random.default_rng(12)

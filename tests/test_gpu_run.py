@@ -1,0 +1,219 @@
+"""HybridGLPipeline.run -- the product's evaluation loop at the grouped, two-stream rate (Hybridgl_main.py:45,79-230
+taken several images at a time) -- against the per-ref step() it replaces: same metric rows bit for bit, on REFER-format
+data with images of different sizes, several refs per image, ragged proposal counts and SAM's OWN masks feeding CLIP."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(root, n_images=9):
+    """REFER directory layout with `n_images` images of different sizes and 1-3 consecutive refs per image (18 refs)."""
+    from PIL import Image
+    from hybridgl_amd.synth import synth_image
+    (root / "refcoco").mkdir(parents=True)
+    img_dir = root / "images/mscoco/images/train2014"
+    img_dir.mkdir(parents=True)
+    images, anns, refs = [], [], []
+    rid = 200
+    for i in range(n_images):
+        h, w = 96 + 16 * (i % 4), 128 + 24 * (i % 3)
+        name = f"COCO_train2014_{i:012d}.png"
+        Image.fromarray(synth_image(h, w, 70 + i)).save(img_dir / name)
+        images.append({"id": 10 + i, "file_name": name, "height": h, "width": w})
+        for j in range(1 + i % 3):
+            aid = 1000 + rid
+            x0 = 8 + 20 * j
+            anns.append({"id": aid, "image_id": 10 + i, "category_id": 1,
+                         "segmentation": [[x0, 12, x0 + 70, 15, x0 + 60, h - 10, x0 + 5, h - 20]], "bbox": [0, 0, 1, 1]})
+            sents = [{"sent_id": 2 * rid, "raw": "the cat on left", "tokens": []}]
+            if (i + j) % 2:
+                sents.append({"sent_id": 2 * rid + 1, "raw": "a big dog", "tokens": []})
+            refs.append({"ref_id": rid, "ann_id": aid, "image_id": 10 + i, "category_id": 1, "split": "val",
+                         "sent_ids": [s["sent_id"] for s in sents], "sentences": sents})
+            rid += 1
+    json.dump({"images": images, "annotations": anns, "categories": [{"id": 1, "name": "thing"}]},
+              open(root / "refcoco/instances.json", "w"))
+    pickle.dump(refs, open(root / "refcoco/refs(unc).p", "wb"))
+    parse = {}
+    for r in refs:
+        parse[str(r["sent_ids"][0])] = {"noun_phrase": "the cat", "other_nouns": ["left"], "dirflag": "left", "relaflag": "left"}
+        if len(r["sent_ids"]) > 1:
+            parse[str(r["sent_ids"][1])] = {"noun_phrase": "dog", "other_nouns": [], "dirflag": "none", "relaflag": "big"}
+    json.dump(parse, open(root / "parse.json", "w"))
+    return refs
+
+
+@pytest.fixture(scope="module")
+def models(cuda):
+    from hybridgl_amd.backbone import CLIPViTFM
+    from hybridgl_amd.gem import create_gem_model
+    from hybridgl_amd.sam import SamAutomaticMaskGenerator, sam_model_registry
+    model = CLIPViTFM("ViT-B/16", seed=0, device=cuda)
+    gem = create_gem_model("ViT-B/16", clip=model)
+    # thresholds that DECIDE: the 0.7 box NMS of the reference on a 5x5 grid, an IoU threshold near the median of the
+    # tiny model's predictions -> a different number of proposals for every image
+    sam = sam_model_registry["tiny"](device=cuda)
+    gen = SamAutomaticMaskGenerator(sam, points_per_side=5, pred_iou_thresh=-1.0,
+                                    stability_score_thresh=0.0, box_nms_thresh=0.7, min_mask_region_area=2)
+    # random weights give noise logits whose masks at threshold 0 all span the image (one survivor of the NMS): a mask
+    # threshold at the 99.95 % quantile leaves a handful of pixels per candidate, so the boxes differ and the NMS decides
+    from hybridgl_amd.sam import SamPredictor
+    from hybridgl_amd.synth import synth_image
+    pred = SamPredictor(sam)
+    pred.set_image(torch.from_numpy(synth_image(96, 128, 70)).to(cuda))
+    pts = torch.from_numpy(pred.transform.apply_coords(gen.point_grids[0] * np.array([[128, 96]]), (96, 128)))[:, None, :]
+    logits, _, _ = pred.predict_torch(pts, torch.ones((len(pts), 1), dtype=torch.int64), return_logits=True)
+    sam.mask_threshold = float(torch.quantile(logits.flatten()[:4_000_000].float(), 0.9995))
+    return model, gem, gen
+
+
+def _args(root, golden_dir, heatmap="device"):
+    from hybridgl_amd import main as drv
+    return drv.default_argument_parser().parse_args([
+        "--real", "--refer_data_root", str(root), "--dataset", "refcoco", "--split", "val",
+        "--bpe_vocab", os.path.join(golden_dir, "tiny_bpe_vocab.txt.gz"), "--parse_json", str(root / "parse.json"),
+        "--heatmap", heatmap])
+
+
+def test_run_equals_per_ref_steps_on_a_refer_set(cuda, golden_dir, tmp_path, models):
+    """18 refs over 9 images of 9 different sizes: (a) step() ref by ref on one stream, items prepared on the calling
+    thread; (b) run() in groups of 8 images fed by 4 loader threads; (c) groups of 3.  The metric rows (dataset position,
+    sentence, I, U, I_final, U_final) are identical, and so is the report."""
+    from hybridgl_amd import main as drv
+    from hybridgl_amd.loader import Prefetcher
+    from hybridgl_amd.pipeline import HybridGLPipeline
+    model, gem, gen = models
+    root = tmp_path / "refer_data"
+    refs = _dataset(root)
+    assert len(refs) >= 16
+    args = _args(root, golden_dir)
+    rr = drv.RealRefs(args, cuda, "unc", 77)
+    mk = lambda: HybridGLPipeline(model, fusion_mode="G2L", masking_block=9, mask_generator=gen, use_sam_masks=True,
+                                  gem_model=gem)
+    a = mk()
+    counts = []
+    for i in rr.jobs():
+        a.step(rr.load(i))
+        counts.append(int(a._cache_ref.masks.shape[0]))
+    torch.cuda.synchronize()
+    assert len(set(counts)) >= 3, f"the proposal counts should be ragged, got {counts}"
+    b = mk()
+    n = b.run(Prefetcher(rr.jobs(), rr.load, workers=4, depth=12, device=cuda), group=8)
+    torch.cuda.synchronize()
+    assert n == len(refs) and b.skipped == 0
+    rows_a, rows_b = a.partial_rows(), b.partial_rows()
+    assert rows_a.shape == (sum(len(r["sent_ids"]) for r in refs), 6)
+    assert np.array_equal(rows_a, rows_b)
+    assert a.metrics() == b.metrics()
+    c = mk()
+    c.run(Prefetcher(rr.jobs(), rr.load, workers=2, depth=4, device=cuda), group=3, collect=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(rows_a, c.partial_rows())
+    assert len(c.collected) == len(refs)
+    # the k1 / k2 clamp state after the loop is the per-ref one as well (same order of refs)
+    assert (a.k1, a.k2) == (b.k1, b.k2) == (c.k1, c.k2)
+
+
+def test_run_skips_images_without_proposals_and_goes_on(cuda, golden_dir, tmp_path, models):
+    """An IoU threshold no candidate passes on some images: their refs are counted as skipped (the reference would fail
+    at torch.stack([])), the rest of the group is scored; rows equal the per-ref loop's, which skips the same refs."""
+    from hybridgl_amd import main as drv
+    from hybridgl_amd.pipeline import EmptyProposals, HybridGLPipeline
+    from hybridgl_amd.sam import SamAutomaticMaskGenerator
+    model, gem, gen0 = models
+    root = tmp_path / "refer_data"
+    refs = _dataset(root, n_images=6)
+    args = _args(root, golden_dir, heatmap="given")
+    rr = drv.RealRefs(args, cuda, "unc", 77)
+    # find a threshold between the images' best predicted IoUs
+    best = []
+    for i in rr.jobs():
+        r = rr.load(i)
+        _, _, iou, _, order, n, _ = gen0.propose(r.sam_img)
+        best.append(float(iou.max()))
+    thr = float(np.median(sorted(set(best))))
+    gen = SamAutomaticMaskGenerator(gen0.model, points_per_side=5, pred_iou_thresh=thr, stability_score_thresh=0.0,
+                                    box_nms_thresh=0.7, min_mask_region_area=2)
+    mk = lambda: HybridGLPipeline(model, mask_generator=gen, use_sam_masks=True, k_clamp="per_ref")
+    a, skipped = mk(), 0
+    for i in rr.jobs():
+        try:
+            a.step(rr.load(i))
+        except EmptyProposals:
+            skipped += 1
+    b = mk()
+    n = b.run((rr.load(i) for i in rr.jobs()), group=4)
+    torch.cuda.synchronize()
+    assert 0 < skipped < len(refs) and b.skipped == skipped and n == len(refs) - skipped
+    assert np.array_equal(a.partial_rows(), b.partial_rows())
+
+
+def test_run_on_given_proposals_equals_step_group(cuda):
+    """Without a mask generator run() is the grouped CLIP + scoring stage over the items' own masks (scope A)."""
+    from hybridgl_amd.backbone import CLIPViTFM
+    from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
+    model = CLIPViTFM("ViT-B/16", seed=0, device=cuda)
+    refs = [synthetic_ref(i, cuda, N=6 + i, H=120, W=160)[0] for i in range(5)]
+    a, b = HybridGLPipeline(model), HybridGLPipeline(model)
+    for r in refs:
+        a.step(r)
+    assert b.run(iter(refs), group=4) == 5
+    torch.cuda.synchronize()
+    assert np.array_equal(a.partial_rows(), b.partial_rows())
+
+
+def test_hybrid_forward_over_segments_equals_per_image_calls(cuda):
+    """hgl_clip_hybrid_forward_segments: the proposals of three images of different sizes in one forward == the three
+    forwards, row for row (every mask row is independent); wrong run lengths are refused."""
+    from hybridgl_amd._lib import HybridGLError
+    from hybridgl_amd.backbone import CLIPViTFM
+    from hybridgl_amd.synth import synth_masks
+    model = CLIPViTFM("ViT-B/16", seed=0, device=cuda)
+    rng = np.random.default_rng(3)
+    sizes, ns = [(120, 160), (97, 130), (200, 64)], [9, 1, 14]
+    masks = [torch.from_numpy(synth_masks(n, h, w, 40 + i)).to(cuda) for i, ((h, w), n) in enumerate(zip(sizes, ns))]
+    loc = torch.from_numpy(rng.standard_normal((sum(ns), 3, 224, 224)).astype(np.float32)).to(cuda)
+    glo = torch.from_numpy(rng.standard_normal((sum(ns), 3, 224, 224)).astype(np.float32)).to(cuda)
+    for mode in ("G2L", "L2G", "G2L&L2G"):
+        whole = model(loc, glo, masks, masking_block=9, fusion_mode=mode)
+        o = 0
+        for mk, n in zip(masks, ns):
+            # 9, 1 and 14 masks alone are small-M launches that take other GEMM kernels than the stacked 24: rounding-level
+            part = model(loc[o:o + n], glo[o:o + n], mk, masking_block=9, fusion_mode=mode)
+            assert torch.allclose(whole[o:o + n], part, rtol=0, atol=2e-5), mode
+            o += n
+    with pytest.raises(HybridGLError, match="mask runs hold"):
+        model(loc, glo, masks[:2], masking_block=9, fusion_mode="G2L")
+
+
+def test_full_size_dependent_groups_are_composition_independent(cuda):
+    """BASELINE size (640x640, SAM ViT-H, ViT-B/16, 64 of SAM's own masks per image through clean-up into CLIP): run() in
+    groups of 4 and in groups of 2 file the same rows bit for bit (no encoder pass of these sizes uses split-K), run to run
+    as well; the proposals CLIP scored are SAM's (not the items' seeded masks)."""
+    from hybridgl_amd.backbone import CLIPViTFM
+    from hybridgl_amd.gem import create_gem_model
+    from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
+    from hybridgl_amd.sam import SamAutomaticMaskGenerator, sam_model_registry
+    model = CLIPViTFM("ViT-B/16", seed=0, device=cuda)
+    gem = create_gem_model("ViT-B/16", clip=model)
+    gen = SamAutomaticMaskGenerator(sam_model_registry["default"](seed=0, device=cuda), points_per_side=8, pred_iou_thresh=-1e30,
+                                    stability_score_thresh=0.0, box_nms_thresh=2.0, min_mask_region_area=800)
+    refs = [synthetic_ref(i, cuda, N=64, sam_img_size=1024, gem=True, device_blur=True)[0] for i in range(8)]
+    mk = lambda: HybridGLPipeline(model, mask_generator=gen, use_sam_masks=True, gem_model=gem)
+    rows = []
+    for g in (4, 2, 4):
+        p = mk()
+        assert p.run(iter(refs), group=g, proposal_cap=64, collect=True) == 8
+        torch.cuda.synchronize()
+        rows.append(p.partial_rows())
+        assert all(h.shape == (64, 512) for h, _, _ in p.collected)
+    assert np.array_equal(rows[0], rows[1]) and np.array_equal(rows[0], rows[2])
+    assert rows[0].shape == (24, 6) and (rows[0][:, 3] > 0).all()
+    del gen
+    torch.cuda.empty_cache()
