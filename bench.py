@@ -356,7 +356,7 @@ def main():
     do_steps(args.warmup)
     torch.cuda.synchronize()
     # the metric rows of the report are those of the timed steps only
-    pipe.cum.zero_(); pipe.iu_log.clear(); pipe.iu_owner.clear()
+    pipe.cum.zero_(); pipe.iu_log.clear(); pipe.iu_owner.clear(); pipe.idx_log.clear()
     ops.split_overflow_count(reset=True)
     barrier()
     torch.cuda.synchronize()
@@ -373,7 +373,7 @@ def main():
     # ---- roofline leg: one group of the same loop with every stage on ONE stream, HIP events around every launch
     lib.hgl_prof_enable(1)
     nprof = max(nbatch, 2)
-    keep_rows = (pipe.cum.clone(), list(pipe.iu_log), list(pipe.iu_owner))
+    keep_rows = (pipe.cum.clone(), list(pipe.iu_log), list(pipe.iu_owner), list(pipe.idx_log))
     if nbatch == 1:
         for i in range(nprof):
             pipe.step(refs[i % len(refs)])
@@ -382,7 +382,7 @@ def main():
                  serial=True)
     torch.cuda.synchronize()
     lib.hgl_prof_enable(0)
-    pipe.cum.copy_(keep_rows[0]); pipe.iu_log[:] = keep_rows[1]; pipe.iu_owner[:] = keep_rows[2]
+    pipe.cum.copy_(keep_rows[0]); pipe.iu_log[:] = keep_rows[1]; pipe.iu_owner[:] = keep_rows[2]; pipe.idx_log[:] = keep_rows[3]
     g_n, g_ms, g_fl, g_by = prof_read(lib, 0)
     a_n, a_ms, a_fl, a_by = prof_read(lib, 1)
     x_n, x_ms, x_fl, x_by = prof_read(lib, 3)

@@ -265,8 +265,7 @@ class CLIPViTFM:
             # over all rows (a group of dataset items; every row is independent)
             segs = [pm if pm.dtype in (torch.bool, torch.uint8) else (pm != 0) for pm in pred_masks]
             segs = [ops._u8(pm.contiguous(), "pred_masks")[1] for pm in segs]
-            assert sum(int(pm.shape[0]) for pm in segs) == N, "one mask per image row"
-            ns = len(segs)
+            ns = len(segs)       # (the library checks that the runs hold N masks in all)
             ptrs = (C.c_void_p * ns)(*[pm.data_ptr() for pm in segs])
             sn = (C.c_int * ns)(*[int(pm.shape[0]) for pm in segs])
             sh = (C.c_int * ns)(*[int(pm.shape[1]) for pm in segs])

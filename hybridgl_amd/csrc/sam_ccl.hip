@@ -164,32 +164,10 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t* __restric
   })
 }
 
-// Pass C -- per run (its last pixel): add the run length to the component's area.
-__global__ __launch_bounds__(256) void ccl_count_kernel(const uint8_t* __restrict__ masks, int holes, const int* __restrict__ L,
-                                                        int* __restrict__ area, int W, long long rows) {
-  const int lane = threadIdx.x & 63;
-  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const long long base = row * W;
-  RowScan c;
-  c.init(masks + base, W, holes, lane);
-  CCL_FOR_STEPS(c.load(g0, lane), {
-    c.step(k, x0, lane);
-    if (c.work && !c.right) {
-      const int r = uf_find(L, (int)(base + c.start));
-      atomicAdd(&area[r], x0 + lane - c.start + 1);
-    }
-    c.advance(x0);
-  })
-}
-
-// Pass D -- run starts are pointed at their root; the lane that finds a root (L[i] == i) also files the component
-// into its mask's statistics: stats[n*4+0] = number of small components, [1] = number of large ones, ([3]:[2]) =
-// one 64-bit key (area << 32 | 0x7fffffff - root) maximised atomically, i.e. the largest area and, among equals,
-// the smallest root -- the reference's "first largest" component (label order = raster order of first pixels).
+// Pass C -- every run start is pointed at its root (find with path halving: the chains the unions left behind collapse as
+// the pass goes), so the passes after it read a run's component with ONE load.
 __global__ __launch_bounds__(256) void ccl_compress_kernel(const uint8_t* __restrict__ masks, int holes, int* __restrict__ L,
-                                                           const int* __restrict__ area, int W, long long HW, long long rows,
-                                                           int thresh, int* __restrict__ stats) {
+                                                           int W, long long rows) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -200,18 +178,106 @@ __global__ __launch_bounds__(256) void ccl_compress_kernel(const uint8_t* __rest
     c.step(k, x0, lane);
     if (c.work && !c.left) {
       const int i = (int)(base + x0 + lane);
-      const int r = uf_find(L, i);
-      if (r == i) {
-        const int n = (int)(i / HW), a = area[i];
-        atomicAdd(&stats[n * 4 + (a < thresh ? 0 : 1)], 1);
-        const unsigned long long key = ((unsigned long long)(unsigned)a << 32) | (unsigned)(0x7fffffff - i);
-        atomicMax((unsigned long long*)(stats + n * 4 + 2), key);
-      } else {
-        L[i] = r;
+      const int r = uf_find_compress(L, i);
+      if (r != i) L[i] = r;      // (a plain store: links only ever move towards the root, and r IS the root now)
+    }
+    c.advance(x0);
+  })
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Pass D -- per run (its last pixel): add the run length to the component's area.  Speckled masks (thousands of runs per
+// row, most of them in ONE percolating component) would send all those adds to one address; the wave therefore carries
+// a (root, sum) pair across the steps of its row: lanes whose run belongs to the carried root are summed with shuffles,
+// the pair is flushed with one atomic when another root takes over or the row ends.  Two candidate roots per step at most;
+// what is left adds on its own.
+__global__ __launch_bounds__(256) void ccl_count_kernel(const uint8_t* __restrict__ masks, int holes, const int* __restrict__ L,
+                                                        int* __restrict__ area, int W, long long rows) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long long base = row * W;
+  RowScan c;
+  c.init(masks + base, W, holes, lane);
+  int acc_root = -1, acc_sum = 0;      // wave-uniform
+  CCL_FOR_STEPS(c.load(g0, lane), {
+    c.step(k, x0, lane);
+    bool act = c.work && !c.right;
+    const int r = act ? L[base + c.start] : -1;
+    const int len = x0 + lane - c.start + 1;
+    unsigned long long todo = __ballot(act);
+    if (todo) {
+      if (acc_root >= 0) {
+        const bool same = act && r == acc_root;
+        const unsigned long long m = __ballot(same);
+        if (m) { acc_sum += wave_sum(same ? len : 0); act = act && !same; todo &= ~m; }
+      }
+      if (todo) {     // runs of other components: the first one's root becomes the carried one if it brings company
+        const int rr = __shfl(r, __ffsll((long long)todo) - 1);
+        const bool same = act && r == rr;
+        const unsigned long long m = __ballot(same);
+        if (__popcll(m) > 1 || acc_root < 0) {
+          if (acc_root >= 0 && lane == 0) atomicAdd(&area[acc_root], acc_sum);
+          acc_root = rr;
+          acc_sum = wave_sum(same ? len : 0);
+          act = act && !same;
+        }
+      }
+      if (act) atomicAdd(&area[r], len);
+    }
+    c.advance(x0);
+  })
+  if (acc_root >= 0 && lane == 0) atomicAdd(&area[acc_root], acc_sum);
+}
+
+// Pass E -- the roots (L[i] == i) file their component into the mask's statistics: stats[n*4+0] = number of small
+// components, [1] = number of large ones, ([3]:[2]) = one 64-bit key (area << 32 | 0x7fffffff - root) maximised, i.e. the
+// largest area and, among equals, the smallest root -- the reference's "first largest" component (label order = raster
+// order of first pixels).  A wave's row belongs to ONE mask, so the counts and the key are reduced over the row first:
+// three atomics per row, not three per component (a speckled mask has tens of thousands).
+__global__ __launch_bounds__(256) void ccl_stats_kernel(const uint8_t* __restrict__ masks, int holes, const int* __restrict__ L,
+                                                        const int* __restrict__ area, int W, long long HW, long long rows,
+                                                        int thresh, int* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long long base = row * W;
+  RowScan c;
+  c.init(masks + base, W, holes, lane);
+  int n_small = 0, n_large = 0;
+  unsigned long long key = 0;
+  CCL_FOR_STEPS(c.load(g0, lane), {
+    c.step(k, x0, lane);
+    if (c.work && !c.left) {
+      const int i = (int)(base + x0 + lane);
+      if (L[i] == i) {
+        const int a = area[i];
+        if (a < thresh) ++n_small; else ++n_large;
+        const unsigned long long kk = ((unsigned long long)(unsigned)a << 32) | (unsigned)(0x7fffffff - i);
+        key = kk > key ? kk : key;
       }
     }
     c.advance(x0);
   })
+  n_small = wave_sum(n_small);
+  n_large = wave_sum(n_large);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = ((unsigned long long)(unsigned)__shfl_xor((int)(key >> 32), o) << 32) |
+                                     (unsigned)__shfl_xor((int)(unsigned)key, o);
+    key = other > key ? other : key;
+  }
+  if (lane == 0) {
+    const int n = (int)(base / HW);
+    if (n_small) atomicAdd(&stats[n * 4 + 0], n_small);
+    if (n_large) atomicAdd(&stats[n * 4 + 1], n_large);
+    if (key) atomicMax((unsigned long long*)(stats + n * 4 + 2), key);
+  }
 }
 
 __global__ void ccl_stats_init_kernel(int* stats, int N) {
@@ -220,7 +286,7 @@ __global__ void ccl_stats_init_kernel(int* stats, int N) {
   stats[n * 4 + 0] = 0; stats[n * 4 + 1] = 0; stats[n * 4 + 2] = 0; stats[n * 4 + 3] = 0;
 }
 
-// Pass E -- holes:   out = mask | (working && area < thresh)                      (fill small holes)
+// Pass F -- holes:   out = mask | (working && area < thresh)                      (fill small holes)
 //           islands: out = working && area >= thresh ; if no component is large, keep the (first) largest
 __global__ __launch_bounds__(256) void ccl_apply_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ L,
                                                         const int* __restrict__ area, const int* __restrict__ stats,
@@ -335,9 +401,10 @@ int hgl_remove_small_regions(const uint8_t* masks, int N, int H, int W, int area
   hipLaunchKernelGGL(ccl_rows_kernel, grid, dim3(256), 0, st, masks, holes, W, rows, L, area);
   hipLaunchKernelGGL(ccl_stats_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stats, N);
   hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, st, masks, holes, L, H, W, rows);
+  hipLaunchKernelGGL(ccl_compress_kernel, grid, dim3(256), 0, st, masks, holes, L, W, rows);
   hipLaunchKernelGGL(ccl_count_kernel, grid, dim3(256), 0, st, masks, holes, (const int*)L, area, W, rows);
-  hipLaunchKernelGGL(ccl_compress_kernel, grid, dim3(256), 0, st, masks, holes, L, (const int*)area, W, HW, rows, area_thresh,
-                     stats);
+  hipLaunchKernelGGL(ccl_stats_kernel, grid, dim3(256), 0, st, masks, holes, (const int*)L, (const int*)area, W, HW, rows,
+                     area_thresh, stats);
   hipLaunchKernelGGL(ccl_apply_kernel, grid, dim3(256), 0, st, masks, (const int*)L, (const int*)area, (const int*)stats, holes,
                      H, W, rows, area_thresh, out, changed);
   return hgl_check_launch("remove_small_regions");

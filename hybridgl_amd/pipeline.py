@@ -126,6 +126,7 @@ class HybridGLPipeline:
         self.cum = torch.zeros(4, dtype=torch.int64, device=dev)
         self.iu_log = []  # per sentence (IU_pure, IU_final) device tensors
         self.iu_owner = []  # per sentence (dataset position of its ref, sentence number)
+        self.idx_log = []   # per sentence: device int32 [2] = (index of the pure-CLIP winner, index with spatial guidance)
         self._n_refs = 0
 
     def _join_side_streams(self, cur, outs):
@@ -250,6 +251,7 @@ class HybridGLPipeline:
             self.cum[2:4] += iu1
             self.iu_log.append((iu0, iu1))
             self.iu_owner.append((ref_index, sent_no))
+            self.idx_log.append(idx)
             last = (idx, sc, sn, gem)
         return last
 
@@ -448,6 +450,13 @@ class HybridGLPipeline:
             return np.zeros((0, 6), dtype=np.int64)
         iu = torch.stack([torch.cat([a.reshape(2), b.reshape(2)]) for a, b in self.iu_log]).cpu().numpy().astype(np.int64)
         return np.concatenate([np.asarray(self.iu_owner, dtype=np.int64).reshape(-1, 2), iu], axis=1)
+
+    def winning_indices(self):
+        """[n_sentences, 2] int64: per sentence the proposal indices (pure CLIP, with spatial guidance) into that ref's
+        proposal list, in the order the sentences were scored.  One device->host copy."""
+        if not self.idx_log:
+            return np.zeros((0, 2), dtype=np.int64)
+        return torch.stack(self.idx_log).cpu().numpy().astype(np.int64)
 
     def metrics(self, dist=None):
         """Hybridgl_main.py:240-247: overall IoU and mean IoU, pure and with spatial guidance; with an initialised

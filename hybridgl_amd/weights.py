@@ -93,6 +93,18 @@ def clip_state_dict(name="ViT-B/16", seed=0):
     return sd
 
 
+def clip_shapes(name="ViT-B/16"):
+    """{key: shape} of the CLIP state_dict of a geometry, without drawing a single value (the key set and shapes are what
+    build_model's geometry inference reads, clip/model.py:474-503)"""
+    global _draw
+    keep = _draw
+    _draw = lambda seed, nm, shape, std, mean=0.0: np.broadcast_to(np.float32(0), shape)
+    try:
+        return {k: tuple(v.shape) for k, v in clip_state_dict(name, 0).items()}
+    finally:
+        _draw = keep
+
+
 def clip_vision_heads(cfg):
     return cfg["vision_width"] // 64  # clip/model.py:333
 

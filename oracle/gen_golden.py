@@ -281,7 +281,7 @@ def gen_scoring():
     np.savez_compressed(os.path.join(GOLD, "scoring.npz"), **out)
 
 
-def ref_tail(bb, utils, hybrid, t_pos, t_neg, masks, boxes, attn, gt, rela, dirflag, has_other, k1=3, k2=6):
+def ref_tail(bb, utils, hybrid, t_pos, t_neg, masks, boxes, attn, gt, rela, dirflag, has_other, k1=3, k2=6, info=None):
     """One sentence of the tail of Hybridgl_main.py:153-230, glue restated, every helper the reference's own
     (calculate_score, relation_boxes, gen_dir_mask, Compute_IoU).  Returns (idx_pure, idx_final, (I, U), k1, k2) with the
     k1 / k2 the reference would carry on to the next sentence (:178-181)."""
@@ -319,6 +319,9 @@ def ref_tail(bb, utils, hybrid, t_pos, t_neg, masks, boxes, attn, gt, rela, dirf
         for i in range(k1):
             topscores[i] = topscores[i] * (1 - 0.6) + 0.6 * float(gem[maxidxs[i]])
         idx_final = int(maxidxs[torch.argmax(topscores)])
+        if info is not None:     # how decided the final arg-max was (fixture selection only)
+            ts = torch.sort(topscores, descending=True).values
+            info["final_margin"] = float(ts[0] - ts[1]) if len(ts) > 1 else float("inf")
         _, _, cI, cU = utils.Compute_IoU(torch.from_numpy(masks[idx_final]), torch.from_numpy(gt[None].astype(np.uint8)), 0, 0, [])
     return idx_pure, idx_final, (int(cI), int(cU)), k1, k2, gem
 
@@ -690,6 +693,201 @@ def gen_tokenizer():
     np.savez_compressed(os.path.join(GOLD, "tokenizer.npz"), **out)
 
 
+from oracle.gen_cases_e2e import E2E_CASES  # noqa: E402
+
+
+def ref_views(img, blurred, masks_np, res):
+    """Hybridgl_main.py:93-125, statement for statement (see gen_views for what stands in for cv2 / torchvision)."""
+    from hybridgl_amd import synth
+    imagesrc = torch.from_numpy(img)[None]
+    original_img = torch.from_numpy(synth.imagenet_normalize(img))[None]       # image['image'] (dataset_refer_bert.py:155)
+    masks = torch.from_numpy(masks_np)
+    pixel_mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).reshape(1, 3, 1, 1)
+    to_tensor = lambda a: torch.from_numpy(a).permute(2, 0, 1).float().div(255)
+    resize = lambda x: F.interpolate(x[None] if x.dim() == 3 else x, size=(res, res), mode="bilinear", align_corners=False)[0]
+    normalize = lambda x: (x - torch.tensor([0.485, 0.456, 0.406])[:, None, None]) / torch.tensor([0.229, 0.224, 0.225])[:, None, None]
+    global_imgs, local_imgs = [], []
+    for pred_mask in masks:
+        pred_mask = pred_mask.type(torch.uint8)
+        global_img = imagesrc[0].numpy()
+        mask = pred_mask.cpu().numpy()
+        sharp_region = np.where(np.clip(mask, 0, 255).astype(np.uint8)[:, :, None] != 0, global_img, 0).astype(np.uint8)  # cv2.bitwise_and(img, img, mask=)
+        inv_mask = 1 - mask
+        blurred_region = (blurred * inv_mask[:, :, None]).astype(np.uint8)
+        global_img = np.clip(sharp_region.astype(np.int32) + blurred_region.astype(np.int32), 0, 255).astype(np.uint8)  # cv2.add (saturating)
+        global_img = normalize(resize(to_tensor(global_img)))
+        global_imgs.append(global_img)
+        masked_image = original_img * pred_mask[None, None, ...] + (1 - pred_mask[None, None, ...]) * pixel_mean
+        masked_image = resize(masked_image.squeeze(0))
+        local_imgs.append(masked_image.squeeze(0))
+    return torch.stack(local_imgs, dim=0), torch.stack(global_imgs, dim=0)
+
+
+def gen_e2e_tiny():
+    """WHOLE refs through the reference, stage into stage (Hybridgl_main.py:85-230): the reference's
+    SamAutomaticMaskGenerator.generate (tiny SAM) -> masks / XYWH boxes exactly as :86-90 build them -> the view loop
+    (:93-125) -> the reference's CLIPViTFM.forward (tiny CLIP, :128) -> encode_text + the text glue (:146-165) -> the tail
+    (:153-230, ref_tail) with a seeded heat-map in the place of GEM's -> per sentence (idx_pure, idx_final, I, U).  The k1 / k2
+    clamp is carried from ref to ref as the reference's loop does.  What this pins are the JOINS between the stages (bbox
+    format into relation_boxes, the order of the masks after the second NMS, bool / uint8 conventions, which tensors the
+    views are cut from); every stage alone has its own fixture.  Unpinned inputs, as everywhere: the blur taps (cv_oracle),
+    NMS / connected components (stubs = our restatements), the heat-map (given)."""
+    from hybridgl_amd import synth
+    from oracle import cv_oracle as CV
+    sys.path.insert(0, REF)
+    utils = _load("ref_utils", os.path.join(REF, "utils.py"))
+    bb = build_ref_backbone("tiny", 0)
+    sam = build_ref_sam("tiny", 0)
+    from segment_anything import SamAutomaticMaskGenerator
+    import warnings
+    out = {}
+    # Random weights give noise logits.  The mask threshold sits at their 97 % quantile: the candidates then differ a lot
+    # (areas from 0 to a sixth of the image), their hybrid features with them (logit margins of 1e-2 .. 1e-1 between the best
+    # proposals, printed below), and few pixels lie near the threshold (0.5 per mask within 1e-4).  box_nms_thresh is opened
+    # (1.5): the NMS then only ORDERS the candidates (by predicted IoU; with 0.7 the large ones suppress each other and what
+    # is left are empty masks whose features coincide) -- deciding thresholds have their own fixture (sam_tiny.npz: dec_*).
+    # measured once on the first image and stored
+    with torch.no_grad():
+        probe = SamAutomaticMaskGenerator(sam, points_per_side=6, pred_iou_thresh=-1e9, stability_score_thresh=0.0, box_nms_thresh=1.5)
+        img0 = synth.synth_image(E2E_CASES[0][1], E2E_CASES[0][2], E2E_CASES[0][0])
+        probe.predictor.set_image(img0)
+        pts = probe.point_grids[0] * np.array([[img0.shape[1], img0.shape[0]]])
+        tp = probe.predictor.transform.apply_coords(pts, img0.shape[:2])
+        lg, _, _ = probe.predictor.predict_torch(torch.as_tensor(tp)[:, None, :], torch.ones(len(tp), 1, dtype=torch.int),
+                                                 multimask_output=True, return_logits=True)
+        thr = float(np.quantile(lg.numpy(), 0.97))
+    sam.mask_threshold = thr
+    out["mask_threshold"] = np.array([thr], np.float64)
+    out["amg"] = np.array([6, -1e9, 0.0, 1.5, 6], dtype=np.float64)   # points_per_side, pred_iou, stability, box_nms, min_area
+    gen = SamAutomaticMaskGenerator(sam, points_per_side=6, pred_iou_thresh=-1e9, stability_score_thresh=0.0,
+                                    box_nms_thresh=1.5, crop_n_layers=0, crop_n_points_downscale_factor=1, min_mask_region_area=6)
+    r = 0.5
+    k1, k2 = 3, 6
+    for ci, (iseed, H, W, tseed, sents, gseed) in enumerate(E2E_CASES):
+        for mode in ("G2L", "G2L&L2G"):
+            if mode != "G2L" and ci != 0:
+                continue
+            tag = f"c{ci}_{mode.replace('&', '_')}"
+            kk1, kk2 = (k1, k2) if mode == "G2L" else (3, 6)
+            with torch.no_grad(), warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                sam_img = synth.synth_image(H, W, iseed)
+                sam_masks = gen.generate(sam_img)                                            # :85
+                masks = torch.stack([torch.tensor(m["segmentation"]) for m in sam_masks])   # :86-87
+                boxes = torch.tensor([m["bbox"] for m in sam_masks])                         # :89-90
+                blurred = CV.gaussian_blur_u8(sam_img, 15)                                   # :99 (restated taps)
+                local_imgs, global_imgs = ref_views(sam_img, blurred, masks.numpy(), 64)
+                hybrid = bb(local_imgs=local_imgs, global_imgs=global_imgs, pred_masks=masks, fusion_mode=mode, masking_block=9)  # :128
+                n_rows = sum(2 + n for _, _, n in sents)
+                gt = synth.synth_masks(1, H, W, gseed)[0]
+                # the strings are seeded tokens; the seed is advanced until both decisions of every sentence are clear of
+                # the device's error budget (raw logits 4e-3 apart, blended top-k scores 1e-4 apart) -- the chosen seed is stored
+                for tries in range(200):
+                    tok = synth.synth_tokens(n_rows, 16, 512, tseed + 1000 * tries)
+                    row = 0
+                    res_idx, res_iu, margins = [], [], []
+                    c1, c2 = kk1_in, kk2_in = kk1, kk2
+                    for j, (dirflag, rela, n_other) in enumerate(sents):
+                        t = torch.from_numpy(tok[row:row + 2 + n_other].astype(np.int64))
+                        row += 2 + n_other
+                        sentence_features = bb.model.encode_text(t[0:1])
+                        noun_phrase_features = bb.model.encode_text(t[1:2])
+                        text_ensemble = r * sentence_features + (1 - r) * noun_phrase_features
+                        other = torch.zeros(1, sentence_features.shape[1])
+                        for q in range(n_other):
+                            other += bb.model.encode_text(t[2 + q:3 + q])
+                        if n_other:
+                            other = other / n_other
+                        attn = synth.synth_heatmap(H, W, 6000 + 10 * ci + j)
+                        info = {}
+                        ip, ifin, iu_f, c1, c2, gem_s = ref_tail(bb, utils, hybrid.numpy(), text_ensemble.numpy(), other.numpy(),
+                                                                masks.numpy(), boxes.numpy(), attn, gt, rela, dirflag, n_other > 0, c1, c2, info)
+                        _, _, cI, cU = utils.Compute_IoU(masks[ip], torch.from_numpy(gt[None].astype(np.uint8)), 0, 0, [])
+                        res_idx.append([ip, ifin])
+                        res_iu.append([int(cI), int(cU), iu_f[0], iu_f[1]])
+                        sc = bb.calculate_score(hybrid, text_ensemble).view(-1)
+                        top2 = torch.topk(sc, min(2, len(sc))).values
+                        margins.append([float(top2[0] - top2[-1]), info["final_margin"]])
+                    if all(a >= 4e-3 and b >= 1e-4 for a, b in margins):
+                        break
+                else:
+                    raise RuntimeError(f"e2e {tag}: no text seed with clear decisions")
+                kk1, kk2 = c1, c2
+                for j in range(len(sents)):
+                    print(f"  e2e {tag} sentence {j}: idx {res_idx[j]} IU {res_iu[j]} margins {margins[j][0]:.4f} / {margins[j][1]:.2e} (text seed {tseed + 1000 * tries})")
+                out[f"{tag}_text_seed"] = np.array([tseed + 1000 * tries], dtype=np.int64)
+                if mode == "G2L":
+                    k1, k2 = kk1, kk2
+            out[f"{tag}_masks"] = np.packbits(masks.numpy(), axis=-1)
+            out[f"{tag}_boxes"] = boxes.numpy().astype(np.int64)
+            out[f"{tag}_hybrid"] = hybrid.numpy().astype(np.float32)
+            out[f"{tag}_idx"] = np.array(res_idx, dtype=np.int64)
+            out[f"{tag}_IU"] = np.array(res_iu, dtype=np.int64)
+            out[f"{tag}_k"] = np.array([kk1, kk2], dtype=np.int64)
+            out[f"{tag}_margin"] = np.array(margins, dtype=np.float64)
+            print("e2e", tag, "masks", tuple(masks.shape), "k after", kk1, kk2)
+    np.savez_compressed(os.path.join(GOLD, "e2e_tiny.npz"), **out)
+
+
+def state_dict_digest(sd):
+    """order-independent digest of a state_dict: key names, dtypes, shapes and raw bytes"""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        v = sd[k].detach().cpu().contiguous()
+        h.update(k.encode())
+        h.update(str(v.dtype).encode())
+        h.update(str(tuple(v.shape)).encode())
+        h.update(v.numpy().tobytes() if v.dtype != torch.bfloat16 else v.view(torch.int16).numpy().tobytes())
+    return h.hexdigest()
+
+
+def gen_ckpt():
+    """Checkpoint files as the reference's loaders meet them, for the loaders of this package.  The files themselves are
+    30 MB, so they are NOT stored: tests/ckpt_files.py rebuilds them from the seeded weights, and this fixture holds what
+    makes that rebuild a reference-produced file -- the digest of the reference's own state_dicts and the list of tensors
+    its convert_weights stores as fp16 -- plus the reference's outputs with those weights:
+    * CLIP: the OpenAI archives hold fp16 weights (the reference's convert_weights, clip/model.py:434-459, says which);
+      clip/clip.py:119-142 hands their state_dict -- incl. the three scalar entries -- to build_model
+      (clip/model.py:474-511), which infers the geometry from the key set and leaves the weights up-cast to fp32
+      because :509 is commented out.  Stored: outputs of build_model(that state_dict).
+    * SAM: build_sam.py:103-106 torch.load()s a plain fp32 state_dict."""
+    m = ref_clip_model_module()
+    model = build_ref_clip("tiny", 0)
+    m.convert_weights(model)                              # fp16 storage, as the published archives
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    cfg = weights.CLIP_CONFIGS["tiny"]
+    sd["input_resolution"] = torch.tensor(cfg["image_resolution"])
+    sd["context_length"] = torch.tensor(cfg["context_length"])
+    sd["vocab_size"] = torch.tensor(cfg["vocab_size"])
+    out = {"clip_fp16_keys": np.array(sorted(k for k, v in sd.items() if v.dtype == torch.float16)),
+           "clip_digest": np.array(state_dict_digest(sd)),
+           "clip_keys": np.array(sorted(sd))}
+    # the reference's loader on that state_dict: build_model (clip/model.py:474-511) -> fp32 model
+    ref = m.build_model({k: v.clone() for k, v in sd.items()}).float().eval()
+    tok = torch.from_numpy(glue_tokens(31, 2).astype(np.int64))
+    with torch.no_grad():
+        out["text"] = ref.encode_text(tok).numpy().astype(np.float32)
+    out["text_tokens_case"] = np.array([31, 2])
+    clip_stub = types.ModuleType("clip")
+    clip_stub.load = lambda name, *a, **k: (ref, None)
+    sys.modules["clip"] = clip_stub
+    bb = _load("ref_backbone_ckpt", os.path.join(REF, "model/backbone.py")).CLIPViTFM(model_name="ViT-B/16").eval()
+    bb.num_heads = cfg["vision_width"] // 64
+    loc, glo, masks = views_for_case(3, 64, 97, 130)
+    with torch.no_grad():
+        out["hybrid_G2L"] = bb(local_imgs=torch.from_numpy(loc), global_imgs=torch.from_numpy(glo), pred_masks=torch.from_numpy(masks),
+                               fusion_mode="G2L", masking_block=9).numpy().astype(np.float32)
+    # SAM: the reference module's own state_dict (what a released .pth holds)
+    install_sam_stubs()
+    sam = build_ref_sam("tiny", 0)
+    ssd = sam.state_dict()
+    out["sam_digest"] = np.array(state_dict_digest(ssd))
+    out["sam_keys"] = np.array(sorted(ssd))
+    print("ckpt: clip", len(sd), "entries,", len(out["clip_fp16_keys"]), "fp16; sam", len(ssd), "entries")
+    np.savez_compressed(os.path.join(GOLD, "ckpt.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -736,3 +934,8 @@ if __name__ == "__main__":
     if want("sam_crops"):
         install_sam_stubs()
         gen_sam_crops()
+    if want("e2e_tiny"):
+        install_sam_stubs()
+        gen_e2e_tiny()
+    if want("ckpt"):
+        gen_ckpt()

@@ -1,0 +1,114 @@
+"""WHOLE refs against the reference (tests/golden/e2e_tiny.npz, oracle/gen_golden.py: gen_e2e_tiny): the reference's
+generate() -> masks / XYWH boxes -> view loop -> CLIPViTFM.forward -> encode_text + text glue -> tail -> (idx_pure,
+idx_final, I, U), stage into stage (Hybridgl_main.py:85-230).  Every stage alone has its own fixture; this one pins the
+JOINS: the bbox format handed to relation_boxes, the order of the masks after the two NMS passes, bool / uint8
+conventions, which tensors the views are cut from, the k1 / k2 carried from ref to ref."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.gen_cases_e2e import E2E_CASES   # noqa: E402  (seeds and parse records of the fixture's refs)
+
+
+def _ref(case, tag, g, cuda, index):
+    from hybridgl_amd import synth
+    from hybridgl_amd.pipeline import RefBatch, Sentence
+    iseed, H, W, _, sents, gseed = case
+    img = synth.synth_image(H, W, iseed)
+    n_rows = sum(2 + n for _, _, n in sents)
+    tok = synth.synth_tokens(n_rows, 16, 512, int(g[f"{tag}_text_seed"][0]))
+    gt = synth.synth_masks(1, H, W, gseed)[0]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    ss, row = [], 0
+    ci = index
+    for j, (dirflag, rela, n_other) in enumerate(sents):
+        ss.append(Sentence(row, row + 1, list(range(row + 2, row + 2 + n_other)), dirflag, rela, n_other,
+                           t(synth.synth_heatmap(H, W, 6000 + 10 * ci + j))))
+        row += 2 + n_other
+    return RefBatch(t(img), None, t(synth.imagenet_normalize(img)), torch.zeros((1, H, W), dtype=torch.bool, device=cuda),
+                    torch.zeros((1, 4), dtype=torch.int64, device=cuda), t(tok), t(gt), ss, None,
+                    token_len=int(tok.argmax(axis=1).max()) + 1, index=index)
+
+
+@pytest.fixture(scope="module")
+def world(cuda, golden_dir):
+    from hybridgl_amd import sam as hsam, weights
+    from hybridgl_amd.backbone import CLIPViTFM
+    g = np.load(os.path.join(golden_dir, "e2e_tiny.npz"))
+    model = CLIPViTFM("tiny", state_dict=weights.clip_state_dict("tiny", 0), device=cuda)
+    sam = hsam.sam_model_registry["tiny"](device=cuda)
+    sam.mask_threshold = float(g["mask_threshold"][0])
+    pps, iou_thr, stab_thr, nms_thr, area = g["amg"]
+    gen = hsam.SamAutomaticMaskGenerator(sam, points_per_side=int(pps), pred_iou_thresh=float(iou_thr),
+                                         stability_score_thresh=float(stab_thr), box_nms_thresh=float(nms_thr), crop_n_layers=0,
+                                         crop_n_points_downscale_factor=1, min_mask_region_area=int(area))
+    return g, model, gen
+
+
+def _check_ref(g, tag, W, masks, boxes, hybrid, idx, rows):
+    """masks [n,H,W] bool, boxes [n,4], hybrid [n,E], idx [s,2], rows [s,4] = (I, U, I_final, U_final) of one ref"""
+    ref_masks = np.unpackbits(g[f"{tag}_masks"], axis=-1)[..., :W].astype(bool)
+    assert masks.shape == ref_masks.shape, (masks.shape, ref_masks.shape)       # same number of proposals, same order below
+    mism = (masks != ref_masks).reshape(len(masks), -1).sum(axis=1)
+    # a logit within ~1e-5 of the mask threshold may fall on the other side (documented): a handful of pixels in all
+    assert mism.sum() <= 40 and mism.max() <= 10, (int(mism.sum()), int(mism.max()))
+    exact = mism == 0
+    assert exact.mean() > 0.9
+    assert np.array_equal(boxes[exact], g[f"{tag}_boxes"][exact])              # XYWH, exactly as :89-90 hand them on
+    assert np.abs(boxes - g[f"{tag}_boxes"]).max() <= 2
+    np.testing.assert_allclose(hybrid[exact], g[f"{tag}_hybrid"][exact], rtol=0, atol=1e-4)
+    assert np.array_equal(idx, g[f"{tag}_idx"]), (idx.tolist(), g[f"{tag}_idx"].tolist())     # winners: bit-exact
+    want = g[f"{tag}_IU"]
+    for s in range(len(idx)):
+        tol = (int(mism[idx[s, 0]]), int(mism[idx[s, 1]]))
+        assert abs(int(rows[s, 0]) - int(want[s, 0])) <= tol[0] and abs(int(rows[s, 1]) - int(want[s, 1])) <= tol[0]
+        assert abs(int(rows[s, 2]) - int(want[s, 2])) <= tol[1] and abs(int(rows[s, 3]) - int(want[s, 3])) <= tol[1]
+    return int(mism.sum())
+
+
+@pytest.mark.parametrize("how", ["step", "run"])
+def test_whole_refs_vs_reference(cuda, world, how):
+    """three refs (three image sizes, 3 + 2 + 3 sentences with every parse-record kind) in the reference's order, G2L;
+    `step`: ref by ref, `run`: the grouped two-stream loop over the same three."""
+    from hybridgl_amd.pipeline import HybridGLPipeline
+    g, model, gen = world
+    pipe = HybridGLPipeline(model, fusion_mode="G2L", masking_block=9, res=64, mask_generator=gen, use_sam_masks=True)
+    refs = [_ref(c, f"c{ci}_G2L", g, cuda, ci) for ci, c in enumerate(E2E_CASES)]
+    props, hybrids = [], []
+    if how == "step":
+        for r in refs:
+            hyb, _, _ = pipe.step(r)
+            props.append(pipe.last_proposals[:2])
+            hybrids.append(hyb)
+    else:
+        assert pipe.run(iter(refs), group=3, collect=True) == 3
+        hybrids = [c[0] for c in pipe.collected]
+        props = [gen.generate_device(r.sam_img)[:2] for r in refs]
+    torch.cuda.synchronize()
+    idx, rows = pipe.winning_indices(), pipe.partial_rows()
+    s0 = 0
+    flips = 0
+    for ci, c in enumerate(E2E_CASES):
+        ns = len(c[4])
+        assert (rows[s0:s0 + ns, 0] == ci).all() and rows[s0:s0 + ns, 1].tolist() == list(range(ns))
+        flips += _check_ref(g, f"c{ci}_G2L", c[2], props[ci][0].bool().cpu().numpy(), props[ci][1].cpu().numpy(),
+                            hybrids[ci].cpu().numpy(), idx[s0:s0 + ns], rows[s0:s0 + ns, 2:6])
+        s0 += ns
+    assert (pipe.k1, pipe.k2) == tuple(int(v) for v in g[f"c{len(E2E_CASES) - 1}_G2L_k"])
+    print(f"e2e {how}: {flips} pixels of {sum(np.prod(p[0].shape) for p in props)} differ from the reference's masks")
+
+
+def test_whole_ref_four_stream_fusion(cuda, world):
+    """the first ref again with fusion_mode G2L&L2G (BASELINE configs[3])"""
+    from hybridgl_amd.pipeline import HybridGLPipeline
+    g, model, gen = world
+    pipe = HybridGLPipeline(model, fusion_mode="G2L&L2G", masking_block=9, res=64, mask_generator=gen, use_sam_masks=True)
+    c = E2E_CASES[0]
+    hyb, _, _ = pipe.step(_ref(c, "c0_G2L_L2G", g, cuda, 0))
+    torch.cuda.synchronize()
+    _check_ref(g, "c0_G2L_L2G", c[2], pipe.last_proposals[0].bool().cpu().numpy(), pipe.last_proposals[1].cpu().numpy(),
+               hyb.cpu().numpy(), pipe.winning_indices(), pipe.partial_rows()[:, 2:6])

@@ -416,6 +416,26 @@ def test_remove_small_regions_full_size(cuda):
             assert np.array_equal(out[i], ref) and bool(changed[i]) == ch
 
 
+@pytest.mark.parametrize("mode", ["holes", "islands"])
+def test_remove_small_regions_speckled_full_size(cuda, mode):
+    """Speckle at full size -- what a random-weight SAM hands to the clean-up in the benchmark: blobs of a few pixels at
+    densities around the percolation threshold of 8-connectivity (tens of thousands of components per mask, one giant
+    component that collects most runs: the wave-carried area sums and the per-row statistics of the count / stats passes)."""
+    rng = np.random.default_rng(11)
+    H = W = 640
+    masks = np.zeros((6, H, W), dtype=bool)
+    for i, p in enumerate((0.3, 0.41, 0.5, 0.59, 0.7, 0.5)):
+        coarse = rng.random((H // 2 + 1, W // 2 + 1)) < p            # 2 x 2 blobs
+        masks[i] = np.repeat(np.repeat(coarse, 2, axis=0), 2, axis=1)[:H, :W]
+    masks[5] ^= rng.random((H, W)) > 0.9                             # + single-pixel noise
+    out, changed = hsam.remove_small_regions(T(masks.astype(np.uint8), cuda), 800, mode)
+    out, changed = out.cpu().numpy().astype(bool), changed.cpu().numpy()
+    for i in range(len(masks)):
+        ref, ch = S.remove_small_regions(masks[i], 800, mode)
+        assert bool(changed[i]) == ch, (i, mode)
+        assert np.array_equal(out[i], ref), (i, mode)
+
+
 @pytest.mark.parametrize("shape", [(160, 200, 256), (427, 640, 1024), (640, 640, 1024), (1500, 2000, 1024)])
 def test_resize_longest_side_bit_exact_vs_pillow(cuda, shape):
     from PIL import Image
