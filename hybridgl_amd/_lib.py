@@ -165,6 +165,8 @@ PROTOTYPES = {
     "hgl_gt_mask_from_polygons": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP]),
     "hgl_gt_mask_from_rle_counts": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "hgl_gt_mask_from_rle_string": (_I, [C.c_char_p, _I, _I, _VP, _VP]),
+    "hgl_rle_encode_mask": (_I, [_VP, _I, _I, _VP, _LL, C.POINTER(C.c_longlong)]),
+    "hgl_rle_to_string": (_I, [_VP, _LL, C.c_char_p, _SZ, C.POINTER(C.c_size_t)]),
 }
 
 _lib = None

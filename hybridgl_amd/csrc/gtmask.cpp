@@ -178,4 +178,57 @@ int hgl_gt_mask_from_rle_string(const char* s, int H, int W, uint8_t* mask, int6
   return HGL_OK;
 }
 
+// ---- the other direction: what SamAutomaticMaskGenerator's output_mode "uncompressed_rle" / "coco_rle" hands out
+// (automatic_mask_generator.py:176-182, utils/amg.py:107-153,294-300 -> pycocotools frPyObjects -> maskApi.c rleToString)
+
+// Column-major run lengths of a host mask [H,W] (any non-zero byte = foreground), first count = leading zeros (0 when the
+// mask starts with foreground): utils/amg.py:107-136 mask_to_rle_pytorch.  *m receives the number of counts; with
+// counts == nullptr or cap too small nothing is written beyond cap and the needed length is still reported.
+int hgl_rle_encode_mask(const uint8_t* mask, int H, int W, uint32_t* counts, long long cap, long long* m) {
+  HGL_REQUIRE(mask && m && H > 0 && W > 0 && cap >= 0, "rle_encode_mask: bad arguments");
+  long long n = 0;
+  unsigned run = 0;
+  bool cur = false;      // the first run counts zeros
+  for (int x = 0; x < W; ++x)
+    for (int y = 0; y < H; ++y) {
+      const bool v = mask[(size_t)y * W + x] != 0;
+      if (v != cur) {
+        if (counts && n < cap) counts[n] = run;
+        ++n;
+        run = 0;
+        cur = v;
+      }
+      ++run;
+    }
+  if (counts && n < cap) counts[n] = run;
+  ++n;
+  *m = n;
+  return HGL_OK;
+}
+
+// maskApi.c:203-216 rleToString: every count (from the fourth on: its difference to the count two places earlier) as a
+// little-endian group of 5-bit digits + continuation bit, one ASCII character (offset 48) per digit.  out needs
+// 6 * m + 1 bytes at most (a 32-bit value takes 7 characters only when negative differences need the sign digit; the
+// bound checked here is the exact one).  *len receives strlen(out).
+int hgl_rle_to_string(const uint32_t* counts, long long m, char* out, size_t cap, size_t* len) {
+  HGL_REQUIRE(counts && out && len && m >= 0 && cap >= 1, "rle_to_string: bad arguments");
+  size_t p = 0;
+  for (long long i = 0; i < m; ++i) {
+    long long x = (long long)counts[i];
+    if (i > 2) x -= (long long)counts[i - 2];
+    bool more = true;
+    while (more) {
+      unsigned c = (unsigned)(x & 0x1f);
+      x >>= 5;                                        // arithmetic shift, as the C `long` of the original
+      more = (c & 0x10) ? x != -1 : x != 0;
+      if (more) c |= 0x20;
+      HGL_REQUIRE(p + 1 < cap, "rle_to_string: output buffer too small (%zu bytes)", cap);
+      out[p++] = (char)(c + 48);
+    }
+  }
+  out[p] = 0;
+  *len = p;
+  return HGL_OK;
+}
+
 }  // extern "C"

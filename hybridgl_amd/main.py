@@ -53,6 +53,11 @@ def default_argument_parser():
     p.add_argument("--group", type=int, default=8,
                    help="images taken at a time by the two-stream loop (HybridGLPipeline.run); 1 = ref by ref on one stream")
     p.add_argument("--workers", type=int, default=4, help="loader threads (Hybridgl_main.py:45 num_workers)")
+    p.add_argument("--k_clamp", default="auto", choices=["auto", "persistent", "per_ref"],
+                   help="the k1 / k2 clamp of Hybridgl_main.py:178-181: persistent = the reference's quirk (once an image yields "
+                        "fewer than 3 / 6 proposals the clamp stays for every later item OF THE PROCESS: depends on the number of "
+                        "ranks); per_ref = that item only (order- and sharding-independent); auto = persistent on one rank, "
+                        "per_ref under sharding")
     return p
 
 
@@ -144,6 +149,7 @@ def main(args):
     assert torch.cuda.is_available(), "hybridgl_amd has no CPU path"
     rank, local_rank, world = D.env_rank()
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    cores = D.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # launch + loader threads of a rank on its own cores
     torch.cuda.set_device(dev)
     dist = D.init_process_group(os.environ.get("HYBRIDGL_DIST_BACKEND", "nccl"), dev) if world > 1 else None
     splitBy = "umd" if args.dataset == "refcocog" else "unc"          # Hybridgl_main.py:26-29
@@ -160,10 +166,13 @@ def main(args):
     if args.heatmap == "device":
         from .gem import create_gem_model
         gem_model = create_gem_model(args.clip_model, clip=model)          # Hybridgl_main.py:36-38 (same checkpoint: shared weights)
+    k_clamp = args.k_clamp if args.k_clamp != "auto" else ("persistent" if world == 1 else "per_ref")
     pipe = HybridGLPipeline(model, fusion_mode=args.fusion_mode, masking_block=9, mask_generator=gen,
-                            use_sam_masks=args.real, gem_model=gem_model)
+                            use_sam_masks=args.real, gem_model=gem_model, k_clamp=k_clamp)
     if rank == 0:
         print(f"fusion mode={args.fusion_mode}")
+        if world > 1:
+            print(f"ranks: {dist.get_world_size()} ({dist.get_backend()}), k_clamp={k_clamp}, host cores per rank: {len(cores) or 'unpinned'}")
     from .loader import Prefetcher
     if args.real:
         from .weights import CLIP_CONFIGS

@@ -463,9 +463,18 @@ class HybridGLPipeline:
         torch.distributed (`dist`) the rows of all ranks are gathered first (the job's metrics, on every rank)."""
         from . import dist as D
         rows = self.partial_rows()
+        overflow = 0
         if getattr(self.model.model, "precision", "f32") == "f16x3":
-            ops.check_split_overflow()     # an activation beyond the fp16 range voids the run: raise, do not report
-        return D.gather_metrics(rows, dist, self.model.device)
+            overflow = ops.split_overflow_count(reset=True)
+        # exchange first, raise afterwards and on EVERY rank: a rank that raised before the all-gather would leave the others
+        # waiting in the collective
+        m = D.gather_metrics(rows, dist, self.model.device)
+        overflow = int(D.max_over_ranks(float(overflow), dist, self.model.device))
+        if overflow:     # an activation beyond the fp16 range voids the run: raise, do not report
+            from ._lib import HybridGLError
+            raise HybridGLError(f"activations exceeded the fp16 range (|x| > 65504) in f16x3 mode ({overflow} GPU threads saw one on "
+                                "some rank): the results contain inf / NaN; rerun with HYBRIDGL_PRECISION=f32 (or precision='f32')")
+        return m
 
 
 def synthetic_ref(i, device, N=64, H=640, W=640, n_sent=3, context=77, vocab=49408, sam_img_size=0, gem=False, gem_size=448,

@@ -489,7 +489,8 @@ class SamAutomaticMaskGenerator:
                  point_grids=None, min_mask_region_area=0, output_mode="binary_mask"):
         assert (points_per_side is None) != (point_grids is None), \
             "Exactly one of points_per_side or point_grid must be provided."
-        assert output_mode == "binary_mask", "only binary_mask output is on the reference's path"
+        assert output_mode in ["binary_mask", "uncompressed_rle", "coco_rle"], f"Unknown output_mode {output_mode}."
+        self.output_mode = output_mode      # automatic_mask_generator.py:103-112 (coco_rle needs no pycocotools here: native codec)
         self.model = model
         self.predictor = SamPredictor(model)
         if point_grids is None:
@@ -754,8 +755,16 @@ class SamAutomaticMaskGenerator:
             max(self.box_nms_thresh, self.crop_nms_thresh))
         return m2, nb
 
+    def _segmentation(self, mask):
+        """automatic_mask_generator.py:176-182: the record's `segmentation` in the configured output mode (binary mask,
+        uncompressed RLE dict, COCO RLE dict with the compressed counts string)."""
+        if self.output_mode == "binary_mask":
+            return mask
+        rle = mask_to_rle(mask)
+        return coco_encode_rle(rle) if self.output_mode == "coco_rle" else rle
+
     def generate(self, image):
-        """automatic_mask_generator.py:137-195 -> list of records (binary masks)."""
+        """automatic_mask_generator.py:137-195 -> list of records."""
         if self.crop_n_layers > 0:
             m, xywh, iou, stab, pts, cbs = self.generate_device_crops(image)
             masks = m.bool().cpu().numpy()
@@ -763,7 +772,7 @@ class SamAutomaticMaskGenerator:
             out = []
             for i in range(len(masks)):
                 cb = cbs[i]
-                out.append({"segmentation": masks[i], "area": int(masks[i].sum()), "bbox": [int(v) for v in xywh[i]],
+                out.append({"segmentation": self._segmentation(masks[i]), "area": int(masks[i].sum()), "bbox": [int(v) for v in xywh[i]],
                             "predicted_iou": float(iou[i]), "point_coords": [pts[i].tolist()],
                             "stability_score": float(stab[i]),
                             "crop_box": [int(cb[0]), int(cb[1]), int(cb[2] - cb[0]), int(cb[3] - cb[1])]})   # XYWH
@@ -775,11 +784,51 @@ class SamAutomaticMaskGenerator:
         points = np.repeat(self.point_grids[0] * np.array([[W, H]], dtype=np.float64), 3, axis=0)
         out = []
         for i in range(len(masks)):
-            out.append({"segmentation": masks[i], "area": int(masks[i].sum()),
+            out.append({"segmentation": self._segmentation(masks[i]), "area": int(masks[i].sum()),
                         "bbox": [int(v) for v in xywh[i]], "predicted_iou": float(iou[i]),
                         "point_coords": [points[idx[i]].tolist()], "stability_score": float(stab[i]),
                         "crop_box": [0, 0, W, H]})
         return out
+
+
+def mask_to_rle(mask):
+    """utils/amg.py:107-136 mask_to_rle_pytorch for one host mask [H,W]: {"size": [h, w], "counts": [...]} (column-major
+    runs, the first one counts zeros) through the native codec."""
+    lib = _lib.load()
+    mk = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+    H, W = mk.shape
+    m = C.c_longlong(0)
+    check(lib.hgl_rle_encode_mask(mk.ctypes.data, H, W, None, 0, C.byref(m)), "hgl_rle_encode_mask")
+    counts = np.empty(m.value, dtype=np.uint32)
+    check(lib.hgl_rle_encode_mask(mk.ctypes.data, H, W, counts.ctypes.data, m.value, C.byref(m)), "hgl_rle_encode_mask")
+    return {"size": [H, W], "counts": [int(v) for v in counts]}
+
+
+def rle_to_mask(rle):
+    """utils/amg.py:139-151."""
+    lib = _lib.load()
+    h, w = rle["size"]
+    counts = np.ascontiguousarray(np.asarray(rle["counts"], dtype=np.uint32))
+    out = np.empty((h, w), dtype=np.uint8)
+    check(lib.hgl_gt_mask_from_rle_counts(counts.ctypes.data, len(counts), h, w, out.ctypes.data, None), "hgl_gt_mask_from_rle_counts")
+    return out.astype(bool)
+
+
+def area_from_rle(rle):
+    """utils/amg.py:154-155."""
+    return sum(rle["counts"][1::2])
+
+
+def coco_encode_rle(uncompressed_rle):
+    """utils/amg.py:294-300: pycocotools' frPyObjects(uncompressed_rle) with the counts as a str -- the compressed string
+    comes from the native restatement of maskApi.c:203-216 rleToString."""
+    lib = _lib.load()
+    h, w = uncompressed_rle["size"]
+    counts = np.ascontiguousarray(np.asarray(uncompressed_rle["counts"], dtype=np.uint32))
+    buf = C.create_string_buffer(7 * len(counts) + 1)
+    n = C.c_size_t(0)
+    check(lib.hgl_rle_to_string(counts.ctypes.data, len(counts), buf, len(buf), C.byref(n)), "hgl_rle_to_string")
+    return {"size": [h, w], "counts": buf.raw[:n.value].decode("utf-8")}
 
 
 def remove_small_regions(masks, area_thresh, mode):

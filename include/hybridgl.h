@@ -470,6 +470,14 @@ int hgl_gt_mask_from_polygons(const double* xy, const int32_t* n_points, int n_p
 /* uncompressed RLE counts (column-major runs, zeros first) / the compressed string form */
 int hgl_gt_mask_from_rle_counts(const uint32_t* counts, int m, int H, int W, uint8_t* mask, int64_t* area);
 int hgl_gt_mask_from_rle_string(const char* s, int H, int W, uint8_t* mask, int64_t* area);
+/* The other direction -- the "uncompressed_rle" / "coco_rle" output modes of SamAutomaticMaskGenerator
+ * (automatic_mask_generator.py:176-182; utils/amg.py:107-136 mask_to_rle_pytorch, :294-300 coco_encode_rle ->
+ * pycocotools frPyObjects -> refer/external/maskApi.c:203-216 rleToString).  HOST memory.
+ * hgl_rle_encode_mask: column-major run lengths of mask [H,W] (first count = leading zeros); *m = number of counts
+ * (reported even when counts is NULL / cap too small: size query).
+ * hgl_rle_to_string: the compressed ASCII string of COCO; out needs at most 7*m+1 bytes; *len = strlen(out). */
+int hgl_rle_encode_mask(const uint8_t* mask, int H, int W, uint32_t* counts, long long cap, long long* m);
+int hgl_rle_to_string(const uint32_t* counts, long long m, char* out, size_t cap, size_t* len);
 
 #ifdef __cplusplus
 }

@@ -192,17 +192,25 @@ def test_hybrid_forward_over_segments_equals_per_image_calls(cuda):
         model(loc, glo, masks[:2], masking_block=9, fusion_mode="G2L")
 
 
-def test_full_size_dependent_groups_are_composition_independent(cuda):
+@pytest.fixture(scope="module")
+def full(cuda):
+    """ViT-B/16 + GEM + SAM ViT-H with seeded weights (full size)"""
+    from hybridgl_amd.backbone import CLIPViTFM
+    from hybridgl_amd.gem import create_gem_model
+    from hybridgl_amd.sam import sam_model_registry
+    model = CLIPViTFM("ViT-B/16", seed=0, device=cuda)
+    yield model, create_gem_model("ViT-B/16", clip=model), sam_model_registry["default"](seed=0, device=cuda)
+    torch.cuda.empty_cache()
+
+
+def test_full_size_dependent_groups_are_composition_independent(cuda, full):
     """BASELINE size (640x640, SAM ViT-H, ViT-B/16, 64 of SAM's own masks per image through clean-up into CLIP): run() in
     groups of 4 and in groups of 2 file the same rows bit for bit (no encoder pass of these sizes uses split-K), run to run
     as well; the proposals CLIP scored are SAM's (not the items' seeded masks)."""
-    from hybridgl_amd.backbone import CLIPViTFM
-    from hybridgl_amd.gem import create_gem_model
     from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
-    from hybridgl_amd.sam import SamAutomaticMaskGenerator, sam_model_registry
-    model = CLIPViTFM("ViT-B/16", seed=0, device=cuda)
-    gem = create_gem_model("ViT-B/16", clip=model)
-    gen = SamAutomaticMaskGenerator(sam_model_registry["default"](seed=0, device=cuda), points_per_side=8, pred_iou_thresh=-1e30,
+    from hybridgl_amd.sam import SamAutomaticMaskGenerator
+    model, gem, sam = full
+    gen = SamAutomaticMaskGenerator(sam, points_per_side=8, pred_iou_thresh=-1e30,
                                     stability_score_thresh=0.0, box_nms_thresh=2.0, min_mask_region_area=800)
     refs = [synthetic_ref(i, cuda, N=64, sam_img_size=1024, gem=True, device_blur=True)[0] for i in range(8)]
     mk = lambda: HybridGLPipeline(model, mask_generator=gen, use_sam_masks=True, gem_model=gem)
@@ -215,5 +223,60 @@ def test_full_size_dependent_groups_are_composition_independent(cuda):
         assert all(h.shape == (64, 512) for h, _, _ in p.collected)
     assert np.array_equal(rows[0], rows[1]) and np.array_equal(rows[0], rows[2])
     assert rows[0].shape == (24, 6) and (rows[0][:, 3] > 0).all()
-    del gen
-    torch.cuda.empty_cache()
+
+
+def test_phrasecut_configuration_at_full_size(cuda, full):
+    """BASELINE configs[4] (Hybridgl_main_PhraseCut.py:56-62): 64 x 64 points + one crop layer (downscale 2), min area 100, on
+    a 480 x 640 image with SAM ViT-H -- 5 encoder passes, 128 decoder batches, per-crop NMS over 12 288 / 3 072 candidates
+    (bit-matrix kernels), cross-crop NMS, small-region clean-up, last NMS.  No oracle can run this size in seconds, so the
+    checks are the properties the reference's generator guarantees: determinism, output records consistent with each other
+    (boxes = batched_mask_to_box of the masks, crop boxes from the crop list, layer-1 masks inside their crop), clean-up
+    idempotent on a sample, and independence of the composition of the CLIP batch the proposals are scored in."""
+    from hybridgl_amd import sam as hsam
+    from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
+    from hybridgl_amd.synth import synth_image
+    from oracle import sam_oracle as S
+    model, gem, sam = full
+    # thresholds: the reference's 0.86 / 0.92 reject everything a random-weight model predicts; they sit at values that keep a
+    # part of the candidates, so that every filter decides
+    H, W = 480, 640
+    img = torch.from_numpy(synth_image(H, W, 9)).to(cuda)
+    probe = hsam.SamAutomaticMaskGenerator(sam, points_per_side=8, pred_iou_thresh=-1e30, stability_score_thresh=0.0, box_nms_thresh=2.0)
+    _, _, iou, stab, _, _, _ = probe.propose(img)
+    iou_thr = float(torch.quantile(iou, 0.5))
+    gen = hsam.SamAutomaticMaskGenerator(sam, points_per_side=64, pred_iou_thresh=iou_thr, stability_score_thresh=0.0,
+                                         crop_n_layers=1, crop_n_points_downscale_factor=2, min_mask_region_area=100)
+    a = gen.generate_device_crops(img)
+    b = gen.generate_device_crops(img)
+    torch.cuda.synchronize()
+    n = a[0].shape[0]
+    assert n > 0 and all(torch.equal(x, y) for x, y in zip(a[:4], b[:4])) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    masks, xywh, iou_k, stab_k, pts, cbs = a
+    assert masks.shape == (n, H, W) and xywh.shape == (n, 4) and (iou_k >= iou_thr).all()
+    crop_list, layers = hsam.generate_crop_boxes((H, W), 1, 512 / 1500)
+    assert len(crop_list) == 5 and set(map(tuple, cbs.tolist())) <= set(map(tuple, crop_list))
+    # boxes are the boxes of the masks (XYXY inclusive rule -> XYWH), for every record
+    bx = hsam.mask_boxes(masks.contiguous()).long()
+    assert torch.equal(torch.stack([bx[:, 0], bx[:, 1], bx[:, 2] - bx[:, 0], bx[:, 3] - bx[:, 1]], 1), xywh)
+    mk = masks.cpu().numpy().astype(bool)
+    sel = np.linspace(0, n - 1, min(n, 6)).astype(int)
+    for i in sel:
+        x0, y0, x1, y1 = cbs[i]
+        inside = np.zeros((H, W), bool)
+        inside[y0:y1, x0:x1] = True
+        assert not (mk[i] & ~inside).any()                      # a crop's mask never leaves its crop (uncrop_masks pads with 0)
+        assert x0 <= pts[i][0] <= x1 and y0 <= pts[i][1] <= y1   # its prompt point lies in the crop
+        # the clean-up already ran: running it again changes nothing (utils/amg.py:267-291)
+        m1, ch1 = S.remove_small_regions(mk[i], 100, "holes")
+        m2, ch2 = S.remove_small_regions(m1, 100, "islands")
+        assert np.array_equal(m2, mk[i]) or mk[i].sum() < 100    # (a mask whose largest island is small is kept as it is)
+    # the same image twice in one group / alone: same rows
+    ref = synthetic_ref(50, cuda, N=8, H=H, W=W, n_sent=8, sam_img_size=1024, gem=True, device_blur=True)[0]
+    ref2 = synthetic_ref(51, cuda, N=8, H=H, W=W, n_sent=8, sam_img_size=1024, gem=True, device_blur=True)[0]
+    mkp = lambda: HybridGLPipeline(model, fusion_mode="G2L&L2G", mask_generator=gen, use_sam_masks=True, gem_model=gem)
+    p1, p2 = mkp(), mkp()
+    assert p1.run(iter([ref, ref2]), group=2, proposal_cap=128) == 2
+    assert p2.run(iter([ref, ref2]), group=1, proposal_cap=128) == 2
+    torch.cuda.synchronize()
+    r1, r2 = p1.partial_rows(), p2.partial_rows()
+    assert r1.shape == (16, 6) and np.array_equal(r1, r2)

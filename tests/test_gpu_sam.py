@@ -194,6 +194,25 @@ def test_tiny_generate_vs_reference(cuda, g, tiny):
     assert all(a["crop_box"] == [0, 0, 200, 160] for a in anns)
 
 
+@pytest.mark.parametrize("mode", ["uncompressed_rle", "coco_rle"])
+def test_generate_rle_output_modes(cuda, tiny, mode):
+    """output_mode (automatic_mask_generator.py:176-182): the records of the RLE modes decode to the binary_mask records"""
+    from hybridgl_amd import refer_io
+    c = sam_tiny_case()
+    kw = dict(points_per_side=4, pred_iou_thresh=-1e9, stability_score_thresh=0.0, crop_n_layers=0, min_mask_region_area=20,
+              box_nms_thresh=1.5)
+    plain = hsam.SamAutomaticMaskGenerator(tiny[1], **kw).generate(c["image"])
+    anns = hsam.SamAutomaticMaskGenerator(tiny[1], output_mode=mode, **kw).generate(c["image"])
+    assert len(anns) == len(plain) > 0
+    for a, b in zip(anns, plain):
+        seg = a["segmentation"]
+        assert seg["size"] == [160, 200] and isinstance(seg["counts"], list if mode == "uncompressed_rle" else str)
+        assert np.array_equal(refer_io.gt_mask_from_rle(seg)[0].astype(bool), b["segmentation"])
+        assert a["area"] == b["area"] and a["bbox"] == b["bbox"]
+    with pytest.raises(AssertionError):
+        hsam.SamAutomaticMaskGenerator(tiny[1], output_mode="polygons", **kw)
+
+
 def test_tiny_generate_with_deciding_thresholds_vs_reference(cuda, g, tiny):
     """The generator with filters that DECIDE (Hybridgl_main.py:67-73 runs pred_iou 0.7 / NMS 0.7 on trained weights): a
     6 x 6 grid, pred_iou_thresh at the 45 % quantile of the predicted IoUs, box_nms_thresh = 0.7 on sparse masks (mask

@@ -88,6 +88,49 @@ def test_fuzz_against_compiled_reference():
         assert np.array_equal(refer_io.gt_mask_from_rle({"size": [H, W], "counts": cnts})[0], m)
 
 
+def test_rle_output_modes_against_reference_vectors(gold):
+    """SamAutomaticMaskGenerator's output modes uncompressed_rle / coco_rle (automatic_mask_generator.py:176-182,
+    utils/amg.py:107-153,294-300): mask -> counts -> compressed string, against counts and strings the reference's
+    maskApi.c produced (tests/golden/gtmask.npz), and back."""
+    from hybridgl_amd import sam as hsam
+    strs = [str(s) for s in gold["r_strings"]]
+    for j in range(int(gold["n_rle"][0])):
+        H, W = (int(v) for v in gold[f"r{j}_size"])
+        mask = gold[f"r{j}_mask"].astype(bool)
+        rle = hsam.mask_to_rle(mask)
+        assert rle == {"size": [H, W], "counts": gold[f"r{j}_counts"].tolist()}
+        assert hsam.area_from_rle(rle) == int(mask.sum())
+        assert np.array_equal(hsam.rle_to_mask(rle), mask)
+        assert hsam.coco_encode_rle(rle) == {"size": [H, W], "counts": strs[j]}
+    # masks that start with foreground carry a leading 0 count (utils/amg.py:131); all-zero / all-one masks
+    m = np.ones((3, 2), bool)
+    assert hsam.mask_to_rle(m)["counts"] == [0, 6] and hsam.mask_to_rle(~m)["counts"] == [6]
+    m[1, 0] = False
+    assert hsam.mask_to_rle(m)["counts"] == [0, 1, 1, 4]
+
+
+@pytest.mark.skipif(not G.have_ref(), reason="oracle/_ref not built (needs /root/reference at build time)")
+def test_rle_encoding_fuzz_against_compiled_reference():
+    """hgl_rle_encode_mask / hgl_rle_to_string == rleEncode / rleToString of the reference's maskApi.c, incl. long runs
+    (negative differences between counts two places apart: the sign digit of the string format)"""
+    from hybridgl_amd import sam as hsam
+    ref = G.RefMaskApi()
+    rng = np.random.default_rng(8)
+    for t in range(120):
+        H, W = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        if t % 4 == 0:       # blobs: long runs
+            m = np.zeros((H, W), np.uint8)
+            for _ in range(int(rng.integers(0, 5))):
+                y0, x0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+                m[y0:y0 + int(rng.integers(1, H + 1)), x0:x0 + int(rng.integers(1, W + 1))] = 1
+        else:
+            m = (rng.random((H, W)) < rng.random() ** 2).astype(np.uint8)
+        s, cnts = ref.encode_to_string(m)
+        rle = hsam.mask_to_rle(m)
+        assert rle["counts"] == cnts, t
+        assert hsam.coco_encode_rle(rle)["counts"] == s, t
+
+
 def test_error_reporting():
     from hybridgl_amd._lib import HybridGLError
     with pytest.raises(HybridGLError):
