@@ -145,6 +145,7 @@ PROTOTYPES = {
     "hgl_sam_dense_pe": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _VP]),
     "hgl_sam_decode_workspace_bytes": (_SZ, [C.POINTER(HglSamDecoderW), _I]),
     "hgl_sam_decode_points": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "hgl_sam_decoder_fusion": (_I, [_I]),
     "hgl_sam_postprocess_workspace_bytes": (_SZ, [_I]),
     "hgl_sam_postprocess": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _VP, _VP, _VP, _VP, _VP,
                                  _VP, _SZ, _VP]),

@@ -43,8 +43,8 @@ struct GemmArgs {
 
 template <int ACT>
 __device__ __forceinline__ float act_apply(float x) {
-  if constexpr (ACT == HGL_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
-  if constexpr (ACT == HGL_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  if constexpr (ACT == HGL_ACT_QUICKGELU) return hgl_quick_gelu(x);
+  if constexpr (ACT == HGL_ACT_GELU) return hgl_gelu_erf(x);
   if constexpr (ACT == HGL_ACT_RELU) return x > 0.0f ? x : 0.0f;
   return x;
 }

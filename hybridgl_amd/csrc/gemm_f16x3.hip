@@ -109,8 +109,8 @@ int pick_x3_kernel(int M, int N, int K, bool has_r) {
 
 template <int ACT>
 __device__ __forceinline__ float act_apply(float x) {
-  if constexpr (ACT == HGL_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
-  if constexpr (ACT == HGL_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  if constexpr (ACT == HGL_ACT_QUICKGELU) return hgl_quick_gelu(x);
+  if constexpr (ACT == HGL_ACT_GELU) return hgl_gelu_erf(x);
   if constexpr (ACT == HGL_ACT_RELU) return x > 0.0f ? x : 0.0f;
   return x;
 }
@@ -317,6 +317,16 @@ __global__ __launch_bounds__(NTHREADS, OCC) void gemm_f16x3_kernel(Args g) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
+// The lane number, computed where it is used.  In the ping-pong kernel (256 VGPRs, the limit at two waves per SIMD) every
+// lane-derived address that lives from the prologue to its one use per output tile is a spill candidate, and a spilled
+// value comes back through a scratch load the compiler waits for with vmcnt(0) -- in the middle of the hand-counted DMA
+// stream (seven units in flight at a tile boundary).  volatile: not merged with the prologue's copy, not hoisted.
+__device__ __forceinline__ int x3p_fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // One LDS-DMA wave-instruction: lane i copies 16 B from sbase + voff(i) to LDS byte lds_addr + 16*i.  Written as
 // inline asm for the SGPR-base + 32-bit-VGPR-offset addressing form (the builtin keeps a 64-bit VGPR address
 // per piece).  M0 is compiler-reserved: saved and restored around the instruction.  The compiler does not count
@@ -343,7 +353,7 @@ __device__ __forceinline__ void x3p_wait() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int ACT, bool WLOADS>
+template <int ACT, int WLOADS>
 __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
   constexpr int TBM = 256, TBN = 256, MB = 8, NB = 4, WTM = 128, WTN = 64;   // 16x16 accumulator blocks per wave
   constexpr int PLANE = 256 * 64;    // bytes of one plane of one stage
@@ -601,9 +611,10 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
     if (more && g.amap) {
       // the two map DMAs are older than the 16 operations of the last two K tiles issued so far (none if nk == 2)
       if (nk >= 4) x3p_wait<10>(); else x3p_wait<0>();
-      const int m0 = *(const int*)(nxp + 1024 + lane * 4), m1 = *(const int*)(nxp + 1280 + lane * 4);
-      *(unsigned*)(nxp + lane * 16) = a_offset(m0);
-      *(unsigned*)(nxp + lane * 16 + 4) = a_offset(m1);
+      const int ln = x3p_fresh_lane();
+      const int m0 = *(const int*)(nxp + 1024 + ln * 4), m1 = *(const int*)(nxp + 1280 + ln * 4);
+      *(unsigned*)(nxp + ln * 16) = a_offset(m0);
+      *(unsigned*)(nxp + ln * 16 + 4) = a_offset(m1);
     }
     tile_body(nk - 2, I10(), I8(), I6(), I4(), yes, no, no, more);
     const bool has_bias = g.bias && g.ksplit <= 1;
@@ -650,11 +661,16 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
         // are then loaded in the same row-contiguous form and a lane needs ONE bias vector.  LDS operations of a wave
         // execute in order, the patch is private: no barrier, no wait between the writes and the reads.
         unsigned char* const tp = smem_p + 2 * STAGE + wave * 4096;
-        const int rl = lane >> 4, cl = lane & 15;
+        const int lw = x3p_fresh_lane();
+        const int rl = lw >> 4, cl = lw & 15;
         const int col = col0 + wn * WTN + 4 * cl;
         const bool cok = col < g.N;
         const int colc = min(col, g.N - 4);
-        // WLOADS = the write-out reads something (residual rows, a row map).  Without loads nothing in the loop waits on
+        // WLOADS = what the write-out reads: 0 nothing, 1 residual rows, 2 a row map (+ residual rows if any).  The flavours
+        // are template instantiations because a load behind a RUN-TIME condition makes the compiler put `s_waitcnt
+        // vmcnt(0)` at the join, taken or not: with `if (g.cmap)` inside the residual flavour every row block of every
+        // residual GEMM drained all earlier stores and the next tile's DMA units before it went on.
+        // Without loads nothing in the loop waits on
         // vmcnt and the stores stream out back to back; with a runtime `R ? load : 0` the compiler put an s_waitcnt
         // vmcnt(0) into every row block -- every block then waited for all earlier stores AND for the next tile's
         // prologue DMA (in-kernel stamps: ~500 cycles per store instruction).  With loads, the rows of block mb+1 are
@@ -666,14 +682,14 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
           for (int i = 0; i < 4; ++i) {
             const int rc = min(row0 + wm * WTM + mb * 16 + 4 * i + rl, mclamp);
             cr[i] = rc;
-            if constexpr (WLOADS) if (g.cmap) cr[i] = g.cmap[rc];
+            if constexpr (WLOADS == 2) cr[i] = g.cmap[rc];
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             rr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (WLOADS) {
+            if constexpr (WLOADS != 0) {
               const long long rrow = g.rmod > 0 ? cr[i] % g.rmod : cr[i];
-              if (g.R) rr[i] = *(const f32x4*)(g.R + rrow * g.ldr + colc);
+              if (WLOADS == 1 || g.R) rr[i] = *(const f32x4*)(g.R + rrow * g.ldr + colc);
             }
           }
         };
@@ -946,6 +962,14 @@ int hgl_precision() { return g_precision; }
 
 bool hgl_has_split_weight(const float* W) { return find_split((const void*)W, nullptr); }
 
+// the registered fp16 halves of a weight, for fused kernels outside this file that multiply with them directly
+bool hgl_get_split_weight(const float* W, const void** hi, const void** lo, int* scale_log2, int* N, int* K) {
+  SplitW sw;
+  if (!find_split((const void*)W, &sw)) return false;
+  *hi = sw.hi; *lo = sw.lo; *scale_log2 = sw.scale_log2; *N = sw.N; *K = sw.K;
+  return true;
+}
+
 int hgl_launch_split_f16(const float* x, float scale, void* hi, void* lo, long long n, hipStream_t st) {
   HGL_REQUIRE(x && hi && lo && n > 0 && (n & 3) == 0, "split_f16: bad arguments (n %% 4 != 0?)");
   long long blocks = (n / 4 + 255) / 256;
@@ -1011,7 +1035,7 @@ int launch_x3_v1(Args& g, hipStream_t st) {
   return HGL_OK;
 }
 
-template <int ACT, bool WLOADS>
+template <int ACT, int WLOADS>
 int launch_x3_p2(Args& g, hipStream_t st) {
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
@@ -1030,7 +1054,9 @@ int launch_x3_p2(Args& g, hipStream_t st) {
 
 template <int ACT>
 int launch_x3_p(Args& g, hipStream_t st) {
-  return (g.R || g.cmap) ? launch_x3_p2<ACT, true>(g, st) : launch_x3_p2<ACT, false>(g, st);
+  // write-out flavour: 0 = reads nothing, 1 = residual rows only (every launch of the CLIP blocks, SAM's MLP), 2 = a row map
+  // (SAM's window un-partition), with or without a residual
+  return g.cmap ? launch_x3_p2<ACT, 2>(g, st) : g.R ? launch_x3_p2<ACT, 1>(g, st) : launch_x3_p2<ACT, 0>(g, st);
 }
 
 template <int ACT>

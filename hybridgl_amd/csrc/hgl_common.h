@@ -51,6 +51,32 @@ __device__ __forceinline__ void hgl_split_commit(float amax) {
     return v;                                                                                         \
   }
 #endif
+// ---- activations of the GEMM epilogues ------------------------------------------------------------------------------
+// nn.GELU (erf form; segment_anything/modeling/common.py:13-24 MLPBlock, mask_decoder.py:76-80): 0.5 x (1 + erf(x / sqrt 2)).
+// The library erff costs ~40 VALU instructions (branches on |x|); in a GEMM write-out -- where the matrix pipe of that
+// workgroup idles -- and in the fused decoder kernels that is the dominant cost (SAM's mlp.lin1: 168 M evaluations per
+// block and group of images).  Here: erfc(t) = 2^(-t P(t)) on t = min(|x| / sqrt 2, 4) with a degree-7 minimax fit of P
+// (|erf error| <= 1.0e-7 over the whole axis, the size of one float rounding of erf itself; one v_exp_f32, 8 fma); for x < 0
+// 1 + erf(x) is erfc(|x|) itself, no subtraction.  |GELU error| <= 2.5e-7 max(1, |x|) (tests/test_gpu_primitives.py).
+__device__ __forceinline__ float hgl_gelu_erf(float x) {
+  const float t = fminf(fabsf(x) * 0.70710678118654752440f, 4.0f);
+  float p = 4.582141628e-05f;
+  p = fmaf(p, t, -4.491848231e-04f);
+  p = fmaf(p, t, 1.500873244e-03f);
+  p = fmaf(p, t, 7.568532601e-04f);
+  p = fmaf(p, t, -2.823902667e-02f);
+  p = fmaf(p, t, 1.484753788e-01f);
+  p = fmaf(p, t, 9.184176326e-01f);
+  p = fmaf(p, t, 1.627908468e+00f);
+  const float q = __builtin_amdgcn_exp2f(-(p * t));   // erfc(t)
+  return 0.5f * x * (x < 0.f ? q : 2.0f - q);
+}
+// QuickGELU (clip/model.py:198-200): x * sigmoid(1.702 x) with the hardware exponential and reciprocal (1 ulp each)
+// instead of an IEEE division sequence
+__device__ __forceinline__ float hgl_quick_gelu(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+}
+
 unsigned long long hgl_split_overflow_gemm(int reset);
 unsigned long long hgl_split_overflow_attention(int reset);
 
@@ -182,6 +208,10 @@ int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long row
 int hgl_launch_ln256_pe_split(float* x, const float* w, const float* b, const float* pe, int pe_rows, long long rows,
                               float eps, int write_f32, void* kh, void* kl, void* ph, void* pl, hipStream_t st);
 int hgl_launch_hyper_logits(const float* u2, const float* hyper, int P, int g, float* low_res, hipStream_t st);
+// fused decoder stages (sam_decoder_fused.hip)
+int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0_w, const float* up0_b, const float* ln_w,
+                        const float* ln_b, const float* up3_w, const float* up3_b, const float* hyper, int P, int g, float eps,
+                        float* low_res, hipStream_t st);
 
 // split-fp16 GEMM path (gemm_f16x3.hip)
 int hgl_precision();

@@ -294,6 +294,13 @@ int dec_attn(const HglSamDecoderW* w, const HglSamAttnW& a, const float* q, bool
 struct SplitPair { uint16_t *hi, *lo; };
 inline SplitPair split_view(float* buf, size_t elems) { return SplitPair{(uint16_t*)buf, (uint16_t*)buf + elems}; }
 
+// which fused decoder stages are in use (bit 0: upscaling + hyper-network products); default from HGL_SAM_DEC_FUSED
+int g_dec_fusion = -1;
+int dec_fusion_mask() {
+  if (g_dec_fusion < 0) { const char* v = getenv("HGL_SAM_DEC_FUSED"); g_dec_fusion = v ? atoi(v) : 0x7fffffff; }
+  return g_dec_fusion;
+}
+
 bool dec_x3_ready(const HglSamDecoderW* w) {
   if (hgl_precision() != HGL_PREC_F16X3 || w->C != 256) return false;
   const float* need[] = {w->layer[0].i2t.out.w, w->layer[1].i2t.out.w, w->layer[1].i2t.q.w, w->layer[1].t2i.k.w,
@@ -444,6 +451,12 @@ size_t hgl_sam_decode_workspace_bytes(const HglSamDecoderW* w, int P) {
   return ar.off;
 }
 
+int hgl_sam_decoder_fusion(int mask) {
+  const int old = dec_fusion_mask();
+  if (mask >= 0) g_dec_fusion = mask;
+  return old;
+}
+
 int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float* points01, int P, float* low_res,
                           float* iou_pred, void* workspace, size_t workspace_bytes, void* stream) {
   HGL_TRY(hgl_require_device());
@@ -527,30 +540,38 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
   // ---- output upscaling: two ConvTranspose2d(k=2,s=2) as GEMMs, columns ordered (pos, out_channel) ----
   const int C4 = C / 4, C8 = C / 8;
   HGL_REQUIRE(C4 == 64, "sam_decode: LayerNorm2d width %d unsupported (64 expected)", C4);
-  if (x3) {
-    HGL_TRY(hgl_launch_gemm_f16x3(keysS.hi, keysS.lo, C, w->up0_w, w->up0_b, nullptr, 0, p.u1, nullptr, nullptr, 4 * C4,
-                                  P * HW, 4 * C4, C, HGL_ACT_NONE, st));
-    const SplitPair u1S = split_view(p.kpe, (size_t)P * HW * 4 * C4);   // kpeS is dead from here on
-    HGL_TRY(hgl_launch_ln_gelu64(p.u1, w->up1.w, w->up1.b, (long long)P * HW * 4, 1e-6f, u1S.hi, u1S.lo, st));
-    HGL_TRY(hgl_launch_gemm_f16x3(u1S.hi, u1S.lo, C4, w->up3_w, w->up3_b, nullptr, 0, p.u2, nullptr, nullptr, 4 * C8,
-                                  P * HW * 4, 4 * C8, C4, HGL_ACT_GELU, st));
-  } else {
-    HGL_TRY(hgl_launch_gemm(p.keys, w->up0_w, w->up0_b, nullptr, p.u1, P * HW, 4 * C4, C, C, C, 0, 4 * C4, 1, 0, 0, 0, 0,
-                            HGL_ACT_NONE, st));
-    HGL_TRY(hgl_launch_ln_gelu64(p.u1, w->up1.w, w->up1.b, (long long)P * HW * 4, 1e-6f, nullptr, nullptr, st));
-    HGL_TRY(hgl_launch_gemm(p.u1, w->up3_w, w->up3_b, nullptr, p.u2, P * HW * 4, 4 * C8, C4, C4, C4, 0, 4 * C8, 1, 0, 0,
-                            0, 0, HGL_ACT_GELU, st));
-  }
+  HGL_REQUIRE(C8 == 32, "sam_decode: hyper-network width %d unsupported (32 expected)", C8);
   // ---- hyper-networks on the mask tokens (rows 1..4 of each prompt's 7 tokens) ----
   for (int i = 0; i < 4; ++i) {
     HGL_TRY(lin(p.queries + (1 + i) * C, T * C, w->hyper[i][0], nullptr, 0, p.hy_a, C, P, C, C, HGL_ACT_RELU, st));
     HGL_TRY(lin(p.hy_a, C, w->hyper[i][1], nullptr, 0, p.hy_b, C, P, C, C, HGL_ACT_RELU, st));
     HGL_TRY(lin(p.hy_b, C, w->hyper[i][2], nullptr, 0, p.hyper + i * C8, 4 * C8, P, C8, C, HGL_ACT_NONE, st));
   }
-  // masks[p, t, pix] = hyper[p, t, :] . upscaled[p, pix, :] for the three multimask tokens, un-shuffled into
-  // [P,3,4g,4g] by the same kernel
-  HGL_REQUIRE(C8 == 32, "sam_decode: hyper-network width %d unsupported (32 expected)", C8);
-  HGL_TRY(hgl_launch_hyper_logits(p.u2, p.hyper, P, g, low_res, st));
+  // fused upscaling + hyper-network products (one launch, the 256-channel rows read once); hgl_sam_decoder_fusion(0) /
+  // HGL_SAM_DEC_FUSED=0 keep the four launches below (same arithmetic, bit for bit: tests compare the two)
+  const bool fused_tail = x3 && (dec_fusion_mask() & 1) && (HW % 64) == 0 && (g % 64 == 0 || 64 % g == 0) && P <= 65535;
+  if (fused_tail) {
+    HGL_TRY(hgl_launch_dec_tail(keysS.hi, keysS.lo, w->up0_w, w->up0_b, w->up1.w, w->up1.b, w->up3_w, w->up3_b, p.hyper, P, g,
+                                1e-6f, low_res, st));
+  } else {
+    if (x3) {
+      HGL_TRY(hgl_launch_gemm_f16x3(keysS.hi, keysS.lo, C, w->up0_w, w->up0_b, nullptr, 0, p.u1, nullptr, nullptr, 4 * C4,
+                                    P * HW, 4 * C4, C, HGL_ACT_NONE, st));
+      const SplitPair u1S = split_view(p.kpe, (size_t)P * HW * 4 * C4);   // kpeS is dead from here on
+      HGL_TRY(hgl_launch_ln_gelu64(p.u1, w->up1.w, w->up1.b, (long long)P * HW * 4, 1e-6f, u1S.hi, u1S.lo, st));
+      HGL_TRY(hgl_launch_gemm_f16x3(u1S.hi, u1S.lo, C4, w->up3_w, w->up3_b, nullptr, 0, p.u2, nullptr, nullptr, 4 * C8,
+                                    P * HW * 4, 4 * C8, C4, HGL_ACT_GELU, st));
+    } else {
+      HGL_TRY(hgl_launch_gemm(p.keys, w->up0_w, w->up0_b, nullptr, p.u1, P * HW, 4 * C4, C, C, C, 0, 4 * C4, 1, 0, 0, 0, 0,
+                              HGL_ACT_NONE, st));
+      HGL_TRY(hgl_launch_ln_gelu64(p.u1, w->up1.w, w->up1.b, (long long)P * HW * 4, 1e-6f, nullptr, nullptr, st));
+      HGL_TRY(hgl_launch_gemm(p.u1, w->up3_w, w->up3_b, nullptr, p.u2, P * HW * 4, 4 * C8, C4, C4, C4, 0, 4 * C8, 1, 0, 0,
+                              0, 0, HGL_ACT_GELU, st));
+    }
+    // masks[p, t, pix] = hyper[p, t, :] . upscaled[p, pix, :] for the three multimask tokens, un-shuffled into
+    // [P,3,4g,4g] by the same kernel
+    HGL_TRY(hgl_launch_hyper_logits(p.u2, p.hyper, P, g, low_res, st));
+  }
   // ---- IoU head on the iou token (row 0); multimask output = columns 1..3 ----
   HGL_TRY(lin(p.queries, T * C, w->iou_head[0], nullptr, 0, p.iou_a, C, P, C, C, HGL_ACT_RELU, st));
   HGL_TRY(lin(p.iou_a, C, w->iou_head[1], nullptr, 0, p.iou_b, C, P, C, C, HGL_ACT_RELU, st));

@@ -1,0 +1,325 @@
+// Fused stages of the SAM mask decoder (split-fp16 matrix-core mode).
+//
+// The decoder's image side works on [P prompts x 4096 tokens x 256 channels] (268 MB in fp32 for 64 prompts): as
+// separate GEMM / LayerNorm / activation launches every stage streams that tensor (or a wider one) through HBM, and the
+// decoder runs at the memory rate (2.9 ms per 64 prompts for 0.23 TFLOP).  Every stage of the OUTPUT UPSCALING is
+// row-wise -- a ConvTranspose2d(k=2, s=2) is a per-pixel GEMM -- so a tile of rows can go through the whole chain on chip:
+//
+//   dec_tail_kernel      upscaled = output_upscaling(src)          mask_decoder.py:132-134, :75-81
+//                          ConvTranspose2d(256 -> 64, k2 s2)   = rows x [4 pos x 64]    (MFMA, K = 256)
+//                          LayerNorm2d(64) + GELU                 per (row, pos)        (common.py:33-43)
+//                          ConvTranspose2d(64 -> 32, k2 s2) + GELU = rows x [4 sub x 32] per pos (MFMA, K = 64)
+//                        masks = hyper_in @ upscaled               mask_decoder.py:146-151 (multimask rows 1..3)
+//                      reads the 256-channel rows once (fp16 hi + lo planes), writes the [P,3,4g,4g] logits: 0.32 GB instead
+//                      of 2.6 GB through four launches.
+//
+// The matrix products are those of the unfused path, operation for operation (the same split-fp16 products in the same
+// order: K steps of 32; per step A_lo*W_hi, A_hi*W_lo, A_hi*W_hi into one fp32 accumulator) and so are the epilogue
+// expressions; the LayerNorm sums and the hyper-network dot products are associated differently (per lane first, then
+// across the four lanes that share a row: a first version reproduced the unfused kernels' butterfly order bit for bit and
+// spent a quarter of its time in 256 dependent ds_bpermute + wait pairs per wave).  Fused and unfused logits agree to
+// fp32 rounding (tests/test_gpu_sam.py); the kernel is bound by its element-wise arithmetic (192 GELUs per lane and tile).
+#include "hgl_common.h"
+
+bool hgl_get_split_weight(const float* W, const void** hi, const void** lo, int* scale_log2, int* N, int* K);
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct TailArgs {
+  const _Float16 *Ah, *Al;     // src rows [P*HW, 256] as fp16 hi / lo planes
+  const _Float16 *W0h, *W0l;   // up0 weight [256 = (ky,kx,c64), 256] split
+  const _Float16 *W3h, *W3l;   // up3 weight [128 = (ky2,kx2,c32), 64] split
+  const float *b0, *ln_w, *ln_b, *b3;
+  const float* hyper;          // [P, 4, 32]
+  float s0, s3, eps;           // weight scales undone in the epilogues; LayerNorm2d eps
+  int g, HW;
+  float* out;                  // [P, 3, 4g, 4g]
+};
+
+// LDS image of an operand tile for the 16-row x 4-chunk fragment reads of v_mfma_f32_16x16x32_f16 (a lane reads row r,
+// 16-byte chunk h of a 32-deep K step): blocks of [16 rows x 64 B] per (K step, row block), chunk ^= {0,2,3,1}[(row >> 2) & 3]
+// (the swizzle of the ping-pong GEMM: the 16 lanes of every ds_read_b128 lane group land on 16 different 16-byte slots).
+__device__ __forceinline__ unsigned frag_off(int kstep, int nmb, int mb, int r, int chunk) {
+  const int sw = (0x78 >> (2 * ((r >> 2) & 3))) & 3;
+  return (unsigned)((((kstep * nmb + mb) * 16 + r) * 64) + ((chunk ^ sw) * 16));
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return hgl_gelu_erf(x); }
+
+constexpr int TAIL_ROWS = 64;
+constexpr int TAIL_A_PLANE = TAIL_ROWS * 256 * 2;        // bytes of one plane of the source tile (32 KiB)
+constexpr int TAIL_G_PLANE = TAIL_ROWS * 64 * 2;         // bytes of one plane of a wave's 64 x 64 patch (8 KiB)
+constexpr int TAIL_STAGE = 2 * TAIL_A_PLANE;             // output staging [3][64 pixels][16] floats behind the tile
+constexpr int TAIL_LDS = TAIL_STAGE + 3 * TAIL_ROWS * 16 * 4;
+
+__global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 15, h = lane >> 4;
+  const int p = blockIdx.y, tile = blockIdx.x;
+  const long long row0 = (long long)p * a.HW + (long long)tile * TAIL_ROWS;
+
+  // ---- the tile's 64 rows x 256 channels, both planes, into the fragment image ----
+  // the first two K steps of this wave's W fragments and its epilogue vectors are requested before the tile itself
+  const _Float16* const wh = a.W0h + (long long)(wave * 64 + r) * 256 + 8 * h;
+  const _Float16* const wl = a.W0l + (long long)(wave * 64 + r) * 256 + 8 * h;
+  f16x8 bh[3][4], bl[3][4];
+#pragma unroll
+  for (int pre = 0; pre < 2; ++pre)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bh[pre][j] = *(const f16x8*)(wh + j * 16 * 256 + pre * 32);
+      bl[pre][j] = *(const f16x8*)(wl + j * 16 * 256 + pre * 32);
+    }
+  f32x4 b0v[4], lw[4], lb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    b0v[j] = *(const f32x4*)(a.b0 + wave * 64 + 16 * j + 4 * h);
+    lw[j] = *(const f32x4*)(a.ln_w + 16 * j + 4 * h);
+    lb[j] = *(const f32x4*)(a.ln_b + 16 * j + 4 * h);
+  }
+  // four consecutive threads fetch the 64 contiguous bytes of one (row, K step), the next four the next ROW: consecutive
+  // K steps of a row lie 4 KiB apart in the image (same banks: an 8-way conflict on the 16-byte stores when threads walk along a row)
+  for (int i = t; i < TAIL_ROWS * 32; i += 256) {
+    const int row = (i >> 2) & 63, kc = 4 * (i >> 8) + (i & 3);
+    const unsigned off = frag_off(kc >> 2, 4, row >> 4, row & 15, kc & 3);
+    *(u32x4*)(smem + off) = *(const u32x4*)(a.Ah + (row0 + row) * 256 + kc * 8);
+    *(u32x4*)(smem + TAIL_A_PLANE + off) = *(const u32x4*)(a.Al + (row0 + row) * 256 + kc * 8);
+  }
+  __syncthreads();
+
+  // ---- ConvTranspose2d(256 -> 64, k2 s2): wave w computes position w = (ky, kx): rows x 64 channels ----
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    // W fragments come straight from L2 (the 256 KiB of up0's halves stay resident), two K steps ahead of their use
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int cb = ks % 3, nb = (ks + 2) % 3;
+      if (ks + 2 < 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bh[nb][j] = *(const f16x8*)(wh + j * 16 * 256 + (ks + 2) * 32);
+          bl[nb][j] = *(const f16x8*)(wl + j * 16 * 256 + (ks + 2) * 32);
+        }
+      }
+      f16x8 ah[4], al[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned off = frag_off(ks, 4, i, r, h);
+        ah[i] = *(const f16x8*)(smem + off);
+        al[i] = *(const f16x8*)(smem + TAIL_A_PLANE + off);
+      }
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f16x8 av = term == 0 ? al[i] : ah[i];
+            const f16x8 bv = term == 1 ? bl[cb][j] : bh[cb][j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, acc[i][j], 0, 0, 0);
+          }
+    }
+  }
+  __syncthreads();   // every wave has read the source tile: its LDS becomes the waves' 64 x 64 patches
+
+  // ---- + bias, LayerNorm2d over the 64 channels of (row, position), GELU, split, into the wave's patch ----
+  unsigned char* const patch = smem + wave * 2 * TAIL_G_PLANE;
+  {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] = acc[i][j][e] * a.s0 + b0v[j][e];
+      // sum over the row's 64 channels: this lane's 16, then the four lanes (h) that share the row
+      auto tree = [&](const f32x4 (&x)[4]) {
+        float s4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s4[j] = (x[j][0] + x[j][1]) + (x[j][2] + x[j][3]);
+        float t = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        return t;
+      };
+      const float mean = tree(v) * (1.f / 64.f);
+      f32x4 d[4], q[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d[j][e] = v[j][e] - mean; q[j][e] = d[j][e] * d[j][e]; }
+      const float var = tree(q) * (1.f / 64.f);
+      const float rs = rsqrtf(var + a.eps);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f16x4 hi4, lo4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = d[j][e] * rs * lw[j][e] + lb[j][e];
+          const float o = gelu_erf(y);
+          _Float16 hh, ll;
+          hgl_split_hi_lo(o, hh, ll);
+          hi4[e] = hh;
+          lo4[e] = ll;
+        }
+        // channel c0 = 16 j + 4 h: K step c0 / 32, chunk (c0 % 32) / 8, half-chunk (c0 % 8) / 4
+        const int c0 = 16 * j + 4 * h;
+        const unsigned off = frag_off(c0 >> 5, 4, i, r, (c0 & 31) >> 3) + (unsigned)((c0 & 7) * 2);
+        *(f16x4*)(patch + off) = hi4;
+        *(f16x4*)(patch + TAIL_G_PLANE + off) = lo4;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();   // the patch is private to the wave: LDS operations of a wave execute in order
+
+  // ---- ConvTranspose2d(64 -> 32, k2 s2) + GELU, then the three hyper-network dot products, per pair of sub-positions ----
+  const float* hy = a.hyper + (long long)p * 4 * 32;
+  float* const stage = (float*)(smem + TAIL_STAGE);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    f32x4 c2[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const _Float16* w3h = a.W3h + (long long)(pass * 64 + r) * 64 + 8 * h;
+    const _Float16* w3l = a.W3l + (long long)(pass * 64 + r) * 64 + 8 * h;
+    f16x8 qh[2][4], ql[2][4];      // both K steps of this pass's W fragments in one burst (one exposed L2 round trip, not two)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { qh[ks][j] = *(const f16x8*)(w3h + j * 16 * 64 + ks * 32); ql[ks][j] = *(const f16x8*)(w3l + j * 16 * 64 + ks * 32); }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 gh[4], gl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned off = frag_off(ks, 4, i, r, h);
+        gh[i] = *(const f16x8*)(patch + off);
+        gl[i] = *(const f16x8*)(patch + TAIL_G_PLANE + off);
+      }
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f16x8 av = term == 0 ? gl[i] : gh[i];
+            const f16x8 bv = term == 1 ? ql[ks][j] : qh[ks][j];
+            c2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, c2[i][j], 0, 0, 0);
+          }
+    }
+    // columns of this pass: n = 64 pass + 16 j + 4 h + e = sub-position (2 pass + (j >> 1)), channel 16 (j & 1) + 4 h + e.
+    // part[sp][i][m]: this lane's share (8 of the 32 channels) of the dot product of row 16 i + r, sub-position 2 pass + sp
+    float part[2][4][3];
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      f32x4 hv[3][2], b3v[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        b3v[jj] = *(const f32x4*)(a.b3 + pass * 64 + 32 * sp + 16 * jj + 4 * h);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) hv[m][jj] = *(const f32x4*)(hy + 32 * (m + 1) + 16 * jj + 4 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float d3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float u = gelu_erf(c2[i][2 * sp + jj][e] * a.s3 + b3v[jj][e]);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) d3[m] = fmaf(u, hv[m][jj][e], d3[m]);
+          }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) part[sp][i][m] = d3[m];
+      }
+    }
+    // Sum over the four lanes (h) of a row as a reduce-scatter: lanes h and h ^ 2 trade the sub-position they do not keep
+    // (12 values), then lanes h and h ^ 1 trade the two row blocks they do not keep (6 values): 18 shuffles instead of 48,
+    // and a lane ends up with six finished logits: sub-position h >> 1, row blocks 2 (h & 1) and 2 (h & 1) + 1, three masks.
+    const bool up2 = (h & 2) != 0, up1 = (h & 1) != 0;
+    float k12[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const float send = up2 ? part[0][i][m] : part[1][i][m];
+        const float keep = up2 ? part[1][i][m] : part[0][i][m];
+        k12[i][m] = keep + __shfl_xor(send, 32);
+      }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const float send = up1 ? k12[ii][m] : k12[2 + ii][m];
+        const float keep = up1 ? k12[2 + ii][m] : k12[ii][m];
+        const float res = keep + __shfl_xor(send, 16);
+        const int i = 2 * (h & 1) + ii;
+        const int sub = 2 * pass + (h >> 1);                   // (ky2, kx2)
+        const int dy = 2 * (wave >> 1) + (sub >> 1), dx = 2 * (wave & 1) + (sub & 1);
+        stage[(m * TAIL_ROWS + 16 * i + r) * 16 + dy * 4 + dx] = res;
+      }
+  }
+  __syncthreads();
+
+  // ---- the tile's 3 x 64 x 16 logits to the [P, 3, 4g, 4g] layout, rows of 4 * min(g, 64) contiguous floats ----
+  const int g = a.g, S4 = 4 * g;
+  const int gw = g < TAIL_ROWS ? g : TAIL_ROWS;          // pixels of one grid row inside the tile
+  const int nrow = TAIL_ROWS / gw;                       // grid rows the tile covers
+  const int pix0 = tile * TAIL_ROWS, y0 = pix0 / g, x0 = pix0 - y0 * g;
+  const int rowlen = 4 * gw;
+  for (int o = t; o < 3 * TAIL_ROWS * 16; o += 256) {
+    const int xx = o % rowlen;
+    int q = o / rowlen;
+    const int dy = q & 3;
+    q >>= 2;
+    const int yl = q % nrow, m = q / nrow;
+    const int xl = xx >> 2, dx = xx & 3;
+    const float v = stage[(m * TAIL_ROWS + yl * gw + xl) * 16 + dy * 4 + dx];
+    a.out[(((long long)p * 3 + m) * S4 + 4 * (y0 + yl) + dy) * S4 + 4 * (x0 + xl) + dx] = v;
+  }
+}
+
+}  // namespace
+
+// upscaling + hyper-network products of the mask decoder in one launch.  src_hi / src_lo: the decoder's final image
+// tokens [P*HW, 256] as fp16 hi / lo planes; hyper [P, 4, 32]; low_res [P, 3, 4g, 4g].  Returns HGL_EINVAL (and leaves the
+// error string) when the geometry or the weights do not fit the kernel: the caller then takes the unfused launches.
+int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0_w, const float* up0_b, const float* ln_w,
+                        const float* ln_b, const float* up3_w, const float* up3_b, const float* hyper, int P, int g, float eps,
+                        float* low_res, hipStream_t st) {
+  const void *w0h, *w0l, *w3h, *w3l;
+  int s0 = 0, s3 = 0, n0 = 0, k0 = 0, n3 = 0, k3 = 0;
+  const int HW = g * g;
+  HGL_REQUIRE(hgl_get_split_weight(up0_w, &w0h, &w0l, &s0, &n0, &k0) && hgl_get_split_weight(up3_w, &w3h, &w3l, &s3, &n3, &k3),
+              "dec_tail: the upscaling weights have no registered fp16 split");
+  HGL_REQUIRE(n0 == 256 && k0 == 256 && n3 == 128 && k3 == 64, "dec_tail: upscaling geometry [%d,%d] / [%d,%d] unsupported", n0, k0, n3, k3);
+  HGL_REQUIRE(HW % TAIL_ROWS == 0 && (g % TAIL_ROWS == 0 || TAIL_ROWS % g == 0) && P > 0 && P <= 65535,
+              "dec_tail: grid %d / %d prompts unsupported", g, P);
+  TailArgs a;
+  a.Ah = (const _Float16*)src_hi; a.Al = (const _Float16*)src_lo;
+  a.W0h = (const _Float16*)w0h; a.W0l = (const _Float16*)w0l; a.W3h = (const _Float16*)w3h; a.W3l = (const _Float16*)w3l;
+  a.b0 = up0_b; a.ln_w = ln_w; a.ln_b = ln_b; a.b3 = up3_b; a.hyper = hyper;
+  a.s0 = ldexpf(1.0f, -s0); a.s3 = ldexpf(1.0f, -s3); a.eps = eps;
+  a.g = g; a.HW = HW; a.out = low_res;
+  static bool set = false;
+  if (!set) {
+    (void)hipFuncSetAttribute((const void*)dec_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS);
+    set = true;
+  }
+  HglProfScope prof(HGL_PROF_OTHER, 2.0 * P * HW * (256.0 * 256 + 4 * 64.0 * 128), 0.0, st);
+  hipLaunchKernelGGL(dec_tail_kernel, dim3((unsigned)(HW / TAIL_ROWS), (unsigned)P), dim3(256), TAIL_LDS, st, a);
+  return hgl_check_launch("dec_tail");
+}

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void ln_gelu64_kernel(float* __restrict__ x, c
   const float d = v - mean;
   const float var = wsum(d * d) * (1.f / 64.f);
   v = d * rsqrtf(var + eps) * w[lane] + b[lane];
-  const float o = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  const float o = hgl_gelu_erf(v);
   if (hi) {
     _Float16 h, l;
     hgl_split_hi_lo(o, h, l);

@@ -411,6 +411,10 @@ size_t hgl_sam_decode_workspace_bytes(const HglSamDecoderW* w, int P);
 int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float* points01, int P,
                           float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* Fused stages of the decoder (split-fp16 mode): bit 0 = output upscaling + hyper-network products in one launch.  Sets
+ * the mask (mask >= 0; default all stages, or HGL_SAM_DEC_FUSED) and returns the previous one; mask < 0 only queries.  The
+ * fused and the unfused stages compute the same values bit for bit: the switch exists for timing and for that test. */
+int hgl_sam_decoder_fusion(int mask);
 
 /* Sam.postprocess_masks + the per-candidate AMG statistics in one pass
  * (modeling/sam.py:133-162, automatic_mask_generator.py:287-308, utils/amg.py:156-176,303-346):

@@ -230,6 +230,32 @@ def test_attention_cls_keep_with_offsets(cuda, precision):
     np.testing.assert_allclose(y, _attn_ref(q, k, v, heads, hd ** -0.5, add), rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("path", ["f32", "f16x3"])
+def test_epilogue_activations_accuracy(cuda, path):
+    """hgl_gelu_erf / hgl_quick_gelu (hgl_common.h) through a GEMM with the identity as weight: erf-GELU within 2.5e-7 *
+    max(1, |x|) of the double-precision function on the whole axis (one float rounding of erf alone is 6e-8; a float
+    erff-based evaluation -- the reference's -- is no closer); QuickGELU within 3e-6 relative (the rounding of the
+    exponential's argument, 1.702 |x| <= 15, is 1e-6 of that in any float evaluation)."""
+    from scipy import special
+    n = 256
+    x = np.concatenate([np.linspace(-9, 9, n * n - 4096), np.random.default_rng(0).standard_normal(4096) * 2]).astype(np.float32)
+    a = x.reshape(n, n)
+    eye = np.eye(n, dtype=np.float32)
+    fn = ops.gemm if path == "f32" else ops.gemm_f16x3
+    xd = a.astype(np.float64)
+    if path == "f16x3":      # the operand is split into fp16 hi + lo: representable only to 2^-22; compare on what the GEMM saw
+        hi = a.astype(np.float16).astype(np.float32)
+        xd = (hi + (a - hi).astype(np.float16).astype(np.float32)).astype(np.float64)
+    y = fn(T(a, cuda), T(eye, cuda), act="gelu").cpu().numpy().astype(np.float64)
+    ref = 0.5 * xd * special.erfc(-xd / np.sqrt(2.0))
+    assert np.abs(y - ref).max() < 2e-7 * 9, np.abs(y - ref).max()
+    assert (np.abs(y - ref) <= 2.5e-7 * np.maximum(1.0, np.abs(xd))).all()
+    q = fn(T(a, cuda), T(eye, cuda), act="quickgelu").cpu().numpy().astype(np.float64)
+    qref = xd / (1.0 + np.exp(-1.702 * xd))
+    big = np.abs(qref) > 1e-30
+    assert (np.abs(q - qref)[big] <= 3e-6 * np.abs(qref[big]) + 1e-37).all(), (np.abs(q - qref)[big] / np.abs(qref[big])).max()
+
+
 @pytest.mark.parametrize("Sk", [300, 600])
 def test_attention_cls_keep_more_keys_than_queries(cuda, precision, Sk):
     """197 queries (the 8-wave kernels' range) against more than 257 keys under the CLS keep mask: the persistent wide

@@ -194,6 +194,41 @@ def test_tiny_generate_vs_reference(cuda, g, tiny):
     assert all(a["crop_box"] == [0, 0, 200, 160] for a in anns)
 
 
+def _fusion(mask):
+    from hybridgl_amd import _lib
+    return _lib.load().hgl_sam_decoder_fusion(mask)
+
+
+@pytest.mark.parametrize("name,P", [("tiny", 5), ("tiny", 64), ("vit_h_d2", 64), ("vit_h_d2", 7)])
+def test_fused_decoder_stages_equal_the_unfused_launches(cuda, name, P):
+    """hgl_sam_decoder_fusion: the fused upscaling + hyper-network kernel against the four launches it replaces
+    (ConvTranspose GEMM, LayerNorm2d + GELU, ConvTranspose GEMM + GELU, hyper-network products), on the tiny grid (16 x 16:
+    a tile spans four grid rows) and the ViT-H grid (64 x 64): the same matrix products in the same order, the LayerNorm sums
+    and the 32-channel dot products associated differently -- equal to fp32 rounding (1e-6 of the largest logit)."""
+    from hybridgl_amd import ops
+    if ops.default_precision() != "f16x3":
+        pytest.skip("the fused stages belong to the split-fp16 mode")
+    cfg = weights.SAM_CONFIGS[name]
+    m = hsam.Sam(weights.sam_state_dict(name, 0), cfg, cuda)
+    g = cfg["img_size"] // cfg["patch_size"]
+    rng = np.random.default_rng(P)
+    emb = T(rng.standard_normal((g * g, 256)).astype(np.float32), cuda)
+    p01 = T(rng.random((P, 2)).astype(np.float32), cuda)
+    old = _fusion(-1)
+    try:
+        _fusion(0)
+        low0, iou0 = m.decode_points(emb, p01)
+        _fusion(old if old > 0 else 0x7fffffff)
+        low1, iou1 = m.decode_points(emb, p01)
+    finally:
+        _fusion(old)
+    assert torch.isfinite(low0).all() and float(low0.abs().max()) > 0
+    assert torch.equal(iou0, iou1)
+    assert float((low0 - low1).abs().max()) <= 2e-6 * float(low0.abs().max()), float((low0 - low1).abs().max())
+    del m
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("mode", ["uncompressed_rle", "coco_rle"])
 def test_generate_rle_output_modes(cuda, tiny, mode):
     """output_mode (automatic_mask_generator.py:176-182): the records of the RLE modes decode to the binary_mask records"""
