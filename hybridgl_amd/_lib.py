@@ -84,7 +84,9 @@ class HglSamDecoderW(C.Structure):
                 ("layer", _Layer * 2), ("final_t2i", HglSamAttnW), ("norm_final", HglNormW),
                 ("up0_w", C.c_void_p), ("up0_b", C.c_void_p), ("up1", HglNormW),
                 ("up3_w", C.c_void_p), ("up3_b", C.c_void_p),
-                ("hyper", (HglLinearW * 3) * 4), ("iou_head", HglLinearW * 3)]
+                ("hyper", (HglLinearW * 3) * 4), ("iou_head", HglLinearW * 3),
+                ("kvq1_w", C.c_void_p), ("kvq1_b", C.c_void_p), ("kvq1_pe", C.c_void_p),
+                ("kvf_w", C.c_void_p), ("kvf_b", C.c_void_p), ("kvf_pe", C.c_void_p)]
 
 
 

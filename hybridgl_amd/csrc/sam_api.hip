@@ -226,9 +226,10 @@ bool carve_dec(HglArena& ar, const HglSamDecoderW* w, int P, DecPlan& p) {
   p.kpe0 = ar.take<float>(HW * C);
   p.keys = ar.take<float>(P * HW * C);
   p.kpe = ar.take<float>(P * HW * C);
-  p.kp = ar.take<float>(P * HW * C / 2);
-  p.vp = ar.take<float>(P * HW * C / 2);
-  p.qi = ar.take<float>(P * HW * C / 2);
+  // k / v / q projections of the image tokens: three [P*HW, C/2] matrices, or -- merged projections -- ONE [P*HW, 3C/2]
+  p.kp = ar.take<float>(3 * (P * HW * C / 2));
+  p.vp = p.kp ? p.kp + P * HW * C / 2 : nullptr;
+  p.qi = p.kp ? p.kp + 2 * (P * HW * C / 2) : nullptr;
   p.atti = ar.take<float>(P * HW * C / 2);
   p.mlp = ar.take<float>(P * T * w->mlp_dim);
   p.u1 = ar.take<float>(P * HW * C);           // [P*HW*4, C/4]
@@ -344,6 +345,44 @@ int dec_t2i_x3(const HglSamDecoderW* w, const HglSamAttnW& a, const float* qpe, 
                                (long long)HW * I, (long long)T * I, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0,
                                nullptr, nullptr, 0, 0, st));
   return hgl_launch_gemm(att, a.out.w, a.out.b, queries, queries, P * T, C, I, I, I, C, C, 1, 0, 0, 0, 0, HGL_ACT_NONE, st);
+}
+
+// ---- merged image-side projections (HglSamDecoderW.kvq1 / kvf) ------------------------------------------------------
+bool dec_merged_ready(const HglSamDecoderW* w) {
+  return (dec_fusion_mask() & 2) && w->kvq1_w && w->kvq1_b && w->kvq1_pe && w->kvf_w && w->kvf_b && w->kvf_pe &&
+         hgl_has_split_weight(w->kvq1_w) && hgl_has_split_weight(w->kvf_w);
+}
+
+// kvq [P*HW, N] = keys W^T + b + pe_table[row % HW]   (N = 3I: k | v | q of layer 1;  N = 2I: k | v of the final attention)
+int dec_project_merged(const SplitPair& keysS, const float* W, const float* b, const float* pe_tab, int P, int HW, int C, int N,
+                       float* kvq, hipStream_t st) {
+  return hgl_launch_gemm_f16x3_rmod(keysS.hi, keysS.lo, C, W, b, pe_tab, N, HW, kvq, nullptr, nullptr, N, P * HW, N, C,
+                                    HGL_ACT_NONE, st);
+}
+
+// token -> image attention on merged projections: k = kvq[:, 0:I], v = kvq[:, I:2I], row stride ld
+int dec_t2i_merged(const HglSamDecoderW* w, const HglSamAttnW& a, const float* qpe, const float* kvq, int ld, int P, int HW,
+                   float* q1, float* att, float* queries, hipStream_t st) {
+  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads, T = 7;
+  HGL_TRY(lin(qpe, C, a.q, nullptr, 0, q1, I, P * T, I, C, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_attention(q1, kvq, kvq + I, att, P, heads, T, HW, hd, I, ld, ld, I, (long long)T * I, (long long)HW * ld,
+                               (long long)HW * ld, (long long)T * I, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0,
+                               nullptr, nullptr, 0, 0, st));
+  return hgl_launch_gemm(att, a.out.w, a.out.b, queries, queries, P * T, C, I, I, I, C, C, 1, 0, 0, 0, 0, HGL_ACT_NONE, st);
+}
+
+// image -> token attention on merged projections: q = kvq[:, 2I:3I]
+int dec_i2t_merged(const HglSamDecoderW* w, const HglSamAttnW& a, const float* kvq, int ld, const float* tok_k, const float* tok_v,
+                   int P, int HW, float* k1, float* v1, float* atti, const float* R, float* keys_out, hipStream_t st) {
+  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads, T = 7;
+  HGL_TRY(lin(tok_k, C, a.k, nullptr, 0, k1, I, P * T, I, C, HGL_ACT_NONE, st));
+  HGL_TRY(lin(tok_v, C, a.v, nullptr, 0, v1, I, P * T, I, C, HGL_ACT_NONE, st));
+  const SplitPair at = split_view(atti, (size_t)P * HW * I);
+  HGL_TRY(hgl_launch_attention_smallk(kvq + 2 * I, k1, v1, nullptr, at.hi, at.lo, P, heads, HW, T, hd, ld, I, I, I,
+                                      (long long)HW * ld, (long long)T * I, (long long)T * I, (long long)HW * I,
+                                      1.0f / sqrtf((float)hd), st));
+  return hgl_launch_gemm_f16x3_rmod(at.hi, at.lo, I, a.out.w, a.out.b, R, C, 0, keys_out, nullptr, nullptr, C, P * HW, C, I,
+                                    HGL_ACT_NONE, st);
 }
 
 }  // namespace
@@ -481,6 +520,9 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
   (void)hipMemcpyAsync(p.queries, p.tokens, sizeof(float) * P * sQ, hipMemcpyDeviceToDevice, st);
 
   const bool x3 = dec_x3_ready(w);
+  const bool merged = x3 && dec_merged_ready(w) && w->layer[1].t2i.internal == w->layer[1].i2t.internal &&
+                      w->layer[1].t2i.internal == w->final_t2i.internal && 2 * w->final_t2i.internal == C;
+  const int I1 = w->layer[1].t2i.internal;
   const SplitPair keysS = split_view(p.keysS, (size_t)P * HW * C), kpeS = split_view(p.kpe, (size_t)P * HW * C);
   for (int li = 0; li < 2; ++li) {
     const auto& L = w->layer[li];
@@ -500,7 +542,11 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
     HGL_TRY(hgl_launch_layernorm(p.queries, L.n1.w, L.n1.b, p.queries, P * T, C, 1e-5f, st));
     // (2) tokens attend to the image
     HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
-    if (x3 && !shared) {
+    if (merged && !shared) {
+      // k, v of this step and q of step (4) read the same rows: one GEMM, the positional encoding as a per-position table
+      HGL_TRY(dec_project_merged(keysS, w->kvq1_w, w->kvq1_b, w->kvq1_pe, P, HW, C, 3 * I1, p.kp, st));
+      HGL_TRY(dec_t2i_merged(w, L.t2i, p.qpe, p.kp, 3 * I1, P, HW, p.q1, p.att, p.queries, st));
+    } else if (x3 && !shared) {
       HGL_TRY(dec_t2i_x3(w, L.t2i, p.qpe, kpeS, keysS, P, HW, p.q1, p.kp, p.vp, p.att, p.queries, st));
     } else {
       HGL_TRY(dec_attn(w, L.t2i, p.qpe, false, T, kpe, keys, shared, HW, P, p.q1, p.kp, p.vp, p.att, p.queries, sQ,
@@ -514,12 +560,16 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
     // (4) image attends to the tokens: q = keys+pe, k = queries+pe, v = queries ; keys += out
     HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
     if (x3) {
-      HGL_TRY(dec_i2t_x3(w, L.i2t, shared, p.kpe0, kpeS, p.qpe, p.queries, P, HW, p.qi, p.k1, p.v1, p.atti, keys,
-                         shared ? HW : 0, p.keys, st));
-      // norm4, then keys and keys + dense_pe as split planes; the fp32 rows are kept only while a later layer needs
-      // them as a residual
+      if (merged && !shared) {
+        HGL_TRY(dec_i2t_merged(w, L.i2t, p.kp, 3 * I1, p.qpe, p.queries, P, HW, p.k1, p.v1, p.atti, keys, p.keys, st));
+      } else {
+        HGL_TRY(dec_i2t_x3(w, L.i2t, shared, p.kpe0, kpeS, p.qpe, p.queries, P, HW, p.qi, p.k1, p.v1, p.atti, keys,
+                           shared ? HW : 0, p.keys, st));
+      }
+      // norm4, then keys (and, unmerged, keys + dense_pe) as split planes; the fp32 rows are kept only while a later layer
+      // needs them as a residual
       HGL_TRY(hgl_launch_ln256_pe_split(p.keys, L.n4.w, L.n4.b, w->dense_pe, HW, (long long)P * HW, 1e-5f, li == 0 ? 1 : 0,
-                                        keysS.hi, keysS.lo, kpeS.hi, kpeS.lo, st));
+                                        keysS.hi, keysS.lo, merged ? nullptr : kpeS.hi, merged ? nullptr : kpeS.lo, st));
     } else {
       HGL_TRY(dec_attn(w, L.i2t, kpe, shared, HW, p.qpe, p.queries, false, T, P, p.qi, p.k1, p.v1, p.atti, keys,
                        shared ? 0 : sK, p.keys, st));
@@ -529,7 +579,10 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
   }
   // final token -> image attention
   HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
-  if (x3) {
+  if (merged) {
+    HGL_TRY(dec_project_merged(keysS, w->kvf_w, w->kvf_b, w->kvf_pe, P, HW, C, 2 * I1, p.kp, st));
+    HGL_TRY(dec_t2i_merged(w, w->final_t2i, p.qpe, p.kp, 2 * I1, P, HW, p.q1, p.att, p.queries, st));
+  } else if (x3) {
     HGL_TRY(dec_t2i_x3(w, w->final_t2i, p.qpe, kpeS, keysS, P, HW, p.q1, p.kp, p.vp, p.att, p.queries, st));
   } else {
     HGL_TRY(dec_attn(w, w->final_t2i, p.qpe, false, T, p.kpe, p.keys, false, HW, P, p.q1, p.kp, p.vp, p.att, p.queries,

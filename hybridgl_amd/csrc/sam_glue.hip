@@ -403,7 +403,8 @@ __global__ __launch_bounds__(256) void ln256_pe_split_kernel(float* __restrict__
   for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
   const float rstd = rsqrtf(wsum(q) * (1.f / 256.f) + eps);
   const f32x4 wv = ((const f32x4*)w)[lane], bv = ((const f32x4*)b)[lane];
-  const f32x4 pv = ((const f32x4*)(pe + (row % pe_rows) * 256))[lane];
+  f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+  if (ph) pv = ((const f32x4*)(pe + (row % pe_rows) * 256))[lane];   // (uniform: ph == nullptr = no "+ pe" planes wanted)
   f32x4 o;
   f16x4g a, c, a2, c2;
 #pragma unroll
@@ -418,8 +419,10 @@ __global__ __launch_bounds__(256) void ln256_pe_split_kernel(float* __restrict__
   if (write_f32) ((f32x4*)(x + row * 256))[lane] = o;
   ((f16x4g*)(kh + row * 256))[lane] = a;
   ((f16x4g*)(kl + row * 256))[lane] = c;
-  ((f16x4g*)(ph + row * 256))[lane] = a2;
-  ((f16x4g*)(pl + row * 256))[lane] = c2;
+  if (ph) {
+    ((f16x4g*)(ph + row * 256))[lane] = a2;
+    ((f16x4g*)(pl + row * 256))[lane] = c2;
+  }
 }
 
 // masks[p, t, Y, X] = hyper[p, t+1, :] . upscaled[p, pixel(Y,X), :]  (mask_decoder.py:146-151, multimask rows 1..3),

@@ -110,6 +110,8 @@ class HybridGLPipeline:
         if k_clamp not in ("persistent", "per_ref"):
             raise ValueError("k_clamp must be 'persistent' or 'per_ref'")
         self.k_clamp = k_clamp
+        import os
+        self.stagger = os.environ.get("HYBRIDGL_STAGGER", "decoder")   # which part of the next group's SAM stage the CLIP stage runs beside
         self._k0 = (k1, k2)
         self.model = model
         self.gem_model = gem_model              # hybridgl_amd.gem.GEMWrapper: heat-maps computed on the device
@@ -321,6 +323,7 @@ class HybridGLPipeline:
                 for r in u:
                     _adopt(r, (s_sam, s_clip))
             state = None
+            ev_enc = None
             if gen is not None:
                 with torch.cuda.stream(s_sam):
                     imgs = [u[0].sam_img for u in units]
@@ -329,11 +332,18 @@ class HybridGLPipeline:
                             state = ("crops", [tuple(t[:proposal_cap] if proposal_cap is not None else t
                                                      for t in gen.generate_device_crops(im)[:2]) for im in imgs])
                         else:
-                            state = ("group", gen.group_begin(imgs, proposal_cap))
+                            # stagger = "decoder": the CLIP stage of the previous group starts when THIS group's encoder pass
+                            # is through, so its large GEMMs run beside the latency-bound rest of the proposal stage (decoder,
+                            # post-processing, NMS, clean-up) instead of beside the encoder's equally matrix-bound GEMMs
+                            if self.stagger == "decoder" and not serial:
+                                ev_enc = torch.cuda.Event()
+                            state = ("group", gen.group_begin(imgs, proposal_cap, ev_enc))
                     else:    # proposal kernels only; their output is not consumed (synthetic benchmark, seeded masks)
                         self.last_proposals = gen.propose_batch(imgs)[-1]
             if pending is not None:
                 with torch.cuda.stream(s_clip):
+                    if ev_enc is not None:
+                        s_clip.wait_event(ev_enc)
                     done += self._clip_group(*pending)
             props, ready = None, None
             if state is not None:

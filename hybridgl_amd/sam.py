@@ -149,6 +149,34 @@ class Sam:
         check(_lib.load().hgl_sam_dense_pe(C.byref(dec), cd.data_ptr(), self.dense_pe.data_ptr(), ops._stream()),
               "hgl_sam_dense_pe")
         torch.cuda.current_stream().synchronize()
+        if precision == "f16x3" and Cc == 256:
+            # merged image-side projections of the decoder (HglSamDecoderW.kvq1 / kvf): concatenated weights, and the
+            # positional-encoding part of k and q as per-position tables: (keys + pe) W^T = keys W^T + pe W^T
+            def cat_w(keys):
+                w = torch.cat([_dev(sd[f"{k}.weight"], self.device) for k in keys], 0).contiguous()
+                b = torch.cat([_dev(sd[f"{k}.bias"], self.device) for k in keys], 0).contiguous()
+                self._t += [w, b]
+                ops.register_split_weight(w)
+                return w, b
+
+            def pe_table(keys, with_pe):
+                cols = []
+                for k, use in zip(keys, with_pe):
+                    wk = _dev(sd[f"{k}.weight"], self.device)
+                    cols.append(ops.gemm(self.dense_pe, wk) if use else
+                                torch.zeros((self.dense_pe.shape[0], wk.shape[0]), dtype=torch.float32, device=self.device))
+                tab = torch.cat(cols, 1).contiguous()
+                self._t.append(tab)
+                return tab
+            l1 = f"{m}.transformer.layers.1"
+            k1 = [f"{l1}.cross_attn_token_to_image.k_proj", f"{l1}.cross_attn_token_to_image.v_proj",
+                  f"{l1}.cross_attn_image_to_token.q_proj"]
+            kf = [f"{m}.transformer.final_attn_token_to_image.k_proj", f"{m}.transformer.final_attn_token_to_image.v_proj"]
+            w1, b1 = cat_w(k1)
+            wf, bf = cat_w(kf)
+            dec.kvq1_w, dec.kvq1_b, dec.kvq1_pe = w1.data_ptr(), b1.data_ptr(), pe_table(k1, (True, False, True)).data_ptr()
+            dec.kvf_w, dec.kvf_b, dec.kvf_pe = wf.data_ptr(), bf.data_ptr(), pe_table(kf, (True, False)).data_ptr()
+            torch.cuda.current_stream().synchronize()
         self.dec_w = dec
         # the fp16 splits registered above die with this model (library registry + hi/lo tensors)
         self._split_keys = ops.split_weight_keys_since(_before)
@@ -526,9 +554,10 @@ class SamAutomaticMaskGenerator:
         emb = m.encode(resized)
         return self._propose_from_embedding(emb, H, W, nh, nw, layer_idx, crop_box, orig_size)
 
-    def propose_batch(self, images):
+    def propose_batch(self, images, encoded_event=None):
         """propose() for several whole images with ONE encoder pass over all of them (Sam.encode_batch); decoder,
-        post-processing and NMS per image.  Returns the list of propose() tuples."""
+        post-processing and NMS per image.  Returns the list of propose() tuples.  encoded_event: a torch.cuda.Event that
+        is recorded behind the encoder pass (the boundary between the GEMM-bound and the latency-bound part of the stage)."""
         m = self.model
         sizes, resized = [], []
         for image in images:
@@ -537,6 +566,8 @@ class SamAutomaticMaskGenerator:
             sizes.append((H, W) + get_preprocess_shape(H, W, m.img_size))
             resized.append(resize_longest_side(dev_img.contiguous(), m.img_size))
         emb = m.encode_batch(resized)
+        if encoded_event is not None:
+            encoded_event.record(torch.cuda.current_stream(m.device))
         return [self._propose_from_embedding(emb[i], *sizes[i], 0, None, None) for i in range(len(images))]
 
     def _propose_from_embedding(self, emb, H, W, nh, nw, layer_idx, crop_box, orig_size):
@@ -651,7 +682,7 @@ class SamAutomaticMaskGenerator:
         return m, xywh, iou.index_select(0, idx), stab.index_select(0, idx), idx
 
     # ---- a GROUP of images through the generator: one encoder pass, two host syncs for the whole group ------------
-    def group_begin(self, images, cap=None):
+    def group_begin(self, images, cap=None, encoded_event=None):
         """Stage A of generate() for several whole images (no crop layers) on the current stream: Pillow-exact resize,
         ONE encoder pass over all of them (Sam.encode_batch), then per image decoder + fused post-processing + first NMS.
         The survivor counts of all images leave in ONE device->host copy (pinned), marked by an event: nothing is waited for
@@ -662,7 +693,7 @@ class SamAutomaticMaskGenerator:
         st = _GroupState()
         st.cap = cap
         st.sizes = [tuple(int(v) for v in im.shape[:2]) for im in images]
-        st.cand = self.propose_batch(images)
+        st.cand = self.propose_batch(images, encoded_event)
         dev = self.model.device
         st.n1_dev = torch.cat([c[5] for c in st.cand])
         st.n1 = torch.empty(len(images), dtype=torch.int32).pin_memory()

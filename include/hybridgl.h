@@ -375,6 +375,13 @@ typedef struct HglSamDecoderW {        /* prompt_encoder.py + mask_decoder.py + 
   const float *up3_w, *up3_b;          /* ConvT 64->32 as GEMM: [(pos,oc)=128, 64], bias [(pos,oc)] */
   HglLinearW hyper[4][3];              /* output_hypernetworks_mlps */
   HglLinearW iou_head[3];
+  /* Optional (NULL = not provided), split-fp16 mode: the image-side projections of one step merged into ONE GEMM over the
+   * 256-channel rows, the positional encoding entering as a per-position table instead of a second copy of the rows:
+   * (keys + pe) Wk^T = keys Wk^T + (pe Wk^T).  kvq1: layer 1's token->image k, v and image->token q (all read the same
+   * rows): weight [3I, C] = rows of layer[1].t2i.k.w, layer[1].t2i.v.w, layer[1].i2t.q.w; bias [3I]; pe table
+   * [grid*grid, 3I] = dense_pe @ [Wk; 0; Wq]^T.  kvf: the final token->image k, v: [2I, C], [2I], [grid*grid, 2I]. */
+  const float *kvq1_w, *kvq1_b, *kvq1_pe;
+  const float *kvf_w, *kvf_b, *kvf_pe;
 } HglSamDecoderW;
 
 /* ResizeLongestSide.apply_image (utils/transforms.py:26-31) = Pillow Image.resize(BILINEAR) on uint8 HWC,
@@ -411,9 +418,10 @@ size_t hgl_sam_decode_workspace_bytes(const HglSamDecoderW* w, int P);
 int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float* points01, int P,
                           float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes,
                           void* stream);
-/* Fused stages of the decoder (split-fp16 mode): bit 0 = output upscaling + hyper-network products in one launch.  Sets
- * the mask (mask >= 0; default all stages, or HGL_SAM_DEC_FUSED) and returns the previous one; mask < 0 only queries.  The
- * fused and the unfused stages compute the same values bit for bit: the switch exists for timing and for that test. */
+/* Fused stages of the decoder (split-fp16 mode): bit 0 = output upscaling + hyper-network products in one launch; bit 1 =
+ * merged image-side projections (kvq1 / kvf of HglSamDecoderW, when provided).  Sets the mask (mask >= 0; default all
+ * stages, or HGL_SAM_DEC_FUSED) and returns the previous one; mask < 0 only queries.  Fused and unfused stages agree to
+ * fp32 rounding: the switch exists for timing and for that test. */
 int hgl_sam_decoder_fusion(int mask);
 
 /* Sam.postprocess_masks + the per-candidate AMG statistics in one pass

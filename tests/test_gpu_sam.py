@@ -201,7 +201,8 @@ def _fusion(mask):
 
 @pytest.mark.parametrize("name,P", [("tiny", 5), ("tiny", 64), ("vit_h_d2", 64), ("vit_h_d2", 7)])
 def test_fused_decoder_stages_equal_the_unfused_launches(cuda, name, P):
-    """hgl_sam_decoder_fusion: the fused upscaling + hyper-network kernel against the four launches it replaces
+    """hgl_sam_decoder_fusion: the merged image-side projections (one GEMM for k | v | q, positional encoding as a table)
+    and the fused upscaling + hyper-network kernel against the launches they replace
     (ConvTranspose GEMM, LayerNorm2d + GELU, ConvTranspose GEMM + GELU, hyper-network products), on the tiny grid (16 x 16:
     a tile spans four grid rows) and the ViT-H grid (64 x 64): the same matrix products in the same order, the LayerNorm sums
     and the 32-channel dot products associated differently -- equal to fp32 rounding (1e-6 of the largest logit)."""
@@ -223,8 +224,15 @@ def test_fused_decoder_stages_equal_the_unfused_launches(cuda, name, P):
     finally:
         _fusion(old)
     assert torch.isfinite(low0).all() and float(low0.abs().max()) > 0
-    assert torch.equal(iou0, iou1)
-    assert float((low0 - low1).abs().max()) <= 2e-6 * float(low0.abs().max()), float((low0 - low1).abs().max())
+    # bit 0 alone (the fused tail): same matrix products, sums associated differently
+    _fusion(1)
+    low2, iou2 = m.decode_points(emb, p01)
+    _fusion(old)
+    assert torch.equal(iou0, iou2)
+    assert float((low0 - low2).abs().max()) <= 2e-6 * float(low0.abs().max()), float((low0 - low2).abs().max())
+    # all stages: the merged projections add the positional encoding AFTER the product ((keys + pe) W = keys W + pe W)
+    assert float((iou0 - iou1).abs().max()) <= 2e-5 * max(1.0, float(iou0.abs().max()))
+    assert float((low0 - low1).abs().max()) <= 2e-5 * float(low0.abs().max()), float((low0 - low1).abs().max())
     del m
     torch.cuda.empty_cache()
 
