@@ -229,8 +229,9 @@ def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False, clip_na
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64,
-                    help="timed steps (refs); the default is a whole number of groups of --sam-batch images")
+    ap.add_argument("--steps", type=int, default=128,
+                    help="timed steps (refs); the default is a whole number of groups of --sam-batch images (16 groups: the "
+                         "fill and the drain of the two-stream loop, which are inside the timed region, weigh 1 / 16 each)")
     ap.add_argument("--warmup", type=int, default=16, help="untimed steps (refs); the default is two full groups")
     ap.add_argument("--fusion", default="G2L", choices=["G2L", "L2G", "G2L&L2G"])
     ap.add_argument("--clip", default="ViT-B/16", choices=list(CLIP_GEOM),

@@ -65,17 +65,19 @@ class EmptyProposals(RuntimeError):
     """the proposal stage kept no mask for this image"""
 
 
-def _adopt(ref, streams):
-    """An item uploaded on a loader thread's stream (RefBatch.ready): the consuming streams wait for its copies, and its
-    tensors are recorded on them so that the caching allocator does not hand their blocks to the next upload while a
-    consumer still reads them."""
-    if ref.ready is None:
+def _adopt(ref, streams, produced=None):
+    """An item whose tensors were produced on another stream than the ones that consume it -- uploaded on a loader thread's
+    stream (RefBatch.ready), or built lazily on the caller's stream while the loop runs (`produced`: an event recorded
+    there behind it): the consuming streams wait for that event, and the tensors are recorded on them so that the caching
+    allocator does not hand their blocks to the next upload while a consumer still reads them."""
+    ev = ref.ready if ref.ready is not None else produced
+    if ev is None:
         return
     ts = [ref.sam_img, ref.blurred, ref.image_norm, ref.masks, ref.boxes, ref.tokens, ref.target, ref.sam_resized, ref.tensor_img]
     for s in ref.sentences:
         ts += [s.imgattn, s.target]
     for st in streams:
-        st.wait_event(ref.ready)
+        st.wait_event(ev)
         for t in ts:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(st)
@@ -98,7 +100,7 @@ def black_for(relaflag):
 class HybridGLPipeline:
     def __init__(self, model, fusion_mode="G2L", masking_block=9, r=0.5, alpha=0.6, k1=3, k2=6, res=224,
                  mask_generator=None, use_sam_masks=False, fixed_proposals=None, cleanup_given_masks=False,
-                 gem_model=None, k_clamp="persistent"):
+                 gem_model=None, k_clamp="persistent", image_cache=32):
         """mask_generator: a hybridgl_amd.sam.SamAutomaticMaskGenerator; when given, every step runs the
         SAM proposal stage (encoder, decoder, post-processing, NMS) on ref.sam_img first.
         use_sam_masks=False keeps ref.masks for the CLIP stage (fixed N; synthetic benchmark, where
@@ -109,6 +111,12 @@ class HybridGLPipeline:
         to that item only (order- and sharding-independent; differs from the reference after such an image)."""
         if k_clamp not in ("persistent", "per_ref"):
             raise ValueError("k_clamp must be 'persistent' or 'per_ref'")
+        # run(): proposals, hybrid features and GEM features of the last `image_cache` images with an image_id (the dataset
+        # yields one item per REF, Hybridgl_main.py:79, and the refs of an image are not always neighbours: RefCOCO has 2.6
+        # refs per image).  0 = off.  Entries are device tensors: ~25 MB per 640 x 480 image with 64 proposals.
+        self.image_cache = int(image_cache)
+        self._img_cache = {}
+        self.cache_hits = 0
         self.k_clamp = k_clamp
         import os
         self.stagger = os.environ.get("HYBRIDGL_STAGGER", "decoder")   # which part of the next group's SAM stage the CLIP stage runs beside
@@ -319,14 +327,34 @@ class HybridGLPipeline:
         done = 0
         pending = None
         for units in self._units(loader, group):
+            produced = None
+            if not serial:      # items a lazy loader built on the caller's stream just now
+                produced = torch.cuda.Event()
+                produced.record(cur)
             for u in units:
                 for r in u:
-                    _adopt(r, (s_sam, s_clip))
+                    _adopt(r, (s_sam, s_clip), produced)
             state = None
             ev_enc = None
-            if gen is not None:
+            # images seen lately (or in the group whose CLIP stage is about to be enqueued: it files them before this
+            # group's CLIP stage looks): no proposal stage, no hybrid forward for them
+            cached = [False] * len(units)
+            held = [None] * len(units)      # the cache entry itself, pinned at look-up (a later put may evict it from the dict)
+            if self.image_cache > 0 and gen is not None and self.use_sam_masks:
+                self._cache_cap = max(self.image_cache, 2 * group)
+                in_pending = {u[0].image_id for u in pending[0]} if pending is not None else set()
+                for i, u in enumerate(units):
+                    iid = u[0].image_id
+                    if iid is None:
+                        continue
+                    if iid in self._img_cache:
+                        cached[i], held[i] = True, ("entry", self._img_cache[iid])
+                    elif iid in in_pending:
+                        cached[i], held[i] = True, ("late",)
+            fresh = [i for i, c in enumerate(cached) if not c]
+            if gen is not None and fresh:
                 with torch.cuda.stream(s_sam):
-                    imgs = [u[0].sam_img for u in units]
+                    imgs = [units[i][0].sam_img for i in fresh]
                     if self.use_sam_masks:
                         if getattr(gen, "crop_n_layers", 0) > 0:   # PhraseCut configuration: crop layers, image by image
                             state = ("crops", [tuple(t[:proposal_cap] if proposal_cap is not None else t
@@ -349,12 +377,17 @@ class HybridGLPipeline:
             if state is not None:
                 with torch.cuda.stream(s_sam):
                     if state[0] == "group":
-                        props = [p[:2] for p in gen.group_finish(gen.group_cleanup(state[1]))]
+                        got = [p[:2] for p in gen.group_finish(gen.group_cleanup(state[1]))]
                     else:
-                        props = state[1]
+                        got = state[1]
                     ready = torch.cuda.Event()
                     ready.record(s_sam)
-            pending = (units, props, ready)
+                props = [None] * len(units)          # None = take it from the image cache
+                for i, pr in zip(fresh, got):
+                    props[i] = pr
+            elif any(cached):
+                props = [None] * len(units)
+            pending = (units, props, ready, held)
         if pending is not None:
             with torch.cuda.stream(s_clip):
                 done += self._clip_group(*pending)
@@ -362,7 +395,7 @@ class HybridGLPipeline:
             self._join_side_streams(cur, self.collected)
         return done
 
-    def _clip_group(self, units, props, ready):
+    def _clip_group(self, units, props, ready, held=None):
         """CLIP + scoring stage of one group on the current stream; props[i] = (masks u8 [n,H,W], boxes XYWH) of unit i from
         the proposal stage (None: the items' own masks / boxes).  Returns the number of refs scored."""
         import dataclasses
@@ -371,21 +404,30 @@ class HybridGLPipeline:
         if ready is not None:
             cur.wait_event(ready)
         gen = self.mask_generator
-        live = []     # (refs of the unit, masks bool [n,H,W], boxes)
+        live = []     # [refs of the unit, masks bool [n,H,W], boxes, hybrid features or None, GEM features or None]
         for i, refs in enumerate(units):
-            if props is not None:
+            if props is not None and props[i] is None:      # an image of the cache
+                hit = held[i][1] if held[i][0] == "entry" else self._img_cache.get(refs[0].image_id)
+                if hit is None:                              # filed as "no proposals"
+                    self.skipped += len(refs)
+                    continue
+                self.cache_hits += 1
+                live.append([refs, hit[0], hit[1], hit[2], hit[3]])
+            elif props is not None:
                 mk, bx = props[i]
                 if mk.shape[0] == 0:
                     self.skipped += len(refs)
+                    if self.image_cache > 0 and refs[0].image_id is not None:
+                        self._cache_put(refs[0].image_id, None)
                     continue
                 mk.record_stream(cur)
                 bx.record_stream(cur)
-                live.append((refs, mk.view(torch.bool) if mk.dtype == torch.uint8 else mk, bx.contiguous()))
+                live.append([refs, mk.view(torch.bool) if mk.dtype == torch.uint8 else mk, bx.contiguous(), None, None])
             else:
                 mk = refs[0].masks
                 if self.cleanup_given_masks and gen is not None:
                     mk = gen.cleanup_fixed(mk.view(torch.uint8))[0].view(torch.bool)
-                live.append((refs, mk, refs[0].boxes))
+                live.append([refs, mk, refs[0].boxes, None, None])
         if not live:
             return 0
         if not hasattr(self, "_s_text"):
@@ -394,7 +436,7 @@ class HybridGLPipeline:
         ev_in, ev_text = torch.cuda.Event(), torch.cuda.Event()
         ev_in.record(cur)
         s_text.wait_event(ev_in)
-        all_refs = [r for refs, _, _ in live for r in refs]
+        all_refs = [r for u in live for r in u[0]]
         offs = np.cumsum([0] + [r.tokens.shape[0] for r in all_refs])
         heats = []
         with torch.cuda.stream(s_text):
@@ -402,20 +444,24 @@ class HybridGLPipeline:
             text_all = m.model.encode_text(torch.cat([r.tokens for r in all_refs], dim=0) if len(all_refs) > 1 else all_refs[0].tokens,
                                            seq_len=None if any(v is None for v in lens) else max(lens))
             # GEM image tower once per IMAGE that has a sentence without a given heat-map
-            need = [i for i, (refs, _, _) in enumerate(live) if any(s.imgattn is None for r in refs for s in r.sentences)]
-            gfeats = {}
+            wants = [i for i, u in enumerate(live) if any(s.imgattn is None for r in u[0] for s in r.sentences)]
+            gfeats = {i: live[i][4] for i in wants if live[i][4] is not None}
+            need = [i for i in wants if i not in gfeats]
             if need:
                 if self.gem_model is None or any(live[i][0][0].tensor_img is None for i in need):
                     raise ValueError("a sentence without imgattn needs gem_model, RefBatch.tensor_img and Sentence.gem_row")
                 timgs = [live[i][0][0].tensor_img for i in need]
                 if len(need) > 1 and all(t.shape == timgs[0].shape for t in timgs):
                     fb = self.gem_model.image_features_batch(torch.stack(timgs, dim=0))
-                    gfeats = {i: fb[j] for j, i in enumerate(need)}
+                    gfeats.update({i: fb[j] for j, i in enumerate(need)})
                 else:
-                    gfeats = {i: self.gem_model.image_features(t) for i, t in zip(need, timgs)}
+                    gfeats.update({i: self.gem_model.image_features(t) for i, t in zip(need, timgs)})
+                for i in need:
+                    gfeats[i].record_stream(cur)
+                    live[i][4] = gfeats[i]
             k = 0
-            for i, (refs, _, _) in enumerate(live):
-                for ref in refs:
+            for i, u in enumerate(live):
+                for ref in u[0]:
                     text = text_all[offs[k]:offs[k + 1]]
                     k += 1
                     gem_rows = [s.gem_row for s in ref.sentences if s.imgattn is None]
@@ -430,21 +476,26 @@ class HybridGLPipeline:
                     heats.append(heat)
             ev_text.record(s_text)
         text_all.record_stream(cur)
-        ns = [mk.shape[0] for _, mk, _ in live]
-        moff = np.cumsum([0] + ns)
-        dev = live[0][1].device
-        local = torch.empty((int(moff[-1]), 3, self.res, self.res), dtype=torch.float32, device=dev)
-        glob = torch.empty_like(local)
-        for i, (refs, mk, _) in enumerate(live):
-            r0 = refs[0]
-            blurred = r0.blurred if r0.blurred is not None else ops.gaussian_blur_u8(r0.sam_img, 15)   # :99
-            ops.synthesize_views(r0.sam_img, blurred, r0.image_norm, mk, self.res,
-                                 out=(local[moff[i]:moff[i + 1]], glob[moff[i]:moff[i + 1]]))
-        hybrid_all = m(local, glob, [mk for _, mk, _ in live], masking_block=self.masking_block, fusion_mode=self.fusion_mode)
+        todo = [i for i, u in enumerate(live) if u[3] is None]       # images whose hybrid features are not cached
+        if todo:
+            ns = [live[i][1].shape[0] for i in todo]
+            moff = np.cumsum([0] + ns)
+            dev = live[todo[0]][1].device
+            local = torch.empty((int(moff[-1]), 3, self.res, self.res), dtype=torch.float32, device=dev)
+            glob = torch.empty_like(local)
+            for j, i in enumerate(todo):
+                r0, mk = live[i][0][0], live[i][1]
+                blurred = r0.blurred if r0.blurred is not None else ops.gaussian_blur_u8(r0.sam_img, 15)   # :99
+                ops.synthesize_views(r0.sam_img, blurred, r0.image_norm, mk, self.res,
+                                     out=(local[moff[j]:moff[j + 1]], glob[moff[j]:moff[j + 1]]))
+            hybrid_all = m(local, glob, [live[i][1] for i in todo], masking_block=self.masking_block, fusion_mode=self.fusion_mode)
+            for j, i in enumerate(todo):
+                live[i][3] = hybrid_all[moff[j]:moff[j + 1]]
         cur.wait_event(ev_text)
         k = 0
-        for i, (refs, mk, bx) in enumerate(live):
-            hybrid = hybrid_all[moff[i]:moff[i + 1]]
+        for refs, mk, bx, hybrid, gfeat in live:
+            if self.image_cache > 0 and props is not None and refs[0].image_id is not None:
+                self._cache_put(refs[0].image_id, (mk, bx, hybrid, gfeat))
             for ref in refs:
                 text = text_all[offs[k]:offs[k + 1]]
                 out = self._score_ref(dataclasses.replace(ref, masks=mk, boxes=bx), hybrid, text, heats[k])
@@ -452,6 +503,13 @@ class HybridGLPipeline:
                 if self.collected is not None:
                     self.collected.append((hybrid, text, out))
         return len(all_refs)
+
+    def _cache_put(self, image_id, entry):
+        """most recently used last; the oldest entry leaves when the cache is full"""
+        self._img_cache.pop(image_id, None)
+        self._img_cache[image_id] = entry
+        while len(self._img_cache) > getattr(self, "_cache_cap", self.image_cache):
+            self._img_cache.pop(next(iter(self._img_cache)))
 
     def partial_rows(self):
         """This process's per-sentence rows [n, 6] int64 = (dataset position, sentence, I, U, I_final, U_final)

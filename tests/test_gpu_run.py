@@ -120,6 +120,40 @@ def test_run_equals_per_ref_steps_on_a_refer_set(cuda, golden_dir, tmp_path, mod
     assert (a.k1, a.k2) == (b.k1, b.k2) == (c.k1, c.k2)
 
 
+def test_run_reuses_images_that_come_back(cuda, golden_dir, tmp_path, models):
+    """The refs of an image are not always neighbours in the loader's order: with the same images coming back after other
+    images (the dataset's refs re-ordered round-robin over the images), run() takes proposals, hybrid and GEM features of a
+    returning image from its image cache -- fewer proposal stages, identical rows to the per-ref loop, cache on or off."""
+    from hybridgl_amd import main as drv
+    from hybridgl_amd.pipeline import HybridGLPipeline
+    model, gem, gen = models
+    root = tmp_path / "refer_data"
+    refs = _dataset(root)
+    # re-order: first refs of all images, then second refs, then third refs
+    import pickle
+    by_img = {}
+    for r in refs:
+        by_img.setdefault(r["image_id"], []).append(r)
+    order = [rs[k] for k in range(3) for rs in by_img.values() if k < len(rs)]
+    assert [r["image_id"] for r in order] != [r["image_id"] for r in refs]
+    pickle.dump(order, open(root / "refcoco/refs(unc).p", "wb"))
+    args = _args(root, golden_dir)
+    rr = drv.RealRefs(args, cuda, "unc", 77)
+    mk = lambda **kw: HybridGLPipeline(model, fusion_mode="G2L", masking_block=9, mask_generator=gen, use_sam_masks=True,
+                                       gem_model=gem, **kw)
+    a = mk()
+    for i in rr.jobs():
+        a.step(rr.load(i))
+    b, c = mk(image_cache=32), mk(image_cache=0)
+    for p, g in ((b, 4), (c, 4)):
+        assert p.run((rr.load(i) for i in rr.jobs()), group=g) == len(order)
+    torch.cuda.synchronize()
+    ra, rb, rc = a.partial_rows(), b.partial_rows(), c.partial_rows()
+    assert np.array_equal(ra, rc), (ra[(ra != rc).any(axis=1)][:4].tolist(), rc[(ra != rc).any(axis=1)][:4].tolist())
+    assert np.array_equal(ra, rb), (ra[(ra != rb).any(axis=1)][:4].tolist(), rb[(ra != rb).any(axis=1)][:4].tolist())
+    assert b.cache_hits == len(order) - len(by_img) and c.cache_hits == 0
+
+
 def test_run_skips_images_without_proposals_and_goes_on(cuda, golden_dir, tmp_path, models):
     """An IoU threshold no candidate passes on some images: their refs are counted as skipped (the reference would fail
     at torch.stack([])), the rest of the group is scored; rows equal the per-ref loop's, which skips the same refs."""

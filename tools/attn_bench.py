@@ -47,6 +47,7 @@ def cls_keep(B, H, S, hd, name):
 cls_keep(1024, 12, 197, 64, "clip 1024x12 S197 CLS-keep")
 
 plain(8, 12, 785, 64, "gem 8x12 S785 hd64")
+plain(24, 12, 785, 64, "gem self-self 24x12 S785")      # q-q / k-k / v-v of eight images stacked along the batch
 plain(8, 16, 4096, 80, "sam global 8x16 S4096 hd80")
 plain(96, 8, 77, 64, "text 96x8 S77 hd64 causal", mask="causal")
 # SAM windows through the fused-table entry point (sam_api path): time via the encoder instead
