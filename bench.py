@@ -450,13 +450,13 @@ def main():
         # layer (5 encoder passes, 128 decoder batches, per-crop + cross-crop NMS over 12288 + 4 x 3072 candidates), 8 phrases
         # per image scored against one hybrid forward; at most 256 proposals per image go on (random weights: noise masks)
         from hybridgl_amd.sam import SamAutomaticMaskGenerator
-        gen_pc = SamAutomaticMaskGenerator(sam, points_per_side=64, pred_iou_thresh=-1e30, stability_score_thresh=0.0,
+        gen_pc = SamAutomaticMaskGenerator(sam, points_per_side=64, points_per_batch=512, pred_iou_thresh=-1e30, stability_score_thresh=0.0,
                                            crop_n_layers=1, crop_n_points_downscale_factor=2, min_mask_region_area=100)
         pc_refs = [synthetic_ref(100 + j, dev, N=args.masks, H=480, W=640, n_sent=8, sam_img_size=1024, gem=use_gem,
                                  device_blur=True)[0] for j in range(2)]
         t = timed(make_pipe(g=gen_pc, fusion="G2L&L2G"), n_steps=2, cap=256, pool=pc_refs)
         also["PhraseCut"] = entry(t, 2, "PhraseCut-shaped item: 480x640 image, heavy AMG (64x64 points, 1 crop layer, downscale 2, min "
-                                        "area 100, thresholds open), <= 256 of SAM's masks into CLIP G2L&L2G, 8 phrases x (sentence + noun "
+                                        "area 100, thresholds open, 512 prompts per decoder launch: points_per_batch is a memory knob), <= 256 of SAM's masks into CLIP G2L&L2G, 8 phrases x (sentence + noun "
                                         "phrase + 1 other noun) + 8 GEM prompts")
         also["PhraseCut"]["unit"] = "images/s (8 phrases each)"
         del gen_pc, pc_refs
