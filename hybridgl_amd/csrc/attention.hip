@@ -673,6 +673,258 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
 }
 
 // ---------------------------------------------------------------------------------------------
+// "Two items per CU" variant for sequences of 129..256 tokens without rel-pos / causal mask (the CLIP sequences): ONE
+// 4-wave workgroup per (batch, head) item, a wave owns TWO 32-query tiles (64 queries), so the item's keys and values are
+// staged once (as in the 8-wave kernels) but a CU holds two workgroups = two items whose phases are independent: while one
+// waits for its loads, splits a chunk or stores its output rows, the other multiplies.  (The 8-wave workgroups put both
+// waves of a SIMD on the SAME item: they meet at every chunk barrier and wait for the same loads.)  Arithmetic per
+// (query tile, key tile) is that of attn_x3_kernel, operation for operation.
+template <int HD, int QT>
+__global__ __launch_bounds__(256, 2) void attn_x3q_kernel(AttnArgs a) {
+  constexpr int NW = 4, NT = NW * 64;
+  constexpr int KS = HD / 16;
+  constexpr int KROW = 2 * HD + 8;
+  constexpr int DT = (HD + 31) / 32;
+  constexpr int VP = HD <= 32 ? 32 : 96;
+  constexpr int F4 = HD / 4;
+  constexpr int NLK = (KV_CHUNK * F4 + NT - 1) / NT;
+  static_assert(KV_CHUNK * F4 % NT == 0 && HD % 16 == 0, "unsupported head dim");
+  __shared__ __attribute__((aligned(16))) _Float16 Ks[KV_CHUNK * KROW];
+  __shared__ __attribute__((aligned(16))) _Float16 Vh[KV_CHUNK * VP];
+  __shared__ __attribute__((aligned(16))) _Float16 Vl[KV_CHUNK * VP];
+  __shared__ uint8_t keepL[256];   // keepL[key - 1] = the item's CLS-keep row (make_attn_mask: only query 0 is restricted)
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.x;
+  const int b = bh / a.H, hh = bh - b * a.H;
+  const float* kp = a.k + b * a.skb + hh * HD;
+  const float* vp = a.v + b * a.svb + hh * HD;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float NEG_INF = __int_as_float(NEG_BIG_BITS);
+  float amax = 0.f;
+
+  const uint8_t* keep_row = nullptr;
+  if (a.mask_kind == HGL_MASK_CLS_KEEP && b >= a.keep_b0)
+    keep_row = a.keep + (long long)((b - a.keep_b0) % a.keep_n) * (a.Sk - 1);
+  if (keep_row && t < a.Sk - 1) keepL[t] = keep_row[t];
+
+  // ---- Q fragments of the wave's QT query tiles (pre-scaled in fp32, then split) ----
+  int qi[QT];
+  bool qvalid[QT], tile_active[QT];
+  h16x8 qh[QT][KS], ql[QT][KS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q0 = (wave * QT + qt) * 32;
+    qi[qt] = q0 + r;
+    qvalid[qt] = qi[qt] < a.Sq;
+    tile_active[qt] = q0 < a.Sq;
+    const float* qp = a.q + b * a.sqb + (long long)(qvalid[qt] ? qi[qt] : 0) * a.ldq + hh * HD;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const f32x4 v = qvalid[qt] ? *(const f32x4*)(qp + 16 * s + 8 * h + 4 * half) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 hi, lo;
+          hgl_split_hi_lo(v[e] * a.scale, hi, lo, amax);
+          qh[qt][s][4 * half + e] = hi;
+          ql[qt][s][4 * half + e] = lo;
+        }
+      }
+  }
+  f32x16 o[QT][DT];
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = NEG_INF;
+    l_run[qt] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qt][d][e] = 0.f;
+  }
+
+  // ---- staging (software pipelined through registers) ----
+  f32x4 pk[NLK], pv[NLK];
+  // Rows of a chunk beyond the sequence's last 16-key step are neither fetched nor converted: their scores are masked and
+  // their probabilities never multiplied (the LDS rows keep the finite values of the previous chunk).  The fourth chunk of
+  // a 197-token sequence holds 5 keys: without this a quarter of all staging work went into clamped copies of key 196.
+  const int sk16 = (a.Sk + 15) & ~15;
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NLK; ++i) {
+      const int idx = t + NT * i;
+      const int row = idx / F4, c4 = idx - row * F4;
+      if (kc + row < sk16) {
+        pk[i] = *(const f32x4*)(kp + (long long)min(kc + row, a.Sk - 1) * a.ldk + c4 * 4);
+        pv[i] = *(const f32x4*)(vp + (long long)min(kc + row, a.Sk - 1) * a.ldv + c4 * 4);
+      }
+    }
+  };
+  auto store_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NLK; ++i) {
+      const int idx = t + NT * i;
+      const int row = idx / F4, c4 = idx - row * F4;
+      if (kc + row < sk16) {
+        h16x4 hi, lo;
+        split4(pk[i], hi, lo, amax);
+        *(h16x4*)(Ks + row * KROW + c4 * 4) = hi;
+        *(h16x4*)(Ks + row * KROW + HD + c4 * 4) = lo;
+        split4(pv[i], hi, lo, amax);
+        *(h16x4*)(Vh + row * VP + c4 * 4) = hi;
+        *(h16x4*)(Vl + row * VP + c4 * 4) = lo;
+      }
+    }
+  };
+  if (VP > HD) {
+    constexpr int PADW = VP - HD > 0 ? VP - HD : 1;
+    for (int i = t; i < KV_CHUNK * PADW; i += NT) {
+      const int row = i / PADW, c = i - row * PADW;
+      Vh[row * VP + HD + c] = (_Float16)0.f;
+      Vl[row * VP + HD + c] = (_Float16)0.f;
+    }
+  }
+  const int tr_off = (((lane >> 2) & 3) + 4 * h) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  for (int kc = 0; kc < a.Sk; kc += KV_CHUNK) {
+    const bool has_next = kc + KV_CHUNK < a.Sk;
+    if (has_next) load_chunk(kc + KV_CHUNK);
+#pragma unroll
+    for (int kt = 0; kt < KV_CHUNK / 32; ++kt) {
+      const int kbase = kc + kt * 32;
+      if (kbase >= a.Sk) break;  // uniform
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        if (!tile_active[qt]) continue;   // uniform per wave
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        const _Float16* krow = Ks + (kt * 32 + r) * KROW + 8 * h;
+#pragma unroll
+        for (int c = 0; c < KS; ++c) {
+          const h16x8 kh8 = *(const h16x8*)(krow + 16 * c);
+          const h16x8 kl8 = *(const h16x8*)(krow + HD + 16 * c);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[qt][c], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, ql[qt][c], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh[qt][c], s, 0, 0, 0);
+        }
+        if (kbase + 32 > a.Sk) {   // uniform: the tile that crosses the end of the sequence
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+            s[e] = kg >= a.Sk ? NEG_INF : s[e];
+          }
+        }
+        if (keep_row && wave == 0 && qt == 0) {   // uniform: the wave and tile that own query 0 of a CLS-keep batch
+          const int kk = kbase + (lane & 31);
+          const unsigned kb = kk >= 1 && kk < a.Sk ? keepL[kk - 1] : 1u;
+          const unsigned bits = (unsigned)__builtin_amdgcn_ballot_w64(kb != 0) >> (4 * h);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const bool kept = (bits >> ((e & 3) + 8 * (e >> 2))) & 1u;
+            s[e] = (qi[0] == 0 && !kept) ? NEG_INF : s[e];
+          }
+        }
+        float mx = NEG_INF;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_cand = fmaxf(m_run[qt], mx);
+        float m_new = m_run[qt];
+        if (__builtin_amdgcn_ballot_w64(m_cand > m_run[qt] + 5.5f)) {   // lazy rescaling (attn_x3_kernel)
+          m_new = m_cand;
+          const float m_use0 = (m_new == NEG_INF) ? 0.f : m_new;
+          const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_use0) * LOG2E);
+          l_run[qt] *= alpha;
+#pragma unroll
+          for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[qt][d][e] *= alpha;
+          m_run[qt] = m_new;
+        }
+        const float mneg = -((m_new == NEG_INF) ? 0.f : m_new) * LOG2E;
+        float rs = 0.f;
+        h16x8 ph[2], pl[2];
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(fmaf(s[e], LOG2E, mneg));
+          const float p1 = __builtin_amdgcn_exp2f(fmaf(s[e + 1], LOG2E, mneg));
+          rs += p0;
+          rs += p1;
+          const h16x2 hi2 = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+          ph[e >> 3][e & 7] = hi2[0]; ph[e >> 3][(e & 7) + 1] = hi2[1];
+          pl[e >> 3][e & 7] = (_Float16)(p0 - (float)hi2[0]);
+          pl[e >> 3][(e & 7) + 1] = (_Float16)(p1 - (float)hi2[1]);
+        }
+        l_run[qt] += rs;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          if (kbase + 16 * s2 >= a.Sk) break;   // uniform
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const int off = (kt * 32 + 16 * s2) * VP + d * 32 + tr_off;
+            const h16x4 vh0 = lds_tr4(Vh + off), vh1 = lds_tr4(Vh + off + 8 * VP);
+            const h16x4 vl0 = lds_tr4(Vl + off), vl1 = lds_tr4(Vl + off + 8 * VP);
+            h16x8 vh8, vl8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vh8[e] = vh0[e]; vh8[4 + e] = vh1[e]; vl8[e] = vl0[e]; vl8[4 + e] = vl1[e]; }
+            o[qt][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph[s2], o[qt][d], 0, 0, 0);
+            o[qt][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl[s2], o[qt][d], 0, 0, 0);
+            o[qt][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph[s2], o[qt][d], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (has_next) {
+      store_chunk(kc + KV_CHUNK);
+      __syncthreads();
+    }
+  }
+
+  hgl_split_commit(amax);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qvalid[qt]) {
+      const long long oo = b * a.sob + (long long)qi[qt] * a.ldo + hh * HD;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = d * 32 + 8 * g + 4 * h;
+          if (dd < HD) {
+            f32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = o[qt][d][4 * g + e] * inv;
+            if (a.out) {
+              *(f32x4*)(a.out + oo + dd) = w;
+            } else {
+              h16x4 hi, lo;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                _Float16 a2, c2;
+                hgl_split_hi_lo(w[e], a2, c2);
+                hi[e] = a2;
+                lo[e] = c2;
+              }
+              *(h16x4*)(a.out_hi + oo + dd) = hi;
+              *(h16x4*)(a.out_lo + oo + dd) = lo;
+            }
+          }
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Wide, PERSISTENT variant for sequences of 129..256 queries (a 14 x 14 window of the SAM encoder, a 197-token CLIP
 // sequence): one 8-wave workgroup per CU walks the (batch, head) items.  In-kernel cycle stamps of the one-item-per-
 // workgroup form (1 workgroup per CU: nothing else hides its latencies) showed 28 % of an item's 38k cycles spent BEFORE
@@ -1330,6 +1582,7 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
   if (hgl_precision() == HGL_PREC_F16X3) {
     // sequences of 129..256 queries (a 14 x 14 window, a 197-token CLIP sequence): one 8-wave workgroup per (batch, head)
     static const int wide = getenv("HGL_ATTN_WIDE") ? atoi(getenv("HGL_ATTN_WIDE")) : 1;
+    static const int dual = getenv("HGL_ATTN_DUAL") ? atoi(getenv("HGL_ATTN_DUAL")) : 1;
     // (longer sequences measured neutral for 785 queries, slower for the 4096-query global blocks: two independent
     // 4-wave workgroups per CU interleave their phases, one 8-wave workgroup meets at every barrier)
     // the persistent kernel parks the CLS-keep row of an item in a 256-byte LDS tail: keys beyond 257 do not fit there
@@ -1337,6 +1590,11 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
                     (a.mask_kind != HGL_MASK_CLS_KEEP || a.Sk <= 257);
     if (HD == 80 && a.rel_h && a.kh == 14 && a.kw == 14 && a.Sk == 196 && a.mask_kind == HGL_MASK_NONE) {
       hipLaunchKernelGGL((attn_x3_kernel<HD, HD == 80 ? 14 : 0>), grid, dim3(256), 0, st, a);   // rel_h / rel_w given as tensors
+    } else if (w8 && !a.rel_h && dual && HD == 64 && (a.mask_kind != HGL_MASK_CLS_KEEP || a.Sk <= 257)) {
+      // head dim 64 (the CLIP sequences): two items per CU -- one 4-wave workgroup per item, two query tiles per wave.
+      // 868 against 976 us on 1024 x 12 x 197 x 64 (141 against 125 TF/s), -0.4 ms per benchmark step (HGL_ATTN_DUAL=0: the
+      // persistent 8-wave kernel)
+      hipLaunchKernelGGL((attn_x3q_kernel<HD == 64 ? 64 : 16, 2>), dim3((unsigned)(a.B * a.H)), dim3(256), 0, st, a);
     } else if (w8 && !a.rel_h && wide == 2) {   // A/B: the one-item-per-workgroup wide kernel
       hipLaunchKernelGGL((attn_x3_kernel<HD, 0, 8>), dim3((a.Sq + 255) / 256, a.B * a.H), dim3(512), 0, st, a);
     } else if (w8 && !a.rel_h) {
