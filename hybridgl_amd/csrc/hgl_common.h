@@ -50,7 +50,6 @@ __device__ __forceinline__ void hgl_split_commit(float amax) {
     }                                                                                                 \
     return v;                                                                                         \
   }
-#endif
 // ---- activations of the GEMM epilogues ------------------------------------------------------------------------------
 // nn.GELU (erf form; segment_anything/modeling/common.py:13-24 MLPBlock, mask_decoder.py:76-80): 0.5 x (1 + erf(x / sqrt 2)).
 // The library erff costs ~40 VALU instructions (branches on |x|); in a GEMM write-out -- where the matrix pipe of that
@@ -76,6 +75,7 @@ __device__ __forceinline__ float hgl_gelu_erf(float x) {
 __device__ __forceinline__ float hgl_quick_gelu(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
 }
+#endif  // __HIPCC__ (device helpers: the host-only sources of the library include this header too)
 
 unsigned long long hgl_split_overflow_gemm(int reset);
 unsigned long long hgl_split_overflow_attention(int reset);
