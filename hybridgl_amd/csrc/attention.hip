@@ -1555,6 +1555,164 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(FewQArgs a) {
   }
 }
 
+// Few queries over many keys, chunked (the decoder's token -> image attention at its real size: 64..512 prompts x 4096 image
+// tokens, 8 heads of 16; transformer.py:126-131).  attn_fewq_kernel keeps the state of all queries (7 x 18 floats) per thread,
+// runs 8 waves per CU and reads 64-byte pieces at the row stride: 140 us for 268 MB (1.9 TB/s).  Here
+//   * a workgroup owns 256 consecutive keys of one prompt and ALL heads: the 16 lanes (head, channel half) of a key read its
+//     512-byte K row and V row contiguously;
+//   * a lane owns 8 of a head's 16 channels (the two halves of a score meet through one DPP add): 7 x 10 floats of state,
+//     ~110 registers, 16 waves per CU, the next key's 64 bytes in flight while the current one is multiplied;
+//   * exponentials in base 2 (log2 e folded into the query scale): one v_exp_f32 each;
+//   * the (max, sum, output) partials of a workgroup go to `part`; attn_fewq_combine_kernel merges the chunks of a prompt.
+constexpr int FQC_KEYS = 256;                 // keys per workgroup
+constexpr int FQC_QS = 7 * 16 + 4;            // floats between the heads of the query block in LDS (distinct bank groups)
+constexpr int FQC_PART = 10;                  // floats of a partial: 8 channels, max, sum
+
+__global__ __launch_bounds__(256, 4) void attn_fewq_chunk_kernel(FewQArgs a, float* __restrict__ part) {
+  constexpr int NQ = 7;
+  __shared__ __attribute__((aligned(16))) float q_s[8 * FQC_QS];
+  __shared__ __attribute__((aligned(16))) float mrg[4][16][NQ][FQC_PART + 2];
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l16 = t & 15, c2 = t & 1, hh = (t >> 1) & 7, ks = t >> 4;
+  constexpr float LOG2E = 1.4426950408889634f;
+  for (int i = t; i < 8 * NQ * 16; i += 256) {
+    const int head = i / (NQ * 16), rem = i - head * (NQ * 16), qi = rem >> 4, d = rem & 15;
+    q_s[head * FQC_QS + rem] = qi < a.Sq ? a.q[b * a.sqb + (long long)qi * a.ldq + head * 16 + d] * (a.scale * LOG2E) : 0.f;
+  }
+  __syncthreads();
+  float m[NQ], l[NQ];
+  f32x4 o[NQ][2];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    m[qi] = -3.0e38f; l[qi] = 0.f;
+    o[qi][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    o[qi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float* kp = a.k + b * a.skb + hh * 16 + c2 * 8;
+  const float* vp = a.v + b * a.svb + hh * 16 + c2 * 8;
+  const float* qs = q_s + hh * FQC_QS + c2 * 8;
+  const int k0 = chunk * FQC_KEYS + ks;
+  f32x4 kn[2], vn[2];
+  {
+    const int key = k0 < a.Sk ? k0 : a.Sk - 1;
+    kn[0] = *(const f32x4*)(kp + (long long)key * a.ldk); kn[1] = *(const f32x4*)(kp + (long long)key * a.ldk + 4);
+    vn[0] = *(const f32x4*)(vp + (long long)key * a.ldv); vn[1] = *(const f32x4*)(vp + (long long)key * a.ldv + 4);
+  }
+#pragma unroll 2
+  for (int pass = 0; pass < FQC_KEYS / 16; ++pass) {
+    const int key = k0 + 16 * pass;
+    const f32x4 kk0 = kn[0], kk1 = kn[1], vv0 = vn[0], vv1 = vn[1];
+    {
+      const int nk = key + 16 < a.Sk ? key + 16 : a.Sk - 1;
+      kn[0] = *(const f32x4*)(kp + (long long)nk * a.ldk); kn[1] = *(const f32x4*)(kp + (long long)nk * a.ldk + 4);
+      vn[0] = *(const f32x4*)(vp + (long long)nk * a.ldv); vn[1] = *(const f32x4*)(vp + (long long)nk * a.ldv + 4);
+    }
+    if (key < a.Sk) {
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        const f32x4 q0 = *(const f32x4*)(qs + qi * 16), q1 = *(const f32x4*)(qs + qi * 16 + 4);
+        float s = q0[0] * kk0[0];
+        s = fmaf(q0[1], kk0[1], s); s = fmaf(q0[2], kk0[2], s); s = fmaf(q0[3], kk0[3], s);
+        s = fmaf(q1[0], kk1[0], s); s = fmaf(q1[1], kk1[1], s); s = fmaf(q1[2], kk1[2], s); s = fmaf(q1[3], kk1[3], s);
+        s += __shfl_xor(s, 1);                      // the other half of the head's 16 channels
+        const float mn = fmaxf(m[qi], s);
+        const float al = __builtin_amdgcn_exp2f(m[qi] - mn), p = __builtin_amdgcn_exp2f(s - mn);
+        l[qi] = fmaf(l[qi], al, p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[qi][0][e] = fmaf(o[qi][0][e], al, p * vv0[e]);
+          o[qi][1][e] = fmaf(o[qi][1][e], al, p * vv1[e]);
+        }
+        m[qi] = mn;
+      }
+    }
+  }
+  // merge the four keys a wave holds per (head, half) (lanes 16 and 32 apart), then the four waves through LDS
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      const float m2 = __shfl_xor(m[qi], off), l2 = __shfl_xor(l[qi], off);
+      const float mn = fmaxf(m[qi], m2);
+      const float a1 = __builtin_amdgcn_exp2f(m[qi] - mn), a2 = __builtin_amdgcn_exp2f(m2 - mn);
+      l[qi] = l[qi] * a1 + l2 * a2;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[qi][c][e] = o[qi][c][e] * a1 + __shfl_xor(o[qi][c][e], off) * a2;
+      m[qi] = mn;
+    }
+    if (lane < 16) {
+      float* d = mrg[wave][l16][qi];
+      *(f32x4*)d = o[qi][0];
+      *(f32x4*)(d + 4) = o[qi][1];
+      d[8] = m[qi];
+      d[9] = l[qi];
+    }
+  }
+  __syncthreads();
+  if (t < 16 * NQ) {
+    const int ll = t / NQ, qi = t - ll * NQ;
+    float mm = mrg[0][ll][qi][8];
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) mm = fmaxf(mm, mrg[w2][ll][qi][8]);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const float sc = __builtin_amdgcn_exp2f(mrg[w2][ll][qi][8] - mm);
+      lsum += mrg[w2][ll][qi][9] * sc;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) acc[d] += mrg[w2][ll][qi][d] * sc;
+    }
+    float* dst = part + ((((long long)b * nchunk + chunk) * 16 + ll) * NQ + qi) * FQC_PART;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) dst[d] = acc[d];
+    dst[8] = mm;
+    dst[9] = lsum;
+  }
+}
+
+// out[b, q, head * 16 + half * 8 + d] = sum_c o_c 2^(m_c - M) / sum_c l_c 2^(m_c - M) over the chunks of prompt b: one thread
+// per output element, the chunk partials fetched sixteen at a time (independent loads: one round trip, not 2 x nchunk)
+__global__ __launch_bounds__(128) void attn_fewq_combine_kernel(const float* __restrict__ part, int nchunk, int Sq, float* __restrict__ out,
+                                                                 int ldo, long long sob) {
+  constexpr int NQ = 7;
+  const int b = blockIdx.y, i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= 16 * NQ * 8) return;
+  const int d = i & 7, qi = (i >> 3) % NQ, ll = i / (8 * NQ);
+  if (qi >= Sq) return;
+  const float* src = part + (((long long)b * nchunk * 16 + ll) * NQ + qi) * FQC_PART;
+  const long long cs = (long long)16 * NQ * FQC_PART;
+  float mm = -3.0e38f, lsum = 0.f, acc = 0.f;
+  for (int c0 = 0; c0 < nchunk; c0 += 16) {
+    float mc[16], lc[16], oc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const bool in = c0 + c < nchunk;
+      const float* s = src + (in ? c0 + c : c0) * cs;
+      mc[c] = in ? s[8] : -3.0e38f;
+      lc[c] = in ? s[9] : 0.f;
+      oc[c] = in ? s[d] : 0.f;
+    }
+    float mn = mm;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) mn = fmaxf(mn, mc[c]);
+    const float a0 = __builtin_amdgcn_exp2f(mm - mn);
+    lsum *= a0;
+    acc *= a0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float sc = __builtin_amdgcn_exp2f(mc[c] - mn);
+      lsum += lc[c] * sc;
+      acc += oc[c] * sc;
+    }
+    mm = mn;
+  }
+  out[b * sob + (long long)qi * ldo + ll * 8 + d] = acc / lsum;
+}
+
 // persistent wide kernel: one workgroup per CU (its two K/V buffers take 84-100 KiB of LDS)
 template <int HD, int RELW>
 void launch_wide(const AttnArgs& a, hipStream_t st) {
@@ -1677,6 +1835,30 @@ int hgl_launch_attention_fewq(const float* q, const float* k, const float* v, fl
   HglProfScope prof(HGL_PROF_ATTN, 4.0 * B * (double)H * Sq * Sk * hd, 0.0, st);
   hipLaunchKernelGGL(attn_fewq_kernel, dim3((unsigned)(B * H)), dim3(256), 0, st, a);
   return hgl_check_launch("attention_fewq");
+}
+
+// chunked form for the decoder's sizes (8 heads of 16, up to 7 queries): `part` >= hgl_attention_fewq_part_bytes(B, Sk) bytes
+size_t hgl_attention_fewq_part_bytes(int B, int Sk) {
+  return (size_t)B * ((Sk + FQC_KEYS - 1) / FQC_KEYS) * 16 * 7 * FQC_PART * sizeof(float);
+}
+
+int hgl_launch_attention_fewq_chunked(const float* q, const float* k, const float* v, float* out, int B, int H, int Sq, int Sk,
+                                      int hd, int ldq, int ldk, int ldv, int ldo, long long sqb, long long skb, long long svb,
+                                      long long sob, float scale, float* part, size_t part_bytes, hipStream_t st) {
+  HGL_REQUIRE(q && k && v && out && part, "attention_fewq_chunked: null operand");
+  HGL_REQUIRE(hd == 16 && H == 8 && Sq >= 1 && Sq <= 7 && Sk >= 1 && B >= 1 && B <= 65535,
+              "attention_fewq_chunked: unsupported shape (hd %d, H %d, Sq %d)", hd, H, Sq);
+  HGL_REQUIRE(((ldk | ldv) & 3) == 0 && ((skb | svb) & 3) == 0 && (((uintptr_t)k | (uintptr_t)v) & 15) == 0,
+              "attention_fewq_chunked: K/V strides must be multiples of 4");
+  HGL_REQUIRE(part_bytes >= hgl_attention_fewq_part_bytes(B, Sk), "attention_fewq_chunked: partial buffer too small");
+  FewQArgs a;
+  a.q = q; a.k = k; a.v = v; a.out = out; a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.sqb = sqb; a.skb = skb; a.svb = svb; a.sob = sob; a.scale = scale;
+  const int nchunk = (Sk + FQC_KEYS - 1) / FQC_KEYS;
+  HglProfScope prof(HGL_PROF_ATTN, 4.0 * B * (double)H * Sq * Sk * hd, 0.0, st);
+  hipLaunchKernelGGL(attn_fewq_chunk_kernel, dim3((unsigned)nchunk, (unsigned)B), dim3(256), 0, st, a, part);
+  hipLaunchKernelGGL(attn_fewq_combine_kernel, dim3(7, (unsigned)B), dim3(128), 0, st, (const float*)part, nchunk, Sq, out, ldo, sob);
+  return hgl_check_launch("attention_fewq_chunked");
 }
 
 int hgl_launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H,

@@ -1101,7 +1101,10 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
   }
   // the LDS-DMA kernel addresses the operands with 32-bit byte offsets from the plane bases and writes 16-byte vectors
   const bool small_offsets = (double)M * lda * (amap ? 4.0 : 2.0) < 4.0e9 && (double)N * K * 2.0 < 4.0e9;   // gathered rows: <= 2M
-  int kind = g_x3_kernel >= 0 ? g_x3_kernel : pick_x3_kernel(M, N, K, R != nullptr);
+  // a row-modulo residual (positional table) of a few MB stays in L2: it does not cost what a streamed residual costs
+  // (decoder k|v|q projection, 262144 x 384 x 256 with a 6 MB table: ping-pong 233 us, register-staged 308 -- the model said 346 / 302)
+  const bool streamed_r = R != nullptr && (rmod == 0 || (double)rmod * N * 4.0 > 8.0e6);
+  int kind = g_x3_kernel >= 0 ? g_x3_kernel : pick_x3_kernel(M, N, K, streamed_r);
   if (!small_offsets || !g.vec4) kind = HGL_X3_V1;
   // launches that cannot fill the 256 CUs once (GEM at 785 rows, text encoder: a 128x128 tile per CU is latency-bound
   // when run alone) are accounted separately from the throughput-bound ones
@@ -1117,8 +1120,8 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
 }
 
 // fp32-A entry for small M (called from hgl_launch_gemm): true when the GEMM was taken
-bool hgl_gemm_skinny_applicable(const float* W32, int M, int N, int K, int lda, int ldw, int batch) {
-  if (g_precision != HGL_PREC_F16X3 || batch != 1 || M > 1024 || (K & 15) || (lda & 3) || ldw != K) return false;
+bool hgl_gemm_skinny_applicable(const float* W32, int M, int N, int K, int lda, int ldw, int batch, int max_m) {
+  if (g_precision != HGL_PREC_F16X3 || batch != 1 || M > max_m || (K & 15) || (lda & 3) || ldw != K) return false;
   SplitW sw;
   return find_split((const void*)W32, &sw) && sw.N == N && sw.K == K;
 }

@@ -136,6 +136,10 @@ int hgl_launch_attention_win14(const float* q, const float* k, const float* v, v
 int hgl_launch_attention_smallk(const float* q, const float* k, const float* v, float* out, void* out_hi, void* out_lo,
                                 int B, int H, int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
                                 long long skb, long long svb, long long sob, float scale, hipStream_t st);
+size_t hgl_attention_fewq_part_bytes(int B, int Sk);
+int hgl_launch_attention_fewq_chunked(const float* q, const float* k, const float* v, float* out, int B, int H, int Sq, int Sk,
+                                      int hd, int ldq, int ldk, int ldv, int ldo, long long sqb, long long skb, long long svb,
+                                      long long sob, float scale, float* part, size_t part_bytes, hipStream_t st);
 int hgl_launch_attention(const float* q, const float* k, const float* v, float* out, int B, int H,
                          int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
                          long long skb, long long svb, long long sob, float scale, int mask_kind,
@@ -212,6 +216,9 @@ int hgl_launch_hyper_logits(const float* u2, const float* hyper, int P, int g, f
 int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0_w, const float* up0_b, const float* ln_w,
                         const float* ln_b, const float* up3_w, const float* up3_b, const float* hyper, int P, int g, float eps,
                         float* low_res, hipStream_t st);
+int hgl_launch_dec_i2t(const float* q, int ldq, long long q_bstride, const float* k1, const float* v1, const float* out_w,
+                       const float* out_b, const float* R, long long r_bstride, const float* ln_w, const float* ln_b, float eps,
+                       float scale, int P, int HW, float* out32, void* out_hi, void* out_lo, hipStream_t st);
 
 // split-fp16 GEMM path (gemm_f16x3.hip)
 int hgl_precision();
@@ -221,7 +228,7 @@ int hgl_launch_layernorm_split(const float* x, const float* w, const float* b, v
                                float eps, hipStream_t st);
 int hgl_launch_layernorm_split_maps(const float* x, const float* w, const float* b, void* hi, void* lo, int rows, int D,
                                     float eps, const int* smap, const int* dmap, hipStream_t st);
-bool hgl_gemm_skinny_applicable(const float* W32, int M, int N, int K, int lda, int ldw, int batch);
+bool hgl_gemm_skinny_applicable(const float* W32, int M, int N, int K, int lda, int ldw, int batch, int max_m = 1024);
 int hgl_launch_gemm_x3_skinny(const float* A, int lda, const float* W32, const float* bias, const float* R, int ldr,
                               float* C, int ldc, int M, int N, int K, int act, hipStream_t st);
 int hgl_gemm_f16x3_splitk_factor(int M, int N, int K);

@@ -263,27 +263,54 @@ bool valid_dec(const HglSamDecoderW* w) {
 
 inline int lin(const float* A, int lda, const HglLinearW& l, const float* R, int ldr, float* Cc, int ldc, int M,
                int N, int K, int act, hipStream_t st) {
+  // the token side of a large prompt batch (512 prompts: 3584 rows) and the image-side projections shared by all prompts
+  // (4096 rows) are still small-tile work: 8 x 116 workgroups of 32 x 32 instead of the fp32 kernel (35 -> 12 us each,
+  // 23 launches per decoder call)
+  if (M > 1024 && hgl_gemm_skinny_applicable(l.w, M, N, K, lda, K, 1, 8192))
+    return hgl_launch_gemm_x3_skinny(A, lda, l.w, l.b, R, ldr, Cc, ldc, M, N, K, act, st);
   return hgl_launch_gemm(A, l.w, l.b, R, Cc, M, N, K, lda, K, ldr, ldc, 1, 0, 0, 0, 0, act, st);
+}
+
+// which fused decoder stages are in use (bit 0: upscaling + hyper-network products, bit 1: merged image-side projections,
+// bit 2: image -> token attention + out-projection + norm4, bit 3: unused, bit 4: chunked token -> image attention);
+// default from HGL_SAM_DEC_FUSED
+int g_dec_fusion = -1;
+int dec_fusion_mask() {
+  if (g_dec_fusion < 0) { const char* v = getenv("HGL_SAM_DEC_FUSED"); g_dec_fusion = v ? atoi(v) : 0x7fffffff; }
+  return g_dec_fusion;
+}
+
+// token -> image attention (7 queries, thousands of keys): the chunked kernel when the shape fits (fusion bit 4), with the
+// partials in `scratch` (the image -> token buffer, idle at that point)
+int dec_fewq(const float* q, const float* k, const float* v, float* att, int B, int heads, int Nq, int Nk, int hd, int ldq,
+             int ldk, int ldv, int ldo, long long sqb, long long skb, long long svb, long long sob, float* scratch,
+             size_t scratch_bytes, hipStream_t st) {
+  const float scale = 1.0f / sqrtf((float)hd);
+  if ((dec_fusion_mask() & 16) && scratch && heads == 8 && hd == 16 && Nq <= 7 && Nk >= 256 && B <= 65535 &&
+      scratch_bytes >= hgl_attention_fewq_part_bytes(B, Nk))
+    return hgl_launch_attention_fewq_chunked(q, k, v, att, B, heads, Nq, Nk, hd, ldq, ldk, ldv, ldo, sqb, skb, svb, sob, scale,
+                                             scratch, scratch_bytes, st);
+  return hgl_launch_attention(q, k, v, att, B, heads, Nq, Nk, hd, ldq, ldk, ldv, ldo, sqb, skb, svb, sob, scale, HGL_MASK_NONE,
+                              nullptr, 0, 0, nullptr, nullptr, 0, 0, st);
 }
 
 // Attention.forward (modeling/transformer.py:218-240).  q: [Bq? , Nq, C] rows; when q_shared the same
 // Nq rows serve every batch (batch stride 0).  out: [B, Nq, C] (+ residual R, may alias out).
 int dec_attn(const HglSamDecoderW* w, const HglSamAttnW& a, const float* q, bool q_shared, int Nq, const float* k,
              const float* v, bool kv_shared, int Nk, int B, float* qp, float* kp, float* vp, float* att,
-             const float* R, long long sR, float* out, hipStream_t st) {
+             const float* R, long long sR, float* out, hipStream_t st, float* scratch = nullptr, size_t scratch_bytes = 0) {
   const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads;
   const int Bq = q_shared ? 1 : B, Bk = kv_shared ? 1 : B;
   HGL_TRY(lin(q, C, a.q, nullptr, 0, qp, I, Bq * Nq, I, C, HGL_ACT_NONE, st));
   HGL_TRY(lin(k, C, a.k, nullptr, 0, kp, I, Bk * Nk, I, C, HGL_ACT_NONE, st));
   HGL_TRY(lin(v, C, a.v, nullptr, 0, vp, I, Bk * Nk, I, C, HGL_ACT_NONE, st));
-  HGL_TRY(hgl_launch_attention(qp, kp, vp, att, B, heads, Nq, Nk, hd, I, I, I, I, q_shared ? 0 : (long long)Nq * I,
-                               kv_shared ? 0 : (long long)Nk * I, kv_shared ? 0 : (long long)Nk * I,
-                               (long long)Nq * I, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, nullptr,
-                               nullptr, 0, 0, st));
+  HGL_TRY(dec_fewq(qp, kp, vp, att, B, heads, Nq, Nk, hd, I, I, I, I, q_shared ? 0 : (long long)Nq * I,
+                   kv_shared ? 0 : (long long)Nk * I, kv_shared ? 0 : (long long)Nk * I, (long long)Nq * I, scratch,
+                   scratch_bytes, st));
   // out_proj (+ residual): one GEMM over all B*Nq rows when the residual is laid out like the output (small row
   // counts then take the small-tile kernel); batched when a shared residual (stride 0) has to be broadcast
   if (!R || sR == (long long)Nq * C)
-    return hgl_launch_gemm(att, a.out.w, a.out.b, R, out, B * Nq, C, I, I, I, C, C, 1, 0, 0, 0, 0, HGL_ACT_NONE, st);
+    return lin(att, I, a.out, R, C, out, C, B * Nq, C, I, HGL_ACT_NONE, st);
   return hgl_launch_gemm(att, a.out.w, a.out.b, R, out, Nq, C, I, I, I, C, C, B, (long long)Nq * I, 0, sR,
                          (long long)Nq * C, HGL_ACT_NONE, st);
 }
@@ -294,13 +321,6 @@ int dec_attn(const HglSamDecoderW* w, const HglSamAttnW& a, const float* q, bool
 // GEMM below reads split operands and nothing is converted in a separate pass.
 struct SplitPair { uint16_t *hi, *lo; };
 inline SplitPair split_view(float* buf, size_t elems) { return SplitPair{(uint16_t*)buf, (uint16_t*)buf + elems}; }
-
-// which fused decoder stages are in use (bit 0: upscaling + hyper-network products); default from HGL_SAM_DEC_FUSED
-int g_dec_fusion = -1;
-int dec_fusion_mask() {
-  if (g_dec_fusion < 0) { const char* v = getenv("HGL_SAM_DEC_FUSED"); g_dec_fusion = v ? atoi(v) : 0x7fffffff; }
-  return g_dec_fusion;
-}
 
 bool dec_x3_ready(const HglSamDecoderW* w) {
   if (hgl_precision() != HGL_PREC_F16X3 || w->C != 256) return false;
@@ -334,17 +354,17 @@ int dec_i2t_x3(const HglSamDecoderW* w, const HglSamAttnW& a, bool shared, const
 
 // token -> image attention with per-prompt image tokens (transformer.py:126-131): K/V projections read the split planes
 int dec_t2i_x3(const HglSamDecoderW* w, const HglSamAttnW& a, const float* qpe, const SplitPair& kpeS, const SplitPair& keysS,
-               int P, int HW, float* q1, float* kp, float* vp, float* att, float* queries, hipStream_t st) {
+               int P, int HW, float* q1, float* kp, float* vp, float* att, float* queries, float* scratch, size_t scratch_bytes,
+               hipStream_t st) {
   const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads, T = 7;
   HGL_TRY(lin(qpe, C, a.q, nullptr, 0, q1, I, P * T, I, C, HGL_ACT_NONE, st));
   HGL_TRY(hgl_launch_gemm_f16x3(kpeS.hi, kpeS.lo, C, a.k.w, a.k.b, nullptr, 0, kp, nullptr, nullptr, I, P * HW, I, C,
                                 HGL_ACT_NONE, st));
   HGL_TRY(hgl_launch_gemm_f16x3(keysS.hi, keysS.lo, C, a.v.w, a.v.b, nullptr, 0, vp, nullptr, nullptr, I, P * HW, I, C,
                                 HGL_ACT_NONE, st));
-  HGL_TRY(hgl_launch_attention(q1, kp, vp, att, P, heads, T, HW, hd, I, I, I, I, (long long)T * I, (long long)HW * I,
-                               (long long)HW * I, (long long)T * I, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0,
-                               nullptr, nullptr, 0, 0, st));
-  return hgl_launch_gemm(att, a.out.w, a.out.b, queries, queries, P * T, C, I, I, I, C, C, 1, 0, 0, 0, 0, HGL_ACT_NONE, st);
+  HGL_TRY(dec_fewq(q1, kp, vp, att, P, heads, T, HW, hd, I, I, I, I, (long long)T * I, (long long)HW * I, (long long)HW * I,
+                   (long long)T * I, scratch, scratch_bytes, st));
+  return lin(att, I, a.out, queries, C, queries, C, P * T, C, I, HGL_ACT_NONE, st);
 }
 
 // ---- merged image-side projections (HglSamDecoderW.kvq1 / kvf) ------------------------------------------------------
@@ -362,13 +382,12 @@ int dec_project_merged(const SplitPair& keysS, const float* W, const float* b, c
 
 // token -> image attention on merged projections: k = kvq[:, 0:I], v = kvq[:, I:2I], row stride ld
 int dec_t2i_merged(const HglSamDecoderW* w, const HglSamAttnW& a, const float* qpe, const float* kvq, int ld, int P, int HW,
-                   float* q1, float* att, float* queries, hipStream_t st) {
+                   float* q1, float* att, float* queries, float* scratch, size_t scratch_bytes, hipStream_t st) {
   const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads, T = 7;
   HGL_TRY(lin(qpe, C, a.q, nullptr, 0, q1, I, P * T, I, C, HGL_ACT_NONE, st));
-  HGL_TRY(hgl_launch_attention(q1, kvq, kvq + I, att, P, heads, T, HW, hd, I, ld, ld, I, (long long)T * I, (long long)HW * ld,
-                               (long long)HW * ld, (long long)T * I, 1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0,
-                               nullptr, nullptr, 0, 0, st));
-  return hgl_launch_gemm(att, a.out.w, a.out.b, queries, queries, P * T, C, I, I, I, C, C, 1, 0, 0, 0, 0, HGL_ACT_NONE, st);
+  HGL_TRY(dec_fewq(q1, kvq, kvq + I, att, P, heads, T, HW, hd, I, ld, ld, I, (long long)T * I, (long long)HW * ld,
+                   (long long)HW * ld, (long long)T * I, scratch, scratch_bytes, st));
+  return lin(att, I, a.out, queries, C, queries, C, P * T, C, I, HGL_ACT_NONE, st);
 }
 
 // image -> token attention on merged projections: q = kvq[:, 2I:3I]
@@ -510,6 +529,7 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
   hipStream_t st = (hipStream_t)stream;
   const int C = w->C, g = w->grid, HW = g * g, T = 7;
   const long long sQ = (long long)T * C, sK = (long long)HW * C;
+  const size_t atti_bytes = (size_t)P * HW * (C / 2) * sizeof(float);
 
   // ---- prompt encoder + token assembly ----
   HGL_TRY(hgl_launch_pe(points01, w->pe_gauss, 2 * P, C / 2, 1, w->point_embed_pos, w->not_a_point, p.sparse, st));
@@ -545,12 +565,12 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
     if (merged && !shared) {
       // k, v of this step and q of step (4) read the same rows: one GEMM, the positional encoding as a per-position table
       HGL_TRY(dec_project_merged(keysS, w->kvq1_w, w->kvq1_b, w->kvq1_pe, P, HW, C, 3 * I1, p.kp, st));
-      HGL_TRY(dec_t2i_merged(w, L.t2i, p.qpe, p.kp, 3 * I1, P, HW, p.q1, p.att, p.queries, st));
+      HGL_TRY(dec_t2i_merged(w, L.t2i, p.qpe, p.kp, 3 * I1, P, HW, p.q1, p.att, p.queries, p.atti, atti_bytes, st));
     } else if (x3 && !shared) {
-      HGL_TRY(dec_t2i_x3(w, L.t2i, p.qpe, kpeS, keysS, P, HW, p.q1, p.kp, p.vp, p.att, p.queries, st));
+      HGL_TRY(dec_t2i_x3(w, L.t2i, p.qpe, kpeS, keysS, P, HW, p.q1, p.kp, p.vp, p.att, p.queries, p.atti, atti_bytes, st));
     } else {
       HGL_TRY(dec_attn(w, L.t2i, p.qpe, false, T, kpe, keys, shared, HW, P, p.q1, p.kp, p.vp, p.att, p.queries, sQ,
-                       p.queries, st));
+                       p.queries, st, p.atti, atti_bytes));
     }
     HGL_TRY(hgl_launch_layernorm(p.queries, L.n2.w, L.n2.b, p.queries, P * T, C, 1e-5f, st));
     // (3) MLP on the tokens
@@ -559,7 +579,18 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
     HGL_TRY(hgl_launch_layernorm(p.queries, L.n3.w, L.n3.b, p.queries, P * T, C, 1e-5f, st));
     // (4) image attends to the tokens: q = keys+pe, k = queries+pe, v = queries ; keys += out
     HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
-    if (x3) {
+    const bool fuse_i2t = merged && (dec_fusion_mask() & 4) && L.i2t.internal == I1 && I1 == 128 && w->heads == 8 &&
+                          HW % 64 == 0 && P <= 65535;
+    if (fuse_i2t) {
+      // attention over the 7 tokens, out-projection, residual and norm4 in one launch: the image tokens leave it as the
+      // split planes the next projections read (and, in layer 0, as the fp32 rows layer 1 adds its update to)
+      HGL_TRY(lin(p.qpe, C, L.i2t.k, nullptr, 0, p.k1, I1, P * T, I1, C, HGL_ACT_NONE, st));
+      HGL_TRY(lin(p.queries, C, L.i2t.v, nullptr, 0, p.v1, I1, P * T, I1, C, HGL_ACT_NONE, st));
+      if (shared) HGL_TRY(lin(p.kpe0, C, L.i2t.q, nullptr, 0, p.qi, I1, HW, I1, C, HGL_ACT_NONE, st));
+      HGL_TRY(hgl_launch_dec_i2t(shared ? p.qi : p.kp + 2 * I1, shared ? I1 : 3 * I1, shared ? 0 : (long long)HW * 3 * I1, p.k1,
+                                 p.v1, L.i2t.out.w, L.i2t.out.b, keys, shared ? 0 : sK, L.n4.w, L.n4.b, 1e-5f,
+                                 1.0f / sqrtf((float)(I1 / w->heads)), P, HW, li == 0 ? p.keys : nullptr, keysS.hi, keysS.lo, st));
+    } else if (x3) {
       if (merged && !shared) {
         HGL_TRY(dec_i2t_merged(w, L.i2t, p.kp, 3 * I1, p.qpe, p.queries, P, HW, p.k1, p.v1, p.atti, keys, p.keys, st));
       } else {
@@ -581,12 +612,12 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
   HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
   if (merged) {
     HGL_TRY(dec_project_merged(keysS, w->kvf_w, w->kvf_b, w->kvf_pe, P, HW, C, 2 * I1, p.kp, st));
-    HGL_TRY(dec_t2i_merged(w, w->final_t2i, p.qpe, p.kp, 2 * I1, P, HW, p.q1, p.att, p.queries, st));
+    HGL_TRY(dec_t2i_merged(w, w->final_t2i, p.qpe, p.kp, 2 * I1, P, HW, p.q1, p.att, p.queries, p.atti, atti_bytes, st));
   } else if (x3) {
-    HGL_TRY(dec_t2i_x3(w, w->final_t2i, p.qpe, kpeS, keysS, P, HW, p.q1, p.kp, p.vp, p.att, p.queries, st));
+    HGL_TRY(dec_t2i_x3(w, w->final_t2i, p.qpe, kpeS, keysS, P, HW, p.q1, p.kp, p.vp, p.att, p.queries, p.atti, atti_bytes, st));
   } else {
     HGL_TRY(dec_attn(w, w->final_t2i, p.qpe, false, T, p.kpe, p.keys, false, HW, P, p.q1, p.kp, p.vp, p.att, p.queries,
-                     sQ, p.queries, st));
+                     sQ, p.queries, st, p.atti, atti_bytes));
   }
   HGL_TRY(hgl_launch_layernorm(p.queries, w->norm_final.w, w->norm_final.b, p.queries, P * T, C, 1e-5f, st));
 
@@ -601,7 +632,7 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
     HGL_TRY(lin(p.hy_b, C, w->hyper[i][2], nullptr, 0, p.hyper + i * C8, 4 * C8, P, C8, C, HGL_ACT_NONE, st));
   }
   // fused upscaling + hyper-network products (one launch, the 256-channel rows read once); hgl_sam_decoder_fusion(0) /
-  // HGL_SAM_DEC_FUSED=0 keep the four launches below (same arithmetic, bit for bit: tests compare the two)
+  // HGL_SAM_DEC_FUSED=0 keep the four launches below (same products, sums associated differently: tests compare the two)
   const bool fused_tail = x3 && (dec_fusion_mask() & 1) && (HW % 64) == 0 && (g % 64 == 0 || 64 % g == 0) && P <= 65535;
   if (fused_tail) {
     HGL_TRY(hgl_launch_dec_tail(keysS.hi, keysS.lo, w->up0_w, w->up0_b, w->up1.w, w->up1.b, w->up3_w, w->up3_b, p.hyper, P, g,

@@ -292,6 +292,263 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+//   dec_i2t_kernel       keys' = norm4(keys + out_proj(softmax(q k^T / 4) v))     transformer.py:139-150 (step 4 of a
+//                        TwoWayAttentionBlock: the image tokens attend to the 7 prompt tokens), per tile of 64 image tokens:
+//                          attention of (token, head) against 7 keys of 16 channels          VALU, the arithmetic of attn_smallk
+//                          out-projection 128 -> 256 (+ bias, + residual)                   MFMA, K = 128, W fragments from L2
+//                          LayerNorm over the 256 channels                                   lane sums + one LDS exchange per pass
+//                        unfused: attention (reads q, writes 134 MB), GEMM (reads them, reads / writes 2 x 268 MB), LayerNorm
+//                        (reads 268, writes 268 / 536 MB).  Fused: reads q (and the per-prompt residual), writes the split planes
+//                        (and, while a later layer needs them as a residual, the fp32 rows).
+struct I2TArgs {
+  const float* q;             // image-side queries: row (p, n) at q + p * sqb + n * ldq, 128 floats (8 heads x 16)
+  long long sqb;
+  int ldq;
+  const float *k1, *v1;       // projected prompt tokens [P, 7, 128]
+  const _Float16 *Wh, *Wl;    // out_proj weight [256, 128] split
+  const float* bo;
+  const float* R;             // residual rows of 256 floats: R + p * srb + n * 256   (srb = 0: the same rows for every prompt)
+  long long srb;
+  const float *ln_w, *ln_b;
+  float so, eps, scale;
+  float* out32;               // [P*HW, 256] fp32 rows or nullptr
+  _Float16 *oh, *ol;          // [P*HW, 256] fp16 hi / lo planes
+  int HW;
+};
+
+constexpr int I2T_ROWS = 64;
+constexpr int I2T_TOK = 7;
+constexpr int I2T_HS = 20;                                  // floats between the heads of a token in LDS (16 + 4 of padding)
+constexpr int I2T_A_PLANE = I2T_ROWS * 128 * 2;          // bytes of one plane of the attention output tile (16 KiB)
+
+__global__ __launch_bounds__(512, 2) void dec_i2t_kernel(I2TArgs a) {
+  // Eight waves per 64-token tile (a wave owns 32 of the 256 output columns): the stages of a tile are a dependent chain
+  // (q -> attention -> product -> residual -> two LayerNorm exchanges -> stores), so what hides its latencies is the number
+  // of resident waves: 16 per CU at 128 registers (four waves of 64 columns each: 198 registers, 8 per CU, 205 us vs ... )
+  __shared__ __attribute__((aligned(16))) unsigned char img[2 * I2T_A_PLANE];
+  __shared__ __attribute__((aligned(16))) float kv_s[2 * I2T_TOK * 8 * I2T_HS];
+  __shared__ __attribute__((aligned(16))) float red[2][I2T_ROWS][8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 15, h = lane >> 4;
+  const int p = blockIdx.y, tile = blockIdx.x;
+  const int n0 = tile * I2T_ROWS;
+  const long long row0 = (long long)p * a.HW + n0;
+
+  // the first two K steps of this wave's W fragments are requested before anything else
+  const _Float16* const wh = a.Wh + (long long)(wave * 32 + r) * 128 + 8 * h;
+  const _Float16* const wl = a.Wl + (long long)(wave * 32 + r) * 128 + 8 * h;
+  f16x8 bh[2][2], bl[2][2];
+#pragma unroll
+  for (int pre = 0; pre < 2; ++pre)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bh[pre][j] = *(const f16x8*)(wh + j * 16 * 128 + pre * 32);
+      bl[pre][j] = *(const f16x8*)(wl + j * 16 * 128 + pre * 32);
+    }
+
+  // ---- the prompt's 7 projected tokens (keys, values): a head's 16 floats at a stride of 20, so that the eight heads a
+  //      ds_read_b128 of the attention touches lie in eight different bank groups ----
+  if (t < I2T_TOK * 32) {
+    const int j = t >> 5, c = t & 31;                    // token, 16-byte piece of its 128 floats
+    const int dst = (j * 8 + (c >> 2)) * I2T_HS + 4 * (c & 3);
+    *(f32x4*)(kv_s + dst) = ((const f32x4*)(a.k1 + (long long)p * I2T_TOK * 128))[t];
+    *(f32x4*)(kv_s + I2T_TOK * 8 * I2T_HS + dst) = ((const f32x4*)(a.v1 + (long long)p * I2T_TOK * 128))[t];
+  }
+  // q of this thread's (token, head): eight consecutive threads read the 512 contiguous bytes of one token
+  const int hh = t & 7, arow = t >> 3;
+  f32x4 qv[4];
+  {
+    const float* qp = a.q + p * a.sqb + (long long)(n0 + arow) * a.ldq + hh * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qv[c] = *(const f32x4*)(qp + 4 * c);
+  }
+  __syncthreads();
+
+  // ---- softmax(q k^T * scale) v over the 7 tokens (the arithmetic of attn_smallk_kernel); the result as fp16 hi + lo
+  //      into the fragment image ----
+  {
+    float sc[I2T_TOK];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < I2T_TOK; ++j) {
+      const float* kr = kv_s + (j * 8 + hh) * I2T_HS;
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 kk = *(const f32x4*)(kr + 4 * c);
+        d += qv[c][0] * kk[0]; d += qv[c][1] * kk[1]; d += qv[c][2] * kk[2]; d += qv[c][3] * kk[3];
+      }
+      sc[j] = d * a.scale;
+      mx = fmaxf(mx, sc[j]);
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < I2T_TOK; ++j) {
+      sc[j] = expf(sc[j] - mx);
+      l += sc[j];
+    }
+    const float inv = 1.0f / l;
+    f32x4 o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < I2T_TOK; ++j) {
+      const float* vr = kv_s + I2T_TOK * 8 * I2T_HS + (j * 8 + hh) * I2T_HS;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 vv = *(const f32x4*)(vr + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[c][e] += sc[j] * vv[e];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f16x4 hi4, lo4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        _Float16 x, y;
+        hgl_split_hi_lo(o[c][e] * inv, x, y);
+        hi4[e] = x;
+        lo4[e] = y;
+      }
+      const int c0 = 16 * hh + 4 * c;       // channel: K step c0 / 32, chunk (c0 % 32) / 8, half-chunk (c0 % 8) / 4
+      const unsigned off = frag_off(c0 >> 5, 4, arow >> 4, arow & 15, (c0 & 31) >> 3) + (unsigned)((c0 & 7) * 2);
+      *(f16x4*)(img + off) = hi4;
+      *(f16x4*)(img + I2T_A_PLANE + off) = lo4;
+    }
+  }
+  __syncthreads();
+
+  // ---- out-projection: wave w computes columns 32 w .. 32 w + 31 of the tile's 64 rows ----
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int cb = ks & 1;
+    f16x8 ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned off = frag_off(ks, 4, i, r, h);
+      ah[i] = *(const f16x8*)(img + off);
+      al[i] = *(const f16x8*)(img + I2T_A_PLANE + off);
+    }
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f16x8 av = term == 0 ? al[i] : ah[i];
+          const f16x8 bv = term == 1 ? bl[cb][j] : bh[cb][j];
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, acc[i][j], 0, 0, 0);
+        }
+    if (ks + 2 < 4) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh[cb][j] = *(const f16x8*)(wh + j * 16 * 128 + (ks + 2) * 32);
+        bl[cb][j] = *(const f16x8*)(wl + j * 16 * 128 + (ks + 2) * 32);
+      }
+    }
+  }
+
+  // ---- + bias + residual; LayerNorm over the 256 channels of a row: lane sums (8 channels), the four lanes of the row,
+  //      then the eight waves through LDS ----
+  const int colw = wave * 32 + 4 * h;           // + 16 j + e
+  f32x4 bov[2], lw[2], lb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    bov[j] = *(const f32x4*)(a.bo + colw + 16 * j);
+    lw[j] = *(const f32x4*)(a.ln_w + colw + 16 * j);
+    lb[j] = *(const f32x4*)(a.ln_b + colw + 16 * j);
+  }
+  const float* Rp = a.R + p * a.srb + (long long)n0 * 256 + colw;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 rv = *(const f32x4*)(Rp + (long long)(16 * i + r) * 256 + 16 * j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = (acc[i][j][e] * a.so + bov[j][e]) + rv[e];
+    }
+  auto row_sum = [&](const f32x4 (&x)[2]) {
+    float u = ((x[0][0] + x[0][1]) + (x[0][2] + x[0][3])) + ((x[1][0] + x[1][1]) + (x[1][2] + x[1][3]));
+    u += __shfl_xor(u, 16);
+    u += __shfl_xor(u, 32);
+    return u;
+  };
+  auto tile_sum = [&](const float* s8) {
+    const f32x4 s = *(const f32x4*)s8, u = *(const f32x4*)(s8 + 4);
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((u[0] + u[1]) + (u[2] + u[3]));
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u = row_sum(acc[i]);
+    if (h == 0) red[0][16 * i + r][wave] = u;
+  }
+  __syncthreads();
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mean[i] = tile_sum(red[0][16 * i + r]) * (1.f / 256.f);
+    f32x4 q[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = acc[i][j][e] - mean[i]; q[j][e] = d * d; }
+    const float u = row_sum(q);
+    if (h == 0) red[1][16 * i + r][wave] = u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rstd[i] = rsqrtf(tile_sum(red[1][16 * i + r]) * (1.f / 256.f) + a.eps);
+  // ---- normalise, split, and write 16 rows at a time through LDS (the fragment image is free): a lane holds 4-channel
+  //      pieces of 16 different rows -- stored directly, an instruction scatters 16 x 32 / 64 bytes and the launch ran at
+  //      the rate of those partial lines (226 us in layer 0; with whole rows per instruction 150).  16-byte chunks of a
+  //      staged row are XOR-swizzled with the row so that neither side of the exchange has bank conflicts ----
+  float* const st32 = (float*)img;                       // [16][256] floats
+  unsigned char* const sth = img + 16 * 256 * 4;         // [16][256] halfs, hi
+  unsigned char* const stl = sth + 16 * 256 * 2;         // lo
+  const int orow = t >> 5, occ = t & 31;                 // read-back of the planes: 16 bytes = 8 channels per thread
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i) __syncthreads();                              // the previous 16 rows have left the staging area
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 y;
+      f16x4 hi4, lo4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = (acc[i][j][e] - mean[i]) * rstd[i] * lw[j][e] + lb[j][e];
+        _Float16 x, z;
+        hgl_split_hi_lo(y[e], x, z);
+        hi4[e] = x;
+        lo4[e] = z;
+      }
+      if (a.out32) *(f32x4*)(st32 + r * 256 + (((wave * 8 + 4 * j + h) ^ r) * 4)) = y;
+      const unsigned off = (unsigned)(r * 512 + (((wave * 4 + 2 * j + (h >> 1)) ^ r) * 16) + (h & 1) * 8);
+      *(f16x4*)(sth + off) = hi4;
+      *(f16x4*)(stl + off) = lo4;
+    }
+    __syncthreads();
+    const long long ob = (row0 + 16 * i) * 256;
+    const unsigned roff = (unsigned)(orow * 512 + ((occ ^ orow) * 16));
+    *(u32x4*)(a.oh + ob + orow * 256 + occ * 8) = *(const u32x4*)(sth + roff);
+    *(u32x4*)(a.ol + ob + orow * 256 + occ * 8) = *(const u32x4*)(stl + roff);
+    if (a.out32) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int idx = t + 512 * k, row = idx >> 6, c4 = idx & 63;
+        *(f32x4*)(a.out32 + ob + row * 256 + c4 * 4) = *(const f32x4*)(st32 + row * 256 + ((c4 ^ row) * 4));
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // upscaling + hyper-network products of the mask decoder in one launch.  src_hi / src_lo: the decoder's final image
@@ -322,4 +579,28 @@ int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0
   HglProfScope prof(HGL_PROF_OTHER, 2.0 * P * HW * (256.0 * 256 + 4 * 64.0 * 128), 0.0, st);
   hipLaunchKernelGGL(dec_tail_kernel, dim3((unsigned)(HW / TAIL_ROWS), (unsigned)P), dim3(256), TAIL_LDS, st, a);
   return hgl_check_launch("dec_tail");
+}
+
+// Image -> token attention + out-projection + residual + norm4 of a TwoWayAttentionBlock in one launch (dec_i2t_kernel).
+// q: image-side queries (row (p, n) at q + p * q_bstride + n * ldq; q_bstride = 0: one set for every prompt), k1 / v1 the
+// projected prompt tokens [P, 7, 128], R the residual rows (r_bstride = 0: shared), out32 (may be null) / out_hi / out_lo the
+// normalised rows.  HGL_EINVAL when the geometry or the weight does not fit.
+int hgl_launch_dec_i2t(const float* q, int ldq, long long q_bstride, const float* k1, const float* v1, const float* out_w,
+                       const float* out_b, const float* R, long long r_bstride, const float* ln_w, const float* ln_b, float eps,
+                       float scale, int P, int HW, float* out32, void* out_hi, void* out_lo, hipStream_t st) {
+  const void *wh, *wl;
+  int s = 0, n = 0, k = 0;
+  HGL_REQUIRE(hgl_get_split_weight(out_w, &wh, &wl, &s, &n, &k), "dec_i2t: the out-projection weight has no registered fp16 split");
+  HGL_REQUIRE(n == 256 && k == 128, "dec_i2t: out-projection geometry [%d,%d] unsupported", n, k);
+  HGL_REQUIRE(q && k1 && v1 && R && out_hi && out_lo, "dec_i2t: null operand");
+  HGL_REQUIRE(HW % I2T_ROWS == 0 && P > 0 && P <= 65535 && (ldq & 3) == 0 && (q_bstride & 3) == 0 && (r_bstride & 3) == 0,
+              "dec_i2t: %d tokens / %d prompts / strides unsupported", HW, P);
+  I2TArgs a;
+  a.q = q; a.sqb = q_bstride; a.ldq = ldq; a.k1 = k1; a.v1 = v1;
+  a.Wh = (const _Float16*)wh; a.Wl = (const _Float16*)wl; a.bo = out_b; a.R = R; a.srb = r_bstride;
+  a.ln_w = ln_w; a.ln_b = ln_b; a.so = ldexpf(1.0f, -s); a.eps = eps; a.scale = scale;
+  a.out32 = out32; a.oh = (_Float16*)out_hi; a.ol = (_Float16*)out_lo; a.HW = HW;
+  HglProfScope prof(HGL_PROF_OTHER, 2.0 * P * HW * (128.0 * 256 + 2 * 7 * 128), 0.0, st);
+  hipLaunchKernelGGL(dec_i2t_kernel, dim3((unsigned)(HW / I2T_ROWS), (unsigned)P), dim3(512), 0, st, a);
+  return hgl_check_launch("dec_i2t");
 }

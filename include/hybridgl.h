@@ -419,7 +419,9 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
                           float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes,
                           void* stream);
 /* Fused stages of the decoder (split-fp16 mode): bit 0 = output upscaling + hyper-network products in one launch; bit 1 =
- * merged image-side projections (kvq1 / kvf of HglSamDecoderW, when provided).  Sets the mask (mask >= 0; default all
+ * merged image-side projections (kvq1 / kvf of HglSamDecoderW, when provided); bit 2 = image -> token attention +
+ * out-projection + residual + norm4 in one launch (needs bit 1); bit 4 = token -> image attention as key chunks of 256 with
+ * all heads per workgroup + a combine pass (either precision mode).  Sets the mask (mask >= 0; default all
  * stages, or HGL_SAM_DEC_FUSED) and returns the previous one; mask < 0 only queries.  Fused and unfused stages agree to
  * fp32 rounding: the switch exists for timing and for that test. */
 int hgl_sam_decoder_fusion(int mask);

@@ -201,8 +201,8 @@ def _fusion(mask):
 
 @pytest.mark.parametrize("name,P", [("tiny", 5), ("tiny", 64), ("vit_h_d2", 64), ("vit_h_d2", 7)])
 def test_fused_decoder_stages_equal_the_unfused_launches(cuda, name, P):
-    """hgl_sam_decoder_fusion: the merged image-side projections (one GEMM for k | v | q, positional encoding as a table)
-    and the fused upscaling + hyper-network kernel against the launches they replace
+    """hgl_sam_decoder_fusion: the merged image-side projections (one GEMM for k | v | q, positional encoding as a table),
+    the fused image -> token step and the fused upscaling + hyper-network kernel against the launches they replace
     (ConvTranspose GEMM, LayerNorm2d + GELU, ConvTranspose GEMM + GELU, hyper-network products), on the tiny grid (16 x 16:
     a tile spans four grid rows) and the ViT-H grid (64 x 64): the same matrix products in the same order, the LayerNorm sums
     and the 32-channel dot products associated differently -- equal to fp32 rounding (1e-6 of the largest logit)."""
@@ -230,6 +230,21 @@ def test_fused_decoder_stages_equal_the_unfused_launches(cuda, name, P):
     _fusion(old)
     assert torch.equal(iou0, iou2)
     assert float((low0 - low2).abs().max()) <= 2e-6 * float(low0.abs().max()), float((low0 - low2).abs().max())
+    # bit 2 on top of bits 0-1 (image -> token attention + out-projection + norm4 in one launch): the attention and the
+    # product are those of the separate launches, the LayerNorm sums over 256 channels are associated differently
+    _fusion(3)
+    low3, iou3 = m.decode_points(emb, p01)
+    _fusion(7)
+    low7, iou7 = m.decode_points(emb, p01)
+    _fusion(old)
+    assert float((iou3 - iou7).abs().max()) <= 4e-6 * max(1.0, float(iou3.abs().max())), float((iou3 - iou7).abs().max())
+    assert float((low3 - low7).abs().max()) <= 4e-6 * float(low3.abs().max()), float((low3 - low7).abs().max())
+    # bit 4: the token -> image attention in key chunks (exponentials in base 2, partials merged in a second pass)
+    _fusion(7 + 16)
+    low23, iou23 = m.decode_points(emb, p01)
+    _fusion(old)
+    assert float((iou7 - iou23).abs().max()) <= 1e-5 * max(1.0, float(iou7.abs().max())), float((iou7 - iou23).abs().max())
+    assert float((low7 - low23).abs().max()) <= 1e-5 * float(low7.abs().max()), float((low7 - low23).abs().max())
     # all stages: the merged projections add the positional encoding AFTER the product ((keys + pe) W = keys W + pe W)
     assert float((iou0 - iou1).abs().max()) <= 2e-5 * max(1.0, float(iou0.abs().max()))
     assert float((low0 - low1).abs().max()) <= 2e-5 * float(low0.abs().max()), float((low0 - low1).abs().max())
