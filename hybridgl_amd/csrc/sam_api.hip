@@ -515,11 +515,16 @@ int hgl_sam_decoder_fusion(int mask) {
   return old;
 }
 
-int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float* points01, int P, float* low_res,
-                          float* iou_pred, void* workspace, size_t workspace_bytes, void* stream) {
+// MaskDecoder.predict_masks for prompts of exactly two sparse tokens.  points01 != null: one foreground point + the padding
+// point per prompt (what SamAutomaticMaskGenerator issues); else coords01 [P,2,2] / labels [P,2].  first_mask = 1: the three
+// multimask outputs (mask tokens 1..3); 0: tokens 0..2 (token 0 is the single-mask output, mask_decoder.py:99-105).
+static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* points01, const float* coords01,
+                       const int32_t* labels, int first_mask, int P, float* low_res, float* iou_pred, void* workspace,
+                       size_t workspace_bytes, void* stream) {
   HGL_TRY(hgl_require_device());
   HGL_REQUIRE(valid_dec(w) && w->dense_pe, "sam_decode: invalid weight struct (dense_pe missing?)");
-  HGL_REQUIRE(emb && points01 && low_res && iou_pred && P > 0, "sam_decode: null input");
+  HGL_REQUIRE(emb && (points01 || (coords01 && labels)) && low_res && iou_pred && P > 0, "sam_decode: null input");
+  HGL_REQUIRE(first_mask == 0 || first_mask == 1, "sam_decode: first_mask must be 0 or 1");
   HglArena ar(workspace, workspace_bytes);
   DecPlan p;
   if (!workspace || !carve_dec(ar, w, P, p)) {
@@ -532,7 +537,13 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
   const size_t atti_bytes = (size_t)P * HW * (C / 2) * sizeof(float);
 
   // ---- prompt encoder + token assembly ----
-  HGL_TRY(hgl_launch_pe(points01, w->pe_gauss, 2 * P, C / 2, 1, w->point_embed_pos, w->not_a_point, p.sparse, st));
+  if (points01) {
+    HGL_TRY(hgl_launch_pe(points01, w->pe_gauss, 2 * P, C / 2, 1, w->point_embed_pos, w->not_a_point, p.sparse, st));
+  } else {
+    const float* pe4[4] = {w->point_embed_neg, w->point_embed_pos, w->point_embed_box0, w->point_embed_box1};
+    HGL_REQUIRE(pe4[0] && pe4[2] && pe4[3], "sam_decode_prompts: the weight struct lacks point_embeddings 0 / 2 / 3");
+    HGL_TRY(hgl_launch_pe_labeled(coords01, labels, w->pe_gauss, 2 * P, C / 2, w->not_a_point, pe4, p.sparse, st));
+  }
   HGL_TRY(hgl_launch_build_tokens(w->iou_token, w->mask_tokens, p.sparse, P, C, p.tokens, st));
   // src = image_embedding + no_mask_embed (dense prompt) ; shared by all prompts until the first update
   HGL_TRY(hgl_launch_add_rows_bcast(emb, C, w->no_mask, C, HW, p.keys0, st));   // rows of C, "pe" = no_mask [C]
@@ -635,8 +646,8 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
   // HGL_SAM_DEC_FUSED=0 keep the four launches below (same products, sums associated differently: tests compare the two)
   const bool fused_tail = x3 && (dec_fusion_mask() & 1) && (HW % 64) == 0 && (g % 64 == 0 || 64 % g == 0) && P <= 65535;
   if (fused_tail) {
-    HGL_TRY(hgl_launch_dec_tail(keysS.hi, keysS.lo, w->up0_w, w->up0_b, w->up1.w, w->up1.b, w->up3_w, w->up3_b, p.hyper, P, g,
-                                1e-6f, low_res, st));
+    HGL_TRY(hgl_launch_dec_tail(keysS.hi, keysS.lo, w->up0_w, w->up0_b, w->up1.w, w->up1.b, w->up3_w, w->up3_b, p.hyper, first_mask,
+                                P, g, 1e-6f, low_res, st));
   } else {
     if (x3) {
       HGL_TRY(hgl_launch_gemm_f16x3(keysS.hi, keysS.lo, C, w->up0_w, w->up0_b, nullptr, 0, p.u1, nullptr, nullptr, 4 * C4,
@@ -654,14 +665,27 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
     }
     // masks[p, t, pix] = hyper[p, t, :] . upscaled[p, pix, :] for the three multimask tokens, un-shuffled into
     // [P,3,4g,4g] by the same kernel
-    HGL_TRY(hgl_launch_hyper_logits(p.u2, p.hyper, P, g, low_res, st));
+    HGL_TRY(hgl_launch_hyper_logits(p.u2, p.hyper, P, g, first_mask, low_res, st));
   }
   // ---- IoU head on the iou token (row 0); multimask output = columns 1..3 ----
   HGL_TRY(lin(p.queries, T * C, w->iou_head[0], nullptr, 0, p.iou_a, C, P, C, C, HGL_ACT_RELU, st));
   HGL_TRY(lin(p.iou_a, C, w->iou_head[1], nullptr, 0, p.iou_b, C, P, C, C, HGL_ACT_RELU, st));
   HGL_TRY(lin(p.iou_b, C, w->iou_head[2], nullptr, 0, p.iou_a, 4, P, 4, C, HGL_ACT_NONE, st));
-  HGL_TRY(hgl_launch_gather_rows(p.iou_a + 1, 4, P, 3, iou_pred, st));
+  HGL_TRY(hgl_launch_gather_rows(p.iou_a + first_mask, 4, P, 3, iou_pred, st));
   return HGL_OK;
+}
+
+int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float* points01, int P, float* low_res,
+                          float* iou_pred, void* workspace, size_t workspace_bytes, void* stream) {
+  HGL_REQUIRE(points01, "sam_decode: null input");
+  return decode_impl(w, emb, points01, nullptr, nullptr, 1, P, low_res, iou_pred, workspace, workspace_bytes, stream);
+}
+
+int hgl_sam_decode_prompts(const HglSamDecoderW* w, const float* emb, const float* coords01, const int32_t* labels,
+                           int first_mask, int P, float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  HGL_REQUIRE(coords01 && labels, "sam_decode_prompts: null input");
+  return decode_impl(w, emb, nullptr, coords01, labels, first_mask, P, low_res, iou_pred, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -37,6 +37,7 @@ struct TailArgs {
   const float* hyper;          // [P, 4, 32]
   float s0, s3, eps;           // weight scales undone in the epilogues; LayerNorm2d eps
   int g, HW;
+  int hrow0;                   // first of the three hyper-network rows multiplied (1: multimask tokens 1..3; 0: tokens 0..2)
   float* out;                  // [P, 3, 4g, 4g]
 };
 
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
       for (int jj = 0; jj < 2; ++jj) {
         b3v[jj] = *(const f32x4*)(a.b3 + pass * 64 + 32 * sp + 16 * jj + 4 * h);
 #pragma unroll
-        for (int m = 0; m < 3; ++m) hv[m][jj] = *(const f32x4*)(hy + 32 * (m + 1) + 16 * jj + 4 * h);
+        for (int m = 0; m < 3; ++m) hv[m][jj] = *(const f32x4*)(hy + 32 * (m + a.hrow0) + 16 * jj + 4 * h);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -555,8 +556,8 @@ __global__ __launch_bounds__(512, 2) void dec_i2t_kernel(I2TArgs a) {
 // tokens [P*HW, 256] as fp16 hi / lo planes; hyper [P, 4, 32]; low_res [P, 3, 4g, 4g].  Returns HGL_EINVAL (and leaves the
 // error string) when the geometry or the weights do not fit the kernel: the caller then takes the unfused launches.
 int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0_w, const float* up0_b, const float* ln_w,
-                        const float* ln_b, const float* up3_w, const float* up3_b, const float* hyper, int P, int g, float eps,
-                        float* low_res, hipStream_t st) {
+                        const float* ln_b, const float* up3_w, const float* up3_b, const float* hyper, int row0, int P, int g,
+                        float eps, float* low_res, hipStream_t st) {
   const void *w0h, *w0l, *w3h, *w3l;
   int s0 = 0, s3 = 0, n0 = 0, k0 = 0, n3 = 0, k3 = 0;
   const int HW = g * g;
@@ -570,7 +571,7 @@ int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0
   a.W0h = (const _Float16*)w0h; a.W0l = (const _Float16*)w0l; a.W3h = (const _Float16*)w3h; a.W3l = (const _Float16*)w3l;
   a.b0 = up0_b; a.ln_w = ln_w; a.ln_b = ln_b; a.b3 = up3_b; a.hyper = hyper;
   a.s0 = ldexpf(1.0f, -s0); a.s3 = ldexpf(1.0f, -s3); a.eps = eps;
-  a.g = g; a.HW = HW; a.out = low_res;
+  a.g = g; a.HW = HW; a.hrow0 = row0; a.out = low_res;
   static bool set = false;
   if (!set) {
     (void)hipFuncSetAttribute((const void*)dec_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS);

@@ -340,6 +340,30 @@ __global__ __launch_bounds__(256) void pe_kernel(const float* __restrict__ coord
   o[f + F] = c;
 }
 
+// Prompt rows with labels (PromptEncoder._embed_points / _embed_boxes, prompt_encoder.py:73-101): row r = the positional
+// encoding of coords01[r] (zeroed for label -1, the padding point) + the label's embedding: -1 not_a_point, 0 / 1
+// point_embeddings[0 / 1] (background / foreground), 2 / 3 point_embeddings[2 / 3] (box corners)
+struct PeLabelTab { const float* e[5]; };
+__global__ __launch_bounds__(256) void pe_labeled_kernel(const float* __restrict__ coords01, const int32_t* __restrict__ labels,
+                                                         const float* __restrict__ G, int n, int F, PeLabelTab tab,
+                                                         float* __restrict__ out) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= (long long)n * F) return;
+  const int f = (int)(i % F);
+  const int r = (int)(i / F);
+  const int lab = labels[r];
+  const float* e = tab.e[lab + 1];
+  float s = 0.f, c = 0.f;
+  if (lab >= 0) {
+    const float cx = 2.f * coords01[2 * r] - 1.f, cy = 2.f * coords01[2 * r + 1] - 1.f;
+    const float v = 6.283185307179586f * (cx * G[f] + cy * G[F + f]);
+    s = sinf(v);
+    c = cosf(v);
+  }
+  out[(long long)r * 2 * F + f] = s + e[f];
+  out[(long long)r * 2 * F + f + F] = c + e[f + F];
+}
+
 // tokens[p, 0] = iou_token; tokens[p, 1..4] = mask_tokens; tokens[p, 5..6] = sparse[p, 0..1]
 __global__ __launch_bounds__(256) void build_tokens_kernel(const float* __restrict__ iou_tok,
                                                            const float* __restrict__ mask_tok,
@@ -432,14 +456,14 @@ __global__ __launch_bounds__(256) void ln256_pe_split_kernel(float* __restrict__
 // a wave covers 8 consecutive X, so the three plane writes are 32-byte segments.  Replaces a [.., 4]-column GEMM
 // (a 128-wide MFMA tile 97 % empty, 431 us) plus the un-shuffle pass (46 us); HBM-bound: 537 MB read, 50 MB written.
 __global__ __launch_bounds__(256) void hyper_logits_kernel(const float* __restrict__ u2, const float* __restrict__ hyper,
-                                                           int g, float* __restrict__ out) {
+                                                           int g, int row0, float* __restrict__ out) {
   const int S4 = 4 * g;
   const int p = blockIdx.y, Y = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int sub = lane & 7, grp = lane >> 3;
-  const float* hp = hyper + (long long)p * 4 * 32;
-  const f32x4 h1 = *(const f32x4*)(hp + 32 + 4 * sub), h2 = *(const f32x4*)(hp + 64 + 4 * sub),
-              h3 = *(const f32x4*)(hp + 96 + 4 * sub);
+  const float* hp = hyper + (long long)p * 4 * 32 + 32 * row0;       // row0 = 1: the multimask tokens 1..3; 0: tokens 0..2
+  const f32x4 h1 = *(const f32x4*)(hp + 4 * sub), h2 = *(const f32x4*)(hp + 32 + 4 * sub),
+              h3 = *(const f32x4*)(hp + 64 + 4 * sub);
   const int y = Y >> 2, ky = (Y >> 1) & 1, ky2 = Y & 1;
   const float* base = u2 + (long long)p * g * g * 16 * 32;
   float* o = out + ((long long)p * 3 * S4 + Y) * S4;
@@ -929,6 +953,14 @@ int hgl_launch_pe(const float* coords01, const float* G, int n, int F, int mode,
   hipLaunchKernelGGL(pe_kernel, dim3(grid1((long long)n * F)), dim3(256), 0, st, coords01, G, n, F, mode, pos_embed, not_a_point, out);
   return hgl_check_launch("pe");
 }
+int hgl_launch_pe_labeled(const float* coords01, const int32_t* labels, const float* G, int n, int F, const float* not_a_point,
+                          const float* const* point_embed, float* out, hipStream_t st) {
+  PeLabelTab tab;
+  tab.e[0] = not_a_point;
+  for (int i = 0; i < 4; ++i) tab.e[i + 1] = point_embed[i];
+  hipLaunchKernelGGL(pe_labeled_kernel, dim3(grid1((long long)n * F)), dim3(256), 0, st, coords01, labels, G, n, F, tab, out);
+  return hgl_check_launch("pe_labeled");
+}
 int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const float* sparse, int P, int C,
                             float* tokens, hipStream_t st) {
   hipLaunchKernelGGL(build_tokens_kernel, dim3(grid1((long long)P * 7 * C)), dim3(256), 0, st, iou_tok, mask_tok, sparse, P, C, tokens);
@@ -946,9 +978,9 @@ int hgl_launch_ln256_pe_split(float* x, const float* w, const float* b, const fl
                      eps, write_f32, (_Float16*)kh, (_Float16*)kl, (_Float16*)ph, (_Float16*)pl);
   return hgl_check_launch("ln256_pe_split");
 }
-int hgl_launch_hyper_logits(const float* u2, const float* hyper, int P, int g, float* low_res, hipStream_t st) {
+int hgl_launch_hyper_logits(const float* u2, const float* hyper, int P, int g, int row0, float* low_res, hipStream_t st) {
   HGL_REQUIRE((4 * g) % 32 == 0, "hyper_logits: 4*grid must be a multiple of 32 (grid %d)", g);
-  hipLaunchKernelGGL(hyper_logits_kernel, dim3(4 * g, P), dim3(256), 0, st, u2, hyper, g, low_res);
+  hipLaunchKernelGGL(hyper_logits_kernel, dim3(4 * g, P), dim3(256), 0, st, u2, hyper, g, row0, low_res);
   return hgl_check_launch("hyper_logits");
 }
 

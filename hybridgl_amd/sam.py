@@ -97,6 +97,9 @@ class Sam:
         dec.pe_gauss = t(sd[f"{pe}.pe_layer.positional_encoding_gaussian_matrix"])
         dec.point_embed_pos = t(np.asarray(sd[f"{pe}.point_embeddings.1.weight"]).reshape(-1))
         dec.not_a_point = t(np.asarray(sd[f"{pe}.not_a_point_embed.weight"]).reshape(-1))
+        dec.point_embed_neg = t(np.asarray(sd[f"{pe}.point_embeddings.0.weight"]).reshape(-1))
+        dec.point_embed_box0 = t(np.asarray(sd[f"{pe}.point_embeddings.2.weight"]).reshape(-1))
+        dec.point_embed_box1 = t(np.asarray(sd[f"{pe}.point_embeddings.3.weight"]).reshape(-1))
         dec.no_mask = t(np.asarray(sd[f"{pe}.no_mask_embed.weight"]).reshape(-1))
         dec.iou_token = t(np.asarray(sd[f"{m}.iou_token.weight"]).reshape(-1))
         dec.mask_tokens = t(sd[f"{m}.mask_tokens.weight"])
@@ -235,6 +238,25 @@ class Sam:
                                         ops._dev(points01, torch.float32, "points01"), P, low.data_ptr(),
                                         iou.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()),
               "hgl_sam_decode_points")
+        return low, iou
+
+    def decode_prompts(self, emb, coords01, labels, first_mask=1):
+        """prompts of exactly two sparse tokens (prompt_encoder.py:73-101): coords01 [P,2,2] fp32 device
+        ((coordinate + 0.5) / img_size), labels [P,2] int32 (-1 padding, 0 / 1 background / foreground point, 2 / 3 box
+        corners); first_mask 1 -> mask tokens 1..3 (multimask), 0 -> tokens 0..2 (column 0 = the single-mask output)
+        -> (low_res [P,3,4g,4g], iou [P,3])."""
+        lib = _lib.load()
+        ops.use_precision(self.precision)
+        P = coords01.shape[0]
+        need = lib.hgl_sam_decode_workspace_bytes(C.byref(self.dec_w), P)
+        ws = ops.workspace(need, self.device, "sam_decode")
+        g4 = 4 * self.grid
+        low = torch.empty((P, 3, g4, g4), dtype=torch.float32, device=self.device)
+        iou = torch.empty((P, 3), dtype=torch.float32, device=self.device)
+        check(lib.hgl_sam_decode_prompts(C.byref(self.dec_w), ops._dev(emb, torch.float32, "emb"),
+                                         ops._dev(coords01, torch.float32, "coords01"), ops._dev(labels, torch.int32, "labels"),
+                                         int(first_mask), P, low.data_ptr(), iou.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         ops._stream()), "hgl_sam_decode_prompts")
         return low, iou
 
     def postprocess(self, low_res, iou_pred, input_size, original_size, pred_iou_thresh=-1e30,
@@ -434,11 +456,17 @@ class ResizeLongestSide:
         c[..., 1] = c[..., 1] * (new_h / old_h)
         return c
 
+    def apply_boxes(self, boxes, original_size):
+        """utils/transforms.py:47-53: [B,4] XYXY -> the resized frame"""
+        return self.apply_coords(np.asarray(boxes, dtype=np.float64).reshape(-1, 2, 2), original_size).reshape(-1, 4)
+
 
 class SamPredictor:
-    """predictor.py:17-269 for what the automatic generator drives: set_image, predict_torch with ONE foreground
-    point per prompt (automatic_mask_generator.py:269-285), multimask output.  Other prompt kinds (boxes, mask inputs,
-    background points, several points per prompt) are not on the reference's path and raise NotImplementedError."""
+    """predictor.py:17-269: set_image, predict_torch, predict.  Prompts of exactly two sparse tokens run on the device
+    decoder: ONE point per prompt (foreground or background; the padding point is the second token -- what
+    automatic_mask_generator.py:269-285 issues), or ONE box per prompt (its two corners); multimask_output True or False.
+    Several points per prompt, points together with a box (other token counts) and mask_input (per-prompt dense
+    embeddings) are not on the reference's path and raise NotImplementedError."""
 
     def __init__(self, sam_model):
         self.model = sam_model
@@ -466,38 +494,75 @@ class SamPredictor:
         self.features = self.model.encode(resized)
         self.is_image_set = True
 
+    def _coords01(self, xy):
+        """(coordinate + 0.5) / img_size in the dtype the caller handed over (prompt_encoder.py:79,95,207-214: float64 from
+        the automatic generator, float32 from predict()), then float32"""
+        xy = torch.as_tensor(xy, device=self.device)
+        xy = xy if xy.dtype == torch.float64 else xy.to(torch.float32)
+        return ((xy + 0.5) / float(self.model.img_size)).to(torch.float32)
+
     def predict_torch(self, point_coords, point_labels, boxes=None, mask_input=None, multimask_output=True,
                       return_logits=False):
-        """point_coords [P,1,2] already in the resized frame (transform.apply_coords), point_labels [P,1] all 1.
-        Returns (masks [P,3,H,W] bool or logits, iou_predictions [P,3], low_res_masks [P,3,256,256])."""
+        """predictor.py:169-243.  point_coords [P,1,2] in the resized frame (transform.apply_coords) with point_labels [P,1]
+        in {0, 1}, OR boxes [P,4] XYXY in the resized frame (transform.apply_boxes).  Returns (masks [P,C,H,W] bool or
+        logits, iou_predictions [P,C], low_res_masks [P,C,4g,4g]) with C = 3 (multimask_output) or 1."""
         if not self.is_image_set:
             raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")   # predictor.py:214
-        if boxes is not None or mask_input is not None or not multimask_output:
-            raise NotImplementedError("only point prompts with multimask output are on the reference's path")
-        pc = torch.as_tensor(point_coords, device=self.device)
-        pl = torch.as_tensor(point_labels, device=self.device)
-        if pc.dim() != 3 or pc.shape[1] != 1 or not bool((pl == 1).all()):
-            raise NotImplementedError("one foreground point per prompt (what SamAutomaticMaskGenerator issues)")
-        p01 = ((pc[:, 0, :].to(torch.float64) + 0.5) / float(self.model.img_size)).to(torch.float32).contiguous()
-        low, iou = self.model.decode_points(self.features, p01)
-        P = low.shape[0]
+        if mask_input is not None:
+            raise NotImplementedError("mask_input (per-prompt dense embeddings) is not on the reference's path")
+        if (point_coords is None) == (boxes is None):
+            raise NotImplementedError("one point per prompt OR one box per prompt (two sparse tokens); got "
+                                      + ("both" if boxes is not None else "neither"))
+        if boxes is not None:
+            b = torch.as_tensor(boxes, device=self.device)
+            if b.dim() != 2 or b.shape[1] != 4:
+                raise ValueError(f"boxes must be [P,4] (XYXY), got {tuple(b.shape)}")
+            c01 = self._coords01(b.reshape(-1, 2, 2))                                   # prompt_encoder.py:93-101
+            labels = torch.tensor([2, 3], dtype=torch.int32, device=self.device).repeat(b.shape[0], 1)
+            fast = False
+        else:
+            pc = torch.as_tensor(point_coords, device=self.device)
+            pl = torch.as_tensor(point_labels, device=self.device)
+            if pc.dim() != 3 or pc.shape[1] != 1 or pl.shape != pc.shape[:2]:
+                raise NotImplementedError("one point per prompt: point_coords [P,1,2], point_labels [P,1]")
+            if not bool(((pl == 0) | (pl == 1)).all()):
+                raise ValueError("point_labels must be 0 (background) or 1 (foreground)")
+            fast = multimask_output and bool((pl == 1).all())
+            p01 = self._coords01(pc[:, 0, :]).contiguous()
+            if not fast:
+                c01 = torch.stack([p01, torch.zeros_like(p01)], dim=1)                   # the padding point (label -1)
+                labels = torch.stack([pl[:, 0].to(torch.int32), torch.full_like(pl[:, 0], -1, dtype=torch.int32)], dim=1)
+        if fast:
+            low, iou = self.model.decode_points(self.features, p01)
+        else:
+            low, iou = self.model.decode_prompts(self.features, c01.contiguous(), labels.contiguous(),
+                                                 first_mask=1 if multimask_output else 0)
+            if not multimask_output:
+                low, iou = low[:, :1].contiguous(), iou[:, :1].contiguous()
+        P, Cm = low.shape[0], low.shape[1]
         H, W = self.original_size
         _, _, _, _, full = self.model.postprocess(low.flatten(0, 1), iou.flatten(), self.input_size, (H, W), -1e30, 0.0, 1.0,
                                                   return_logits=True)
-        full = full.reshape(P, 3, H, W)
+        full = full.reshape(P, Cm, H, W)
         masks = full if return_logits else full > self.model.mask_threshold
         return masks, iou, low
 
     def predict(self, point_coords=None, point_labels=None, box=None, mask_input=None, multimask_output=True,
                 return_logits=False):
-        """predictor.py:90-167 for a single foreground point: numpy in, numpy out ([3,H,W], [3], [3,256,256])."""
-        if point_coords is None or box is not None or mask_input is not None:
-            raise NotImplementedError("only point prompts are on the reference's path")
-        pts = self.transform.apply_coords(np.asarray(point_coords, dtype=np.float64), self.original_size)
-        m, iou, low = self.predict_torch(torch.from_numpy(pts)[:, None, :], torch.as_tensor(point_labels)[:, None],
-                                         multimask_output=multimask_output, return_logits=return_logits)
-        if m.shape[0] != 1:
-            raise NotImplementedError("predict() takes one prompt (several points per prompt are not supported)")
+        """predictor.py:90-167 for one prompt: a point [1,2] with its label [1], or a box [4] (XYXY, original frame):
+        numpy in, numpy out ([C,H,W], [C], [C,4g,4g])."""
+        if mask_input is not None:
+            raise NotImplementedError("mask_input is not on the reference's path")
+        pc = pl = bx = None
+        if point_coords is not None:
+            assert point_labels is not None, "point_labels must be supplied if point_coords is supplied."
+            pts = self.transform.apply_coords(np.asarray(point_coords, dtype=np.float64), self.original_size)
+            pc = torch.as_tensor(pts, dtype=torch.float32)[None, :, :]                   # predictor.py:141-143: float32
+            pl = torch.as_tensor(np.asarray(point_labels), dtype=torch.int32)[None, :]
+        if box is not None:
+            bx = torch.as_tensor(self.transform.apply_boxes(np.asarray(box, dtype=np.float64), self.original_size),
+                                 dtype=torch.float32).reshape(1, 4)
+        m, iou, low = self.predict_torch(pc, pl, bx, None, multimask_output=multimask_output, return_logits=return_logits)
         return m[0].cpu().numpy(), iou[0].cpu().numpy(), low[0].cpu().numpy()
 
 

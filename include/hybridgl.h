@@ -34,7 +34,7 @@ extern "C" {
 
 /* 2: + hgl_clip_hybrid_forward_segments, hgl_split_overflow_count, hgl_clip_encode_text_ex; hgl_gemm_f16x3_select
  * knows kinds -1, 0, 1 only */
-#define HGL_ABI_VERSION 2
+#define HGL_ABI_VERSION 3
 
 /* activation codes for hgl_gemm_f32 */
 #define HGL_ACT_NONE 0
@@ -382,6 +382,9 @@ typedef struct HglSamDecoderW {        /* prompt_encoder.py + mask_decoder.py + 
    * [grid*grid, 3I] = dense_pe @ [Wk; 0; Wq]^T.  kvf: the final token->image k, v: [2I, C], [2I], [grid*grid, 2I]. */
   const float *kvq1_w, *kvq1_b, *kvq1_pe;
   const float *kvf_w, *kvf_b, *kvf_pe;
+  /* Optional (NULL = not provided): the other label embeddings of the prompt encoder, [C] each: point_embeddings[0]
+   * (background point), [2] / [3] (box corners) -- needed by hgl_sam_decode_prompts only (prompt_encoder.py:40-42). */
+  const float *point_embed_neg, *point_embed_box0, *point_embed_box1;
 } HglSamDecoderW;
 
 /* ResizeLongestSide.apply_image (utils/transforms.py:26-31) = Pillow Image.resize(BILINEAR) on uint8 HWC,
@@ -418,6 +421,16 @@ size_t hgl_sam_decode_workspace_bytes(const HglSamDecoderW* w, int P);
 int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float* points01, int P,
                           float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* The same for any prompt of exactly TWO sparse tokens (PromptEncoder._embed_points / _embed_boxes, prompt_encoder.py:73-101;
+ * SamPredictor.predict_torch, predictor.py:169-243): coords01 [P,2,2] ((coordinate + 0.5) / img_size, float64 on the host),
+ * labels [P,2]: -1 padding point (its coordinate is ignored), 0 background point, 1 foreground point, 2 / 3 the top-left /
+ * bottom-right corner of a box.  (point, -1) = one point prompt; (2, 3) = one box prompt.  first_mask = 1: mask tokens 1..3
+ * (multimask_output=True); 0: tokens 0..2 -- column 0 is the single-mask output of multimask_output=False
+ * (mask_decoder.py:99-105).  More points per prompt, points + box and mask_input change the token count / make the image
+ * tokens per-prompt from layer 0 on: not provided. */
+int hgl_sam_decode_prompts(const HglSamDecoderW* w, const float* emb, const float* coords01, const int32_t* labels,
+                           int first_mask, int P, float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes,
+                           void* stream);
 /* Fused stages of the decoder (split-fp16 mode): bit 0 = output upscaling + hyper-network products in one launch; bit 1 =
  * merged image-side projections (kvq1 / kvf of HglSamDecoderW, when provided); bit 2 = image -> token attention +
  * out-projection + residual + norm4 in one launch (needs bit 1); bit 4 = token -> image attention as key chunks of 256 with

@@ -79,6 +79,17 @@ def sam_tiny_case():
     return dict(image=img, resized=resized, input_size=(nh, nw), orig_size=(oh, ow), points=pts, points_in=pts_in)
 
 
+def sam_prompts_case():
+    """prompts of tests/golden/sam_prompts.npz on the sam_tiny_case image (original frame, 160 x 200): single points with
+    labels (0 = background), boxes XYXY, and the prompts of the two predict() calls"""
+    pts = np.array([[20.5, 30.25], [100.0, 80.0], [199.0, 159.0], [0.0, 0.0]], dtype=np.float64)
+    labels = np.array([0, 1, 0, 0], dtype=np.int32)
+    boxes = np.array([[10.0, 20.0, 120.5, 90.0], [0.0, 0.0, 199.0, 159.0], [60.25, 70.0, 61.0, 150.75], [150.0, 5.0, 180.0, 40.0]],
+                     dtype=np.float64)
+    return dict(points=pts, labels=labels, boxes=boxes, one_point=np.array([[33.3, 77.7]]), one_label=np.array([0]),
+                one_box=np.array([12.3, 45.6, 130.1, 140.9]))
+
+
 def sam_crops_case():
     """inputs of the crop-layer generator golden (tests/golden/sam_crops.npz): a 240x320 RGB image run through
     SamAutomaticMaskGenerator(points_per_side=8, crop_n_layers=1, crop_n_points_downscale_factor=2) at the

@@ -622,6 +622,38 @@ TOKENIZER_STRINGS = [
 ]
 
 
+def gen_sam_prompts():
+    """SamPredictor.predict_torch / predict of the reference (predictor.py:90-243) on the tiny geometry for the prompt kinds
+    beyond the automatic generator's foreground points: labelled single points, boxes, multimask_output False."""
+    from oracle.cases import sam_tiny_case, sam_prompts_case
+    sam = build_ref_sam("tiny", 0)
+    from segment_anything import SamPredictor
+    c, q = sam_tiny_case(), sam_prompts_case()
+    pred = SamPredictor(sam)
+    out = {}
+    with torch.no_grad():
+        pred.set_image(c["image"])
+        pts = pred.transform.apply_coords(q["points"], pred.original_size)
+        bxs = pred.transform.apply_boxes(q["boxes"], pred.original_size)
+        out["boxes_in"] = bxs
+        for tag, kw in (("pts", dict(point_coords=torch.as_tensor(pts)[:, None, :], point_labels=torch.as_tensor(q["labels"])[:, None])),
+                        ("box", dict(point_coords=None, point_labels=None, boxes=torch.as_tensor(bxs)))):
+            for mm in (True, False):
+                full, iou, low = pred.predict_torch(multimask_output=mm, return_logits=True, **kw)
+                k = f"{tag}_{'multi' if mm else 'single'}"
+                out[k + "_low"], out[k + "_iou"], out[k + "_full"] = low.numpy()[:, :, ::2, ::2], iou.numpy(), full.numpy()[:, :, ::8, ::8]
+                print("sam_prompts", k, tuple(low.shape), "iou", iou.numpy().round(4).tolist()[:2])
+        sparse, _ = sam.prompt_encoder(points=None, boxes=torch.as_tensor(bxs), masks=None)
+        out["box_sparse"] = sparse.numpy()
+        m, iou, low = pred.predict(point_coords=q["one_point"], point_labels=q["one_label"], multimask_output=True, return_logits=True)
+        out["predict_pt_low"], out["predict_pt_iou"] = low, iou
+        m, iou, low = pred.predict(box=q["one_box"], multimask_output=False, return_logits=True)
+        out["predict_box_low"], out["predict_box_iou"], out["predict_box_full"] = low, iou, m[:, ::4, ::4]
+        mb, _, _ = pred.predict(box=q["one_box"], multimask_output=False)
+        out["predict_box_mask"] = np.packbits(mb, axis=-1)
+    np.savez_compressed(os.path.join(GOLD, "sam_prompts.npz"), **out)
+
+
 def gen_sam_crops():
     """Crop-layer generator (automatic_mask_generator.py:197-267, amg.py:78-88,201-252) at the tiny geometry."""
     from oracle.cases import sam_crops_case
@@ -926,6 +958,9 @@ if __name__ == "__main__":
         gen_scoring()
     if want("resize"):
         gen_resize()
+    if want("sam_prompts"):
+        install_sam_stubs()
+        gen_sam_prompts()
     if want("tokenizer"):
         gen_tokenizer()
     if want("sam_tiny"):

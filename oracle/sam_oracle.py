@@ -157,6 +157,20 @@ def embed_points(sd, points_xy, input_size=1024):
     return emb.astype(F32)
 
 
+def embed_prompts(sd, coords_xy, labels, input_size=1024):
+    """PromptEncoder._embed_points / _embed_boxes for prompts of two tokens (modeling/prompt_encoder.py:73-101).
+    coords_xy: [P,2,2] input-image pixels (float64 or float32: the arithmetic dtype of `+ 0.5` and the division, as the
+    reference takes whatever the caller hands over), labels [P,2]: -1 padding, 0 / 1 points, 2 / 3 box corners -> [P,2,C]."""
+    labels = np.asarray(labels)
+    pts = ((coords_xy + coords_xy.dtype.type(0.5)) / coords_xy.dtype.type(input_size)).astype(F32)
+    emb = pe_encoding(sd, pts)
+    emb[labels == -1] = 0.0
+    emb[labels == -1] += sd["prompt_encoder.not_a_point_embed.weight"][0]
+    for lab in range(4):
+        emb[labels == lab] += sd[f"prompt_encoder.point_embeddings.{lab}.weight"][0]
+    return emb.astype(F32)
+
+
 # ----------------------------------------------------------------------------- mask decoder
 def dec_attention(sd, p, q, k, v, heads):
     """modeling/transformer.py:185-240 Attention."""

@@ -96,10 +96,57 @@ def test_predictor_mirror_vs_reference(cuda, g, tiny):
     np.testing.assert_allclose(logits.cpu().numpy()[:, :, ::4, ::4], g["full_logits"], rtol=0, atol=3e-4)
     masks, _, _ = pred.predict_torch(torch.from_numpy(pts)[:, None, :], torch.ones(len(pts), 1, dtype=torch.int))
     assert masks.dtype == torch.bool and tuple(masks.shape) == (5, 3, 160, 200)
+    with pytest.raises(NotImplementedError):       # two points per prompt: three sparse tokens
+        pred.predict_torch(torch.from_numpy(pts)[None, :2, :], torch.ones(1, 2, dtype=torch.int))
     with pytest.raises(NotImplementedError):
-        pred.predict_torch(torch.from_numpy(pts)[:, None, :], torch.zeros(len(pts), 1, dtype=torch.int))
+        pred.predict_torch(torch.from_numpy(pts)[:, None, :], torch.ones(len(pts), 1, dtype=torch.int),
+                           mask_input=torch.zeros(len(pts), 1, 64, 64))
+    with pytest.raises(NotImplementedError):       # point AND box
+        pred.predict_torch(torch.from_numpy(pts)[:1, None, :], torch.ones(1, 1, dtype=torch.int), boxes=torch.zeros(1, 4))
     m1, i1, l1 = pred.predict(c["points"][:1], np.array([1]))
-    assert m1.shape == (3, 160, 200) and np.array_equal(m1, masks[0].cpu().numpy())
+    assert m1.shape == (3, 160, 200)
+    # predict() hands float32 coordinates to the prompt encoder (predictor.py:141-143), the call above float64
+    assert (m1 != masks[0].cpu().numpy()).mean() < 1e-3
+
+
+def test_predictor_prompt_kinds_vs_reference(cuda, tiny, golden_dir):
+    """labelled single points, boxes, multimask_output False and predict() (predictor.py:90-243, prompt_encoder.py:73-101,
+    mask_decoder.py:99-105) against the reference SamPredictor's outputs (tests/golden/sam_prompts.npz)"""
+    from oracle.cases import sam_prompts_case
+    gp = np.load(os.path.join(golden_dir, "sam_prompts.npz"))
+    c, q = sam_tiny_case(), sam_prompts_case()
+    pred = hsam.SamPredictor(tiny[1])
+    pred.set_image(c["image"])
+    pts = pred.transform.apply_coords(q["points"], pred.original_size)
+    bxs = pred.transform.apply_boxes(q["boxes"], pred.original_size)
+    np.testing.assert_allclose(bxs, gp["boxes_in"], rtol=0, atol=1e-12)
+    calls = (("pts", dict(point_coords=torch.from_numpy(pts)[:, None, :], point_labels=torch.from_numpy(q["labels"])[:, None])),
+             ("box", dict(point_coords=None, point_labels=None, boxes=torch.from_numpy(bxs))))
+    for tag, kw in calls:
+        for mm in (True, False):
+            full, iou, low = pred.predict_torch(multimask_output=mm, return_logits=True, **kw)
+            k = f"{tag}_{'multi' if mm else 'single'}"
+            assert tuple(low.shape) == (4, 3 if mm else 1, 64, 64) and tuple(full.shape) == (4, 3 if mm else 1, 160, 200)
+            np.testing.assert_allclose(iou.cpu().numpy(), gp[k + "_iou"], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(low.cpu().numpy()[:, :, ::2, ::2], gp[k + "_low"], rtol=0, atol=3e-4)
+            np.testing.assert_allclose(full.cpu().numpy()[:, :, ::8, ::8], gp[k + "_full"], rtol=0, atol=3e-4)
+    m, iou, low = pred.predict(point_coords=q["one_point"], point_labels=q["one_label"], multimask_output=True, return_logits=True)
+    np.testing.assert_allclose(low, gp["predict_pt_low"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(iou, gp["predict_pt_iou"], rtol=0, atol=1e-4)
+    m, iou, low = pred.predict(box=q["one_box"], multimask_output=False, return_logits=True)
+    assert m.shape == (1, 160, 200) and low.shape == (1, 64, 64) and iou.shape == (1,)
+    np.testing.assert_allclose(low, gp["predict_box_low"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(iou, gp["predict_box_iou"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(m[:, ::4, ::4], gp["predict_box_full"], rtol=0, atol=3e-4)
+    mb, _, _ = pred.predict(box=q["one_box"], multimask_output=False)
+    ref = np.unpackbits(gp["predict_box_mask"], axis=-1)[..., :200].astype(bool)
+    assert mb.dtype == bool and (mb != ref).mean() < 2e-3     # logits within 3e-4 of zero may flip isolated pixels
+    # the foreground-point fast path and the labelled path are the same decoder
+    a = pred.predict_torch(torch.from_numpy(pts)[:, None, :], torch.ones(4, 1, dtype=torch.int), return_logits=True)
+    lab = torch.stack([torch.ones(4, dtype=torch.int32), torch.full((4,), -1, dtype=torch.int32)], 1).to(cuda)
+    p01 = pred._coords01(torch.from_numpy(pts))
+    low2, iou2 = tiny[1].decode_prompts(pred.features, torch.stack([p01, torch.zeros_like(p01)], 1).contiguous(), lab)
+    assert torch.equal(a[2], low2) and torch.equal(a[1], iou2)
 
 
 def test_tiny_postprocess_vs_reference(cuda, g, tiny):

@@ -106,3 +106,34 @@ def test_pil_bilinear_resize_bit_exact(shape):
     img = np.random.default_rng(H).integers(0, 256, size=(H, W, 3), dtype=np.uint8)
     ref = np.array(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
     assert np.array_equal(S.pil_bilinear_resize(img, oh, ow), ref)
+
+
+def test_prompt_kinds_vs_reference_predictor(sd, emb):
+    """labelled points, boxes and multimask_output False (predictor.py:169-243, prompt_encoder.py:73-101,
+    mask_decoder.py:99-105): the oracle against tests/golden/sam_prompts.npz (reference SamPredictor outputs)"""
+    from oracle.cases import sam_prompts_case
+    gp = np.load(os.path.join(os.path.dirname(__file__), "golden", "sam_prompts.npz"))
+    c, q = sam_tiny_case(), sam_prompts_case()
+    sx, sy = c["input_size"][1] / 200, c["input_size"][0] / 160
+    pts = q["points"] * np.array([sx, sy])
+    co = np.stack([pts, np.zeros_like(pts)], 1)
+    lab = np.stack([q["labels"], np.full_like(q["labels"], -1)], 1)
+    bx = (q["boxes"].reshape(-1, 2, 2) * np.array([sx, sy]))
+    np.testing.assert_allclose(bx.reshape(-1, 4), gp["boxes_in"], rtol=0, atol=1e-12)
+    sp_box = S.embed_prompts(sd, bx, np.tile([2, 3], (4, 1)), 256)
+    np.testing.assert_allclose(sp_box, gp["box_sparse"], rtol=0, atol=2e-5)
+    for tag, sp in (("pts", S.embed_prompts(sd, co, lab, 256)), ("box", sp_box)):
+        for mm in (True, False):
+            low, iou = S.mask_decoder(sd, emb, sp, multimask=mm)
+            k = f"{tag}_{'multi' if mm else 'single'}"
+            np.testing.assert_allclose(low[:, :, ::2, ::2], gp[k + "_low"], rtol=0, atol=2e-4)
+            np.testing.assert_allclose(iou, gp[k + "_iou"], rtol=0, atol=5e-5)
+    # predict(): float32 coordinates (predictor.py:141-150)
+    one = (q["one_point"] * np.array([sx, sy])).astype(np.float32)
+    sp = S.embed_prompts(sd, np.stack([one, np.zeros_like(one)], 1), np.array([[0, -1]]), 256)
+    low, iou = S.mask_decoder(sd, emb, sp)
+    np.testing.assert_allclose(low[0], gp["predict_pt_low"], rtol=0, atol=2e-4)
+    ob = (q["one_box"].reshape(1, 2, 2) * np.array([sx, sy])).astype(np.float32)
+    low, iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, ob, np.array([[2, 3]]), 256), multimask=False)
+    np.testing.assert_allclose(low[0], gp["predict_box_low"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(iou[0], gp["predict_box_iou"], rtol=0, atol=5e-5)
