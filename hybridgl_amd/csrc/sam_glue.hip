@@ -663,6 +663,201 @@ __global__ __launch_bounds__(256) void sam_postprocess_kernel(PostArgs a) {
   }
 }
 
+// The same arithmetic with the work shared inside a tile.  Stage 1 (low-res -> S x S) interpolates horizontally first:
+// h(v, x1) = L[v][u0] n0 + L[v][u1] n1 depends only on the low-res row v and the stage-1 column x1, and every output pixel
+// of a tile column uses the same two stage-1 columns -- the kernel above evaluates it 8 times per output pixel, with three
+// source-index computations in front.  Here a tile first builds the table of its output columns (x0, x1, weights), the
+// table of its stage-1 columns (u0, u1, weights) and h over (low-res rows of the patch) x (stage-1 columns of the tile) in
+// LDS; an output pixel is then 8 LDS reads and the two vertical / one horizontal blends, expression for expression those
+// of the kernel above (same products, same order, same contraction: the logits are bit-identical, tests/test_gpu_sam.py).
+// ~40 instead of ~90 instructions per pixel.  The host picks this kernel when every tile's patch / column count fits.
+constexpr int PX1 = 112;            // max stage-1 columns of a tile (64 output columns at a 1.6 : 1 size ratio: 104)
+
+__global__ __launch_bounds__(256) void sam_postprocess_sep_kernel(PostArgs a) {
+  __shared__ float patch[PR * PR];
+  __shared__ float H1[PR * PX1];
+  __shared__ int xc0[PTW], xc1[PTW];
+  __shared__ float xl0[PTW], xl1[PTW];
+  __shared__ int cu0[PX1], cu1[PX1];
+  __shared__ float cn0[PX1], cn1[PX1];
+  __shared__ unsigned red[6 * 4];
+  const int k = blockIdx.z;
+  const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;
+  const int X0 = blockIdx.x * PTW, Y0 = blockIdx.y * PTH;
+  const int Xb = X0 + tx * PPX, Y = Y0 + ty;
+  if (a.iou && a.iou_thresh > 0.f && !(a.iou[k] > a.iou_thresh)) {
+    if (Xb < a.W && Y < a.H) {
+      const int npx = min(PPX, a.W - Xb);
+      const long long pix0 = (long long)k * a.H * a.W + (long long)Y * a.W + Xb;
+      if (npx == PPX && (pix0 & 15) == 0) {
+        const u32x4g z = {0, 0, 0, 0};
+        *(u32x4g*)(a.masks + pix0) = z;
+      } else {
+        for (int p = 0; p < npx; ++p) a.masks[pix0 + p] = 0;
+      }
+    }
+    return;
+  }
+  const int Xl = min(X0 + PTW - 1, a.W - 1), Yl = min(Y0 + PTH - 1, a.H - 1);
+  const float* L = a.low + (long long)k * a.hl * a.wl;
+  const float sy1 = (float)a.hi / (float)a.H, sx1 = (float)a.wi / (float)a.W;
+  const float s2y = (float)a.hl / (float)a.S, s2x = (float)a.wl / (float)a.S;
+  int i0, i1, j0, j1;
+  float f0, f1;
+  src_idx(sy1, Y0, a.hi, i0, i1, f0, f1);
+  int vb, vdummy;
+  src_idx(s2y, i0, a.hl, vb, vdummy, f0, f1);
+  src_idx(sy1, Yl, a.hi, i0, i1, f0, f1);
+  int ve0, ve;
+  src_idx(s2y, i1, a.hl, ve0, ve, f0, f1);
+  src_idx(sx1, X0, a.wi, j0, j1, f0, f1);
+  const int X1b = j0;                                    // first stage-1 column of the tile
+  int ub, udummy;
+  src_idx(s2x, j0, a.wl, ub, udummy, f0, f1);
+  src_idx(sx1, Xl, a.wi, j0, j1, f0, f1);
+  const int R1w = j1 - X1b + 1;                          // stage-1 columns of the tile (<= PX1: checked by the host)
+  int ue0, ue;
+  src_idx(s2x, j1, a.wl, ue0, ue, f0, f1);
+  const int ph = ve - vb + 1, pw = ue - ub + 1;          // low-res patch (<= PR x PR: checked by the host)
+  for (int i = threadIdx.x; i < ph * pw; i += 256) {
+    const int v = i / pw, u = i - v * pw;
+    patch[v * PR + u] = L[(long long)(vb + v) * a.wl + (ub + u)];
+  }
+  if (threadIdx.x < PTW) {
+    int x0, x1;
+    float lx0, lx1;
+    src_idx(sx1, min(X0 + (int)threadIdx.x, a.W - 1), a.wi, x0, x1, lx0, lx1);
+    xc0[threadIdx.x] = x0 - X1b; xc1[threadIdx.x] = x1 - X1b;
+    xl0[threadIdx.x] = lx0; xl1[threadIdx.x] = lx1;
+  } else if (threadIdx.x - PTW < R1w) {
+    const int c = threadIdx.x - PTW;
+    int u0, u1;
+    float n0, n1;
+    src_idx(s2x, X1b + c, a.wl, u0, u1, n0, n1);
+    cu0[c] = u0 - ub; cu1[c] = u1 - ub;
+    cn0[c] = n0; cn1[c] = n1;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ph * R1w; i += 256) {
+    const int v = i / R1w, c = i - v * R1w;
+    const float n0 = cn0[c], n1 = cn1[c];
+    const float h1 = patch[v * PR + cu0[c]] * n0 + patch[v * PR + cu1[c]] * n1;
+    H1[v * PX1 + c] = h1;
+  }
+  __syncthreads();
+
+  const long long HW = (long long)a.H * a.W;
+  unsigned inter = 0, uni = 0, minx = 0x7fffffff, miny = 0x7fffffff, maxx = 0, maxy = 0, any = 0;
+  if (Xb < a.W && Y < a.H) {
+    int y0, y1;
+    float ly0, ly1;
+    src_idx(sy1, Y, a.hi, y0, y1, ly0, ly1);
+    const int tyv[2] = {y0, y1};
+    float m0[2], m1[2];
+    const float* r0[2];
+    const float* r1[2];
+#pragma unroll
+    for (int iy = 0; iy < 2; ++iy) {
+      int v0, v1;
+      src_idx(s2y, tyv[iy], a.hl, v0, v1, m0[iy], m1[iy]);
+      r0[iy] = H1 + (v0 - vb) * PX1;
+      r1[iy] = H1 + (v1 - vb) * PX1;
+    }
+    unsigned bytes[PPX / 4] = {0, 0, 0, 0};
+    const int npx = min(PPX, a.W - Xb);
+    const long long pix0 = (long long)k * HW + (long long)Y * a.W + Xb;
+#pragma unroll
+    for (int p = 0; p < PPX; ++p) {
+      if (p < npx) {
+        const int X = Xb + p, xi = tx * PPX + p;
+        const float lx0 = xl0[xi], lx1 = xl1[xi];
+        const int txc[2] = {xc0[xi], xc1[xi]};
+        float tap[2][2];
+#pragma unroll
+        for (int ix = 0; ix < 2; ++ix) {
+#pragma unroll
+          for (int iy = 0; iy < 2; ++iy) {
+            const float top = r0[iy][txc[ix]];
+            const float bot = r1[iy][txc[ix]];
+            tap[iy][ix] = top * m0[iy] + bot * m1[iy];
+          }
+        }
+        const float top = tap[0][0] * lx0 + tap[0][1] * lx1;
+        const float bot = tap[1][0] * lx0 + tap[1][1] * lx1;
+        const float v = top * ly0 + bot * ly1;
+        const bool on = v > a.thr;
+        bytes[p >> 2] |= (on ? 1u : 0u) << (8 * (p & 3));
+        if (a.full_logits) a.full_logits[pix0 + p] = v;
+        inter += v > a.thr + a.off;
+        uni += v > a.thr - a.off;
+        if (on) { minx = min(minx, (unsigned)X); maxx = max(maxx, (unsigned)X); any = 1; }
+      }
+    }
+    if (any) miny = maxy = Y;
+    if (npx == PPX && (pix0 & 15) == 0) {
+      u32x4g w; w[0] = bytes[0]; w[1] = bytes[1]; w[2] = bytes[2]; w[3] = bytes[3];
+      *(u32x4g*)(a.masks + pix0) = w;
+    } else {
+      for (int p = 0; p < npx; ++p) a.masks[pix0 + p] = (uint8_t)((bytes[p >> 2] >> (8 * (p & 3))) & 1u);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    inter += __shfl_xor(inter, o);
+    uni += __shfl_xor(uni, o);
+    minx = min(minx, (unsigned)__shfl_xor(minx, o));
+    miny = min(miny, (unsigned)__shfl_xor(miny, o));
+    maxx = max(maxx, (unsigned)__shfl_xor(maxx, o));
+    maxy = max(maxy, (unsigned)__shfl_xor(maxy, o));
+    any |= __shfl_xor(any, o);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wave * 6 + 0] = inter; red[wave * 6 + 1] = uni;
+    red[wave * 6 + 2] = any ? minx : 0x7fffffffu; red[wave * 6 + 3] = any ? miny : 0x7fffffffu;
+    red[wave * 6 + 4] = any ? maxx : 0u; red[wave * 6 + 5] = any ? (maxy | 0x80000000u) : 0u;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned I = 0, U = 0, mnx = 0x7fffffff, mny = 0x7fffffff, mxx = 0, mxy = 0, has = 0;
+    for (int w = 0; w < 4; ++w) {
+      I += red[w * 6]; U += red[w * 6 + 1];
+      mnx = min(mnx, red[w * 6 + 2]); mny = min(mny, red[w * 6 + 3]);
+      if (red[w * 6 + 5] & 0x80000000u) { has = 1; mxx = max(mxx, red[w * 6 + 4]); mxy = max(mxy, red[w * 6 + 5] & 0x7fffffffu); }
+    }
+    unsigned* c = a.counters + (long long)k * 6;
+    if (I) atomicAdd(&c[0], I);
+    if (U) atomicAdd(&c[1], U);
+    if (has) {
+      atomicMin(&c[2], mnx); atomicMin(&c[3], mny);
+      atomicMax(&c[4], mxx); atomicMax(&c[5], mxy);
+    }
+  }
+}
+
+// host twin of src_idx (the same IEEE operations) and the test "does every tile of this geometry fit the shared tables"
+static void src_idx_host(float scale, int dst, int in_size, int& i0, int& i1) {
+  float f = fmaf(scale, dst + 0.5f, -0.5f);
+  f = f < 0.f ? 0.f : f;
+  i0 = (int)f;
+  i0 = i0 < in_size - 1 ? i0 : in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+}
+static bool postprocess_sep_fits(int out, int in1, int low, int S) {
+  const float s1 = (float)in1 / (float)out, s2 = (float)low / (float)S;
+  for (int o0 = 0; o0 < out; o0 += PTW) {
+    const int ol = (o0 + PTW - 1 < out ? o0 + PTW - 1 : out - 1);
+    int a0, a1, b0, b1, u0, u1, e0, e1;
+    src_idx_host(s1, o0, in1, a0, a1);
+    src_idx_host(s1, ol, in1, b0, b1);
+    if (b1 - a0 + 1 > PX1) return false;
+    src_idx_host(s2, a0, low, u0, u1);
+    src_idx_host(s2, b1, low, e0, e1);
+    if (e1 - u0 + 1 > PR) return false;
+  }
+  return true;
+}
+
 __global__ void init_counters_kernel(unsigned* c, int K) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
@@ -1039,7 +1234,13 @@ int hgl_sam_postprocess(const float* low_res, const float* iou_pred, int K, int 
   a.K = K; a.hl = hl; a.wl = wl; a.S = img_size; a.hi = in_h; a.wi = in_w; a.H = H; a.W = W;
   a.thr = mask_threshold; a.off = stability_offset;
   a.masks = masks; a.counters = counters; a.full_logits = full_logits;
-  hipLaunchKernelGGL(sam_postprocess_kernel, dim3((W + PTW - 1) / PTW, (H + PTH - 1) / PTH, K), dim3(256), 0, st, a);
+  const char* sep_env = getenv("HGL_SAM_POST_SEP");     // "0": the per-pixel kernel (A/B in tests: bit-identical outputs)
+  const bool sep_on = !(sep_env && sep_env[0] == '0');
+  const dim3 grid((W + PTW - 1) / PTW, (H + PTH - 1) / PTH, K);
+  if (sep_on && postprocess_sep_fits(W, in_w, wl, img_size) && postprocess_sep_fits(H, in_h, hl, img_size))
+    hipLaunchKernelGGL(sam_postprocess_sep_kernel, grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(sam_postprocess_kernel, grid, dim3(256), 0, st, a);
   hipLaunchKernelGGL(sam_finalize_kernel, dim3((K + 255) / 256), dim3(256), 0, st, counters, iou_pred, K,
                      pred_iou_thresh, stability_thresh, stability, (int*)boxes_xyxy, keep);
   return hgl_check_launch("sam_postprocess");

@@ -149,6 +149,34 @@ def test_predictor_prompt_kinds_vs_reference(cuda, tiny, golden_dir):
     assert torch.equal(a[2], low2) and torch.equal(a[1], iou2)
 
 
+@pytest.mark.parametrize("orig,inp,img,low", [((640, 640), (1024, 1024), 1024, 256), ((427, 640), (683, 1024), 1024, 256),
+                                               ((160, 200), (205, 256), 256, 64), ((1500, 2000), (768, 1024), 1024, 256),
+                                               ((97, 130), (764, 1024), 1024, 256)])
+def test_postprocess_shared_table_kernel_is_bit_identical(cuda, tiny, orig, inp, img, low):
+    """sam_postprocess_sep_kernel (per-tile column tables + the horizontally interpolated patch in LDS) against the per-pixel
+    kernel (HGL_SAM_POST_SEP=0): logits, masks, boxes and stability counters bit for bit, over down- and up-scaling size
+    ratios (the last geometry exceeds the shared tables: both calls take the per-pixel kernel)"""
+    m = tiny[1]
+    rng = np.random.default_rng(orig[0])
+    K = 7
+    lr = T((rng.standard_normal((K, low, low)) * 3).astype(np.float32), cuda)
+    iou = T(rng.random(K).astype(np.float32), cuda)
+    old_img = m.img_size
+    outs = []
+    try:
+        m.img_size = img
+        for flag in ("1", "0"):
+            os.environ["HGL_SAM_POST_SEP"] = flag
+            outs.append(m.postprocess(lr, iou, inp, orig, -1e30, 0.1, 1.0, return_logits=True) +
+                        m.postprocess(lr, iou, inp, orig, 0.5, 0.1, 1.0)[:4])     # with the IoU filter: no logits of the dropped
+    finally:
+        m.img_size = old_img
+        os.environ.pop("HGL_SAM_POST_SEP", None)
+    for x, y in zip(*outs):
+        assert torch.equal(torch.nan_to_num(x), torch.nan_to_num(y)) if x.dtype == torch.float32 else torch.equal(x, y)
+    assert outs[0][0].any()
+
+
 def test_tiny_postprocess_vs_reference(cuda, g, tiny):
     c = sam_tiny_case()
     m = tiny[1]
