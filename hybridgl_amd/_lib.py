@@ -87,7 +87,10 @@ class HglSamDecoderW(C.Structure):
                 ("hyper", (HglLinearW * 3) * 4), ("iou_head", HglLinearW * 3),
                 ("kvq1_w", C.c_void_p), ("kvq1_b", C.c_void_p), ("kvq1_pe", C.c_void_p),
                 ("kvf_w", C.c_void_p), ("kvf_b", C.c_void_p), ("kvf_pe", C.c_void_p),
-                ("point_embed_neg", C.c_void_p), ("point_embed_box0", C.c_void_p), ("point_embed_box1", C.c_void_p)]
+                ("point_embed_neg", C.c_void_p), ("point_embed_box0", C.c_void_p), ("point_embed_box1", C.c_void_p),
+                ("md_c1_w", C.c_void_p), ("md_c1_b", C.c_void_p), ("md_n1_w", C.c_void_p), ("md_n1_b", C.c_void_p),
+                ("md_c2_w", C.c_void_p), ("md_c2_b", C.c_void_p), ("md_n2_w", C.c_void_p), ("md_n2_b", C.c_void_p),
+                ("md_c3_w", C.c_void_p), ("md_c3_b", C.c_void_p)]
 
 
 
@@ -148,7 +151,8 @@ PROTOTYPES = {
     "hgl_sam_dense_pe": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _VP]),
     "hgl_sam_decode_workspace_bytes": (_SZ, [C.POINTER(HglSamDecoderW), _I]),
     "hgl_sam_decode_points": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _I, _VP, _VP, _VP, _SZ, _VP]),
-    "hgl_sam_decode_prompts": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "hgl_sam_decode_prompts": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _VP, _I, _VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "hgl_sam_embed_masks": (_I, [C.POINTER(HglSamDecoderW), _VP, _I, _VP, _VP]),
     "hgl_sam_decoder_fusion": (_I, [_I]),
     "hgl_sam_postprocess_workspace_bytes": (_SZ, [_I]),
     "hgl_sam_postprocess": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _VP, _VP, _VP, _VP, _VP,

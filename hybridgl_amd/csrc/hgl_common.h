@@ -202,8 +202,11 @@ int hgl_launch_add_rows_bcast(const float* a, long long a_bstride, const float* 
                               int B, float* out, hipStream_t st);
 int hgl_launch_pe(const float* coords01, const float* G, int n, int F, int mode, const float* pos_embed,
                   const float* not_a_point, float* out, hipStream_t st);
-int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const float* sparse, int P, int C,
+int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const float* sparse, int P, int C, int T,
                             float* tokens, hipStream_t st);
+int hgl_launch_mask_downscaling(const float* in, int P, int g, const float* c1w, const float* c1b, const float* n1w, const float* n1b,
+                                const float* c2w, const float* c2b, const float* n2w, const float* n2b, const float* c3w,
+                                const float* c3b, float* out, hipStream_t st);
 int hgl_launch_win_maps(int g, int ws, int nw, int nb, int* pad_of, int* tok_of, int* pad_list, int* pad_count, hipStream_t st);
 int hgl_launch_fill_rows(float* dst, int ld, const int* rows, const int* nrows, int max_rows, const float* v, int N,
                          hipStream_t st);

@@ -213,7 +213,7 @@ struct DecPlan {
 };
 
 bool carve_dec(HglArena& ar, const HglSamDecoderW* w, int P, DecPlan& p) {
-  const size_t C = w->C, HW = (size_t)w->grid * w->grid, T = 7;
+  const size_t C = w->C, HW = (size_t)w->grid * w->grid, T = 8;   // 5 output tokens + up to 3 sparse prompt tokens
   p.sparse = ar.take<float>((size_t)P * 2 * C);
   p.tokens = ar.take<float>(P * T * C);
   p.queries = ar.take<float>(P * T * C);
@@ -333,9 +333,9 @@ bool dec_x3_ready(const HglSamDecoderW* w) {
 // image -> token attention of one layer (transformer.py:139-150): q = (keys + pe) Wq, 7 token keys / values,
 // keys' = keys + out_proj(attn)   (LayerNorm follows in the caller)
 int dec_i2t_x3(const HglSamDecoderW* w, const HglSamAttnW& a, bool shared, const float* kpe0, const SplitPair& kpeS,
-               const float* tok_k, const float* tok_v, int P, int HW, float* qi, float* k1, float* v1, float* atti,
+               const float* tok_k, const float* tok_v, int P, int HW, int T, float* qi, float* k1, float* v1, float* atti,
                const float* R, int rmod, float* keys_out, hipStream_t st) {
-  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads, T = 7;
+  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads;
   if (shared) {
     HGL_TRY(lin(kpe0, C, a.q, nullptr, 0, qi, I, HW, I, C, HGL_ACT_NONE, st));
   } else {
@@ -354,9 +354,9 @@ int dec_i2t_x3(const HglSamDecoderW* w, const HglSamAttnW& a, bool shared, const
 
 // token -> image attention with per-prompt image tokens (transformer.py:126-131): K/V projections read the split planes
 int dec_t2i_x3(const HglSamDecoderW* w, const HglSamAttnW& a, const float* qpe, const SplitPair& kpeS, const SplitPair& keysS,
-               int P, int HW, float* q1, float* kp, float* vp, float* att, float* queries, float* scratch, size_t scratch_bytes,
-               hipStream_t st) {
-  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads, T = 7;
+               int P, int HW, int T, float* q1, float* kp, float* vp, float* att, float* queries, float* scratch,
+               size_t scratch_bytes, hipStream_t st) {
+  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads;
   HGL_TRY(lin(qpe, C, a.q, nullptr, 0, q1, I, P * T, I, C, HGL_ACT_NONE, st));
   HGL_TRY(hgl_launch_gemm_f16x3(kpeS.hi, kpeS.lo, C, a.k.w, a.k.b, nullptr, 0, kp, nullptr, nullptr, I, P * HW, I, C,
                                 HGL_ACT_NONE, st));
@@ -382,8 +382,8 @@ int dec_project_merged(const SplitPair& keysS, const float* W, const float* b, c
 
 // token -> image attention on merged projections: k = kvq[:, 0:I], v = kvq[:, I:2I], row stride ld
 int dec_t2i_merged(const HglSamDecoderW* w, const HglSamAttnW& a, const float* qpe, const float* kvq, int ld, int P, int HW,
-                   float* q1, float* att, float* queries, float* scratch, size_t scratch_bytes, hipStream_t st) {
-  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads, T = 7;
+                   int T, float* q1, float* att, float* queries, float* scratch, size_t scratch_bytes, hipStream_t st) {
+  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads;
   HGL_TRY(lin(qpe, C, a.q, nullptr, 0, q1, I, P * T, I, C, HGL_ACT_NONE, st));
   HGL_TRY(dec_fewq(q1, kvq, kvq + I, att, P, heads, T, HW, hd, I, ld, ld, I, (long long)T * I, (long long)HW * ld,
                    (long long)HW * ld, (long long)T * I, scratch, scratch_bytes, st));
@@ -392,8 +392,8 @@ int dec_t2i_merged(const HglSamDecoderW* w, const HglSamAttnW& a, const float* q
 
 // image -> token attention on merged projections: q = kvq[:, 2I:3I]
 int dec_i2t_merged(const HglSamDecoderW* w, const HglSamAttnW& a, const float* kvq, int ld, const float* tok_k, const float* tok_v,
-                   int P, int HW, float* k1, float* v1, float* atti, const float* R, float* keys_out, hipStream_t st) {
-  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads, T = 7;
+                   int P, int HW, int T, float* k1, float* v1, float* atti, const float* R, float* keys_out, hipStream_t st) {
+  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads;
   HGL_TRY(lin(tok_k, C, a.k, nullptr, 0, k1, I, P * T, I, C, HGL_ACT_NONE, st));
   HGL_TRY(lin(tok_v, C, a.v, nullptr, 0, v1, I, P * T, I, C, HGL_ACT_NONE, st));
   const SplitPair at = split_view(atti, (size_t)P * HW * I);
@@ -515,16 +515,18 @@ int hgl_sam_decoder_fusion(int mask) {
   return old;
 }
 
-// MaskDecoder.predict_masks for prompts of exactly two sparse tokens.  points01 != null: one foreground point + the padding
-// point per prompt (what SamAutomaticMaskGenerator issues); else coords01 [P,2,2] / labels [P,2].  first_mask = 1: the three
-// multimask outputs (mask tokens 1..3); 0: tokens 0..2 (token 0 is the single-mask output, mask_decoder.py:99-105).
+// MaskDecoder.predict_masks.  points01 != null: one foreground point + the padding point per prompt (what
+// SamAutomaticMaskGenerator issues); else coords01 [P,n_sparse,2] / labels [P,n_sparse] with n_sparse = 2 or 3 and, optionally,
+// dense [P,HW,C]: per-prompt dense embeddings (mask inputs) instead of no_mask_embed.  first_mask = 1: the three multimask
+// outputs (mask tokens 1..3); 0: tokens 0..2 (token 0 is the single-mask output, mask_decoder.py:99-105).
 static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* points01, const float* coords01,
-                       const int32_t* labels, int first_mask, int P, float* low_res, float* iou_pred, void* workspace,
-                       size_t workspace_bytes, void* stream) {
+                       const int32_t* labels, int n_sparse, const float* dense, int first_mask, int P, float* low_res,
+                       float* iou_pred, void* workspace, size_t workspace_bytes, void* stream) {
   HGL_TRY(hgl_require_device());
   HGL_REQUIRE(valid_dec(w) && w->dense_pe, "sam_decode: invalid weight struct (dense_pe missing?)");
   HGL_REQUIRE(emb && (points01 || (coords01 && labels)) && low_res && iou_pred && P > 0, "sam_decode: null input");
   HGL_REQUIRE(first_mask == 0 || first_mask == 1, "sam_decode: first_mask must be 0 or 1");
+  HGL_REQUIRE(n_sparse == 2 || n_sparse == 3, "sam_decode: %d sparse tokens per prompt (2 or 3 supported)", n_sparse);
   HglArena ar(workspace, workspace_bytes);
   DecPlan p;
   if (!workspace || !carve_dec(ar, w, P, p)) {
@@ -532,7 +534,8 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
     return HGL_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int C = w->C, g = w->grid, HW = g * g, T = 7;
+  const int C = w->C, g = w->grid, HW = g * g, T = 5 + n_sparse;
+  const bool perprompt = dense != nullptr;     // the image tokens differ from prompt to prompt already in layer 0
   const long long sQ = (long long)T * C, sK = (long long)HW * C;
   const size_t atti_bytes = (size_t)P * HW * (C / 2) * sizeof(float);
 
@@ -542,12 +545,18 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
   } else {
     const float* pe4[4] = {w->point_embed_neg, w->point_embed_pos, w->point_embed_box0, w->point_embed_box1};
     HGL_REQUIRE(pe4[0] && pe4[2] && pe4[3], "sam_decode_prompts: the weight struct lacks point_embeddings 0 / 2 / 3");
-    HGL_TRY(hgl_launch_pe_labeled(coords01, labels, w->pe_gauss, 2 * P, C / 2, w->not_a_point, pe4, p.sparse, st));
+    HGL_TRY(hgl_launch_pe_labeled(coords01, labels, w->pe_gauss, n_sparse * P, C / 2, w->not_a_point, pe4, p.sparse, st));
   }
-  HGL_TRY(hgl_launch_build_tokens(w->iou_token, w->mask_tokens, p.sparse, P, C, p.tokens, st));
-  // src = image_embedding + no_mask_embed (dense prompt) ; shared by all prompts until the first update
-  HGL_TRY(hgl_launch_add_rows_bcast(emb, C, w->no_mask, C, HW, p.keys0, st));   // rows of C, "pe" = no_mask [C]
-  HGL_TRY(hgl_launch_add_rows_bcast(p.keys0, 0, w->dense_pe, (long long)HW * C, 1, p.kpe0, st));
+  HGL_TRY(hgl_launch_build_tokens(w->iou_token, w->mask_tokens, p.sparse, P, C, T, p.tokens, st));
+  if (perprompt) {
+    // src[p] = image_embedding + dense[p] (mask_decoder.py:121-123 with dense_prompt_embeddings from mask inputs)
+    HGL_TRY(hgl_launch_add_rows_bcast(dense, sK, emb, sK, P, p.keys, st));
+    HGL_TRY(hgl_launch_add_rows_bcast(p.keys, sK, w->dense_pe, sK, P, p.kpe, st));
+  } else {
+    // src = image_embedding + no_mask_embed (dense prompt) ; shared by all prompts until the first update
+    HGL_TRY(hgl_launch_add_rows_bcast(emb, C, w->no_mask, C, HW, p.keys0, st));   // rows of C, "pe" = no_mask [C]
+    HGL_TRY(hgl_launch_add_rows_bcast(p.keys0, 0, w->dense_pe, (long long)HW * C, 1, p.kpe0, st));
+  }
   (void)hipMemcpyAsync(p.queries, p.tokens, sizeof(float) * P * sQ, hipMemcpyDeviceToDevice, st);
 
   const bool x3 = dec_x3_ready(w);
@@ -557,7 +566,9 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
   const SplitPair keysS = split_view(p.keysS, (size_t)P * HW * C), kpeS = split_view(p.kpe, (size_t)P * HW * C);
   for (int li = 0; li < 2; ++li) {
     const auto& L = w->layer[li];
-    const bool shared = li == 0;   // keys identical for every prompt in layer 0
+    const bool shared = li == 0 && !perprompt;   // keys identical for every prompt in layer 0
+    // layer 0 on per-prompt image tokens: the plain fp32 launches (the split planes / merged weights belong to layer 1's input)
+    const bool plain0 = li == 0 && perprompt;
     const float* keys = shared ? p.keys0 : p.keys;
     const float* kpe = shared ? p.kpe0 : p.kpe;
     // (1) self attention of the tokens
@@ -573,12 +584,12 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
     HGL_TRY(hgl_launch_layernorm(p.queries, L.n1.w, L.n1.b, p.queries, P * T, C, 1e-5f, st));
     // (2) tokens attend to the image
     HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
-    if (merged && !shared) {
+    if (merged && !shared && !plain0) {
       // k, v of this step and q of step (4) read the same rows: one GEMM, the positional encoding as a per-position table
       HGL_TRY(dec_project_merged(keysS, w->kvq1_w, w->kvq1_b, w->kvq1_pe, P, HW, C, 3 * I1, p.kp, st));
-      HGL_TRY(dec_t2i_merged(w, L.t2i, p.qpe, p.kp, 3 * I1, P, HW, p.q1, p.att, p.queries, p.atti, atti_bytes, st));
-    } else if (x3 && !shared) {
-      HGL_TRY(dec_t2i_x3(w, L.t2i, p.qpe, kpeS, keysS, P, HW, p.q1, p.kp, p.vp, p.att, p.queries, p.atti, atti_bytes, st));
+      HGL_TRY(dec_t2i_merged(w, L.t2i, p.qpe, p.kp, 3 * I1, P, HW, T, p.q1, p.att, p.queries, p.atti, atti_bytes, st));
+    } else if (x3 && !shared && !plain0) {
+      HGL_TRY(dec_t2i_x3(w, L.t2i, p.qpe, kpeS, keysS, P, HW, T, p.q1, p.kp, p.vp, p.att, p.queries, p.atti, atti_bytes, st));
     } else {
       HGL_TRY(dec_attn(w, L.t2i, p.qpe, false, T, kpe, keys, shared, HW, P, p.q1, p.kp, p.vp, p.att, p.queries, sQ,
                        p.queries, st, p.atti, atti_bytes));
@@ -591,7 +602,7 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
     // (4) image attends to the tokens: q = keys+pe, k = queries+pe, v = queries ; keys += out
     HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
     const bool fuse_i2t = merged && (dec_fusion_mask() & 4) && L.i2t.internal == I1 && I1 == 128 && w->heads == 8 &&
-                          HW % 64 == 0 && P <= 65535;
+                          HW % 64 == 0 && P <= 65535 && T == 7 && !plain0;
     if (fuse_i2t) {
       // attention over the 7 tokens, out-projection, residual and norm4 in one launch: the image tokens leave it as the
       // split planes the next projections read (and, in layer 0, as the fp32 rows layer 1 adds its update to)
@@ -601,11 +612,15 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
       HGL_TRY(hgl_launch_dec_i2t(shared ? p.qi : p.kp + 2 * I1, shared ? I1 : 3 * I1, shared ? 0 : (long long)HW * 3 * I1, p.k1,
                                  p.v1, L.i2t.out.w, L.i2t.out.b, keys, shared ? 0 : sK, L.n4.w, L.n4.b, 1e-5f,
                                  1.0f / sqrtf((float)(I1 / w->heads)), P, HW, li == 0 ? p.keys : nullptr, keysS.hi, keysS.lo, st));
+    } else if (x3 && plain0) {
+      HGL_TRY(dec_attn(w, L.i2t, kpe, false, HW, p.qpe, p.queries, false, T, P, p.qi, p.k1, p.v1, p.atti, keys, sK, p.keys, st));
+      HGL_TRY(hgl_launch_ln256_pe_split(p.keys, L.n4.w, L.n4.b, w->dense_pe, HW, (long long)P * HW, 1e-5f, 1, keysS.hi, keysS.lo,
+                                        merged ? nullptr : kpeS.hi, merged ? nullptr : kpeS.lo, st));
     } else if (x3) {
       if (merged && !shared) {
-        HGL_TRY(dec_i2t_merged(w, L.i2t, p.kp, 3 * I1, p.qpe, p.queries, P, HW, p.k1, p.v1, p.atti, keys, p.keys, st));
+        HGL_TRY(dec_i2t_merged(w, L.i2t, p.kp, 3 * I1, p.qpe, p.queries, P, HW, T, p.k1, p.v1, p.atti, keys, p.keys, st));
       } else {
-        HGL_TRY(dec_i2t_x3(w, L.i2t, shared, p.kpe0, kpeS, p.qpe, p.queries, P, HW, p.qi, p.k1, p.v1, p.atti, keys,
+        HGL_TRY(dec_i2t_x3(w, L.i2t, shared, p.kpe0, kpeS, p.qpe, p.queries, P, HW, T, p.qi, p.k1, p.v1, p.atti, keys,
                            shared ? HW : 0, p.keys, st));
       }
       // norm4, then keys (and, unmerged, keys + dense_pe) as split planes; the fp32 rows are kept only while a later layer
@@ -623,9 +638,9 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
   HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
   if (merged) {
     HGL_TRY(dec_project_merged(keysS, w->kvf_w, w->kvf_b, w->kvf_pe, P, HW, C, 2 * I1, p.kp, st));
-    HGL_TRY(dec_t2i_merged(w, w->final_t2i, p.qpe, p.kp, 2 * I1, P, HW, p.q1, p.att, p.queries, p.atti, atti_bytes, st));
+    HGL_TRY(dec_t2i_merged(w, w->final_t2i, p.qpe, p.kp, 2 * I1, P, HW, T, p.q1, p.att, p.queries, p.atti, atti_bytes, st));
   } else if (x3) {
-    HGL_TRY(dec_t2i_x3(w, w->final_t2i, p.qpe, kpeS, keysS, P, HW, p.q1, p.kp, p.vp, p.att, p.queries, p.atti, atti_bytes, st));
+    HGL_TRY(dec_t2i_x3(w, w->final_t2i, p.qpe, kpeS, keysS, P, HW, T, p.q1, p.kp, p.vp, p.att, p.queries, p.atti, atti_bytes, st));
   } else {
     HGL_TRY(dec_attn(w, w->final_t2i, p.qpe, false, T, p.kpe, p.keys, false, HW, P, p.q1, p.kp, p.vp, p.att, p.queries,
                      sQ, p.queries, st, p.atti, atti_bytes));
@@ -678,14 +693,25 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
 int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float* points01, int P, float* low_res,
                           float* iou_pred, void* workspace, size_t workspace_bytes, void* stream) {
   HGL_REQUIRE(points01, "sam_decode: null input");
-  return decode_impl(w, emb, points01, nullptr, nullptr, 1, P, low_res, iou_pred, workspace, workspace_bytes, stream);
+  return decode_impl(w, emb, points01, nullptr, nullptr, 2, nullptr, 1, P, low_res, iou_pred, workspace, workspace_bytes, stream);
 }
 
-int hgl_sam_decode_prompts(const HglSamDecoderW* w, const float* emb, const float* coords01, const int32_t* labels,
-                           int first_mask, int P, float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes,
-                           void* stream) {
+int hgl_sam_decode_prompts(const HglSamDecoderW* w, const float* emb, const float* coords01, const int32_t* labels, int n_sparse,
+                           const float* dense, int first_mask, int P, float* low_res, float* iou_pred, void* workspace,
+                           size_t workspace_bytes, void* stream) {
   HGL_REQUIRE(coords01 && labels, "sam_decode_prompts: null input");
-  return decode_impl(w, emb, nullptr, coords01, labels, first_mask, P, low_res, iou_pred, workspace, workspace_bytes, stream);
+  return decode_impl(w, emb, nullptr, coords01, labels, n_sparse, dense, first_mask, P, low_res, iou_pred, workspace,
+                     workspace_bytes, stream);
+}
+
+int hgl_sam_embed_masks(const HglSamDecoderW* w, const float* mask_input, int P, float* dense, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(w && mask_input && dense && P > 0 && P <= 65535, "sam_embed_masks: bad arguments");
+  HGL_REQUIRE(w->md_c1_w && w->md_c1_b && w->md_n1_w && w->md_n1_b && w->md_c2_w && w->md_c2_b && w->md_n2_w && w->md_n2_b &&
+              w->md_c3_w && w->md_c3_b, "sam_embed_masks: the weight struct lacks mask_downscaling");
+  HGL_REQUIRE(w->C == 256, "sam_embed_masks: embedding width %d unsupported", w->C);
+  return hgl_launch_mask_downscaling(mask_input, P, w->grid, w->md_c1_w, w->md_c1_b, w->md_n1_w, w->md_n1_b, w->md_c2_w, w->md_c2_b,
+                                     w->md_n2_w, w->md_n2_b, w->md_c3_w, w->md_c3_b, dense, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -364,19 +364,89 @@ __global__ __launch_bounds__(256) void pe_labeled_kernel(const float* __restrict
   out[(long long)r * 2 * F + f + F] = c + e[f + F];
 }
 
-// tokens[p, 0] = iou_token; tokens[p, 1..4] = mask_tokens; tokens[p, 5..6] = sparse[p, 0..1]
+// tokens[p, 0] = iou_token; tokens[p, 1..4] = mask_tokens; tokens[p, 5..T-1] = sparse[p, 0..T-6]
 __global__ __launch_bounds__(256) void build_tokens_kernel(const float* __restrict__ iou_tok,
                                                            const float* __restrict__ mask_tok,
-                                                           const float* __restrict__ sparse, int P, int C,
+                                                           const float* __restrict__ sparse, int P, int C, int T,
                                                            float* __restrict__ tokens) {
   const long long i = blockIdx.x * 256ll + threadIdx.x;
-  if (i >= (long long)P * 7 * C) return;
-  const int c = (int)(i % C), t = (int)((i / C) % 7), p = (int)(i / (7ll * C));
+  if (i >= (long long)P * T * C) return;
+  const int c = (int)(i % C), t = (int)((i / C) % T), p = (int)(i / ((long long)T * C));
   float v;
   if (t == 0) v = iou_tok[c];
   else if (t < 5) v = mask_tok[(t - 1) * C + c];
-  else v = sparse[((long long)p * 2 + (t - 5)) * C + c];
+  else v = sparse[((long long)p * (T - 5) + (t - 5)) * C + c];
   tokens[i] = v;
+}
+
+// PromptEncoder.mask_downscaling (prompt_encoder.py:57-66, :103-106) on mask inputs [P,1,4g,4g] -> dense rows [P, g*g, 256]:
+// Conv2d(1,4,k2,s2) + LayerNorm2d(4) + GELU + Conv2d(4,16,k2,s2) + LayerNorm2d(16) + GELU + Conv2d(16,256,k1).  64 threads
+// per output pixel: each evaluates the pixel's 16 mid channels from its 4x4 input block (a few hundred flops), then writes
+// four of the 256 output channels.  Off the hot path (SamPredictor with mask_input).
+__global__ __launch_bounds__(256) void mask_downscaling_kernel(const float* __restrict__ in, int g, const float* __restrict__ c1w,
+                                                               const float* __restrict__ c1b, const float* __restrict__ n1w,
+                                                               const float* __restrict__ n1b, const float* __restrict__ c2w,
+                                                               const float* __restrict__ c2b, const float* __restrict__ n2w,
+                                                               const float* __restrict__ n2b, const float* __restrict__ c3w,
+                                                               const float* __restrict__ c3b, float* __restrict__ out) {
+  const int p = blockIdx.y, pix = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
+  if (pix >= g * g) return;
+  const int y = pix / g, x = pix - y * g, S = 4 * g;
+  const float* src = in + ((long long)p * S + 4 * y) * S + 4 * x;
+  float a1[4][4];                                    // [position dy*2+dx][channel]
+#pragma unroll
+  for (int pos = 0; pos < 4; ++pos) {
+    const int dy = pos >> 1, dx = pos & 1;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float acc = c1b[c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc += c1w[c * 4 + k] * src[(long long)(2 * dy + (k >> 1)) * S + 2 * dx + (k & 1)];
+      v[c] = acc;
+    }
+    const float mean = ((v[0] + v[1]) + (v[2] + v[3])) * 0.25f;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) var += (v[c] - mean) * (v[c] - mean);
+    const float rs = 1.0f / sqrtf(var * 0.25f + 1e-6f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float u = n1w[c] * ((v[c] - mean) * rs) + n1b[c];
+      a1[pos][c] = 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
+    }
+  }
+  float a2[16];
+  float mean = 0.f;
+#pragma unroll
+  for (int c2 = 0; c2 < 16; ++c2) {
+    float acc = c2b[c2];
+#pragma unroll
+    for (int c1 = 0; c1 < 4; ++c1)
+#pragma unroll
+      for (int pos = 0; pos < 4; ++pos) acc += c2w[(c2 * 4 + c1) * 4 + pos] * a1[pos][c1];
+    a2[c2] = acc;
+    mean += acc;
+  }
+  mean *= (1.0f / 16.0f);
+  float var = 0.f;
+#pragma unroll
+  for (int c2 = 0; c2 < 16; ++c2) var += (a2[c2] - mean) * (a2[c2] - mean);
+  const float rs = 1.0f / sqrtf(var * (1.0f / 16.0f) + 1e-6f);
+#pragma unroll
+  for (int c2 = 0; c2 < 16; ++c2) {
+    const float u = n2w[c2] * ((a2[c2] - mean) * rs) + n2b[c2];
+    a2[c2] = 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
+  }
+  float* dst = out + ((long long)p * g * g + pix) * 256;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = sub + 64 * j;
+    float acc = c3b[c];
+#pragma unroll
+    for (int c2 = 0; c2 < 16; ++c2) acc += c3w[c * 16 + c2] * a2[c2];
+    dst[c] = acc;
+  }
 }
 
 __device__ __forceinline__ float wsum(float v) {
@@ -1156,10 +1226,17 @@ int hgl_launch_pe_labeled(const float* coords01, const int32_t* labels, const fl
   hipLaunchKernelGGL(pe_labeled_kernel, dim3(grid1((long long)n * F)), dim3(256), 0, st, coords01, labels, G, n, F, tab, out);
   return hgl_check_launch("pe_labeled");
 }
-int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const float* sparse, int P, int C,
+int hgl_launch_build_tokens(const float* iou_tok, const float* mask_tok, const float* sparse, int P, int C, int T,
                             float* tokens, hipStream_t st) {
-  hipLaunchKernelGGL(build_tokens_kernel, dim3(grid1((long long)P * 7 * C)), dim3(256), 0, st, iou_tok, mask_tok, sparse, P, C, tokens);
+  hipLaunchKernelGGL(build_tokens_kernel, dim3(grid1((long long)P * T * C)), dim3(256), 0, st, iou_tok, mask_tok, sparse, P, C, T, tokens);
   return hgl_check_launch("build_tokens");
+}
+int hgl_launch_mask_downscaling(const float* in, int P, int g, const float* c1w, const float* c1b, const float* n1w, const float* n1b,
+                                const float* c2w, const float* c2b, const float* n2w, const float* n2b, const float* c3w,
+                                const float* c3b, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(mask_downscaling_kernel, dim3((unsigned)((g * g + 3) / 4), (unsigned)P), dim3(256), 0, st, in, g, c1w, c1b, n1w,
+                     n1b, c2w, c2b, n2w, n2b, c3w, c3b, out);
+  return hgl_check_launch("mask_downscaling");
 }
 int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long rows, float eps, void* hi, void* lo,
                          hipStream_t st) {

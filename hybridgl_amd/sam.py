@@ -100,6 +100,13 @@ class Sam:
         dec.point_embed_neg = t(np.asarray(sd[f"{pe}.point_embeddings.0.weight"]).reshape(-1))
         dec.point_embed_box0 = t(np.asarray(sd[f"{pe}.point_embeddings.2.weight"]).reshape(-1))
         dec.point_embed_box1 = t(np.asarray(sd[f"{pe}.point_embeddings.3.weight"]).reshape(-1))
+        if f"{pe}.mask_downscaling.0.weight" in sd and tuple(np.asarray(sd[f"{pe}.mask_downscaling.3.weight"]).shape) == (16, 4, 2, 2):
+            md = f"{pe}.mask_downscaling"                      # prompt_encoder.py:57-66 (mask_in_chans = 16)
+            for dst, key, shape in (("md_c1_w", "0.weight", (4, 4)), ("md_c1_b", "0.bias", (4,)), ("md_n1_w", "1.weight", (4,)),
+                                    ("md_n1_b", "1.bias", (4,)), ("md_c2_w", "3.weight", (16, 16)), ("md_c2_b", "3.bias", (16,)),
+                                    ("md_n2_w", "4.weight", (16,)), ("md_n2_b", "4.bias", (16,)),
+                                    ("md_c3_w", "6.weight", (Cc, 16)), ("md_c3_b", "6.bias", (Cc,))):
+                setattr(dec, dst, t(np.asarray(sd[f"{md}.{key}"]).reshape(shape)))
         dec.no_mask = t(np.asarray(sd[f"{pe}.no_mask_embed.weight"]).reshape(-1))
         dec.iou_token = t(np.asarray(sd[f"{m}.iou_token.weight"]).reshape(-1))
         dec.mask_tokens = t(sd[f"{m}.mask_tokens.weight"])
@@ -240,24 +247,37 @@ class Sam:
               "hgl_sam_decode_points")
         return low, iou
 
-    def decode_prompts(self, emb, coords01, labels, first_mask=1):
-        """prompts of exactly two sparse tokens (prompt_encoder.py:73-101): coords01 [P,2,2] fp32 device
-        ((coordinate + 0.5) / img_size), labels [P,2] int32 (-1 padding, 0 / 1 background / foreground point, 2 / 3 box
-        corners); first_mask 1 -> mask tokens 1..3 (multimask), 0 -> tokens 0..2 (column 0 = the single-mask output)
-        -> (low_res [P,3,4g,4g], iou [P,3])."""
+    def decode_prompts(self, emb, coords01, labels, first_mask=1, dense=None):
+        """prompts of two or three sparse tokens (prompt_encoder.py:73-101): coords01 [P,n,2] fp32 device
+        ((coordinate + 0.5) / img_size), labels [P,n] int32 (-1 padding, 0 / 1 background / foreground point, 2 / 3 box
+        corners); dense: None or [P, g*g, C] from embed_masks; first_mask 1 -> mask tokens 1..3 (multimask), 0 -> tokens 0..2
+        (column 0 = the single-mask output) -> (low_res [P,3,4g,4g], iou [P,3])."""
         lib = _lib.load()
         ops.use_precision(self.precision)
-        P = coords01.shape[0]
+        P, n = int(coords01.shape[0]), int(coords01.shape[1])
         need = lib.hgl_sam_decode_workspace_bytes(C.byref(self.dec_w), P)
         ws = ops.workspace(need, self.device, "sam_decode")
         g4 = 4 * self.grid
         low = torch.empty((P, 3, g4, g4), dtype=torch.float32, device=self.device)
         iou = torch.empty((P, 3), dtype=torch.float32, device=self.device)
         check(lib.hgl_sam_decode_prompts(C.byref(self.dec_w), ops._dev(emb, torch.float32, "emb"),
-                                         ops._dev(coords01, torch.float32, "coords01"), ops._dev(labels, torch.int32, "labels"),
+                                         ops._dev(coords01, torch.float32, "coords01"), ops._dev(labels, torch.int32, "labels"), n,
+                                         None if dense is None else ops._dev(dense, torch.float32, "dense"),
                                          int(first_mask), P, low.data_ptr(), iou.data_ptr(), ws.data_ptr(), ws.numel(),
                                          ops._stream()), "hgl_sam_decode_prompts")
         return low, iou
+
+    def embed_masks(self, mask_input):
+        """PromptEncoder._embed_masks (prompt_encoder.py:103-106): [P,1,4g,4g] fp32 device -> dense rows [P, g*g, C]"""
+        lib = _lib.load()
+        P = int(mask_input.shape[0])
+        g4 = 4 * self.grid
+        if tuple(mask_input.shape) != (P, 1, g4, g4):
+            raise ValueError(f"mask_input must be [P,1,{g4},{g4}], got {tuple(mask_input.shape)}")
+        dense = torch.empty((P, self.grid * self.grid, self.dec_w.C), dtype=torch.float32, device=self.device)
+        check(lib.hgl_sam_embed_masks(C.byref(self.dec_w), ops._dev(mask_input, torch.float32, "mask_input"), P, dense.data_ptr(),
+                                      ops._stream()), "hgl_sam_embed_masks")
+        return dense
 
     def postprocess(self, low_res, iou_pred, input_size, original_size, pred_iou_thresh=-1e30,
                     stability_thresh=0.0, stability_offset=1.0, return_logits=False):
@@ -462,11 +482,11 @@ class ResizeLongestSide:
 
 
 class SamPredictor:
-    """predictor.py:17-269: set_image, predict_torch, predict.  Prompts of exactly two sparse tokens run on the device
-    decoder: ONE point per prompt (foreground or background; the padding point is the second token -- what
-    automatic_mask_generator.py:269-285 issues), or ONE box per prompt (its two corners); multimask_output True or False.
-    Several points per prompt, points together with a box (other token counts) and mask_input (per-prompt dense
-    embeddings) are not on the reference's path and raise NotImplementedError."""
+    """predictor.py:17-269: set_image, predict_torch, predict.  Prompts of two or three sparse tokens run on the device
+    decoder: one or two points per prompt (foreground / background; the padding point follows them), one box (its two
+    corners), or one point and a box; optionally a mask input per prompt (per-prompt dense embeddings); multimask_output
+    True or False.  More sparse tokens per prompt (three or more points, two points and a box) raise NotImplementedError:
+    the reference's own path (automatic_mask_generator.py:269-285) issues one foreground point per prompt."""
 
     def __init__(self, sam_model):
         self.model = sam_model
@@ -503,43 +523,55 @@ class SamPredictor:
 
     def predict_torch(self, point_coords, point_labels, boxes=None, mask_input=None, multimask_output=True,
                       return_logits=False):
-        """predictor.py:169-243.  point_coords [P,1,2] in the resized frame (transform.apply_coords) with point_labels [P,1]
-        in {0, 1}, OR boxes [P,4] XYXY in the resized frame (transform.apply_boxes).  Returns (masks [P,C,H,W] bool or
-        logits, iou_predictions [P,C], low_res_masks [P,C,4g,4g]) with C = 3 (multimask_output) or 1."""
+        """predictor.py:169-243.  point_coords [P,N,2] in the resized frame (transform.apply_coords) with point_labels [P,N]
+        in {0, 1}, and / or boxes [P,4] XYXY in the resized frame (transform.apply_boxes), and / or mask_input [P,1,4g,4g]
+        (low-resolution logits of an earlier call).  Up to three sparse tokens per prompt: one or two points (the padding
+        point follows them when there is no box), a box, or one point and a box.  Returns (masks [P,C,H,W] bool or logits,
+        iou_predictions [P,C], low_res_masks [P,C,4g,4g]) with C = 3 (multimask_output) or 1."""
         if not self.is_image_set:
             raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")   # predictor.py:214
-        if mask_input is not None:
-            raise NotImplementedError("mask_input (per-prompt dense embeddings) is not on the reference's path")
-        if (point_coords is None) == (boxes is None):
-            raise NotImplementedError("one point per prompt OR one box per prompt (two sparse tokens); got "
-                                      + ("both" if boxes is not None else "neither"))
-        if boxes is not None:
-            b = torch.as_tensor(boxes, device=self.device)
-            if b.dim() != 2 or b.shape[1] != 4:
-                raise ValueError(f"boxes must be [P,4] (XYXY), got {tuple(b.shape)}")
-            c01 = self._coords01(b.reshape(-1, 2, 2))                                   # prompt_encoder.py:93-101
-            labels = torch.tensor([2, 3], dtype=torch.int32, device=self.device).repeat(b.shape[0], 1)
-            fast = False
-        else:
+        toks, labs = [], []
+        P = None
+        if point_coords is not None:
             pc = torch.as_tensor(point_coords, device=self.device)
             pl = torch.as_tensor(point_labels, device=self.device)
-            if pc.dim() != 3 or pc.shape[1] != 1 or pl.shape != pc.shape[:2]:
-                raise NotImplementedError("one point per prompt: point_coords [P,1,2], point_labels [P,1]")
-            if not bool(((pl == 0) | (pl == 1)).all()):
-                raise ValueError("point_labels must be 0 (background) or 1 (foreground)")
-            fast = multimask_output and bool((pl == 1).all())
-            p01 = self._coords01(pc[:, 0, :]).contiguous()
-            if not fast:
-                c01 = torch.stack([p01, torch.zeros_like(p01)], dim=1)                   # the padding point (label -1)
-                labels = torch.stack([pl[:, 0].to(torch.int32), torch.full_like(pl[:, 0], -1, dtype=torch.int32)], dim=1)
-        if fast:
-            low, iou = self.model.decode_points(self.features, p01)
+            if pc.dim() != 3 or pc.shape[2] != 2 or pl.shape != pc.shape[:2]:
+                raise ValueError(f"point_coords must be [P,N,2] with point_labels [P,N], got {tuple(pc.shape)} / {tuple(pl.shape)}")
+            if not bool(((pl == 0) | (pl == 1) | (pl == -1)).all()):
+                raise ValueError("point_labels must be 1 (foreground), 0 (background) or -1 (padding)")
+            P = int(pc.shape[0])
+            toks.append(self._coords01(pc))
+            labs.append(pl.to(torch.int32))
+            if boxes is None:                                                            # prompt_encoder.py:80-84: padding point
+                toks.append(torch.zeros((P, 1, 2), dtype=torch.float32, device=self.device))
+                labs.append(torch.full((P, 1), -1, dtype=torch.int32, device=self.device))
+        if boxes is not None:
+            b = torch.as_tensor(boxes, device=self.device)
+            if b.dim() != 2 or b.shape[1] != 4 or (P is not None and b.shape[0] != P):
+                raise ValueError(f"boxes must be [P,4] (XYXY), got {tuple(b.shape)}")
+            P = int(b.shape[0])
+            toks.append(self._coords01(b.reshape(-1, 2, 2)))                              # prompt_encoder.py:93-101
+            labs.append(torch.tensor([2, 3], dtype=torch.int32, device=self.device).repeat(P, 1))
+        if P is None:
+            raise NotImplementedError("a prompt needs points and / or a box (a mask input alone has no sparse tokens)")
+        c01, labels = torch.cat(toks, dim=1).contiguous(), torch.cat(labs, dim=1).contiguous()
+        if c01.shape[1] > 3:
+            raise NotImplementedError(f"{c01.shape[1]} sparse tokens per prompt: up to three are supported (two points, or a "
+                                      "point and a box)")
+        dense = None
+        if mask_input is not None:
+            mi = torch.as_tensor(mask_input, device=self.device).to(torch.float32)
+            if mi.shape[0] != P:
+                raise ValueError(f"mask_input must have one mask per prompt ({P}), got {tuple(mi.shape)}")
+            dense = self.model.embed_masks(mi.contiguous())
+        fast = (dense is None and boxes is None and multimask_output and c01.shape[1] == 2 and bool((labels[:, 0] == 1).all()))
+        if fast:                                                                          # the automatic generator's prompts
+            low, iou = self.model.decode_points(self.features, c01[:, 0, :].contiguous())
         else:
-            low, iou = self.model.decode_prompts(self.features, c01.contiguous(), labels.contiguous(),
-                                                 first_mask=1 if multimask_output else 0)
+            low, iou = self.model.decode_prompts(self.features, c01, labels, first_mask=1 if multimask_output else 0, dense=dense)
             if not multimask_output:
                 low, iou = low[:, :1].contiguous(), iou[:, :1].contiguous()
-        P, Cm = low.shape[0], low.shape[1]
+        Cm = low.shape[1]
         H, W = self.original_size
         _, _, _, _, full = self.model.postprocess(low.flatten(0, 1), iou.flatten(), self.input_size, (H, W), -1e30, 0.0, 1.0,
                                                   return_logits=True)
@@ -549,11 +581,9 @@ class SamPredictor:
 
     def predict(self, point_coords=None, point_labels=None, box=None, mask_input=None, multimask_output=True,
                 return_logits=False):
-        """predictor.py:90-167 for one prompt: a point [1,2] with its label [1], or a box [4] (XYXY, original frame):
-        numpy in, numpy out ([C,H,W], [C], [C,4g,4g])."""
-        if mask_input is not None:
-            raise NotImplementedError("mask_input is not on the reference's path")
-        pc = pl = bx = None
+        """predictor.py:90-167 for one prompt: points [N,2] with labels [N] (N <= 2; N <= 1 together with a box), a box [4]
+        (XYXY), both in the original frame, mask_input [1,4g,4g]: numpy in, numpy out ([C,H,W], [C], [C,4g,4g])."""
+        pc = pl = bx = mi = None
         if point_coords is not None:
             assert point_labels is not None, "point_labels must be supplied if point_coords is supplied."
             pts = self.transform.apply_coords(np.asarray(point_coords, dtype=np.float64), self.original_size)
@@ -562,7 +592,9 @@ class SamPredictor:
         if box is not None:
             bx = torch.as_tensor(self.transform.apply_boxes(np.asarray(box, dtype=np.float64), self.original_size),
                                  dtype=torch.float32).reshape(1, 4)
-        m, iou, low = self.predict_torch(pc, pl, bx, None, multimask_output=multimask_output, return_logits=return_logits)
+        if mask_input is not None:
+            mi = torch.as_tensor(np.asarray(mask_input), dtype=torch.float32)[None, :, :, :]
+        m, iou, low = self.predict_torch(pc, pl, bx, mi, multimask_output=multimask_output, return_logits=return_logits)
         return m[0].cpu().numpy(), iou[0].cpu().numpy(), low[0].cpu().numpy()
 
 

@@ -385,6 +385,9 @@ typedef struct HglSamDecoderW {        /* prompt_encoder.py + mask_decoder.py + 
   /* Optional (NULL = not provided): the other label embeddings of the prompt encoder, [C] each: point_embeddings[0]
    * (background point), [2] / [3] (box corners) -- needed by hgl_sam_decode_prompts only (prompt_encoder.py:40-42). */
   const float *point_embed_neg, *point_embed_box0, *point_embed_box1;
+  /* Optional: PromptEncoder.mask_downscaling (prompt_encoder.py:57-66) for hgl_sam_embed_masks: Conv2d(1,4,k2,s2) [4,4] / [4],
+   * LayerNorm2d(4), Conv2d(4,16,k2,s2) [16,16 = (c_in,ky,kx)] / [16], LayerNorm2d(16), Conv2d(16,C,k1) [C,16] / [C]. */
+  const float *md_c1_w, *md_c1_b, *md_n1_w, *md_n1_b, *md_c2_w, *md_c2_b, *md_n2_w, *md_n2_b, *md_c3_w, *md_c3_b;
 } HglSamDecoderW;
 
 /* ResizeLongestSide.apply_image (utils/transforms.py:26-31) = Pillow Image.resize(BILINEAR) on uint8 HWC,
@@ -421,16 +424,21 @@ size_t hgl_sam_decode_workspace_bytes(const HglSamDecoderW* w, int P);
 int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float* points01, int P,
                           float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes,
                           void* stream);
-/* The same for any prompt of exactly TWO sparse tokens (PromptEncoder._embed_points / _embed_boxes, prompt_encoder.py:73-101;
- * SamPredictor.predict_torch, predictor.py:169-243): coords01 [P,2,2] ((coordinate + 0.5) / img_size, float64 on the host),
- * labels [P,2]: -1 padding point (its coordinate is ignored), 0 background point, 1 foreground point, 2 / 3 the top-left /
- * bottom-right corner of a box.  (point, -1) = one point prompt; (2, 3) = one box prompt.  first_mask = 1: mask tokens 1..3
- * (multimask_output=True); 0: tokens 0..2 -- column 0 is the single-mask output of multimask_output=False
- * (mask_decoder.py:99-105).  More points per prompt, points + box and mask_input change the token count / make the image
- * tokens per-prompt from layer 0 on: not provided. */
-int hgl_sam_decode_prompts(const HglSamDecoderW* w, const float* emb, const float* coords01, const int32_t* labels,
-                           int first_mask, int P, float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes,
-                           void* stream);
+/* The same for the other prompt kinds of SamPredictor.predict_torch (predictor.py:169-243; PromptEncoder._embed_points /
+ * _embed_boxes / _embed_masks, prompt_encoder.py:73-127): n_sparse = 2 or 3 sparse tokens per prompt, coords01
+ * [P,n_sparse,2] ((coordinate + 0.5) / img_size, computed by the caller in the dtype the reference would use), labels
+ * [P,n_sparse]: -1 padding point (its coordinate is ignored), 0 background point, 1 foreground point, 2 / 3 the top-left /
+ * bottom-right corner of a box.  (point, -1) = one point; (point, point, -1) = two points; (2, 3) = a box; (point, 2, 3) =
+ * a point and a box.  dense: NULL (no_mask_embed for every prompt) or [P, grid*grid, C] from hgl_sam_embed_masks (mask
+ * inputs: the image tokens then differ per prompt from the first layer on, which runs as plain fp32 launches).
+ * first_mask = 1: mask tokens 1..3 (multimask_output=True); 0: tokens 0..2 -- column 0 is the single-mask output of
+ * multimask_output=False (mask_decoder.py:99-105).  More than three sparse tokens per prompt: HGL_EINVAL. */
+int hgl_sam_decode_prompts(const HglSamDecoderW* w, const float* emb, const float* coords01, const int32_t* labels, int n_sparse,
+                           const float* dense, int first_mask, int P, float* low_res, float* iou_pred, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* PromptEncoder._embed_masks (prompt_encoder.py:103-106): mask_input [P,1,4*grid,4*grid] fp32 -> dense [P, grid*grid, C] */
+int hgl_sam_embed_masks(const HglSamDecoderW* w, const float* mask_input, int P, float* dense, void* stream);
+
 /* Fused stages of the decoder (split-fp16 mode): bit 0 = output upscaling + hyper-network products in one launch; bit 1 =
  * merged image-side projections (kvq1 / kvf of HglSamDecoderW, when provided); bit 2 = image -> token attention +
  * out-projection + residual + norm4 in one launch (needs bit 1); bit 4 = token -> image attention as key chunks of 256 with

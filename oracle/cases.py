@@ -86,8 +86,11 @@ def sam_prompts_case():
     labels = np.array([0, 1, 0, 0], dtype=np.int32)
     boxes = np.array([[10.0, 20.0, 120.5, 90.0], [0.0, 0.0, 199.0, 159.0], [60.25, 70.0, 61.0, 150.75], [150.0, 5.0, 180.0, 40.0]],
                      dtype=np.float64)
+    pairs = np.array([[[20.5, 30.25], [150.0, 100.0]], [[100.0, 80.0], [10.0, 12.5]], [[199.0, 159.0], [60.0, 60.0]],
+                      [[0.0, 0.0], [190.5, 20.0]]], dtype=np.float64)
+    pair_labels = np.array([[1, 0], [1, 1], [0, 1], [0, 0]], dtype=np.int32)
     return dict(points=pts, labels=labels, boxes=boxes, one_point=np.array([[33.3, 77.7]]), one_label=np.array([0]),
-                one_box=np.array([12.3, 45.6, 130.1, 140.9]))
+                one_box=np.array([12.3, 45.6, 130.1, 140.9]), pairs=pairs, pair_labels=pair_labels)
 
 
 def sam_crops_case():

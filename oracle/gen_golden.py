@@ -645,12 +645,32 @@ def gen_sam_prompts():
                 print("sam_prompts", k, tuple(low.shape), "iou", iou.numpy().round(4).tolist()[:2])
         sparse, _ = sam.prompt_encoder(points=None, boxes=torch.as_tensor(bxs), masks=None)
         out["box_sparse"] = sparse.numpy()
+        # three sparse tokens: two points (+ padding), a point and a box
+        prs = pred.transform.apply_coords(q["pairs"], pred.original_size)
+        full, iou, low = pred.predict_torch(torch.as_tensor(prs), torch.as_tensor(q["pair_labels"]), multimask_output=True,
+                                            return_logits=True)
+        out["pair_low"], out["pair_iou"] = low.numpy()[:, :, ::2, ::2], iou.numpy()
+        full, iou, low = pred.predict_torch(torch.as_tensor(pts)[:, None, :], torch.as_tensor(q["labels"])[:, None],
+                                            boxes=torch.as_tensor(bxs), multimask_output=False, return_logits=True)
+        out["ptbox_low"], out["ptbox_iou"] = low.numpy()[:, :, ::2, ::2], iou.numpy()
+        # mask inputs: the single-mask logits of the box prompts fed back with the same boxes (predictor.py:106-110)
+        _, _, low1 = pred.predict_torch(None, None, boxes=torch.as_tensor(bxs), multimask_output=False, return_logits=True)
+        out["mask_in"] = low1.numpy()
+        _, dense = sam.prompt_encoder(points=None, boxes=torch.as_tensor(bxs), masks=low1)
+        out["mask_dense"] = dense.permute(0, 2, 3, 1).reshape(dense.shape[0], -1, dense.shape[1]).numpy()[:, ::7]
+        full, iou, low = pred.predict_torch(None, None, boxes=torch.as_tensor(bxs), mask_input=low1, multimask_output=True,
+                                            return_logits=True)
+        out["maskin_low"], out["maskin_iou"], out["maskin_full"] = low.numpy()[:, :, ::2, ::2], iou.numpy(), full.numpy()[:, :, ::8, ::8]
+        print("sam_prompts mask input: iou", iou.numpy().round(4).tolist()[:2])
         m, iou, low = pred.predict(point_coords=q["one_point"], point_labels=q["one_label"], multimask_output=True, return_logits=True)
         out["predict_pt_low"], out["predict_pt_iou"] = low, iou
         m, iou, low = pred.predict(box=q["one_box"], multimask_output=False, return_logits=True)
         out["predict_box_low"], out["predict_box_iou"], out["predict_box_full"] = low, iou, m[:, ::4, ::4]
         mb, _, _ = pred.predict(box=q["one_box"], multimask_output=False)
         out["predict_box_mask"] = np.packbits(mb, axis=-1)
+        m, iou, low2 = pred.predict(point_coords=q["one_point"], point_labels=np.array([1]), box=q["one_box"], mask_input=low,
+                                    multimask_output=True, return_logits=True)
+        out["predict_all_low"], out["predict_all_iou"] = low2[:, ::2, ::2], iou
     np.savez_compressed(os.path.join(GOLD, "sam_prompts.npz"), **out)
 
 

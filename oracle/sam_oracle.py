@@ -158,9 +158,9 @@ def embed_points(sd, points_xy, input_size=1024):
 
 
 def embed_prompts(sd, coords_xy, labels, input_size=1024):
-    """PromptEncoder._embed_points / _embed_boxes for prompts of two tokens (modeling/prompt_encoder.py:73-101).
-    coords_xy: [P,2,2] input-image pixels (float64 or float32: the arithmetic dtype of `+ 0.5` and the division, as the
-    reference takes whatever the caller hands over), labels [P,2]: -1 padding, 0 / 1 points, 2 / 3 box corners -> [P,2,C]."""
+    """PromptEncoder._embed_points / _embed_boxes for prompts of n tokens (modeling/prompt_encoder.py:73-101).
+    coords_xy: [P,n,2] input-image pixels (float64 or float32: the arithmetic dtype of `+ 0.5` and the division, as the
+    reference takes whatever the caller hands over), labels [P,n]: -1 padding, 0 / 1 points, 2 / 3 box corners -> [P,n,C]."""
     labels = np.asarray(labels)
     pts = ((coords_xy + coords_xy.dtype.type(0.5)) / coords_xy.dtype.type(input_size)).astype(F32)
     emb = pe_encoding(sd, pts)
@@ -228,15 +228,39 @@ def mlp3(sd, p, x, n=3):
     return x.astype(F32)
 
 
-def mask_decoder(sd, image_emb_nhwc, sparse, multimask=True):
+def embed_masks(sd, mask_input):
+    """PromptEncoder._embed_masks = mask_downscaling (modeling/prompt_encoder.py:57-66, :103-106).
+    mask_input [B,1,4h,4w] -> dense rows [B, h*w, C] (NHWC)."""
+    p = "prompt_encoder.mask_downscaling"
+    x = mask_input[:, 0].astype(F32)                                     # [B, 4h, 4w]
+
+    def conv2(x_nhwc, w, b):                                              # Conv2d(k=2, s=2): w [co, ci, 2, 2]
+        B, H, W, ci = x_nhwc.shape
+        blk = x_nhwc.reshape(B, H // 2, 2, W // 2, 2, ci).transpose(0, 1, 3, 5, 2, 4).reshape(B, H // 2, W // 2, ci * 4)
+        return (blk @ w.reshape(w.shape[0], -1).T + b).astype(F32)
+
+    x = conv2(x[..., None], sd[f"{p}.0.weight"], sd[f"{p}.0.bias"])
+    x = gelu(layer_norm_2d(x, sd[f"{p}.1.weight"], sd[f"{p}.1.bias"]))
+    x = conv2(x, sd[f"{p}.3.weight"], sd[f"{p}.3.bias"])
+    x = gelu(layer_norm_2d(x, sd[f"{p}.4.weight"], sd[f"{p}.4.bias"]))
+    w3 = sd[f"{p}.6.weight"]
+    x = (x @ w3.reshape(w3.shape[0], -1).T + sd[f"{p}.6.bias"]).astype(F32)
+    return x.reshape(x.shape[0], -1, x.shape[-1])
+
+
+def mask_decoder(sd, image_emb_nhwc, sparse, multimask=True, dense=None):
     """MaskDecoder.forward/predict_masks (modeling/mask_decoder.py:71-149).
-    image_emb_nhwc: [h,w,C]; sparse: [B,P,C] -> (low-res logits [B,3,4h,4w], iou [B,3])."""
+    image_emb_nhwc: [h,w,C]; sparse: [B,P,C]; dense: None (no_mask_embed) or [B,h*w,C] (embed_masks)
+    -> (low-res logits [B,3,4h,4w], iou [B,3])."""
     h, w, C = image_emb_nhwc.shape
     B = sparse.shape[0]
     out_tok = np.concatenate([sd["mask_decoder.iou_token.weight"], sd["mask_decoder.mask_tokens.weight"]], 0)
     tokens = np.concatenate([np.broadcast_to(out_tok, (B,) + out_tok.shape), sparse], axis=1).astype(F32)
-    src = image_emb_nhwc.reshape(1, h * w, C) + sd["prompt_encoder.no_mask_embed.weight"].reshape(1, 1, C)
-    src = np.broadcast_to(src, (B, h * w, C)).astype(F32)
+    if dense is None:
+        src = image_emb_nhwc.reshape(1, h * w, C) + sd["prompt_encoder.no_mask_embed.weight"].reshape(1, 1, C)
+        src = np.broadcast_to(src, (B, h * w, C)).astype(F32)
+    else:
+        src = (image_emb_nhwc.reshape(1, h * w, C) + dense).astype(F32)
     pos = dense_pe(sd, h, w)
     hs, src = two_way_transformer(sd, src, pos, tokens)
     iou_tok, mask_tok = hs[:, 0, :], hs[:, 1:5, :]

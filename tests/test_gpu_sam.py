@@ -96,13 +96,12 @@ def test_predictor_mirror_vs_reference(cuda, g, tiny):
     np.testing.assert_allclose(logits.cpu().numpy()[:, :, ::4, ::4], g["full_logits"], rtol=0, atol=3e-4)
     masks, _, _ = pred.predict_torch(torch.from_numpy(pts)[:, None, :], torch.ones(len(pts), 1, dtype=torch.int))
     assert masks.dtype == torch.bool and tuple(masks.shape) == (5, 3, 160, 200)
-    with pytest.raises(NotImplementedError):       # two points per prompt: three sparse tokens
-        pred.predict_torch(torch.from_numpy(pts)[None, :2, :], torch.ones(1, 2, dtype=torch.int))
-    with pytest.raises(NotImplementedError):
-        pred.predict_torch(torch.from_numpy(pts)[:, None, :], torch.ones(len(pts), 1, dtype=torch.int),
-                           mask_input=torch.zeros(len(pts), 1, 64, 64))
-    with pytest.raises(NotImplementedError):       # point AND box
-        pred.predict_torch(torch.from_numpy(pts)[:1, None, :], torch.ones(1, 1, dtype=torch.int), boxes=torch.zeros(1, 4))
+    with pytest.raises(NotImplementedError):       # three points per prompt: four sparse tokens
+        pred.predict_torch(torch.from_numpy(pts)[None, :3, :], torch.ones(1, 3, dtype=torch.int))
+    with pytest.raises(NotImplementedError):       # two points AND a box: four sparse tokens
+        pred.predict_torch(torch.from_numpy(pts)[None, :2, :], torch.ones(1, 2, dtype=torch.int), boxes=torch.zeros(1, 4))
+    with pytest.raises(NotImplementedError):       # a mask input alone
+        pred.predict_torch(None, None, mask_input=torch.zeros(1, 1, 64, 64))
     m1, i1, l1 = pred.predict(c["points"][:1], np.array([1]))
     assert m1.shape == (3, 160, 200)
     # predict() hands float32 coordinates to the prompt encoder (predictor.py:141-143), the call above float64
@@ -141,6 +140,27 @@ def test_predictor_prompt_kinds_vs_reference(cuda, tiny, golden_dir):
     mb, _, _ = pred.predict(box=q["one_box"], multimask_output=False)
     ref = np.unpackbits(gp["predict_box_mask"], axis=-1)[..., :200].astype(bool)
     assert mb.dtype == bool and (mb != ref).mean() < 2e-3     # logits within 3e-4 of zero may flip isolated pixels
+    # three sparse tokens: two points (+ padding), a point and a box; mask inputs (per-prompt dense embeddings)
+    prs = pred.transform.apply_coords(q["pairs"], pred.original_size)
+    _, iou, low = pred.predict_torch(torch.from_numpy(prs), torch.from_numpy(q["pair_labels"]), return_logits=True)
+    np.testing.assert_allclose(iou.cpu().numpy(), gp["pair_iou"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(low.cpu().numpy()[:, :, ::2, ::2], gp["pair_low"], rtol=0, atol=3e-4)
+    _, iou, low = pred.predict_torch(torch.from_numpy(pts)[:, None, :], torch.from_numpy(q["labels"])[:, None],
+                                     boxes=torch.from_numpy(bxs), multimask_output=False, return_logits=True)
+    np.testing.assert_allclose(iou.cpu().numpy(), gp["ptbox_iou"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(low.cpu().numpy()[:, :, ::2, ::2], gp["ptbox_low"], rtol=0, atol=3e-4)
+    dense = tiny[1].embed_masks(T(gp["mask_in"], cuda))
+    np.testing.assert_allclose(dense.cpu().numpy()[:, ::7], gp["mask_dense"], rtol=0, atol=2e-5)
+    full, iou, low = pred.predict_torch(None, None, boxes=torch.from_numpy(bxs), mask_input=torch.from_numpy(gp["mask_in"]),
+                                        return_logits=True)
+    np.testing.assert_allclose(iou.cpu().numpy(), gp["maskin_iou"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(low.cpu().numpy()[:, :, ::2, ::2], gp["maskin_low"], rtol=0, atol=5e-4)
+    np.testing.assert_allclose(full.cpu().numpy()[:, :, ::8, ::8], gp["maskin_full"], rtol=0, atol=5e-4)
+    _, _, low1 = pred.predict(box=q["one_box"], multimask_output=False, return_logits=True)
+    _, iou, low = pred.predict(point_coords=q["one_point"], point_labels=np.array([1]), box=q["one_box"], mask_input=low1,
+                               multimask_output=True, return_logits=True)
+    np.testing.assert_allclose(iou, gp["predict_all_iou"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(low[:, ::2, ::2], gp["predict_all_low"], rtol=0, atol=5e-4)
     # the foreground-point fast path and the labelled path are the same decoder
     a = pred.predict_torch(torch.from_numpy(pts)[:, None, :], torch.ones(4, 1, dtype=torch.int), return_logits=True)
     lab = torch.stack([torch.ones(4, dtype=torch.int32), torch.full((4,), -1, dtype=torch.int32)], 1).to(cuda)

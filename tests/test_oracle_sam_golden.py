@@ -137,3 +137,29 @@ def test_prompt_kinds_vs_reference_predictor(sd, emb):
     low, iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, ob, np.array([[2, 3]]), 256), multimask=False)
     np.testing.assert_allclose(low[0], gp["predict_box_low"], rtol=0, atol=2e-4)
     np.testing.assert_allclose(iou[0], gp["predict_box_iou"], rtol=0, atol=5e-5)
+
+
+def test_three_token_prompts_and_mask_inputs_vs_reference_predictor(sd, emb):
+    """two points, point + box, mask inputs (prompt_encoder.py:73-127, predictor.py:169-243): the oracle against the
+    reference SamPredictor's outputs (tests/golden/sam_prompts.npz)"""
+    from oracle.cases import sam_prompts_case
+    gp = np.load(os.path.join(os.path.dirname(__file__), "golden", "sam_prompts.npz"))
+    c, q = sam_tiny_case(), sam_prompts_case()
+    sc = np.array([c["input_size"][1] / 200, c["input_size"][0] / 160])
+    prs = q["pairs"] * sc
+    co = np.concatenate([prs, np.zeros((4, 1, 2))], 1)
+    lab = np.concatenate([q["pair_labels"], np.full((4, 1), -1)], 1)
+    low, iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, co, lab, 256))
+    np.testing.assert_allclose(low[:, :, ::2, ::2], gp["pair_low"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(iou, gp["pair_iou"], rtol=0, atol=5e-5)
+    bx = q["boxes"].reshape(-1, 2, 2) * sc
+    co = np.concatenate([(q["points"] * sc)[:, None, :], bx], 1)
+    lab = np.concatenate([q["labels"][:, None], np.tile([2, 3], (4, 1))], 1)
+    low, iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, co, lab, 256), multimask=False)
+    np.testing.assert_allclose(low[:, :, ::2, ::2], gp["ptbox_low"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(iou, gp["ptbox_iou"], rtol=0, atol=5e-5)
+    dense = S.embed_masks(sd, gp["mask_in"])
+    np.testing.assert_allclose(dense[:, ::7], gp["mask_dense"], rtol=0, atol=2e-5)
+    low, iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, bx, np.tile([2, 3], (4, 1)), 256), dense=dense)
+    np.testing.assert_allclose(low[:, :, ::2, ::2], gp["maskin_low"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(iou, gp["maskin_iou"], rtol=0, atol=1e-4)
