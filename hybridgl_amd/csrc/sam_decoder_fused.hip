@@ -13,6 +13,9 @@
 //                      reads the 256-channel rows once (fp16 hi + lo planes), writes the [P,3,4g,4g] logits: 0.32 GB instead
 //                      of 2.6 GB through four launches.
 //
+//   dec_i2t_kernel       keys' = norm4(keys + out_proj(attention of the image tokens over the 7 prompt tokens))
+//                                                                   transformer.py:139-150; described at the kernel
+//
 // The matrix products are those of the unfused path, operation for operation (the same split-fp16 products in the same
 // order: K steps of 32; per step A_lo*W_hi, A_hi*W_lo, A_hi*W_hi into one fp32 accumulator) and so are the epilogue
 // expressions; the LayerNorm sums and the hyper-network dot products are associated differently (per lane first, then
@@ -325,9 +328,9 @@ constexpr int I2T_HS = 20;                                  // floats between th
 constexpr int I2T_A_PLANE = I2T_ROWS * 128 * 2;          // bytes of one plane of the attention output tile (16 KiB)
 
 __global__ __launch_bounds__(512, 2) void dec_i2t_kernel(I2TArgs a) {
-  // Eight waves per 64-token tile (a wave owns 32 of the 256 output columns): the stages of a tile are a dependent chain
-  // (q -> attention -> product -> residual -> two LayerNorm exchanges -> stores), so what hides its latencies is the number
-  // of resident waves: 16 per CU at 128 registers (four waves of 64 columns each: 198 registers, 8 per CU, 205 us vs ... )
+  // Eight waves per 64-token tile (a wave owns 32 of the 256 output columns): 101 registers, 16 waves per CU.  (Four waves of 64
+  // columns each needed 198 registers, 8 waves per CU, and took the same time: the launch is bound by its ~1100 VALU
+  // instructions per wave and by the store pattern, see the staging at the end, not by latency.)
   __shared__ __attribute__((aligned(16))) unsigned char img[2 * I2T_A_PLANE];
   __shared__ __attribute__((aligned(16))) float kv_s[2 * I2T_TOK * 8 * I2T_HS];
   __shared__ __attribute__((aligned(16))) float red[2][I2T_ROWS][8];
