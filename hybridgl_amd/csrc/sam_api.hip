@@ -214,7 +214,7 @@ struct DecPlan {
 
 bool carve_dec(HglArena& ar, const HglSamDecoderW* w, int P, DecPlan& p) {
   const size_t C = w->C, HW = (size_t)w->grid * w->grid, T = 8;   // 5 output tokens + up to 3 sparse prompt tokens
-  p.sparse = ar.take<float>((size_t)P * 2 * C);
+  p.sparse = ar.take<float>((size_t)P * (T - 5) * C);
   p.tokens = ar.take<float>(P * T * C);
   p.queries = ar.take<float>(P * T * C);
   p.qpe = ar.take<float>(P * T * C);

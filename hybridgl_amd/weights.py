@@ -127,6 +127,10 @@ SAM_CONFIGS = {
     # tiny geometry for parity tests: 16x16 tokens, 2 heads of 80, windowed + global blocks
     "tiny": dict(embed_dim=160, depth=4, num_heads=2, global_attn_indexes=(1, 3),
                  img_size=256, patch_size=16, window_size=14, out_chans=256),
+    # 24x24 tokens (576: not a multiple of the 256-key chunks of the decoder's token -> image attention, nor of a whole
+    # number of 64-token tiles per grid row): the ragged paths of the decoder kernels
+    "tiny24": dict(embed_dim=160, depth=2, num_heads=2, global_attn_indexes=(1,),
+                   img_size=384, patch_size=16, window_size=14, out_chans=256),
 }
 
 

@@ -347,6 +347,36 @@ def test_fused_decoder_stages_equal_the_unfused_launches(cuda, name, P):
     torch.cuda.empty_cache()
 
 
+def test_decoder_on_a_24x24_grid_vs_oracle(cuda):
+    """576 image tokens: the last key chunk of the token -> image attention holds 64 keys, a 64-token tile of the fused
+    image -> token step spans 2 2/3 grid rows, the fused tail does not apply (the four launches run); labelled prompts with
+    three tokens take the unfused image -> token step.  Against the oracle (pinned at 16 x 16 by the reference)."""
+    name = "tiny24"
+    cfg = weights.SAM_CONFIGS[name]
+    sd = weights.sam_state_dict(name, 3)
+    m = hsam.Sam(sd, cfg, cuda)
+    g = cfg["img_size"] // cfg["patch_size"]
+    rng = np.random.default_rng(24)
+    emb = rng.standard_normal((g, g, 256)).astype(np.float32)
+    pts = (rng.random((9, 2)) * cfg["img_size"]).astype(np.float64)
+    p01 = T(((pts + 0.5) / cfg["img_size"]).astype(np.float32), cuda)
+    low, iou = m.decode_points(T(emb.reshape(g * g, 256), cuda), p01)
+    ref_low, ref_iou = S.mask_decoder(sd, emb, S.embed_points(sd, pts, cfg["img_size"]))
+    scale = float(np.abs(ref_low).max())
+    np.testing.assert_allclose(low.cpu().numpy(), ref_low, rtol=0, atol=2e-4 * max(1.0, scale))
+    np.testing.assert_allclose(iou.cpu().numpy(), ref_iou, rtol=0, atol=1e-4)
+    # two points + padding (three sparse tokens), single-mask output
+    co = np.concatenate([pts[:8].reshape(4, 2, 2), np.zeros((4, 1, 2))], 1)
+    lab = np.array([[1, 0, -1], [0, 0, -1], [1, 1, -1], [0, 1, -1]])
+    c01 = T(((co + 0.5) / cfg["img_size"]).astype(np.float32), cuda)
+    low, iou = m.decode_prompts(T(emb.reshape(g * g, 256), cuda), c01, T(lab.astype(np.int32), cuda), first_mask=0)
+    ref_low, ref_iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, co, lab, cfg["img_size"]), multimask=False)
+    np.testing.assert_allclose(low.cpu().numpy()[:, :1], ref_low, rtol=0, atol=2e-4 * max(1.0, float(np.abs(ref_low).max())))
+    np.testing.assert_allclose(iou.cpu().numpy()[:, :1], ref_iou, rtol=0, atol=1e-4)
+    del m
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("mode", ["uncompressed_rle", "coco_rle"])
 def test_generate_rle_output_modes(cuda, tiny, mode):
     """output_mode (automatic_mask_generator.py:176-182): the records of the RLE modes decode to the binary_mask records"""
