@@ -213,7 +213,7 @@ struct DecPlan {
 };
 
 bool carve_dec(HglArena& ar, const HglSamDecoderW* w, int P, DecPlan& p) {
-  const size_t C = w->C, HW = (size_t)w->grid * w->grid, T = 8;   // 5 output tokens + up to 3 sparse prompt tokens
+  const size_t C = w->C, HW = (size_t)w->grid * w->grid, T = 16;   // 5 output tokens + up to 11 sparse prompt tokens
   p.sparse = ar.take<float>((size_t)P * (T - 5) * C);
   p.tokens = ar.take<float>(P * T * C);
   p.queries = ar.take<float>(P * T * C);
@@ -286,10 +286,15 @@ int dec_fewq(const float* q, const float* k, const float* v, float* att, int B, 
              int ldk, int ldv, int ldo, long long sqb, long long skb, long long svb, long long sob, float* scratch,
              size_t scratch_bytes, hipStream_t st) {
   const float scale = 1.0f / sqrtf((float)hd);
-  if ((dec_fusion_mask() & 16) && scratch && heads == 8 && hd == 16 && Nq <= 7 && Nk >= 256 && B <= 65535 &&
-      scratch_bytes >= hgl_attention_fewq_part_bytes(B, Nk))
-    return hgl_launch_attention_fewq_chunked(q, k, v, att, B, heads, Nq, Nk, hd, ldq, ldk, ldv, ldo, sqb, skb, svb, sob, scale,
-                                             scratch, scratch_bytes, st);
+  if ((dec_fusion_mask() & 16) && scratch && heads == 8 && hd == 16 && Nk >= 256 && B <= 65535 &&
+      scratch_bytes >= hgl_attention_fewq_part_bytes(B, Nk)) {
+    // the chunked kernel holds up to 7 queries: longer prompts (more sparse tokens) go through it 7 queries at a time
+    for (int q0 = 0; q0 < Nq; q0 += 7)
+      HGL_TRY(hgl_launch_attention_fewq_chunked(q + (long long)q0 * ldq, k, v, att + (long long)q0 * ldo, B, heads,
+                                                Nq - q0 < 7 ? Nq - q0 : 7, Nk, hd, ldq, ldk, ldv, ldo, sqb, skb, svb, sob, scale,
+                                                scratch, scratch_bytes, st));
+    return HGL_OK;
+  }
   return hgl_launch_attention(q, k, v, att, B, heads, Nq, Nk, hd, ldq, ldk, ldv, ldo, sqb, skb, svb, sob, scale, HGL_MASK_NONE,
                               nullptr, 0, 0, nullptr, nullptr, 0, 0, st);
 }
@@ -345,9 +350,10 @@ int dec_i2t_x3(const HglSamDecoderW* w, const HglSamAttnW& a, bool shared, const
   HGL_TRY(lin(tok_k, C, a.k, nullptr, 0, k1, I, P * T, I, C, HGL_ACT_NONE, st));
   HGL_TRY(lin(tok_v, C, a.v, nullptr, 0, v1, I, P * T, I, C, HGL_ACT_NONE, st));
   const SplitPair at = split_view(atti, (size_t)P * HW * I);
-  HGL_TRY(hgl_launch_attention_smallk(qi, k1, v1, nullptr, at.hi, at.lo, P, heads, HW, T, hd, I, I, I, I,
-                                      shared ? 0 : (long long)HW * I, (long long)T * I, (long long)T * I, (long long)HW * I,
-                                      1.0f / sqrtf((float)hd), st));
+  // (the few-key kernel for up to 8 tokens, the general one beyond)
+  HGL_TRY(hgl_launch_attention_split(qi, k1, v1, nullptr, at.hi, at.lo, P, heads, HW, T, hd, I, I, I, I,
+                                     shared ? 0 : (long long)HW * I, (long long)T * I, (long long)T * I, (long long)HW * I,
+                                     1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, nullptr, nullptr, 0, 0, st));
   return hgl_launch_gemm_f16x3_rmod(at.hi, at.lo, I, a.out.w, a.out.b, R, C, rmod, keys_out, nullptr, nullptr, C, P * HW, C,
                                     I, HGL_ACT_NONE, st);
 }
@@ -397,9 +403,9 @@ int dec_i2t_merged(const HglSamDecoderW* w, const HglSamAttnW& a, const float* k
   HGL_TRY(lin(tok_k, C, a.k, nullptr, 0, k1, I, P * T, I, C, HGL_ACT_NONE, st));
   HGL_TRY(lin(tok_v, C, a.v, nullptr, 0, v1, I, P * T, I, C, HGL_ACT_NONE, st));
   const SplitPair at = split_view(atti, (size_t)P * HW * I);
-  HGL_TRY(hgl_launch_attention_smallk(kvq + 2 * I, k1, v1, nullptr, at.hi, at.lo, P, heads, HW, T, hd, ld, I, I, I,
-                                      (long long)HW * ld, (long long)T * I, (long long)T * I, (long long)HW * I,
-                                      1.0f / sqrtf((float)hd), st));
+  HGL_TRY(hgl_launch_attention_split(kvq + 2 * I, k1, v1, nullptr, at.hi, at.lo, P, heads, HW, T, hd, ld, I, I, I,
+                                     (long long)HW * ld, (long long)T * I, (long long)T * I, (long long)HW * I,
+                                     1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, nullptr, nullptr, 0, 0, st));
   return hgl_launch_gemm_f16x3_rmod(at.hi, at.lo, I, a.out.w, a.out.b, R, C, 0, keys_out, nullptr, nullptr, C, P * HW, C, I,
                                     HGL_ACT_NONE, st);
 }
@@ -516,7 +522,7 @@ int hgl_sam_decoder_fusion(int mask) {
 }
 
 // MaskDecoder.predict_masks.  points01 != null: one foreground point + the padding point per prompt (what
-// SamAutomaticMaskGenerator issues); else coords01 [P,n_sparse,2] / labels [P,n_sparse] with n_sparse = 2 or 3 and, optionally,
+// SamAutomaticMaskGenerator issues); else coords01 [P,n_sparse,2] / labels [P,n_sparse] with n_sparse = 2 .. 11 and, optionally,
 // dense [P,HW,C]: per-prompt dense embeddings (mask inputs) instead of no_mask_embed.  first_mask = 1: the three multimask
 // outputs (mask tokens 1..3); 0: tokens 0..2 (token 0 is the single-mask output, mask_decoder.py:99-105).
 static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* points01, const float* coords01,
@@ -526,7 +532,8 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
   HGL_REQUIRE(valid_dec(w) && w->dense_pe, "sam_decode: invalid weight struct (dense_pe missing?)");
   HGL_REQUIRE(emb && (points01 || (coords01 && labels)) && low_res && iou_pred && P > 0, "sam_decode: null input");
   HGL_REQUIRE(first_mask == 0 || first_mask == 1, "sam_decode: first_mask must be 0 or 1");
-  HGL_REQUIRE(n_sparse == 2 || n_sparse == 3, "sam_decode: %d sparse tokens per prompt (2 or 3 supported)", n_sparse);
+  HGL_REQUIRE(n_sparse >= 2 && n_sparse <= 11, "sam_decode: %d sparse tokens per prompt (2 .. 11 supported)", n_sparse);
+  HGL_REQUIRE(n_sparse <= 3 || (long long)P * w->heads <= 65535, "sam_decode: %d prompts of more than 3 sparse tokens in one call", P);
   HglArena ar(workspace, workspace_bytes);
   DecPlan p;
   if (!workspace || !carve_dec(ar, w, P, p)) {

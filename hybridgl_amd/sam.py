@@ -482,11 +482,10 @@ class ResizeLongestSide:
 
 
 class SamPredictor:
-    """predictor.py:17-269: set_image, predict_torch, predict.  Prompts of two or three sparse tokens run on the device
-    decoder: one or two points per prompt (foreground / background; the padding point follows them), one box (its two
-    corners), or one point and a box; optionally a mask input per prompt (per-prompt dense embeddings); multimask_output
-    True or False.  More sparse tokens per prompt (three or more points, two points and a box) raise NotImplementedError:
-    the reference's own path (automatic_mask_generator.py:269-285) issues one foreground point per prompt."""
+    """predictor.py:17-269: set_image, predict_torch, predict.  Points (foreground / background; the padding point follows
+    them), a box (its two corners), or points and a box -- up to eleven sparse tokens per prompt --, optionally a mask
+    input per prompt (per-prompt dense embeddings); multimask_output True or False.  One point per prompt (what
+    automatic_mask_generator.py:269-285 issues) takes the fused decoder stages."""
 
     def __init__(self, sam_model):
         self.model = sam_model
@@ -525,8 +524,8 @@ class SamPredictor:
                       return_logits=False):
         """predictor.py:169-243.  point_coords [P,N,2] in the resized frame (transform.apply_coords) with point_labels [P,N]
         in {0, 1}, and / or boxes [P,4] XYXY in the resized frame (transform.apply_boxes), and / or mask_input [P,1,4g,4g]
-        (low-resolution logits of an earlier call).  Up to three sparse tokens per prompt: one or two points (the padding
-        point follows them when there is no box), a box, or one point and a box.  Returns (masks [P,C,H,W] bool or logits,
+        (low-resolution logits of an earlier call).  Up to eleven sparse tokens per prompt: points (the padding point
+        follows them when there is no box), a box, or points and a box.  Returns (masks [P,C,H,W] bool or logits,
         iou_predictions [P,C], low_res_masks [P,C,4g,4g]) with C = 3 (multimask_output) or 1."""
         if not self.is_image_set:
             raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")   # predictor.py:214
@@ -555,9 +554,9 @@ class SamPredictor:
         if P is None:
             raise NotImplementedError("a prompt needs points and / or a box (a mask input alone has no sparse tokens)")
         c01, labels = torch.cat(toks, dim=1).contiguous(), torch.cat(labs, dim=1).contiguous()
-        if c01.shape[1] > 3:
-            raise NotImplementedError(f"{c01.shape[1]} sparse tokens per prompt: up to three are supported (two points, or a "
-                                      "point and a box)")
+        if c01.shape[1] > 11:
+            raise NotImplementedError(f"{c01.shape[1]} sparse tokens per prompt: up to eleven are supported (ten points, or nine "
+                                      "points and a box)")
         dense = None
         if mask_input is not None:
             mi = torch.as_tensor(mask_input, device=self.device).to(torch.float32)
@@ -581,8 +580,8 @@ class SamPredictor:
 
     def predict(self, point_coords=None, point_labels=None, box=None, mask_input=None, multimask_output=True,
                 return_logits=False):
-        """predictor.py:90-167 for one prompt: points [N,2] with labels [N] (N <= 2; N <= 1 together with a box), a box [4]
-        (XYXY), both in the original frame, mask_input [1,4g,4g]: numpy in, numpy out ([C,H,W], [C], [C,4g,4g])."""
+        """predictor.py:90-167 for one prompt: points [N,2] with labels [N], a box [4] (XYXY), both in the original frame,
+        mask_input [1,4g,4g]: numpy in, numpy out ([C,H,W], [C], [C,4g,4g])."""
         pc = pl = bx = mi = None
         if point_coords is not None:
             assert point_labels is not None, "point_labels must be supplied if point_coords is supplied."

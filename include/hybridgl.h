@@ -425,14 +425,15 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
                           float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes,
                           void* stream);
 /* The same for the other prompt kinds of SamPredictor.predict_torch (predictor.py:169-243; PromptEncoder._embed_points /
- * _embed_boxes / _embed_masks, prompt_encoder.py:73-127): n_sparse = 2 or 3 sparse tokens per prompt, coords01
+ * _embed_boxes / _embed_masks, prompt_encoder.py:73-127): n_sparse = 2 .. 11 sparse tokens per prompt, coords01
  * [P,n_sparse,2] ((coordinate + 0.5) / img_size, computed by the caller in the dtype the reference would use), labels
  * [P,n_sparse]: -1 padding point (its coordinate is ignored), 0 background point, 1 foreground point, 2 / 3 the top-left /
- * bottom-right corner of a box.  (point, -1) = one point; (point, point, -1) = two points; (2, 3) = a box; (point, 2, 3) =
- * a point and a box.  dense: NULL (no_mask_embed for every prompt) or [P, grid*grid, C] from hgl_sam_embed_masks (mask
- * inputs: the image tokens then differ per prompt from the first layer on, which runs as plain fp32 launches).
- * first_mask = 1: mask tokens 1..3 (multimask_output=True); 0: tokens 0..2 -- column 0 is the single-mask output of
- * multimask_output=False (mask_decoder.py:99-105).  More than three sparse tokens per prompt: HGL_EINVAL. */
+ * bottom-right corner of a box.  (point, -1) = one point; (point, ..., point, -1) = several points; (2, 3) = a box;
+ * (point, ..., 2, 3) = points and a box.  dense: NULL (no_mask_embed for every prompt) or [P, grid*grid, C] from
+ * hgl_sam_embed_masks (mask inputs: the image tokens then differ per prompt from the first layer on, which runs as plain fp32
+ * launches).  first_mask = 1: mask tokens 1..3 (multimask_output=True); 0: tokens 0..2 -- column 0 is the single-mask output
+ * of multimask_output=False (mask_decoder.py:99-105).  Two sparse tokens take the fused decoder stages; more tokens the
+ * general attention kernels (and, beyond three, at most 8191 prompts per call). */
 int hgl_sam_decode_prompts(const HglSamDecoderW* w, const float* emb, const float* coords01, const int32_t* labels, int n_sparse,
                            const float* dense, int first_mask, int P, float* low_res, float* iou_pred, void* workspace,
                            size_t workspace_bytes, void* stream);

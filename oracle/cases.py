@@ -89,8 +89,12 @@ def sam_prompts_case():
     pairs = np.array([[[20.5, 30.25], [150.0, 100.0]], [[100.0, 80.0], [10.0, 12.5]], [[199.0, 159.0], [60.0, 60.0]],
                       [[0.0, 0.0], [190.5, 20.0]]], dtype=np.float64)
     pair_labels = np.array([[1, 0], [1, 1], [0, 1], [0, 0]], dtype=np.int32)
+    rng = np.random.default_rng(11)
+    many = np.stack([rng.random((2, 6)) * 199.0, rng.random((2, 6)) * 159.0], -1)          # [2 prompts, 6 points, (x, y)]
+    many_labels = np.array([[1, 0, 1, 1, 0, 0], [0, 1, 1, 0, 1, 1]], dtype=np.int32)
     return dict(points=pts, labels=labels, boxes=boxes, one_point=np.array([[33.3, 77.7]]), one_label=np.array([0]),
-                one_box=np.array([12.3, 45.6, 130.1, 140.9]), pairs=pairs, pair_labels=pair_labels)
+                one_box=np.array([12.3, 45.6, 130.1, 140.9]), pairs=pairs, pair_labels=pair_labels, many=many,
+                many_labels=many_labels)
 
 
 def sam_crops_case():

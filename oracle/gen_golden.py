@@ -653,6 +653,14 @@ def gen_sam_prompts():
         full, iou, low = pred.predict_torch(torch.as_tensor(pts)[:, None, :], torch.as_tensor(q["labels"])[:, None],
                                             boxes=torch.as_tensor(bxs), multimask_output=False, return_logits=True)
         out["ptbox_low"], out["ptbox_iou"] = low.numpy()[:, :, ::2, ::2], iou.numpy()
+        # more tokens: six points (+ padding: T = 12), three points and a box (T = 10)
+        mny = pred.transform.apply_coords(q["many"], pred.original_size)
+        full, iou, low = pred.predict_torch(torch.as_tensor(mny), torch.as_tensor(q["many_labels"]), multimask_output=True,
+                                            return_logits=True)
+        out["many_low"], out["many_iou"] = low.numpy()[:, :, ::2, ::2], iou.numpy()
+        full, iou, low = pred.predict_torch(torch.as_tensor(mny)[:, :3], torch.as_tensor(q["many_labels"])[:, :3],
+                                            boxes=torch.as_tensor(bxs)[:2], multimask_output=False, return_logits=True)
+        out["manybox_low"], out["manybox_iou"] = low.numpy()[:, :, ::2, ::2], iou.numpy()
         # mask inputs: the single-mask logits of the box prompts fed back with the same boxes (predictor.py:106-110)
         _, _, low1 = pred.predict_torch(None, None, boxes=torch.as_tensor(bxs), multimask_output=False, return_logits=True)
         out["mask_in"] = low1.numpy()

@@ -96,10 +96,8 @@ def test_predictor_mirror_vs_reference(cuda, g, tiny):
     np.testing.assert_allclose(logits.cpu().numpy()[:, :, ::4, ::4], g["full_logits"], rtol=0, atol=3e-4)
     masks, _, _ = pred.predict_torch(torch.from_numpy(pts)[:, None, :], torch.ones(len(pts), 1, dtype=torch.int))
     assert masks.dtype == torch.bool and tuple(masks.shape) == (5, 3, 160, 200)
-    with pytest.raises(NotImplementedError):       # three points per prompt: four sparse tokens
-        pred.predict_torch(torch.from_numpy(pts)[None, :3, :], torch.ones(1, 3, dtype=torch.int))
-    with pytest.raises(NotImplementedError):       # two points AND a box: four sparse tokens
-        pred.predict_torch(torch.from_numpy(pts)[None, :2, :], torch.ones(1, 2, dtype=torch.int), boxes=torch.zeros(1, 4))
+    with pytest.raises(NotImplementedError):       # eleven points per prompt: twelve sparse tokens
+        pred.predict_torch(torch.zeros(1, 11, 2), torch.ones(1, 11, dtype=torch.int))
     with pytest.raises(NotImplementedError):       # a mask input alone
         pred.predict_torch(None, None, mask_input=torch.zeros(1, 1, 64, 64))
     m1, i1, l1 = pred.predict(c["points"][:1], np.array([1]))
@@ -149,6 +147,15 @@ def test_predictor_prompt_kinds_vs_reference(cuda, tiny, golden_dir):
                                      boxes=torch.from_numpy(bxs), multimask_output=False, return_logits=True)
     np.testing.assert_allclose(iou.cpu().numpy(), gp["ptbox_iou"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(low.cpu().numpy()[:, :, ::2, ::2], gp["ptbox_low"], rtol=0, atol=3e-4)
+    # more tokens (the general attention kernels; the token -> image attention 7 queries at a time): six points, three + a box
+    mny = pred.transform.apply_coords(q["many"], pred.original_size)
+    _, iou, low = pred.predict_torch(torch.from_numpy(mny), torch.from_numpy(q["many_labels"]), return_logits=True)
+    np.testing.assert_allclose(iou.cpu().numpy(), gp["many_iou"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(low.cpu().numpy()[:, :, ::2, ::2], gp["many_low"], rtol=0, atol=3e-4)
+    _, iou, low = pred.predict_torch(torch.from_numpy(mny)[:, :3], torch.from_numpy(q["many_labels"])[:, :3],
+                                     boxes=torch.from_numpy(bxs)[:2], multimask_output=False, return_logits=True)
+    np.testing.assert_allclose(iou.cpu().numpy(), gp["manybox_iou"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(low.cpu().numpy()[:, :, ::2, ::2], gp["manybox_low"], rtol=0, atol=3e-4)
     dense = tiny[1].embed_masks(T(gp["mask_in"], cuda))
     np.testing.assert_allclose(dense.cpu().numpy()[:, ::7], gp["mask_dense"], rtol=0, atol=2e-5)
     full, iou, low = pred.predict_torch(None, None, boxes=torch.from_numpy(bxs), mask_input=torch.from_numpy(gp["mask_in"]),
@@ -393,6 +400,14 @@ def test_decoder_on_a_24x24_grid_vs_oracle(cuda):
     ref_low, ref_iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, co, lab, cfg["img_size"]), multimask=False)
     np.testing.assert_allclose(low.cpu().numpy()[:, :1], ref_low, rtol=0, atol=2e-4 * max(1.0, float(np.abs(ref_low).max())))
     np.testing.assert_allclose(iou.cpu().numpy()[:, :1], ref_iou, rtol=0, atol=1e-4)
+    # eight points + padding (T = 14: the token -> image attention runs 7 queries at a time, the general kernel on 14 keys)
+    co = np.concatenate([(rng.random((3, 8, 2)) * cfg["img_size"]), np.zeros((3, 1, 2))], 1)
+    lab = np.concatenate([rng.integers(0, 2, (3, 8)), np.full((3, 1), -1)], 1)
+    c01 = T(((co + 0.5) / cfg["img_size"]).astype(np.float32), cuda)
+    low, iou = m.decode_prompts(T(emb.reshape(g * g, 256), cuda), c01, T(lab.astype(np.int32), cuda))
+    ref_low, ref_iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, co, lab, cfg["img_size"]))
+    np.testing.assert_allclose(low.cpu().numpy(), ref_low, rtol=0, atol=2e-4 * max(1.0, float(np.abs(ref_low).max())))
+    np.testing.assert_allclose(iou.cpu().numpy(), ref_iou, rtol=0, atol=1e-4)
     del m
     torch.cuda.empty_cache()
 

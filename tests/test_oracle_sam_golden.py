@@ -158,6 +158,17 @@ def test_three_token_prompts_and_mask_inputs_vs_reference_predictor(sd, emb):
     low, iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, co, lab, 256), multimask=False)
     np.testing.assert_allclose(low[:, :, ::2, ::2], gp["ptbox_low"], rtol=0, atol=2e-4)
     np.testing.assert_allclose(iou, gp["ptbox_iou"], rtol=0, atol=5e-5)
+    mny = q["many"] * sc
+    co = np.concatenate([mny, np.zeros((2, 1, 2))], 1)
+    lab = np.concatenate([q["many_labels"], np.full((2, 1), -1)], 1)
+    low, iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, co, lab, 256))
+    np.testing.assert_allclose(low[:, :, ::2, ::2], gp["many_low"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(iou, gp["many_iou"], rtol=0, atol=5e-5)
+    co = np.concatenate([mny[:, :3], bx[:2]], 1)
+    lab = np.concatenate([q["many_labels"][:, :3], np.tile([2, 3], (2, 1))], 1)
+    low, iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, co, lab, 256), multimask=False)
+    np.testing.assert_allclose(low[:, :, ::2, ::2], gp["manybox_low"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(iou, gp["manybox_iou"], rtol=0, atol=5e-5)
     dense = S.embed_masks(sd, gp["mask_in"])
     np.testing.assert_allclose(dense[:, ::7], gp["mask_dense"], rtol=0, atol=2e-5)
     low, iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, bx, np.tile([2, 3], (4, 1)), 256), dense=dense)
