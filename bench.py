@@ -100,6 +100,10 @@ def roofline(precision, nprof, g, x, a, traffic, whole_tflops, xg=(0, 0.0, 0.0),
                 "note": "achieved counts ALGORITHMIC flops (2MNK); the kernel issues 3x that on the fp16 matrix cores",
                 "issued_mfma_tflops": 3 * ach, "frac_issued": 3 * ach / PEAK_FP16_MFMA_TFLOPS,
                 "x_fp32_matrix_peak": ach / PEAK_FP32_MFMA_TFLOPS,
+                # what the bare v_mfma_f32_16x16x32_f16 stream sustains with every CU busy: 2420 TF/s on all-zero operands, 1920
+                # on operands whose bits toggle (the power limit; tools/micro/mfma_rate.hip, not measured in this run)
+                "frac_issued_of_sustained_mfma_rate": 3 * ach / 1920.0,
+                "sustained_mfma_rate_source": "profiles/r03_mfma_rate_microbench.txt (1920 TF/s issued, random operands)",
                 "launches_per_step": x_n / nprof, "avg_launch_ms": x_ms / max(x_n, 1), "ms_per_step": x_ms / nprof,
                 "algorithmic_flops_per_step": x_fl / nprof}
     else:
