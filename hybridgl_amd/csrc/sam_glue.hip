@@ -633,9 +633,9 @@ __global__ __launch_bounds__(256) void sam_postprocess_kernel(PostArgs a) {
   const int ph = ve - vb + 1, pw = ue - ub + 1;
   const bool staged = ph <= PR && pw <= PR;      // uniform
   if (staged) {
-    for (int i = threadIdx.x; i < ph * pw; i += 256) {
-      const int v = i / pw, u = i - v * pw;
-      patch[v * PR + u] = L[(long long)(vb + v) * a.wl + (ub + u)];
+    for (int v = threadIdx.x >> 6; v < ph; v += 4) {       // (row, column) by shifts: no integer division per element
+      const int u = threadIdx.x & 63;
+      if (u < pw) patch[v * PR + u] = L[(long long)(vb + v) * a.wl + (ub + u)];
     }
   }
   __syncthreads();
@@ -741,15 +741,16 @@ __global__ __launch_bounds__(256) void sam_postprocess_kernel(PostArgs a) {
 // LDS; an output pixel is then 8 LDS reads and the two vertical / one horizontal blends, expression for expression those
 // of the kernel above (same products, same order, same contraction: the logits are bit-identical, tests/test_gpu_sam.py).
 // ~40 instead of ~90 instructions per pixel.  The host picks this kernel when every tile's patch / column count fits.
-constexpr int PX1 = 112;            // max stage-1 columns of a tile (64 output columns at a 1.6 : 1 size ratio: 104)
+constexpr int PX1 = 112;            // max stage-1 columns of a tile (64 output columns at a 1.6 : 1 size ratio: 104).  Wider
+                                    // tables (192 columns = 47 KB of LDS, for the 2.7 : 1 crops of a crop layer) measured SLOWER
+                                    // than the per-pixel kernel there (3.1 against 2.0 ms per crop): three workgroups per CU
+                                    // do not hide the load -> build -> interpolate chain of a tile
 
 __global__ __launch_bounds__(256) void sam_postprocess_sep_kernel(PostArgs a) {
   __shared__ float patch[PR * PR];
   __shared__ float H1[PR * PX1];
   __shared__ int xc0[PTW], xc1[PTW];
   __shared__ float xl0[PTW], xl1[PTW];
-  __shared__ int cu0[PX1], cu1[PX1];
-  __shared__ float cn0[PX1], cn1[PX1];
   __shared__ unsigned red[6 * 4];
   const int k = blockIdx.z;
   const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;
@@ -789,9 +790,10 @@ __global__ __launch_bounds__(256) void sam_postprocess_sep_kernel(PostArgs a) {
   int ue0, ue;
   src_idx(s2x, j1, a.wl, ue0, ue, f0, f1);
   const int ph = ve - vb + 1, pw = ue - ub + 1;          // low-res patch (<= PR x PR: checked by the host)
-  for (int i = threadIdx.x; i < ph * pw; i += 256) {
-    const int v = i / pw, u = i - v * pw;
-    patch[v * PR + u] = L[(long long)(vb + v) * a.wl + (ub + u)];
+  // (thread -> (row, column) by shifts: an integer division per element cost more than the element)
+  for (int v = threadIdx.x >> 6; v < ph; v += 4) {
+    const int u = threadIdx.x & 63;
+    if (u < pw) patch[v * PR + u] = L[(long long)(vb + v) * a.wl + (ub + u)];
   }
   if (threadIdx.x < PTW) {
     int x0, x1;
@@ -799,20 +801,23 @@ __global__ __launch_bounds__(256) void sam_postprocess_sep_kernel(PostArgs a) {
     src_idx(sx1, min(X0 + (int)threadIdx.x, a.W - 1), a.wi, x0, x1, lx0, lx1);
     xc0[threadIdx.x] = x0 - X1b; xc1[threadIdx.x] = x1 - X1b;
     xl0[threadIdx.x] = lx0; xl1[threadIdx.x] = lx1;
-  } else if (threadIdx.x - PTW < R1w) {
-    const int c = threadIdx.x - PTW;
-    int u0, u1;
-    float n0, n1;
-    src_idx(s2x, X1b + c, a.wl, u0, u1, n0, n1);
-    cu0[c] = u0 - ub; cu1[c] = u1 - ub;
-    cn0[c] = n0; cn1[c] = n1;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < ph * R1w; i += 256) {
-    const int v = i / R1w, c = i - v * R1w;
-    const float n0 = cn0[c], n1 = cn1[c];
-    const float h1 = patch[v * PR + cu0[c]] * n0 + patch[v * PR + cu1[c]] * n1;
-    H1[v * PX1 + c] = h1;
+  {
+    // h(v, c) for the patch rows x the tile's stage-1 columns: a thread owns one column (its source indices and weights in
+    // registers) and walks the rows
+    const int cshift = R1w <= 64 ? 6 : (R1w <= 128 ? 7 : 8);
+    const int c = threadIdx.x & ((1 << cshift) - 1), vstep = 256 >> cshift;
+    if (c < R1w) {
+      int u0, u1;
+      float n0, n1;
+      src_idx(s2x, X1b + c, a.wl, u0, u1, n0, n1);
+      u0 -= ub; u1 -= ub;
+      for (int v = threadIdx.x >> cshift; v < ph; v += vstep) {
+        const float h1 = patch[v * PR + u0] * n0 + patch[v * PR + u1] * n1;
+        H1[v * PX1 + c] = h1;
+      }
+    }
   }
   __syncthreads();
 
