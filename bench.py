@@ -234,14 +234,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128,
-                    help="timed steps (refs); the default is a whole number of groups of --sam-batch images (16 groups: the "
-                         "fill and the drain of the two-stream loop, which are inside the timed region, weigh 1 / 16 each)")
-    ap.add_argument("--warmup", type=int, default=16, help="untimed steps (refs); the default is two full groups")
+                    help="timed steps (refs); the default is a whole number of groups of --sam-batch images (8 groups: the "
+                         "fill and the drain of the two-stream loop, which are inside the timed region, weigh 1 / 8 each)")
+    ap.add_argument("--warmup", type=int, default=32, help="untimed steps (refs); the default is two full groups")
     ap.add_argument("--fusion", default="G2L", choices=["G2L", "L2G", "G2L&L2G"])
     ap.add_argument("--clip", default="ViT-B/16", choices=list(CLIP_GEOM),
                     help="CLIP geometry: ViT-B/16 = the reference's configuration; ViT-L/14 = the extension BASELINE.json names")
     ap.add_argument("--masks", type=int, default=64)
-    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic refs resident per rank (a group of 8 = 8 different images)")
+    ap.add_argument("--pool", type=int, default=16, help="distinct synthetic refs resident per rank (a group of 16 = 16 different images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the SAM stage and the CLIP stage of the loop back to back on one stream (HybridGLPipeline.run(serial=True)) "
@@ -254,7 +254,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 path on a box "
                          "with fewer GPUs than ranks)")
-    ap.add_argument("--sam-batch", type=int, default=8, choices=[1, 2, 4, 8, 16],
+    ap.add_argument("--sam-batch", type=int, default=16, choices=[1, 2, 4, 8, 12, 16, 24, 32],
                     help="images per group of the evaluation loop (HybridGLPipeline.run): ONE SAM encoder pass over the images of "
                          "group g+1 (token rows stacked, weights read once) beside ONE text-encoder batch + ONE hybrid forward "
                          "over the proposals of group g; same work and same results per ref (1: ref by ref, HybridGLPipeline.step)")
@@ -406,7 +406,7 @@ def main():
             and dependent:
         also = {}
 
-        def timed(p2, n_steps=16, **kw):
+        def timed(p2, n_steps=3 * nbatch, **kw):     # three groups: the middle one runs with both neighbours beside it
             do_steps(n_steps, p2, **kw)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -419,12 +419,12 @@ def main():
                     "whole_step_algorithmic_tflops": None if fl is None else fl / t / 1e12}
         text_S = max(r.token_len or 77 for r in refs)
         t = timed(make_pipe(dep=False))
-        also["seeded_masks"] = entry(t, 16, "rounds 1-2's headline workload (--proposals-from seeded): the SAM proposal kernels run, their "
+        also["seeded_masks"] = entry(t, 3 * nbatch, "rounds 1-2's headline workload (--proposals-from seeded): the SAM proposal kernels run, their "
                                      "masks are discarded, clean-up + CLIP take the 64 seeded masks; no count read-back")
         t = timed(make_pipe(fusion="L2G"))
-        also["L2G"] = entry(t, 16, "the headline workload with fusion_mode L2G (BASELINE configs[2] per GPU)")
+        also["L2G"] = entry(t, 3 * nbatch, "the headline workload with fusion_mode L2G (BASELINE configs[2] per GPU)")
         t = timed(make_pipe(fusion="G2L&L2G"))
-        also["G2L&L2G"] = entry(t, 16, "the headline workload with fusion_mode G2L&L2G (BASELINE configs[3] per GPU)")
+        also["G2L&L2G"] = entry(t, 3 * nbatch, "the headline workload with fusion_mode G2L&L2G (BASELINE configs[3] per GPU)")
         # strict fp32: every product an exact fp32 MFMA (v_mfma_f32_32x32x2_f32), own model objects
         model_f = CLIPViTFM(args.clip, seed=0, device=dev, precision="f32")
         from hybridgl_amd.sam import sam_model_registry
@@ -433,8 +433,8 @@ def main():
         if use_gem:
             from hybridgl_amd.gem import create_gem_model
             gem_f = create_gem_model(args.clip, clip=model_f)
-        t = timed(make_pipe(m=model_f, g=make_gen(sam_f), gm=gem_f), n_steps=8)
-        also["f32"] = entry(t, 8, "the headline workload with HYBRIDGL_PRECISION=f32 semantics (exact fp32 MFMA products in every "
+        t = timed(make_pipe(m=model_f, g=make_gen(sam_f), gm=gem_f), n_steps=2 * nbatch)
+        also["f32"] = entry(t, 2 * nbatch, "the headline workload with HYBRIDGL_PRECISION=f32 semantics (exact fp32 MFMA products in every "
                                   "GEMM and attention; roofline denominator 157.3 TFLOP/s)",
                             algorithmic_flops_per_ref(args.masks, sam=True, gem=use_gem, clip_name=args.clip, text_S=text_S))
         del model_f, sam_f, gem_f
@@ -445,8 +445,8 @@ def main():
         if use_gem:
             from hybridgl_amd.gem import create_gem_model
             gem_l = create_gem_model("ViT-L/14", clip=model_l)
-        t = timed(make_pipe(m=model_l, gm=gem_l, mb=gl["masking_block"]), n_steps=8)
-        also["ViT-L/14"] = entry(t, 8, "the headline workload with the CLIP / GEM ViT-L/14 geometry north_star names (masking_block 21)",
+        t = timed(make_pipe(m=model_l, gm=gem_l, mb=gl["masking_block"]), n_steps=2 * nbatch)
+        also["ViT-L/14"] = entry(t, 2 * nbatch, "the headline workload with the CLIP / GEM ViT-L/14 geometry north_star names (masking_block 21)",
                                  algorithmic_flops_per_ref(args.masks, sam=True, gem=use_gem, clip_name="ViT-L/14", text_S=text_S))
         del model_l, gem_l
         torch.cuda.empty_cache()

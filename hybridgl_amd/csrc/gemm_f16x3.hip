@@ -1080,6 +1080,20 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
   HGL_REQUIRE(sw.N == N && sw.K == K, "gemm_f16x3: registered split is [%d,%d], GEMM wants [%d,%d]", sw.N, sw.K, N, K);
   HGL_REQUIRE(Ah && Al && (C || (Ch && Cl)) && M > 0 && N > 0 && K > 0, "gemm_f16x3: bad arguments");
   HGL_REQUIRE((K % 64) == 0 && (lda & 7) == 0, "gemm_f16x3: K must be a multiple of 64 and lda of 8 (K=%d lda=%d)", K, lda);
+  // The LDS-DMA kernel addresses an operand plane with 32-bit byte offsets: a plane of 4 GB or more (CLIP ViT-L/14 fc2 over a
+  // group of 16 refs: 526 336 rows x 4096 halves) would fall back to the register-staged kernel at half the rate.  Rows are
+  // independent: run it as row chunks that fit (same tiles, same sums per row).
+  if (!amap && !cmap && rmod == 0 && (double)M * lda * 2.0 >= 4.0e9 && (double)256 * lda * 2.0 < 2.0e9) {
+    const int chunk = (int)(3.9e9 / ((double)lda * 2.0)) / 256 * 256;
+    for (int m0 = 0; m0 < M; m0 += chunk) {
+      const int mc = M - m0 < chunk ? M - m0 : chunk;
+      HGL_TRY(hgl_launch_gemm_f16x3_maps((const _Float16*)Ah + (long long)m0 * lda, (const _Float16*)Al + (long long)m0 * lda, lda,
+                                         nullptr, W32, bias, R ? R + (long long)m0 * ldr : nullptr, ldr, 0, nullptr,
+                                         C ? C + (long long)m0 * ldc : nullptr, Ch ? (_Float16*)Ch + (long long)m0 * ldc : nullptr,
+                                         Cl ? (_Float16*)Cl + (long long)m0 * ldc : nullptr, ldc, mc, N, K, act, st));
+    }
+    return HGL_OK;
+  }
   Args g;
   g.Ah = (const _Float16*)Ah; g.Al = (const _Float16*)Al; g.Wh = sw.hi; g.Wl = sw.lo;
   g.bias = bias; g.R = R; g.C = C; g.Ch = (_Float16*)Ch; g.Cl = (_Float16*)Cl;

@@ -50,7 +50,7 @@ def default_argument_parser():
     p.add_argument("--pred_iou_thresh", type=float, default=0.7)
     p.add_argument("--stability_score_thresh", type=float, default=0.7)
     p.add_argument("--min_mask_region_area", type=int, default=800)
-    p.add_argument("--group", type=int, default=8,
+    p.add_argument("--group", type=int, default=16,
                    help="images taken at a time by the two-stream loop (HybridGLPipeline.run); 1 = ref by ref on one stream")
     p.add_argument("--workers", type=int, default=4, help="loader threads (Hybridgl_main.py:45 num_workers)")
     p.add_argument("--k_clamp", default="auto", choices=["auto", "persistent", "per_ref"],

@@ -293,7 +293,7 @@ class HybridGLPipeline:
         if units:
             yield units
 
-    def run(self, loader, group=8, proposal_cap=None, collect=False, serial=False):
+    def run(self, loader, group=16, proposal_cap=None, collect=False, serial=False):
         """The loop of Hybridgl_main.py:79-230 over a whole loader, taken `group` images at a time on two streams:
 
             SAM stream   group g+1: ONE encoder pass over its images, per image decoder + post-processing + NMS, small-region

@@ -143,6 +143,28 @@ def test_gemm_f16x3_inplace_residual(cuda):
     assert np.abs(ref - z).max() < 3e-5
 
 
+def test_gemm_f16x3_operand_planes_beyond_4gb(cuda):
+    """an A plane of 4 GB or more (CLIP ViT-L/14 fc2 over a group of 16 refs) runs as row chunks on the LDS-DMA kernel, whose
+    operand offsets are 32-bit: every row equals the row of a small GEMM over its neighbourhood, at the chunk borders too"""
+    M, N, K = 1_050_000, 256, 2048                      # 4.3 GB per fp16 plane
+    g = torch.Generator(device=cuda).manual_seed(7)
+    a = torch.randn((M, K), device=cuda, generator=g)
+    w = torch.randn((N, K), device=cuda, generator=g) / 45.0
+    bias = torch.randn((N,), device=cuda, generator=g)
+    r = torch.randn((M, N), device=cuda, generator=g)
+    out = ops.gemm_f16x3(a, w, bias, r, "gelu")
+    chunk = int(3.9e9 / (K * 2.0)) // 256 * 256
+    for m0 in (0, chunk - 300, chunk, M - 700):
+        sl = slice(m0, min(M, m0 + 700))
+        small = ops.gemm_f16x3(a[sl].contiguous(), w, bias, r[sl].contiguous(), "gelu")
+        assert torch.equal(small, out[sl]), m0
+    ref = torch.nn.functional.gelu(a[:64].double() @ w.double().T + bias.double()) + r[:64].double()
+    assert float((out[:64].double() - ref).abs().max()) < 2e-4
+    del a, r, out
+    ops.release_split_weights([w.data_ptr()])
+    torch.cuda.empty_cache()
+
+
 def test_gemm_inplace_residual_and_asymmetry(cuda):
     """A = I with an asymmetric W catches a transposed C write; residual aliasing C must work."""
     n = 160

@@ -12,7 +12,7 @@ tail -c 600 $O/${tag}_bench_default.json | head -c 300; echo
 python3 $R/bench.py --gpus 2 --backend gloo --steps 32 --warmup 8 --no-cpu-baseline --no-also > $O/${tag}_bench_2ranks_gloo.json 2> $O/${tag}_bench_2ranks_gloo.err
 head -c 260 $O/${tag}_bench_2ranks_gloo.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats -o p -- python3 $R/bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-also > $O/${tag}_stats.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats_serial -o p -- python3 $R/tools/group_profile.py 3 8 > $O/${tag}_stats_serial.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats_serial -o p -- python3 $R/tools/group_profile.py 2 16 > $O/${tag}_stats_serial.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_fetch -o p -- python3 $R/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-also > $O/${tag}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_write -o p -- python3 $R/bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-also > $O/${tag}_write.log 2>&1
 # sustained run + clock samples (rocm-smi is read-only here)
