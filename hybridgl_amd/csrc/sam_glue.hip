@@ -786,10 +786,12 @@ __global__ __launch_bounds__(256) void sam_postprocess_sep_kernel(PostArgs a) {
   int ub, udummy;
   src_idx(s2x, j0, a.wl, ub, udummy, f0, f1);
   src_idx(sx1, Xl, a.wi, j0, j1, f0, f1);
-  const int R1w = j1 - X1b + 1;                          // stage-1 columns of the tile (<= PX1: checked by the host)
+  // (the host launches this kernel only when these fit, with the same IEEE arithmetic; the clamps keep a disagreement -- which
+  // cannot happen -- inside the tables)
+  const int R1w = min(j1 - X1b + 1, PX1);                // stage-1 columns of the tile
   int ue0, ue;
   src_idx(s2x, j1, a.wl, ue0, ue, f0, f1);
-  const int ph = ve - vb + 1, pw = ue - ub + 1;          // low-res patch (<= PR x PR: checked by the host)
+  const int ph = min(ve - vb + 1, PR), pw = min(ue - ub + 1, PR);   // low-res patch
   // (thread -> (row, column) by shifts: an integer division per element cost more than the element)
   for (int v = threadIdx.x >> 6; v < ph; v += 4) {
     const int u = threadIdx.x & 63;
