@@ -425,6 +425,23 @@ def main():
         also["L2G"] = entry(t, 3 * nbatch, "the headline workload with fusion_mode L2G (BASELINE configs[2] per GPU)")
         t = timed(make_pipe(fusion="G2L&L2G"))
         also["G2L&L2G"] = entry(t, 3 * nbatch, "the headline workload with fusion_mode G2L&L2G (BASELINE configs[3] per GPU)")
+        # CLIP / GEM weights fp16-valued, as the OpenAI archives the reference loads hold them (clip/model.py:509 is commented
+        # out: fp32 tensors with fp16 values): W_lo == 0, the GEMMs on them issue two of the three products (same results) and
+        # multiply by zeros less often under the power limit.  The headline keeps genuine fp32 random weights.
+        import numpy as _np
+        from hybridgl_amd import weights as _w
+        sd16 = {k: (_np.asarray(v).astype(_np.float16).astype(_np.float32) if _np.asarray(v).dtype.kind == "f" else v)
+                for k, v in _w.clip_state_dict(args.clip, 0).items()}
+        model_h = CLIPViTFM(args.clip, state_dict=sd16, device=dev)
+        gem_h = None
+        if use_gem:
+            from hybridgl_amd.gem import create_gem_model
+            gem_h = create_gem_model(args.clip, clip=model_h)
+        t = timed(make_pipe(m=model_h, gm=gem_h))
+        also["clip_weights_fp16_valued"] = entry(t, 3 * nbatch, "the headline workload with CLIP / GEM weights rounded through fp16 (the "
+                                                 "values an OpenAI CLIP archive holds); SAM's weights stay genuine fp32")
+        del model_h, gem_h, sd16
+        torch.cuda.empty_cache()
         # strict fp32: every product an exact fp32 MFMA (v_mfma_f32_32x32x2_f32), own model objects
         model_f = CLIPViTFM(args.clip, seed=0, device=dev, precision="f32")
         from hybridgl_amd.sam import sam_model_registry

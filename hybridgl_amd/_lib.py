@@ -110,6 +110,7 @@ PROTOTYPES = {
     "hgl_split_overflow_count": (_I, [_I, C.POINTER(C.c_ulonglong)]),
     "hgl_register_split_weight": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP]),
     "hgl_unregister_split_weight": (_I, [_VP]),
+    "hgl_split_weight_is_fp16_valued": (_I, [_VP]),
     "hgl_gemm_f16x3": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _SZ, _VP]),
     "hgl_gemm_f32": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _LL, _LL, _LL, _LL, _I, _VP]),
     "hgl_layernorm_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I, _F, _VP]),
@@ -179,7 +180,7 @@ PROTOTYPES = {
 }
 
 _lib = None
-ABI_VERSION = 3   # include/hybridgl.h HGL_ABI_VERSION
+ABI_VERSION = 4   # include/hybridgl.h HGL_ABI_VERSION
 
 
 def load():

@@ -37,6 +37,7 @@ struct SplitW {
   const _Float16 *hi, *lo;
   int scale_log2;
   int N, K;
+  bool lo_zero;   // every lo half is zero: the weight is fp16-valued (OpenAI's CLIP archives), W = W_hi exactly
 };
 std::unordered_map<const void*, SplitW> g_split;   // fp32 weight pointer -> its fp16 split
 std::mutex g_split_mu;                             // the registry may be touched from several host threads
@@ -58,6 +59,7 @@ struct Args {
   _Float16 *Ch, *Cl;   // split output (when C == nullptr)
   int M, N, K, lda, ldw, ldr, ldc;
   float out_scale;
+  int lo_zero;                // the W_lo plane is all zero: the A_hi * W_lo products are skipped (they add exact zeros)
   int tiles_m, tiles_n;
   int gm;      // M-tiles per tile group (L2 blocking of the resident tile set)
   float* part;   // split-K (ping-pong kernel, grid.y = ksplit): raw partial sums [ksplit][M][N]; bias / act / residual are
@@ -353,7 +355,7 @@ __device__ __forceinline__ void x3p_wait() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int ACT, int WLOADS>
+template <int ACT, int WLOADS, int NT>
 __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
   constexpr int TBM = 256, TBN = 256, MB = 8, NB = 4, WTM = 128, WTN = 64;   // 16x16 accumulator blocks per wave
   constexpr int PLANE = 256 * 64;    // bytes of one plane of one stage
@@ -481,7 +483,8 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
     }
   };
   // the 24 MFMAs of quadrant (ih, j): per accumulator lo*hi, hi*lo, hi*hi over the whole K tile; W fragment first =
-  // transposed accumulator (lane: output row r, four consecutive columns)
+  // transposed accumulator (lane: output row r, four consecutive columns).  NT == 2: the weight is fp16-valued (W_lo == 0),
+  // the hi*lo products would add exact zeros and are not issued (16 MFMAs; same accumulators bit for bit)
   auto quad = [&](int ih, int j) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
       for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
+          if (NT == 2 && term == 1) continue;
           const f16x8 a = term == 0 ? al[ib] : ah[ib];
           const f16x8 b = term == 1 ? bl[j][jb] : bh[j][jb];
           acc[4 * ih + ib][2 * j + jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, acc[4 * ih + ib][2 * j + jb], 0, 0, 0);
@@ -848,6 +852,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // x (fp32) * 2^scale_log2 -> hi, lo fp16
+__device__ unsigned g_lo_nonzero;
+__global__ __launch_bounds__(256) void lo_nonzero_kernel(const u32x4* __restrict__ lo, long long n8) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= n8) return;
+  const u32x4 v = lo[i];
+  // (-0.0 halves count as zero: a product with them adds zeros as well)
+  if (((v[0] | v[1] | v[2] | v[3]) & 0x7fff7fffu) != 0) atomicOr(&g_lo_nonzero, 1u);
+}
+
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, float scale,
                                                         _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                         long long n4) {
@@ -1035,8 +1048,8 @@ int launch_x3_v1(Args& g, hipStream_t st) {
   return HGL_OK;
 }
 
-template <int ACT, int WLOADS>
-int launch_x3_p2(Args& g, hipStream_t st) {
+template <int ACT, int WLOADS, int NT>
+int launch_x3_p3(Args& g, hipStream_t st) {
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
   const long long nwg = (long long)g.tiles_m * g.tiles_n;
@@ -1044,12 +1057,17 @@ int launch_x3_p2(Args& g, hipStream_t st) {
   const size_t lds = (size_t)2 * 4 * 256 * 64 + 8 * 4096;   // two stages + the write-out patches: all 160 KiB
   static bool set = false;
   if (!set) {
-    (void)hipFuncSetAttribute((const void*)gemm_x3p_kernel<ACT, WLOADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_x3p_kernel<ACT, WLOADS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     set = true;
   }
   const long long grid = g.ksplit > 1 ? nwg : x3p_grid(nwg);
-  hipLaunchKernelGGL((gemm_x3p_kernel<ACT, WLOADS>), dim3((unsigned)grid, (unsigned)(g.ksplit > 1 ? g.ksplit : 1)), dim3(512), lds, st, g);
+  hipLaunchKernelGGL((gemm_x3p_kernel<ACT, WLOADS, NT>), dim3((unsigned)grid, (unsigned)(g.ksplit > 1 ? g.ksplit : 1)), dim3(512), lds, st, g);
   return HGL_OK;
+}
+
+template <int ACT, int WLOADS>
+int launch_x3_p2(Args& g, hipStream_t st) {
+  return g.lo_zero ? launch_x3_p3<ACT, WLOADS, 2>(g, st) : launch_x3_p3<ACT, WLOADS, 3>(g, st);
 }
 
 template <int ACT>
@@ -1062,6 +1080,12 @@ int launch_x3_p(Args& g, hipStream_t st) {
 template <int ACT>
 int launch_x3(int kind, Args& g, hipStream_t st) {
   return kind == HGL_X3_P ? launch_x3_p<ACT>(g, st) : launch_x3_v1<ACT>(g, st);
+}
+
+// HGL_X3_TERMS=3 keeps the third product for fp16-valued weights too (A/B; the results are the same bit for bit)
+bool x3_two_terms(const SplitW& sw) {
+  const char* v = getenv("HGL_X3_TERMS");      // read per launch: tests flip it inside one process
+  return sw.lo_zero && !(v && v[0] == '3');
 }
 
 int x3_gm() {
@@ -1101,6 +1125,7 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
   g.rmod = rmod; g.amap = amap; g.cmap = cmap;
   g.part = nullptr; g.ksplit = 1;
   g.out_scale = ldexpf(1.0f, -sw.scale_log2);
+  g.lo_zero = x3_two_terms(sw) ? 1 : 0;
   g.gm = x3_gm();
   g.vec4 = x3_vec4_ok(bias, R, ldr, C, Ch, Cl, ldc, N) ? 1 : 0;
   // kernel selection (hgl_gemm_f16x3_select / HGL_X3_KERNEL={v1,P,auto}); both tilings accumulate in the same order
@@ -1189,6 +1214,7 @@ int hgl_launch_gemm_f16x3_splitk(const void* Ah, const void* Al, int lda, const 
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldr = 0; g.ldc = N;
   g.rmod = 0; g.amap = amap; g.cmap = nullptr; g.part = part; g.ksplit = ksplit; g.vec4 = 1;
   g.out_scale = ldexpf(1.0f, -sw.scale_log2);
+  g.lo_zero = x3_two_terms(sw) ? 1 : 0;
   g.gm = 8;
   {
     const long long few_tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
@@ -1229,9 +1255,28 @@ int hgl_register_split_weight(const float* w_fp32, int N, int K, int scale_log2,
   HGL_REQUIRE(w_fp32 && hi && lo && N > 0 && K > 0 && (K & 7) == 0, "register_split_weight: bad arguments (K %% 8)");
   HGL_REQUIRE(scale_log2 >= -24 && scale_log2 <= 24, "register_split_weight: scale_log2 out of range");
   HGL_TRY(hgl_launch_split_f16(w_fp32, ldexpf(1.0f, scale_log2), hi, lo, (long long)N * K, (hipStream_t)stream));
+  // fp16-valued weights (the OpenAI CLIP archives store fp16; clip/model.py:509 is commented out in the reference, so the
+  // model holds those values as fp32): every lo half is zero and the GEMMs drop the A_hi * W_lo products.  One read-back
+  // per weight at model construction.
+  unsigned nz = 1;
+  {
+    const unsigned zero = 0;
+    HGL_REQUIRE(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lo_nonzero), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess,
+                "register_split_weight: flag reset failed");
+    const long long n8 = (long long)N * K / 8;
+    hipLaunchKernelGGL(lo_nonzero_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)lo, n8);
+    HGL_REQUIRE(hipMemcpyFromSymbolAsync(&nz, HIP_SYMBOL(g_lo_nonzero), sizeof(nz), 0, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
+                hipStreamSynchronize((hipStream_t)stream) == hipSuccess, "register_split_weight: flag read-back failed");
+  }
   std::lock_guard<std::mutex> lk(g_split_mu);
-  g_split[(const void*)w_fp32] = SplitW{(const _Float16*)hi, (const _Float16*)lo, scale_log2, N, K};
+  g_split[(const void*)w_fp32] = SplitW{(const _Float16*)hi, (const _Float16*)lo, scale_log2, N, K, nz == 0};
   return HGL_OK;
+}
+
+int hgl_split_weight_is_fp16_valued(const float* w_fp32) {
+  SplitW sw;
+  if (!find_split((const void*)w_fp32, &sw)) return -1;
+  return sw.lo_zero ? 1 : 0;
 }
 
 int hgl_unregister_split_weight(const float* w_fp32) {

@@ -34,7 +34,7 @@ extern "C" {
 
 /* 2: + hgl_clip_hybrid_forward_segments, hgl_split_overflow_count, hgl_clip_encode_text_ex; hgl_gemm_f16x3_select
  * knows kinds -1, 0, 1 only */
-#define HGL_ABI_VERSION 3
+#define HGL_ABI_VERSION 4
 
 /* activation codes for hgl_gemm_f32 */
 #define HGL_ACT_NONE 0
@@ -92,6 +92,11 @@ int hgl_split_overflow_count(int reset, unsigned long long* count);
  * choose max|w| * 2^scale_log2 <= 2^14). */
 int hgl_register_split_weight(const float* w_fp32, int N, int K, int scale_log2, void* hi, void* lo, void* stream);
 int hgl_unregister_split_weight(const float* w_fp32);
+/* 1: every lo half of the registered split is zero -- the weight is fp16-valued, as the tensors of OpenAI's CLIP archives are
+ * (clip/model.py:509 is commented out in the reference: they are held as fp32 with fp16 values) -- and the GEMMs on it issue two
+ * MFMAs per product step instead of three (the A_hi * W_lo products would add exact zeros: same results bit for bit;
+ * HGL_X3_TERMS=3 keeps them).  0: a genuine fp32 weight.  -1: not registered. */
+int hgl_split_weight_is_fp16_valued(const float* w_fp32);
 /* hgl_gemm_f32 semantics (no batch, dense leading dims) through the split path; A is split into
  * `scratch` (>= M*K*4 bytes) first.  W must be registered. */
 int hgl_gemm_f16x3(const float* A, const float* W, const float* bias, const float* R, float* C,

@@ -1,4 +1,6 @@
 """GPU parity of every primitive kernel against the numpy oracle, through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -540,3 +542,45 @@ def test_models_release_their_split_weights_and_keep_their_precision(cuda):
     del m16, solo
     gc.collect()
     assert len(ops._split_cache) == n0
+
+
+def test_gemm_f16x3_fp16_valued_weights_drop_the_zero_products(cuda):
+    """a weight whose values are fp16 numbers (OpenAI's CLIP archives) has an all-zero lo plane: the registry says so and the
+    ping-pong GEMM issues two products per step; the result is that of the three-product kernel (HGL_X3_TERMS=3) and of the
+    register-staged tiling, bit for bit; a genuine fp32 weight keeps three"""
+    import ctypes as C
+    from hybridgl_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=cuda).manual_seed(3)
+    M, N, K = 4096, 768, 512
+    a = torch.randn((M, K), device=cuda, generator=g)
+    w32 = torch.randn((N, K), device=cuda, generator=g) / 22.0
+    w16 = w32.half().float()
+    b = torch.randn((N,), device=cuda, generator=g)
+    r = torch.randn((M, N), device=cuda, generator=g)
+    try:
+        outs = {}
+        for name, w in (("fp32", w32), ("fp16", w16)):
+            for terms in ("auto", "3"):
+                for kind in ("P", "v1"):
+                    ops.select_x3_kernel(kind)
+                    if terms == "3":
+                        os.environ["HGL_X3_TERMS"] = "3"
+                    else:
+                        os.environ.pop("HGL_X3_TERMS", None)
+                    outs[(name, terms, kind)] = ops.gemm_f16x3(a, w, b, r, "quickgelu")
+        assert lib.hgl_split_weight_is_fp16_valued(C.c_void_p(w16.data_ptr())) == 1
+        assert lib.hgl_split_weight_is_fp16_valued(C.c_void_p(w32.data_ptr())) == 0
+        assert lib.hgl_split_weight_is_fp16_valued(C.c_void_p(a.data_ptr())) == -1
+        for name in ("fp32", "fp16"):
+            ref = outs[(name, "3", "v1")]
+            for key, o in outs.items():
+                if key[0] == name:
+                    assert torch.equal(o, ref), key
+        z = torch.nn.functional.linear(a.double(), w16.double(), b.double())
+        z = z * torch.sigmoid(1.702 * z) + r.double()
+        assert float((outs[("fp16", "auto", "P")].double() - z).abs().max()) < 3e-5
+    finally:
+        os.environ.pop("HGL_X3_TERMS", None)
+        ops.select_x3_kernel("auto")
+        ops.release_split_weights([w32.data_ptr(), w16.data_ptr()])
