@@ -230,6 +230,91 @@ def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False, clip_na
                       f"3-sentence tail on 64 masks ({t4 - t3:.1f}s){gem_note}{sam_note}; numpy BLAS threads = host default"}
 
 
+def evaluator_from_disk(args, model, gen, gem_model, dev, group, n_images=208, keep_root=None):
+    """`python -m hybridgl_amd.main --real` on a synthetic REFER tree written to local disk (hybridgl_amd.synth.write_refer_tree:
+    COCO-sized JPEGs of 8 sizes, 2-3 refs per image, 3 sentences per ref, polygon ground truth, parse records, a BPE merges
+    file): JPEG decode, BPE, ground-truth rasterisation and pinned uploads on 4 loader threads (hybridgl_amd.loader.Prefetcher),
+    the two dataset transforms on the device, the product's run() loop with its per-image cache.  Same models as the
+    headline (filters open, first 64 proposals).  Three timings of the SAME refs: from disk; the same items resident in HBM
+    (what the headline's loop sees); from disk with this process confined to 1/8 of the host cores (what a rank of an
+    8-GPU job owns)."""
+    import shutil
+    import tempfile
+    from hybridgl_amd import dist as D, main as drv, synth
+    from hybridgl_amd.pipeline import HybridGLPipeline
+    root = keep_root or tempfile.mkdtemp(prefix="hgl_refer_")
+    try:
+        t0 = time.perf_counter()
+        info = synth.write_refer_tree(root, n_images=n_images)
+        t_write = time.perf_counter() - t0
+        a = drv.default_argument_parser().parse_args([
+            "--real", "--refer_data_root", root, "--dataset", "refcoco", "--split", "val", "--bpe_vocab", os.path.join(root, "bpe.txt.gz"),
+            "--parse_json", os.path.join(root, "parse.json"), "--proposal_cap", str(args.masks), "--group", str(group),
+            "--fusion_mode", args.fusion, "--clip_model", args.clip, "--heatmap", args.heatmap])
+        a.masking_block = CLIP_GEOM[args.clip]["masking_block"]
+
+        def leg(**over):
+            b = argparse.Namespace(**{**vars(a), **over})
+            m, st = drv.evaluate(b, model, gen, gem_model, dev)
+            return m, {"value": st["refs"] / st["seconds"], "unit": "images/s", "refs": st["refs"], "seconds": st["seconds"],
+                       "ms_per_ref": st["seconds"] / max(st["refs"], 1) * 1e3,
+                       "distinct_images_per_s": st["images_decoded"] / st["seconds"] if st["images_decoded"] else None,
+                       "loader_wait_ms_per_group": st["loader_wait_s"] / max(st["groups"] or 1, 1) * 1e3,
+                       "loader_wait_frac": st["loader_wait_s"] / st["seconds"],
+                       "loader_cpu_ms_per_ref": st["loader_make_s"] / max(st["refs"], 1) * 1e3,
+                       "images_decoded": st["images_decoded"], "image_cache_hits": st["image_cache_hits"], "groups": st["groups"],
+                       "skipped": st["skipped"], "workers": st["workers"]}
+        leg(max_refs=4 * group)                               # warm: page cache, allocator, coefficient tables, BPE cache
+        m_disk, disk = leg()
+        # the same items resident in HBM before the clock starts (what bench.py's headline loop is fed)
+        rr = drv.RealRefs(a, dev, "unc", 77)
+        resident = [rr.load(i) for i in rr.jobs()]
+        torch.cuda.synchronize()
+        pipe = HybridGLPipeline(model, fusion_mode=args.fusion, masking_block=a.masking_block, mask_generator=gen, use_sam_masks=True,
+                                gem_model=gem_model)
+        t1 = time.perf_counter()
+        n = pipe.run(iter(resident), group=group, proposal_cap=args.masks)
+        torch.cuda.synchronize()
+        t_res = time.perf_counter() - t1
+        m_res = pipe.metrics()
+        del resident, pipe
+        torch.cuda.empty_cache()
+        # 1/8 of the cores: this thread (and the loader threads it starts) confined like rank 0 of an 8-rank job
+        all_cores = sorted(os.sched_getaffinity(0))
+        share = D.rank_cpu_affinity(0, 8, all_cores)
+        eighth = None
+        if share:
+            old_threads = torch.get_num_threads()
+            os.sched_setaffinity(0, share)
+            D.size_host_threads(share, a.workers)
+            try:
+                _, eighth = leg()
+                eighth["host_cores"] = len(share)
+            finally:
+                os.sched_setaffinity(0, all_cores)
+                torch.set_num_threads(old_threads)
+        out = dict(disk)
+        out.update({
+            "config": f"synthetic REFER tree on local disk: {info['images']} JPEGs (8 COCO sizes up to 640x640), {info['refs']} refs "
+                      f"(2-3 per image, ~10 % of them ~20 images late), {info['sentences']} sentences; python -m hybridgl_amd.main "
+                      f"--real --group {group} --workers {a.workers} --proposal_cap {args.masks} (evaluate()), filters open; the refs of an "
+                      "image share its proposals / hybrid / GEM features (the product's image cache), so a ref costs less "
+                      "than a headline step, whose refs are all different images",
+            "host_cores": len(all_cores),
+            "tree_write_s": t_write,
+            "resident_same_items": {"value": n / t_res, "unit": "images/s", "seconds": t_res,
+                                    "note": "the same RefBatches already in HBM, same run() call, same image cache"},
+            "disk_over_resident": (disk["value"] / (n / t_res)) if n else None,
+            "one_eighth_of_host_cores": eighth,
+            "metrics_equal_resident": m_disk == m_res,
+            "metrics": m_disk,
+        })
+        return out
+    finally:
+        if keep_root is None:
+            shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,6 +354,9 @@ def main():
     ap.add_argument("--no-also", action="store_true",
                     help="skip the short secondary timings (seeded masks, L2G, G2L&L2G, strict fp32, ViT-L/14, PhraseCut) that are "
                          "attached under the `also` key at N = 1")
+    ap.add_argument("--no-rccl-check", action="store_true",
+                    help="N = 1: skip the RCCL self-check (nccl backend in a world of one, the timed steps' metric rows through it)")
+    ap.add_argument("--no-disk", action="store_true", help="skip also['evaluator_from_disk'] (the evaluator fed from a REFER tree on disk)")
     ap.add_argument("--timeout", type=float, default=3600.0, help="--gpus N without a launcher: seconds before the ranks are killed")
     args = ap.parse_args()
 
@@ -292,6 +380,7 @@ def main():
     local_dev = local_rank % ngpu      # identity on a node with one GPU per rank
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     cores = D.pin_rank_to_cores(local_rank, local_world)    # each rank's launch thread on its own share of the host cores
+    D.size_host_threads(cores, 4)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     dist = None
@@ -483,6 +572,22 @@ def main():
         del gen_pc, pc_refs
         torch.cuda.empty_cache()
 
+    # ---- the evaluator's real feed: a REFER tree on disk through hybridgl_amd.main.evaluate (loader threads -> run())
+    if also is not None and not args.no_disk:
+        try:
+            also["evaluator_from_disk"] = evaluator_from_disk(args, model, gen, gem_model, dev, nbatch)
+        except Exception as e:      # the headline must not die with a secondary leg
+            also["evaluator_from_disk"] = {"error": repr(e)}
+
+    # ---- RCCL once on a 1-GPU box: the nccl branch of hybridgl_amd/dist.py in a world of one (device tensors through the
+    # same two all-gathers + all-reduce the multi-GPU job uses); no process group is alive here at N = 1
+    rccl = None
+    if world == 1 and not args.no_rccl_check:
+        try:
+            rccl = D.rccl_selfcheck(dev, rows)
+        except Exception as e:
+            rccl = {"error": repr(e)}
+
     if rank == 0:
         total_refs = args.steps * world
         traffic, traffic_src = None, None
@@ -569,6 +674,8 @@ def main():
         rec["roofline"]["traffic_source"] = traffic_src
         if also is not None:
             rec["also"] = also
+        if rccl is not None:
+            rec["rccl_selfcheck"] = rccl
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.fusion, with_sam=args.scope == "B", with_gem=use_gem, clip_name=args.clip)
         print(json.dumps(rec))

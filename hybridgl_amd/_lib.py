@@ -108,6 +108,7 @@ PROTOTYPES = {
     "hgl_get_precision": (_I, []),
     "hgl_gemm_f16x3_select": (_I, [_I]),
     "hgl_split_overflow_count": (_I, [_I, C.POINTER(C.c_ulonglong)]),
+    "hgl_split_overflow_peek_async": (_I, [_VP, _VP]),
     "hgl_register_split_weight": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP]),
     "hgl_unregister_split_weight": (_I, [_VP]),
     "hgl_split_weight_is_fp16_valued": (_I, [_VP]),
@@ -172,6 +173,7 @@ PROTOTYPES = {
     "hgl_gaussian_blur_u8": (_I, [_VP, _I, _I, _I, C.POINTER(C.c_double), _I, _VP, _VP, _SZ, _VP]),
     "hgl_cv_gaussian_kernel_q8": (_I, [_I, C.c_double, C.POINTER(C.c_uint16)]),
     "hgl_gaussian_blur_u8_q8": (_I, [_VP, _I, _I, _I, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), _I, _VP, _VP, _SZ, _VP]),
+    "hgl_u8_to_chw_lut": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP]),
     "hgl_gt_mask_from_polygons": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP]),
     "hgl_gt_mask_from_rle_counts": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "hgl_gt_mask_from_rle_string": (_I, [C.c_char_p, _I, _I, _VP, _VP]),
@@ -180,7 +182,7 @@ PROTOTYPES = {
 }
 
 _lib = None
-ABI_VERSION = 4   # include/hybridgl.h HGL_ABI_VERSION
+ABI_VERSION = 5   # include/hybridgl.h HGL_ABI_VERSION
 
 
 def load():

@@ -95,6 +95,20 @@ int hgl_split_overflow_count(int reset, unsigned long long* count) {
   return HGL_OK;
 }
 
+// The same counters copied to `host2` (two words of PINNED host memory: GEMM, attention) in stream order, without waiting:
+// the value is what the device had counted when the stream reached this point.  Lets a caller that already reads something
+// back per batch (the evaluator's proposal counts) notice an overflow within that batch instead of at the end of the run.
+int hgl_split_overflow_peek_async(unsigned int* host2, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(host2 != nullptr, "split_overflow_peek_async: null argument");
+  if (hgl_split_overflow_gemm_peek(host2, (hipStream_t)stream) != 0 ||
+      hgl_split_overflow_attention_peek(host2 + 1, (hipStream_t)stream) != 0) {
+    hgl_set_error("split_overflow_peek_async: hipMemcpyFromSymbolAsync failed");
+    return HGL_ELAUNCH;
+  }
+  return HGL_OK;
+}
+
 int hgl_abi_version(void) { return HGL_ABI_VERSION; }
 const char* hgl_last_error(void) { return g_err; }
 

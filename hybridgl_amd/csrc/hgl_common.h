@@ -49,6 +49,10 @@ __device__ __forceinline__ void hgl_split_commit(float amax) {
       (void)hipMemcpyToSymbol(HIP_SYMBOL(hgl_tu_split_overflow), &z, sizeof(z));                      \
     }                                                                                                 \
     return v;                                                                                         \
+  }                                                                                                   \
+  int name##_peek(unsigned int* dst, hipStream_t st) {                                                \
+    return hipMemcpyFromSymbolAsync(dst, HIP_SYMBOL(hgl_tu_split_overflow), sizeof(unsigned int), 0,  \
+                                    hipMemcpyDeviceToHost, st) == hipSuccess ? 0 : -1;                \
   }
 // ---- activations of the GEMM epilogues ------------------------------------------------------------------------------
 // nn.GELU (erf form; segment_anything/modeling/common.py:13-24 MLPBlock, mask_decoder.py:76-80): 0.5 x (1 + erf(x / sqrt 2)).
@@ -78,6 +82,8 @@ __device__ __forceinline__ float hgl_quick_gelu(float x) {
 #endif  // __HIPCC__ (device helpers: the host-only sources of the library include this header too)
 
 unsigned long long hgl_split_overflow_gemm(int reset);
+int hgl_split_overflow_gemm_peek(unsigned int* dst, hipStream_t st);
+int hgl_split_overflow_attention_peek(unsigned int* dst, hipStream_t st);
 unsigned long long hgl_split_overflow_attention(int reset);
 
 void hgl_set_error(const char* fmt, ...);

@@ -56,6 +56,32 @@ __global__ __launch_bounds__(256) void pil_resample_kernel(const uint8_t* __rest
   out[r * out_outer_stride + (long long)o * out_axis_stride + c] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
 }
 
+// ToTensor + Normalize of a uint8 HWC image as a table look-up: out[c, y, x] = lut[c * 256 + img[y, x, c]].  The 3 x 256
+// table is computed on the host with the reference's own fp32 arithmetic ((v / 255 - mean) / std), so the result is the
+// reference's bit for bit whatever the device's division does.  Thread = 4 consecutive pixels of one channel plane.
+__global__ __launch_bounds__(256) void u8_to_chw_lut_kernel(const uint8_t* __restrict__ img, const float* __restrict__ lut,
+                                                            float* __restrict__ out, long long HW, int C) {
+  const long long q = blockIdx.x * 256ll + threadIdx.x;     // quad of pixels
+  const int c = blockIdx.y;
+  const long long p0 = q * 4;
+  if (p0 >= HW) return;
+  const float* t = lut + c * 256;
+  if (p0 + 4 <= HW) {
+    f32x4 v;
+    v[0] = t[img[(p0 + 0) * C + c]];
+    v[1] = t[img[(p0 + 1) * C + c]];
+    v[2] = t[img[(p0 + 2) * C + c]];
+    v[3] = t[img[(p0 + 3) * C + c]];
+    if ((((size_t)(out + (long long)c * HW + p0)) & 15) == 0) {
+      *(f32x4*)(out + (long long)c * HW + p0) = v;
+    } else {
+      for (int j = 0; j < 4; ++j) out[(long long)c * HW + p0 + j] = v[j];
+    }
+  } else {
+    for (long long p = p0; p < HW; ++p) out[(long long)c * HW + p] = t[img[p * C + c]];
+  }
+}
+
 // Hw[(wy*nwx + wx)*ws*ws + py*ws + px, :] = (y<g && x<g) ? H[y*g+x, :] : 0
 __global__ __launch_bounds__(256) void win_partition_kernel(const float* __restrict__ H, int g, int ws,
                                                             int nw, int D4, float* __restrict__ Hw,
@@ -1293,6 +1319,14 @@ int hgl_resize_pil_bilinear(const uint8_t* img, int H, int W, int C, int out_h, 
                        ksize_y, out_h, 1ll, (long long)out_w * C, 0ll, (long long)out_w * C, 0ll, (long long)out_w * C);
   }
   return hgl_check_launch("resize_pil_bilinear");
+}
+
+int hgl_u8_to_chw_lut(const uint8_t* img, int H, int W, int C, const float* lut, float* out, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(img && lut && out && H > 0 && W > 0 && C > 0 && C <= 4, "u8_to_chw_lut: bad arguments");
+  const long long HW = (long long)H * W;
+  hipLaunchKernelGGL(u8_to_chw_lut_kernel, dim3(grid1((HW + 3) / 4), C), dim3(256), 0, (hipStream_t)stream, img, lut, out, HW, C);
+  return hgl_check_launch("u8_to_chw_lut");
 }
 
 size_t hgl_sam_postprocess_workspace_bytes(int K) { return hgl_align_up((size_t)K * 6 * sizeof(unsigned), 256); }

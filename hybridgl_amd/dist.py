@@ -74,12 +74,13 @@ def _comm_device(dist, device):
     return torch.device("cpu")
 
 
-def gather_rows(rows, dist=None, device=None):
+def gather_rows(rows, dist=None, device=None, force=False):
     """All ranks' per-sentence rows [n, 6] int64 (ROW_FIELDS) -> the rows of the whole job on every rank.
-    Two all-gathers: the row counts, then the rows padded to the largest count."""
+    Two all-gathers: the row counts, then the rows padded to the largest count.  A world of one returns its rows as they
+    are unless force=True, which sends them through the collectives anyway (the RCCL self-check of a 1-GPU box)."""
     import torch
     rows = np.ascontiguousarray(np.asarray(rows, dtype=np.int64).reshape(-1, len(ROW_FIELDS)))
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return rows
     world = dist.get_world_size()
     cdev = _comm_device(dist, device)
@@ -129,14 +130,38 @@ def gather_metrics(rows, dist=None, device=None):
     return metrics_from_rows(gather_rows(rows, dist, device))
 
 
-def max_over_ranks(value, dist=None, device=None):
+def max_over_ranks(value, dist=None, device=None, force=False):
     """the job's time = the slowest rank's"""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(dist, device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def rccl_selfcheck(device, rows=None):
+    """Initialise the `nccl` (= RCCL) backend with a world of ONE on `device` and push metric rows through the same
+    collectives a multi-GPU job uses (gather_rows / max_over_ranks with force=True): librccl load, communicator creation and
+    the device-tensor branch run on a 1-GPU box.  Returns {"backend", "world_size_seen", "rows_roundtrip_ok", "max_ok",
+    "seconds"}; the process group is destroyed again.  Must not be called while another process group is alive."""
+    import time
+    import torch.distributed as dist
+    t0 = time.perf_counter()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        if rows is None:
+            rows = np.arange(42, dtype=np.int64).reshape(7, 6) * 1000003
+        got = gather_rows(rows, dist, device, force=True)
+        mx = max_over_ranks(3.25, dist, device, force=True)
+        dist.barrier()
+        return {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                "rows_roundtrip_ok": bool(np.array_equal(got, np.asarray(rows, dtype=np.int64).reshape(-1, len(ROW_FIELDS)))),
+                "max_ok": mx == 3.25, "seconds": time.perf_counter() - t0}
+    finally:
+        dist.destroy_process_group()
 
 
 def free_port():
@@ -169,6 +194,18 @@ def pin_rank_to_cores(local_rank, local_world):
         except OSError:
             return []
     return cores
+
+
+def size_host_threads(cores, workers=4):
+    """After pin_rank_to_cores: size torch's intra-op (OpenMP) pool for the share of cores this rank owns.  `import torch`
+    sized it for ALL host cores; the loader threads' tensor ops would each fan out to that pool on the rank's small share
+    and oversubscribe exactly the cores the launch thread needs.  Returns the thread count set (None: not pinned)."""
+    if not cores:
+        return None
+    import torch
+    n = max(1, len(cores) // (int(workers) + 1))
+    torch.set_num_threads(n)
+    return n
 
 
 def spawn_local_ranks(n, argv, extra_env=None, timeout=None, poll_s=0.05):

@@ -28,8 +28,23 @@ class Prefetcher:
         self.device = device
         self._tls = threading.local()
         self.max_in_flight = 0     # high-water mark of prepared-but-unconsumed items (tests: the look-ahead is bounded)
+        # where the host time goes (read by hybridgl_amd.main / bench.py): seconds the workers spent preparing items, seconds
+        # the consumer sat waiting for the next item, items delivered
+        self.make_s = 0.0
+        self.wait_s = 0.0
+        self.items = 0
+        self._stat_lock = threading.Lock()
 
     def _run(self, job):
+        import time
+        t0 = time.perf_counter()
+        try:
+            return self._run_inner(job)
+        finally:
+            with self._stat_lock:
+                self.make_s += time.perf_counter() - t0
+
+    def _run_inner(self, job):
         if self.device is None:
             return self.make(job)
         import torch
@@ -47,6 +62,7 @@ class Prefetcher:
         return item
 
     def __iter__(self):
+        import time
         it = iter(self.jobs)
         q = collections.deque()
         with ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="hgl-loader") as pool:
@@ -57,7 +73,10 @@ class Prefetcher:
                         break
                 while q:
                     self.max_in_flight = max(self.max_in_flight, len(q))
+                    t0 = time.perf_counter()
                     item = q.popleft().result()      # re-raises the worker's exception at this position
+                    self.wait_s += time.perf_counter() - t0
+                    self.items += 1
                     for job in it:                   # keep the window full: one new job per consumed item
                         q.append(pool.submit(self._run, job))
                         break

@@ -53,6 +53,12 @@ def default_argument_parser():
     p.add_argument("--group", type=int, default=16,
                    help="images taken at a time by the two-stream loop (HybridGLPipeline.run); 1 = ref by ref on one stream")
     p.add_argument("--workers", type=int, default=4, help="loader threads (Hybridgl_main.py:45 num_workers)")
+    p.add_argument("--proposal_cap", type=int, default=0,
+                   help="keep at most this many proposals of the first NMS order per image (0 = all; the benchmark's fixed 64)")
+    p.add_argument("--host_transforms", action="store_true",
+                   help="ToTensor/Normalize and the GEM transform on the loader threads' CPU (numpy / PIL) as the reference's "
+                        "DataLoader workers do, instead of bit-identical device kernels (hybridgl_amd/transforms.py)")
+    p.add_argument("--stats_json", default="", help="rank 0 writes {stats, metrics} of the run here (throughput, loader wait)")
     p.add_argument("--k_clamp", default="auto", choices=["auto", "persistent", "per_ref"],
                    help="the k1 / k2 clamp of Hybridgl_main.py:178-181: persistent = the reference's quirk (once an image yields "
                         "fewer than 3 / 6 proposals the clamp stays for every later item OF THE PROCESS: depends on the number of "
@@ -72,53 +78,129 @@ def sentence_strings(raw, rec):
     return [raw, rec.get("noun_phrase", raw)] + [OTHER_NOUN_PREFIX + o for o in others]
 
 
+class _Slot:
+    """one image of RealRefs' look-aside: filled by the loader thread that met the image first, awaited by the others"""
+    __slots__ = ("done", "value", "error")
+
+    def __init__(self):
+        import threading
+        self.done, self.value, self.error = threading.Event(), None, None
+
+
 class RealRefs:
     """The dataset side of the loop (Hybridgl_main.py:40-45,79-146): `jobs(rank, world)` = the dataset positions of this
-    rank in the loader's order, `load(i)` = one RefBatch (image decode, GEM transform, strings, tokens, ground truth on the
-    host; uploads on the calling thread's current stream).  `load` is what hybridgl_amd.loader.Prefetcher runs on its
-    background threads."""
+    rank in the loader's order, `load(i)` = one RefBatch.  `load` is what hybridgl_amd.loader.Prefetcher runs on its
+    background threads, each with its own copy stream current:
 
-    def __init__(self, args, dev, splitBy, context_length):
+        host    JPEG decode (PIL), BPE, ground-truth rasterisation (native codec), pinned uploads of the uint8 image,
+                the tokens and the target
+        device  image['image'] = ToTensor + Normalize and image['tensor_img'] = the GEM transform (bicubic resize to
+                448 x 448 + Normalize), bit-identical to the host transforms (hybridgl_amd/transforms.py) -- 24 of the
+                28 ms of host work an item costs the reference's workers; `device_transforms=False` restores the host
+                versions (numpy / PIL)
+
+    The dataset yields one item per REF and re-decodes the image for each (data/dataset_refer_bert.py:103-110); here
+    the decoded image and its two device tensors are shared by the refs of an image that the loader meets within its
+    look-ahead (`image_lru` images)."""
+
+    def __init__(self, args, dev, splitBy, context_length, device_transforms=True, image_lru=48):
+        import collections
         import json
+        import threading
         from .refer_io import ReferDataset
         from .tokenizer import SimpleTokenizer
         from .gem import get_gem_img_transform
         self.args, self.dev, self.context_length = args, dev, context_length
         self.ds = ReferDataset(args.refer_data_root, args.dataset, splitBy, args.split)
         self.tk = SimpleTokenizer(args.bpe_vocab or None)
+        self._tk_lock = threading.Lock()        # the BPE cache is a plain dict shared by the loader threads
         self.preprocess = get_gem_img_transform()                                       # Hybridgl_main.py:39
         self.parse = json.load(open(args.parse_json)) if args.parse_json else {}
         self.n = len(self.ds) if args.max_refs <= 0 else min(len(self.ds), args.max_refs)
+        self.device_transforms = device_transforms
+        self.image_lru = int(image_lru)
+        self._imgs = collections.OrderedDict()
+        self._lock = threading.Lock()
+        self.decoded = 0        # images decoded / uploaded (<= items loaded)
 
     def jobs(self, rank=0, world=1):
         from .dist import shard_by_groups
-        image_ids = [self.ds.refer.Refs[r]["image_id"] for r in self.ds.ref_ids[:self.n]]
+        image_ids = [self.ds.image_id(i) for i in range(self.n)]
         return shard_by_groups(image_ids, rank, world)   # refs of one image stay on one rank (per-image cache)
+
+    def _image(self, i):
+        """(sam_img u8 [H,W,3], image_norm f32 [3,H,W], tensor_img f32 [3,448,448] | None) of item i on the device, valid
+        on the calling thread's current stream."""
+        iid = self.ds.image_id(i)
+        with self._lock:
+            slot = self._imgs.get(iid) if self.image_lru > 0 else None
+            owner = slot is None
+            if owner:
+                slot = _Slot()
+                if self.image_lru > 0:
+                    self._imgs[iid] = slot
+                    while len(self._imgs) > self.image_lru:
+                        self._imgs.popitem(last=False)
+            elif self.image_lru > 0:
+                self._imgs.move_to_end(iid)
+        if not owner:
+            slot.done.wait()
+            if slot.error is not None:
+                raise slot.error
+            ev, val = slot.value
+            torch.cuda.current_stream().wait_event(ev)     # the uploads ran on another loader thread's stream
+            return val
+        try:
+            from . import synth, transforms as T
+            from .loader import pin_upload
+            img = self.ds.image(i)
+            sam_img = pin_upload(img, self.dev)
+            want_gem = self.args.heatmap == "device"
+            if self.device_transforms:
+                norm = T.to_tensor_normalize(sam_img)
+                timg = T.gem_img_transform(sam_img) if want_gem else None
+            else:
+                norm = pin_upload(synth.imagenet_normalize(img), self.dev)
+                timg = pin_upload(self.preprocess(img), self.dev) if want_gem else None
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with self._lock:
+                self.decoded += 1
+            slot.value = (ev, (sam_img, norm, timg))
+            return slot.value[1]
+        except BaseException as e:
+            slot.error = e
+            with self._lock:
+                self._imgs.pop(iid, None)
+            raise
+        finally:
+            slot.done.set()
 
     def load(self, i):
         import numpy as np
-        from . import synth
-        from .gem import GEMWrapper
+        from .gem import GEMWrapper, resize_antialias
         from .loader import pin_upload
         from .pipeline import RefBatch, Sentence
         from .tokenizer import tokenize
         args, dev = self.args, self.dev
-        data, annot, sentences = self.ds[i]
-        img = data["sam_img"]
-        H, W = img.shape[:2]
+        sam_img, image_norm, tensor_img = self._image(i)
+        H, W = sam_img.shape[:2]
+        rid = self.ds.ref_ids[i]
+        ref = self.ds.refer.Refs[rid]
+        annot, sentences = self.ds.target(i), self.ds.sentence_raws[i]
         strings, sents = [], []
         t = lambda a: pin_upload(a, dev)
-        for sent_id, raw in zip(data["sent_ids"], sentences):
+        for sent_id, raw in zip(ref["sent_ids"], sentences):
             rec = self.parse.get(str(sent_id), {})
             row = len(strings)
             others = list(rec.get("other_nouns", []))   # extract_nouns' phrases, bare (utils.py:82-98)
             strings += sentence_strings(raw, rec)
             attn = None
             if args.heatmap_dir and os.path.exists(os.path.join(args.heatmap_dir, f"{sent_id}.npy")):
-                a = torch.from_numpy(np.load(os.path.join(args.heatmap_dir, f"{sent_id}.npy")).astype(np.float32))
-                if tuple(a.shape) != (H, W):     # Hybridgl_main.py:201-202: bilinear to the image size
-                    a = torch.nn.functional.interpolate(a[None, None], size=(H, W), mode="bilinear", align_corners=False)[0, 0]
-                attn = t(a)
+                a = t(np.load(os.path.join(args.heatmap_dir, f"{sent_id}.npy")).astype(np.float32))
+                if tuple(a.shape) != (H, W):     # Hybridgl_main.py:201: T.Resize((h, w), antialias=True)
+                    a = resize_antialias(a[None], (H, W))[0]
+                attn = a
             gem_row = None
             if attn is None and args.heatmap == "device":
                 gem_row = len(strings)                                         # Hybridgl_main.py:200 gem_model(tensor_img, [noun_phrase])
@@ -127,11 +209,12 @@ class RealRefs:
                 attn = torch.ones((H, W), dtype=torch.float32, device=dev)     # uniform: no spatial guidance
             sents.append(Sentence(row, row + 1, list(range(row + 2, row + 2 + len(others))), rec.get("dirflag", "none"),
                                   rec.get("relaflag", "none"), len(others), attn, gem_row=gem_row))
-        tokens = tokenize(strings, context_length=self.context_length, tokenizer=self.tk)   # raises on over-long text, as clip.tokenize
+        with self._tk_lock:
+            tokens = tokenize(strings, context_length=self.context_length, tokenizer=self.tk)   # raises on over-long text, as clip.tokenize
         placeholder = torch.zeros((1, H, W), dtype=torch.bool, device=dev)
-        return RefBatch(t(img), None, t(synth.imagenet_normalize(img)), placeholder,
+        return RefBatch(sam_img, None, image_norm, placeholder,
                         torch.zeros((1, 4), dtype=torch.int64, device=dev), t(tokens), t(annot), sents, None,
-                        int(data["img_id"][0]), tensor_img=t(self.preprocess(img)) if args.heatmap == "device" else None,
+                        int(ref["image_id"]), tensor_img=tensor_img,
                         token_len=int(tokens.argmax(axis=1).max()) + 1, index=i)
 
 
@@ -142,17 +225,13 @@ def real_refs(args, dev, splitBy, context_length, rank=0, world=1):
         yield rr.load(i)
 
 
-def main(args):
+def split_by(dataset):
+    return "umd" if dataset == "refcocog" else "unc"          # Hybridgl_main.py:26-29
+
+
+def build_models(args, dev):
+    """(CLIPViTFM, SamAutomaticMaskGenerator | None, GEM model | None) as Hybridgl_main.py:36-38,47-48,66-74 builds them"""
     from .backbone import CLIPViTFM
-    from .pipeline import EmptyProposals, HybridGLPipeline, synthetic_ref
-    from . import dist as D
-    assert torch.cuda.is_available(), "hybridgl_amd has no CPU path"
-    rank, local_rank, world = D.env_rank()
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
-    cores = D.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # launch + loader threads of a rank on its own cores
-    torch.cuda.set_device(dev)
-    dist = D.init_process_group(os.environ.get("HYBRIDGL_DIST_BACKEND", "nccl"), dev) if world > 1 else None
-    splitBy = "umd" if args.dataset == "refcocog" else "unc"          # Hybridgl_main.py:26-29
     model = CLIPViTFM(model_name=args.clip_model, device=dev).eval()
     gen = None
     if args.sam or args.real:
@@ -166,17 +245,26 @@ def main(args):
     if args.heatmap == "device":
         from .gem import create_gem_model
         gem_model = create_gem_model(args.clip_model, clip=model)          # Hybridgl_main.py:36-38 (same checkpoint: shared weights)
-    k_clamp = args.k_clamp if args.k_clamp != "auto" else ("persistent" if world == 1 else "per_ref")
-    pipe = HybridGLPipeline(model, fusion_mode=args.fusion_mode, masking_block=9, mask_generator=gen,
-                            use_sam_masks=args.real, gem_model=gem_model, k_clamp=k_clamp)
-    if rank == 0:
-        print(f"fusion mode={args.fusion_mode}")
-        if world > 1:
-            print(f"ranks: {dist.get_world_size()} ({dist.get_backend()}), k_clamp={k_clamp}, host cores per rank: {len(cores) or 'unpinned'}")
+    return model, gen, gem_model
+
+
+def evaluate(args, model, gen, gem_model, dev, rank=0, world=1, dist=None):
+    """The loop of Hybridgl_main.py:79-247 over this rank's share of the dataset: loader threads -> HybridGLPipeline.run ->
+    one exchange of the metric rows.  Returns (metrics of the whole job, stats of this rank: refs, seconds of the loop,
+    seconds the loop waited for the loader, host seconds spent preparing items, images decoded, image-cache hits,
+    refs skipped)."""
+    import time
     from .loader import Prefetcher
+    from .pipeline import EmptyProposals, HybridGLPipeline, synthetic_ref
+    from . import dist as D
+    k_clamp = args.k_clamp if args.k_clamp != "auto" else ("persistent" if world == 1 else "per_ref")
+    pipe = HybridGLPipeline(model, fusion_mode=args.fusion_mode, masking_block=getattr(args, "masking_block", 9), mask_generator=gen,
+                            use_sam_masks=args.real, gem_model=gem_model, k_clamp=k_clamp)
+    rr = None
     if args.real:
         from .weights import CLIP_CONFIGS
-        rr = RealRefs(args, dev, splitBy, CLIP_CONFIGS[args.clip_model]["context_length"])
+        rr = RealRefs(args, dev, split_by(args.dataset), CLIP_CONFIGS[args.clip_model]["context_length"],
+                      device_transforms=not getattr(args, "host_transforms", False))
         jobs, make = rr.jobs(rank, world), rr.load
     else:
         jobs = D.shard_indices(args.synthetic, rank, world)
@@ -184,22 +272,58 @@ def main(args):
                                        device_blur=True)[0]
     # Hybridgl_main.py:45,79: DataLoader(num_workers=4) feeding the loop; here loader threads feed the grouped loop
     loader = Prefetcher(jobs, make, workers=args.workers, depth=2 * args.group + 2, device=dev)
+    cap = getattr(args, "proposal_cap", 0) or None
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
     if args.group <= 1:      # ref by ref on one stream (Hybridgl_main.py:79-230 as written)
+        n = 0
         for ref in loader:
             try:
                 pipe.step(ref)
+                n += 1
             except EmptyProposals:
                 pipe.skipped = getattr(pipe, "skipped", 0) + 1
     else:
-        pipe.run(loader, group=args.group)
-    if getattr(pipe, "skipped", 0):
-        # the reference would fail on an image without proposals; count and go on
-        print(f"{pipe.skipped} refs skipped: the proposal stage returned no mask")
+        n = pipe.run(loader, group=args.group, proposal_cap=cap)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
     m = pipe.metrics(dist)      # one all-gather of the metric rows; identical on every rank
+    stats = {"refs": n, "seconds": dt, "loader_wait_s": loader.wait_s, "loader_make_s": loader.make_s,
+             "images_decoded": rr.decoded if rr is not None else None, "image_cache_hits": pipe.cache_hits,
+             "skipped": getattr(pipe, "skipped", 0), "groups": getattr(pipe, "groups_run", None),
+             "workers": args.workers, "group": args.group}
+    return m, stats
+
+
+def main(args):
+    from . import dist as D
+    assert torch.cuda.is_available(), "hybridgl_amd has no CPU path"
+    rank, local_rank, world = D.env_rank()
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    cores = D.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # launch + loader threads of a rank on its own cores
+    D.size_host_threads(cores, args.workers)
+    torch.cuda.set_device(dev)
+    dist = D.init_process_group(os.environ.get("HYBRIDGL_DIST_BACKEND", "nccl"), dev) if world > 1 else None
+    splitBy = split_by(args.dataset)
+    model, gen, gem_model = build_models(args, dev)
+    if rank == 0:
+        print(f"fusion mode={args.fusion_mode}")
+        if world > 1:
+            print(f"ranks: {dist.get_world_size()} ({dist.get_backend()}), host cores per rank: {len(cores) or 'unpinned'}")
+    m, stats = evaluate(args, model, gen, gem_model, dev, rank, world, dist)
+    if stats["skipped"]:
+        # the reference would fail on an image without proposals; count and go on
+        print(f"{stats['skipped']} refs skipped: the proposal stage returned no mask")
     if dist is not None:
         dist.destroy_process_group()
     if rank != 0:
         return m
+    if getattr(args, "stats_json", ""):
+        import json
+        stats["refs_per_s"] = stats["refs"] / stats["seconds"] if stats["seconds"] > 0 else 0.0
+        stats["world"] = world
+        stats["host_cores_per_rank"] = len(cores) if cores else len(os.sched_getaffinity(0))
+        json.dump({"stats": stats, "metrics": m}, open(args.stats_json, "w"))
     text = (f"\n\n fusion_mode={args.fusion_mode} "
             f"\nDataset: {args.dataset} / {args.split} / {splitBy}"
             f"\nOverall IoU / mean IoU"

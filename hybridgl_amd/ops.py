@@ -129,13 +129,24 @@ def split_overflow_count(reset=True, sync=True):
     return int(n.value)
 
 
+def split_overflow_peek(buf):
+    """Enqueue, on the current stream, a copy of the two overflow counters into `buf` (pinned int32 [2] host tensor): no
+    wait, no reset.  Read buf after an event recorded behind this call has completed."""
+    assert buf.is_pinned() and buf.dtype == torch.int32 and buf.numel() >= 2
+    check(_lib.load().hgl_split_overflow_peek_async(buf.data_ptr(), _stream()), "hgl_split_overflow_peek_async")
+
+
+class SplitOverflow(_lib.HybridGLError):
+    """an activation left the fp16 range in f16x3 mode: the results since the last clean check contain inf / NaN"""
+
+
 def check_split_overflow():
     """raise if the f16x3 path met a value it cannot represent (the results since the last check are then not
     fp32-class); the cure is HYBRIDGL_PRECISION=f32"""
     n = split_overflow_count(reset=True)
     if n:
-        raise _lib.HybridGLError(f"activations exceeded the fp16 range (|x| > 65504) in f16x3 mode ({n} GPU threads saw one): "
-                                 "the results contain inf / NaN; rerun with HYBRIDGL_PRECISION=f32 (or precision='f32')")
+        raise SplitOverflow(f"activations exceeded the fp16 range (|x| > 65504) in f16x3 mode ({n} GPU threads saw one): "
+                            "the results contain inf / NaN; rerun with HYBRIDGL_PRECISION=f32 (or precision='f32')")
 
 
 X3_KERNELS = {"auto": -1, "v1": 0, "P": 1}

@@ -326,7 +326,9 @@ class HybridGLPipeline:
         self.skipped = getattr(self, "skipped", 0)
         done = 0
         pending = None
+        self.groups_run = getattr(self, "groups_run", 0)
         for units in self._units(loader, group):
+            self.groups_run += 1
             produced = None
             if not serial:      # items a lazy loader built on the caller's stream just now
                 produced = torch.cuda.Event()
@@ -377,7 +379,15 @@ class HybridGLPipeline:
             if state is not None:
                 with torch.cuda.stream(s_sam):
                     if state[0] == "group":
-                        got = [p[:2] for p in gen.group_finish(gen.group_cleanup(state[1]))]
+                        stc = gen.group_cleanup(state[1])
+                        if stc.overflow:
+                            # fail at THIS group, not in metrics() after the whole dataset: the counter rode on the group's
+                            # count read-back (everything the device had finished by then, on any stream)
+                            raise ops.SplitOverflow(
+                                f"activations exceeded the fp16 range (|x| > 65504) in f16x3 mode by group {self.groups_run} of the "
+                                f"loop ({stc.overflow} GPU threads saw one; refs up to dataset position {units[-1][-1].index}): the "
+                                "results from the previous group on contain inf / NaN; rerun with HYBRIDGL_PRECISION=f32 (or precision='f32')")
+                        got = [p[:2] for p in gen.group_finish(stc)]
                     else:
                         got = state[1]
                     ready = torch.cuda.Event()

@@ -149,14 +149,26 @@ class ReferDataset:
     def __len__(self):
         return len(self.ref_ids)
 
-    def __getitem__(self, index):
+    def image_id(self, index):
+        return self.refer.Refs[self.ref_ids[index]]["image_id"]
+
+    def image(self, index):
+        """the decoded RGB image of item `index`, uint8 [H, W, 3] (data/dataset_refer_bert.py:107-110)"""
         from PIL import Image
+        img_info = self.refer.Imgs[self.image_id(index)]
+        return np.array(Image.open(os.path.join(self.refer.IMAGE_DIR, img_info["file_name"])).convert("RGB"))
+
+    def target(self, index):
+        """ground truth of item `index`: the pixels covered by exactly one polygon (:112-121), uint8 [H, W]"""
+        return (self.refer.getMask(self.refer.Refs[self.ref_ids[index]])["mask"] == 1).astype(np.uint8)
+
+    def __getitem__(self, index, sam_img=None):
         rid = self.ref_ids[index]
         ref = self.refer.Refs[rid]
         img_info = self.refer.Imgs[ref["image_id"]]
-        sam_img = np.array(Image.open(os.path.join(self.refer.IMAGE_DIR, img_info["file_name"])).convert("RGB"))
-        ref_mask = self.refer.getMask(ref)["mask"]
-        annot = (ref_mask == 1).astype(np.uint8)
+        if sam_img is None:
+            sam_img = self.image(index)
+        annot = self.target(index)
         data = dict(sam_img=sam_img, height=sam_img.shape[0], width=sam_img.shape[1], file_name=img_info["file_name"],
                     cat_name=self.cat_names[index], img_id=[ref["image_id"]], ref_id=rid,
                     sent_ids=list(ref["sent_ids"]))

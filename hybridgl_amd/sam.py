@@ -599,7 +599,7 @@ class SamPredictor:
 
 class _GroupState:
     """a group of images on its way through SamAutomaticMaskGenerator.group_begin / group_cleanup / group_finish"""
-    __slots__ = ("sizes", "cap", "cand", "n1_dev", "n1", "ev1", "n1_list", "stage", "n2", "ev2")
+    __slots__ = ("sizes", "cap", "cand", "n1_dev", "n1", "ev1", "n1_list", "stage", "n2", "ev2", "ovf", "overflow")
 
 
 class SamAutomaticMaskGenerator:
@@ -802,6 +802,11 @@ class SamAutomaticMaskGenerator:
         st.n1_dev = torch.cat([c[5] for c in st.cand])
         st.n1 = torch.empty(len(images), dtype=torch.int32).pin_memory()
         st.n1.copy_(st.n1_dev, non_blocking=True)
+        # the fp16 range guard of the f16x3 mode rides on the same read-back: what the device had counted (any stream) when
+        # this stream got here -- the caller stops at this group instead of finding out at the end of the dataset
+        st.overflow = 0
+        st.ovf = torch.zeros(2, dtype=torch.int32).pin_memory()
+        ops.split_overflow_peek(st.ovf)
         st.ev1 = torch.cuda.Event()
         st.ev1.record(torch.cuda.current_stream(dev))
         return st
@@ -811,6 +816,8 @@ class SamAutomaticMaskGenerator:
         postprocess_small_regions' kernels on them (holes, islands, boxes, second NMS; automatic_mask_generator.py:324-372).
         The second NMS counts leave in one copy again."""
         st.ev1.synchronize()
+        if st.ovf is not None:
+            st.overflow = int(st.ovf[0]) + int(st.ovf[1])
         dev = self.model.device
         n1 = [int(v) for v in st.n1.tolist()]
         if st.cap is not None:

@@ -113,3 +113,129 @@ def box_blur_u8(img, k=15):
     pad = np.pad(a, ((0, 0), (r, r), (0, 0)), mode="reflect")
     a = sum(g[i] * pad[:, i:i + img.shape[1]] for i in range(k))
     return np.clip(np.floor(a + 0.5), 0, 255).astype(np.uint8)
+
+
+# ---- a REFER tree on disk (the evaluator's real feed: JPEG decode, GEM transform, BPE, polygon rasterisation, uploads) -------
+_NOUNS = ("man woman girl boy person child player dog cat horse zebra giraffe elephant bear sheep cow bird bus car truck train "
+          "bike motorcycle boat plane bench chair couch table bed laptop phone book clock vase cup bowl bottle pizza sandwich "
+          "cake banana apple orange donut umbrella kite surfboard skateboard racket bat glove hat shirt jacket").split()
+_ADJS = "red blue green white black yellow brown striped tall short young old big small dark bright wooden empty".split()
+_SPATIAL = (("on the left", "left", "none"), ("on the right", "right", "none"), ("in the middle", "middle", "none"),
+            ("at the top", "up", "none"), ("at the bottom", "down", "none"), ("to the left of the {o}", "none", "left"),
+            ("behind the {o}", "none", "behind"), ("next to the {o}", "none", "none"), ("bigger than the {o}", "none", "big"),
+            ("smaller than the {o}", "none", "small"), ("inside the {o}", "none", "within"), ("", "none", "none"))
+REFER_IMAGE_SIZES = ((480, 640), (640, 480), (427, 640), (640, 427), (375, 500), (500, 375), (480, 640), (640, 640))
+
+
+def synth_sentence(rng):
+    """one referring expression + the parse record the (external) spaCy step would produce for it:
+    (raw, {"noun_phrase", "other_nouns", "dirflag", "relaflag"})"""
+    noun, adj = _NOUNS[int(rng.integers(len(_NOUNS)))], _ADJS[int(rng.integers(len(_ADJS)))]
+    other = _NOUNS[int(rng.integers(len(_NOUNS)))]
+    tail, dirflag, relaflag = _SPATIAL[int(rng.integers(len(_SPATIAL)))]
+    np_ = f"the {adj} {noun}"
+    uses_other = "{o}" in tail
+    raw = (np_ + " " + tail.format(o=other)).strip()
+    return raw, {"noun_phrase": np_, "other_nouns": [other] if uses_other else [], "dirflag": dirflag, "relaflag": relaflag}
+
+
+def write_bpe_merges(path, n_merges=600):
+    """A byte-level BPE merges file in the format of OpenAI's bpe_simple_vocab_16e6.txt.gz (header line + one 'left right'
+    merge per line) learnt from the synthetic sentences' word list with a plain most-frequent-pair trainer, so that -- as
+    with the real vocabulary on real captions -- nearly every word is one token.  Our own data."""
+    import collections
+    import gzip
+    from .tokenizer import byte_table
+    enc, _ = byte_table()
+    words = collections.Counter()
+    corpus = list(_NOUNS) + list(_ADJS) + "the a photo of on left right in middle at top bottom to behind next bigger smaller than inside".split()
+    for w in corpus:
+        sym = [enc[b] for b in w.encode("utf-8")]
+        sym[-1] += "</w>"
+        words[tuple(sym)] += 1
+    merges = []
+    for _ in range(n_merges):
+        pairs = collections.Counter()
+        for w, c in words.items():
+            for a, b in zip(w, w[1:]):
+                pairs[(a, b)] += c
+        if not pairs:
+            break
+        (a, b), _c = max(sorted(pairs.items()), key=lambda kv: kv[1])
+        merges.append((a, b))
+        new = collections.Counter()
+        for w, c in words.items():
+            out, i = [], 0
+            while i < len(w):
+                if i + 1 < len(w) and w[i] == a and w[i + 1] == b:
+                    out.append(a + b)
+                    i += 2
+                else:
+                    out.append(w[i])
+                    i += 1
+            new[tuple(out)] += c
+        words = new
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(("#version: synthetic\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n").encode("utf-8"))
+    return len(merges)
+
+
+def write_refer_tree(root, n_images=200, dataset="refcoco", splitBy="unc", split="val", sentences_per_ref=3, seed=0,
+                     sizes=REFER_IMAGE_SIZES, fmt="jpg", far_refs=0.1):
+    """A dataset in the directory layout refer/refer.py:40-76 reads -- <root>/<dataset>/refs(<splitBy>).p, instances.json,
+    <root>/images/mscoco/images/train2014/*.jpg -- plus <root>/parse.json (the parse records, keyed by sent_id) and
+    <root>/bpe.txt.gz: COCO-sized JPEGs of mixed sizes, 2-3 refs per image (RefCOCO: 2.6), `sentences_per_ref` sentences
+    per ref, polygon ground truth.  The refs of an image are neighbours in the refs file except a fraction `far_refs`
+    of them, which come back ~20 images later (the per-image cache of the loop has to hold them).  Returns
+    {"refs", "images", "sentences"} counts."""
+    import json
+    import os
+    import pickle
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(root, dataset), exist_ok=True)
+    img_dir = os.path.join(root, "images/mscoco/images/train2014")
+    os.makedirs(img_dir, exist_ok=True)
+    images, anns, refs, parse, late = [], [], [], {}, []
+    sent_id = 0
+    for i in range(n_images):
+        h, w = sizes[i % len(sizes)]
+        name = f"COCO_train2014_{i:012d}.{fmt}"
+        # a cheap image with JPEG-realistic entropy: low-frequency field + per-pixel jitter (synth_image costs 0.3 s at 640 x 480)
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        img = np.empty((h, w, 3), np.float32)
+        for c in range(3):
+            fy, fx, ph = rng.uniform(0.5, 4.0), rng.uniform(0.5, 4.0), rng.uniform(0, 6.28)
+            img[..., c] = 128 + 60 * np.sin(6.28 * (fy * yy / h + fx * xx / w) + ph)
+        img += rng.uniform(0, 24, size=img.shape).astype(np.float32)
+        Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(os.path.join(img_dir, name), quality=90)
+        images.append({"id": 1000 + i, "file_name": name, "height": h, "width": w})
+        for j in range(2 + int(rng.integers(2))):
+            aid, rid = 10 * (1000 + i) + j, 100000 + 10 * i + j
+            cx, cy = rng.uniform(0.25, 0.75) * w, rng.uniform(0.25, 0.75) * h
+            ax, ay = rng.uniform(0.08, 0.24) * w, rng.uniform(0.08, 0.24) * h
+            th = np.linspace(0, 2 * np.pi, 24, endpoint=False)
+            rad = 1 + 0.15 * np.sin(3 * th + rng.uniform(0, 6.28))
+            poly = np.stack([cx + ax * rad * np.cos(th), cy + ay * rad * np.sin(th)], axis=1).round(2).ravel().tolist()
+            anns.append({"id": aid, "image_id": 1000 + i, "category_id": 1, "segmentation": [poly], "bbox": [0, 0, 1, 1]})
+            sents = []
+            for _ in range(sentences_per_ref):
+                raw, rec = synth_sentence(rng)
+                sents.append({"sent_id": sent_id, "raw": raw, "sent": raw, "tokens": raw.split()})
+                parse[str(sent_id)] = rec
+                sent_id += 1
+            ref = {"ref_id": rid, "ann_id": aid, "image_id": 1000 + i, "category_id": 1, "split": split,
+                   "sent_ids": [s["sent_id"] for s in sents], "sentences": sents}
+            if j > 0 and rng.uniform() < far_refs:
+                late.append((len(refs) + 50, ref))
+            else:
+                refs.append(ref)
+        while late and late[0][0] <= len(refs):
+            refs.append(late.pop(0)[1])
+    refs += [r for _, r in late]
+    json.dump({"images": images, "annotations": anns, "categories": [{"id": 1, "name": "thing"}]},
+              open(os.path.join(root, dataset, "instances.json"), "w"))
+    pickle.dump(refs, open(os.path.join(root, dataset, f"refs({splitBy}).p"), "wb"))
+    json.dump(parse, open(os.path.join(root, "parse.json"), "w"))
+    write_bpe_merges(os.path.join(root, "bpe.txt.gz"))
+    return {"refs": len(refs), "images": len(images), "sentences": sent_id}

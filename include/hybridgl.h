@@ -33,8 +33,9 @@ extern "C" {
 #define HGL_ELAUNCH (-4)   /* kernel launch failed */
 
 /* 2: + hgl_clip_hybrid_forward_segments, hgl_split_overflow_count, hgl_clip_encode_text_ex; hgl_gemm_f16x3_select
- * knows kinds -1, 0, 1 only */
-#define HGL_ABI_VERSION 4
+ * knows kinds -1, 0, 1 only
+ * 5: + hgl_u8_to_chw_lut, hgl_split_overflow_peek_async */
+#define HGL_ABI_VERSION 5
 
 /* activation codes for hgl_gemm_f32 */
 #define HGL_ACT_NONE 0
@@ -87,6 +88,11 @@ int hgl_gemm_f16x3_select(int kind);
  * such a value since the last reset (a blocking device read: synchronise the producing streams first).  Non-zero means
  * the results of that run contain inf / NaN: rerun with hgl_set_precision(HGL_PREC_F32). */
 int hgl_split_overflow_count(int reset, unsigned long long* count);
+/* The same counters copied in STREAM ORDER to host2[0..1] (pinned host memory; GEMM kernels, attention kernels) without
+ * waiting and without a reset: the values are what the device had counted when `stream` reached this call.  A caller
+ * that reads something back per batch anyway (the evaluator's proposal counts, Hybridgl_main.py:85-87) rides this on the
+ * same event and stops at the offending batch instead of voiding the run at its end. */
+int hgl_split_overflow_peek_async(unsigned int* host2, void* stream);
 /* Splits w_fp32 [N,K] * 2^scale_log2 into caller-owned fp16 arrays hi, lo ([N,K] each) and
  * records them under the fp32 pointer (scale_log2 keeps the lo half in the fp16 normal range;
  * choose max|w| * 2^scale_log2 <= 2^14). */
@@ -403,6 +409,14 @@ size_t hgl_resize_pil_bilinear_workspace_bytes(int H, int out_w, int C);
 int hgl_resize_pil_bilinear(const uint8_t* img, int H, int W, int C, int out_h, int out_w, const int32_t* kx,
                             const int32_t* bx, int ksize_x, const int32_t* ky, const int32_t* by, int ksize_y,
                             uint8_t* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The dataset transforms T.ToTensor() + T.Normalize(mean, std) on a uint8 HWC image (data/dataset_refer_bert.py:155-158;
+ * gem.get_gem_img_transform, Hybridgl_main.py:39) as a table look-up: out[c, y, x] = lut[c * 256 + img[y, x, c]], out
+ * [C, H, W] fp32.  lut [C, 256] is built on the host with the reference's fp32 arithmetic ((v / 255 - mean[c]) / std[c]),
+ * which makes the result bit-identical to the host transform.  With hgl_resize_pil_bilinear (any Pillow filter: the
+ * weights are the caller's tables, bicubic for the GEM transform) this moves the per-item float work of the reference's
+ * DataLoader workers onto the device; the host keeps the JPEG decode. */
+int hgl_u8_to_chw_lut(const uint8_t* img, int H, int W, int C, const float* lut, float* out, void* stream);
 
 /* Sam.preprocess + ImageEncoderViT.forward (modeling/sam.py:164-174, image_encoder.py:106-116).
  * resized_img: [in_h,in_w,3] uint8 -- the image after ResizeLongestSide.apply_image (PIL

@@ -195,3 +195,38 @@ def test_other_nouns_carry_the_reference_prefix():
     assert sentence_strings("the cat left of a dog on the sofa", rec) == [
         "the cat left of a dog on the sofa", "the cat", "a photo of a dog", "a photo of sofa"]
     assert sentence_strings("cat", {}) == ["cat", "cat"]
+
+
+def _force_worker(port, q):
+    os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    sys.path.insert(0, ROOT)
+    from hybridgl_amd import dist as DD
+    dist = DD.init_process_group("gloo")
+    rows = np.arange(30, dtype=np.int64).reshape(5, 6)
+    q.put((DD.gather_rows(rows, dist, force=True).tolist(), DD.gather_rows(rows, dist).tolist(),
+           DD.max_over_ranks(2.5, dist, force=True)))
+    dist.destroy_process_group()
+
+
+def test_a_world_of_one_goes_through_the_collectives_when_forced():
+    """gather_rows / max_over_ranks return early in a world of one; force=True sends the rows through the two all-gathers
+    and the all-reduce anyway (what the RCCL self-check of a 1-GPU box does, dist.rccl_selfcheck; here over gloo)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_force_worker, args=(D.free_port(), q))
+    p.start()
+    forced, plain, mx = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert forced == plain == np.arange(30).reshape(5, 6).tolist() and mx == 2.5
+
+
+def test_host_thread_pool_is_sized_for_the_rank_s_share():
+    import torch
+    old = torch.get_num_threads()
+    try:
+        assert D.size_host_threads([], 4) is None and torch.get_num_threads() == old
+        assert D.size_host_threads(list(range(32)), 4) == 6 and torch.get_num_threads() == 6
+        assert D.size_host_threads([0, 1], 4) == 1
+    finally:
+        torch.set_num_threads(old)

@@ -262,3 +262,19 @@ def test_bench_two_ranks(cuda):
     assert two["metrics"]["n_sentences"] == one["metrics"]["n_sentences"] == 48
     assert two["metrics"] == one["metrics"]
     assert two["value"] > 0 and two["scaling"] == "weak"
+
+
+def test_rccl_backend_at_world_size_one(cuda):
+    """The `nccl` (= RCCL) branch of hybridgl_amd/dist.py -- init_process_group with device_id, all_gather / all_reduce on
+    DEVICE tensors -- executed on the 1-GPU box in a world of one (a child process with a time limit: a communicator that
+    cannot come up must fail this test, not hang the suite)."""
+    import subprocess
+    import sys
+    code = ("import json, sys, torch; sys.path.insert(0, %r); from hybridgl_amd import dist as D; "
+            "torch.cuda.set_device(0); print('RCCL', json.dumps(D.rccl_selfcheck(torch.device('cuda', 0))))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL ")][-1]
+    import json
+    got = json.loads(line[5:])
+    assert got["backend"] == "nccl" and got["world_size_seen"] == 1 and got["rows_roundtrip_ok"] and got["max_ok"], got

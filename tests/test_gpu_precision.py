@@ -108,3 +108,32 @@ def test_activation_beyond_fp16_range_is_reported_not_propagated(cuda):
     m32 = CLIPViTFM("ViT-B/16", state_dict=sd, device=cuda, precision="f32")     # the cure the message names
     y32 = m32(T(loc, cuda), T(glo, cuda), T(masks, cuda), masking_block=9, fusion_mode="G2L")
     assert torch.isfinite(y32).all() and ops.split_overflow_count() == 0
+
+
+def test_overflow_stops_the_loop_at_the_offending_group_not_at_the_end(cuda):
+    """The fp16 range guard rides on the per-group count read-back of run() (SamAutomaticMaskGenerator.group_begin /
+    group_cleanup): a CLIP model whose MLP overflows makes the loop raise two groups after the first offending CLIP stage
+    -- with five groups on offer it never reaches the fourth -- instead of voiding the run in metrics()."""
+    from hybridgl_amd import sam as hsam
+    from hybridgl_amd.backbone import CLIPViTFM
+    from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
+    sd = {k: np.array(v, copy=True) for k, v in weights.clip_state_dict("ViT-B/16", 0).items()}
+    sd["visual.transformer.resblocks.3.mlp.c_fc.weight"][:8] *= np.float32(3.0e4)
+    sd["visual.transformer.resblocks.3.mlp.c_fc.bias"][:8] = np.float32(1.0e5)
+    ops.split_overflow_count()
+    m = CLIPViTFM("ViT-B/16", state_dict=sd, device=cuda, precision="f16x3")
+    tiny = hsam.sam_model_registry["tiny"](device=cuda)
+    gen = hsam.SamAutomaticMaskGenerator(tiny, points_per_side=3, pred_iou_thresh=-1e30, stability_score_thresh=0.0,
+                                         box_nms_thresh=2.0, min_mask_region_area=0)
+    refs = [synthetic_ref(i, cuda, N=4, H=96, W=128)[0] for i in range(10)]
+    pipe = HybridGLPipeline(m, mask_generator=gen, use_sam_masks=True)
+    with pytest.raises(ops.SplitOverflow, match="by group 3 of the loop"):
+        pipe.run(iter(refs), group=2, proposal_cap=4, serial=True)
+    assert pipe.groups_run == 3
+    torch.cuda.synchronize()
+    assert ops.split_overflow_count() > 0          # the counters were only peeked at; this resets them for the next test
+    # a clean model runs through and the peeks stay zero
+    ok = CLIPViTFM("ViT-B/16", seed=0, device=cuda, precision="f16x3")
+    pipe = HybridGLPipeline(ok, mask_generator=gen, use_sam_masks=True)
+    assert pipe.run(iter(refs), group=2, proposal_cap=4) == 10 and pipe.groups_run == 5
+    pipe.metrics()
