@@ -230,14 +230,14 @@ def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False, clip_na
                       f"3-sentence tail on 64 masks ({t4 - t3:.1f}s){gem_note}{sam_note}; numpy BLAS threads = host default"}
 
 
-def evaluator_from_disk(args, model, gen, gem_model, dev, group, n_images=208, keep_root=None):
+def evaluator_from_disk(args, model, gen, gem_model, dev, group, n_images=208, keep_root=None, host_cores=None):
     """`python -m hybridgl_amd.main --real` on a synthetic REFER tree written to local disk (hybridgl_amd.synth.write_refer_tree:
     COCO-sized JPEGs of 8 sizes, 2-3 refs per image, 3 sentences per ref, polygon ground truth, parse records, a BPE merges
     file): JPEG decode, BPE, ground-truth rasterisation and pinned uploads on 4 loader threads (hybridgl_amd.loader.Prefetcher),
     the two dataset transforms on the device, the product's run() loop with its per-image cache.  Same models as the
-    headline (filters open, first 64 proposals).  Three timings of the SAME refs: from disk; the same items resident in HBM
-    (what the headline's loop sees); from disk with this process confined to 1/8 of the host cores (what a rank of an
-    8-GPU job owns)."""
+    headline (filters open, first 64 proposals).  Timings of the SAME refs: from disk on the cores this process is pinned to
+    (at most 32: a rank's share of an 8-GPU job on a 256-core host); the same items resident in HBM (what the headline's
+    loop sees); from disk on 8 cores and roaming over all host cores (`host_cores`: the affinity before pinning)."""
     import shutil
     import tempfile
     from hybridgl_amd import dist as D, main as drv, synth
@@ -279,19 +279,24 @@ def evaluator_from_disk(args, model, gen, gem_model, dev, group, n_images=208, k
         m_res = pipe.metrics()
         del resident, pipe
         torch.cuda.empty_cache()
-        # 1/8 of the cores: this thread (and the loader threads it starts) confined like rank 0 of an 8-rank job
-        all_cores = sorted(os.sched_getaffinity(0))
-        share = D.rank_cpu_affinity(0, 8, all_cores)
-        eighth = None
-        if share:
-            old_threads = torch.get_num_threads()
-            os.sched_setaffinity(0, share)
-            D.size_host_threads(share, a.workers)
+        # other core budgets for the same feed: this thread (and the loader threads it starts) confined to 8 cores (a quarter
+        # of what a rank of an 8-GPU job owns on this host), and roaming over every core of the host (no pinning)
+        now_cores = sorted(os.sched_getaffinity(0))
+        variants = {}
+        old_threads = torch.get_num_threads()
+        for name, share in (("eight_cores", now_cores[:8]), ("all_host_cores_unpinned", list(host_cores or now_cores))):
+            if not share or share == now_cores:
+                continue
             try:
-                _, eighth = leg()
-                eighth["host_cores"] = len(share)
+                os.sched_setaffinity(0, share)
+                D.size_host_threads(share, a.workers)
+                _, v = leg()
+                v["host_cores"] = len(share)
+                variants[name] = v
+            except OSError as e:
+                variants[name] = {"error": repr(e)}
             finally:
-                os.sched_setaffinity(0, all_cores)
+                os.sched_setaffinity(0, now_cores)
                 torch.set_num_threads(old_threads)
         out = dict(disk)
         out.update({
@@ -300,12 +305,14 @@ def evaluator_from_disk(args, model, gen, gem_model, dev, group, n_images=208, k
                       f"--real --group {group} --workers {a.workers} --proposal_cap {args.masks} (evaluate()), filters open; the refs of an "
                       "image share its proposals / hybrid / GEM features (the product's image cache), so a ref costs less "
                       "than a headline step, whose refs are all different images",
-            "host_cores": len(all_cores),
+            "host_cores": len(now_cores),
+            "host_cores_note": "the cores this process is confined to (hybridgl_amd.dist.pin_rank_to_cores: at most 32 per rank, = the "
+                               "share of a rank of an 8-GPU job on a 256-core host)",
             "tree_write_s": t_write,
             "resident_same_items": {"value": n / t_res, "unit": "images/s", "seconds": t_res,
                                     "note": "the same RefBatches already in HBM, same run() call, same image cache"},
             "disk_over_resident": (disk["value"] / (n / t_res)) if n else None,
-            "one_eighth_of_host_cores": eighth,
+            "other_core_budgets": variants,
             "metrics_equal_resident": m_disk == m_res,
             "metrics": m_disk,
         })
@@ -375,10 +382,16 @@ def main():
         sys.exit(D.spawn_local_ranks(args.gpus, argv, timeout=args.timeout))
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner at communicator
+    # creation): from here on fd 1 is stderr for everything in this process, and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists)"
     ngpu = torch.cuda.device_count()
     local_dev = local_rank % ngpu      # identity on a node with one GPU per rank
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    host_cores_at_start = sorted(os.sched_getaffinity(0))
     cores = D.pin_rank_to_cores(local_rank, local_world)    # each rank's launch thread on its own share of the host cores
     D.size_host_threads(cores, 4)
     torch.cuda.set_device(local_dev)
@@ -575,7 +588,7 @@ def main():
     # ---- the evaluator's real feed: a REFER tree on disk through hybridgl_amd.main.evaluate (loader threads -> run())
     if also is not None and not args.no_disk:
         try:
-            also["evaluator_from_disk"] = evaluator_from_disk(args, model, gen, gem_model, dev, nbatch)
+            also["evaluator_from_disk"] = evaluator_from_disk(args, model, gen, gem_model, dev, nbatch, host_cores=host_cores_at_start)
         except Exception as e:      # the headline must not die with a secondary leg
             also["evaluator_from_disk"] = {"error": repr(e)}
 
@@ -678,7 +691,7 @@ def main():
             rec["rccl_selfcheck"] = rccl
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.fusion, with_sam=args.scope == "B", with_gem=use_gem, clip_name=args.clip)
-        print(json.dumps(rec))
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
     if overflow:

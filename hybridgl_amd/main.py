@@ -50,6 +50,7 @@ def default_argument_parser():
     p.add_argument("--pred_iou_thresh", type=float, default=0.7)
     p.add_argument("--stability_score_thresh", type=float, default=0.7)
     p.add_argument("--min_mask_region_area", type=int, default=800)
+    p.add_argument("--box_nms_thresh", type=float, default=0.7, help="SamAutomaticMaskGenerator's default (Hybridgl_main.py:67-73 does not set it)")
     p.add_argument("--group", type=int, default=16,
                    help="images taken at a time by the two-stream loop (HybridGLPipeline.run); 1 = ref by ref on one stream")
     p.add_argument("--workers", type=int, default=4, help="loader threads (Hybridgl_main.py:45 num_workers)")
@@ -239,7 +240,7 @@ def build_models(args, dev):
         sam = sam_model_registry[args.sam_model](device=dev)
         # Hybridgl_main.py:67-73
         gen = SamAutomaticMaskGenerator(sam, points_per_side=args.points_per_side, pred_iou_thresh=args.pred_iou_thresh,
-                                        stability_score_thresh=args.stability_score_thresh, crop_n_layers=0,
+                                        stability_score_thresh=args.stability_score_thresh, box_nms_thresh=args.box_nms_thresh, crop_n_layers=0,
                                         crop_n_points_downscale_factor=1, min_mask_region_area=args.min_mask_region_area)
     gem_model = None
     if args.heatmap == "device":
@@ -288,7 +289,7 @@ def evaluate(args, model, gen, gem_model, dev, rank=0, world=1, dist=None):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     m = pipe.metrics(dist)      # one all-gather of the metric rows; identical on every rank
-    stats = {"refs": n, "seconds": dt, "loader_wait_s": loader.wait_s, "loader_make_s": loader.make_s,
+    stats = {"refs": n, "seconds": dt, "seconds_job": D.max_over_ranks(dt, dist, dev), "loader_wait_s": loader.wait_s, "loader_make_s": loader.make_s,
              "images_decoded": rr.decoded if rr is not None else None, "image_cache_hits": pipe.cache_hits,
              "skipped": getattr(pipe, "skipped", 0), "groups": getattr(pipe, "groups_run", None),
              "workers": args.workers, "group": args.group}

@@ -271,10 +271,9 @@ def test_rccl_backend_at_world_size_one(cuda):
     import subprocess
     import sys
     code = ("import json, sys, torch; sys.path.insert(0, %r); from hybridgl_amd import dist as D; "
-            "torch.cuda.set_device(0); print('RCCL', json.dumps(D.rccl_selfcheck(torch.device('cuda', 0))))" % ROOT)
+            "torch.cuda.set_device(0); print('HGL_SELFCHECK', json.dumps(D.rccl_selfcheck(torch.device('cuda', 0))))" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL ")][-1]
-    import json
-    got = json.loads(line[5:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("HGL_SELFCHECK ")][-1]     # RCCL prints its own banner to stdout
+    got = json.loads(line[len("HGL_SELFCHECK "):])
     assert got["backend"] == "nccl" and got["world_size_seen"] == 1 and got["rows_roundtrip_ok"] and got["max_ok"], got
