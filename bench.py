@@ -446,7 +446,7 @@ def main():
 
     nbatch = args.sam_batch
 
-    def do_steps(k, p=None, cap=args.masks, pool=None):
+    def do_steps(k, p=None, cap=args.masks, pool=None, group=None):
         """k steps = k refs completed, start to finish (proposal stage + CLIP/scoring stage of each), through the PRODUCT's
         loop: HybridGLPipeline.run over a loader that yields k resident refs (hybridgl_amd.main runs the same call over a
         Prefetcher)."""
@@ -456,7 +456,7 @@ def main():
             for i in range(k):
                 p.step(pool[i % len(pool)])
             return
-        n = p.run((pool[i % len(pool)] for i in range(k)), group=nbatch, proposal_cap=cap if p.use_sam_masks else None,
+        n = p.run((pool[i % len(pool)] for i in range(k)), group=group or nbatch, proposal_cap=cap if p.use_sam_masks else None,
                   serial=args.no_overlap)
         assert n == k, f"{k - n} refs were skipped (no proposals)"
 
@@ -577,8 +577,10 @@ def main():
                                            crop_n_layers=1, crop_n_points_downscale_factor=2, min_mask_region_area=100)
         pc_refs = [synthetic_ref(100 + j, dev, N=args.masks, H=480, W=640, n_sent=8, sam_img_size=1024, gem=use_gem,
                                  device_blur=True)[0] for j in range(2)]
-        t = timed(make_pipe(g=gen_pc, fusion="G2L&L2G"), n_steps=2, cap=256, pool=pc_refs)
-        also["PhraseCut"] = entry(t, 2, "PhraseCut-shaped item: 480x640 image, heavy AMG (64x64 points, 1 crop layer, downscale 2, min "
+        # three groups of two images: the crop-layer proposal stage of group g+1 (three count read-backs per group) runs beside
+        # the CLIP stage of group g, fill and drain inside the timed region
+        t = timed(make_pipe(g=gen_pc, fusion="G2L&L2G"), n_steps=6, cap=256, pool=pc_refs, group=2)
+        also["PhraseCut"] = entry(t, 6, "PhraseCut-shaped item, run() in groups of 2 images: 480x640 image, heavy AMG (64x64 points, 1 crop layer, downscale 2, min "
                                         "area 100, thresholds open, 512 prompts per decoder launch: points_per_batch is a memory knob), <= 256 of SAM's masks into CLIP G2L&L2G, 8 phrases x (sentence + noun "
                                         "phrase + 1 other noun) + 8 GEM prompts")
         also["PhraseCut"]["unit"] = "images/s (8 phrases each)"
@@ -590,7 +592,8 @@ def main():
         try:
             also["evaluator_from_disk"] = evaluator_from_disk(args, model, gen, gem_model, dev, nbatch, host_cores=host_cores_at_start)
         except Exception as e:      # the headline must not die with a secondary leg
-            also["evaluator_from_disk"] = {"error": repr(e)}
+            import traceback
+            also["evaluator_from_disk"] = {"error": repr(e)[:400], "traceback": traceback.format_exc()[-1500:]}
 
     # ---- RCCL once on a 1-GPU box: the nccl branch of hybridgl_amd/dist.py in a world of one (device tensors through the
     # same two all-gathers + all-reduce the multi-GPU job uses); no process group is alive here at N = 1

@@ -133,6 +133,7 @@ PROTOTYPES = {
     "hgl_gem_heatmap_workspace_bytes": (_SZ, [_I, _I, _I]),
     "hgl_gem_heatmap": (_I, [_VP, _I, _I, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP]),
     "hgl_resize_bilinear_aa": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _VP]),
+    "hgl_resize_bilinear": (_I, [_VP, _I, _I, _I, _VP, _I, _I, _VP]),
     "hgl_mask_resize": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hgl_calculate_score": (_I, [_VP, _VP, _I, _I, _I, _F, _VP, _VP]),
     "hgl_coherence_workspace_bytes": (_SZ, [_I, _I, _I]),

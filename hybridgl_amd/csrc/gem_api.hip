@@ -205,6 +205,28 @@ __global__ __launch_bounds__(256) void minmax_apply_kernel(float* __restrict__ u
   }
 }
 
+// F.interpolate(bilinear, align_corners=False, antialias=False) of [C, h, w] -> [C, H, W]: what T.Resize does to a TENSOR
+// in torchvision 0.15 (Hybridgl_main_PhraseCut.py:69-70 resizes the normalised image to the annotation's size this way).
+// Source index as ATen's single fma, the four products and three sums rounded one by one in the order of ATen's CPU
+// kernel (rows first, then columns) -- no contraction into fmas.
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, int h, int w, float* __restrict__ out,
+                                                              int H, int W, float sy_scale, float sx_scale) {
+  const int c = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * W) return;
+  const int Y = i / W, X = i % W;
+  const float sy = fmaxf(fmaf(sy_scale, (float)Y + 0.5f, -0.5f), 0.f);
+  const float sx = fmaxf(fmaf(sx_scale, (float)X + 0.5f, -0.5f), 0.f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+  const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+  const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+  const float* m = in + (long long)c * h * w;
+  const float t = __fadd_rn(__fmul_rn(m[(long long)y0 * w + x0], lx0), __fmul_rn(m[(long long)y0 * w + x1], lx1));
+  const float b = __fadd_rn(__fmul_rn(m[(long long)y1 * w + x0], lx0), __fmul_rn(m[(long long)y1 * w + x1], lx1));
+  out[(long long)c * H * W + i] = __fadd_rn(__fmul_rn(t, ly0), __fmul_rn(b, ly1));
+}
+
 // ATen _upsample_bilinear2d_aa (align_corners=False): triangle filter of support max(scale, 1), weights
 // normalised per output index; out[c, Y, X] = sum_y wy * (sum_x wx * in[c, y, x])
 struct AaSpan {
@@ -431,6 +453,15 @@ int hgl_gem_heatmap(const float* feat, int grid, int E, const float* text, int T
     HGL_TRY(hgl_check_launch("gem_minmax"));
   }
   return HGL_OK;
+}
+
+int hgl_resize_bilinear(const float* in, int C, int h, int w, float* out, int H, int W, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(in && out, "resize_bilinear: null operand");
+  HGL_REQUIRE(C > 0 && C <= 65535 && h > 0 && w > 0 && H > 0 && W > 0, "resize_bilinear: bad shape");
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)(((long long)H * W + 255) / 256), (unsigned)C), dim3(256), 0,
+                     (hipStream_t)stream, in, h, w, out, H, W, (float)h / (float)H, (float)w / (float)W);
+  return hgl_check_launch("resize_bilinear");
 }
 
 int hgl_resize_bilinear_aa(const float* in, int C, int h, int w, float* out, int H, int W, void* stream) {

@@ -28,7 +28,12 @@ import torch
 def default_argument_parser():
     """the live flags of utils.py:397-471"""
     p = argparse.ArgumentParser(description="HybridGL evaluation (MI355X-native hot path)")
-    p.add_argument("--dataset", default="refcoco", choices=["refcoco", "refcoco+", "refcocog"])
+    p.add_argument("--dataset", default="refcoco", choices=["refcoco", "refcoco+", "refcocog", "phrasecut"],
+                   help="phrasecut = the Hybridgl_main_PhraseCut.py path: one item per IMAGE with all its phrases, heavy AMG")
+    p.add_argument("--phrasecut_root", default="./PhraseCutDataset/data/VGPhraseCut_v0",
+                   help="image_data_split.json, refer_<split>.json, images/ (data/dataset_phrasecut.py:40)")
+    p.add_argument("--unseen_mode", action="store_true", help="PhraseCut: skip phrases of COCO categories (dataset_phrasecut.py:63)")
+    p.add_argument("--seen_mode", action="store_true", help="PhraseCut: only phrases of COCO categories (:65)")
     p.add_argument("--split", default="val")
     p.add_argument("--fusion_mode", default="G2L", choices=["G2L", "L2G", "G2L&L2G"])
     p.add_argument("--refer_data_root", default="./refer/data")
@@ -45,14 +50,20 @@ def default_argument_parser():
     p.add_argument("--clip_model", default="ViT-B/16")
     p.add_argument("--sam_model", default="default")
     p.add_argument("--bpe_vocab", default="", help="bpe_simple_vocab_16e6.txt.gz (or HYBRIDGL_BPE_VOCAB)")
-    # proposal thresholds of Hybridgl_main.py:67-73
-    p.add_argument("--points_per_side", type=int, default=8)
-    p.add_argument("--pred_iou_thresh", type=float, default=0.7)
-    p.add_argument("--stability_score_thresh", type=float, default=0.7)
-    p.add_argument("--min_mask_region_area", type=int, default=800)
+    # proposal thresholds: Hybridgl_main.py:67-73 (8 / 0.7 / 0.7 / 800, no crops); --dataset phrasecut:
+    # Hybridgl_main_PhraseCut.py:56-62 (64 / 0.86 / 0.92 / 100, one crop layer with 32 x 32 points per crop)
+    p.add_argument("--points_per_side", type=int, default=None)
+    p.add_argument("--pred_iou_thresh", type=float, default=None)
+    p.add_argument("--stability_score_thresh", type=float, default=None)
+    p.add_argument("--min_mask_region_area", type=int, default=None)
+    p.add_argument("--crop_n_layers", type=int, default=None)
+    p.add_argument("--crop_n_points_downscale_factor", type=int, default=None)
+    p.add_argument("--points_per_batch", type=int, default=None,
+                   help="prompts per decoder launch (a memory knob: 64 in the reference; default 64, PhraseCut 512)")
     p.add_argument("--box_nms_thresh", type=float, default=0.7, help="SamAutomaticMaskGenerator's default (Hybridgl_main.py:67-73 does not set it)")
-    p.add_argument("--group", type=int, default=16,
-                   help="images taken at a time by the two-stream loop (HybridGLPipeline.run); 1 = ref by ref on one stream")
+    p.add_argument("--group", type=int, default=None,
+                   help="images taken at a time by the two-stream loop (HybridGLPipeline.run); 1 = ref by ref on one stream; "
+                        "default 16 (PhraseCut: 4 -- a heavy-AMG image holds ~5 GB of candidate masks until its counts are read)")
     p.add_argument("--workers", type=int, default=4, help="loader threads (Hybridgl_main.py:45 num_workers)")
     p.add_argument("--proposal_cap", type=int, default=0,
                    help="keep at most this many proposals of the first NMS order per image (0 = all; the benchmark's fixed 64)")
@@ -226,6 +237,85 @@ def real_refs(args, dev, splitBy, context_length, rank=0, world=1):
         yield rr.load(i)
 
 
+AMG_DEFAULTS = {   # Hybridgl_main.py:67-73 / Hybridgl_main_PhraseCut.py:56-62
+    "refer": dict(points_per_side=8, pred_iou_thresh=0.7, stability_score_thresh=0.7, min_mask_region_area=800, crop_n_layers=0,
+                  crop_n_points_downscale_factor=1, points_per_batch=64, group=16),
+    "phrasecut": dict(points_per_side=64, pred_iou_thresh=0.86, stability_score_thresh=0.92, min_mask_region_area=100,
+                      crop_n_layers=1, crop_n_points_downscale_factor=2, points_per_batch=512, group=4),
+}
+
+
+def resolve_defaults(args):
+    """fill the flags left at None with the configuration of the reference script that --dataset selects"""
+    for k, v in AMG_DEFAULTS["phrasecut" if args.dataset == "phrasecut" else "refer"].items():
+        if getattr(args, k, None) is None:
+            setattr(args, k, v)
+    return args
+
+
+class RealPhraseCut:
+    """The dataset side of Hybridgl_main_PhraseCut.py:40-43,67-119: one item per IMAGE (hybridgl_amd/phrasecut_io.py), all its
+    phrases scored against one proposal set and one hybrid forward, a ground truth per phrase.  `load(i)` -> RefBatch whose
+    sentences carry their own targets (None for an image whose phrases are all filtered out: the loop skips it)."""
+
+    def __init__(self, args, dev, context_length):
+        import json
+        import threading
+        from .phrasecut_io import PhraseCutDataset
+        from .tokenizer import SimpleTokenizer
+        self.args, self.dev, self.context_length = args, dev, context_length
+        self.ds = PhraseCutDataset(args.phrasecut_root, args.split, unseen_mode=args.unseen_mode, seen_mode=args.seen_mode)
+        self.tk = SimpleTokenizer(args.bpe_vocab or None)
+        self._tk_lock = threading.Lock()
+        self.parse = json.load(open(args.parse_json)) if args.parse_json else {}
+        self.n = len(self.ds) if args.max_refs <= 0 else min(len(self.ds), args.max_refs)
+        self.decoded = 0
+
+    def jobs(self, rank=0, world=1):
+        from .dist import shard_indices
+        return shard_indices(self.n, rank, world)
+
+    def load(self, i):
+        from . import transforms as T
+        from .gem import GEMWrapper
+        from .loader import pin_upload
+        from .pipeline import RefBatch, Sentence
+        from .tokenizer import tokenize
+        item = self.ds[i]
+        if item is None:
+            return None
+        dev = self.dev
+        H, W = item["height"], item["width"]
+        sam_img = pin_upload(item["sam_img"], dev)
+        file_img = sam_img if item["file_img"] is None else pin_upload(item["file_img"], dev)
+        image_norm = T.phrasecut_image_norm(file_img, H, W)             # dataset_phrasecut.py:49-51 + Hybridgl_main_PhraseCut.py:69-70
+        want_gem = self.args.heatmap == "device"
+        tensor_img = T.gem_img_transform(file_img) if want_gem else None    # :44-45 preprocessor(image): the file's own pixels
+        self.decoded += 1
+        strings, sents = [], []
+        for j, phrase in enumerate(item["phrases"]):
+            rec = self.parse.get(phrase, self.parse.get(phrase.lower(), {}))
+            sentence = rec.get("sentence_for_spacy", phrase.lower())          # Hybridgl_main_PhraseCut.py:118-129
+            row = len(strings)
+            others = list(rec.get("other_nouns", []))
+            strings += sentence_strings(sentence, rec)
+            gem_row, attn = None, None
+            if want_gem:
+                gem_row = len(strings)
+                strings += GEMWrapper.prompts([rec.get("noun_phrase", sentence)])      # :200
+            else:
+                attn = torch.ones((H, W), dtype=torch.float32, device=dev)
+            gt = pin_upload(self.ds.gt_mask(item, j).astype("uint8"), dev)
+            sents.append(Sentence(row, row + 1, list(range(row + 2, row + 2 + len(others))), rec.get("dirflag", "none"),
+                                  rec.get("relaflag", "none"), len(others), attn, gt, gem_row=gem_row))
+        with self._tk_lock:
+            tokens = tokenize(strings, context_length=self.context_length, tokenizer=self.tk)
+        placeholder = torch.zeros((1, H, W), dtype=torch.bool, device=dev)
+        return RefBatch(sam_img, None, image_norm, placeholder, torch.zeros((1, 4), dtype=torch.int64, device=dev),
+                        pin_upload(tokens, dev), sents[0].target, sents, None, int(item["image_id"]), tensor_img=tensor_img,
+                        token_len=int(tokens.argmax(axis=1).max()) + 1, index=i)
+
+
 def split_by(dataset):
     return "umd" if dataset == "refcocog" else "unc"          # Hybridgl_main.py:26-29
 
@@ -233,15 +323,18 @@ def split_by(dataset):
 def build_models(args, dev):
     """(CLIPViTFM, SamAutomaticMaskGenerator | None, GEM model | None) as Hybridgl_main.py:36-38,47-48,66-74 builds them"""
     from .backbone import CLIPViTFM
+    resolve_defaults(args)
     model = CLIPViTFM(model_name=args.clip_model, device=dev).eval()
     gen = None
     if args.sam or args.real:
         from .sam import SamAutomaticMaskGenerator, sam_model_registry
         sam = sam_model_registry[args.sam_model](device=dev)
         # Hybridgl_main.py:67-73
-        gen = SamAutomaticMaskGenerator(sam, points_per_side=args.points_per_side, pred_iou_thresh=args.pred_iou_thresh,
-                                        stability_score_thresh=args.stability_score_thresh, box_nms_thresh=args.box_nms_thresh, crop_n_layers=0,
-                                        crop_n_points_downscale_factor=1, min_mask_region_area=args.min_mask_region_area)
+        gen = SamAutomaticMaskGenerator(sam, points_per_side=args.points_per_side, points_per_batch=args.points_per_batch,
+                                        pred_iou_thresh=args.pred_iou_thresh, stability_score_thresh=args.stability_score_thresh,
+                                        box_nms_thresh=args.box_nms_thresh, crop_n_layers=args.crop_n_layers,
+                                        crop_n_points_downscale_factor=args.crop_n_points_downscale_factor,
+                                        min_mask_region_area=args.min_mask_region_area)
     gem_model = None
     if args.heatmap == "device":
         from .gem import create_gem_model
@@ -258,11 +351,16 @@ def evaluate(args, model, gen, gem_model, dev, rank=0, world=1, dist=None):
     from .loader import Prefetcher
     from .pipeline import EmptyProposals, HybridGLPipeline, synthetic_ref
     from . import dist as D
+    resolve_defaults(args)
     k_clamp = args.k_clamp if args.k_clamp != "auto" else ("persistent" if world == 1 else "per_ref")
     pipe = HybridGLPipeline(model, fusion_mode=args.fusion_mode, masking_block=getattr(args, "masking_block", 9), mask_generator=gen,
                             use_sam_masks=args.real, gem_model=gem_model, k_clamp=k_clamp)
     rr = None
-    if args.real:
+    if args.real and args.dataset == "phrasecut":
+        from .weights import CLIP_CONFIGS
+        rr = RealPhraseCut(args, dev, CLIP_CONFIGS[args.clip_model]["context_length"])
+        jobs, make = rr.jobs(rank, world), rr.load
+    elif args.real:
         from .weights import CLIP_CONFIGS
         rr = RealRefs(args, dev, split_by(args.dataset), CLIP_CONFIGS[args.clip_model]["context_length"],
                       device_transforms=not getattr(args, "host_transforms", False))
@@ -279,6 +377,8 @@ def evaluate(args, model, gen, gem_model, dev, rank=0, world=1, dist=None):
     if args.group <= 1:      # ref by ref on one stream (Hybridgl_main.py:79-230 as written)
         n = 0
         for ref in loader:
+            if ref is None:
+                continue
             try:
                 pipe.step(ref)
                 n += 1
@@ -325,13 +425,15 @@ def main(args):
         stats["world"] = world
         stats["host_cores_per_rank"] = len(cores) if cores else len(os.sched_getaffinity(0))
         json.dump({"stats": stats, "metrics": m}, open(args.stats_json, "w"))
+    pc = args.dataset == "phrasecut"
     text = (f"\n\n fusion_mode={args.fusion_mode} "
-            f"\nDataset: {args.dataset} / {args.split} / {splitBy}"
+            + (f"\nDataset: PhraseCut / {args.split}" if pc else f"\nDataset: {args.dataset} / {args.split} / {splitBy}") +
             f"\nOverall IoU / mean IoU"
             f"\npure hybridgl: {m['oIoU']:.2f} / {m['mIoU']:.2f}"
             f"\nhybridgl w/ spatial guidance: {m['oIoU_final']:.2f} / {m['mIoU_final']:.2f}")
     os.makedirs(args.result_dir, exist_ok=True)                         # Hybridgl_main.py:233-248
-    with open(os.path.join(args.result_dir, f"result_log_{args.dataset}_{args.split}.txt"), "a") as f:
+    # Hybridgl_main.py:233-248 / Hybridgl_main_PhraseCut.py:224-238
+    with open(os.path.join(args.result_dir, "result_log_PhraseCut.txt" if pc else f"result_log_{args.dataset}_{args.split}.txt"), "a") as f:
         f.write(text)
     print(text)
     return m

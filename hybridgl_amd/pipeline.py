@@ -97,6 +97,20 @@ def black_for(relaflag):
     return 1.95 if relaflag == "big" else (1.5 if relaflag == "small" else 1.8)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device):
+    """The three side streams of the loop (proposal stage, CLIP stage, text / GEM stage), ONE set per device for every
+    pipeline object of the process: ops.workspace keeps one grow-only arena per (tag, stream), so pipelines that each
+    brought their own streams would each leave ~30 GB of arenas behind (bench.py builds a dozen pipelines)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = tuple(torch.cuda.Stream(dev) for _ in range(3))
+    return _SIDE_STREAMS[key]
+
+
 class HybridGLPipeline:
     def __init__(self, model, fusion_mode="G2L", masking_block=9, r=0.5, alpha=0.6, k1=3, k2=6, res=224,
                  mask_generator=None, use_sam_masks=False, fixed_proposals=None, cleanup_given_masks=False,
@@ -169,7 +183,7 @@ class HybridGLPipeline:
         # own stream underneath the SAM / CLIP image kernels and is joined before the scoring tail.
         cur = torch.cuda.current_stream()
         if not hasattr(self, "_s_text"):
-            self._s_text = torch.cuda.Stream()
+            self._streams()
         ev_in, ev_text = torch.cuda.Event(), torch.cuda.Event()
         ev_in.record(cur)
         self._s_text.wait_event(ev_in)
@@ -268,7 +282,7 @@ class HybridGLPipeline:
     # ---- the evaluation loop at the grouped rate ----------------------------------------------------------------------
     def _streams(self):
         if not hasattr(self, "_s_sam"):
-            self._s_sam, self._s_clip = torch.cuda.Stream(), torch.cuda.Stream()
+            self._s_sam, self._s_clip, self._s_text = _side_streams(self.model.device)
             self._ev = torch.cuda.Event()
         return self._s_sam, self._s_clip
 
@@ -279,6 +293,8 @@ class HybridGLPipeline:
         the image only).  Items without an image_id are units of their own."""
         units, cur = [], None
         for ref in loader:
+            if ref is None:      # an item the dataset filtered out entirely (PhraseCut seen / unseen modes)
+                continue
             if cur is not None and ref.image_id is not None and ref.image_id == cur[0].image_id:
                 cur.append(ref)
                 continue
@@ -358,9 +374,13 @@ class HybridGLPipeline:
                 with torch.cuda.stream(s_sam):
                     imgs = [units[i][0].sam_img for i in fresh]
                     if self.use_sam_masks:
-                        if getattr(gen, "crop_n_layers", 0) > 0:   # PhraseCut configuration: crop layers, image by image
-                            state = ("crops", [tuple(t[:proposal_cap] if proposal_cap is not None else t
-                                                     for t in gen.generate_device_crops(im)[:2]) for im in imgs])
+                        if getattr(gen, "crop_n_layers", 0) > 0:
+                            # PhraseCut configuration (crop layers): the same begin / finish split -- every crop of every image
+                            # of the group is enqueued here without a wait, the three count read-backs come after the CLIP
+                            # stage of the previous group has been enqueued
+                            if self.stagger == "decoder" and not serial:
+                                ev_enc = torch.cuda.Event()
+                            state = ("crops", gen.crops_begin(imgs, ev_enc))
                         else:
                             # stagger = "decoder": the CLIP stage of the previous group starts when THIS group's encoder pass
                             # is through, so its large GEMMs run beside the latency-bound rest of the proposal stage (decoder,
@@ -389,7 +409,13 @@ class HybridGLPipeline:
                                 "results from the previous group on contain inf / NaN; rerun with HYBRIDGL_PRECISION=f32 (or precision='f32')")
                         got = [p[:2] for p in gen.group_finish(stc)]
                     else:
-                        got = state[1]
+                        stc = gen.crops_mid(state[1])
+                        if stc.overflow:
+                            raise ops.SplitOverflow(
+                                f"activations exceeded the fp16 range (|x| > 65504) in f16x3 mode by group {self.groups_run} of the "
+                                f"loop ({stc.overflow} GPU threads saw one): rerun with HYBRIDGL_PRECISION=f32 (or precision='f32')")
+                        got = [tuple(t[:proposal_cap] if proposal_cap is not None else t for t in p[:2])
+                               for p in gen.crops_finish(gen.crops_post(stc))]
                     ready = torch.cuda.Event()
                     ready.record(s_sam)
                 props = [None] * len(units)          # None = take it from the image cache
@@ -441,7 +467,7 @@ class HybridGLPipeline:
         if not live:
             return 0
         if not hasattr(self, "_s_text"):
-            self._s_text = torch.cuda.Stream()
+            self._streams()
         s_text = cur if getattr(self, "_serial", False) else self._s_text
         ev_in, ev_text = torch.cuda.Event(), torch.cuda.Event()
         ev_in.record(cur)

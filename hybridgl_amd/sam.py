@@ -673,10 +673,12 @@ class SamAutomaticMaskGenerator:
         tp[:, 0] *= nw / W                                                       # apply_coords, utils/transforms.py:33-45
         tp[:, 1] *= nh / H
         key = (H, W, layer_idx)
-        if getattr(self, "_p01_key", None) != key:      # the prompt grid depends on the image size only: upload it once
-            self._p01_key = key
-            self._p01 = torch.from_numpy(((tp + 0.5) / float(m.img_size)).astype(np.float32)).to(m.device)
-        p01 = self._p01
+        cache = self.__dict__.setdefault("_p01_cache", {})
+        p01 = cache.get(key)
+        if p01 is None:      # the prompt grid depends on the crop size only: upload it once (a crop layer alternates between sizes)
+            if len(cache) >= 64:
+                cache.clear()
+            p01 = cache[key] = torch.from_numpy(((tp + 0.5) / float(m.img_size)).astype(np.float32)).to(m.device)
         lows, ious = [], []
         for s in range(0, len(pts), self.points_per_batch):
             low, iou = m.decode_points(emb, p01[s:s + self.points_per_batch].contiguous())
@@ -753,6 +755,165 @@ class SamAutomaticMaskGenerator:
         b = bx.long()
         xywh = torch.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1)
         return mk, xywh, iou, stab, pts, cbs
+
+    # ---- crop layers for a GROUP of images: three host syncs for the whole group instead of 1 per crop + 2 per image ----
+    def crops_begin(self, images, encoded_event=None):
+        """Stage A of generate_device_crops for several images on the current stream, nothing waited for: the crops of all
+        images through the encoder in batches of up to 16, then decoder + fused post-processing + crop-edge filter + first
+        NMS crop by crop; the survivor counts of ALL crops leave in one pinned copy behind an event (with the fp16 range
+        counters).  The caller enqueues other work (the CLIP stage of the previous group) before crops_mid()."""
+        m = self.model
+        st = _GroupState()
+        st.sizes, st.cand = [], []
+        res, owner = [], []
+        imgs = []
+        for image in images:
+            dev_img = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image)).to(m.device)
+            H, W = dev_img.shape[:2]
+            crop_boxes, layer_idxs = generate_crop_boxes((H, W), self.crop_n_layers, self.crop_overlap_ratio)
+            st.sizes.append((int(H), int(W), crop_boxes, layer_idxs))
+            imgs.append(dev_img)
+            for x0, y0, x1, y1 in crop_boxes:
+                res.append(resize_longest_side(dev_img[y0:y1, x0:x1, :].contiguous(), m.img_size))
+                owner.append(len(imgs) - 1)
+        embs = []
+        for c0 in range(0, len(res), 16):
+            chunk = res[c0:c0 + 16]
+            e = m.encode_batch(chunk) if len(chunk) > 1 else [m.encode(chunk[0])]
+            embs.extend(e[i] for i in range(len(chunk)))
+        if encoded_event is not None:
+            encoded_event.record(torch.cuda.current_stream(m.device))
+        k, counts = 0, []
+        for (H, W, crop_boxes, layer_idxs) in st.sizes:
+            per = []
+            for crop_box, layer_idx in zip(crop_boxes, layer_idxs):
+                x0, y0, x1, y1 = crop_box
+                ch, cw = y1 - y0, x1 - x0
+                c = self._propose_from_embedding(embs[k], ch, cw, *get_preprocess_shape(ch, cw, m.img_size), layer_idx, crop_box, (H, W))
+                k += 1
+                per.append(c[:5])
+                counts.append(c[5])
+            st.cand.append(per)
+        st.n1_dev = torch.cat(counts)
+        st.n1 = torch.empty(len(counts), dtype=torch.int32).pin_memory()
+        st.n1.copy_(st.n1_dev, non_blocking=True)
+        st.overflow = 0
+        st.ovf = torch.zeros(2, dtype=torch.int32).pin_memory()
+        ops.split_overflow_peek(st.ovf)
+        st.ev1 = torch.cuda.Event()
+        st.ev1.record(torch.cuda.current_stream(m.device))
+        return st
+
+    def crops_mid(self, st):
+        """Stage B (host sync 1 of 3): every crop's survivors pasted into full-size masks (uncrop_masks / uncrop_boxes_xyxy,
+        amg.py:225-252), the crops of an image concatenated in the reference's order, the cross-crop NMS that prefers
+        masks of smaller crops (automatic_mask_generator.py:209-220); its counts leave in one copy."""
+        st.ev1.synchronize()
+        st.overflow = int(st.ovf[0]) + int(st.ovf[1])
+        m = self.model
+        dev = m.device
+        n1 = [int(v) for v in st.n1.tolist()]
+        k = 0
+        st.stage, n_dev = [], []
+        for (H, W, crop_boxes, layer_idxs), per in zip(st.sizes, st.cand):
+            all_m, all_b, all_iou, all_stab, areas = [], [], [], [], []
+            for crop_box, (masks, boxes, iou, stab, order) in zip(crop_boxes, per):
+                n = n1[k]
+                k += 1
+                if n == 0:
+                    continue
+                x0, y0, x1, y1 = crop_box
+                idx = order[:n].long()
+                if (x0, y0, x1, y1) == (0, 0, W, H):
+                    full = masks.index_select(0, idx)
+                else:
+                    full = torch.zeros((n, H, W), dtype=torch.uint8, device=dev)
+                    full[:, y0:y1, x0:x1] = masks.index_select(0, idx)
+                all_m.append(full)
+                all_b.append(boxes.index_select(0, idx) + torch.tensor([x0, y0, x0, y0], dtype=torch.int32, device=dev))
+                all_iou.append(iou.index_select(0, idx))
+                all_stab.append(stab.index_select(0, idx))
+                areas.append(np.full(n, (x1 - x0) * (y1 - y0), dtype=np.int64))
+            if not all_m:
+                st.stage.append(None)
+                n_dev.append(torch.zeros(1, dtype=torch.int32, device=dev))
+                continue
+            mk, bx = torch.cat(all_m), torch.cat(all_b).contiguous()
+            iou, stab = torch.cat(all_iou), torch.cat(all_stab)
+            order, n = None, torch.full((1,), len(bx), dtype=torch.int32, device=dev)
+            if len(crop_boxes) > 1:
+                area = np.concatenate(areas)
+                scores = torch.from_numpy((1.0 / torch.from_numpy(area)).to(torch.float32).numpy()).to(dev)
+                order, n = nms(bx, scores, torch.ones(len(bx), dtype=torch.uint8, device=dev), self.crop_nms_thresh)
+            st.stage.append((mk, bx, iou, stab, order))
+            n_dev.append(n.reshape(1))
+        st.cand = None
+        st.n2 = torch.empty(len(n_dev), dtype=torch.int32).pin_memory()
+        st.n2.copy_(torch.cat(n_dev), non_blocking=True)
+        st.ev2 = torch.cuda.Event()
+        st.ev2.record(torch.cuda.current_stream(dev))
+        return st
+
+    def crops_post(self, st):
+        """Stage C (host sync 2 of 3): the survivors of the cross-crop NMS through postprocess_small_regions' kernels (holes,
+        islands, boxes, the NMS that prefers untouched masks; automatic_mask_generator.py:324-372); counts in one copy."""
+        st.ev2.synchronize()
+        dev = self.model.device
+        n2 = [int(v) for v in st.n2.tolist()]
+        stage, n_dev = [], []
+        for stg, n in zip(st.stage, n2):
+            if stg is None or n == 0:
+                stage.append(None)
+                n_dev.append(torch.zeros(1, dtype=torch.int32, device=dev))
+                continue
+            mk, bx, iou, stab, order = stg
+            if order is not None:
+                k = order[:n].long()
+                mk, bx, iou, stab = mk.index_select(0, k), bx.index_select(0, k).contiguous(), iou[k], stab[k]
+            if self.min_mask_region_area > 0:
+                m1, c1 = remove_small_regions(mk.contiguous(), self.min_mask_region_area, "holes")
+                m2, c2 = remove_small_regions(m1, self.min_mask_region_area, "islands")
+                unchanged = ((c1 | c2) == 0).to(torch.float32)
+                nb = mask_boxes(m2)
+                order2, nn = nms(nb, unchanged, torch.ones(len(nb), dtype=torch.uint8, device=dev),
+                                 max(self.box_nms_thresh, self.crop_nms_thresh))
+                stage.append((m2, nb, iou, stab, order2))
+                n_dev.append(nn.reshape(1))
+            else:
+                stage.append((mk, bx, iou, stab, None))
+                n_dev.append(torch.full((1,), n, dtype=torch.int32, device=dev))
+        st.stage = stage
+        st.n1 = torch.empty(len(n_dev), dtype=torch.int32).pin_memory()
+        st.n1.copy_(torch.cat(n_dev), non_blocking=True)
+        st.ev1 = torch.cuda.Event()
+        st.ev1.record(torch.cuda.current_stream(dev))
+        return st
+
+    def crops_finish(self, st):
+        """Stage D (host sync 3 of 3): the final gathers.  Per image (masks [n,H,W] u8, boxes_xywh [n,4] i64, iou [n],
+        stability [n]) -- the first four outputs of generate_device_crops, same order; n may be 0."""
+        st.ev1.synchronize()
+        dev = self.model.device
+        n3 = [int(v) for v in st.n1.tolist()]
+        out = []
+        for stg, n, (H, W, _cb, _li) in zip(st.stage, n3, st.sizes):
+            if stg is None or n == 0:
+                e = torch.empty
+                out.append((e((0, H, W), dtype=torch.uint8, device=dev), e((0, 4), dtype=torch.int64, device=dev),
+                            e((0,), device=dev), e((0,), device=dev)))
+                continue
+            mk, bx, iou, stab, order2 = stg
+            if order2 is not None:
+                k = order2[:n].long()
+                mk, bx, iou, stab = mk.index_select(0, k), bx.index_select(0, k), iou[k], stab[k]
+            b = bx.long()
+            out.append((mk, torch.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1), iou, stab))
+        st.stage = None
+        return out
+
+    def generate_crops_group(self, images):
+        """generate_device_crops (masks, boxes, iou, stability) for several images with three host syncs in all"""
+        return self.crops_finish(self.crops_post(self.crops_mid(self.crops_begin(images))))
 
     def generate_device(self, image, resized=None, fixed_n=None):
         """Whole `generate` on the device.  Returns (masks [n,H,W] uint8, boxes_xywh [n,4] int64,

@@ -239,3 +239,58 @@ def write_refer_tree(root, n_images=200, dataset="refcoco", splitBy="unc", split
     json.dump(parse, open(os.path.join(root, "parse.json"), "w"))
     write_bpe_merges(os.path.join(root, "bpe.txt.gz"))
     return {"refs": len(refs), "images": len(images), "sentences": sent_id}
+
+
+def write_phrasecut_tree(root, n_images=8, split="test", phrases_per_image=8, seed=0, sizes=((480, 640), (640, 480), (375, 500)),
+                         resized_files=0.25):
+    """A dataset in the published VGPhraseCut layout (hybridgl_amd/phrasecut_io.py): <root>/image_data_split.json,
+    <root>/refer_<split>.json, <root>/images/<image_id>.jpg, plus <root>/parse.json (parse records keyed by phrase) and
+    <root>/bpe.txt.gz.  Every task has 1-3 instances of 1-2 polygons; a fraction `resized_files` of the image FILES is
+    stored at 3/4 of the annotated size, so that the cv2.resize step of data/dataset_phrasecut.py:55 has work to do.
+    Returns {"images", "phrases"}."""
+    import json
+    import os
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    infos, tasks, parse = [], [], {}
+    n_phr = 0
+    for i in range(n_images):
+        h, w = sizes[i % len(sizes)]
+        iid = 2300000 + 7 * i
+        fh, fw = (h * 3 // 4, w * 3 // 4) if rng.uniform() < resized_files else (h, w)
+        yy, xx = np.mgrid[0:fh, 0:fw].astype(np.float32)
+        img = np.empty((fh, fw, 3), np.float32)
+        for c in range(3):
+            fy, fx, ph = rng.uniform(0.5, 4.0), rng.uniform(0.5, 4.0), rng.uniform(0, 6.28)
+            img[..., c] = 128 + 60 * np.sin(6.28 * (fy * yy / fh + fx * xx / fw) + ph)
+        img += rng.uniform(0, 24, size=img.shape).astype(np.float32)
+        Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(os.path.join(root, "images", f"{iid}.jpg"), quality=90)
+        infos.append({"image_id": iid, "width": w, "height": h, "split": split, "coco_id": None})
+        for j in range(phrases_per_image):
+            raw, rec = synth_sentence(rng)
+            phrase = raw.replace("the ", "", 1).capitalize() if j % 3 == 0 else raw      # the evaluator lower-cases phrases
+            polys, boxes = [], []
+            for _ in range(1 + int(rng.integers(3))):
+                inst = []
+                for _ in range(1 + int(rng.integers(2))):
+                    cx, cy = rng.uniform(0.2, 0.8) * w, rng.uniform(0.2, 0.8) * h
+                    ax, ay = rng.uniform(0.05, 0.18) * w, rng.uniform(0.05, 0.18) * h
+                    th = np.linspace(0, 2 * np.pi, 16, endpoint=False)
+                    inst.append(np.stack([cx + ax * np.cos(th), cy + ay * np.sin(th)], axis=1).round(2).tolist())
+                pts = np.concatenate([np.asarray(p) for p in inst])
+                x0, y0 = pts.min(axis=0)
+                x1, y1 = pts.max(axis=0)
+                boxes.append([float(x0), float(y0), float(x1 - x0), float(y1 - y0)])
+                polys.append(inst)
+            noun = rec["noun_phrase"].split()[-1]
+            tasks.append({"task_id": f"{iid}__{j}", "image_id": iid, "phrase": phrase,
+                          "phrase_structure": {"name": noun, "attributes": [], "relation_descriptions": [], "type": "name"},
+                          "instance_boxes": boxes, "Polygons": polys})
+            parse[phrase] = rec
+            n_phr += 1
+    json.dump(infos, open(os.path.join(root, "image_data_split.json"), "w"))
+    json.dump(tasks, open(os.path.join(root, f"refer_{split}.json"), "w"))
+    json.dump(parse, open(os.path.join(root, "parse.json"), "w"))
+    write_bpe_merges(os.path.join(root, "bpe.txt.gz"))
+    return {"images": n_images, "phrases": n_phr}

@@ -162,3 +162,34 @@ def gem_img_transform(img_u8, img_size=448):
     """gem.get_gem_img_transform() on the device: Resize((s, s), bicubic) on uint8 -> ToTensor -> Normalize(OpenAI)."""
     from .gem import OPENAI_MEAN, OPENAI_STD
     return to_tensor_normalize(pil_resize_u8(img_u8, img_size, img_size, "bicubic"), OPENAI_MEAN, OPENAI_STD)
+
+
+def resize_bilinear(x, size):
+    """T.Resize(size) on a float TENSOR [C, h, w] as torchvision 0.15 does it: F.interpolate(bilinear, align_corners=False,
+    antialias=False); current stream."""
+    lib = _lib.load()
+    Cc, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+    if (H, W) == (h, w):
+        return x
+    out = torch.empty((Cc, H, W), dtype=torch.float32, device=x.device)
+    check(lib.hgl_resize_bilinear(ops._dev(x, torch.float32, "x"), Cc, h, w, out.data_ptr(), H, W, ops._stream()), "hgl_resize_bilinear")
+    return out
+
+
+def resize_shorter_side(h, w, size):
+    """output (h, w) of T.Resize(int) (torchvision _compute_resized_output_size): the shorter side becomes `size`, the
+    longer one int(size * long / short)"""
+    short, long = (w, h) if w <= h else (h, w)
+    new_short, new_long = size, int(size * long / short)
+    return (new_long, new_short) if w <= h else (new_short, new_long)
+
+
+def phrasecut_image_norm(file_img_u8, height, width):
+    """image['image'] of the PhraseCut evaluator as its loop uses it: T.Resize(800) on the PIL image (shorter side to 800,
+    Pillow bilinear) -> ToTensor -> Normalize(ImageNet) (data/dataset_phrasecut.py:49-51), then T.Resize((height, width)) on
+    that tensor (Hybridgl_main_PhraseCut.py:69-70: plain bilinear, no antialias) -> fp32 [3, height, width]."""
+    H, W = file_img_u8.shape[:2]
+    nh, nw = resize_shorter_side(H, W, 800)
+    r = file_img_u8 if (nh, nw) == (H, W) else pil_resize_u8(file_img_u8, nh, nw, "bilinear")
+    return resize_bilinear(to_tensor_normalize(r), (height, width))

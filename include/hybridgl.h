@@ -34,7 +34,7 @@ extern "C" {
 
 /* 2: + hgl_clip_hybrid_forward_segments, hgl_split_overflow_count, hgl_clip_encode_text_ex; hgl_gemm_f16x3_select
  * knows kinds -1, 0, 1 only
- * 5: + hgl_u8_to_chw_lut, hgl_split_overflow_peek_async */
+ * 5: + hgl_u8_to_chw_lut, hgl_split_overflow_peek_async, hgl_resize_bilinear */
 #define HGL_ABI_VERSION 5
 
 /* activation codes for hgl_gemm_f32 */
@@ -249,6 +249,10 @@ int hgl_gem_image_features_batch(const HglClipVisionW* w, const float* imgs, int
 size_t hgl_gem_heatmap_workspace_bytes(int grid, int T, int res);
 int hgl_gem_heatmap(const float* feat, int grid, int E, const float* text, int T, int res, int normalize,
                     float* heat, void* workspace, size_t workspace_bytes, void* stream);
+
+/* F.interpolate(bilinear, align_corners=False, antialias=False) of a float tensor [C, h, w] -> [C, H, W] = torchvision
+ * 0.15's T.Resize on a TENSOR (Hybridgl_main_PhraseCut.py:69-70: the normalised image back to the annotation's size). */
+int hgl_resize_bilinear(const float* in, int C, int h, int w, float* out, int H, int W, void* stream);
 
 /* T.Resize((H,W), antialias=True) on a float tensor (Hybridgl_main.py:201):
  * F.interpolate(bilinear, antialias=True, align_corners=False); in [C,h,w] -> out [C,H,W]. */

@@ -314,3 +314,51 @@ def test_phrasecut_configuration_at_full_size(cuda, full):
     torch.cuda.synchronize()
     r1, r2 = p1.partial_rows(), p2.partial_rows()
     assert r1.shape == (16, 6) and np.array_equal(r1, r2)
+
+
+def test_crop_layers_in_groups_equal_image_by_image(cuda):
+    """SamAutomaticMaskGenerator.crops_begin / crops_mid / crops_post / crops_finish (three host syncs per GROUP of images)
+    against generate_device_crops (one per crop + two per image): identical masks, boxes, scores, for images of different
+    sizes, with thresholds that decide."""
+    from hybridgl_amd.sam import SamAutomaticMaskGenerator, sam_model_registry
+    from hybridgl_amd.synth import synth_image
+    sam = sam_model_registry["tiny"](device=cuda)
+    imgs = [torch.from_numpy(synth_image(h, w, 11 + i)).to(cuda) for i, (h, w) in enumerate(((150, 200), (200, 150), (120, 120)))]
+    gen = SamAutomaticMaskGenerator(sam, points_per_side=6, points_per_batch=16, pred_iou_thresh=0.0, stability_score_thresh=0.0,
+                                    crop_n_layers=1, crop_n_points_downscale_factor=2, min_mask_region_area=10)
+    # thresholds that decide: the IoU threshold at the median prediction of the first image, sparse masks for the NMS passes
+    probe = gen.generate_device_crops(imgs[0])
+    gen.pred_iou_thresh = float(probe[2].median()) if len(probe[2]) else 0.0
+    one = [gen.generate_device_crops(im) for im in imgs]
+    grp = gen.generate_crops_group(imgs)
+    assert len(grp) == 3
+    for a, b in zip(one, grp):
+        assert a[0].shape == b[0].shape and a[0].shape[0] > 0
+        for x, y in zip(a[:4], b[:4]):
+            assert torch.equal(x, y)
+
+
+def test_phrasecut_from_disk_groups_equal_image_by_image(cuda, tmp_path):
+    """python -m hybridgl_amd.main --dataset phrasecut on a tree in the published VGPhraseCut layout (synth.write_phrasecut_tree:
+    image files smaller than their annotation included): the grouped loop (crop layers through the three-sync protocol,
+    loader threads, device transforms) reports exactly what the image-by-image loop (--group 1: step()) reports; every
+    phrase is scored against its own ground truth."""
+    from hybridgl_amd import main as drv, synth
+    root = str(tmp_path / "pc")
+    info = synth.write_phrasecut_tree(root, n_images=5, phrases_per_image=3, sizes=((120, 160), (160, 120), (96, 128)), resized_files=0.5)
+    base = ["--real", "--dataset", "phrasecut", "--split", "test", "--phrasecut_root", root, "--bpe_vocab", os.path.join(root, "bpe.txt.gz"),
+            "--parse_json", os.path.join(root, "parse.json"), "--sam_model", "tiny", "--points_per_side", "4", "--points_per_batch", "16",
+            "--pred_iou_thresh", "0.0", "--stability_score_thresh", "0", "--min_mask_region_area", "10", "--fusion_mode", "G2L&L2G",
+            "--proposal_cap", "24", "--k_clamp", "per_ref", "--result_dir", str(tmp_path / "log")]
+    args = drv.default_argument_parser().parse_args(base + ["--group", "2"])
+    model, gen, gem = drv.build_models(args, cuda)
+    assert gen.crop_n_layers == 1 and len(gen.point_grids) == 2
+    m_grp, st = drv.evaluate(args, model, gen, gem, cuda)
+    assert st["refs"] == info["images"] and m_grp["n_sentences"] == info["phrases"] and st["skipped"] == 0
+    args1 = drv.default_argument_parser().parse_args(base + ["--group", "1"])
+    m_one, st1 = drv.evaluate(args1, model, gen, gem, cuda)
+    assert m_one["n_sentences"] == info["phrases"]
+    # step() applies no proposal cap: compare with an uncapped grouped run as well when the cap did not bind
+    args_nc = drv.default_argument_parser().parse_args([a for a in base if a not in ("--proposal_cap", "24")] + ["--group", "3"])
+    m_nc, _ = drv.evaluate(args_nc, model, gen, gem, cuda)
+    assert m_nc == m_one

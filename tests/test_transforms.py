@@ -55,3 +55,49 @@ def test_synthetic_refer_tree_reads_back(tmp_path):
     import json
     parse = json.load(open(tmp_path / "parse.json"))
     assert set(parse) == {str(s) for r in ds.ref_ids for s in ds.refer.Refs[r]["sent_ids"]}
+
+
+def test_phrasecut_tree_reads_back(tmp_path):
+    """hybridgl_amd/phrasecut_io.py on a tree in the published VGPhraseCut layout: one item per image, every phrase with the
+    polygons of all its instances, the image brought to the annotation's size, ground truth as dataset_phrasecut.py:108-122
+    rasterises it; the seen / unseen filters."""
+    from hybridgl_amd.phrasecut_io import COCO_CLASSES, PhraseCutDataset, RefVGLoader, cv_resize_linear_u8
+    info = synth.write_phrasecut_tree(str(tmp_path), n_images=6, phrases_per_image=4, sizes=((60, 80), (80, 60)), resized_files=0.5)
+    ds = PhraseCutDataset(str(tmp_path), "test")
+    assert len(ds) == 6 and ds.refvg_loader.img_ids == sorted(ds.refvg_loader.img_ids)
+    n_resized = 0
+    for i in range(6):
+        it = ds[i]
+        assert it["sam_img"].shape == (it["height"], it["width"], 3) and len(it["phrases"]) == 4
+        n_resized += it["file_img"] is not None
+        gt = ds.gt_mask(it, 1)
+        assert gt.shape == (it["height"], it["width"]) and gt.dtype == bool and 0 < gt.sum() < gt.size
+    assert 0 < n_resized < 6
+    assert sum(len(ds[i]["phrases"]) for i in range(6)) == info["phrases"]
+    with pytest.raises(FileNotFoundError):
+        RefVGLoader(str(tmp_path), "val")
+    seen, unseen = PhraseCutDataset(str(tmp_path), "test", seen_mode=True), PhraseCutDataset(str(tmp_path), "test", unseen_mode=True)
+    for i in range(6):
+        a, b = seen[i], unseen[i]
+        assert len(a["phrases"] if a else []) + len(b["phrases"] if b else []) == 4
+    names = {t["phrase_structure"]["name"] for ts in ds.refvg_loader.ImgReferTasks.values() for t in ts}
+    assert names & set(COCO_CLASSES) and names - set(COCO_CLASSES)
+    # the cv2.resize restatement: identity at equal size, constants stay constant, a ramp stays within one grey level of
+    # the real-valued interpolation (parity with opencv-python itself is unpinned: absent offline)
+    img = np.random.default_rng(0).integers(0, 256, (30, 40, 3), dtype=np.uint8)
+    assert cv_resize_linear_u8(img, 40, 30) is img
+    assert (cv_resize_linear_u8(np.full((30, 40, 3), 77, np.uint8), 80, 45) == 77).all()
+    ramp = np.tile(np.arange(0, 200, 5, dtype=np.uint8)[None, :, None], (30, 1, 3))
+    x = np.clip((np.arange(80) + 0.5) * 0.5 - 0.5, 0, 39)
+    assert np.abs(cv_resize_linear_u8(ramp, 80, 30)[0, :, 0] - np.interp(x, np.arange(40), np.arange(0, 200, 5))).max() <= 1.0
+
+
+def test_dataset_defaults_follow_the_reference_scripts():
+    from hybridgl_amd import main as drv
+    a = drv.resolve_defaults(drv.default_argument_parser().parse_args(["--dataset", "refcocog"]))
+    assert (a.points_per_side, a.pred_iou_thresh, a.stability_score_thresh, a.min_mask_region_area, a.crop_n_layers, a.group) == \
+           (8, 0.7, 0.7, 800, 0, 16)                                             # Hybridgl_main.py:67-73
+    b = drv.resolve_defaults(drv.default_argument_parser().parse_args(["--dataset", "phrasecut", "--group", "2"]))
+    assert (b.points_per_side, b.pred_iou_thresh, b.stability_score_thresh, b.min_mask_region_area, b.crop_n_layers,
+            b.crop_n_points_downscale_factor, b.group) == (64, 0.86, 0.92, 100, 1, 2, 2)   # Hybridgl_main_PhraseCut.py:56-62
+    assert T.resize_shorter_side(480, 640, 800) == (800, 1066) and T.resize_shorter_side(640, 480, 800) == (1066, 800)

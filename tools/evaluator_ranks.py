@@ -35,7 +35,7 @@ def main():
         stats = os.path.join(root, "stats.json")
         argv = [sys.executable, "-m", "hybridgl_amd.main", "--real", "--refer_data_root", root, "--dataset", "refcoco", "--split", "val",
                 "--bpe_vocab", os.path.join(root, "bpe.txt.gz"), "--parse_json", os.path.join(root, "parse.json"),
-                "--proposal_cap", "64", "--pred_iou_thresh", "-1e30", "--stability_score_thresh", "0", "--box_nms_thresh", "2.0",
+                "--proposal_cap", "64", "--pred_iou_thresh=-1e30", "--stability_score_thresh", "0", "--box_nms_thresh", "2.0",
                 "--group", str(args.group), "--workers", str(args.workers), "--result_dir", os.path.join(root, "log"),
                 "--stats_json", stats]
         env = {"HYBRIDGL_DIST_BACKEND": "gloo", "PYTHONPATH": ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")}
