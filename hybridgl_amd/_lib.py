@@ -20,6 +20,13 @@ class HybridGLError(RuntimeError):
     pass
 
 
+class HglSentence(C.Structure):
+    """include/hybridgl.h HglSentence: one referring expression of a ref for hgl_score_ref"""
+    _fields_ = [("sentence_row", C.c_int), ("noun_phrase_row", C.c_int), ("other_row0", C.c_int), ("n_other", C.c_int),
+                ("dirflag", C.c_int), ("relaword", C.c_int), ("has_other_nouns", C.c_int), ("black", C.c_float),
+                ("imgattn", C.c_void_p), ("target", C.c_void_p)]
+
+
 class HglResBlockW(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln1_w", "ln1_b", "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b",
@@ -174,6 +181,9 @@ PROTOTYPES = {
     "hgl_gaussian_blur_u8": (_I, [_VP, _I, _I, _I, C.POINTER(C.c_double), _I, _VP, _VP, _SZ, _VP]),
     "hgl_cv_gaussian_kernel_q8": (_I, [_I, C.c_double, C.POINTER(C.c_uint16)]),
     "hgl_gaussian_blur_u8_q8": (_I, [_VP, _I, _I, _I, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), _I, _VP, _VP, _SZ, _VP]),
+    "hgl_score_ref_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "hgl_score_ref": (_I, [_VP, _VP, _I, _VP, _VP, _I, _I, _I, _I, C.POINTER(HglSentence), _I, C.c_float, C.c_float, _I, _I, C.c_float,
+                           _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_u8_to_chw_lut": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP]),
     "hgl_gt_mask_from_polygons": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP]),
     "hgl_gt_mask_from_rle_counts": (_I, [_VP, _I, _I, _I, _VP, _VP]),

@@ -6,6 +6,7 @@
 //   synthesize_views     Hybridgl_main.py:93-125
 #include "hgl_common.h"
 #include <math.h>
+#include <string.h>
 
 namespace {
 
@@ -303,7 +304,7 @@ __device__ float relation_boxes_dev(const long long* bi, const long long* bj, fl
   }
 }
 
-__global__ __launch_bounds__(256) void score_sentence_kernel(
+__device__ __forceinline__ void score_sentence_body(
     const float* __restrict__ hybrid, const float* __restrict__ sent, const float* __restrict__ nphr,
     const float* __restrict__ others, int n_other, float r_mix,
     const long long* __restrict__ boxes, const float* __restrict__ gem, int N, int E,
@@ -466,6 +467,245 @@ __global__ __launch_bounds__(256) void score_sentence_kernel(
       if (i == 0 || v > bv || (v != v && bv == bv)) { bv = v; best = i; }
     }
     idx[1] = top1[best];
+  }
+}
+
+__global__ __launch_bounds__(256) void score_sentence_kernel(
+    const float* __restrict__ hybrid, const float* __restrict__ sent, const float* __restrict__ nphr,
+    const float* __restrict__ others, int n_other, float r_mix,
+    const long long* __restrict__ boxes, const float* __restrict__ gem, int N, int E,
+    float logit_scale, int k1, int k2, float alpha, int rela, int has_other, int* __restrict__ idx,
+    float* __restrict__ score_clip, float* __restrict__ score_neg, float* __restrict__ soft_scratch) {
+  score_sentence_body(hybrid, sent, nphr, others, n_other, r_mix, boxes, gem, N, E, logit_scale, k1, k2, alpha, rela, has_other,
+                      idx, score_clip, score_neg, soft_scratch);
+}
+
+// ---- the tail of a whole REF (all its sentences) in four launches: Hybridgl_main.py:153-230 -------------------------------
+// The per-sentence launches above re-read the N mask planes for every sentence (83.6 MB per ref at N = 64, 640 x 640, three
+// sentences) and cost ~15 launches per sentence with torch glue between them.  Here every mask byte is read ONCE for all the
+// sentences' heat-maps (31.1 MB per ref), the scoring of the sentences runs as one workgroup each in one launch, the IoU of
+// both winners of every sentence in one launch, and the four accumulators of Hybridgl_main.py:52-55 are updated by the
+// last block of that launch.  Arithmetic and reduction orders are those of the per-sentence kernels (bit-identical results).
+constexpr int REF_MAXS = 16;       // sentences per launch (the host loops over chunks)
+constexpr int REF_MM_BLOCKS = 64;  // min / max partials per heat-map
+constexpr int REF_SC = 4;          // heat-maps pooled per pass over a mask's bytes
+
+struct RefSentences {
+  const float* attn[REF_MAXS];
+  const uint8_t* target[REF_MAXS];
+  int sent_row[REF_MAXS], nphr_row[REF_MAXS], other_row0[REF_MAXS], n_other[REF_MAXS];
+  int dirflag[REF_MAXS], rela[REF_MAXS], has_other[REF_MAXS];
+  float black[REF_MAXS];
+};
+
+__global__ __launch_bounds__(256) void ref_minmax_kernel(RefSentences rs, long long n, float* __restrict__ part_mm) {
+  const int s = blockIdx.y;
+  const float* a = rs.attn[s];
+  float mn = INFINITY, mx = -INFINITY;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = a[i];
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  __shared__ float smn[4], smx[4];
+  if ((threadIdx.x & 63) == 0) {
+    smn[threadIdx.x >> 6] = mn;
+    smx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* p = part_mm + ((long long)s * REF_MM_BLOCKS + blockIdx.x) * 2;
+    p[0] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    p[1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  }
+}
+
+// min / max are exact in any order: every wave folds the 64 partial pairs of a map itself (one pair per lane)
+__device__ __forceinline__ void ref_fold_minmax(const float* __restrict__ part_mm, int s, int lane, float& mn, float& mx) {
+  const float* p = part_mm + ((long long)s * REF_MM_BLOCKS + lane) * 2;
+  mn = p[0];
+  mx = p[1];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+}
+
+// masked_pool_kernel for S heat-maps at once: grid (pixel blocks, mask groups); the mask bytes of a (block, mask) are read
+// once per pass of REF_SC maps (one pass for the three sentences of a RefCOCO ref)
+__global__ __launch_bounds__(256) void ref_masked_pool_kernel(RefSentences rs, int S, const uint8_t* __restrict__ masks, int N, int H,
+                                                              int W, const float* __restrict__ part_mm, double* __restrict__ part_sum,
+                                                              unsigned* __restrict__ part_cnt, double* __restrict__ part_tot,
+                                                              int nparts) {
+  const long long HW = (long long)H * W;
+  const long long p0 = (long long)blockIdx.x * PIX_PER_BLOCK + threadIdx.x * PX_LANE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long part = (long long)blockIdx.x * 4 + wave;
+  const bool inb = p0 + PX_LANE <= HW;
+  const int n0 = blockIdx.y * MASK_GROUP;
+  const int n1 = min(N, n0 + MASK_GROUP);
+  for (int s0 = 0; s0 < S; s0 += REF_SC) {
+    const int sc = min(REF_SC, S - s0);
+    float v[REF_SC][PX_LANE];
+#pragma unroll
+    for (int j = 0; j < REF_SC; ++j) {
+      if (j < sc) {
+        float mn, mx;
+        ref_fold_minmax(part_mm, s0 + j, lane, mn, mx);
+        const float range = mx - mn;
+        const float* attn = rs.attn[s0 + j];
+        const int dirflag = rs.dirflag[s0 + j];
+        double tot = 0.0;
+#pragma unroll
+        for (int e = 0; e < PX_LANE; ++e) {
+          const long long p = p0 + e;
+          float val = 0.f;
+          if (p < HW) {
+            const int x = (int)(p % W);
+            val = ((attn[p] - mn) / range) * dir_weight(dirflag, x, W);
+          }
+          v[j][e] = val;
+          tot += (double)val;
+        }
+        if (blockIdx.y == 0) {
+          tot = wave_sum_d(tot);
+          if (lane == 0) part_tot[(long long)(s0 + j) * nparts + part] = tot;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < PX_LANE; ++e) v[j][e] = 0.f;
+      }
+    }
+    for (int n = n0; n < n1; ++n) {
+      const uint8_t* m = masks + (long long)n * HW + p0;
+      bool on[PX_LANE];
+      if (inb && (((uintptr_t)m) & 15) == 0) {
+        const uint4 mv = *(const uint4*)m;
+        const unsigned w4[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+        for (int e = 0; e < PX_LANE; ++e) on[e] = ((w4[e >> 2] >> (8 * (e & 3))) & 0xff) != 0;
+      } else {
+#pragma unroll
+        for (int e = 0; e < PX_LANE; ++e) on[e] = (p0 + e < HW) && m[e] != 0;
+      }
+      if (s0 == 0) {
+        unsigned c = 0;
+#pragma unroll
+        for (int e = 0; e < PX_LANE; ++e) c += on[e] ? 1u : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) part_cnt[part * N + n] = c;
+      }
+#pragma unroll
+      for (int j = 0; j < REF_SC; ++j) {
+        if (j < sc) {
+          double sum = 0.0;
+#pragma unroll
+          for (int e = 0; e < PX_LANE; ++e) sum += on[e] ? (double)v[j][e] : 0.0;
+          sum = wave_sum_d(sum);
+          if (lane == 0) part_sum[((long long)(s0 + j) * nparts + part) * N + n] = sum;
+        }
+      }
+    }
+  }
+}
+
+// one workgroup per sentence: coherence_final_kernel's reduction for its N masks, then the sentence's scoring
+__global__ __launch_bounds__(256) void ref_score_kernel(RefSentences rs, const float* __restrict__ hybrid, const float* __restrict__ text,
+                                                        const long long* __restrict__ boxes, int N, int E, int H, int W,
+                                                        float logit_scale, float r_mix, int k1, int k2, float alpha,
+                                                        const double* __restrict__ part_sum, const unsigned* __restrict__ part_cnt,
+                                                        const double* __restrict__ part_tot, int nparts, float* __restrict__ gem_all,
+                                                        float* __restrict__ clip_all, float* __restrict__ neg_all,
+                                                        float* __restrict__ soft_all, int* __restrict__ idx_all,
+                                                        unsigned long long* __restrict__ iu_all, unsigned* __restrict__ done) {
+  const int s = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long HW = (long long)H * W;
+  float* gem = gem_all + (long long)s * N;
+  const float black = rs.black[s];
+  for (int n = wave; n < N; n += 4) {
+    double tot = 0.0, sm = 0.0;
+    unsigned long long c = 0;
+    for (int b = lane; b < nparts; b += 64) {
+      tot += part_tot[(long long)s * nparts + b];
+      sm += part_sum[((long long)s * nparts + b) * N + n];
+      c += part_cnt[(long long)b * N + n];
+    }
+    tot = wave_sum_d(tot);
+    sm = wave_sum_d(sm);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) {
+      const double mean = tot / (double)HW;
+      const double in_sum = sm / mean, out_sum = (tot - sm) / mean;
+      const double a = (double)(2.f - black) * in_sum / (double)c;
+      const double bterm = (double)black * out_sum / (double)(HW - (long long)c);
+      gem[n] = (float)(a - bterm);
+    }
+  }
+  if (threadIdx.x < 4) iu_all[4 * s + threadIdx.x] = 0ull;
+  if (s == 0 && threadIdx.x == 0) *done = 0u;
+  __syncthreads();
+  __threadfence_block();
+  score_sentence_body(hybrid, text + (long long)rs.sent_row[s] * E, text + (long long)rs.nphr_row[s] * E,
+                      text + (long long)rs.other_row0[s] * E, rs.n_other[s], r_mix, boxes, gem, N, E, logit_scale, k1, k2, alpha,
+                      rs.rela[s], rs.has_other[s], idx_all + 2 * s, clip_all + (long long)s * N, neg_all + (long long)s * N,
+                      soft_all + (long long)s * (2 * N + 2 * E));
+}
+
+// Compute_IoU of both winners of every sentence: grid (blocks, 2 S); the last block to finish adds the ref's counts to
+// the running accumulators cum_I, cum_U, cum_I_final, cum_U_final (integers: order-free)
+__global__ __launch_bounds__(256) void ref_iou_kernel(RefSentences rs, int S, const uint8_t* __restrict__ masks, long long n,
+                                                      const int* __restrict__ idx_all, unsigned long long* __restrict__ iu_all,
+                                                      unsigned long long* __restrict__ cum, unsigned* __restrict__ done) {
+  const int s = blockIdx.y >> 1, which = blockIdx.y & 1;
+  const uint8_t* p = masks + (long long)idx_all[2 * s + which] * n;
+  const uint8_t* g = rs.target[s];
+  unsigned I = 0, U = 0;
+  const bool al = ((((uintptr_t)p) | ((uintptr_t)g)) & 15) == 0;
+  const long long n16 = al ? n / 16 : 0;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
+    const uint4 a = ((const uint4*)p)[i], b = ((const uint4*)g)[i];
+    const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned x = aw[w], y = bw[w];
+      x |= x >> 4; x |= x >> 2; x |= x >> 1; x &= 0x01010101u;
+      y |= y >> 4; y |= y >> 2; y |= y >> 1; y &= 0x01010101u;
+      I += __popc(x & y);
+      U += __popc(x | y);
+    }
+  }
+  for (long long i = n16 * 16 + blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const bool a = p[i] != 0, b = g[i] != 0;
+    I += (a && b);
+    U += (a || b);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    I += __shfl_xor(I, o);
+    U += __shfl_xor(U, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&iu_all[4 * s + 2 * which], (unsigned long long)I);
+    atomicAdd(&iu_all[4 * s + 2 * which + 1], (unsigned long long)U);
+  }
+  __threadfence();
+  __syncthreads();
+  __shared__ int last;
+  if (threadIdx.x == 0) last = atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1;
+  __syncthreads();
+  if (last && cum != nullptr && threadIdx.x < 4) {
+    unsigned long long a = 0;
+    for (int j = 0; j < S; ++j) a += atomicAdd(&iu_all[4 * j + threadIdx.x], 0ull);   // coherent read of the other blocks' sums
+    cum[threadIdx.x] += a;
   }
 }
 
@@ -717,6 +957,88 @@ int hgl_score_sentence(const float* hybrid, const float* sentence_feat, const fl
   float* pool = (float*)workspace;
   hipLaunchKernelGGL(score_sentence_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, hybrid, sentence_feat, noun_phrase_feat, other_noun_feats, n_other, r, (const long long*)boxes, gem_score, N, E, logit_scale, k1, k2, alpha, relaword, has_other_nouns, (int*)idx, score_clip, score_neg, pool);
   return hgl_check_launch("score_sentence");
+}
+
+static size_t ref_ws_layout(int S, int N, int E, int H, int W, size_t* off) {
+  const size_t nparts = coh_nparts(H, W);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += hgl_align_up(bytes, 256); return at; };
+  off[0] = take((size_t)S * REF_MM_BLOCKS * 2 * sizeof(float));          // part_mm
+  off[1] = take((size_t)S * nparts * N * sizeof(double));                 // part_sum
+  off[2] = take(nparts * (size_t)N * sizeof(unsigned));                   // part_cnt
+  off[3] = take((size_t)S * nparts * sizeof(double));                     // part_tot
+  off[4] = take((size_t)S * (2 * (size_t)N + 2 * (size_t)E) * sizeof(float));   // soft-max + text scratch per sentence
+  off[5] = take((size_t)3 * S * N * sizeof(float));                       // gem / clip / neg when the caller does not want them
+  off[6] = take(256);                                                     // done counter
+  return o;
+}
+
+size_t hgl_score_ref_workspace_bytes(int S, int N, int E, int H, int W) {
+  size_t off[7];
+  return ref_ws_layout(S < REF_MAXS ? S : REF_MAXS, N, E, H, W, off);
+}
+
+int hgl_score_ref(const float* hybrid, const float* text, int T, const int64_t* boxes, const uint8_t* masks, int N, int E,
+                  int H, int W, const HglSentence* sentences, int S, float logit_scale, float r, int k1, int k2, float alpha,
+                  int32_t* idx, int64_t* iu, int64_t* cum, float* score_clip, float* score_neg, float* gem_score,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(hybrid && text && boxes && masks && sentences && idx && iu, "score_ref: null argument");
+  HGL_REQUIRE(N > 0 && E > 0 && H > 0 && W > 0 && S > 0 && T > 0, "score_ref: bad shape");
+  if (k1 > N) k1 = N;       // Hybridgl_main.py:178-181
+  if (k2 > N) k2 = N;
+  HGL_REQUIRE(k1 >= 1 && k1 <= MAXK && k2 >= 1 && k2 <= MAXK, "score_ref: k1,k2 must be in [1,%d]", MAXK);
+  for (int s = 0; s < S; ++s) {
+    const HglSentence& q = sentences[s];
+    HGL_REQUIRE(q.imgattn && q.target, "score_ref: sentence %d has no heat-map / target", s);
+    HGL_REQUIRE(q.sentence_row >= 0 && q.sentence_row < T && q.noun_phrase_row >= 0 && q.noun_phrase_row < T, "score_ref: sentence %d: text row out of range", s);
+    HGL_REQUIRE(q.n_other >= 0 && (q.n_other == 0 || (q.other_row0 >= 0 && q.other_row0 + q.n_other <= T)), "score_ref: sentence %d: other-noun rows out of range", s);
+    HGL_REQUIRE(q.dirflag >= 0 && q.dirflag <= 3 && q.relaword >= 0 && q.relaword <= 7, "score_ref: sentence %d: bad dirflag / relaword", s);
+  }
+  if (!workspace || workspace_bytes < hgl_score_ref_workspace_bytes(S, N, E, H, W)) {
+    hgl_set_error("score_ref: workspace too small (%zu < %zu)", workspace_bytes, hgl_score_ref_workspace_bytes(S, N, E, H, W));
+    return HGL_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long long HW = (long long)H * W;
+  const int nparts = coh_nparts(H, W);
+  for (int s0 = 0; s0 < S; s0 += REF_MAXS) {
+    const int sc = S - s0 < REF_MAXS ? S - s0 : REF_MAXS;
+    size_t off[7];
+    ref_ws_layout(sc, N, E, H, W, off);
+    char* base = (char*)workspace;
+    RefSentences rs;
+    memset(&rs, 0, sizeof(rs));
+    for (int j = 0; j < sc; ++j) {
+      const HglSentence& q = sentences[s0 + j];
+      rs.attn[j] = q.imgattn; rs.target[j] = q.target;
+      rs.sent_row[j] = q.sentence_row; rs.nphr_row[j] = q.noun_phrase_row;
+      rs.other_row0[j] = q.n_other > 0 ? q.other_row0 : 0; rs.n_other[j] = q.n_other;
+      rs.dirflag[j] = q.dirflag; rs.rela[j] = q.relaword; rs.has_other[j] = q.has_other_nouns; rs.black[j] = q.black;
+    }
+    float* part_mm = (float*)(base + off[0]);
+    double* psum = (double*)(base + off[1]);
+    unsigned* pcnt = (unsigned*)(base + off[2]);
+    double* ptot = (double*)(base + off[3]);
+    float* soft = (float*)(base + off[4]);
+    float* spare = (float*)(base + off[5]);
+    unsigned* done = (unsigned*)(base + off[6]);
+    float* gem = gem_score ? gem_score + (long long)s0 * N : spare;
+    float* clip = score_clip ? score_clip + (long long)s0 * N : spare + (long long)sc * N;
+    float* neg = score_neg ? score_neg + (long long)s0 * N : spare + 2ll * sc * N;
+    hipLaunchKernelGGL(ref_minmax_kernel, dim3(REF_MM_BLOCKS, sc), dim3(256), 0, st, rs, HW, part_mm);
+    hipLaunchKernelGGL(ref_masked_pool_kernel, dim3(coh_nblk(H, W), (N + MASK_GROUP - 1) / MASK_GROUP), dim3(256), 0, st, rs, sc, masks,
+                       N, H, W, part_mm, psum, pcnt, ptot, nparts);
+    hipLaunchKernelGGL(ref_score_kernel, dim3(sc), dim3(256), 0, st, rs, hybrid, text, (const long long*)boxes, N, E, H, W, logit_scale,
+                       r, k1, k2, alpha, psum, pcnt, ptot, nparts, gem, clip, neg, soft, (int*)idx + 2 * s0,
+                       (unsigned long long*)iu + 4 * s0, done);
+    long long blocks = (HW / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 128) blocks = 128;
+    hipLaunchKernelGGL(ref_iou_kernel, dim3((unsigned)blocks, 2 * sc), dim3(256), 0, st, rs, sc, masks, HW, (const int*)idx + 2 * s0,
+                       (unsigned long long*)iu + 4 * s0, (unsigned long long*)cum, done);
+  }
+  return hgl_check_launch("score_ref");
 }
 
 int hgl_gen_dir_mask(int dirflag, int H, int W, float* out, void* stream) {

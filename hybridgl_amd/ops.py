@@ -318,6 +318,50 @@ def score_sentence(hybrid, sentence_feat, noun_phrase_feat, other_noun_feats, bo
     return idx, sc, sn
 
 
+def score_ref(hybrid, text, boxes, masks, sentences, logit_scale=100.0, r=0.5, k1=3, k2=6, alpha=0.6, cum=None, want_scores=False):
+    """The whole tail of one dataset item (Hybridgl_main.py:153-230) in four launches: hgl_score_ref.
+
+    hybrid [N,E], text [T,E] (every string of the ref), boxes [N,4] int64 XYWH, masks [N,H,W] bool / uint8;
+    sentences: list of dicts {sentence_row, noun_phrase_row, other_row0, n_other, dirflag, relaword (strings as in the
+    reference), has_other_nouns, black, imgattn [H,W] fp32 tensor, target [H,W] bool / uint8 tensor}.
+    cum: int64 [4] device tensor incremented in place by (I, U, I_final, U_final) summed over the sentences.
+    Returns (idx [S,2] int32, iu [S,4] int64) and, with want_scores, (score_clip, score_neg, gem) [S,N] each."""
+    lib = _lib.load()
+    N, E = hybrid.shape
+    T = text.shape[0]
+    S = len(sentences)
+    mp, masks = _u8(masks, "masks")
+    _, H, W = masks.shape
+    dev = hybrid.device
+    recs = (_lib.HglSentence * S)()
+    keep = []       # tensors whose pointers sit in the records
+    for j, q in enumerate(sentences):
+        a = q["imgattn"]
+        if tuple(a.shape) != (H, W):
+            raise ValueError(f"sentence {j}: imgattn {tuple(a.shape)} != masks {(H, W)}")
+        tp, tt = _u8(q["target"], "target")
+        if tuple(tt.shape) != (H, W):
+            raise ValueError(f"sentence {j}: target {tuple(tt.shape)} != masks {(H, W)}")
+        keep += [a, tt]
+        recs[j] = _lib.HglSentence(int(q["sentence_row"]), int(q["noun_phrase_row"]), int(q.get("other_row0", 0)), int(q.get("n_other", 0)),
+                                   DIRFLAG.get(q.get("dirflag", "none"), 0), RELAWORD.get(q.get("relaword", "none"), 0),
+                                   int(bool(q.get("has_other_nouns", False))), float(q.get("black", 1.8)),
+                                   _dev(a, torch.float32, "imgattn"), tp)
+    idx = torch.empty((S, 2), dtype=torch.int32, device=dev)
+    iu = torch.empty((S, 4), dtype=torch.int64, device=dev)
+    sc = sn = gm = None
+    if want_scores:
+        sc, sn, gm = (torch.empty((S, N), dtype=torch.float32, device=dev) for _ in range(3))
+    need = lib.hgl_score_ref_workspace_bytes(S, N, E, H, W)
+    ws = workspace(need, dev, "score_ref")
+    check(lib.hgl_score_ref(_dev(hybrid, torch.float32, "hybrid"), _dev(text, torch.float32, "text"), T,
+                            _dev(boxes, torch.int64, "boxes"), mp, N, E, H, W, recs, S, float(logit_scale), float(r), int(k1), int(k2),
+                            float(alpha), idx.data_ptr(), iu.data_ptr(), _dev(cum, torch.int64, "cum") if cum is not None else None,
+                            sc.data_ptr() if sc is not None else None, sn.data_ptr() if sn is not None else None,
+                            gm.data_ptr() if gm is not None else None, ws.data_ptr(), ws.numel(), _stream()), "hgl_score_ref")
+    return (idx, iu, sc, sn, gm) if want_scores else (idx, iu)
+
+
 def synthesize_views(sam_img, blurred, image_norm, masks, res=224, out=None):
     """Hybridgl_main.py:93-125 -> (local_imgs, global_imgs) [N,3,res,res] fp32 (written into `out` when given)."""
     lib = _lib.load()

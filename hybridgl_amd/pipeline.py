@@ -133,6 +133,8 @@ class HybridGLPipeline:
         self.cache_hits = 0
         self.k_clamp = k_clamp
         import os
+        # the per-sentence tail as ONE hgl_score_ref call per ref (HYBRIDGL_FUSED_TAIL=0: the per-sentence launches)
+        self.fused_tail = os.environ.get("HYBRIDGL_FUSED_TAIL", "1") != "0"
         self.stagger = os.environ.get("HYBRIDGL_STAGGER", "decoder")   # which part of the next group's SAM stage the CLIP stage runs beside
         self._k0 = (k1, k2)
         self.model = model
@@ -256,13 +258,28 @@ class HybridGLPipeline:
         self.k2 = min(self.k2, hybrid.shape[0])
         ref_index = ref.index if ref.index is not None else self._n_refs
         self._n_refs += 1
+        heats = iter(heat) if heat is not None else None
+        attn = [s.imgattn if s.imgattn is not None else next(heats) for s in ref.sentences]
+        fused = self.fused_tail and text.is_contiguous() and all(
+            list(s.other_noun_rows) == list(range(s.other_noun_rows[0], s.other_noun_rows[0] + len(s.other_noun_rows)))
+            for s in ref.sentences if s.other_noun_rows)
+        if fused:
+            # hgl_score_ref: every mask byte read once for all sentences' heat-maps, one scoring workgroup per sentence,
+            # both IoUs of every sentence and the accumulators of Hybridgl_main.py:52-55 in the same four launches
+            recs = [dict(sentence_row=s.sentence_row, noun_phrase_row=s.noun_phrase_row,
+                         other_row0=s.other_noun_rows[0] if s.other_noun_rows else 0, n_other=len(s.other_noun_rows),
+                         dirflag=s.dirflag, relaword=s.relaflag, has_other_nouns=s.n_nouns != 0, black=black_for(s.relaflag),
+                         imgattn=a if a.is_contiguous() else a.contiguous(), target=s.target if s.target is not None else ref.target)
+                    for s, a in zip(ref.sentences, attn)]
+            idx, iu, sc, sn, gm = ops.score_ref(hybrid, text, ref.boxes, ref.masks, recs, m.model._logit_scale_exp, self.r, self.k1,
+                                                self.k2, self.alpha, cum=self.cum, want_scores=True)
+            for j in range(len(recs)):
+                self.iu_log.append((iu[j, 0:2], iu[j, 2:4]))
+                self.iu_owner.append((ref_index, j))
+                self.idx_log.append(idx[j])
+            return (idx[-1], sc[-1], sn[-1], gm[-1]) if recs else None
         last = None
-        n_heat = 0
-        for sent_no, s in enumerate(ref.sentences):
-            imgattn = s.imgattn
-            if imgattn is None:
-                imgattn = heat[n_heat]
-                n_heat += 1
+        for sent_no, (s, imgattn) in enumerate(zip(ref.sentences, attn)):
             gem = ops.coherence_scores(imgattn, ref.masks, s.dirflag, black_for(s.relaflag))
             others = _rows(text, s.other_noun_rows)
             idx, sc, sn = ops.score_sentence(hybrid, text[s.sentence_row], text[s.noun_phrase_row], others,

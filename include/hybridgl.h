@@ -34,7 +34,7 @@ extern "C" {
 
 /* 2: + hgl_clip_hybrid_forward_segments, hgl_split_overflow_count, hgl_clip_encode_text_ex; hgl_gemm_f16x3_select
  * knows kinds -1, 0, 1 only
- * 5: + hgl_u8_to_chw_lut, hgl_split_overflow_peek_async, hgl_resize_bilinear */
+ * 5: + hgl_u8_to_chw_lut, hgl_split_overflow_peek_async, hgl_resize_bilinear, hgl_score_ref */
 #define HGL_ABI_VERSION 5
 
 /* activation codes for hgl_gemm_f32 */
@@ -302,6 +302,33 @@ int hgl_score_sentence(const float* hybrid, const float* sentence_feat, const fl
                        int relaword, int has_other_nouns,
                        int32_t* idx, float* score_clip, float* score_neg,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* The whole tail of ONE dataset item (Hybridgl_main.py:153-230: every sentence of the ref) in four launches -- SURVEY.md
+ * 8b's `score_ref`.  Per sentence: text ensemble r*sentence + (1-r)*noun phrase and the mean of the other-noun features
+ * (rows of `text` [T,E]), logits against hybrid [N,E], the two soft-maxes and top-k lists, the relation_boxes sums over boxes
+ * [N,4] int64 XYWH, the coherence score of every proposal under the sentence's heat-map imgattn [H,W] (min-max, gen_dir_mask,
+ * /mean, `black`: :203-223), the blend and both arg-maxes, Compute_IoU of both winners against the sentence's target [H,W]
+ * uint8.  Every byte of masks [N,H,W] uint8 is read ONCE for all sentences' heat-maps.  `sentences`: HOST array of S records
+ * holding device pointers.  Outputs: idx [S,2] int32 (pure CLIP winner, winner with spatial guidance), iu [S,4] int64
+ * (I, U, I_final, U_final); cum [4] int64 (may be NULL) is INCREMENTED by the column sums of iu on the device
+ * (cum_I, cum_U, cum_I_final, cum_U_final of Hybridgl_main.py:52-55); score_clip / score_neg / gem_score [S,N] are optional
+ * (NULL) copies of the per-sentence logits and coherence scores.  Results are those of hgl_coherence_scores +
+ * hgl_score_sentence + hgl_iou_select per sentence, bit for bit. */
+typedef struct {
+  int sentence_row, noun_phrase_row;  /* rows of text: clip.tokenize(sentence), clip.tokenize(noun_phrase) (:146-152) */
+  int other_row0, n_other;            /* n_other consecutive rows from other_row0: 'a photo of ' + other noun (:157-164) */
+  int dirflag;                        /* 0 none, 1 left, 2 right, 3 middle (utils.py:135-161) */
+  int relaword;                       /* 0 none .. 7 within (utils.py:240-268) */
+  int has_other_nouns;                /* len(nouns) != 0 (:184) */
+  float black;                        /* :211-216 */
+  const float* imgattn;               /* [H,W] fp32, device: gem_model(...) resized to the image (:200-202) */
+  const uint8_t* target;              /* [H,W] uint8, device: the sentence's ground truth */
+} HglSentence;
+size_t hgl_score_ref_workspace_bytes(int S, int N, int E, int H, int W);
+int hgl_score_ref(const float* hybrid, const float* text, int T, const int64_t* boxes, const uint8_t* masks, int N, int E,
+                  int H, int W, const HglSentence* sentences, int S, float logit_scale, float r, int k1, int k2, float alpha,
+                  int32_t* idx, int64_t* iu, int64_t* cum, float* score_clip, float* score_neg, float* gem_score,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* Compute_IoU on a mask selected on the device: pred = masks[idx[which]] ([N,HW] uint8),
  * so the winning index never travels to the host (Hybridgl_main.py:169-171,227-230). */

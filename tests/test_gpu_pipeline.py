@@ -277,3 +277,30 @@ def test_rccl_backend_at_world_size_one(cuda):
     line = [l for l in r.stdout.splitlines() if l.startswith("HGL_SELFCHECK ")][-1]     # RCCL prints its own banner to stdout
     got = json.loads(line[len("HGL_SELFCHECK "):])
     assert got["backend"] == "nccl" and got["world_size_seen"] == 1 and got["rows_roundtrip_ok"] and got["max_ok"], got
+
+
+@pytest.mark.parametrize("N,H,W,n_sent", [(64, 640, 640, 3), (13, 97, 131, 5), (7, 120, 160, 9), (30, 200, 150, 18), (1, 64, 64, 2)])
+def test_fused_tail_equals_per_sentence_launches(cuda, N, H, W, n_sent):
+    """hgl_score_ref (one call per ref: every mask byte read once for all sentences' heat-maps, one scoring workgroup per
+    sentence, both IoUs and the accumulators in the same four launches) against hgl_coherence_scores + hgl_score_sentence +
+    2 x hgl_iou_select per sentence: indices, counts, accumulators, logits and coherence scores BIT FOR BIT -- ragged sizes,
+    more sentences than one pooling pass (4) and than one launch (16) hold, a single proposal (k1 / k2 clamp)."""
+    from hybridgl_amd.backbone import CLIPViTFM
+    from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
+    model = CLIPViTFM("tiny", seed=0, device=cuda)
+    refs = [synthetic_ref(i, cuda, N=N, H=H, W=W, n_sent=n_sent, vocab=512, context=16)[0] for i in range(2)]
+    for r in refs:        # a ref whose second sentence has no other noun and whose last has two (consecutive rows)
+        r.sentences[1].other_noun_rows = []
+        r.sentences[1].n_nouns = 0
+    a, b = HybridGLPipeline(model, res=64), HybridGLPipeline(model, res=64)
+    a.fused_tail, b.fused_tail = True, False
+    outs = []
+    for p in (a, b):
+        outs.append([p.step(r)[2] for r in refs])
+    torch.cuda.synchronize()
+    assert np.array_equal(a.partial_rows(), b.partial_rows()) and a.partial_rows().shape == (2 * n_sent, 6)
+    assert np.array_equal(a.winning_indices(), b.winning_indices())
+    assert torch.equal(a.cum, b.cum) and int(a.cum[1]) > 0
+    for x, y in zip(*outs):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v, ) or (torch.isnan(u) == torch.isnan(v)).all() and torch.equal(torch.nan_to_num(u), torch.nan_to_num(v))
