@@ -1260,6 +1260,11 @@ int hgl_register_split_weight(const float* w_fp32, int N, int K, int scale_log2,
   // per weight at model construction.
   unsigned nz = 1;
   {
+    // ONE device-global flag: reset, kernel and read-back of two registrations (two models built on two host threads /
+    // streams) must not interleave -- A's flag zeroed by B between A's kernel and A's read-back would record a genuine fp32
+    // weight as fp16-valued and silently drop its A_hi * W_lo products.  Serialised here (construction time only).
+    static std::mutex flag_mu;
+    std::lock_guard<std::mutex> flag_lk(flag_mu);
     const unsigned zero = 0;
     HGL_REQUIRE(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_lo_nonzero), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess,
                 "register_split_weight: flag reset failed");

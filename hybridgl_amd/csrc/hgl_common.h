@@ -71,7 +71,10 @@ __device__ __forceinline__ float hgl_gelu_erf(float x) {
   p = fmaf(p, t, 1.484753788e-01f);
   p = fmaf(p, t, 9.184176326e-01f);
   p = fmaf(p, t, 1.627908468e+00f);
-  const float q = __builtin_amdgcn_exp2f(-(p * t));   // erfc(t)
+  float q = __builtin_amdgcn_exp2f(-(p * t));   // erfc(t)
+  // beyond the clamp erfc(4) = 1.5e-8 would stay: on the negative side that is an error of 7.7e-9 |x| that grows without bound
+  // (x = -1e4 -> -7.7e-5 where nn.GELU gives -0); erfc(t) < 2^-24 for t > 4, so 0 is the correctly rounded factor there
+  q = fabsf(x) > 5.65685424949238f ? 0.f : q;
   return 0.5f * x * (x < 0.f ? q : 2.0f - q);
 }
 // QuickGELU (clip/model.py:198-200): x * sigmoid(1.702 x) with the hardware exponential and reciprocal (1 ulp each)

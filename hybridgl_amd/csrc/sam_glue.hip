@@ -377,7 +377,8 @@ __global__ __launch_bounds__(256) void pe_labeled_kernel(const float* __restrict
   if (i >= (long long)n * F) return;
   const int f = (int)(i % F);
   const int r = (int)(i / F);
-  const int lab = labels[r];
+  int lab = labels[r];
+  if (lab < -1 || lab > 3) lab = -1;   // labels outside [-1, 3] (prompt_encoder.py:73-86 knows no other) read as padding, never past the table
   const float* e = tab.e[lab + 1];
   float s = 0.f, c = 0.f;
   if (lab >= 0) {

@@ -51,7 +51,10 @@ class RefBatch:
     target: torch.Tensor       # [H,W] bool/uint8 ground truth
     sentences: List[Sentence] = field(default_factory=list)
     sam_resized: Optional[torch.Tensor] = None  # [h,w,3] uint8: sam_img after ResizeLongestSide (PIL, host)
-    image_id: Optional[int] = None  # COCO image id: consecutive refs of one image reuse proposals + hybrid features
+    image_id: Optional[int] = None  # COCO image id.  CONTRACT: items with the same image_id carry the same image tensors
+                                    # (sam_img, image_norm, tensor_img); with a mask generator their proposals, hybrid and GEM
+                                    # features are computed once per image (unit merging in run(), the image cache, step()'s
+                                    # one-entry cache).  With GIVEN proposals run() never merges items.
     tensor_img: Optional[torch.Tensor] = None   # [3,448,448] fp32: image['tensor_img'] = gem.get_gem_img_transform()(img)
     token_len: Optional[int] = None   # 1 + the largest EOT position of `tokens` (host knowledge of the tokenizer): the text
                                       # encoder then computes only that prefix of the 77 positions (exact: causal mask)
@@ -214,7 +217,8 @@ class HybridGLPipeline:
         # Per-image caching: the dataset yields one item per REF and the same image backs
         # several consecutive refs (Hybridgl_main.py:79); proposals, views and hybrid features depend on the
         # image only, so they are computed once per image.  Results are identical.
-        if ref.image_id is not None and getattr(self, "_cache_id", None) == ref.image_id:
+        from_gen = self.mask_generator is not None and self.use_sam_masks     # given proposals belong to the ITEM, not to the image
+        if from_gen and ref.image_id is not None and getattr(self, "_cache_id", None) == ref.image_id:
             hybrid = self._cache_hybrid
             ref = dataclasses.replace(self._cache_ref, tokens=ref.tokens, token_len=ref.token_len, sentences=ref.sentences,
                                       target=ref.target, index=ref.index)
@@ -243,7 +247,7 @@ class HybridGLPipeline:
             blurred = ref.blurred if ref.blurred is not None else ops.gaussian_blur_u8(ref.sam_img, 15)   # :99
             local, glob = ops.synthesize_views(ref.sam_img, blurred, ref.image_norm, ref.masks, self.res)
             hybrid = m(local, glob, ref.masks, masking_block=self.masking_block, fusion_mode=self.fusion_mode)
-            if ref.image_id is not None:
+            if from_gen and ref.image_id is not None:
                 self._cache_id, self._cache_ref, self._cache_hybrid = ref.image_id, ref, hybrid
         cur.wait_event(ev_text)
         return hybrid, text, self._score_ref(ref, hybrid, text, heat)
@@ -304,15 +308,17 @@ class HybridGLPipeline:
         return self._s_sam, self._s_clip
 
     @staticmethod
-    def _units(loader, group):
+    def _units(loader, group, merge=True):
         """Groups of up to `group` IMAGE UNITS in the loader's order; a unit = the consecutive items that share an
         image_id (the dataset yields one item per ref, Hybridgl_main.py:79; proposals, views and hybrid features depend on
-        the image only).  Items without an image_id are units of their own."""
+        the image only).  Items without an image_id are units of their own; merge=False makes every item its own unit
+        (proposals GIVEN per item: two items of one image may carry different masks / boxes, and a unit uses its first
+        item's)."""
         units, cur = [], None
         for ref in loader:
             if ref is None:      # an item the dataset filtered out entirely (PhraseCut seen / unseen modes)
                 continue
-            if cur is not None and ref.image_id is not None and ref.image_id == cur[0].image_id:
+            if merge and cur is not None and ref.image_id is not None and ref.image_id == cur[0].image_id:
                 cur.append(ref)
                 continue
             if cur is not None:
@@ -360,7 +366,9 @@ class HybridGLPipeline:
         done = 0
         pending = None
         self.groups_run = getattr(self, "groups_run", 0)
-        for units in self._units(loader, group):
+        # items of one image are merged into a unit only when the proposals come from the generator (then they are a function
+        # of the image); with given proposals every item keeps its own masks / boxes, as step() does
+        for units in self._units(loader, group, merge=gen is not None and self.use_sam_masks):
             self.groups_run += 1
             produced = None
             if not serial:      # items a lazy loader built on the caller's stream just now

@@ -274,6 +274,12 @@ def test_epilogue_activations_accuracy(cuda, path):
     ref = 0.5 * xd * special.erfc(-xd / np.sqrt(2.0))
     assert np.abs(y - ref).max() < 2e-7 * 9, np.abs(y - ref).max()
     assert (np.abs(y - ref) <= 2.5e-7 * np.maximum(1.0, np.abs(xd))).all()
+    # the negative tail: nn.GELU tends to -0, not to a multiple of x (erfc is clamped at t = 4 inside the fit)
+    far = np.zeros((n, n), dtype=np.float32)
+    far[0, :6] = [-10.0, -100.0, -1.0e4, -6.0, 10.0, 1.0e4]
+    yf = fn(T(far, cuda), T(eye, cuda), act="gelu").cpu().numpy()[0, :6].astype(np.float64)
+    assert (np.abs(yf[:3]) == 0).all() and abs(yf[3] - (-6.0 * 0.5 * special.erfc(6.0 / np.sqrt(2.0)))) < 5e-8, yf
+    assert yf[4] == 10.0 and yf[5] == 1.0e4
     q = fn(T(a, cuda), T(eye, cuda), act="quickgelu").cpu().numpy().astype(np.float64)
     qref = xd / (1.0 + np.exp(-1.702 * xd))
     big = np.abs(qref) > 1e-30

@@ -316,13 +316,13 @@ def test_phrasecut_configuration_at_full_size(cuda, full):
     assert r1.shape == (16, 6) and np.array_equal(r1, r2)
 
 
-def test_crop_layers_in_groups_equal_image_by_image(cuda):
+def test_crop_layers_in_groups_equal_image_by_image(cuda, models):
     """SamAutomaticMaskGenerator.crops_begin / crops_mid / crops_post / crops_finish (three host syncs per GROUP of images)
     against generate_device_crops (one per crop + two per image): identical masks, boxes, scores, for images of different
     sizes, with thresholds that decide."""
     from hybridgl_amd.sam import SamAutomaticMaskGenerator, sam_model_registry
     from hybridgl_amd.synth import synth_image
-    sam = sam_model_registry["tiny"](device=cuda)
+    sam = models[2].model      # the tiny SAM whose mask threshold leaves sparse masks: boxes differ, the NMS passes decide
     imgs = [torch.from_numpy(synth_image(h, w, 11 + i)).to(cuda) for i, (h, w) in enumerate(((150, 200), (200, 150), (120, 120)))]
     gen = SamAutomaticMaskGenerator(sam, points_per_side=6, points_per_batch=16, pred_iou_thresh=0.0, stability_score_thresh=0.0,
                                     crop_n_layers=1, crop_n_points_downscale_factor=2, min_mask_region_area=10)
