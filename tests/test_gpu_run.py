@@ -335,8 +335,8 @@ def test_crop_layers_in_groups_equal_image_by_image(cuda, models):
     assert len(grp) == 3 and sum(a[0].shape[0] for a in one) > 0 and 0 < one[0][0].shape[0] < probe[0].shape[0]
     for a, b in zip(one, grp):
         assert a[0].shape == b[0].shape
-        for x, y in zip(a[:4], b[:4]):
-            assert torch.equal(x, y)
+        for x, y in zip(a[:4], b[:4]):      # stability of an empty mask is 0 / 0: NaN in both
+            assert torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0)) if x.is_floating_point() else torch.equal(x, y)
     # an IoU threshold nothing passes: empty outputs of the right shapes, no failure
     gen.pred_iou_thresh = 1e9
     for (m, bx, iou, stab), im in zip(gen.generate_crops_group(imgs), imgs):
