@@ -112,3 +112,54 @@ def test_whole_ref_four_stream_fusion(cuda, world):
     torch.cuda.synchronize()
     _check_ref(g, "c0_G2L_L2G", c[2], pipe.last_proposals[0].bool().cpu().numpy(), pipe.last_proposals[1].cpu().numpy(),
                hyb.cpu().numpy(), pipe.winning_indices(), pipe.partial_rows()[:, 2:6])
+
+
+def test_whole_ref_across_the_gem_join_vs_oracle_chain(cuda):
+    """A whole ref with the heat-map COMPUTED, not given (Hybridgl_main.py:200-230): fixed-point blur -> views -> hybrid
+    forward -> text encoder (sentences, noun phrases, other nouns AND the GEM prompts in one batch) -> GEM image tower ->
+    heat-maps -> antialiased resize -> coherence -> scoring -> IoU on the device (HybridGLPipeline.step, fused tail) against
+    the same chain in the numpy oracle, stage into stage.  gem_torch is not installed offline, so the GEM stage's checker is
+    the restated published algorithm (oracle/gem_oracle.py: parity with the package unpinned); what this test pins is the
+    JOIN: which text rows become prompts, the map's orientation and resize, its way into the coherence scores."""
+    from hybridgl_amd import gem as G, weights
+    from hybridgl_amd.backbone import CLIPViTFM
+    from hybridgl_amd.pipeline import HybridGLPipeline, black_for, synthetic_ref
+    from oracle import clip_oracle as O, cv_oracle as CV, gem_oracle as GO
+    sd = weights.clip_state_dict("tiny", 0)
+    model = CLIPViTFM("tiny", state_dict=sd, device=cuda)
+    gm = G.create_gem_model("tiny", clip=model)
+    N, H, W, n_sent = 10, 96, 128, 3
+    checked = 0
+    for i in range(3):
+        ref, host = synthetic_ref(i, cuda, N=N, H=H, W=W, n_sent=n_sent, context=16, vocab=512, gem=True, gem_size=128, device_blur=True)
+        pipe = HybridGLPipeline(model, fusion_mode="G2L", masking_block=9, res=64, gem_model=gm)
+        hyb, text, (idx_last, sc, sn, gem_last) = pipe.step(ref)
+        torch.cuda.synchronize()
+        idx, rows = pipe.winning_indices(), pipe.partial_rows()
+        # ---- the oracle chain
+        blur = CV.gaussian_blur_u8(host["img"], 15)
+        loc, glo = O.synthesize_views(host["img"], blur, host["norm"], host["masks"], 64)
+        hyb_ref = O.clip_hybrid_forward(sd, loc, glo, host["masks"], 9, "G2L", 10)
+        text_ref = O.encode_text(sd, host["tokens"], heads=1)
+        np.testing.assert_allclose(hyb.cpu().numpy(), hyb_ref, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(text.cpu().numpy(), text_ref, rtol=0, atol=1e-4)
+        feat, _ = GO.gem_vit_forward(sd, host["tensor_img"][None])
+        maps = GO.resize_bilinear_aa(GO.gem_heatmap(feat[0], text_ref[3 * n_sent:4 * n_sent], 128), H, W)
+        for j, s in enumerate(ref.sentences):
+            gem_ref = O.coherence_scores(maps[j], host["masks"], s.dirflag, black_for(s.relaflag))
+            if j == n_sent - 1:
+                np.testing.assert_allclose(gem_last.cpu().numpy(), gem_ref, rtol=0, atol=2e-3)
+            t_pos = 0.5 * text_ref[3 * j:3 * j + 1] + 0.5 * text_ref[3 * j + 1:3 * j + 2]
+            ip, ifin, sc_ref, _ = O.score_sentence(hyb_ref, t_pos, text_ref[3 * j + 2:3 * j + 3], host["boxes"], gem_ref, 100.0, 3, 6, 0.6,
+                                                   s.relaflag, s.n_nouns != 0)
+            # the pure-CLIP decision is checked when the oracle's own margin is clear of the 1e-3 logit tolerance
+            top2 = np.sort(np.asarray(sc_ref).reshape(-1))[-2:]
+            if top2[1] - top2[0] > 5e-3:
+                assert idx[j, 0] == ip
+                I, U = O.compute_iou(host["masks"][ip], host["gt"])
+                assert (int(rows[j, 2]), int(rows[j, 3])) == (int(I), int(U))
+                checked += 1
+            if idx[j, 1] == ifin:
+                I, U = O.compute_iou(host["masks"][ifin], host["gt"])
+                assert (int(rows[j, 4]), int(rows[j, 5])) == (int(I), int(U))
+    assert checked >= 5

@@ -13,6 +13,8 @@ iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 dev = torch.device("cuda:0")
 A = torch.randn(M, K, device=dev)
 W = torch.randn(N, K, device=dev) / K ** 0.5
+if os.environ.get("X3_FP16_VALUED_W", "0") == "1":     # what an OpenAI CLIP archive holds: W_lo == 0 -> the NT = 2 instantiation
+    W = W.half().float()
 b = torch.randn(N, device=dev)
 out = torch.empty(M, N, device=dev)
 for _ in range(iters):
