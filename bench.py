@@ -230,6 +230,57 @@ def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False, clip_na
                       f"3-sentence tail on 64 masks ({t4 - t3:.1f}s){gem_note}{sam_note}; numpy BLAS threads = host default"}
 
 
+def live_pmc_traffic(prefix, timeout_s=150.0):
+    """HBM bytes per launch of the kernels whose name starts with `prefix`, measured NOW: two child processes
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only, as MI355X_MICROARCH.md prescribes) over
+    tools/group_profile.py (the headline's loop: two serial groups of 16 refs, same models and shapes), corrected as that
+    guide says (KB units x1024, FETCH_SIZE x2 on gfx950), launch-weighted over the template instantiations.  Returns
+    (bytes per launch, description) or (None, why not)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from profile_summary import short
+    out = tempfile.mkdtemp(prefix="hgl_pmc_")
+    try:
+        sums = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, ctr)
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                                sys.executable, os.path.join(ROOT, "tools", "group_profile.py"), "1", "16"],
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} exited {r.returncode}"
+            acc = collections.defaultdict(lambda: [0, 0.0])
+            for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if row["Counter_Name"] == ctr:
+                        k = short(row["Kernel_Name"])
+                        acc[k][0] += 1
+                        acc[k][1] += float(row["Counter_Value"])
+            sums[ctr] = acc
+        n = sum(v[0] for k, v in sums["FETCH_SIZE"].items() if k.startswith(prefix))
+        if n == 0:
+            return None, f"no launch of {prefix} in the counter pass"
+        fetch = 2.0 * 1024.0 * sum(v[1] for k, v in sums["FETCH_SIZE"].items() if k.startswith(prefix)) / n
+        nw = max(sum(v[0] for k, v in sums["WRITE_SIZE"].items() if k.startswith(prefix)), 1)
+        write = 1024.0 * sum(v[1] for k, v in sums["WRITE_SIZE"].items() if k.startswith(prefix)) / nw
+        return fetch + write, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child processes) over "
+                               f"tools/group_profile.py 1 16, {n} launches of {prefix}...>, FETCH x2 x1024 + WRITE x1024 bytes per launch "
+                               f"(fetch {fetch / 1e9:.3f} GB + write {write / 1e9:.3f} GB)")
+    except Exception as e:
+        return None, repr(e)[:200]
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def evaluator_from_disk(args, model, gen, gem_model, dev, group, n_images=208, keep_root=None, host_cores=None):
     """`python -m hybridgl_amd.main --real` on a synthetic REFER tree written to local disk (hybridgl_amd.synth.write_refer_tree:
     COCO-sized JPEGs of 8 sizes, 2-3 refs per image, 3 sentences per ref, polygon ground truth, parse records, a BPE merges
@@ -361,6 +412,9 @@ def main():
     ap.add_argument("--no-also", action="store_true",
                     help="skip the short secondary timings (seeded masks, L2G, G2L&L2G, strict fp32, ViT-L/14, PhraseCut) that are "
                          "attached under the `also` key at N = 1")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="N = 1: do not measure roofline.traffic in this run (two rocprofv3 --pmc child processes, ~1 min); replay "
+                         "profiles/pmc_traffic.json instead")
     ap.add_argument("--no-rccl-check", action="store_true",
                     help="N = 1: skip the RCCL self-check (nccl backend in a world of one, the timed steps' metric rows through it)")
     ap.add_argument("--no-disk", action="store_true", help="skip also['evaluator_from_disk'] (the evaluator fed from a REFER tree on disk)")
@@ -611,7 +665,17 @@ def main():
             tpath = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(tpath):
                 break
-        if os.path.exists(tpath):
+        live = None
+        if world == 1 and not args.no_live_pmc:
+            if precision == "f16x3":
+                live_prefix = "gemm_x3p_kernel<" if xg_ms > x_ms else "gemm_f16x3_kernel<"
+            else:
+                live_prefix = "gemm_f32_kernel<"
+            torch.cuda.empty_cache()      # the child processes build their own models on this GPU
+            live = live_pmc_traffic(live_prefix)
+        if live is not None and live[0] is not None:
+            traffic, traffic_src = live
+        elif os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 # launch-weighted mean over the template instantiations of the dominant kernel
@@ -627,7 +691,8 @@ def main():
                         den += n_l
                 traffic = num / den if den > 0 else None
                 traffic_src = (f"profiles/{os.path.basename(tpath)}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
-                               "command on an earlier box (tools/profile_round.sh), replayed here -- not measured in this run")
+                               "command on an earlier box (tools/profile_round.sh), replayed here -- not measured in this run"
+                               + (f" (live counter pass unavailable: {live[1]})" if live is not None else ""))
             except Exception:
                 traffic = None
         workload = (f"RefCOCO-shaped ref (BASELINE configs[1]): 640x640 image, 3 queries x (sentence+noun phrase+1 other noun); "

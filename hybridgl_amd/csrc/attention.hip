@@ -317,6 +317,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
   const float* kp = a.k + b * a.skb + hh * HD;
   const float* vp = a.v + b * a.svb + hh * HD;
 
+  // chunk 0 of K / V is requested FIRST: its round trip overlaps the Q loads, the Q split and the rel-pos table products
+  f32x4 pk[NLK], pv[NLV];
+#pragma unroll
+  for (int i = 0; i < NLK; ++i) {
+    const int idx = t + NT * i;
+    if (!EXACT && idx >= KV_CHUNK * F4) break;
+    const int row = idx / F4, c4 = idx - row * F4;
+    pk[i] = *(const f32x4*)(kp + (long long)min(row, a.Sk - 1) * a.ldk + c4 * 4);
+    pv[i] = *(const f32x4*)(vp + (long long)min(row, a.Sk - 1) * a.ldv + c4 * 4);
+  }
   // Q fragments (pre-scaled in fp32, then split -- through hgl_split_hi_lo, see its comment: this product is where
   // the inconsistent-rounding problem was found): lane (r,h) element j of step s = Q[q][16s + 8h + j].
   // The scores are moved to log2 units AFTER the QK^T product (one multiply per score) so that the softmax is one
@@ -326,11 +336,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
   const float qscale = a.scale;
   float amax = 0.f;   // of the Q / K / V values this thread splits (fp16 range guard, hgl_common.h)
   h16x8 qh[KS], ql[KS];
+  // ALL of the query's raw fragments are requested before the first one is split: hgl_split_hi_lo's opaque asm keeps the
+  // compiler from moving a load across it, so `load; split; load; split ...` compiled to one global round trip PER
+  // 16-byte piece (10 here, 10 more for the unscaled copy, 20 for the rel-pos tables: 40 serial memory latencies at the
+  // head of every 196-token item -- 56 % of the windowed kernel's wave cycles were spent waiting, tools/isa_serial_loads.py)
+  f32x4 qraw[KS][2];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+      qraw[s][half] = *(const f32x4*)(qp + 16 * s + 8 * h + 4 * half);   // qp is clamped to a valid row: unconditional, no branch
+  __builtin_amdgcn_sched_barrier(0);
+  if (!qvalid) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qraw[s][0] = qraw[s][1] = f32x4{0, 0, 0, 0};
+  }
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      f32x4 v = qvalid ? *(const f32x4*)(qp + 16 * s + 8 * h + 4 * half) : f32x4{0, 0, 0, 0};
+      const f32x4 v = qraw[s][half];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float x = v[e] * qscale;
@@ -371,7 +396,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
         for (int sx = 0; sx < KS; ++sx) {
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
-            const f32x4 v = qvalid ? *(const f32x4*)(qp + 16 * sx + 8 * h + 4 * half) : f32x4{0, 0, 0, 0};
+            const f32x4 v = qraw[sx][half];      // the same registers as the scaled fragments: no second fetch
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               _Float16 hi, lo;
@@ -388,13 +413,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
           f32x16 acc;
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+          f32x4 traw[KS][2];       // the axis' table fragments in one batch of loads (see the Q fragments)
+#pragma unroll
+          for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              traw[sx][half] = *(const f32x4*)(Rt + (long long)min(r, 2 * RELW - 2) * HD + 16 * sx + 8 * h + 4 * half);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          if (r >= 2 * RELW - 1) {
+#pragma unroll
+            for (int sx = 0; sx < KS; ++sx) traw[sx][0] = traw[sx][1] = f32x4{0, 0, 0, 0};
+          }
 #pragma unroll
           for (int sx = 0; sx < KS; ++sx) {
             h16x8 th, tl;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-              f32x4 v = {0, 0, 0, 0};
-              if (r < 2 * RELW - 1) v = *(const f32x4*)(Rt + (long long)r * HD + 16 * sx + 8 * h + 4 * half);
+              const f32x4 v = traw[sx][half];
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 _Float16 hi, lo;
@@ -451,7 +487,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
   }
 
   // ---- staging (software pipelined through registers) ----
-  f32x4 pk[NLK], pv[NLV];
   auto load_chunk = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < NLK; ++i) {
@@ -509,8 +544,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
   // transposed-read addressing: lane = 16*grp + 4*q + p supplies row q, columns 4p..4p+3 of its group's block;
   // groups 0/1 carry d columns 0-15 / 16-31 for h = 0, groups 2/3 the same for h = 1
   const int tr_off = (((lane >> 2) & 3) + 4 * h) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  load_chunk(0);
-  store_chunk(0);
+  store_chunk(0);      // chunk 0 was requested at the top of the kernel
   __syncthreads();
 
   for (int kc = 0; kc < sk_eff; kc += KV_CHUNK) {
@@ -720,11 +754,22 @@ __global__ __launch_bounds__(256, 2) void attn_x3q_kernel(AttnArgs a) {
     qvalid[qt] = qi[qt] < a.Sq;
     tile_active[qt] = q0 < a.Sq;
     const float* qp = a.q + b * a.sqb + (long long)(qvalid[qt] ? qi[qt] : 0) * a.ldq + hh * HD;
+    f32x4 qraw[KS][2];      // one batch of loads, then the splits (see attn_x3_kernel: a split right behind its load serialises them)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+        qraw[s][half] = *(const f32x4*)(qp + 16 * s + 8 * h + 4 * half);     // qp is clamped to a valid row
+    __builtin_amdgcn_sched_barrier(0);
+    if (!qvalid[qt]) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) qraw[s][0] = qraw[s][1] = f32x4{0, 0, 0, 0};
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        const f32x4 v = qvalid[qt] ? *(const f32x4*)(qp + 16 * s + 8 * h + 4 * half) : f32x4{0, 0, 0, 0};
+        const f32x4 v = qraw[s][half];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           _Float16 hi, lo;
@@ -1124,13 +1169,24 @@ __global__ __launch_bounds__(512, 1) void attn_x3w_kernel(AttnArgs a) {
           f32x16 acc;
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+          f32x4 traw[KS][2];       // the axis' table fragments in one batch of loads (see the Q fragments)
+#pragma unroll
+          for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              traw[sx][half] = *(const f32x4*)(Rt + (long long)min(r, 2 * RELW - 2) * HD + 16 * sx + 8 * h + 4 * half);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          if (r >= 2 * RELW - 1) {
+#pragma unroll
+            for (int sx = 0; sx < KS; ++sx) traw[sx][0] = traw[sx][1] = f32x4{0, 0, 0, 0};
+          }
 #pragma unroll
           for (int sx = 0; sx < KS; ++sx) {
             h16x8 th, tl;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-              f32x4 v = {0, 0, 0, 0};
-              if (r < 2 * RELW - 1) v = *(const f32x4*)(Rt + (long long)r * HD + 16 * sx + 8 * h + 4 * half);
+              const f32x4 v = traw[sx][half];
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 _Float16 hi, lo;

@@ -814,14 +814,19 @@ __global__ __launch_bounds__(256) void gemm_x3_skinny_kernel(SkinnyArgs g) {
   const int col = col0 + r;
   if (col >= g.N) return;
   const float bv = g.bias ? g.bias[col] : 0.0f;
+  // the 16 residual values in one batch of loads (a load behind `if (row < M)` inside the store loop is waited for before
+  // the next one is issued: 16 serial round trips per tile)
+  float rv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+  if (g.R) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) rv[e] = g.R[(long long)min(row0 + (e & 3) + 8 * (e >> 2) + 4 * h, g.M - 1) * g.ldr + col];
+  }
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-    if (row < g.M) {
-      float v = act_apply<ACT>(acc[e] * g.out_scale + bv);
-      if (g.R) v += g.R[(long long)row * g.ldr + col];
-      g.C[(long long)row * g.ldc + col] = v;
-    }
+    if (row < g.M) g.C[(long long)row * g.ldc + col] = act_apply<ACT>(acc[e] * g.out_scale + bv) + rv[e];
   }
 }
 

@@ -206,11 +206,23 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const float* __restric
   const bool qvalid = q < S;
   const float* qp = qkv + ((long long)b * S + (qvalid ? q : 0)) * ldq + hh * HD;
   rp_h8 qh[KS], ql[KS];
+  // one batch of loads, then the splits: a split right behind its load (hgl_split_hi_lo's opaque asm) is one serial memory
+  // round trip per 16-byte piece
+  f32x4 qraw[KS][2];
+#pragma unroll
+  for (int c = 0; c < KS; ++c)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) qraw[c][half] = *(const f32x4*)(qp + 16 * c + 8 * h + 4 * half);   // qp: clamped row
+  __builtin_amdgcn_sched_barrier(0);
+  if (!qvalid) {
+#pragma unroll
+    for (int c = 0; c < KS; ++c) qraw[c][0] = qraw[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int c = 0; c < KS; ++c) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      const f32x4 v = qvalid ? *(const f32x4*)(qp + 16 * c + 8 * h + 4 * half) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 v = qraw[c][half];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         _Float16 h0, l0;

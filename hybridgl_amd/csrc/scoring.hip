@@ -120,13 +120,25 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(const float* __restric
   float v[PX_LANE];
   double tot = 0.0;
   const bool inb = p0 + PX_LANE <= HW;
+  // the lane's 16 heat-map values as four 16-byte loads issued together (sixteen conditional scalar loads compiled to
+  // sixteen serial round trips: tools/isa_serial_loads.py)
+  float raw[PX_LANE];
+  if (inb && ((((uintptr_t)(attn + p0)) & 15) == 0)) {
+    const f32x4 r0 = *(const f32x4*)(attn + p0), r1 = *(const f32x4*)(attn + p0 + 4);
+    const f32x4 r2 = *(const f32x4*)(attn + p0 + 8), r3 = *(const f32x4*)(attn + p0 + 12);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { raw[e] = r0[e]; raw[4 + e] = r1[e]; raw[8 + e] = r2[e]; raw[12 + e] = r3[e]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < PX_LANE; ++e) raw[e] = attn[min(p0 + e, HW - 1)];
+  }
 #pragma unroll
   for (int e = 0; e < PX_LANE; ++e) {
     const long long p = p0 + e;
     float val = 0.f;
     if (p < HW) {
       const int x = (int)(p % W);
-      val = ((attn[p] - mn) / range) * dir_weight(dirflag, x, W);
+      val = ((raw[e] - mn) / range) * dir_weight(dirflag, x, W);
     }
     v[e] = val;
     tot += (double)val;
@@ -562,13 +574,23 @@ __global__ __launch_bounds__(256) void ref_masked_pool_kernel(RefSentences rs, i
         const float* attn = rs.attn[s0 + j];
         const int dirflag = rs.dirflag[s0 + j];
         double tot = 0.0;
+        float raw[PX_LANE];      // four 16-byte loads issued together (see masked_pool_kernel)
+        if (inb && ((((uintptr_t)(attn + p0)) & 15) == 0)) {
+          const f32x4 r0 = *(const f32x4*)(attn + p0), r1 = *(const f32x4*)(attn + p0 + 4);
+          const f32x4 r2 = *(const f32x4*)(attn + p0 + 8), r3 = *(const f32x4*)(attn + p0 + 12);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { raw[e] = r0[e]; raw[4 + e] = r1[e]; raw[8 + e] = r2[e]; raw[12 + e] = r3[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < PX_LANE; ++e) raw[e] = attn[min(p0 + e, HW - 1)];
+        }
 #pragma unroll
         for (int e = 0; e < PX_LANE; ++e) {
           const long long p = p0 + e;
           float val = 0.f;
           if (p < HW) {
             const int x = (int)(p % W);
-            val = ((attn[p] - mn) / range) * dir_weight(dirflag, x, W);
+            val = ((raw[e] - mn) / range) * dir_weight(dirflag, x, W);
           }
           v[j][e] = val;
           tot += (double)val;
@@ -582,12 +604,27 @@ __global__ __launch_bounds__(256) void ref_masked_pool_kernel(RefSentences rs, i
         for (int e = 0; e < PX_LANE; ++e) v[j][e] = 0.f;
       }
     }
-    for (int n = n0; n < n1; ++n) {
+    // all the group's mask words requested up front (eight independent 16-byte loads in flight per lane), then consumed
+    const bool fast = inb && ((HW & 15) == 0) && ((((uintptr_t)masks) & 15) == 0);     // every plane's piece is 16-byte aligned
+    uint4 mv[MASK_GROUP];
+    if (fast) {
+#pragma unroll
+      for (int i = 0; i < MASK_GROUP; ++i)
+        mv[i] = *(const uint4*)(masks + (long long)min(n0 + i, N - 1) * HW + p0);
+    }
+#pragma unroll
+    for (int i = 0; i < MASK_GROUP; ++i) {
+      const int n = n0 + i;
+      if (n >= n1) break;
       const uint8_t* m = masks + (long long)n * HW + p0;
       bool on[PX_LANE];
-      if (inb && (((uintptr_t)m) & 15) == 0) {
-        const uint4 mv = *(const uint4*)m;
-        const unsigned w4[4] = {mv.x, mv.y, mv.z, mv.w};
+      if (fast) {
+        const unsigned w4[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
+#pragma unroll
+        for (int e = 0; e < PX_LANE; ++e) on[e] = ((w4[e >> 2] >> (8 * (e & 3))) & 0xff) != 0;
+      } else if (inb && (((uintptr_t)m) & 15) == 0) {
+        const uint4 mw = *(const uint4*)m;
+        const unsigned w4[4] = {mw.x, mw.y, mw.z, mw.w};
 #pragma unroll
         for (int e = 0; e < PX_LANE; ++e) on[e] = ((w4[e >> 2] >> (8 * (e & 3))) & 0xff) != 0;
       } else {

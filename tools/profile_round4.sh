@@ -11,9 +11,9 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/${tag}_bench_default.json 2> $O/${tag}_bench_default.err
 tail -c 400 $O/${tag}_bench_default.json | head -c 200; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats_serial -o p -- python3 $R/tools/group_profile.py 3 16 > $O/${tag}_stats_serial.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats -o p -- python3 $R/bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-also --no-disk --no-rccl-check > $O/${tag}_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_fetch -o p -- python3 $R/bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-also --no-disk --no-rccl-check > $O/${tag}_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_write -o p -- python3 $R/bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-also --no-disk --no-rccl-check > $O/${tag}_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats -o p -- python3 $R/bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-also --no-disk --no-rccl-check --no-live-pmc > $O/${tag}_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_fetch -o p -- python3 $R/bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-also --no-disk --no-rccl-check --no-live-pmc > $O/${tag}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_write -o p -- python3 $R/bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-also --no-disk --no-rccl-check --no-live-pmc > $O/${tag}_write.log 2>&1
 for f in $O/${tag}_stats_serial; do
   s=$(find $f -name "*kernel_stats.csv" | head -1); [ -n "$s" ] && cp $s $O/${tag}_serial_group_kernel_stats.csv
 done
