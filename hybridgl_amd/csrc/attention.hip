@@ -546,6 +546,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
   const int tr_off = (((lane >> 2) & 3) + 4 * h) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   store_chunk(0);      // chunk 0 was requested at the top of the kernel
   __syncthreads();
+  // Decomposed rel-pos terms given as tensors (SAM's global blocks: 64 x 64 keys): the 17 values a lane adds to the scores
+  // of a key tile are fetched ONE TILE AHEAD.  Requested behind the tile's QK^T products and used at once they cost a
+  // full memory round trip per 32 keys (the tables of a group of images are 2 x 268 MB: L2 misses), with nothing of the
+  // wave's own work beside it.
+  const bool relfast = RELW == 0 && relh != nullptr && (a.kw & 31) == 0;
+  float rh_next = 0.f;
+  f32x4 rw_next[4];
+  // uniform base + 32-bit lane offset (a 64-bit per-lane pointer kept across the tile spilled, and its reload waited for
+  // the loads just issued): (batch * head, query) rows of kh / kw floats -- 268 MB per tensor at sixteen images, < 2^32 bytes
+  const unsigned relh_off = (unsigned)(((long long)bh * a.Sq + (qvalid ? qi : 0)) * a.kh);
+  const unsigned relw_off = (unsigned)(((long long)bh * a.Sq + (qvalid ? qi : 0)) * a.kw) + 4u * h;
+  auto rel_prefetch = [&](int kb) {
+    kb = min(kb, a.Sk - 32);
+    rh_next = a.rel_h[relh_off + (unsigned)(kb / a.kw)];
+    const unsigned o = relw_off + (unsigned)(kb % a.kw);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) rw_next[g4] = *(const f32x4*)(a.rel_w + o + 8 * g4);
+  };
+  if (relfast && wave_active) rel_prefetch(0);
 
   for (int kc = 0; kc < sk_eff; kc += KV_CHUNK) {
     const bool has_next = kc + KV_CHUNK < sk_eff;
@@ -555,8 +574,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
       const int kbase = kc + kt * 32;
       if (kbase >= sk_eff || !wave_active) break;  // uniform
       f32x16 s;
+      if (relfast) {     // the score accumulators START at the rel-pos terms (fetched during the previous tile's P V products)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        for (int e = 0; e < 16; ++e) s[e] = rh_next + rw_next[e >> 2][e & 3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+      }
       const _Float16* krow = Ks + (kt * 32 + r) * KROW + 8 * h;
 #pragma unroll
       for (int c = 0; c < KS; ++c) {
@@ -580,14 +604,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
         // bias already accumulated by the MFMAs above
       } else if (relh) {
         if ((a.kw & 31) == 0) {
-          const float rh = relh[kbase / a.kw];
-          const float* rw = relw + (kbase % a.kw) + 4 * h;
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 w4 = *(const f32x4*)(rw + 8 * g4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s[4 * g4 + i] += rh + w4[i];
-          }
+          // already in the accumulators (see the tile's start)
         } else {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
@@ -647,6 +664,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
         pl[e >> 3][(e & 7) + 1] = (_Float16)(p1 - (float)hi2[1]);
       }
       l_run += rs;
+      // the scores are dead from here on: the next tile's rel-pos terms are requested now and travel under the P V products
+      if (relfast) rel_prefetch(kbase + 32);
       // O^T += V^T P^T ; A operand element j of lane (d, h) = V^T[d][kt*32 + 16*s2 + 8*(j>>2) + 4*h + (j&3)]
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {

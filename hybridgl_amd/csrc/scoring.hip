@@ -730,14 +730,20 @@ __global__ __launch_bounds__(256) void ref_iou_kernel(RefSentences rs, int S, co
     I += __shfl_xor(I, o);
     U += __shfl_xor(U, o);
   }
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&iu_all[4 * s + 2 * which], (unsigned long long)I);
-    atomicAdd(&iu_all[4 * s + 2 * which + 1], (unsigned long long)U);
-  }
-  __threadfence();
-  __syncthreads();
+  // one pair of atomics per BLOCK (thousands of 64-bit atomics on two dozen addresses serialise in L2: 68 us for six IoUs)
+  __shared__ unsigned sI[4], sU[4];
   __shared__ int last;
-  if (threadIdx.x == 0) last = atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1;
+  if ((threadIdx.x & 63) == 0) {
+    sI[threadIdx.x >> 6] = I;
+    sU[threadIdx.x >> 6] = U;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&iu_all[4 * s + 2 * which], (unsigned long long)((sI[0] + sI[1]) + (sI[2] + sI[3])));
+    atomicAdd(&iu_all[4 * s + 2 * which + 1], (unsigned long long)((sU[0] + sU[1]) + (sU[2] + sU[3])));
+    __threadfence();
+    last = atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1;
+  }
   __syncthreads();
   if (last && cum != nullptr && threadIdx.x < 4) {
     unsigned long long a = 0;
@@ -1069,9 +1075,9 @@ int hgl_score_ref(const float* hybrid, const float* text, int T, const int64_t* 
     hipLaunchKernelGGL(ref_score_kernel, dim3(sc), dim3(256), 0, st, rs, hybrid, text, (const long long*)boxes, N, E, H, W, logit_scale,
                        r, k1, k2, alpha, psum, pcnt, ptot, nparts, gem, clip, neg, soft, (int*)idx + 2 * s0,
                        (unsigned long long*)iu + 4 * s0, done);
-    long long blocks = (HW / 16 + 255) / 256;
+    long long blocks = (HW / 16 + 1023) / 1024;      // four 16-byte words per thread
     if (blocks < 1) blocks = 1;
-    if (blocks > 128) blocks = 128;
+    if (blocks > 32) blocks = 32;
     hipLaunchKernelGGL(ref_iou_kernel, dim3((unsigned)blocks, 2 * sc), dim3(256), 0, st, rs, sc, masks, HW, (const int*)idx + 2 * s0,
                        (unsigned long long*)iu + 4 * s0, (unsigned long long*)cum, done);
   }
