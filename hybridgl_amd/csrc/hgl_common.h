@@ -237,6 +237,7 @@ int hgl_launch_dec_i2t(const float* q, int ldq, long long q_bstride, const float
 // split-fp16 GEMM path (gemm_f16x3.hip)
 int hgl_precision();
 bool hgl_has_split_weight(const float* W);
+bool hgl_get_split_weight(const float* W, const void** hi, const void** lo, int* scale_log2, int* N, int* K);
 int hgl_launch_split_f16(const float* x, float scale, void* hi, void* lo, long long n, hipStream_t st);
 int hgl_launch_layernorm_split(const float* x, const float* w, const float* b, void* hi, void* lo, int rows, int D,
                                float eps, hipStream_t st);

@@ -59,10 +59,11 @@ def gemm(a, w, bias=None, residual=None, act="none", out=None):
 _split_cache = {}  # fp32 weight data_ptr -> (weight, hi, lo): keeps the registered halves alive while a model owns them
 
 
-def register_split_weight(w):
+def register_split_weight(w, scale_log2=None):
     """Register the fp16 hi/lo split of a [N,K] fp32 weight for the HGL_PREC_F16X3 GEMM path.
-    The power-of-two scale puts max|w| at <= 2^14 (lo halves stay normal fp16).  Returns the registry key; the owner
-    hands its keys to release_split_weights when it dies (the models do that through weakref.finalize)."""
+    The power-of-two scale puts max|w| at <= 2^14 (lo halves stay normal fp16); scale_log2=0 registers the UNSCALED split (the
+    values a kernel's own hgl_split_hi_lo gives: SAM's rel-pos tables for the windowed attention).  Returns the registry key;
+    the owner hands its keys to release_split_weights when it dies (the models do that through weakref.finalize)."""
     import math
     lib = _lib.load()
     key = w.data_ptr()
@@ -71,6 +72,8 @@ def register_split_weight(w):
     N, K = w.shape
     amax = float(w.abs().max().item())
     s = 0 if amax == 0 else max(-24, min(24, 14 - math.ceil(math.log2(amax))))
+    if scale_log2 is not None:
+        s = int(scale_log2)
     hi = torch.empty((N, K), dtype=torch.float16, device=w.device)
     lo = torch.empty((N, K), dtype=torch.float16, device=w.device)
     check(lib.hgl_register_split_weight(_dev(w, torch.float32, "w"), N, K, s, hi.data_ptr(), lo.data_ptr(),

@@ -75,6 +75,10 @@ class Sam:
                 setattr(b, f, t(sd[f"{p}.{k}"]))
                 if precision == "f16x3" and f in ("qkv_w", "proj_w", "lin1_w", "lin2_w"):
                     ops.register_split_weight(self._t[-1])
+                if precision == "f16x3" and f in ("rel_pos_h", "rel_pos_w") and b.window == 14 and self._t[-1].shape == (27, 80):
+                    # the windowed attention multiplies with these tables on the matrix cores: split once here (unscaled)
+                    # instead of per wave and item in the kernel
+                    ops.register_split_weight(self._t[-1], scale_log2=0)
         enc = HglSamEncoderW()
         enc.embed_dim, enc.depth, enc.heads, enc.img_size, enc.patch, enc.out_chans = D, L, H, S, ps, Cc
         enc.patch_w = t(np.asarray(sd[f"{e}.patch_embed.proj.weight"]).reshape(D, -1))
