@@ -765,6 +765,318 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_x3_kernel(AttnA
 }
 
 // ---------------------------------------------------------------------------------------------
+// PING-PONG variant for long sequences without a mask (SAM's global blocks: 4096 x 4096 keys with the rel-pos terms given
+// as tensors; GEM's 785-token self-self attention).  Counters of attn_x3_kernel on the global blocks
+// (profiles/r04c_sq_counters_attn_x3_global_4096x80.json): matrix pipe busy 37 % of the cycles, VALU issue 42 %, and only 22 %
+// of the matrix-busy cycles had a vector instruction executing beside them -- the two waves of a SIMD ran the same phase
+// at the same time (two independent 4-wave workgroups drift into lock-step at the chunk barriers), so the soft-max of
+// one never filled the issue gaps of the other's MFMAs.  Here ONE 8-wave workgroup (256 queries) is two groups of four
+// waves, one wave of each per SIMD, that run ONE BARRIER INTERVAL APART (the schedule of gemm_x3p_kernel):
+//
+//     interval   2t          2t+1            2t+2           2t+3
+//     group A    M(t)        V(t)            M(t+1)         V(t+1)          M(t) = P V of tile t-1, then Q K^T of tile t
+//     group B    V(t-1)      M(t)            V(t)           M(t+1)          V(t) = soft-max of tile t (+ staging duty)
+//
+// so that in every interval one wave of a SIMD issues matrix instructions and the other vector instructions.  K / V chunks
+// of 64 keys are double-buffered in LDS; chunk c is written by group B in interval 4c-2 and by group A in interval 4c-1
+// (each thread its own pieces, fetched four intervals earlier), after the last reader of the buffer's previous chunk
+// (group B's P V of tile 2c-3, interval 4c-3) and before its first reader (group A's Q K^T of tile 2c, interval 4c).
+// The arithmetic of a (query tile, key tile) pair is attn_x3_kernel's, instruction for instruction: identical results.
+template <int HD>
+__global__ __launch_bounds__(512, 1) void attn_x3pp_kernel(AttnArgs a) {
+  constexpr int NT = 512;
+  constexpr int KS = HD / 16;
+  constexpr int KROW = 2 * HD + 8;
+  constexpr int DT = (HD + 31) / 32;
+  constexpr int VP = HD <= 32 ? 32 : 96;
+  constexpr int F4 = HD / 4;
+  constexpr int HALF = KV_CHUNK * F4;            // float4 pieces of K (and of V) per chunk
+  constexpr int NP = 2 * HALF / NT;              // pieces per thread and chunk
+  static_assert(2 * HALF % NT == 0 && HD % 16 == 0, "unsupported head dim");
+  constexpr int KBUF = KV_CHUNK * KROW, VBUF = KV_CHUNK * VP;
+  extern __shared__ __attribute__((aligned(16))) _Float16 pp_smem[];
+  _Float16* const Ks = pp_smem;                  // [2][KBUF]
+  _Float16* const Vh = Ks + 2 * KBUF;            // [2][VBUF]
+  _Float16* const Vl = Vh + 2 * VBUF;            // [2][VBUF]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2;
+  const int r = lane & 31, h = lane >> 5;
+  int bx = blockIdx.x, bh = blockIdx.y;
+  if (gridDim.x > 1 && (gridDim.y & 7) == 0) {   // an XCD works through whole heads (see attn_x3_kernel)
+    const unsigned G = gridDim.x, L = blockIdx.y * G + blockIdx.x;
+    const unsigned c = L & 7, j = L >> 3;
+    bh = (int)((j / G) * 8 + c);
+    bx = (int)(j % G);
+  }
+  const int b = bh / a.H, hh = bh - b * a.H;
+  const int q0 = (bx * 8 + wave) * 32;
+  const int qi = q0 + r;
+  const bool qvalid = qi < a.Sq;
+  const bool wave_active = q0 < a.Sq;
+  const float* qp = a.q + b * a.sqb + (long long)(qvalid ? qi : 0) * a.ldq + hh * HD;
+  const float* kp = a.k + b * a.skb + hh * HD;
+  const float* vp = a.v + b * a.svb + hh * HD;
+  const int ntile = (a.Sk + 31) / 32, nchunk = (a.Sk + KV_CHUNK - 1) / KV_CHUNK;
+
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float sl2e = a.scale * LOG2E;
+  const float inv_scale = 1.0f / a.scale;
+  const float rescale_thr = 5.5f * inv_scale;
+  float amax = 0.f;
+
+  // ---- staging pieces of this thread: piece p = t + NT * i; p < HALF: K row p / F4, else V ----
+  f32x4 pc[NP];
+  auto load_pieces = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = t + NT * i;
+      const int q = p < HALF ? p : p - HALF;
+      const int row = q / F4, c4 = q - row * F4;
+      const long long gr = min(c * KV_CHUNK + row, a.Sk - 1);
+      pc[i] = p < HALF ? *(const f32x4*)(kp + gr * a.ldk + c4 * 4) : *(const f32x4*)(vp + gr * a.ldv + c4 * 4);
+    }
+  };
+  auto store_pieces = [&](int c) {
+    const int buf = c & 1;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int p = t + NT * i;
+      const int q = p < HALF ? p : p - HALF;
+      const int row = q / F4, c4 = q - row * F4;
+      h16x4 hi, lo;
+      split4(pc[i], hi, lo, amax);
+      if (p < HALF) {
+        *(h16x4*)(Ks + buf * KBUF + row * KROW + c4 * 4) = hi;
+        *(h16x4*)(Ks + buf * KBUF + row * KROW + HD + c4 * 4) = lo;
+      } else {
+        *(h16x4*)(Vh + buf * VBUF + row * VP + c4 * 4) = hi;
+        *(h16x4*)(Vl + buf * VBUF + row * VP + c4 * 4) = lo;
+      }
+    }
+  };
+  load_pieces(0);
+  // Q fragments, unscaled (the scale lives in the exponent's constant): one batch of loads, then the splits
+  h16x8 qh[KS], ql[KS];
+  {
+    f32x4 qraw[KS][2];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) qraw[s][half] = *(const f32x4*)(qp + 16 * s + 8 * h + 4 * half);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!qvalid) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) qraw[s][0] = qraw[s][1] = f32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 hi, lo;
+          hgl_split_hi_lo(qraw[s][half][e], hi, lo, amax);
+          qh[s][4 * half + e] = hi;
+          ql[s][4 * half + e] = lo;
+        }
+  }
+  if (VP > HD) {   // zero the d padding of both V buffers once
+    constexpr int PADW = VP - HD > 0 ? VP - HD : 1;
+    for (int i = t; i < 2 * KV_CHUNK * PADW; i += NT) {
+      const int row = i / PADW, c = i - row * PADW;
+      Vh[row * VP + HD + c] = (_Float16)0.f;     // rows 0..127 = both buffers (VBUF = 64 * VP)
+      Vl[row * VP + HD + c] = (_Float16)0.f;
+    }
+  }
+  store_pieces(0);
+  if (nchunk > 1) {
+    load_pieces(1);
+    store_pieces(1);
+  }
+  if (nchunk > 2) load_pieces(2);
+  __syncthreads();
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  const float NEG_INF = __int_as_float(NEG_BIG_BITS);
+  float m_run = NEG_INF, l_run = 0.f;
+  const int tr_off = (((lane >> 2) & 3) + 4 * h) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  // rel-pos terms of the NEXT tile (tensors [B*H, Sq, kh] / [B*H, Sq, kw], kw a multiple of 32)
+  const bool rel = a.rel_h != nullptr;
+  float rh_next = 0.f;
+  f32x4 rw_next[4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) rw_next[g4] = f32x4{0, 0, 0, 0};
+  const unsigned rel_row = (unsigned)bh * (unsigned)a.Sq + (unsigned)min(qi, a.Sq - 1);
+  auto rel_prefetch = [&](int kb) {
+    kb = min(kb, a.Sk - 32);
+    rh_next = a.rel_h[rel_row * (unsigned)a.kh + (unsigned)(kb / a.kw)];
+    const unsigned o2 = rel_row * (unsigned)a.kw + 4u * (unsigned)h + (unsigned)(kb % a.kw);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) rw_next[g4] = *(const f32x4*)(a.rel_w + o2 + 8 * g4);
+  };
+  if (rel && wave_active) rel_prefetch(0);
+
+  auto bar = [&]() {     // this wave's LDS writes (staging) and reads (fragments) retired, then the workgroup barrier
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  f32x16 s;
+  h16x8 ph[2], pl[2];
+  auto pv_step = [&](int tp) {      // O^T += V^T P^T for tile tp (its probabilities are in ph / pl)
+    const int buf = (tp >> 1) & 1, kt = tp & 1, kbase = tp * 32;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      if (kbase + 16 * s2 >= a.Sk) break;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const int off = buf * VBUF + (kt * 32 + 16 * s2) * VP + d * 32 + tr_off;
+        const h16x4 vh0 = lds_tr4(Vh + off), vh1 = lds_tr4(Vh + off + 8 * VP);
+        const h16x4 vl0 = lds_tr4(Vl + off), vl1 = lds_tr4(Vl + off + 8 * VP);
+        h16x8 vh8, vl8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vh8[e] = vh0[e]; vh8[4 + e] = vh1[e]; vl8[e] = vl0[e]; vl8[4 + e] = vl1[e]; }
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph[s2], o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl[s2], o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph[s2], o[d], 0, 0, 0);
+      }
+    }
+  };
+
+  if (grp == 1) bar();               // group B runs one interval behind group A
+  for (int tt = 0; tt < ntile; ++tt) {
+    const int kbase = tt * 32;
+    // ---------------- M step: P V of the previous tile, Q K^T of this one ----------------
+    if (wave_active) {
+      __builtin_amdgcn_s_setprio(1);
+      if (tt > 0) pv_step(tt - 1);
+      if (rel) {
+        const float rhs = rh_next * inv_scale;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = fmaf(rw_next[e >> 2][e & 3], inv_scale, rhs);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+      }
+      const _Float16* krow = Ks + ((tt >> 1) & 1) * KBUF + ((tt & 1) * 32 + r) * KROW + 8 * h;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        const h16x8 kh8 = *(const h16x8*)(krow + 16 * c);
+        const h16x8 kl8 = *(const h16x8*)(krow + HD + 16 * c);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, ql[c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh[c], s, 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    bar();
+    // ---------------- V step: staging duty, soft-max of this tile ----------------
+    // staging duty FIRST (the next pieces then travel under the soft-max, a barrier and the next P V products): group B writes
+    // its pieces of chunk c in its V step of tile 2c-2, group A in its V step of tile 2c-1
+    {
+      const int c = grp == 1 ? (tt + 2) >> 1 : (tt + 1) >> 1;
+      const bool mine = grp == 1 ? (tt & 1) == 0 : (tt & 1) == 1;
+      if (mine && c >= 2 && c < nchunk) {
+        store_pieces(c);
+        if (c + 1 < nchunk) load_pieces(c + 1);
+      }
+    }
+    if (wave_active) {
+      if (rel) rel_prefetch(kbase + 32);       // consumed at the next M step's start: a whole V step + a barrier away
+      float mx = NEG_INF;
+      if (kbase + 32 > a.Sk) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float sv = kg >= a.Sk ? NEG_INF : s[e];
+          s[e] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_cand = fmaxf(m_run, mx);
+      float m_new = m_run;
+      if (__builtin_amdgcn_ballot_w64(m_cand > m_run + rescale_thr)) {
+        m_new = m_cand;
+        const float m_use0 = (m_new == NEG_INF) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_use0) * sl2e);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        m_run = m_new;
+      }
+      const float mneg = -((m_new == NEG_INF) ? 0.f : m_new) * sl2e;
+      float rs = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[e], sl2e, mneg));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[e + 1], sl2e, mneg));
+        rs += p0;
+        rs += p1;
+        const h16x2 hi2 = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+        ph[e >> 3][e & 7] = hi2[0]; ph[e >> 3][(e & 7) + 1] = hi2[1];
+        pl[e >> 3][e & 7] = (_Float16)(p0 - (float)hi2[0]);
+        pl[e >> 3][(e & 7) + 1] = (_Float16)(p1 - (float)hi2[1]);
+      }
+      l_run += rs;
+    }
+    bar();
+  }
+  if (wave_active) {
+    __builtin_amdgcn_s_setprio(1);
+    pv_step(ntile - 1);
+    __builtin_amdgcn_s_setprio(0);
+  }
+  if (grp == 0) bar();               // group A's last interval: group B is still one behind
+
+  hgl_split_commit(amax);
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (qvalid) {
+    const long long oo = b * a.sob + (long long)qi * a.ldo + hh * HD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * h;
+        if (dd < HD) {
+          f32x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = o[d][4 * g + e] * inv;
+          if (a.out) {
+            *(f32x4*)(a.out + oo + dd) = w;
+          } else {
+            h16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              _Float16 a2, c2;
+              hgl_split_hi_lo(w[e], a2, c2);
+              hi[e] = a2;
+              lo[e] = c2;
+            }
+            *(h16x4*)(a.out_hi + oo + dd) = hi;
+            *(h16x4*)(a.out_lo + oo + dd) = lo;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // "Two items per CU" variant for sequences of 129..256 tokens without rel-pos / causal mask (the CLIP sequences): ONE
 // 4-wave workgroup per (batch, head) item, a wave owns TWO 32-query tiles (64 queries), so the item's keys and values are
 // staged once (as in the 8-wave kernels) but a CU holds two workgroups = two items whose phases are independent: while one
@@ -1860,6 +2172,22 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
     // the persistent kernel parks the CLS-keep row of an item in a 256-byte LDS tail: keys beyond 257 do not fit there
     const bool w8 = wide && HD >= 64 && a.Sq > 128 && a.Sq <= 256 && a.mask_kind != HGL_MASK_CAUSAL &&
                     (a.mask_kind != HGL_MASK_CLS_KEEP || a.Sk <= 257);
+    // long unmasked sequences (SAM's global blocks, GEM's 785 tokens): the ping-pong kernel, one 8-wave workgroup per 256 queries
+    static const int pp = getenv("HGL_ATTN_PP") ? atoi(getenv("HGL_ATTN_PP")) : 1;
+    if constexpr (HD == 64 || HD == 80) {
+      if (pp && a.Sq >= 512 && a.Sk >= 128 && a.mask_kind == HGL_MASK_NONE && (!a.rel_h || (a.kw & 31) == 0) &&
+          ((a.Sk & 31) == 0 || !a.rel_h)) {
+        constexpr int KROW_ = 2 * HD + 8, VP_ = 96;
+        constexpr size_t lds = (size_t)2 * KV_CHUNK * (KROW_ + 2 * VP_) * sizeof(_Float16);
+        static bool set = false;
+        if (!set) {
+          (void)hipFuncSetAttribute((const void*)attn_x3pp_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          set = true;
+        }
+        hipLaunchKernelGGL((attn_x3pp_kernel<HD>), dim3((a.Sq + 255) / 256, a.B * a.H), dim3(512), lds, st, a);
+        return hgl_check_launch("attention");
+      }
+    }
     if (HD == 80 && a.rel_h && a.kh == 14 && a.kw == 14 && a.Sk == 196 && a.mask_kind == HGL_MASK_NONE) {
       hipLaunchKernelGGL((attn_x3_kernel<HD, HD == 80 ? 14 : 0>), grid, dim3(256), 0, st, a);   // rel_h / rel_w given as tensors
     } else if (w8 && !a.rel_h && dual && HD == 64 && (a.mask_kind != HGL_MASK_CLS_KEEP || a.Sk <= 257)) {
