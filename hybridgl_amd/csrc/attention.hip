@@ -2175,7 +2175,10 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
     // long unmasked sequences (SAM's global blocks, GEM's 785 tokens): the ping-pong kernel, one 8-wave workgroup per 256 queries
     static const int pp = getenv("HGL_ATTN_PP") ? atoi(getenv("HGL_ATTN_PP")) : 1;
     if constexpr (HD == 64 || HD == 80) {
-      if (pp && a.Sq >= 512 && a.Sk >= 128 && a.mask_kind == HGL_MASK_NONE && (!a.rel_h || (a.kw & 31) == 0) &&
+      // (measured, tools/attn_pp_ab.py: 4096 x 4096 x 80 with rel-pos 1690 against 1745 us; 785- and 1000-token sequences
+      // 15-25 % SLOWER than two 4-wave workgroups per CU -- few query blocks per head, and the co-execution the schedule
+      // is built for did not appear: SQ_VALU_MFMA_COEXEC stayed at 23 % of the matrix-busy cycles)
+      if (pp && a.Sq >= 2048 && a.Sk >= 2048 && a.mask_kind == HGL_MASK_NONE && (!a.rel_h || (a.kw & 31) == 0) &&
           ((a.Sk & 31) == 0 || !a.rel_h)) {
         constexpr int KROW_ = 2 * HD + 8, VP_ = 96;
         constexpr size_t lds = (size_t)2 * KV_CHUNK * (KROW_ + 2 * VP_) * sizeof(_Float16);

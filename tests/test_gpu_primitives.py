@@ -10,6 +10,7 @@ from oracle import clip_oracle as O
 from oracle.cases import RESIZE_CASES, TAIL_CASES, resize_case, tail_case
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def T(a, dev):
@@ -590,3 +591,32 @@ def test_gemm_f16x3_fp16_valued_weights_drop_the_zero_products(cuda):
         os.environ.pop("HGL_X3_TERMS", None)
         ops.select_x3_kernel("auto")
         ops.release_split_weights([w32.data_ptr(), w16.data_ptr()])
+
+
+@pytest.mark.parametrize("B,H,S,hd,rel", [(2, 4, 2304, 80, True), (1, 8, 2048, 64, False), (1, 2, 2100, 80, False)])
+def test_ping_pong_attention_is_bit_identical_to_the_tile_kernel(cuda, B, H, S, hd, rel):
+    """attn_x3pp_kernel (one 8-wave workgroup per 256 queries, two wave groups one barrier interval apart, K / V chunks
+    double-buffered) against attn_x3_kernel (HGL_ATTN_PP=0, a child process): same arithmetic per (query tile, key tile)
+    pair -> identical bits; with the rel-pos tensors of SAM's global blocks, a 64-wide head, a ragged last key tile."""
+    import subprocess
+    import sys
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {ROOT!r})
+from hybridgl_amd import ops
+ops.set_precision('f16x3')
+g = torch.Generator().manual_seed({S + hd})
+q, k, v = (torch.randn({B}, {S}, {H * hd}, generator=g).cuda() for _ in range(3))
+kw = {{}}
+if {rel}:
+    side = int(round({S} ** 0.5))
+    kw = dict(rel_h=torch.randn({B * H}, {S}, side, generator=g).cuda(), rel_w=torch.randn({B * H}, {S}, side, generator=g).cuda())
+np.save(sys.argv[1], ops.attention(q, k, v, {H}, **kw).cpu().numpy())
+"""
+    outs = []
+    for pp in ("1", "0"):
+        path = f"/tmp/hgl_pp_{pp}_{S}_{hd}.npy"
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, HGL_ATTN_PP=pp), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(np.load(path))
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
