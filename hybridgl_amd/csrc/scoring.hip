@@ -132,16 +132,17 @@ __global__ __launch_bounds__(256) void masked_pool_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < PX_LANE; ++e) raw[e] = attn[min(p0 + e, HW - 1)];
   }
+  // the column of the lane's first pixel by ONE 64-bit division; the others follow by increment and wrap (a 64-bit modulo per
+  // pixel was most of this kernel's instructions: it ran at 0.4 TB/s of mask bytes)
+  int xcol = (int)(p0 % W);
 #pragma unroll
   for (int e = 0; e < PX_LANE; ++e) {
     const long long p = p0 + e;
     float val = 0.f;
-    if (p < HW) {
-      const int x = (int)(p % W);
-      val = ((raw[e] - mn) / range) * dir_weight(dirflag, x, W);
-    }
+    if (p < HW) val = ((raw[e] - mn) / range) * dir_weight(dirflag, xcol, W);
     v[e] = val;
     tot += (double)val;
+    if (++xcol >= W) xcol = 0;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long part = (long long)blockIdx.x * 4 + wave;  // one partial per wave: no block sync
@@ -562,6 +563,7 @@ __global__ __launch_bounds__(256) void ref_masked_pool_kernel(RefSentences rs, i
   const bool inb = p0 + PX_LANE <= HW;
   const int n0 = blockIdx.y * MASK_GROUP;
   const int n1 = min(N, n0 + MASK_GROUP);
+  const int xcol0 = (int)(p0 % W);      // one 64-bit division per lane; the pixels' columns follow by increment and wrap
   for (int s0 = 0; s0 < S; s0 += REF_SC) {
     const int sc = min(REF_SC, S - s0);
     float v[REF_SC][PX_LANE];
@@ -584,16 +586,15 @@ __global__ __launch_bounds__(256) void ref_masked_pool_kernel(RefSentences rs, i
 #pragma unroll
           for (int e = 0; e < PX_LANE; ++e) raw[e] = attn[min(p0 + e, HW - 1)];
         }
+        int xcol = xcol0;
 #pragma unroll
         for (int e = 0; e < PX_LANE; ++e) {
           const long long p = p0 + e;
           float val = 0.f;
-          if (p < HW) {
-            const int x = (int)(p % W);
-            val = ((raw[e] - mn) / range) * dir_weight(dirflag, x, W);
-          }
+          if (p < HW) val = ((raw[e] - mn) / range) * dir_weight(dirflag, xcol, W);
           v[j][e] = val;
           tot += (double)val;
+          if (++xcol >= W) xcol = 0;
         }
         if (blockIdx.y == 0) {
           tot = wave_sum_d(tot);
