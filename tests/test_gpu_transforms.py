@@ -73,3 +73,34 @@ def test_evaluate_from_disk_reports_loader_statistics(cuda, golden_dir, tmp_path
     pipe = HybridGLPipeline(model, mask_generator=gen, use_sam_masks=True, gem_model=gem)
     pipe.run((rr.load(i) for i in rr.jobs()), group=4, proposal_cap=12)
     assert pipe.metrics() == m
+
+
+@pytest.mark.parametrize("hw,out", [((800, 1066), (480, 640)), ((600, 800), (600, 800)), ((97, 131), (200, 333)), ((1066, 800), (500, 375))])
+def test_plain_bilinear_tensor_resize_vs_oracle(cuda, hw, out):
+    """hgl_resize_bilinear == F.interpolate(bilinear, align_corners=False, antialias=False) as the oracle restates it (pinned
+    against torch in tests/golden/resize.npz): T.Resize on a TENSOR, Hybridgl_main_PhraseCut.py:69-70.  Bit for bit."""
+    from hybridgl_amd import transforms as T
+    from oracle import clip_oracle as O
+    x = np.random.default_rng(hw[0] + out[1]).standard_normal((3,) + hw).astype(np.float32)
+    got = T.resize_bilinear(torch.from_numpy(x).to(cuda), out).cpu().numpy()
+    assert got.shape == (3,) + out and np.array_equal(got, O.bilinear_resize(x, out[0], out[1]))
+    import torch.nn.functional as F
+    want = F.interpolate(torch.from_numpy(x)[None], size=out, mode="bilinear", align_corners=False)[0].numpy()
+    assert np.abs(got - want).max() < 1e-5          # torch's CPU kernel contracts some of the products into fmas
+
+
+@pytest.mark.parametrize("file_hw,annot_hw", [((480, 640), (480, 640)), ((360, 480), (480, 640)), ((640, 427), (640, 427))])
+def test_phrasecut_image_norm_vs_host_chain(cuda, file_hw, annot_hw):
+    """image['image'] of the PhraseCut loop (data/dataset_phrasecut.py:49-51 + Hybridgl_main_PhraseCut.py:69-70): T.Resize(800) on
+    the PIL image -> ToTensor -> Normalize -> T.Resize((height, width)) on the tensor, all on the device, against the same
+    chain on the host (Pillow's own resize, numpy normalisation, the oracle's bilinear): bit for bit."""
+    from PIL import Image
+    from hybridgl_amd import synth, transforms as T
+    from oracle import clip_oracle as O
+    img = np.random.default_rng(file_hw[0]).integers(0, 256, file_hw + (3,), dtype=np.uint8)
+    nh, nw = T.resize_shorter_side(file_hw[0], file_hw[1], 800)
+    assert min(nh, nw) == 800
+    host = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+    want = O.bilinear_resize(synth.imagenet_normalize(host), annot_hw[0], annot_hw[1])
+    got = T.phrasecut_image_norm(torch.from_numpy(img).to(cuda), annot_hw[0], annot_hw[1]).cpu().numpy()
+    assert got.shape == (3,) + annot_hw and np.array_equal(got, want)
