@@ -354,6 +354,14 @@ template <int N>
 __device__ __forceinline__ void x3p_wait() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
+// The counts below are written for NT = 3, where every staging unit is TWO DMA pieces per wave (hi and lo plane).  With an
+// fp16-valued weight (NT = 2) the W_lo plane is all zero and is NOT STAGED: the two W units of a K tile are one piece each
+// (U1 = 2, U2 = 1, U3 = 1, U4 = 2 pieces).  "All but the five youngest units" is then 8, 8, 7, 7 pieces in the four phases
+// (7 everywhere is stricter, hence safe); the drained tail 8, 6, 4, 2, 0 becomes 6, 4, 3, 2, 0; the 32 stores of a full
+// write-out are added as before; the four units a K tile issues are 6 pieces.
+constexpr int x3p_cnt(int nt, int c) {
+  return nt == 3 ? c : (c == 42 ? 39 : c == 10 ? 7 : c == 8 ? 6 : c == 6 ? 4 : c == 4 ? 3 : c);
+}
 
 template <int ACT, int WLOADS, int NT>
 __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
@@ -441,11 +449,11 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
     } else if (u == 1) {
       const unsigned off = wrap ? nx[2] : o0.ow0;
       glds16(bWh + ko, off, sb + 2 * PLANE + cgW0 * 1024);
-      glds16(bWl + ko, off, sb + 3 * PLANE + cgW0 * 1024);
+      if (NT == 3) glds16(bWl + ko, off, sb + 3 * PLANE + cgW0 * 1024);     // NT = 2: the plane is all zero and never read
     } else if (u == 2) {
       const unsigned off = wrap ? nx[3] : o0.ow1;
       glds16(bWh + ko, off, sb + 2 * PLANE + cgW1 * 1024);
-      glds16(bWl + ko, off, sb + 3 * PLANE + cgW1 * 1024);
+      if (NT == 3) glds16(bWl + ko, off, sb + 3 * PLANE + cgW1 * 1024);
     } else {
       const unsigned off = wrap ? nx[1] : o0.oa1;
       glds16(bAh + ko, off, sb + rgA1 * 1024);
@@ -515,9 +523,9 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
     const int stage = tile & 1;
     auto wait = [&](auto c) {
       constexpr int CC = decltype(c)::value;
-      if constexpr (CC == 10 || CC == 42) x3p_wait<CC>();
-      else if (go) x3p_wait<10>();
-      else x3p_wait<CC>();
+      if constexpr (CC == 10 || CC == 42) x3p_wait<x3p_cnt(NT, CC)>();
+      else if (go) x3p_wait<x3p_cnt(NT, 10)>();
+      else x3p_wait<x3p_cnt(NT, CC)>();
     };
     // phase 1
     read_A(0, stage);
@@ -595,14 +603,14 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
     // drain under the first five phases of this tile.  From phase 2 of K tile 1 on the needed units are younger than the
     // stores (count 10).
     if (prev_full && nk >= 4) {
-      x3p_wait<42>();
+      x3p_wait<x3p_cnt(NT, 42)>();
       bar();
       if (wm == 1) bar();   // group 1 runs one barrier behind group 0
       tile_body(0, I42(), I42(), I42(), I42(), yes, yes, no, false);
       tile_body(1, I42(), I10(), I10(), I10(), yes, yes, no, false);
       for (int tile = 2; tile + 2 < nk; ++tile) tile_body(tile, I10(), I10(), I10(), I10(), yes, yes, no, false);
     } else {
-      x3p_wait<10>();
+      x3p_wait<x3p_cnt(NT, 10)>();
       bar();
       if (wm == 1) bar();   // group 1 runs one barrier behind group 0
       for (int tile = 0; tile + 2 < nk; ++tile) tile_body(tile, I10(), I10(), I10(), I10(), yes, yes, no, false);
@@ -614,7 +622,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (more && g.amap) {
       // the two map DMAs are older than the 16 operations of the last two K tiles issued so far (none if nk == 2)
-      if (nk >= 4) x3p_wait<10>(); else x3p_wait<0>();
+      if (nk >= 4) x3p_wait<x3p_cnt(NT, 10)>(); else x3p_wait<0>();
       const int ln = x3p_fresh_lane();
       const int m0 = *(const int*)(nxp + 1024 + ln * 4), m1 = *(const int*)(nxp + 1280 + ln * 4);
       *(unsigned*)(nxp + ln * 16) = a_offset(m0);
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
       asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bv) : "v"(bp) : "memory");
     }
     tile_body(nk - 1, I2_(), I0(), I0(), I0(), no, no, yes, more);
-    if (has_bias) asm volatile("s_waitcnt vmcnt(8)" : "+v"(bv)::"memory");
+    if (has_bias) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(bv) : "n"(x3p_cnt(NT, 8)) : "memory");
     const TileOff done = cur;
     v += vstride;
     if (more) {

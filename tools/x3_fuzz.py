@@ -4,6 +4,8 @@ tile counts (one tile per workgroup up to many tiles per persistent workgroup). 
 hand (LDS-DMA units, write-out stores, bias / row-map loads on one in-order counter), so an under-count would show up as
 a result that differs from the register-staged kernel, whose waits the compiler counts; both accumulate in the same
 order and must agree BIT FOR BIT.  Every case is repeated to catch timing-dependent differences.
+X3_FUZZ_FP16_W=1: every second case uses an fp16-valued weight (the NT = 2 instantiation: two products per step, W_lo plane not
+staged, its own wait counts).
 usage: x3_fuzz.py [cases] [seed]"""
 import os
 import sys
@@ -28,6 +30,8 @@ for c in range(n_cases):
     act = ("none", "quickgelu", "gelu", "relu")[int(rng.integers(0, 4))]
     A = torch.randn(M, K, device=dev)
     W = torch.randn(N, K, device=dev) / K ** 0.5
+    if os.environ.get("X3_FUZZ_FP16_W", "0") == "1" and c % 2 == 0:
+        W = W.half().float()
     b = torch.randn(N, device=dev) if rng.random() < 0.7 else None
     R = torch.randn(M, N, device=dev) if rng.random() < 0.5 else None
     ops.select_x3_kernel("v1")
