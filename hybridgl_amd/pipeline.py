@@ -262,6 +262,8 @@ class HybridGLPipeline:
         self.k2 = min(self.k2, hybrid.shape[0])
         ref_index = ref.index if ref.index is not None else self._n_refs
         self._n_refs += 1
+        if not ref.sentences:        # an item without a sentence scores nothing (the reference's inner loop does not run)
+            return None
         heats = iter(heat) if heat is not None else None
         attn = [s.imgattn if s.imgattn is not None else next(heats) for s in ref.sentences]
         fused = self.fused_tail and text.is_contiguous() and all(
