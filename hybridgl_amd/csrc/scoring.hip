@@ -495,13 +495,13 @@ __global__ __launch_bounds__(256) void score_sentence_kernel(
 
 // ---- the tail of a whole REF (all its sentences) in four launches: Hybridgl_main.py:153-230 -------------------------------
 // The per-sentence launches above re-read the N mask planes for every sentence (83.6 MB per ref at N = 64, 640 x 640, three
-// sentences) and cost ~15 launches per sentence with torch glue between them.  Here every mask byte is read ONCE for all the
-// sentences' heat-maps (31.1 MB per ref), the scoring of the sentences runs as one workgroup each in one launch, the IoU of
+// sentences) and cost ~15 launches per sentence with torch glue between them.  Here the pooling of ALL sentences' heat-maps is
+// one launch (the mask planes come from HBM once: the other maps' workgroups find them in L2 / the Infinity Cache), the
+// scoring of the sentences runs as one workgroup each in one launch, the IoU of
 // both winners of every sentence in one launch, and the four accumulators of Hybridgl_main.py:52-55 are updated by the
 // last block of that launch.  Arithmetic and reduction orders are those of the per-sentence kernels (bit-identical results).
 constexpr int REF_MAXS = 16;       // sentences per launch (the host loops over chunks)
 constexpr int REF_MM_BLOCKS = 64;  // min / max partials per heat-map
-constexpr int REF_SC = 4;          // heat-maps pooled per pass over a mask's bytes
 
 struct RefSentences {
   const float* attn[REF_MAXS];
@@ -550,106 +550,82 @@ __device__ __forceinline__ void ref_fold_minmax(const float* __restrict__ part_m
   }
 }
 
-// masked_pool_kernel for S heat-maps at once: grid (pixel blocks, mask groups); the mask bytes of a (block, mask) are read
-// once per pass of REF_SC maps (one pass for the three sentences of a RefCOCO ref)
+// masked_pool_kernel for the S heat-maps of a ref in ONE launch: grid (pixel blocks, mask groups, S).  A first version kept the
+// tiles of up to four heat-maps in registers and read every mask byte once for all of them: 260 VGPRs (one wave per SIMD) and
+// 8.5 k instructions -- 108 us per ref, slower than three launches of the per-sentence kernel (3 x 21 us): this pass is bound
+// by its instructions and round trips, not by the 26 MB of mask bytes.  Now every (block, group, map) is a small workgroup of
+// the per-sentence kernel's code (79 VGPRs, six waves per SIMD); the masks of the second and third map come from L2 / the
+// Infinity Cache.  Partials in the layout and order of masked_pool_kernel: identical sums.
 __global__ __launch_bounds__(256) void ref_masked_pool_kernel(RefSentences rs, int S, const uint8_t* __restrict__ masks, int N, int H,
                                                               int W, const float* __restrict__ part_mm, double* __restrict__ part_sum,
                                                               unsigned* __restrict__ part_cnt, double* __restrict__ part_tot,
                                                               int nparts) {
+  const int sidx = blockIdx.z;
   const long long HW = (long long)H * W;
   const long long p0 = (long long)blockIdx.x * PIX_PER_BLOCK + threadIdx.x * PX_LANE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long part = (long long)blockIdx.x * 4 + wave;
   const bool inb = p0 + PX_LANE <= HW;
+  float mn, mx;
+  ref_fold_minmax(part_mm, sidx, lane, mn, mx);
+  const float range = mx - mn;
+  const float* attn = rs.attn[sidx];
+  const int dirflag = rs.dirflag[sidx];
+  float v[PX_LANE];
+  double tot = 0.0;
+  float raw[PX_LANE];      // four 16-byte loads issued together
+  if (inb && ((((uintptr_t)(attn + p0)) & 15) == 0)) {
+    const f32x4 r0 = *(const f32x4*)(attn + p0), r1 = *(const f32x4*)(attn + p0 + 4);
+    const f32x4 r2 = *(const f32x4*)(attn + p0 + 8), r3 = *(const f32x4*)(attn + p0 + 12);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { raw[e] = r0[e]; raw[4 + e] = r1[e]; raw[8 + e] = r2[e]; raw[12 + e] = r3[e]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < PX_LANE; ++e) raw[e] = attn[min(p0 + e, HW - 1)];
+  }
+  int xcol = (int)(p0 % W);      // one 64-bit division per lane; the pixels' columns follow by increment and wrap
+#pragma unroll
+  for (int e = 0; e < PX_LANE; ++e) {
+    const long long p = p0 + e;
+    float val = 0.f;
+    if (p < HW) val = ((raw[e] - mn) / range) * dir_weight(dirflag, xcol, W);
+    v[e] = val;
+    tot += (double)val;
+    if (++xcol >= W) xcol = 0;
+  }
+  if (blockIdx.y == 0) {
+    tot = wave_sum_d(tot);
+    if (lane == 0) part_tot[(long long)sidx * nparts + part] = tot;
+  }
   const int n0 = blockIdx.y * MASK_GROUP;
   const int n1 = min(N, n0 + MASK_GROUP);
-  const int xcol0 = (int)(p0 % W);      // one 64-bit division per lane; the pixels' columns follow by increment and wrap
-  for (int s0 = 0; s0 < S; s0 += REF_SC) {
-    const int sc = min(REF_SC, S - s0);
-    float v[REF_SC][PX_LANE];
+  for (int n = n0; n < n1; ++n) {
+    const uint8_t* m = masks + (long long)n * HW + p0;
+    double sum = 0.0;
+    unsigned c = 0;
+    if (inb && (((uintptr_t)m) & 15) == 0) {
+      const uint4 mv = *(const uint4*)m;
+      const unsigned w4[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
-    for (int j = 0; j < REF_SC; ++j) {
-      if (j < sc) {
-        float mn, mx;
-        ref_fold_minmax(part_mm, s0 + j, lane, mn, mx);
-        const float range = mx - mn;
-        const float* attn = rs.attn[s0 + j];
-        const int dirflag = rs.dirflag[s0 + j];
-        double tot = 0.0;
-        float raw[PX_LANE];      // four 16-byte loads issued together (see masked_pool_kernel)
-        if (inb && ((((uintptr_t)(attn + p0)) & 15) == 0)) {
-          const f32x4 r0 = *(const f32x4*)(attn + p0), r1 = *(const f32x4*)(attn + p0 + 4);
-          const f32x4 r2 = *(const f32x4*)(attn + p0 + 8), r3 = *(const f32x4*)(attn + p0 + 12);
+      for (int e = 0; e < PX_LANE; ++e) {
+        const bool on = ((w4[e >> 2] >> (8 * (e & 3))) & 0xff) != 0;
+        sum += on ? (double)v[e] : 0.0;
+        c += on ? 1u : 0u;
+      }
+    } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { raw[e] = r0[e]; raw[4 + e] = r1[e]; raw[8 + e] = r2[e]; raw[12 + e] = r3[e]; }
-        } else {
-#pragma unroll
-          for (int e = 0; e < PX_LANE; ++e) raw[e] = attn[min(p0 + e, HW - 1)];
-        }
-        int xcol = xcol0;
-#pragma unroll
-        for (int e = 0; e < PX_LANE; ++e) {
-          const long long p = p0 + e;
-          float val = 0.f;
-          if (p < HW) val = ((raw[e] - mn) / range) * dir_weight(dirflag, xcol, W);
-          v[j][e] = val;
-          tot += (double)val;
-          if (++xcol >= W) xcol = 0;
-        }
-        if (blockIdx.y == 0) {
-          tot = wave_sum_d(tot);
-          if (lane == 0) part_tot[(long long)(s0 + j) * nparts + part] = tot;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < PX_LANE; ++e) v[j][e] = 0.f;
+      for (int e = 0; e < PX_LANE; ++e) {
+        const bool on = (p0 + e < HW) && m[e] != 0;
+        sum += on ? (double)v[e] : 0.0;
+        c += on ? 1u : 0u;
       }
     }
-    // all the group's mask words requested up front (eight independent 16-byte loads in flight per lane), then consumed
-    const bool fast = inb && ((HW & 15) == 0) && ((((uintptr_t)masks) & 15) == 0);     // every plane's piece is 16-byte aligned
-    uint4 mv[MASK_GROUP];
-    if (fast) {
+    sum = wave_sum_d(sum);
+    if (lane == 0) part_sum[((long long)sidx * nparts + part) * N + n] = sum;
+    if (sidx == 0) {
 #pragma unroll
-      for (int i = 0; i < MASK_GROUP; ++i)
-        mv[i] = *(const uint4*)(masks + (long long)min(n0 + i, N - 1) * HW + p0);
-    }
-#pragma unroll
-    for (int i = 0; i < MASK_GROUP; ++i) {
-      const int n = n0 + i;
-      if (n >= n1) break;
-      const uint8_t* m = masks + (long long)n * HW + p0;
-      bool on[PX_LANE];
-      if (fast) {
-        const unsigned w4[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
-#pragma unroll
-        for (int e = 0; e < PX_LANE; ++e) on[e] = ((w4[e >> 2] >> (8 * (e & 3))) & 0xff) != 0;
-      } else if (inb && (((uintptr_t)m) & 15) == 0) {
-        const uint4 mw = *(const uint4*)m;
-        const unsigned w4[4] = {mw.x, mw.y, mw.z, mw.w};
-#pragma unroll
-        for (int e = 0; e < PX_LANE; ++e) on[e] = ((w4[e >> 2] >> (8 * (e & 3))) & 0xff) != 0;
-      } else {
-#pragma unroll
-        for (int e = 0; e < PX_LANE; ++e) on[e] = (p0 + e < HW) && m[e] != 0;
-      }
-      if (s0 == 0) {
-        unsigned c = 0;
-#pragma unroll
-        for (int e = 0; e < PX_LANE; ++e) c += on[e] ? 1u : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (lane == 0) part_cnt[part * N + n] = c;
-      }
-#pragma unroll
-      for (int j = 0; j < REF_SC; ++j) {
-        if (j < sc) {
-          double sum = 0.0;
-#pragma unroll
-          for (int e = 0; e < PX_LANE; ++e) sum += on[e] ? (double)v[j][e] : 0.0;
-          sum = wave_sum_d(sum);
-          if (lane == 0) part_sum[((long long)(s0 + j) * nparts + part) * N + n] = sum;
-        }
-      }
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+      if (lane == 0) part_cnt[part * N + n] = c;
     }
   }
 }
@@ -1071,8 +1047,8 @@ int hgl_score_ref(const float* hybrid, const float* text, int T, const int64_t* 
     float* clip = score_clip ? score_clip + (long long)s0 * N : spare + (long long)sc * N;
     float* neg = score_neg ? score_neg + (long long)s0 * N : spare + 2ll * sc * N;
     hipLaunchKernelGGL(ref_minmax_kernel, dim3(REF_MM_BLOCKS, sc), dim3(256), 0, st, rs, HW, part_mm);
-    hipLaunchKernelGGL(ref_masked_pool_kernel, dim3(coh_nblk(H, W), (N + MASK_GROUP - 1) / MASK_GROUP), dim3(256), 0, st, rs, sc, masks,
-                       N, H, W, part_mm, psum, pcnt, ptot, nparts);
+    hipLaunchKernelGGL(ref_masked_pool_kernel, dim3(coh_nblk(H, W), (N + MASK_GROUP - 1) / MASK_GROUP, sc), dim3(256), 0, st, rs, sc,
+                       masks, N, H, W, part_mm, psum, pcnt, ptot, nparts);
     hipLaunchKernelGGL(ref_score_kernel, dim3(sc), dim3(256), 0, st, rs, hybrid, text, (const long long*)boxes, N, E, H, W, logit_scale,
                        r, k1, k2, alpha, psum, pcnt, ptot, nparts, gem, clip, neg, soft, (int*)idx + 2 * s0,
                        (unsigned long long*)iu + 4 * s0, done);

@@ -308,7 +308,7 @@ int hgl_score_sentence(const float* hybrid, const float* sentence_feat, const fl
  * (rows of `text` [T,E]), logits against hybrid [N,E], the two soft-maxes and top-k lists, the relation_boxes sums over boxes
  * [N,4] int64 XYWH, the coherence score of every proposal under the sentence's heat-map imgattn [H,W] (min-max, gen_dir_mask,
  * /mean, `black`: :203-223), the blend and both arg-maxes, Compute_IoU of both winners against the sentence's target [H,W]
- * uint8.  Every byte of masks [N,H,W] uint8 is read ONCE for all sentences' heat-maps.  `sentences`: HOST array of S records
+ * uint8.  The pooling over masks [N,H,W] uint8 for ALL sentences' heat-maps is one launch.  `sentences`: HOST array of S records
  * holding device pointers.  Outputs: idx [S,2] int32 (pure CLIP winner, winner with spatial guidance), iu [S,4] int64
  * (I, U, I_final, U_final); cum [4] int64 (may be NULL) is INCREMENTED by the column sums of iu on the device
  * (cum_I, cum_U, cum_I_final, cum_U_final of Hybridgl_main.py:52-55); score_clip / score_neg / gem_score [S,N] are optional
