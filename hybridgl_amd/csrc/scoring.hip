@@ -644,24 +644,59 @@ __global__ __launch_bounds__(256) void ref_score_kernel(RefSentences rs, const f
   const long long HW = (long long)H * W;
   float* gem = gem_all + (long long)s * N;
   const float black = rs.black[s];
-  for (int n = wave; n < N; n += 4) {
-    double tot = 0.0, sm = 0.0;
-    unsigned long long c = 0;
-    for (int b = lane; b < nparts; b += 64) {
-      tot += part_tot[(long long)s * nparts + b];
-      sm += part_sum[((long long)s * nparts + b) * N + n];
-      c += part_cnt[(long long)b * N + n];
-    }
-    tot = wave_sum_d(tot);
-    sm = wave_sum_d(sm);
+  // coherence_final_kernel's reduction for this sentence's N masks.  One wave per mask, lanes stride over the per-wave
+  // partials -- but a plain `for (b = lane; b < nparts; b += 64)` is one memory round trip per trip, and sixteen masks per
+  // wave one after the other made this workgroup the longest kernel of the tail (130 us).  The total is summed ONCE per wave
+  // (it is the same for every mask), and four masks' partials are fetched in batches of up to eight trips before they are
+  // added -- in the same order as before: identical sums.
+  constexpr int MR = 4, UB = 8;
+  double tot = 0.0;
+  for (int b0 = lane; b0 < nparts; b0 += 64 * UB) {
+    double tv[UB];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if (lane == 0) {
-      const double mean = tot / (double)HW;
-      const double in_sum = sm / mean, out_sum = (tot - sm) / mean;
-      const double a = (double)(2.f - black) * in_sum / (double)c;
-      const double bterm = (double)black * out_sum / (double)(HW - (long long)c);
-      gem[n] = (float)(a - bterm);
+    for (int u = 0; u < UB; ++u) tv[u] = part_tot[(long long)s * nparts + min(b0 + 64 * u, nparts - 1)];
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      if (b0 + 64 * u < nparts) tot += tv[u];
+  }
+  tot = wave_sum_d(tot);
+  for (int nb = wave * MR; nb < N; nb += 4 * MR) {
+    double sm[MR];
+    unsigned long long c[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) { sm[i] = 0.0; c[i] = 0; }
+    for (int b0 = lane; b0 < nparts; b0 += 64 * UB) {
+      double sv[MR][UB];
+      unsigned cv[MR][UB];
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const int n = min(nb + i, N - 1);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const long long b = min(b0 + 64 * u, nparts - 1);
+          sv[i][u] = part_sum[((long long)s * nparts + b) * N + n];
+          cv[i][u] = part_cnt[b * N + n];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+          if (b0 + 64 * u < nparts) { sm[i] += sv[i][u]; c[i] += cv[i][u]; }
+    }
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      double smr = wave_sum_d(sm[i]);
+      unsigned long long cr = c[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o);
+      if (lane == 0 && nb + i < N) {
+        const double mean = tot / (double)HW;
+        const double in_sum = smr / mean, out_sum = (tot - smr) / mean;
+        const double a = (double)(2.f - black) * in_sum / (double)cr;
+        const double bterm = (double)black * out_sum / (double)(HW - (long long)cr);
+        gem[nb + i] = (float)(a - bterm);
+      }
     }
   }
   if (threadIdx.x < 4) iu_all[4 * s + threadIdx.x] = 0ull;
