@@ -351,23 +351,63 @@ __device__ __forceinline__ void score_sentence_body(
     if (lane == 0) nrm[which] = sqrtf(s);
   }
   __syncthreads();
-  // logits: one wave per mask (strided)
-  for (int n = wave; n < N; n += 4) {
-    const float* ir = hybrid + (long long)n * E;
-    float s = 0.f;
-    for (int i = lane; i < E; i += 64) s += ir[i] * ir[i];
-    const float ni = sqrtf(wave_sum_f(s));
-    float d0 = 0.f, d1 = 0.f;
-    for (int i = lane; i < E; i += 64) {
-      const float v = logit_scale * (ir[i] / ni);
-      d0 += v * (tpos[i] / nrm[0]);
-      d1 += v * (tneg[i] / nrm[1]);
-    }
-    d0 = wave_sum_f(d0);
-    d1 = wave_sum_f(d1);
-    if (lane == 0) {
-      score_clip[n] = d0;
-      score_neg[n] = d1;
+  // logits: one wave per mask (strided).  A lane's elements of a feature row (and of the two text vectors) are fetched in
+  // batches of eight and four masks are in flight per wave: `for (i = lane; i < E; i += 64) s += ir[i] * ir[i]` is one memory
+  // round trip per trip, twice per mask, sixteen masks per wave -- most of this kernel's 80-130 us.  Same operations in the
+  // same order per lane: identical logits.
+  {
+    constexpr int UE = 8, MQ = 4;
+    for (int nb = wave; nb < N; nb += 4 * MQ) {
+      float sq[MQ], d0[MQ], d1[MQ], ni[MQ];
+#pragma unroll
+      for (int j = 0; j < MQ; ++j) { sq[j] = 0.f; d0[j] = 0.f; d1[j] = 0.f; }
+      for (int i0 = lane; i0 < E; i0 += 64 * UE) {
+        float x[MQ][UE];
+#pragma unroll
+        for (int j = 0; j < MQ; ++j) {
+          const float* ir = hybrid + (long long)min(nb + 4 * j, N - 1) * E;
+#pragma unroll
+          for (int u = 0; u < UE; ++u) x[j][u] = ir[min(i0 + 64 * u, E - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < MQ; ++j)
+#pragma unroll
+          for (int u = 0; u < UE; ++u)
+            if (i0 + 64 * u < E) sq[j] += x[j][u] * x[j][u];
+      }
+#pragma unroll
+      for (int j = 0; j < MQ; ++j) ni[j] = sqrtf(wave_sum_f(sq[j]));
+      for (int i0 = lane; i0 < E; i0 += 64 * UE) {
+        float x[MQ][UE], tp[UE], tn[UE];
+#pragma unroll
+        for (int u = 0; u < UE; ++u) {
+          tp[u] = tpos[min(i0 + 64 * u, E - 1)];
+          tn[u] = tneg[min(i0 + 64 * u, E - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < MQ; ++j) {
+          const float* ir = hybrid + (long long)min(nb + 4 * j, N - 1) * E;
+#pragma unroll
+          for (int u = 0; u < UE; ++u) x[j][u] = ir[min(i0 + 64 * u, E - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < MQ; ++j)
+#pragma unroll
+          for (int u = 0; u < UE; ++u)
+            if (i0 + 64 * u < E) {
+              const float v = logit_scale * (x[j][u] / ni[j]);
+              d0[j] += v * (tp[u] / nrm[0]);
+              d1[j] += v * (tn[u] / nrm[1]);
+            }
+      }
+#pragma unroll
+      for (int j = 0; j < MQ; ++j) {
+        const float r0 = wave_sum_f(d0[j]), r1 = wave_sum_f(d1[j]);
+        if (lane == 0 && nb + 4 * j < N) {
+          score_clip[nb + 4 * j] = r0;
+          score_neg[nb + 4 * j] = r1;
+        }
+      }
     }
   }
   __syncthreads();
