@@ -367,6 +367,22 @@ def evaluator_from_disk(args, model, gen, gem_model, dev, group, n_images=208, k
             "metrics_equal_resident": m_disk == m_res,
             "metrics": m_disk,
         })
+        # the same evaluator as EIGHT ranks sharing this GPU (tools/evaluator_ranks.py: python -m hybridgl_amd.main --real x 8, gloo,
+        # 32 cores each): a separate tool run (8 model sets, ~45 s), REPLAYED here from the tracked file of the last evidence pass
+        for tag in ("r04i", "r04h", "r04f", "r04a"):
+            p8 = os.path.join(ROOT, "profiles", f"{tag}_evaluator_8ranks_gloo.json")
+            p1 = os.path.join(ROOT, "profiles", f"{tag}_evaluator_1rank.json")
+            if os.path.exists(p8) and os.path.exists(p1):
+                try:
+                    j8, j1 = json.load(open(p8)), json.load(open(p1))
+                    out["eight_ranks_one_gpu"] = {
+                        "value": j8["value"], "unit": j8["unit"], "host_cores_per_rank": j8["host_cores_per_rank"],
+                        "one_rank_same_tree": j1["value"], "images": j8["tree"]["images"], "refs": j8["tree"]["refs"],
+                        "rank0_loader_wait_s": j8["rank0"]["loader_wait_s"], "seconds_job": j8["seconds_job"],
+                        "source": f"profiles/{tag}_evaluator_8ranks_gloo.json / _1rank.json -- replayed, not measured in this run"}
+                except Exception:
+                    pass
+                break
         return out
     finally:
         if keep_root is None:
