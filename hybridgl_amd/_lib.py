@@ -164,6 +164,7 @@ PROTOTYPES = {
     "hgl_sam_decode_prompts": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _VP, _I, _VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_sam_embed_masks": (_I, [C.POINTER(HglSamDecoderW), _VP, _I, _VP, _VP]),
     "hgl_sam_decoder_fusion": (_I, [_I]),
+    "hgl_attention_presplit": (_I, [_I]),
     "hgl_sam_postprocess_workspace_bytes": (_SZ, [_I]),
     "hgl_sam_postprocess": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _VP, _VP, _VP, _VP, _VP,
                                  _VP, _SZ, _VP]),
@@ -193,7 +194,7 @@ PROTOTYPES = {
 }
 
 _lib = None
-ABI_VERSION = 5   # include/hybridgl.h HGL_ABI_VERSION
+ABI_VERSION = 6   # include/hybridgl.h HGL_ABI_VERSION
 
 
 def load():

@@ -1,0 +1,575 @@
+// Fused attention on PRE-SPLIT operands (f16x3 mode): q, k, v arrive as the fp16 hi / lo planes that the in-projection GEMM's
+// write-out emits (gemm_f16x3.hip: C == nullptr -> Ch / Cl), so this kernel converts nothing on the way in.
+//
+// Replaces, for the shapes that carry the step, attn_x3_kernel<80,14,8> (SAM's 14 x 14 windows, image_encoder.py:224-240 with
+// the decomposed rel-pos terms of :325-361 computed in the kernel), attn_x3pp_kernel<80> (SAM's global blocks, rel-pos terms
+// given as tensors) and attn_x3q_kernel<64,2> (CLIP's 197-token sequences, clip/model.py:209, with the CLS-row keep mask of
+// model/backbone.py:108-115).  Counters of the windowed kernel (profiles/r04h_sq_counters_attn_x3_win14_6400items.json):
+// 9.4 vector instructions per matrix instruction, matrix pipe 24 % busy, waves parked 40 % of their cycles, ONE 8-wave
+// workgroup per CU (238 VGPRs, 118 KB of LDS) -- so nothing covered an item's head (Q / K / V round trips, 1300 of the 2300
+// vector instructions of a wave and item were fp32 -> fp16 hi / lo conversions of Q, K and V) or its eight chunk barriers.
+//
+// Here:
+//   * no conversion work: Q fragments are 16-byte loads of the planes in MFMA operand layout; K / V tiles go global -> LDS by
+//     LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write pass, no vector instruction but the address);
+//   * 4-wave workgroups, a wave owns QT tiles of 32 queries, 32-key chunks double-buffered by the DMA with ONE barrier per
+//     chunk; <= 66 KB of LDS and <= 256 VGPRs: TWO workgroups per CU whose phases are independent (one's prologue, barrier
+//     waits and write-out run beside the other's MFMAs);
+//   * windows: two workgroups per (window, head) (query tiles 0-3 / 4-6), placed on the same XCD so that the second finds the
+//     item's K / V planes in L2; staging twice costs DMA bytes only.
+// The arithmetic of a (query tile, key tile) pair is attn_x3_kernel's, operation for operation (swapped QK^T, scale in the
+// exponent, lazy rescaling, P split by a packed round-toward-zero conversion, P^T accumulators as the B operand of P V through
+// the transposing LDS read): results are bit-identical to that kernel on the same hi / lo planes.
+#include "hgl_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+constexpr int PS_NEG_BIG_BITS = 0xff800000;  // -inf
+constexpr int PS_CHUNK = 32;                 // keys per staged chunk = one key tile
+
+enum { PS_PLAIN = 0, PS_WIN14 = 1, PS_RELT = 2 };
+
+struct PsArgs {
+  const _Float16 *hi, *lo;      // the qkv planes: row (b * sb + s), column xcol + head * HD; leading dimension ld (halfs)
+  int ld, qcol, kcol, vcol;
+  long long sb;                 // rows between two batch elements
+  int B, H, S;
+  float* out;                   // fp32 output, or nullptr: the fp16 pair below (the operand form of the projection GEMM)
+  _Float16 *out_hi, *out_lo;
+  int ldo;
+  long long sob;
+  float scale;
+  int mask_kind;                // HGL_MASK_NONE / HGL_MASK_CLS_KEEP
+  const uint8_t* keep;
+  int keep_b0, keep_n;
+  const float *rel_h, *rel_w;   // PS_RELT: [B*H, S, kh] / [B*H, S, kw] fp32
+  int kh, kw;
+  const _Float16 *tabh_hi, *tabh_lo, *tabw_hi, *tabw_lo;   // PS_WIN14: the [27, 80] tables split once per model (scale 2^0)
+  int nqb;                      // workgroups (blocks of 128 * QT queries) per item
+};
+
+// ds_read_b64_tr_b16 (EXEC must be all ones at the call)
+__device__ __forceinline__ h16x4 ps_tr4(const _Float16* p) {
+  typedef __attribute__((address_space(3))) fp16x4v lds_v;
+  const fp16x4v v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_v*)p);
+  h16x4 r;
+  __builtin_memcpy(&r, &v, 8);
+  return r;
+}
+
+// One LDS-DMA wave-instruction: lane i copies 16 B from sbase + voff(i) to LDS byte lds_addr + 16 * i (see gemm_f16x3.hip).
+// Not counted by the compiler on vmcnt: the consumer waits with an explicit s_waitcnt.
+__device__ __forceinline__ void ps_glds16(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+
+template <int HD>
+struct PsGeom {
+  static constexpr int KS = HD / 16;                    // k-steps of the QK^T contraction
+  static constexpr int DT = (HD + 31) / 32;             // 32-wide d tiles of the output
+  static constexpr int KSL = HD / 4 + 1;                // 16-byte slots of a staged K row: hi | lo | pad (odd: conflict-free b128 reads)
+  static constexpr int KP = KSL * 8;                    // halfs per staged K row
+  static constexpr int VSL = 12;                        // slots of a staged V row (192 B: the transposing reads' pitch)
+  static constexpr int VP = VSL * 8;                    // halfs
+  static constexpr int NSLOT = PS_CHUNK * (KSL + 2 * VSL);
+  static constexpr int NI = (NSLOT + 63) / 64;          // DMA wave-instructions per chunk
+  static constexpr int NJ = (NI + 3) / 4;               // per wave
+  static constexpr int STAGE = NI * 1024;               // bytes
+  static constexpr int K_OFF = 0, VH_OFF = PS_CHUNK * KSL * 16, VL_OFF = VH_OFF + PS_CHUNK * VSL * 16;
+  static_assert(DT * 32 <= VP, "V row pitch");
+};
+constexpr int PS_EP = 40;            // halfs per row of the indicator table (80 B: conflict-free b128 reads)
+constexpr int PS_EROWS = 224;        // 7 key tiles
+
+template <int HD, int MODE>
+constexpr size_t ps_lds_bytes() {
+  return (size_t)2 * PsGeom<HD>::STAGE + (MODE == PS_WIN14 ? PS_EROWS * PS_EP * 2 : 0) + 256;
+}
+
+template <int HD, int MODE, int QT>
+__global__ __launch_bounds__(256, 2) void attn_ps_kernel(PsArgs a) {
+  using G = PsGeom<HD>;
+  constexpr int KS = G::KS, DT = G::DT, KP = G::KP, VP = G::VP;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ps_smem[];
+  unsigned char* const Ebase = ps_smem + 2 * G::STAGE;
+  uint8_t* const keepL = ps_smem + 2 * G::STAGE + (MODE == PS_WIN14 ? PS_EROWS * PS_EP * 2 : 0);
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  // XCD-aware item map: workgroups go to the eight XCDs round-robin in linear order; consecutive slots of ONE XCD are the
+  // query blocks of one item (they stream the same K / V), items are dealt to the XCDs round-robin.
+  int item, bx;
+  {
+    const unsigned L = blockIdx.x, nqb = (unsigned)a.nqb, items = (unsigned)(a.B * a.H);
+    if ((items & 7u) == 0) {
+      const unsigned c = L & 7u, j = L >> 3;
+      item = (int)((j / nqb) * 8u + c);
+      bx = (int)(j % nqb);
+    } else {
+      item = (int)(L / nqb);
+      bx = (int)(L % nqb);
+    }
+  }
+  const int b = item / a.H, hh = item - b * a.H;
+  const float NEG_INF = __int_as_float(PS_NEG_BIG_BITS);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float sl2e = a.scale * LOG2E;
+  const float inv_scale = 1.0f / a.scale;
+  const float rescale_thr = 5.5f * inv_scale;     // 5.5 nats ~ 2^8, in units of the unscaled scores
+
+  // ---- DMA plan: slot n = 64 * i + lane of instruction i = wave + 4 * j -> (plane, key row of the chunk, 16-byte column) ----
+  const unsigned ldb = (unsigned)a.ld * 2u;
+  const long long lo_delta_ll = (const char*)a.lo - (const char*)a.hi;   // checked by the launcher to fit 32 bits with the offsets
+  const unsigned lo_delta = (unsigned)lo_delta_ll;
+  const char* const kv_base = (const char*)a.hi + (long long)b * a.sb * (long long)ldb;
+  unsigned d_row[G::NJ], d_col[G::NJ];
+#pragma unroll
+  for (int j = 0; j < G::NJ; ++j) {
+    const int n = 64 * (wave + 4 * j) + lane;
+    int row = 0;
+    unsigned col = (unsigned)(a.kcol + hh * HD) * 2u;    // pad slots and slots beyond the image fetch a valid, unused piece
+    if (n < PS_CHUNK * G::KSL) {
+      row = n / G::KSL;
+      const int c = n - row * G::KSL;
+      if (c < HD / 8) col = (unsigned)(a.kcol + hh * HD + 8 * c) * 2u;
+      else if (c < HD / 4) col = (unsigned)(a.kcol + hh * HD + 8 * (c - HD / 8)) * 2u + lo_delta;
+    } else if (n < G::NSLOT) {
+      const int n2 = n - PS_CHUNK * G::KSL;
+      const int pl = n2 / (PS_CHUNK * G::VSL), n3 = n2 - pl * (PS_CHUNK * G::VSL);
+      row = n3 / G::VSL;
+      const int c = n3 - row * G::VSL;
+      if (c < HD / 8) col = (unsigned)(a.vcol + hh * HD + 8 * c) * 2u + (pl ? lo_delta : 0u);
+    }
+    d_row[j] = (unsigned)row;
+    d_col[j] = col;
+  }
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)ps_smem;
+  auto issue_chunk = [&](int ci) {
+    const unsigned sbase = lds0 + (unsigned)(ci & 1) * G::STAGE;
+#pragma unroll
+    for (int j = 0; j < G::NJ; ++j) {
+      const int i = wave + 4 * j;
+      if (i < G::NI) {   // uniform
+        const unsigned krow = min((unsigned)(ci * PS_CHUNK) + d_row[j], (unsigned)(a.S - 1));
+        ps_glds16(kv_base, krow * ldb + d_col[j], sbase + (unsigned)i * 1024u);
+      }
+    }
+  };
+  issue_chunk(0);      // requested first: its round trip overlaps the Q loads and the rel-pos table products
+
+  // ---- CLS keep row / indicator table ----
+  const uint8_t* keep_row = nullptr;
+  if (MODE == PS_PLAIN && a.mask_kind == HGL_MASK_CLS_KEEP && b >= a.keep_b0)
+    keep_row = a.keep + (long long)((b - a.keep_b0) % a.keep_n) * (a.S - 1);
+  if (keep_row && t < a.S - 1) keepL[t] = keep_row[t];
+  if constexpr (MODE == PS_WIN14) {
+    // E[key][j] = 1 at j = key / 14 and j = 14 + key % 14 (32 columns): the rel-pos bias is two more k-steps R[q] . E[key]
+    for (int idx = t; idx < PS_EROWS * 4; idx += 256) {
+      const int row = idx >> 2, j0 = 8 * (idx & 3);
+      const int ih = row / 14, iw = 14 + row - ih * 14;
+      h16x8 e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = (j0 + j == ih || j0 + j == iw) ? (_Float16)1.f : (_Float16)0.f;
+      *(h16x8*)(Ebase + (row * PS_EP + j0) * 2) = e;
+    }
+  }
+
+  // ---- Q fragments: lane (r, h) element j of k-step s = Q[q][16 s + 8 h + j], straight from the planes ----
+  int qi[QT];
+  bool qvalid[QT], tile_active[QT];
+  h16x8 qh[QT][KS], ql[QT][KS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q0 = ((bx * 4 + wave) * QT + qt) * 32;
+    qi[qt] = q0 + r;
+    qvalid[qt] = qi[qt] < a.S;
+    tile_active[qt] = q0 < a.S;
+    const long long qo = ((long long)b * a.sb + (qvalid[qt] ? qi[qt] : 0)) * a.ld + a.qcol + hh * HD + 8 * h;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      qh[qt][s] = *(const h16x8*)(a.hi + qo + 16 * s);
+      ql[qt][s] = *(const h16x8*)(a.lo + qo + 16 * s);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    if (!qvalid[qt]) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qh[qt][s][e] = (_Float16)0.f; ql[qt][s][e] = (_Float16)0.f; }
+    }
+  }
+  const bool wave_active = tile_active[0];
+
+  f32x16 o[QT][DT];
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = NEG_INF;
+    l_run[qt] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qt][d][e] = 0.f;
+  }
+
+  // ---- PS_WIN14: R fragments of the MFMA bias.  rel_h[q][k] = q . Rh[qy - k + 13] (image_encoder.py:325-361, UNSCALED q):
+  // T^T = R . Q^T on the matrix cores with the split scheme and summation order of attn_x3_kernel, per wave, through an LDS
+  // patch [table index][query] that aliases the second K / V stage (its first DMA is issued behind the loop's first barrier).
+  h16x8 rbh[2], rbl[2];
+  if constexpr (MODE == PS_WIN14) {
+    float xs[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xs[c][j] = 0.f;
+    if (wave_active) {
+      float* const P0 = (float*)(ps_smem + G::STAGE) + wave * 32 * 32;
+      const int qq = qvalid[0] ? qi[0] : 0;
+      const int qy = qq / 14, qx = qq - qy * 14;
+#pragma unroll
+      for (int axis = 0; axis < 2; ++axis) {
+        const _Float16* Th = axis ? a.tabw_hi : a.tabh_hi;
+        const _Float16* Tl = axis ? a.tabw_lo : a.tabh_lo;
+        const long long to = (long long)min(r, 26) * HD + 8 * h;
+        h16x8 thr[KS], tlr[KS];
+#pragma unroll
+        for (int sx = 0; sx < KS; ++sx) {
+          thr[sx] = *(const h16x8*)(Th + to + 16 * sx);
+          tlr[sx] = *(const h16x8*)(Tl + to + 16 * sx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (r >= 27) {
+#pragma unroll
+          for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { thr[sx][e] = (_Float16)0.f; tlr[sx][e] = (_Float16)0.f; }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int sx = 0; sx < KS; ++sx) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tlr[sx], qh[0][sx], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(thr[sx], ql[0][sx], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(thr[sx], qh[0][sx], acc, 0, 0, 0);
+        }
+        // acc[e] = T[table index (e&3) + 8*(e>>2) + 4*h][query r]
+#pragma unroll
+        for (int e = 0; e < 16; ++e) P0[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[e];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // R[q][idx]: idx < 14 -> rel_h[q][k = idx] (axis 0), 14 <= idx < 28 -> rel_w[q][k = idx - 14] (axis 1), else 0
+        const int qc = axis ? qx : qy;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = 16 * c + 8 * h + j - 14 * axis;
+            if (k >= 0 && k < 14) xs[c][j] = P0[(qc + 13 - k) * 32 + r];
+          }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float x = xs[c][j] * inv_scale;
+        _Float16 hi, lo;
+        hgl_split_hi_lo(x, hi, lo);
+        rbh[c][j] = hi;
+        rbl[c][j] = lo;
+      }
+  }
+
+  // ---- PS_RELT: the 17 rel-pos values a lane adds to the scores of a key tile, fetched ONE TILE AHEAD (attn_x3_kernel) ----
+  float rh_next = 0.f;
+  f32x4 rw_next[4];
+  const int rel_q0 = (bx * 4 + wave) * QT * 32;
+  auto rel_prefetch = [&](int kb) {
+    if constexpr (MODE == PS_RELT) {
+      int ln;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      const unsigned row = (unsigned)item * (unsigned)a.S + (unsigned)min(rel_q0 + (ln & 31), a.S - 1);
+      const unsigned relh_off = row * (unsigned)a.kh;
+      const unsigned relw_off = row * (unsigned)a.kw + 4u * (unsigned)(ln >> 5);
+      kb = min(kb, a.S - 32);
+      rh_next = a.rel_h[relh_off + (unsigned)(kb / a.kw)];
+      const unsigned o2 = relw_off + (unsigned)(kb % a.kw);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) rw_next[g4] = *(const f32x4*)(a.rel_w + o2 + 8 * g4);
+    }
+  };
+  if (MODE == PS_RELT && wave_active) rel_prefetch(0);
+
+  // transposed-read addressing (attn_x3_kernel): lane = 16*grp + 4*q + p supplies row q, columns 4p..4p+3 of its group's block
+  const int tr_off = (((lane >> 2) & 3) + 4 * h) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  const int nchunk = (a.S + PS_CHUNK - 1) / PS_CHUNK;
+  for (int ci = 0; ci < nchunk; ++ci) {
+    // this wave's pieces of chunk ci have landed; behind the barrier so have everyone's, and every wave has finished reading
+    // chunk ci - 1, whose stage the next DMA overwrites (PS_WIN14, ci == 0: every wave has finished with its rel-pos patch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ci + 1 < nchunk) issue_chunk(ci + 1);
+    if (!wave_active) continue;   // uniform: a wave beyond the sequence only helps staging
+    const unsigned char* const st = ps_smem + (ci & 1) * G::STAGE;
+    const _Float16* const Ks = (const _Float16*)(st + G::K_OFF);
+    const _Float16* const Vh = (const _Float16*)(st + G::VH_OFF);
+    const _Float16* const Vl = (const _Float16*)(st + G::VL_OFF);
+    const int kbase = ci * PS_CHUNK;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      if (!tile_active[qt]) continue;   // uniform per wave
+      f32x16 s;
+      if constexpr (MODE == PS_RELT) {   // the score accumulators START at the rel-pos terms
+        const float rhs = rh_next * inv_scale;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = fmaf(rw_next[e >> 2][e & 3], inv_scale, rhs);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+      }
+      const _Float16* krow = Ks + r * KP + 8 * h;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        const h16x8 kh8 = *(const h16x8*)(krow + 16 * c);
+        const h16x8 kl8 = *(const h16x8*)(krow + HD + 16 * c);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[qt][c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, ql[qt][c], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh[qt][c], s, 0, 0, 0);
+      }
+      if constexpr (MODE == PS_WIN14) {
+        const _Float16* erow = (const _Float16*)Ebase + (kbase + r) * PS_EP + 8 * h;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const h16x8 e8 = *(const h16x8*)(erow + 16 * c);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(e8, rbl[c], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(e8, rbh[c], s, 0, 0, 0);
+        }
+      }
+      // s[e] = S^T[key = kbase + (e&3) + 8*(e>>2) + 4*h][query], unscaled; scale and log2(e) are folded into the exponent's fma
+      float mx = NEG_INF;
+      if (kbase + 32 > a.S) {   // uniform: the tile that crosses the end of the sequence
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+          s[e] = kg >= a.S ? NEG_INF : s[e];
+        }
+      }
+      if (MODE == PS_PLAIN && keep_row && bx == 0 && wave == 0 && qt == 0) {   // uniform: the tile that owns query 0
+        const int kk = kbase + (lane & 31);
+        const unsigned kb = kk >= 1 && kk < a.S ? keepL[kk - 1] : 1u;
+        const unsigned bits = (unsigned)__builtin_amdgcn_ballot_w64(kb != 0) >> (4 * h);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const bool kept = (bits >> ((e & 3) + 8 * (e >> 2))) & 1u;
+          s[e] = (qi[0] == 0 && !kept) ? NEG_INF : s[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      // lazy rescaling (attn_x3_kernel): the running maximum follows the scores only when some query of the wave would
+      // otherwise see probabilities above 2^8 (uniform branch)
+      const float m_cand = fmaxf(m_run[qt], mx);
+      float m_new = m_run[qt];
+      if (__builtin_amdgcn_ballot_w64(m_cand > m_run[qt] + rescale_thr)) {
+        m_new = m_cand;
+        const float m_use0 = (m_new == NEG_INF) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_use0) * sl2e);
+        l_run[qt] *= alpha;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[qt][d][e] *= alpha;
+        m_run[qt] = m_new;
+      }
+      const float mneg = -((m_new == NEG_INF) ? 0.f : m_new) * sl2e;
+      float rs = 0.f;
+      h16x8 ph[2], pl[2];
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[e], sl2e, mneg));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[e + 1], sl2e, mneg));
+        rs += p0;
+        rs += p1;
+        // hi by one packed round-toward-zero conversion (any rounding works: lo is the exact remainder, rounded to nearest)
+        const h16x2 hi2 = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+        ph[e >> 3][e & 7] = hi2[0]; ph[e >> 3][(e & 7) + 1] = hi2[1];
+        pl[e >> 3][e & 7] = (_Float16)(p0 - (float)hi2[0]);
+        pl[e >> 3][(e & 7) + 1] = (_Float16)(p1 - (float)hi2[1]);
+      }
+      l_run[qt] += rs;
+      // the scores are dead from here on: the next tile's rel-pos terms travel under the P V products
+      if (MODE == PS_RELT && qt == QT - 1) rel_prefetch(kbase + 32);
+      // O^T += V^T P^T ; A operand element j of lane (d, h) = V^T[d][16*s2 + 8*(j>>2) + 4*h + (j&3)]
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (kbase + 16 * s2 >= a.S) break;   // uniform: the keys of this k-step are all beyond the sequence (P = 0)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const int off = (16 * s2) * VP + d * 32 + tr_off;
+          const h16x4 vh0 = ps_tr4(Vh + off), vh1 = ps_tr4(Vh + off + 8 * VP);
+          const h16x4 vl0 = ps_tr4(Vl + off), vl1 = ps_tr4(Vl + off + 8 * VP);
+          h16x8 vh8, vl8;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vh8[e] = vh0[e]; vh8[4 + e] = vh1[e]; vl8[e] = vl0[e]; vl8[4 + e] = vl1[e]; }
+          o[qt][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph[s2], o[qt][d], 0, 0, 0);
+          o[qt][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl[s2], o[qt][d], 0, 0, 0);
+          o[qt][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph[s2], o[qt][d], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qvalid[qt]) {
+      const long long oo = b * a.sob + (long long)qi[qt] * a.ldo + hh * HD;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = d * 32 + 8 * g + 4 * h;
+          if (dd < HD) {
+            f32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = o[qt][d][4 * g + e] * inv;
+            if (a.out) {
+              *(f32x4*)(a.out + oo + dd) = w;
+            } else {   // the operand form of the following f16x3 projection
+              h16x4 hi, lo;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                _Float16 a2, c2;
+                hgl_split_hi_lo(w[e], a2, c2);
+                hi[e] = a2;
+                lo[e] = c2;
+              }
+              *(h16x4*)(a.out_hi + oo + dd) = hi;
+              *(h16x4*)(a.out_lo + oo + dd) = lo;
+            }
+          }
+        }
+    }
+  }
+}
+
+template <int HD, int MODE, int QT>
+int ps_launch(const PsArgs& a, hipStream_t st) {
+  constexpr size_t lds = ps_lds_bytes<HD, MODE>();
+  // the attribute is per device: keyed by the device, result checked
+  static bool set_for[64] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!set_for[dev]) {
+    if (hipFuncSetAttribute((const void*)attn_ps_kernel<HD, MODE, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      hgl_set_error("attention_ps: cannot reserve %zu bytes of LDS", lds);
+      return HGL_ELAUNCH;
+    }
+    set_for[dev] = true;
+  }
+  const long long wgs = (long long)a.B * a.H * a.nqb;
+  hipLaunchKernelGGL((attn_ps_kernel<HD, MODE, QT>), dim3((unsigned)wgs), dim3(256), lds, st, a);
+  return hgl_check_launch("attention_ps");
+}
+
+}  // namespace
+
+static int g_attn_ps = -1;   // -1: read HGL_ATTN_PS on first use (default on)
+static int attn_ps_flag() {
+  if (g_attn_ps < 0) { const char* v = getenv("HGL_ATTN_PS"); g_attn_ps = v ? (atoi(v) != 0) : 1; }
+  return g_attn_ps;
+}
+bool hgl_attention_ps_enabled() { return attn_ps_flag() != 0 && hgl_precision() == HGL_PREC_F16X3; }
+
+extern "C" int hgl_attention_presplit(int on) {
+  const int prev = attn_ps_flag();
+  if (on >= 0) g_attn_ps = on != 0;
+  return prev;
+}
+
+// Attention on the split qkv planes.  Returns 1 ("not applicable": the caller takes the fp32-input path) when the shape is
+// not one this kernel serves, 0 on success, < 0 on error.
+//   qkv_hi / qkv_lo : fp16 planes, row (b * sb + s), columns qcol / kcol / vcol + head * hd, leading dimension ld (halfs)
+//   tab_h / tab_w   : SAM's windowed blocks (S == 196, hd == 80): the rel-pos tables (fp32 pointers registered with
+//                     hgl_register_split_weight at scale 2^0); rel_h / rel_w: the terms as tensors (global blocks)
+int hgl_launch_attention_ps(const void* qkv_hi, const void* qkv_lo, int ld, int qcol, int kcol, int vcol, long long sb, int B,
+                            int H, int S, int hd, float* out, void* out_hi, void* out_lo, int ldo, long long sob, float scale,
+                            int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, const float* rel_h, const float* rel_w,
+                            int kh, int kw, const float* tab_h, const float* tab_w, hipStream_t st) {
+  if (!hgl_attention_ps_enabled()) return 1;
+  if (!(hd == 80 || hd == 64) || mask_kind == HGL_MASK_CAUSAL) return 1;
+  HGL_REQUIRE(qkv_hi && qkv_lo && (out || (out_hi && out_lo)) && B > 0 && H > 0 && S > 0, "attention_ps: bad arguments");
+  HGL_REQUIRE((ld & 7) == 0 && (qcol & 7) == 0 && (kcol & 7) == 0 && (vcol & 7) == 0 && (ldo & 3) == 0 && (sob & 3) == 0 &&
+                  (((uintptr_t)qkv_hi | (uintptr_t)qkv_lo | (uintptr_t)out | (uintptr_t)out_hi | (uintptr_t)out_lo) & 15) == 0,
+              "attention_ps: operands must be 16-byte aligned");
+  HGL_REQUIRE(mask_kind != HGL_MASK_CLS_KEEP || keep, "attention_ps: HGL_MASK_CLS_KEEP needs keep bytes");
+  HGL_REQUIRE((rel_h == nullptr) == (rel_w == nullptr) && (tab_h == nullptr) == (tab_w == nullptr), "attention_ps: rel-pos operands go in pairs");
+  // the DMA addresses one item's K / V rows with a 32-bit offset from the item's base in the hi plane, lo plane included
+  const long long delta = (const char*)qkv_lo - (const char*)qkv_hi;
+  const long long span = (long long)S * ld * 2 + (long long)ld * 2;
+  if (delta < 0 || delta + span >= (1ll << 32)) return 1;
+  PsArgs a;
+  a.hi = (const _Float16*)qkv_hi; a.lo = (const _Float16*)qkv_lo;
+  a.ld = ld; a.qcol = qcol; a.kcol = kcol; a.vcol = vcol; a.sb = sb;
+  a.B = B; a.H = H; a.S = S;
+  a.out = out; a.out_hi = (_Float16*)out_hi; a.out_lo = (_Float16*)out_lo; a.ldo = ldo; a.sob = sob;
+  a.scale = scale; a.mask_kind = mask_kind; a.keep = keep; a.keep_b0 = keep_b0; a.keep_n = keep_n > 0 ? keep_n : B;
+  a.rel_h = rel_h; a.rel_w = rel_w; a.kh = kh; a.kw = kw;
+  a.tabh_hi = a.tabh_lo = a.tabw_hi = a.tabw_lo = nullptr;
+  a.nqb = 1;
+  enum { K_NONE, K_WIN, K_RELT80, K_RELT64, K_CLIP, K_PLAIN80, K_PLAIN64 } kind = K_NONE;
+  if (tab_h) {
+    const void *hh = nullptr, *hl = nullptr, *wh = nullptr, *wl = nullptr;
+    int sh = 1, sw = 1, n1 = 0, k1 = 0, n2 = 0, k2 = 0;
+    if (hd == 80 && S == 196 && mask_kind == HGL_MASK_NONE && !rel_h && hgl_get_split_weight(tab_h, &hh, &hl, &sh, &n1, &k1) &&
+        hgl_get_split_weight(tab_w, &wh, &wl, &sw, &n2, &k2) && sh == 0 && sw == 0 && n1 == 27 && n2 == 27 && k1 == 80 && k2 == 80) {
+      a.tabh_hi = (const _Float16*)hh; a.tabh_lo = (const _Float16*)hl;
+      a.tabw_hi = (const _Float16*)wh; a.tabw_lo = (const _Float16*)wl;
+      a.nqb = 2;
+      kind = K_WIN;
+    }
+  } else if (rel_h) {
+    // 32-bit element offsets into the rel-pos tensors
+    if (mask_kind == HGL_MASK_NONE && (kw & 31) == 0 && (S & 31) == 0 && kh * kw == S &&
+        (long long)B * H * S * (long long)(kh > kw ? kh : kw) < (1ll << 32)) {
+      a.nqb = (S + 127) / 128;
+      kind = hd == 80 ? K_RELT80 : K_RELT64;
+    }
+  } else if (hd == 64 && S > 128 && S <= 256) {
+    kind = K_CLIP;    // one 4-wave workgroup per item, two query tiles per wave
+  } else if (mask_kind == HGL_MASK_NONE) {
+    a.nqb = (S + 127) / 128;   // blocks of 128 queries
+    kind = hd == 80 ? K_PLAIN80 : K_PLAIN64;
+  }
+  if (kind == K_NONE) return 1;
+  HglProfScope prof(HGL_PROF_ATTN, 4.0 * B * H * (double)S * S * hd, 0.0, st);
+  switch (kind) {
+    case K_WIN: return ps_launch<80, PS_WIN14, 1>(a, st);
+    case K_RELT80: return ps_launch<80, PS_RELT, 1>(a, st);
+    case K_RELT64: return ps_launch<64, PS_RELT, 1>(a, st);
+    case K_CLIP: return ps_launch<64, PS_PLAIN, 2>(a, st);
+    case K_PLAIN80: return ps_launch<80, PS_PLAIN, 1>(a, st);
+    default: return ps_launch<64, PS_PLAIN, 1>(a, st);
+  }
+}

@@ -142,6 +142,12 @@ int hgl_launch_attention_split(const float* q, const float* k, const float* v, f
 int hgl_launch_attention_win14(const float* q, const float* k, const float* v, void* out_hi, void* out_lo, int B, int H, int hd,
                                int ldq, int ldk, int ldv, int ldo, long long sqb, long long skb, long long svb, long long sob,
                                float scale, const float* Rh, const float* Rw, hipStream_t st);
+// attention on the split qkv planes the in-projection GEMM emits (attention_ps.hip); returns 1 when the shape is not served
+bool hgl_attention_ps_enabled();
+int hgl_launch_attention_ps(const void* qkv_hi, const void* qkv_lo, int ld, int qcol, int kcol, int vcol, long long sb, int B,
+                            int H, int S, int hd, float* out, void* out_hi, void* out_lo, int ldo, long long sob, float scale,
+                            int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, const float* rel_h, const float* rel_w,
+                            int kh, int kw, const float* tab_h, const float* tab_w, hipStream_t st);
 int hgl_launch_attention_smallk(const float* q, const float* k, const float* v, float* out, void* out_hi, void* out_lo,
                                 int B, int H, int Sq, int Sk, int hd, int ldq, int ldk, int ldv, int ldo, long long sqb,
                                 long long skb, long long svb, long long sob, float scale, hipStream_t st);
@@ -219,6 +225,8 @@ int hgl_launch_mask_downscaling(const float* in, int P, int g, const float* c1w,
 int hgl_launch_win_maps(int g, int ws, int nw, int nb, int* pad_of, int* tok_of, int* pad_list, int* pad_count, hipStream_t st);
 int hgl_launch_fill_rows(float* dst, int ld, const int* rows, const int* nrows, int max_rows, const float* v, int N,
                          hipStream_t st);
+int hgl_launch_fill_rows_split(void* hi, void* lo, int ld, const int* rows, const int* nrows, int max_rows, const float* v,
+                               int N, hipStream_t st);
 int hgl_launch_ln_gelu64(float* x, const float* w, const float* b, long long rows, float eps, void* hi, void* lo,
                          hipStream_t st);
 int hgl_launch_ln256_pe_split(float* x, const float* w, const float* b, const float* pe, int pe_rows, long long rows,

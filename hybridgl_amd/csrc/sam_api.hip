@@ -90,6 +90,15 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
   uint16_t* Hl = Hh + (size_t)T * D;
   uint16_t* Fh = (uint16_t*)p.F;
   uint16_t* Fl = Fh + (size_t)T * 4 * D;
+  uint16_t* Qh = (uint16_t*)p.QKV;                  // split qkv (aliases the fp32 tensor)
+  uint16_t* Ql = Qh + (size_t)M * 3 * D;
+  bool ps_win = false;
+  if (x3 && ws == 14 && hd == 80 && S == 196 && hgl_attention_ps_enabled()) {
+    const void *th = nullptr, *tl = nullptr;
+    int sc = 1, n1 = 0, k1 = 0;
+    ps_win = hgl_get_split_weight(b.rel_pos_h, &th, &tl, &sc, &n1, &k1) && sc == 0 && n1 == 27 && k1 == 80 &&
+             hgl_get_split_weight(b.rel_pos_w, &th, &tl, &sc, &n1, &k1) && sc == 0 && n1 == 27 && k1 == 80;
+  }
   if (x3) {
     if (ws > 0 && M > T && padskip) {
       // norm1 of the real tokens written straight to their rows of the padded window layout (the pad rows are never
@@ -103,7 +112,17 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
     } else {
       HGL_TRY(hgl_launch_layernorm_split(p.X, b.norm1_w, b.norm1_b, Ah, Al, T, D, 1e-6f, st));
     }
-    if (ws > 0 && M > T && padskip) {
+    // q | k | v as fp16 hi / lo planes (the in-projection's write-out splits; same bytes as the fp32 tensor) for the attention
+    // kernel that stages them by LDS-DMA without converting (attention_ps.hip): the 14 x 14 windows at head dim 80
+    if (ps_win) {
+      if (M > T && padskip) {
+        HGL_TRY(hgl_launch_fill_rows_split(Qh, Ql, 3 * D, p.pad_list, p.pad_count, p.n_pad_max, b.qkv_b, 3 * D, st));
+        HGL_TRY(hgl_launch_gemm_f16x3_maps(Ah, Al, D, p.pad_of, b.qkv_w, b.qkv_b, nullptr, 0, 0, p.pad_of, nullptr, Qh, Ql, 3 * D,
+                                           T, 3 * D, D, HGL_ACT_NONE, st));
+      } else {
+        HGL_TRY(hgl_launch_gemm_f16x3(Ah, Al, D, b.qkv_w, b.qkv_b, nullptr, 0, nullptr, Qh, Ql, 3 * D, M, 3 * D, D, HGL_ACT_NONE, st));
+      }
+    } else if (ws > 0 && M > T && padskip) {
       // only the real tokens go through the GEMM (16 % fewer rows at 64x64 / 14x14); a padded row of qkv is the bias
       HGL_TRY(hgl_launch_fill_rows(p.QKV, 3 * D, p.pad_list, p.pad_count, p.n_pad_max, b.qkv_b, 3 * D, st));
       HGL_TRY(hgl_launch_gemm_f16x3_maps(Ah, Al, D, p.pad_of, b.qkv_w, b.qkv_b, nullptr, 0, 0, p.pad_of, p.QKV, nullptr,
@@ -122,6 +141,14 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
     }
     HGL_TRY(hgl_launch_gemm(A, b.qkv_w, b.qkv_b, nullptr, p.QKV, M, 3 * D, D, D, D, 0, 3 * D, 1, 0, 0, 0, 0,
                             HGL_ACT_NONE, st));
+  }
+  if (ps_win) {
+    const int rc = hgl_launch_attention_ps(Qh, Ql, 3 * D, 0, D, 2 * D, S, B, heads, S, hd, nullptr, Ah, Al, D, (long long)S * D,
+                                           1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, nullptr, nullptr, 0, 0,
+                                           b.rel_pos_h, b.rel_pos_w, st);
+    if (rc < 0) return rc;
+    HGL_REQUIRE(rc == 0, "sam_encode: the pre-split attention refused a shape its caller had checked");
+    goto attention_done;
   }
   // 14 x 14 windows at head dim 80 in f16x3 mode: the attention kernel computes the decomposed rel-pos terms itself
   if (x3 && ws == 14 && hd == 80) {

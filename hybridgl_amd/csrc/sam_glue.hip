@@ -323,6 +323,30 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(float* __restrict__ dst,
   for (int c = blockIdx.x * 256 + threadIdx.x; c < N4; c += gridDim.x * 256) d[c] = ((const f32x4*)v)[c];
 }
 
+// the same rows of a tensor kept as fp16 hi | lo planes (the split qkv output of the windowed blocks): hi[rows[i], :] | lo[rows[i], :]
+// = the split of v[:]
+__global__ __launch_bounds__(256) void fill_rows_split_kernel(_Float16* __restrict__ hi, _Float16* __restrict__ lo, int ld,
+                                                              const int* __restrict__ rows, const int* __restrict__ nrows,
+                                                              const float* __restrict__ v, int N4) {
+  typedef _Float16 fr_h4 __attribute__((ext_vector_type(4)));
+  const int i = blockIdx.y;
+  if (i >= *nrows) return;
+  const long long ro = (long long)rows[i] * ld;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < N4; c += gridDim.x * 256) {
+    const f32x4 x = ((const f32x4*)v)[c];
+    fr_h4 a, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 h0, l0;
+      hgl_split_hi_lo(x[e], h0, l0);
+      a[e] = h0;
+      l[e] = l0;
+    }
+    *(fr_h4*)(hi + ro + 4 * c) = a;
+    *(fr_h4*)(lo + ro + 4 * c) = l;
+  }
+}
+
 // cols[(y*g+x), c*9 + ky*3+kx] = in[(y+ky-1), (x+kx-1), c] (zero padded), NHWC input
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ in, int g, int C,
                                                         float* __restrict__ cols, long long total) {
@@ -1247,6 +1271,13 @@ int hgl_launch_fill_rows(float* dst, int ld, const int* rows, const int* nrows, 
   HGL_REQUIRE((N & 3) == 0 && max_rows > 0, "fill_rows: bad arguments");
   hipLaunchKernelGGL(fill_rows_kernel, dim3(4, (unsigned)max_rows), dim3(256), 0, st, dst, ld, rows, nrows, v, N / 4);
   return hgl_check_launch("fill_rows");
+}
+int hgl_launch_fill_rows_split(void* hi, void* lo, int ld, const int* rows, const int* nrows, int max_rows, const float* v,
+                               int N, hipStream_t st) {
+  HGL_REQUIRE((N & 3) == 0 && (ld & 3) == 0 && max_rows > 0 && hi && lo, "fill_rows_split: bad arguments");
+  hipLaunchKernelGGL(fill_rows_split_kernel, dim3(4, (unsigned)max_rows), dim3(256), 0, st, (_Float16*)hi, (_Float16*)lo, ld, rows,
+                     nrows, v, N / 4);
+  return hgl_check_launch("fill_rows_split");
 }
 int hgl_launch_im2col3x3(const float* in, int g, int C, float* cols, hipStream_t st) {
   const long long total = (long long)g * g * C * 9;

@@ -35,7 +35,7 @@ extern "C" {
 /* 2: + hgl_clip_hybrid_forward_segments, hgl_split_overflow_count, hgl_clip_encode_text_ex; hgl_gemm_f16x3_select
  * knows kinds -1, 0, 1 only
  * 5: + hgl_u8_to_chw_lut, hgl_split_overflow_peek_async, hgl_resize_bilinear, hgl_score_ref */
-#define HGL_ABI_VERSION 5
+#define HGL_ABI_VERSION 6
 
 /* activation codes for hgl_gemm_f32 */
 #define HGL_ACT_NONE 0
@@ -497,6 +497,13 @@ int hgl_sam_embed_masks(const HglSamDecoderW* w, const float* mask_input, int P,
  * stages, or HGL_SAM_DEC_FUSED) and returns the previous one; mask < 0 only queries.  Fused and unfused stages agree to
  * fp32 rounding: the switch exists for timing and for that test. */
 int hgl_sam_decoder_fusion(int mask);
+
+/* Attention on pre-split operands (split-fp16 mode): the in-projection GEMMs of SAM's encoder blocks and of CLIP's residual
+ * blocks write q | k | v as fp16 hi / lo planes and the attention kernel stages them by LDS-DMA without converting
+ * (csrc/attention_ps.hip).  on >= 0 sets the switch (default on, or HGL_ATTN_PS) and returns the previous value; on < 0 only
+ * queries.  Both paths evaluate the same products on the same hi / lo values: the switch exists for timing and for the
+ * test that compares them. */
+int hgl_attention_presplit(int on);
 
 /* Sam.postprocess_masks + the per-candidate AMG statistics in one pass
  * (modeling/sam.py:133-162, automatic_mask_generator.py:287-308, utils/amg.py:156-176,303-346):
