@@ -212,6 +212,8 @@ int hgl_launch_relpos_gather(const float* T, int B, int heads, int S, int size, 
                              float* rel, hipStream_t st);
 int hgl_launch_relpos_direct(const float* qkv, int ldq, int B, int heads, int S, int size, int hd,
                              const float* Rh, const float* Rw, float* rel_h, float* rel_w, hipStream_t st);
+int hgl_launch_relpos_split(const void* q_hi, const void* q_lo, int ldq, int B, int heads, int S, int size, int hd,
+                            const float* Rh, const float* Rw, float* rel_h, float* rel_w, hipStream_t st);
 int hgl_launch_im2col3x3(const float* in, int g, int C, float* cols, hipStream_t st);
 int hgl_launch_add_rows_bcast(const float* a, long long a_bstride, const float* pe, long long rows_elems,
                               int B, float* out, hipStream_t st);

@@ -92,6 +92,11 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
   uint16_t* Fl = Fh + (size_t)T * 4 * D;
   uint16_t* Qh = (uint16_t*)p.QKV;                  // split qkv (aliases the fp32 tensor)
   uint16_t* Ql = Qh + (size_t)M * 3 * D;
+  // global blocks (the whole 64 x 64 grid, rel-pos terms as tensors): the same split planes, the terms from the split q
+  static int ps_glob_on = -1;     // HGL_ATTN_PS_GLOBAL=0: the global blocks keep the fp32-input kernels (A/B timing)
+  if (ps_glob_on < 0) { const char* v = getenv("HGL_ATTN_PS_GLOBAL"); ps_glob_on = (v && v[0] == '0') ? 0 : 1; }
+  const bool ps_glob = x3 && ws == 0 && (hd == 80 || hd == 64) && size == 64 && ps_glob_on && hgl_attention_ps_enabled() &&
+                       (size_t)M * 3 * D * 2 + (size_t)(S + 1) * 3 * D * 2 < (1ull << 32);
   bool ps_win = false;
   if (x3 && ws == 14 && hd == 80 && S == 196 && hgl_attention_ps_enabled()) {
     const void *th = nullptr, *tl = nullptr;
@@ -114,7 +119,9 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
     }
     // q | k | v as fp16 hi / lo planes (the in-projection's write-out splits; same bytes as the fp32 tensor) for the attention
     // kernel that stages them by LDS-DMA without converting (attention_ps.hip): the 14 x 14 windows at head dim 80
-    if (ps_win) {
+    if (ps_glob) {
+      HGL_TRY(hgl_launch_gemm_f16x3(Ah, Al, D, b.qkv_w, b.qkv_b, nullptr, 0, nullptr, Qh, Ql, 3 * D, M, 3 * D, D, HGL_ACT_NONE, st));
+    } else if (ps_win) {
       if (M > T && padskip) {
         HGL_TRY(hgl_launch_fill_rows_split(Qh, Ql, 3 * D, p.pad_list, p.pad_count, p.n_pad_max, b.qkv_b, 3 * D, st));
         HGL_TRY(hgl_launch_gemm_f16x3_maps(Ah, Al, D, p.pad_of, b.qkv_w, b.qkv_b, nullptr, 0, 0, p.pad_of, nullptr, Qh, Ql, 3 * D,
@@ -146,6 +153,15 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
     const int rc = hgl_launch_attention_ps(Qh, Ql, 3 * D, 0, D, 2 * D, S, B, heads, S, hd, nullptr, Ah, Al, D, (long long)S * D,
                                            1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, nullptr, nullptr, 0, 0,
                                            b.rel_pos_h, b.rel_pos_w, st);
+    if (rc < 0) return rc;
+    HGL_REQUIRE(rc == 0, "sam_encode: the pre-split attention refused a shape its caller had checked");
+    goto attention_done;
+  }
+  if (ps_glob) {
+    HGL_TRY(hgl_launch_relpos_split(Qh, Ql, 3 * D, B, heads, S, size, hd, b.rel_pos_h, b.rel_pos_w, p.relh, p.relw, st));
+    const int rc = hgl_launch_attention_ps(Qh, Ql, 3 * D, 0, D, 2 * D, S, B, heads, S, hd, nullptr, Ah, Al, D, (long long)S * D,
+                                           1.0f / sqrtf((float)hd), HGL_MASK_NONE, nullptr, 0, 0, p.relh, p.relw, size, size,
+                                           nullptr, nullptr, st);
     if (rc < 0) return rc;
     HGL_REQUIRE(rc == 0, "sam_encode: the pre-split attention refused a shape its caller had checked");
     goto attention_done;

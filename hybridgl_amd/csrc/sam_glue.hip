@@ -185,10 +185,13 @@ __global__ __launch_bounds__(256) void relpos_direct_kernel(const float* __restr
 // 16-byte read per 4 fmas): 30 us per windowed block against ~10 for the bytes this one moves.
 typedef _Float16 rp_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 rp_h4 __attribute__((ext_vector_type(4)));
-template <int HD, int NT>
+// PS: q arrives as the fp16 hi / lo planes of the in-projection's split write-out (q_hi, q_lo; ldq in halfs; qkv unused)
+template <int HD, int NT, bool PS = false>
 __global__ __launch_bounds__(256) void relpos_mfma_kernel(const float* __restrict__ qkv, int ldq, int heads, int S, int size,
                                                           const float* __restrict__ Rh, const float* __restrict__ Rw,
-                                                          float* __restrict__ rel_h, float* __restrict__ rel_w) {
+                                                          float* __restrict__ rel_h, float* __restrict__ rel_w,
+                                                          const _Float16* __restrict__ q_hi = nullptr,
+                                                          const _Float16* __restrict__ q_lo = nullptr) {
   constexpr int KS = HD / 16;          // k steps
   constexpr int TP = HD + 8;           // halfs per staged table row (16-byte aligned, odd multiple of 16 B)
   constexpr int GP = NT * 32 + 1;      // floats per query row of the gather patch
@@ -204,8 +207,23 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const float* __restric
   // the wave's 32 query vectors, split once and used for both axes
   const int q = (blockIdx.x * 4 + wave) * 32 + r;
   const bool qvalid = q < S;
-  const float* qp = qkv + ((long long)b * S + (qvalid ? q : 0)) * ldq + hh * HD;
   rp_h8 qh[KS], ql[KS];
+  if constexpr (PS) {
+    const long long qo = ((long long)b * S + (qvalid ? q : 0)) * ldq + hh * HD + 8 * h;
+#pragma unroll
+    for (int c = 0; c < KS; ++c) {
+      qh[c] = *(const rp_h8*)(q_hi + qo + 16 * c);
+      ql[c] = *(const rp_h8*)(q_lo + qo + 16 * c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!qvalid) {
+#pragma unroll
+      for (int c = 0; c < KS; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qh[c][e] = (_Float16)0.f; ql[c][e] = (_Float16)0.f; }
+    }
+  } else {
+  const float* qp = qkv + ((long long)b * S + (qvalid ? q : 0)) * ldq + hh * HD;
   // one batch of loads, then the splits: a split right behind its load (hgl_split_hi_lo's opaque asm) is one serial memory
   // round trip per 16-byte piece
   f32x4 qraw[KS][2];
@@ -231,6 +249,7 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const float* __restric
         ql[c][4 * half + e] = l0;
       }
     }
+  }
   }
   float* Gw = G + (wave * 32 + r) * GP;
   for (int axis = 0; axis < 2; ++axis) {
@@ -1256,6 +1275,30 @@ int hgl_launch_relpos_direct(const float* qkv, int ldq, int B, int heads, int S,
   if (hd == 80) hipLaunchKernelGGL(relpos_direct_kernel<80>, grid, dim3(256), lds, st, qkv, ldq, heads, S, size, Rh, Rw, rel_h, rel_w);
   else hipLaunchKernelGGL(relpos_direct_kernel<64>, grid, dim3(256), lds, st, qkv, ldq, heads, S, size, Rh, Rw, rel_h, rel_w);
   return hgl_check_launch("relpos_direct");
+}
+// the same tables from q given as split planes (f16x3 mode, size 14 or 64); ldq in halfs
+int hgl_launch_relpos_split(const void* q_hi, const void* q_lo, int ldq, int B, int heads, int S, int size, int hd,
+                            const float* Rh, const float* Rw, float* rel_h, float* rel_w, hipStream_t st) {
+  HGL_REQUIRE((hd == 80 || hd == 64) && (size == 14 || size == 64) && q_hi && q_lo && (ldq & 7) == 0,
+              "relpos_split: unsupported shape (hd %d, size %d)", hd, size);
+  const int NT = size == 14 ? 1 : 4;
+  const dim3 gridm((unsigned)((S + 127) / 128), (unsigned)(B * heads), 1);
+  const size_t ldsm = (size_t)2 * NT * 32 * (hd + 8) * sizeof(_Float16) + (size_t)4 * 32 * (NT * 32 + 1) * sizeof(float);
+#define HGL_RPS_LAUNCH(HD_, NT_)                                                                                         \
+  do {                                                                                                                 \
+    if (hipFuncSetAttribute((const void*)relpos_mfma_kernel<HD_, NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm) != hipSuccess) { \
+      hgl_set_error("relpos_split: cannot reserve %zu bytes of LDS", ldsm);                                           \
+      return HGL_ELAUNCH;                                                                                              \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((relpos_mfma_kernel<HD_, NT_, true>), gridm, dim3(256), ldsm, st, (const float*)nullptr, ldq, heads, S, size, Rh, \
+                       Rw, rel_h, rel_w, (const _Float16*)q_hi, (const _Float16*)q_lo);                                \
+  } while (0)
+  if (hd == 80 && NT == 1) HGL_RPS_LAUNCH(80, 1);
+  else if (hd == 80) HGL_RPS_LAUNCH(80, 4);
+  else if (NT == 1) HGL_RPS_LAUNCH(64, 1);
+  else HGL_RPS_LAUNCH(64, 4);
+#undef HGL_RPS_LAUNCH
+  return hgl_check_launch("relpos_split");
 }
 int hgl_launch_win_maps(int g, int ws, int nw, int nb, int* pad_of, int* tok_of, int* pad_list, int* pad_count, hipStream_t st) {
   if (hipMemsetAsync(pad_count, 0, sizeof(int), st) != hipSuccess) {
