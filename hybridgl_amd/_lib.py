@@ -165,6 +165,7 @@ PROTOTYPES = {
     "hgl_sam_embed_masks": (_I, [C.POINTER(HglSamDecoderW), _VP, _I, _VP, _VP]),
     "hgl_sam_decoder_fusion": (_I, [_I]),
     "hgl_attention_presplit": (_I, [_I]),
+    "hgl_attention_presplit_f32": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _I, C.c_float, _I, _VP, _I, _I, _VP, C.c_size_t, _VP]),
     "hgl_sam_postprocess_workspace_bytes": (_SZ, [_I]),
     "hgl_sam_postprocess": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _VP, _VP, _VP, _VP, _VP,
                                  _VP, _SZ, _VP]),

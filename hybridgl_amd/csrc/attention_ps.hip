@@ -1204,6 +1204,9 @@ int hgl_launch_attention_ps(const void* qkv_hi, const void* qkv_lo, int ld, int 
   a.nqb = 1;
   static const int dbg = getenv("HGL_ATTN_PS_DBG") ? atoi(getenv("HGL_ATTN_PS_DBG")) : 0;
   a.dbg = dbg;
+  // the 197-token CLIP sequences: 1 = one workgroup per item with two query tiles per wave (K / V staged once),
+  // 2 = the pipelined persistent kernel with two workgroups per item
+  static const int clip_kernel = getenv("HGL_ATTN_PS_CLIP") ? atoi(getenv("HGL_ATTN_PS_CLIP")) : 1;
   enum { K_NONE, K_WIN, K_RELT80, K_RELT64, K_CLIP, K_PLAIN80, K_PLAIN64 } kind = K_NONE;
   if (tab_h) {
     const void *hh = nullptr, *hl = nullptr, *wh = nullptr, *wl = nullptr;
@@ -1222,10 +1225,10 @@ int hgl_launch_attention_ps(const void* qkv_hi, const void* qkv_lo, int ld, int 
       a.nqb = (S + 127) / 128;
       kind = hd == 80 ? K_RELT80 : K_RELT64;
     }
-  } else if (hd == 64 && S > 128 && S <= 256) {
+  } else if (hd == 64 && S > 128 && S <= 256 && clip_kernel == 1) {
     kind = K_CLIP;    // one 4-wave workgroup per item, two query tiles per wave
-  } else if (mask_kind == HGL_MASK_NONE) {
-    a.nqb = (S + 127) / 128;   // blocks of 128 queries
+  } else if (mask_kind == HGL_MASK_NONE || (mask_kind == HGL_MASK_CLS_KEEP && S <= 257)) {
+    a.nqb = (S + 127) / 128;   // blocks of 128 queries (the CLS keep row of an item sits in 256 bytes of LDS)
     kind = hd == 80 ? K_PLAIN80 : K_PLAIN64;
   }
   if (kind == K_NONE) return 1;
@@ -1249,4 +1252,27 @@ int hgl_launch_attention_ps(const void* qkv_hi, const void* qkv_lo, int ld, int 
     case K_PLAIN80: return ps_launch<80, PS_PLAIN, 1>(a, st);
     default: return ps_launch<64, PS_PLAIN, 1>(a, st);
   }
+}
+
+// The same kernels behind the C ABI for tests and micro-benchmarks: qkv [B*S, ld] fp32 with q | k | v at columns 0, H*hd, 2*H*hd is
+// split into fp16 hi / lo planes in `scratch` (>= B*S*ld*4 bytes) the way the in-projection's write-out splits it, then
+// multiplied.  HGL_EINVAL when the shape is not one the pre-split kernels serve.
+extern "C" int hgl_attention_presplit_f32(const float* qkv, int ld, int B, int H, int S, int hd, float* out, int ldo, float scale,
+                                          int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, void* scratch,
+                                          size_t scratch_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(qkv && out && scratch && B > 0 && H > 0 && S > 0 && ld >= 3 * H * hd && (ld & 7) == 0, "attention_presplit: bad arguments");
+  const size_t n = (size_t)B * S * ld;
+  HGL_REQUIRE(scratch_bytes >= n * 4, "attention_presplit: scratch too small (%zu bytes for %zu)", scratch_bytes, n * 4);
+  HGL_REQUIRE(hgl_precision() == HGL_PREC_F16X3, "attention_presplit: split-fp16 mode only");
+  hipStream_t st = (hipStream_t)stream;
+  uint16_t* hi = (uint16_t*)scratch;
+  uint16_t* lo = hi + n;
+  HGL_TRY(hgl_launch_split_f16(qkv, 1.0f, hi, lo, (long long)n, st));
+  const int prev = hgl_attention_presplit(1);
+  const int rc = hgl_launch_attention_ps(hi, lo, ld, 0, H * hd, 2 * H * hd, S, B, H, S, hd, out, nullptr, nullptr, ldo, (long long)S * ldo,
+                                         scale, mask_kind, keep, keep_b0, keep_n, nullptr, nullptr, 0, 0, nullptr, nullptr, st);
+  hgl_attention_presplit(prev);
+  HGL_REQUIRE(rc <= 0, "attention_presplit: shape not served (B %d, H %d, S %d, hd %d, mask %d)", B, H, S, hd, mask_kind);
+  return rc;
 }

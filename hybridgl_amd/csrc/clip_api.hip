@@ -25,15 +25,31 @@ bool hgl_clip_block_uses_x3(const HglResBlockW& w, int M, int D) {
          hgl_use_x3(w.proj_w, 4 * D) && (D % 256) == 0;
 }
 
+// the attention of a block runs on q | k | v as fp16 hi / lo planes (attention_ps.hip): head dim 64, sequences of more
+// than 128 tokens, no causal mask, a CLS keep mask only up to 257 keys -- CLIP's image sequences and GEM's 785 tokens
+bool hgl_clip_block_presplit(const HglResBlockW& w, int B, int S, int D, int heads, int mask_kind) {
+  const int hd = D / heads;
+  return hgl_clip_block_uses_x3(w, B * S, D) && hgl_attention_ps_enabled() && hd == 64 && S > 128 &&
+         (mask_kind == HGL_MASK_NONE || (mask_kind == HGL_MASK_CLS_KEEP && S <= 257)) &&
+         (size_t)B * S * 3 * D * 2 + (size_t)(S + 1) * 3 * D * 2 < (1ull << 32);
+}
+
 // first half of a block: H = ln_1(X) (fp32, or the fp16 hi+lo pair aliasing bf.H on the split path), QKV = H W_in + b
-int hgl_clip_block_qkv(const HglResBlockW& w, const float* X, int M, int D, const HglBlockBufs& bf, hipStream_t st) {
+// (split_out: q | k | v as fp16 hi / lo planes aliasing bf.QKV, for hgl_clip_block_rest(..., qkv_split = true))
+int hgl_clip_block_qkv(const HglResBlockW& w, const float* X, int M, int D, const HglBlockBufs& bf, hipStream_t st, bool split_out) {
   if (hgl_clip_block_uses_x3(w, M, D)) {
     uint16_t* Hh = (uint16_t*)bf.H;
     uint16_t* Hl = Hh + (size_t)M * D;
     HGL_TRY(hgl_launch_layernorm_split(X, w.ln1_w, w.ln1_b, Hh, Hl, M, D, 1e-5f, st));
+    if (split_out) {
+      uint16_t* Qh = (uint16_t*)bf.QKV;
+      return hgl_launch_gemm_f16x3(Hh, Hl, D, w.in_proj_w, w.in_proj_b, nullptr, 0, nullptr, Qh, Qh + (size_t)M * 3 * D, 3 * D, M,
+                                   3 * D, D, HGL_ACT_NONE, st);
+    }
     return hgl_launch_gemm_f16x3(Hh, Hl, D, w.in_proj_w, w.in_proj_b, nullptr, 0, bf.QKV, nullptr, nullptr, 3 * D, M, 3 * D, D,
                                  HGL_ACT_NONE, st);
   }
+  HGL_REQUIRE(!split_out, "clip_block_qkv: split output exists on the split-fp16 path only");
   HGL_TRY(hgl_launch_layernorm(X, w.ln1_w, w.ln1_b, bf.H, M, D, 1e-5f, st));
   return hgl_launch_gemm(bf.H, w.in_proj_w, w.in_proj_b, nullptr, bf.QKV, M, 3 * D, D, D, D, 0, 3 * D, 1, 0, 0, 0, 0,
                          HGL_ACT_NONE, st);
@@ -41,7 +57,7 @@ int hgl_clip_block_qkv(const HglResBlockW& w, const float* X, int M, int D, cons
 
 // second half: x <- x + out_proj(attention(QKV)) ; x <- x + mlp(ln_2 x)
 int hgl_clip_block_rest(const HglResBlockW& w, float* X, int B, int S, int D, int heads, const HglBlockBufs& bf,
-                        int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st) {
+                        int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st, bool qkv_split) {
   const int M = B * S;
   const int hd = D / heads;
   const long long sQKV = (long long)S * 3 * D;
@@ -52,9 +68,18 @@ int hgl_clip_block_rest(const HglResBlockW& w, float* X, int B, int S, int D, in
     uint16_t* Fh = (uint16_t*)bf.F;
     uint16_t* Fl = Fh + (size_t)M * 4 * D;
     // the attention writes its output as the fp16 hi+lo pair the out-projection reads
+    if (qkv_split) {
+      const uint16_t* Qh = (const uint16_t*)bf.QKV;
+      const int rc = hgl_launch_attention_ps(Qh, Qh + (size_t)M * 3 * D, 3 * D, 0, D, 2 * D, S, B, heads, S, hd, nullptr, Hh, Hl, D,
+                                             (long long)S * D, 1.0f / sqrtf((float)hd), mask_kind, keep, keep_b0, keep_n, nullptr,
+                                             nullptr, 0, 0, nullptr, nullptr, st);
+      if (rc < 0) return rc;
+      HGL_REQUIRE(rc == 0, "clip_block: the pre-split attention refused a shape its caller had checked");
+    } else {
     HGL_TRY(hgl_launch_attention_split(bf.QKV, bf.QKV + D, bf.QKV + 2 * D, nullptr, Hh, Hl, B, heads, S, S, hd, 3 * D, 3 * D,
                                        3 * D, D, sQKV, sQKV, sQKV, (long long)S * D, 1.0f / sqrtf((float)hd), mask_kind, keep,
                                        keep_b0, keep_n, nullptr, nullptr, 0, 0, st));
+    }
     HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, w.out_proj_w, w.out_proj_b, X, D, X, nullptr, nullptr, D, M, D, D,
                                   HGL_ACT_NONE, st));
     HGL_TRY(hgl_launch_layernorm_split(X, w.ln2_w, w.ln2_b, Hh, Hl, M, D, 1e-5f, st));
@@ -74,6 +99,7 @@ int hgl_clip_block_rest(const HglResBlockW& w, float* X, int B, int S, int D, in
     }
     return HGL_OK;
   }
+  HGL_REQUIRE(!qkv_split, "clip_block_rest: split qkv exists on the split-fp16 path only");
   HGL_TRY(hgl_launch_attention(bf.QKV, bf.QKV + D, bf.QKV + 2 * D, bf.H, B, heads, S, S, hd, 3 * D,
                                3 * D, 3 * D, D, sQKV, sQKV, sQKV, (long long)S * D, 1.0f / sqrtf((float)hd),
                                mask_kind, keep, keep_b0, keep_n, nullptr, nullptr, 0, 0, st));
@@ -90,8 +116,9 @@ int hgl_clip_block_rest(const HglResBlockW& w, float* X, int B, int S, int D, in
 // x <- x + attn(ln_1 x) ; x <- x + mlp(ln_2 x)      (clip/model.py:244-257)
 int hgl_clip_run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, const HglBlockBufs& bf,
                        int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st) {
-  HGL_TRY(hgl_clip_block_qkv(w, X, B * S, D, bf, st));
-  return hgl_clip_block_rest(w, X, B, S, D, heads, bf, mask_kind, keep, keep_b0, keep_n, st);
+  const bool ps = hgl_clip_block_presplit(w, B, S, D, heads, mask_kind);
+  HGL_TRY(hgl_clip_block_qkv(w, X, B * S, D, bf, st, ps));
+  return hgl_clip_block_rest(w, X, B, S, D, heads, bf, mask_kind, keep, keep_b0, keep_n, st, ps);
 }
 
 // patch embedding + cls + pos + ln_pre for `n_img` images -> X [n_img, S, D]; cols holds the im2col matrix

@@ -189,9 +189,11 @@ struct HglBlockBufs {
 int hgl_clip_run_block(const HglResBlockW& w, float* X, int B, int S, int D, int heads, const HglBlockBufs& bf,
                        int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st);
 bool hgl_clip_block_uses_x3(const HglResBlockW& w, int M, int D);
-int hgl_clip_block_qkv(const HglResBlockW& w, const float* X, int M, int D, const HglBlockBufs& bf, hipStream_t st);
+bool hgl_clip_block_presplit(const HglResBlockW& w, int B, int S, int D, int heads, int mask_kind);
+int hgl_clip_block_qkv(const HglResBlockW& w, const float* X, int M, int D, const HglBlockBufs& bf, hipStream_t st,
+                       bool split_out = false);
 int hgl_clip_block_rest(const HglResBlockW& w, float* X, int B, int S, int D, int heads, const HglBlockBufs& bf,
-                        int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st);
+                        int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, hipStream_t st, bool qkv_split = false);
 int hgl_clip_embed_images(const HglClipVisionW* w, const float* imgs, int n_img, float* X, float* cols, float* tok,
                           hipStream_t st);
 

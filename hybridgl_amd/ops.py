@@ -215,6 +215,26 @@ def attention(q, k, v, heads, scale=None, mask="none", keep=None, keep_b0=0, kee
     return out
 
 
+def attention_presplit(qkv, heads, scale=None, mask="none", keep=None, keep_b0=0, keep_n=0):
+    """qkv: [B,S,3*H*hd] fp32 contiguous (the in-projection output, q | k | v) -> [B,S,H*hd] through the kernels that take
+    the fp16 hi / lo planes (csrc/attention_ps.hip); split-fp16 mode, hd in {64, 80}."""
+    lib = _lib.load()
+    B, S, D3 = qkv.shape
+    Dm = D3 // 3
+    hd = Dm // heads
+    if scale is None:
+        scale = hd ** -0.5
+    out = torch.empty((B, S, Dm), dtype=torch.float32, device=qkv.device)
+    scratch = torch.empty(B * S * D3, dtype=torch.float32, device=qkv.device)
+    kp = None
+    if keep is not None:
+        kp, keep = _u8(keep, "keep")
+    check(lib.hgl_attention_presplit_f32(_dev(qkv, torch.float32, "qkv"), D3, B, heads, S, hd, _dev(out, torch.float32, "out"), Dm,
+                                         float(scale), MASK[mask], kp, keep_b0, keep_n, scratch.data_ptr(), scratch.numel() * 4,
+                                         _stream()), "hgl_attention_presplit_f32")
+    return out
+
+
 def mask_resize(masks, g):
     """TF.resize(masks.float(), (g,g)) of model/backbone.py:160 -> [N, g*g] fp32."""
     lib = _lib.load()

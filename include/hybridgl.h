@@ -504,6 +504,13 @@ int hgl_sam_decoder_fusion(int mask);
  * queries.  Both paths evaluate the same products on the same hi / lo values: the switch exists for timing and for the
  * test that compares them. */
 int hgl_attention_presplit(int on);
+/* The pre-split kernels on a packed fp32 in-projection output (tests, micro-benchmarks): qkv [B*S, ld] with q | k | v at
+ * columns 0, H*hd, 2*H*hd (ld >= 3*H*hd, a multiple of 8) is split into fp16 hi / lo planes in scratch (>= B*S*ld*4 bytes)
+ * exactly as the GEMM write-out splits it, then multiplied: out [B*S, ldo] fp32.  hd in {64, 80}; mask_kind
+ * HGL_MASK_NONE, or HGL_MASK_CLS_KEEP for S <= 257 (keep as for hgl_attention_f32).  Split-fp16 mode only. */
+int hgl_attention_presplit_f32(const float* qkv, int ld, int B, int H, int S, int hd, float* out, int ldo, float scale,
+                               int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, void* scratch,
+                               size_t scratch_bytes, void* stream);
 
 /* Sam.postprocess_masks + the per-candidate AMG statistics in one pass
  * (modeling/sam.py:133-162, automatic_mask_generator.py:287-308, utils/amg.py:156-176,303-346):
