@@ -134,100 +134,114 @@ def prof_read(lib, cls):
     return n.value, ms.value, fl.value, by.value
 
 
-def cpu_baseline_sam():
-    """SAM stages of the oracle on a bounded sample: one windowed + one global ViT-H block (scaled
-    x28 / x4), the neck, the decoder on 2 of 64 prompts (x32), post-processing on 6 of 192 (x32)."""
-    from hybridgl_amd import synth, weights
-    from oracle import sam_oracle as S
-    cfg = weights.SAM_CONFIGS["vit_h_d2"]
-    sd = weights.sam_state_dict("vit_h_d2", 0)
-    img = synth.synth_image(1024, 1024, 1000)
-    x = S.preprocess(img, 1024)
-    t0 = time.perf_counter()
-    w = sd["image_encoder.patch_embed.proj.weight"]
-    cols = x.reshape(3, 64, 16, 64, 16).transpose(1, 3, 0, 2, 4).reshape(4096, 768)
-    tk = (cols @ w.reshape(1280, -1).T + sd["image_encoder.patch_embed.proj.bias"]).reshape(1, 64, 64, 1280)
-    tk = (tk + sd["image_encoder.pos_embed"]).astype(np.float32)
-    t1 = time.perf_counter()
-    b0 = S.encoder_block(tk, sd, "image_encoder.blocks.0", 16, 14)
-    t2 = time.perf_counter()
-    b1 = S.encoder_block(b0, sd, "image_encoder.blocks.1", 16, 0)
-    t3 = time.perf_counter()
-    n = b1[0].reshape(4096, 1280) @ sd["image_encoder.neck.0.weight"].reshape(-1, 1280).T
-    n = S.layer_norm_2d(n.reshape(64, 64, -1).astype(np.float32), sd["image_encoder.neck.1.weight"], sd["image_encoder.neck.1.bias"])
-    n = S.layer_norm_2d(S.conv3x3_nhwc(n, sd["image_encoder.neck.2.weight"]), sd["image_encoder.neck.3.weight"], sd["image_encoder.neck.3.bias"])
-    t4 = time.perf_counter()
-    pts = S.point_grid(8)[:2] * 1024.0
-    low, iou = S.mask_decoder(sd, n, S.embed_points(sd, pts, 1024))
-    t5 = time.perf_counter()
-    full = S.postprocess_masks(low, (1024, 1024), (640, 640))
-    S.stability_score(full.reshape(6, 640, 640)); S.mask_to_box(full.reshape(6, 640, 640) > 0)
-    t6 = time.perf_counter()
-    t_img = (t1 - t0) + (t2 - t1) * 28 + (t3 - t2) * 4 + (t4 - t3) + (t5 - t4) * 32 + (t6 - t5) * 32
-    return t_img, (f"SAM ViT-H: 1 windowed block {t2 - t1:.1f}s x28 + 1 global block {t3 - t2:.1f}s x4 + neck, "
-                   f"decoder on 2 of 64 prompts {t5 - t4:.1f}s x32, post-process 6 of 192 {t6 - t5:.1f}s x32")
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(fusion_mode, n_sample=8, with_sam=True, with_gem=False, clip_name="ViT-B/16"):
-    """Oracle (numpy port of the reference algorithm, oracle/clip_oracle.py) timed on the host
-    cores for a bounded sample of the same workload; extrapolated to one ref."""
+def cpu_baseline(fusion_mode, with_sam=True, with_gem=False, clip_name="ViT-B/16", host_cores=None):
+    """The reference's CPU path restated in plain PyTorch (oracle/torch_cpu.py: nn.Linear / LayerNorm / softmax / matmul in
+    fp32, the operators the reference runs with device = "cpu", Hybridgl_main.py:30-34), timed on the host cores: ONE ref of
+    the benchmarked workload, UNSAMPLED where the work is -- the CLIP hybrid encoder on all 64 masks, the 12 text strings, all
+    32 blocks of the SAM ViT-H encoder, the mask decoder on all 64 prompts.  The cheap stages (blur, view synthesis, the
+    three-sentence tail, post-processing of a sample of the candidates) run through the numpy oracle.  The bench confines
+    itself to 32 cores and shrinks torch's thread pool for the GPU run: both are undone for this leg (every core the process
+    was started on, torch threads = that count) and restored afterwards."""
+    import torch
     from hybridgl_amd import synth, weights
     from oracle import clip_oracle as O
-    threads = os.cpu_count() or 1
-    geom = CLIP_GEOM[clip_name]
-    sd = weights.clip_state_dict(clip_name, 0)
-    H = W = 640
-    img = synth.synth_image(H, W, 1000)
     from oracle import cv_oracle as CV
-    norm = synth.imagenet_normalize(img)
-    masks = synth.synth_masks(64, H, W, 2000)
-    boxes = synth.boxes_from_masks(masks)
-    tokens = synth.synth_tokens(9, 77, 49408, 3000)
-    tb = time.perf_counter()
-    blur = CV.gaussian_blur_u8(img, 15)
-    t0 = time.perf_counter()
-    loc, glo = O.synthesize_views(img, blur, norm, masks[:n_sample], 224)
-    t1 = time.perf_counter()
-    feats = O.clip_hybrid_forward(sd, loc, glo, masks[:n_sample], geom["masking_block"], fusion_mode, geom["last_layer"])
-    t2 = time.perf_counter()
-    text = O.encode_text(sd, tokens, heads=geom["text_D"] // 64)
-    t3 = time.perf_counter()
-    hyb = np.concatenate([feats] * (64 // n_sample), 0)
-    for j in range(3):
-        d, r, nn = synth.PARSE_RECORDS[j]
-        attn = synth.synth_heatmap(H, W, 4000 + j)
-        gem = O.coherence_scores(attn, masks, d, 1.8)
-        ip, ifin, _, _ = O.score_sentence(hyb, 0.5 * text[3 * j:3 * j + 1] + 0.5 * text[3 * j + 1:3 * j + 2],
-                                          text[3 * j + 2:3 * j + 3], boxes, gem, 100.0, 3, 6, 0.6, r, nn != 0)
-        O.compute_iou(masks[ip], masks[0]); O.compute_iou(masks[ifin], masks[0])
-    t4 = time.perf_counter()
-    scale = 64 / n_sample
-    t_ref = (t0 - tb) + (t1 - t0) * scale + (t2 - t1) * scale + (t3 - t2) + (t4 - t3)
-    gem_note = ""
-    if with_gem:
-        from hybridgl_amd.gem import get_gem_img_transform
-        from oracle import gem_oracle as GO
-        timg = get_gem_img_transform()(img).numpy()
-        t5 = time.perf_counter()
-        feat, _ = GO.gem_vit_forward(sd, timg[None])
-        heat = GO.gem_heatmap(feat[0], text[:3], 448)
-        GO.resize_bilinear_aa(heat, H, W)
-        t6 = time.perf_counter()
-        t_ref += (t6 - t5) + (t3 - t2) / 3.0
-        gem_note = f"; GEM heat-maps: 1 image encode at 448 + 3 maps ({t6 - t5:.1f}s; the reference re-encodes per sentence) + 3 prompts"
-    sam_note = ""
-    if with_sam:
-        t_sam, sam_note = cpu_baseline_sam()
-        t_ref += t_sam
-        sam_note = "; " + sam_note
-    return {"value": 1.0 / t_ref, "unit": "images/s", "cores": threads, "kind": "port",
+    from oracle import sam_oracle as S
+    from oracle import torch_cpu as T
+    pinned = sorted(os.sched_getaffinity(0))
+    threads_before = torch.get_num_threads()
+    if host_cores:
+        try:
+            os.sched_setaffinity(0, host_cores)
+        except OSError:
+            pass
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    try:
+        geom = CLIP_GEOM[clip_name]
+        sd = weights.clip_state_dict(clip_name, 0)
+        sdt = T.to_torch(sd)
+        H = W = 640
+        img = synth.synth_image(H, W, 1000)
+        norm = synth.imagenet_normalize(img)
+        masks = synth.synth_masks(64, H, W, 2000)
+        boxes = synth.boxes_from_masks(masks)
+        tokens = synth.synth_tokens(12 if with_gem else 9, 77, 49408, 3000)
+        stages = {}
+        with torch.no_grad():
+            t = time.perf_counter()
+            blur = CV.gaussian_blur_u8(img, 15)
+            loc, glo = O.synthesize_views(img, blur, norm, masks, 224)
+            stages["blur + view synthesis (numpy)"] = time.perf_counter() - t
+            t = time.perf_counter()
+            feats = T.clip_hybrid_forward(sdt, torch.from_numpy(loc), torch.from_numpy(glo), torch.from_numpy(masks),
+                                          geom["masking_block"], fusion_mode, geom["last_layer"]).numpy()
+            stages[f"CLIP {clip_name} hybrid {fusion_mode}, 64 masks"] = time.perf_counter() - t
+            t = time.perf_counter()
+            text = T.encode_text(sdt, tokens).numpy()
+            stages[f"text encoder, {len(tokens)} strings"] = time.perf_counter() - t
+            t = time.perf_counter()
+            for j in range(3):
+                d, r, nn = synth.PARSE_RECORDS[j]
+                attn = synth.synth_heatmap(H, W, 4000 + j)
+                gem = O.coherence_scores(attn, masks, d, 1.8)
+                ip, ifin, _, _ = O.score_sentence(feats, 0.5 * text[3 * j:3 * j + 1] + 0.5 * text[3 * j + 1:3 * j + 2],
+                                                  text[3 * j + 2:3 * j + 3], boxes, gem, 100.0, 3, 6, 0.6, r, nn != 0)
+                O.compute_iou(masks[ip], masks[0]); O.compute_iou(masks[ifin], masks[0])
+            stages["3-sentence tail + IoU (numpy)"] = time.perf_counter() - t
+            if with_gem:
+                from hybridgl_amd.gem import get_gem_img_transform
+                from oracle import gem_oracle as GO
+                timg = get_gem_img_transform()(img).numpy()
+                t = time.perf_counter()
+                feat, _ = GO.gem_vit_forward(sd, timg[None])
+                heat = GO.gem_heatmap(feat[0], text[:3], 448)
+                GO.resize_bilinear_aa(heat, H, W)
+                stages["GEM heat-maps: 1 image at 448 + 3 maps (numpy; the reference re-encodes per sentence)"] = time.perf_counter() - t
+            if with_sam:
+                cfg = weights.SAM_CONFIGS["vit_h"]
+                ssd = weights.sam_state_dict("vit_h", 0)
+                sst = T.to_torch(ssd)
+                x = S.preprocess(S.pil_bilinear_resize(img, 1024, 1024), 1024)
+                t = time.perf_counter()
+                emb = T.image_encoder(sst, torch.from_numpy(x), cfg)
+                stages["SAM ViT-H encoder, 32 blocks"] = time.perf_counter() - t
+                pts = S.point_grid(8) * 1024.0
+                sparse = torch.from_numpy(S.embed_points(ssd, pts, 1024))
+                t = time.perf_counter()
+                low, iou = T.mask_decoder(sst, emb, sparse)
+                stages["SAM mask decoder, 64 prompts"] = time.perf_counter() - t
+                t = time.perf_counter()
+                T.postprocess_and_stats(low, (1024, 1024), (640, 640))
+                stages["post-processing, stability, boxes of the 192 candidates"] = time.perf_counter() - t
+        t_ref = sum(stages.values())
+    finally:
+        torch.set_num_threads(threads_before)
+        try:
+            os.sched_setaffinity(0, pinned)
+        except OSError:
+            pass
+    return {"value": 1.0 / t_ref, "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
+            "torch_threads": cores, "seconds_per_ref": t_ref,
+            "stages_s": {k: round(v, 3) for k, v in stages.items()},
             "reference_torch_cpu": {"value": 0.014, "unit": "images/s", "cores": 8,
                                     "note": "the reference's own torch CPU path (imported, seeded weights) measured in the build "
                                             "container on 8 vCPU, BASELINE.md section 2 / SURVEY.md section 6: ~73 s per ref; the reference "
                                             "cannot travel to the GPU box, so this number is quoted, not re-measured there"},
-            "sample": f"numpy oracle: views+CLIP hybrid {fusion_mode} on {n_sample} of 64 masks "
-                      f"({t2 - t0:.1f}s, scaled x{scale:g}), 9 text strings ({t3 - t2:.1f}s), "
-                      f"3-sentence tail on 64 masks ({t4 - t3:.1f}s){gem_note}{sam_note}; numpy BLAS threads = host default"}
+            "sample": "ONE ref of the benchmarked workload through oracle/torch_cpu.py (plain PyTorch fp32 on the CPU, pinned to the numpy "
+                      "oracle by tests/test_torch_cpu_baseline.py): CLIP hybrid on all 64 masks, all text strings, all 32 SAM encoder "
+                      "blocks, the decoder on all 64 prompts and the post-processing of all 192 candidates, nothing sampled or "
+                      "extrapolated; blur, views, tail and the GEM stage through the numpy oracle"}
 
 
 def live_pmc_traffic(prefix, timeout_s=150.0):
@@ -774,7 +788,8 @@ def main():
         if rccl is not None:
             rec["rccl_selfcheck"] = rccl
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(args.fusion, with_sam=args.scope == "B", with_gem=use_gem, clip_name=args.clip)
+            rec["cpu_baseline"] = cpu_baseline(args.fusion, with_sam=args.scope == "B", with_gem=use_gem, clip_name=args.clip,
+                                               host_cores=host_cores_at_start)
         os.write(real_stdout, (json.dumps(rec) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
