@@ -1340,429 +1340,6 @@ __global__ __launch_bounds__(256, 2) void attn_x3q_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wide, PERSISTENT variant for sequences of 129..256 queries (a 14 x 14 window of the SAM encoder, a 197-token CLIP
-// sequence): one 8-wave workgroup per CU walks the (batch, head) items.  In-kernel cycle stamps of the one-item-per-
-// workgroup form (1 workgroup per CU: nothing else hides its latencies) showed 28 % of an item's 38k cycles spent BEFORE
-// the first MFMA (the Q load 7.9k, the first K/V chunk 2.9k) and 23 % in the store-next-chunk / barrier gaps between
-// chunks.  Here
-//   * the raw Q rows and the first K/V chunk of the NEXT item are loaded into registers while the last chunks of the
-//     current item are multiplied (the loads have two chunks of compute to land);
-//   * the K/V chunks are double-buffered in LDS: chunk c+1 is split and stored at the START of iteration c (its
-//     buffer was released by the barrier that ended iteration c-1), so an iteration has ONE barrier and the staging
-//     VALU / ds_write work of one wave runs beside the MFMAs of the others;
-//   * the output rows are stored fire-and-forget under the next item's prologue.
-// The arithmetic of a tile (QK^T on split operands, lazy-rescaled online softmax, PV through transposing LDS reads, the
-// rel-pos bias of a 14 x 14 window as two extra k-steps against indicator columns) is that of attn_x3_kernel.
-// In-kernel cycle stamps (tools/attn_stamps.py; compiled in with -DHGL_ATTN_STAMPS only): workgroup 0, one wave
-#ifdef HGL_ATTN_STAMPS
-__device__ unsigned long long g_attn_stamps[2048];
-__device__ int g_attn_stamp_wave = 0;
-#define STAMP(id) do { if (blockIdx.x == 0 && t == 64 * g_attn_stamp_wave && nst < 2040) { g_attn_stamps[nst++] = ((unsigned long long)(id) << 48) | ((unsigned long long)clock64() & 0xffffffffffffull); } } while (0)
-#else
-#define STAMP(id) do {} while (0)
-#endif
-
-template <int HD, int RELW>
-__global__ __launch_bounds__(512, 1) void attn_x3w_kernel(AttnArgs a) {
-  constexpr int NW = 8, NT = NW * 64;
-  constexpr int KS = HD / 16;
-  constexpr int EW = RELW > 0 ? 32 : 0;
-  constexpr int KROW = 2 * HD + EW + 8;
-  static_assert(2 * RELW <= 32 && HD % 16 == 0, "unsupported shape");
-  constexpr int DT = (HD + 31) / 32;
-  constexpr int VP = HD <= 32 ? 32 : 96;
-  constexpr int F4 = HD / 4;
-  constexpr int NLK = (KV_CHUNK * F4 + NT - 1) / NT;
-  constexpr bool EXACT = KV_CHUNK * F4 % NT == 0;
-  constexpr int BUF_H = KV_CHUNK * (KROW + 2 * VP);      // halfs of one K/V buffer: [Ks | Vh | Vl]
-  constexpr int RPP = 33;
-  // head dim 80 has no registers left to carry the next item's raw Q rows across the main loop (it would spill): its Q
-  // rows are loaded at the start of the item, beside the split / store of the prefetched first K/V chunk
-  constexpr bool PREQ = HD <= 64;
-  static_assert(RELW == 0 || (size_t)NW * 2 * 32 * RPP * 4 <= (size_t)2 * BUF_H * 2, "rel-pos patch must fit the two buffers");
-  extern __shared__ __attribute__((aligned(16))) _Float16 smem_w[];
-  float* const RPatch = (float*)smem_w;                  // prologue only: aliases the (then idle) K/V buffers
-  uint8_t* const keepL = (uint8_t*)(smem_w + 2 * BUF_H);   // [256]: keepL[key - 1] = the item's CLS-keep row
-
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int q0 = wave * 32, qi = q0 + r;
-  const bool qvalid = qi < a.Sq;
-  const bool wave_active = q0 < a.Sq;
-  const int qrow = qvalid ? qi : a.Sq - 1;
-  const int nitems = a.B * a.H;
-  const int nch = (a.Sk + KV_CHUNK - 1) / KV_CHUNK;
-  constexpr float LOG2E = 1.4426950408889634f;
-  const float NEG_INF = __int_as_float(NEG_BIG_BITS);
-  float amax = 0.f;
-
-  // zero the d padding of the V rows of both buffers once (it feeds output rows that are never stored)
-  if (VP > HD) {
-    constexpr int PADW = VP - HD > 0 ? VP - HD : 1;
-    for (int i = t; i < 2 * 2 * KV_CHUNK * PADW; i += NT) {
-      const int c = i % PADW, row = (i / PADW) % KV_CHUNK, pl = (i / (PADW * KV_CHUNK)) & 1, bi = i / (2 * PADW * KV_CHUNK);
-      smem_w[bi * BUF_H + KV_CHUNK * KROW + pl * KV_CHUNK * VP + row * VP + HD + c] = (_Float16)0.f;
-    }
-  }
-  const int tr_off = (((lane >> 2) & 3) + 4 * h) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-
-  // ---- register staging: raw Q rows of the next item, one K/V chunk ----
-  f32x4 pq[2 * KS], pk[NLK], pv[NLK];
-  auto load_q = [&](int item) {
-    const int b = item / a.H, hh = item - b * a.H;
-    const float* qp = a.q + b * a.sqb + (long long)qrow * a.ldq + hh * HD + 8 * h;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      pq[2 * s] = *(const f32x4*)(qp + 16 * s);
-      pq[2 * s + 1] = *(const f32x4*)(qp + 16 * s + 4);
-    }
-  };
-  auto load_chunk = [&](int item, int kc) {
-    const int b = item / a.H, hh = item - b * a.H;
-    const float* kp = a.k + b * a.skb + hh * HD;
-    const float* vp = a.v + b * a.svb + hh * HD;
-#pragma unroll
-    for (int i = 0; i < NLK; ++i) {
-      const int idx = t + NT * i;
-      if (!EXACT && idx >= KV_CHUNK * F4) break;
-      const int row = idx / F4, c4 = idx - row * F4;
-      pk[i] = *(const f32x4*)(kp + (long long)min(kc + row, a.Sk - 1) * a.ldk + c4 * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < NLK; ++i) {
-      const int idx = t + NT * i;
-      if (!EXACT && idx >= KV_CHUNK * F4) break;
-      const int row = idx / F4, c4 = idx - row * F4;
-      pv[i] = *(const f32x4*)(vp + (long long)min(kc + row, a.Sk - 1) * a.ldv + c4 * 4);
-    }
-  };
-  auto store_chunk = [&](int kc, int bi) {
-    _Float16* Ks = smem_w + bi * BUF_H;
-    _Float16* Vh = Ks + KV_CHUNK * KROW;
-    _Float16* Vl = Vh + KV_CHUNK * VP;
-#pragma unroll
-    for (int i = 0; i < NLK; ++i) {
-      const int idx = t + NT * i;
-      if (!EXACT && idx >= KV_CHUNK * F4) break;
-      const int row = idx / F4, c4 = idx - row * F4;
-      h16x4 hi, lo;
-      split4(pk[i], hi, lo, amax);
-      *(h16x4*)(Ks + row * KROW + c4 * 4) = hi;
-      *(h16x4*)(Ks + row * KROW + HD + c4 * 4) = lo;
-    }
-    if (RELW > 0 && t < 256) {   // indicator columns: thread -> (key row t/4, 8 of the 32 columns)
-      const int row = t >> 2, j0 = 8 * (t & 3), kg = kc + row;
-      const int ih = kg / (RELW > 0 ? RELW : 1), iw = RELW + kg - ih * RELW;
-      h16x8 e;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) e[j] = (j0 + j == ih || j0 + j == iw) ? (_Float16)1.f : (_Float16)0.f;
-      *(h16x8*)(Ks + row * KROW + 2 * HD + j0) = e;
-    }
-#pragma unroll
-    for (int i = 0; i < NLK; ++i) {
-      const int idx = t + NT * i;
-      if (!EXACT && idx >= KV_CHUNK * F4) break;
-      const int row = idx / F4, c4 = idx - row * F4;
-      h16x4 hi, lo;
-      split4(pv[i], hi, lo, amax);
-      *(h16x4*)(Vh + row * VP + c4 * 4) = hi;
-      *(h16x4*)(Vl + row * VP + c4 * 4) = lo;
-    }
-  };
-
-  // CLS-keep row of an item (make_attn_mask: only query 0 is masked): one byte per thread, prefetched with the item's first
-  // K/V chunk and parked in LDS.  Per-score global byte loads (the generic kernel) serialise 16 load + wait pairs per key
-  // tile on the one wave that owns query 0 while the other seven wait for it at the chunk barrier.
-  unsigned pkeep = 1;
-  auto keep_ptr = [&](int it) -> const uint8_t* {
-    const int bb = it / a.H;
-    return (a.mask_kind == HGL_MASK_CLS_KEEP && bb >= a.keep_b0) ? a.keep + (long long)((bb - a.keep_b0) % a.keep_n) * (a.Sk - 1) : nullptr;
-  };
-  auto load_keep = [&](int it) {
-    const uint8_t* kr = keep_ptr(it);
-    if (kr && t < a.Sk - 1) pkeep = kr[t];
-  };
-
-  int item = blockIdx.x;
-  if (item >= nitems) return;
-  int nst = 0; (void)nst;
-  if constexpr (PREQ) load_q(item);
-  load_chunk(item, 0);
-  load_keep(item);
-  __syncthreads();   // the padding zeros
-
-  for (;;) {
-    const int b = item / a.H, hh = item - b * a.H;
-    const int next = item + (int)gridDim.x;
-    const bool has_next = next < nitems;
-    STAMP(1);
-
-    // ---- Q fragments (pre-scaled in fp32, then split: see attn_x3_kernel) from the prefetched rows ----
-    if constexpr (!PREQ) {
-      load_q(item);
-      if constexpr (RELW == 0) store_chunk(0, 0);   // under the Q loads (with a rel-pos patch the buffers are not free yet)
-    }
-    h16x8 qh[KS], ql[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int half = 0; half < 2; ++half)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = qvalid ? pq[2 * s + half][e] * a.scale : 0.f;
-          _Float16 hi, lo;
-          hgl_split_hi_lo(x, hi, lo, amax);
-          qh[s][4 * half + e] = hi;
-          ql[s][4 * half + e] = lo;
-        }
-    h16x8 rbh[2], rbl[2];
-    if constexpr (RELW > 0) {
-      // rel_h[q][k] = q . Rh[qy - k + RELW-1] (image_encoder.py:325-361, UNSCALED q): T^T = R . Q^T on the matrix cores with
-      // the split-fp16 scheme and summation order of relpos_mfma_kernel, per wave, through an LDS patch
-      if (wave_active) {
-        h16x8 uh[KS], ul[KS];
-#pragma unroll
-        for (int sx = 0; sx < KS; ++sx)
-#pragma unroll
-          for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              _Float16 hi, lo;
-              hgl_split_hi_lo(qvalid ? pq[2 * sx + half][e] : 0.f, hi, lo);
-              uh[sx][4 * half + e] = hi;
-              ul[sx][4 * half + e] = lo;
-            }
-        float* P0 = RPatch + wave * 2 * 32 * RPP;
-#pragma unroll
-        for (int axis = 0; axis < 2; ++axis) {
-          const float* Rt = axis ? a.tab_w : a.tab_h;
-          f32x16 acc;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-          f32x4 traw[KS][2];       // the axis' table fragments in one batch of loads (see the Q fragments)
-#pragma unroll
-          for (int sx = 0; sx < KS; ++sx)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-              traw[sx][half] = *(const f32x4*)(Rt + (long long)min(r, 2 * RELW - 2) * HD + 16 * sx + 8 * h + 4 * half);
-            }
-          __builtin_amdgcn_sched_barrier(0);
-          if (r >= 2 * RELW - 1) {
-#pragma unroll
-            for (int sx = 0; sx < KS; ++sx) traw[sx][0] = traw[sx][1] = f32x4{0, 0, 0, 0};
-          }
-#pragma unroll
-          for (int sx = 0; sx < KS; ++sx) {
-            h16x8 th, tl;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-              const f32x4 v = traw[sx][half];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                _Float16 hi, lo;
-                hgl_split_hi_lo(v[e], hi, lo);
-                th[4 * half + e] = hi;
-                tl[4 * half + e] = lo;
-              }
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, uh[sx], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, ul[sx], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, uh[sx], acc, 0, 0, 0);
-          }
-          float* Pw = P0 + axis * 32 * RPP + r * RPP;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) Pw[(e & 3) + 8 * (e >> 2) + 4 * h] = acc[e];
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        const int qq = qvalid ? qi : 0;
-        const int qy = qq / (RELW > 0 ? RELW : 1), qx = qq - qy * RELW;
-        const float* Ph = P0 + r * RPP + qy + RELW - 1;
-        const float* Pv = P0 + 32 * RPP + r * RPP + qx + RELW - 1;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int idx = 16 * c + 8 * h + j;
-            float x = 0.f;
-            if (idx < RELW) x = Ph[-idx];
-            else if (idx < 2 * RELW) x = Pv[-(idx - RELW)];
-            _Float16 hi, lo;
-            hgl_split_hi_lo(x, hi, lo);
-            rbh[c][j] = hi;
-            rbl[c][j] = lo;
-          }
-      }
-      __syncthreads();   // every wave has read its patch: the buffers may be filled
-    }
-
-    f32x16 o[DT];
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-    float m_run = NEG_INF, l_run = 0.f;
-    const bool has_keep = keep_ptr(item) != nullptr;
-    STAMP(2);
-
-    if constexpr (PREQ || RELW > 0) store_chunk(0, 0);
-    if (has_keep && t < a.Sk - 1) keepL[t] = (uint8_t)pkeep;
-    if (nch > 1) load_chunk(item, KV_CHUNK);
-    else if (has_next) { if constexpr (PREQ) load_q(next); load_chunk(next, 0); load_keep(next); }
-    STAMP(3);
-    __syncthreads();
-    STAMP(4);
-
-    for (int c = 0; c < nch; ++c) {
-      const int kc = c * KV_CHUNK;
-      if (c + 1 < nch) {
-        store_chunk(kc + KV_CHUNK, (c + 1) & 1);     // its buffer was released by the barrier that ended iteration c-1
-        if (c + 2 < nch) load_chunk(item, kc + 2 * KV_CHUNK);
-        else if (has_next) { if constexpr (PREQ) load_q(next); load_chunk(next, 0); load_keep(next); }
-      }
-      STAMP(5);
-      const _Float16* Ks = smem_w + (c & 1) * BUF_H;
-      const _Float16* Vh = Ks + KV_CHUNK * KROW;
-      const _Float16* Vl = Vh + KV_CHUNK * VP;
-#pragma unroll
-      for (int kt = 0; kt < KV_CHUNK / 32; ++kt) {
-        const int kbase = kc + kt * 32;
-        if (kbase >= a.Sk || !wave_active) break;  // uniform
-        f32x16 s;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
-        const _Float16* krow = Ks + (kt * 32 + r) * KROW + 8 * h;
-#pragma unroll
-        for (int cc = 0; cc < KS; ++cc) {
-          const h16x8 kh8 = *(const h16x8*)(krow + 16 * cc);
-          const h16x8 kl8 = *(const h16x8*)(krow + HD + 16 * cc);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[cc], s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, ql[cc], s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh[cc], s, 0, 0, 0);
-        }
-        if constexpr (RELW > 0) {
-#pragma unroll
-          for (int cc = 0; cc < 2; ++cc) {
-            const h16x8 e8 = *(const h16x8*)(krow + 2 * HD + 16 * cc);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(e8, rbl[cc], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(e8, rbh[cc], s, 0, 0, 0);
-          }
-        }
-        STAMP(6);
-        float mx = NEG_INF;
-        if (kbase + 32 > a.Sk) {   // uniform: the tile that crosses the end of the sequence
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-            s[e] = kg >= a.Sk ? NEG_INF : s[e];
-          }
-        }
-        if (has_keep && wave == 0) {   // uniform: the wave that owns query 0 of a CLS-keep batch
-          // the tile's 32 keep bytes as one bit mask (a ballot over one byte read per lane), bit c = key kbase + c; the
-          // CLS key itself (key 0) is always kept.  A lane's element e is key kbase + 4h + (e & 3) + 8 (e >> 2).
-          const int kk = kbase + (lane & 31);
-          const unsigned kb = kk >= 1 && kk < a.Sk ? keepL[kk - 1] : 1u;
-          const unsigned bits = (unsigned)__builtin_amdgcn_ballot_w64(kb != 0) >> (4 * h);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const bool kept = (bits >> ((e & 3) + 8 * (e >> 2))) & 1u;
-            s[e] = (qi == 0 && !kept) ? NEG_INF : s[e];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_cand = fmaxf(m_run, mx);
-        float m_new = m_run;
-        if (__builtin_amdgcn_ballot_w64(m_cand > m_run + 5.5f)) {   // lazy rescaling (attn_x3_kernel)
-          m_new = m_cand;
-          const float m_use0 = (m_new == NEG_INF) ? 0.f : m_new;
-          const float alpha = __builtin_amdgcn_exp2f((m_run - m_use0) * LOG2E);
-          l_run *= alpha;
-#pragma unroll
-          for (int d = 0; d < DT; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
-          m_run = m_new;
-        }
-        const float mneg = -((m_new == NEG_INF) ? 0.f : m_new) * LOG2E;
-        float rs = 0.f;
-        h16x8 ph[2], pl[2];
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const float p0 = __builtin_amdgcn_exp2f(fmaf(s[e], LOG2E, mneg));
-          const float p1 = __builtin_amdgcn_exp2f(fmaf(s[e + 1], LOG2E, mneg));
-          rs += p0;
-          rs += p1;
-          const h16x2 hi2 = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(p0, p1));
-          ph[e >> 3][e & 7] = hi2[0]; ph[e >> 3][(e & 7) + 1] = hi2[1];
-          pl[e >> 3][e & 7] = (_Float16)(p0 - (float)hi2[0]);
-          pl[e >> 3][(e & 7) + 1] = (_Float16)(p1 - (float)hi2[1]);
-        }
-        l_run += rs;
-        STAMP(7);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          if (kbase + 16 * s2 >= a.Sk) break;   // uniform: the keys of this k-step are all beyond the sequence (P = 0)
-#pragma unroll
-          for (int d = 0; d < DT; ++d) {
-            const int off = (kt * 32 + 16 * s2) * VP + d * 32 + tr_off;
-            const h16x4 vh0 = lds_tr4(Vh + off), vh1 = lds_tr4(Vh + off + 8 * VP);
-            const h16x4 vl0 = lds_tr4(Vl + off), vl1 = lds_tr4(Vl + off + 8 * VP);
-            h16x8 vh8, vl8;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { vh8[e] = vh0[e]; vh8[4 + e] = vh1[e]; vl8[e] = vl0[e]; vl8[4 + e] = vl1[e]; }
-            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph[s2], o[d], 0, 0, 0);
-            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl[s2], o[d], 0, 0, 0);
-            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph[s2], o[d], 0, 0, 0);
-          }
-        }
-      }
-      STAMP(12);
-      __syncthreads();
-      STAMP(13);
-    }
-
-    // ---- output rows of this item (the stores drain under the next item's prologue) ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (qvalid) {
-      const long long oo = b * a.sob + (long long)qi * a.ldo + hh * HD;
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int dd = d * 32 + 8 * g + 4 * h;
-          if (dd < HD) {
-            f32x4 w;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = o[d][4 * g + e] * inv;
-            if (a.out) {
-              *(f32x4*)(a.out + oo + dd) = w;
-            } else {   // the operand form of the following f16x3 projection
-              h16x4 hi, lo;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                _Float16 a2, c2;
-                hgl_split_hi_lo(w[e], a2, c2);
-                hi[e] = a2;
-                lo[e] = c2;
-              }
-              *(h16x4*)(a.out_hi + oo + dd) = hi;
-              *(h16x4*)(a.out_lo + oo + dd) = lo;
-            }
-          }
-        }
-      }
-    }
-    STAMP(14);
-    if (!has_next) break;
-    item = next;
-  }
-  hgl_split_commit(amax);
-}
-
-// ---------------------------------------------------------------------------------------------
 // Attention with a handful of keys (the mask decoder's image -> token direction, transformer.py:139-150: 4096
 // image queries per prompt against the 7 prompt tokens, 8 heads of 16).  An MFMA tile would be 78 % padding;
 // here one thread owns one (query, head): 16 q values in registers, the prompt's K and V (Sk x H*16 floats each)
@@ -2139,25 +1716,6 @@ __global__ __launch_bounds__(128) void attn_fewq_combine_kernel(const float* __r
   out[b * sob + (long long)qi * ldo + ll * 8 + d] = acc / lsum;
 }
 
-// persistent wide kernel: one workgroup per CU (its two K/V buffers take 84-100 KiB of LDS)
-template <int HD, int RELW>
-void launch_wide(const AttnArgs& a, hipStream_t st) {
-  constexpr int KROW = 2 * HD + (RELW > 0 ? 32 : 0) + 8, VP = HD <= 32 ? 32 : 96;
-  constexpr size_t lds = (size_t)2 * KV_CHUNK * (KROW + 2 * VP) * sizeof(_Float16) + 256;   // + the CLS-keep row
-  static bool set = false;
-  static int ncu = 0;
-  if (!set) {
-    (void)hipFuncSetAttribute((const void*)attn_x3w_kernel<HD, RELW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    if (ncu <= 0) ncu = 256;
-    set = true;
-  }
-  const int items = a.B * a.H;
-  hipLaunchKernelGGL((attn_x3w_kernel<HD, RELW>), dim3((unsigned)(items < ncu ? items : ncu)), dim3(512), lds, st, a);
-}
-
 template <int HD>
 int launch_hd(const AttnArgs& a, hipStream_t st) {
   dim3 grid((a.Sq + 127) / 128, a.B * a.H);
@@ -2182,10 +1740,17 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
           ((a.Sk & 31) == 0 || !a.rel_h)) {
         constexpr int KROW_ = 2 * HD + 8, VP_ = 96;
         constexpr size_t lds = (size_t)2 * KV_CHUNK * (KROW_ + 2 * VP_) * sizeof(_Float16);
-        static bool set = false;
-        if (!set) {
-          (void)hipFuncSetAttribute((const void*)attn_x3pp_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-          set = true;
+        // the attribute is per device (a second device, or this one after a reset, would otherwise fail every launch of a
+        // 2048-token block): keyed by the device, result checked
+        static bool set_for[64] = {false};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!set_for[dev]) {
+          if (hipFuncSetAttribute((const void*)attn_x3pp_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            hgl_set_error("attention: cannot reserve %zu bytes of LDS for the ping-pong kernel", lds);
+            return HGL_ELAUNCH;
+          }
+          set_for[dev] = true;
         }
         hipLaunchKernelGGL((attn_x3pp_kernel<HD>), dim3((a.Sq + 255) / 256, a.B * a.H), dim3(512), lds, st, a);
         return hgl_check_launch("attention");
@@ -2198,10 +1763,8 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
       // 868 against 976 us on 1024 x 12 x 197 x 64 (141 against 125 TF/s), -0.4 ms per benchmark step (HGL_ATTN_DUAL=0: the
       // persistent 8-wave kernel)
       hipLaunchKernelGGL((attn_x3q_kernel<HD == 64 ? 64 : 16, 2>), dim3((unsigned)(a.B * a.H)), dim3(256), 0, st, a);
-    } else if (w8 && !a.rel_h && wide == 2) {   // A/B: the one-item-per-workgroup wide kernel
+    } else if (w8 && !a.rel_h) {   // one 8-wave workgroup per item (K / V staged once)
       hipLaunchKernelGGL((attn_x3_kernel<HD, 0, 8>), dim3((a.Sq + 255) / 256, a.B * a.H), dim3(512), 0, st, a);
-    } else if (w8 && !a.rel_h) {
-      launch_wide<HD, 0>(a, st);
     } else {
       hipLaunchKernelGGL((attn_x3_kernel<HD, 0>), grid, dim3(256), 0, st, a);
     }
@@ -2212,15 +1775,6 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
 
 }  // namespace
 
-#ifdef HGL_ATTN_STAMPS
-extern "C" int hgl_debug_attn_stamps(unsigned long long* out, int n, int wave) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * (n < 2048 ? n : 2048));
-  unsigned long long z[2048] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), z, sizeof(z));
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp_wave), &wave, sizeof(int));
-  return 0;
-}
-#endif
 
 // Windowed attention of the SAM encoder (14 x 14 windows, head dim 80, f16x3 mode) with the decomposed rel-pos terms
 // computed INSIDE the kernel from the tables Rh / Rw [27, 80] (no rel_h / rel_w tensors, no separate table kernel).
@@ -2251,10 +1805,7 @@ int hgl_launch_attention_win14(const float* q, const float* k, const float* v, v
   }
   a.out_hi = (_Float16*)out_hi; a.out_lo = (_Float16*)out_lo;
   HglProfScope prof(HGL_PROF_ATTN, 4.0 * B * H * 196.0 * 196.0 * 80, 0.0, st);
-  // the one-item-per-workgroup wide kernel measures faster here (1.77 ms against 1.92 for 1600 windows x 16 heads): at head
-  // dim 80 the persistent form has no registers to prefetch the next item's Q rows (HGL_ATTN_WIDE=3 selects it)
-  if (wide == 3) launch_wide<80, 14>(a, st);
-  else hipLaunchKernelGGL((attn_x3_kernel<80, 14, 8>), dim3(1, (unsigned)(B * H)), dim3(512), 0, st, a);
+  hipLaunchKernelGGL((attn_x3_kernel<80, 14, 8>), dim3(1, (unsigned)(B * H)), dim3(512), 0, st, a);
   return hgl_check_launch("attention_win14");
 }
 

@@ -34,7 +34,8 @@ def default_argument_parser():
                    help="image_data_split.json, refer_<split>.json, images/ (data/dataset_phrasecut.py:40)")
     p.add_argument("--unseen_mode", action="store_true", help="PhraseCut: skip phrases of COCO categories (dataset_phrasecut.py:63)")
     p.add_argument("--seen_mode", action="store_true", help="PhraseCut: only phrases of COCO categories (:65)")
-    p.add_argument("--split", default="val")
+    p.add_argument("--split", default=None,
+                   help="default: val (Hybridgl_main.py), test for --dataset phrasecut (Hybridgl_main_PhraseCut.py:42)")
     p.add_argument("--fusion_mode", default="G2L", choices=["G2L", "L2G", "G2L&L2G"])
     p.add_argument("--refer_data_root", default="./refer/data")
     p.add_argument("--synthetic", type=int, default=4, help="number of seeded synthetic refs to evaluate")
@@ -250,6 +251,13 @@ def resolve_defaults(args):
     for k, v in AMG_DEFAULTS["phrasecut" if args.dataset == "phrasecut" else "refer"].items():
         if getattr(args, k, None) is None:
             setattr(args, k, v)
+    if getattr(args, "split", None) is None:
+        # Hybridgl_main_PhraseCut.py:42 evaluates PhraseCutDataset(split='test'); the REFER scripts their val split
+        args.split = "test" if args.dataset == "phrasecut" else "val"
+    if getattr(args, "group", None) is not None and args.group <= 1 and getattr(args, "proposal_cap", 0):
+        # the ref-by-ref path (HybridGLPipeline.step) keeps every proposal: silently ignoring the cap would give other results
+        # than the grouped loop whenever the cap binds
+        raise SystemExit("--proposal_cap applies to the grouped loop only: use --group >= 2 with it (or drop the cap)")
     return args
 
 
@@ -398,7 +406,12 @@ def evaluate(args, model, gen, gem_model, dev, rank=0, world=1, dist=None):
 
 def main(args):
     from . import dist as D
-    assert torch.cuda.is_available(), "hybridgl_amd has no CPU path"
+    if not torch.cuda.is_available():
+        # the reference falls back to the CPU (Hybridgl_main.py:30-34); this package is the MI355X hot path and nothing else:
+        # libhybridgl.so's entries return HGL_ENODEVICE without a HIP device (tests/test_abi.py)
+        raise SystemExit("hybridgl_amd.main: no HIP device is visible.  This package has no CPU implementation of the hot path (by "
+                         "design: a CPU fallback would void every parity claim); the reference's CPU configuration (BASELINE "
+                         "configs[0]) is covered by the oracle tests: python -m pytest tests -m 'not gpu'")
     rank, local_rank, world = D.env_rank()
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     cores = D.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # launch + loader threads of a rank on its own cores

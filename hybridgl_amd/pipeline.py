@@ -429,7 +429,10 @@ class HybridGLPipeline:
                         stc = gen.group_cleanup(state[1])
                         if stc.overflow:
                             # fail at THIS group, not in metrics() after the whole dataset: the counter rode on the group's
-                            # count read-back (everything the device had finished by then, on any stream)
+                            # count read-back (everything the device had finished by then, on any stream).  The counters are
+                            # process-global: cleared here, or every later run() of the process -- the f32 rerun this message
+                            # recommends included -- would trip over the same count at its first group
+                            ops.split_overflow_count(reset=True)
                             raise ops.SplitOverflow(
                                 f"activations exceeded the fp16 range (|x| > 65504) in f16x3 mode by group {self.groups_run} of the "
                                 f"loop ({stc.overflow} GPU threads saw one; refs up to dataset position {units[-1][-1].index}): the "
@@ -438,6 +441,7 @@ class HybridGLPipeline:
                     else:
                         stc = gen.crops_mid(state[1])
                         if stc.overflow:
+                            ops.split_overflow_count(reset=True)
                             raise ops.SplitOverflow(
                                 f"activations exceeded the fp16 range (|x| > 65504) in f16x3 mode by group {self.groups_run} of the "
                                 f"loop ({stc.overflow} GPU threads saw one): rerun with HYBRIDGL_PRECISION=f32 (or precision='f32')")

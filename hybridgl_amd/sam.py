@@ -803,7 +803,10 @@ class SamAutomaticMaskGenerator:
         st.n1.copy_(st.n1_dev, non_blocking=True)
         st.overflow = 0
         st.ovf = torch.zeros(2, dtype=torch.int32).pin_memory()
-        ops.split_overflow_peek(st.ovf)
+        if self.model.precision == "f16x3":     # the counters only move in the split-fp16 mode
+            ops.split_overflow_peek(st.ovf)
+        else:
+            st.ovf.zero_()
         st.ev1 = torch.cuda.Event()
         st.ev1.record(torch.cuda.current_stream(m.device))
         return st
@@ -971,7 +974,10 @@ class SamAutomaticMaskGenerator:
         # this stream got here -- the caller stops at this group instead of finding out at the end of the dataset
         st.overflow = 0
         st.ovf = torch.zeros(2, dtype=torch.int32).pin_memory()
-        ops.split_overflow_peek(st.ovf)
+        if self.model.precision == "f16x3":     # the counters only move in the split-fp16 mode
+            ops.split_overflow_peek(st.ovf)
+        else:
+            st.ovf.zero_()
         st.ev1 = torch.cuda.Event()
         st.ev1.record(torch.cuda.current_stream(dev))
         return st

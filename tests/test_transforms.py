@@ -100,4 +100,8 @@ def test_dataset_defaults_follow_the_reference_scripts():
     b = drv.resolve_defaults(drv.default_argument_parser().parse_args(["--dataset", "phrasecut", "--group", "2"]))
     assert (b.points_per_side, b.pred_iou_thresh, b.stability_score_thresh, b.min_mask_region_area, b.crop_n_layers,
             b.crop_n_points_downscale_factor, b.group) == (64, 0.86, 0.92, 100, 1, 2, 2)   # Hybridgl_main_PhraseCut.py:56-62
+    assert (a.split, b.split) == ("val", "test")                                 # Hybridgl_main_PhraseCut.py:42: split='test'
+    import pytest
+    with pytest.raises(SystemExit):      # the ref-by-ref path keeps every proposal: a cap there would be silently ignored
+        drv.resolve_defaults(drv.default_argument_parser().parse_args(["--group", "1", "--proposal_cap", "64"]))
     assert T.resize_shorter_side(480, 640, 800) == (800, 1066) and T.resize_shorter_side(640, 480, 800) == (1066, 800)
