@@ -175,6 +175,7 @@ PROTOTYPES = {
     "hgl_box_near_crop_edge": (_I, [_VP, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _F, _VP, _VP]),
     "hgl_remove_small_regions_workspace_bytes": (_SZ, [_I, _I, _I]),
     "hgl_remove_small_regions": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "hgl_remove_small_regions_boxes": (_I, [_VP, _I, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_mask_boxes": (_I, [_VP, _I, _I, _I, _VP, _VP]),
     "hgl_gather_masks": (_I, [_VP, _VP, _VP, _I, _LL, _VP, _VP]),
     "hgl_gen_dir_mask": (_I, [_I, _I, _I, _VP, _VP]),

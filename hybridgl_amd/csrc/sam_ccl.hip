@@ -280,10 +280,11 @@ __global__ __launch_bounds__(256) void ccl_stats_kernel(const uint8_t* __restric
   }
 }
 
-__global__ void ccl_stats_init_kernel(int* stats, int N) {
+__global__ void ccl_stats_init_kernel(int* stats, int N, int* boxes) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   stats[n * 4 + 0] = 0; stats[n * 4 + 1] = 0; stats[n * 4 + 2] = 0; stats[n * 4 + 3] = 0;
+  if (boxes) { boxes[n * 4 + 0] = 0x7fffffff; boxes[n * 4 + 1] = 0x7fffffff; boxes[n * 4 + 2] = -1; boxes[n * 4 + 3] = -1; }
 }
 
 // Pass F -- holes:   out = mask | (working && area < thresh)                      (fill small holes)
@@ -291,7 +292,8 @@ __global__ void ccl_stats_init_kernel(int* stats, int N) {
 __global__ __launch_bounds__(256) void ccl_apply_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ L,
                                                         const int* __restrict__ area, const int* __restrict__ stats,
                                                         int holes, int H, int W, long long rows, int thresh,
-                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ changed) {
+                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ changed,
+                                                        int* __restrict__ boxes) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -299,8 +301,32 @@ __global__ __launch_bounds__(256) void ccl_apply_kernel(const uint8_t* __restric
   const int n = (int)(row / H);
   const int n_small = stats[n * 4 + 0];
   if (row % H == 0 && lane == 0) changed[n] = n_small != 0;
+  // boxes != nullptr: the written mask's box (batched_mask_to_box, utils/amg.py:303-346) comes out of this pass -- the row's
+  // first / last set pixel from the wave's ballots, four atomics per row that holds a pixel -- instead of another pass
+  // over the N*H*W bytes just written (box_kernel: 96 us per ref)
+  int rminx = 0x7fffffff, rmaxx = -1;
+  auto row_bits = [&](bool o, int x0) {
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(o);
+    if (b) {
+      rminx = min(rminx, x0 + (int)__builtin_ctzll(b));
+      rmaxx = max(rmaxx, x0 + 63 - (int)__builtin_clzll(b));
+    }
+  };
+  auto row_done = [&]() {
+    if (boxes && lane == 0 && rmaxx >= 0) {
+      const int y = (int)(row % H);
+      atomicMin(&boxes[n * 4 + 0], rminx); atomicMin(&boxes[n * 4 + 1], y);
+      atomicMax(&boxes[n * 4 + 2], rmaxx); atomicMax(&boxes[n * 4 + 3], y);
+    }
+  };
   if (n_small == 0) {            // nothing below the threshold: mask unchanged (utils/amg.py:281-282)
-    for (int x = lane; x < W; x += 64) out[base + x] = masks[base + x] != 0 ? 1 : 0;
+    for (int x0 = 0; x0 < W; x0 += 64) {
+      const int x = x0 + lane;
+      const bool o = x < W && masks[base + x] != 0;
+      if (x < W) out[base + x] = o ? 1 : 0;
+      if (boxes) row_bits(o, x0);
+    }
+    row_done();
     return;
   }
   const bool any_large = stats[n * 4 + 1] > 0;
@@ -310,17 +336,19 @@ __global__ __launch_bounds__(256) void ccl_apply_kernel(const uint8_t* __restric
   CCL_FOR_STEPS(c.load(g0, lane), {
     c.step(k, x0, lane);
     const int x = x0 + lane;
+    bool o = false;
     if (x < W) {
       const bool m = c.v[k] != 0;
       int r = -1;
       if (c.work) r = L[base + c.start];     // the run start holds the root (or is the root)
-      bool o;
       if (holes) o = m || (r >= 0 && area[r] < thresh);
       else o = r >= 0 && (any_large ? area[r] >= thresh : r == best);
       out[base + x] = o ? 1 : 0;
     }
+    if (boxes) row_bits(o, x0);
     c.advance(x0);
   })
+  row_done();
 }
 
 // batched_mask_to_box: counters [N,4] = minx, miny, maxx, maxy
@@ -380,8 +408,22 @@ size_t hgl_remove_small_regions_workspace_bytes(int N, int H, int W) {
   return hgl_align_up(px * sizeof(int), 256) * 2 + hgl_align_up((size_t)N * 4 * sizeof(int), 256);
 }
 
+static int remove_small_regions_impl(const uint8_t* masks, int N, int H, int W, int area_thresh, int holes, uint8_t* out,
+                                     uint8_t* changed, int32_t* boxes_xyxy, void* workspace, size_t workspace_bytes, void* stream);
+
 int hgl_remove_small_regions(const uint8_t* masks, int N, int H, int W, int area_thresh, int holes, uint8_t* out,
                              uint8_t* changed, void* workspace, size_t workspace_bytes, void* stream) {
+  return remove_small_regions_impl(masks, N, H, W, area_thresh, holes, out, changed, nullptr, workspace, workspace_bytes, stream);
+}
+
+int hgl_remove_small_regions_boxes(const uint8_t* masks, int N, int H, int W, int area_thresh, int holes, uint8_t* out,
+                                   uint8_t* changed, int32_t* boxes_xyxy, void* workspace, size_t workspace_bytes, void* stream) {
+  HGL_REQUIRE(boxes_xyxy, "remove_small_regions_boxes: null boxes");
+  return remove_small_regions_impl(masks, N, H, W, area_thresh, holes, out, changed, boxes_xyxy, workspace, workspace_bytes, stream);
+}
+
+static int remove_small_regions_impl(const uint8_t* masks, int N, int H, int W, int area_thresh, int holes, uint8_t* out,
+                                     uint8_t* changed, int32_t* boxes_xyxy, void* workspace, size_t workspace_bytes, void* stream) {
   HGL_TRY(hgl_require_device());
   HGL_REQUIRE(masks && out && changed && N > 0 && H > 0 && W > 0, "remove_small_regions: bad arguments");
   const long long total = (long long)N * H * W;
@@ -399,14 +441,15 @@ int hgl_remove_small_regions(const uint8_t* masks, int N, int H, int W, int area
   const long long rows = (long long)N * H;
   const dim3 grid((unsigned)((rows + 3) / 4));
   hipLaunchKernelGGL(ccl_rows_kernel, grid, dim3(256), 0, st, masks, holes, W, rows, L, area);
-  hipLaunchKernelGGL(ccl_stats_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stats, N);
+  hipLaunchKernelGGL(ccl_stats_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stats, N, (int*)boxes_xyxy);
   hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, st, masks, holes, L, H, W, rows);
   hipLaunchKernelGGL(ccl_compress_kernel, grid, dim3(256), 0, st, masks, holes, L, W, rows);
   hipLaunchKernelGGL(ccl_count_kernel, grid, dim3(256), 0, st, masks, holes, (const int*)L, area, W, rows);
   hipLaunchKernelGGL(ccl_stats_kernel, grid, dim3(256), 0, st, masks, holes, (const int*)L, (const int*)area, W, HW, rows,
                      area_thresh, stats);
   hipLaunchKernelGGL(ccl_apply_kernel, grid, dim3(256), 0, st, masks, (const int*)L, (const int*)area, (const int*)stats, holes,
-                     H, W, rows, area_thresh, out, changed);
+                     H, W, rows, area_thresh, out, changed, (int*)boxes_xyxy);
+  if (boxes_xyxy) hipLaunchKernelGGL(box_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, (int*)boxes_xyxy, N);
   return hgl_check_launch("remove_small_regions");
 }
 

@@ -748,9 +748,8 @@ class SamAutomaticMaskGenerator:
             mk, bx, iou, stab, pts, cbs = mk.index_select(0, k), bx.index_select(0, k).contiguous(), iou[k], stab[k], pts[kc], cbs[kc]
         if self.min_mask_region_area > 0 and len(bx) > 0:
             m1, c1 = remove_small_regions(mk.contiguous(), self.min_mask_region_area, "holes")
-            m2, c2 = remove_small_regions(m1, self.min_mask_region_area, "islands")
+            m2, c2, nb = remove_small_regions_boxes(m1, self.min_mask_region_area, "islands")
             unchanged = ((c1 | c2) == 0).to(torch.float32)
-            nb = mask_boxes(m2)
             order2, n2 = nms(nb, unchanged, torch.ones(len(nb), dtype=torch.uint8, device=m.device),
                              max(self.box_nms_thresh, self.crop_nms_thresh))
             k = order2[: int(n2.item())].long()
@@ -879,9 +878,8 @@ class SamAutomaticMaskGenerator:
                 mk, bx, iou, stab = mk.index_select(0, k), bx.index_select(0, k).contiguous(), iou[k], stab[k]
             if self.min_mask_region_area > 0:
                 m1, c1 = remove_small_regions(mk.contiguous(), self.min_mask_region_area, "holes")
-                m2, c2 = remove_small_regions(m1, self.min_mask_region_area, "islands")
+                m2, c2, nb = remove_small_regions_boxes(m1, self.min_mask_region_area, "islands")
                 unchanged = ((c1 | c2) == 0).to(torch.float32)
-                nb = mask_boxes(m2)
                 order2, nn = nms(nb, unchanged, torch.ones(len(nb), dtype=torch.uint8, device=dev),
                                  max(self.box_nms_thresh, self.crop_nms_thresh))
                 stage.append((m2, nb, iou, stab, order2))
@@ -942,9 +940,8 @@ class SamAutomaticMaskGenerator:
         if self.min_mask_region_area > 0 and n > 0:
             # postprocess_small_regions (automatic_mask_generator.py:324-372) on the device
             m1, c1 = remove_small_regions(m, self.min_mask_region_area, "holes")
-            m2, c2 = remove_small_regions(m1, self.min_mask_region_area, "islands")
+            m2, c2, nb = remove_small_regions_boxes(m1, self.min_mask_region_area, "islands")
             unchanged = ((c1 | c2) == 0).to(torch.float32)           # score 1 for untouched masks
-            nb = mask_boxes(m2)
             keep_all = torch.ones(n, dtype=torch.uint8, device=m.device)
             order2, n2 = nms(nb, unchanged, keep_all, max(self.box_nms_thresh, self.crop_nms_thresh))
             k = order2[: int(n2.item())].long()
@@ -1006,9 +1003,8 @@ class SamAutomaticMaskGenerator:
             bx = boxes.index_select(0, idx)
             if self.min_mask_region_area > 0:
                 m1, c1 = remove_small_regions(m, self.min_mask_region_area, "holes")
-                m2, c2 = remove_small_regions(m1, self.min_mask_region_area, "islands")
+                m2, c2, nb = remove_small_regions_boxes(m1, self.min_mask_region_area, "islands")
                 unchanged = ((c1 | c2) == 0).to(torch.float32)           # score 1 for untouched masks
-                nb = mask_boxes(m2)
                 order2, n2 = nms(nb, unchanged, torch.ones(n, dtype=torch.uint8, device=dev),
                                  max(self.box_nms_thresh, self.crop_nms_thresh))
                 st.stage.append((m2, nb, idx, order2, iou, stab))
@@ -1062,8 +1058,7 @@ class SamAutomaticMaskGenerator:
         if self.min_mask_region_area <= 0:
             return m, mask_boxes(m)
         m1, c1 = remove_small_regions(m, self.min_mask_region_area, "holes")
-        m2, c2 = remove_small_regions(m1, self.min_mask_region_area, "islands")
-        nb = mask_boxes(m2)
+        m2, c2, nb = remove_small_regions_boxes(m1, self.min_mask_region_area, "islands")
         nms(nb, ((c1 | c2) == 0).to(torch.float32), torch.ones(m.shape[0], dtype=torch.uint8, device=m.device),
             max(self.box_nms_thresh, self.crop_nms_thresh))
         return m2, nb
@@ -1156,6 +1151,22 @@ def remove_small_regions(masks, area_thresh, mode):
                                        1 if mode == "holes" else 0, out.data_ptr(), changed.data_ptr(),
                                        ws.data_ptr(), ws.numel(), ops._stream()), "hgl_remove_small_regions")
     return out, changed
+
+
+def remove_small_regions_boxes(masks, area_thresh, mode):
+    """remove_small_regions with the boxes of the masks it writes (batched_mask_to_box, utils/amg.py:303-346) out of the
+    same pass -> (new masks, changed [n] uint8, int32 XYXY [n,4])."""
+    lib = _lib.load()
+    n, H, W = masks.shape
+    out = torch.empty_like(masks)
+    changed = torch.empty((n,), dtype=torch.uint8, device=masks.device)
+    boxes = torch.empty((n, 4), dtype=torch.int32, device=masks.device)
+    need = lib.hgl_remove_small_regions_workspace_bytes(n, H, W)
+    ws = ops.workspace(need, masks.device, "sam_ccl")
+    check(lib.hgl_remove_small_regions_boxes(ops._dev(masks, torch.uint8, "masks"), n, H, W, int(area_thresh),
+                                             1 if mode == "holes" else 0, out.data_ptr(), changed.data_ptr(), boxes.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), ops._stream()), "hgl_remove_small_regions_boxes")
+    return out, changed, boxes
 
 
 def mask_boxes(masks):

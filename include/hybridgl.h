@@ -541,6 +541,11 @@ size_t hgl_remove_small_regions_workspace_bytes(int N, int H, int W);
 int hgl_remove_small_regions(const uint8_t* masks, int N, int H, int W, int area_thresh, int holes,
                              uint8_t* out, uint8_t* changed, void* workspace, size_t workspace_bytes,
                              void* stream);
+/* The same pass with the written masks' boxes (batched_mask_to_box, utils/amg.py:303-346: int32 XYXY, inclusive, zeros for an
+ * empty mask) out of the pass that writes them, instead of hgl_mask_boxes over `out` afterwards. */
+int hgl_remove_small_regions_boxes(const uint8_t* masks, int N, int H, int W, int area_thresh, int holes,
+                                   uint8_t* out, uint8_t* changed, int32_t* boxes_xyxy, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 /* NMS for any K <= 32768 (dense point grids, crop layers and the cross-crop pass of
  * automatic_mask_generator.py:209-220,259-266): identical semantics to hgl_nms (descending score, the original
  * index breaks ties, suppress IoU > threshold), three kernels through a caller-supplied workspace. */

@@ -360,10 +360,12 @@ def test_phrasecut_from_disk_groups_equal_image_by_image(cuda, tmp_path):
     assert gen.crop_n_layers == 1 and len(gen.point_grids) == 2
     m_grp, st = drv.evaluate(args, model, gen, gem, cuda)
     assert st["refs"] == info["images"] and m_grp["n_sentences"] == info["phrases"] and st["skipped"] == 0
-    args1 = drv.default_argument_parser().parse_args(base + ["--group", "1"])
+    uncapped = [a for a in base if a not in ("--proposal_cap", "24")]
+    with pytest.raises(SystemExit):       # step() applies no proposal cap: the flag combination is refused, not silently ignored
+        drv.evaluate(drv.default_argument_parser().parse_args(base + ["--group", "1"]), model, gen, gem, cuda)
+    args1 = drv.default_argument_parser().parse_args(uncapped + ["--group", "1"])
     m_one, st1 = drv.evaluate(args1, model, gen, gem, cuda)
     assert m_one["n_sentences"] == info["phrases"]
-    # step() applies no proposal cap: compare with an uncapped grouped run as well when the cap did not bind
-    args_nc = drv.default_argument_parser().parse_args([a for a in base if a not in ("--proposal_cap", "24")] + ["--group", "3"])
+    args_nc = drv.default_argument_parser().parse_args(uncapped + ["--group", "3"])
     m_nc, _ = drv.evaluate(args_nc, model, gen, gem, cuda)
     assert m_nc == m_one

@@ -718,3 +718,25 @@ def test_encoder_batch_of_eight_equals_single_images(cuda):
     for i in (0, 3, 7):
         np.testing.assert_allclose(both[i].cpu().numpy(), m.encode(imgs[i]).cpu().numpy(), rtol=0, atol=2e-4)
     assert torch.equal(both, m.encode_batch(imgs))          # run-to-run bit reproducible
+
+
+@pytest.mark.parametrize("mode", ["holes", "islands"])
+def test_remove_small_regions_boxes_equal_mask_boxes_of_the_output(cuda, mode):
+    """hgl_remove_small_regions_boxes: the boxes that come out of the clean-up's last pass (row ballots + four atomics per
+    row) are batched_mask_to_box (utils/amg.py:303-346) of the masks it wrote -- blobs, speckle, an empty mask, a mask that
+    the clean-up empties, a full mask, ragged width (not a multiple of 64)."""
+    rng = np.random.default_rng(5)
+    H, W = 97, 150
+    m = np.zeros((7, H, W), dtype=np.uint8)
+    m[0, 10:40, 20:90] = 1; m[0, 20:25, 30:35] = 0; m[0, 60:62, 100:102] = 1
+    m[1] = rng.random((H, W)) < 0.5
+    m[2] = 0
+    m[3, 5:7, 140:150] = 1                      # small island only: islands keeps the largest, holes leaves it
+    m[4] = 1
+    m[5] = rng.random((H, W)) < 0.08
+    m[6, :, 149] = 1; m[6, 96, :] = 1
+    mt = T(m, cuda)
+    out, ch, bx = hsam.remove_small_regions_boxes(mt, 30, mode)
+    out0, ch0 = hsam.remove_small_regions(mt, 30, mode)
+    assert torch.equal(out, out0) and torch.equal(ch, ch0)
+    assert torch.equal(bx, hsam.mask_boxes(out))
