@@ -30,6 +30,8 @@ import torch
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_FP16_MFMA_TFLOPS = 2500.0   # dense; AMD's 5 PF headline includes 2:1 sparsity
 PEAK_HBM_GBS = 8000.0
+PEAK_HBM_TBPS = PEAK_HBM_GBS / 1000.0
+TAIL_GROUP_REFS = 16     # refs per launch of the group-wide scoring tail (hgl_score_group) in the counter pass: its group of 16
 
 
 # CLIP geometries: ViT-B/16 is the reference's configuration (Hybridgl_main.py:37,47); ViT-L/14 is the extension named by
@@ -244,12 +246,13 @@ def cpu_baseline(fusion_mode, with_sam=True, with_gem=False, clip_name="ViT-B/16
                       "extrapolated; blur, views, tail and the GEM stage through the numpy oracle"}
 
 
-def live_pmc_traffic(prefix, timeout_s=150.0):
-    """HBM bytes per launch of the kernels whose name starts with `prefix`, measured NOW: two child processes
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only, as MI355X_MICROARCH.md prescribes) over
-    tools/group_profile.py (the headline's loop: two serial groups of 16 refs, same models and shapes), corrected as that
-    guide says (KB units x1024, FETCH_SIZE x2 on gfx950), launch-weighted over the template instantiations.  Returns
-    (bytes per launch, description) or (None, why not)."""
+def live_pmc_table(timeout_s=150.0, refs=16):
+    """Per-kernel HBM bytes and launch times of the headline's loop, measured NOW: two child processes `rocprofv3 --pmc
+    FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only, as MI355X_MICROARCH.md prescribes) over
+    tools/group_profile.py (one serial group of `refs` refs after a warm-up group, same models and shapes), corrected as that
+    guide says (KB units x1024, FETCH_SIZE x2 on gfx950).  Returns ({kernel: {launches, fetch_bytes, write_bytes, us}}, note)
+    with per-launch averages (us from the kernel trace of the FETCH_SIZE pass: a profiled pass, a few per cent slow), or
+    (None, why not)."""
     import collections
     import csv
     import glob
@@ -263,12 +266,12 @@ def live_pmc_traffic(prefix, timeout_s=150.0):
     from profile_summary import short
     out = tempfile.mkdtemp(prefix="hgl_pmc_")
     try:
-        sums = {}
+        sums, dur = {}, collections.defaultdict(lambda: [0, 0.0])
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out, ctr)
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-                                sys.executable, os.path.join(ROOT, "tools", "group_profile.py"), "1", "16"],
+                                sys.executable, os.path.join(ROOT, "tools", "group_profile.py"), "1", str(refs)],
                                cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {ctr} exited {r.returncode}"
@@ -280,19 +283,93 @@ def live_pmc_traffic(prefix, timeout_s=150.0):
                         acc[k][0] += 1
                         acc[k][1] += float(row["Counter_Value"])
             sums[ctr] = acc
-        n = sum(v[0] for k, v in sums["FETCH_SIZE"].items() if k.startswith(prefix))
-        if n == 0:
-            return None, f"no launch of {prefix} in the counter pass"
-        fetch = 2.0 * 1024.0 * sum(v[1] for k, v in sums["FETCH_SIZE"].items() if k.startswith(prefix)) / n
-        nw = max(sum(v[0] for k, v in sums["WRITE_SIZE"].items() if k.startswith(prefix)), 1)
-        write = 1024.0 * sum(v[1] for k, v in sums["WRITE_SIZE"].items() if k.startswith(prefix)) / nw
-        return fetch + write, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child processes) over "
-                               f"tools/group_profile.py 1 16, {n} launches of {prefix}...>, FETCH x2 x1024 + WRITE x1024 bytes per launch "
-                               f"(fetch {fetch / 1e9:.3f} GB + write {write / 1e9:.3f} GB)")
+            if ctr == "FETCH_SIZE":
+                for path in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
+                    for row in csv.DictReader(open(path)):
+                        k = short(row["Kernel_Name"])
+                        dur[k][0] += 1
+                        dur[k][1] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+        table = {}
+        for k, (n, v) in sums["FETCH_SIZE"].items():
+            nw, vw = sums["WRITE_SIZE"].get(k, [0, 0.0])
+            table[k] = {"launches": n, "fetch_bytes": 2.0 * 1024.0 * v / max(n, 1), "write_bytes": 1024.0 * vw / max(nw, 1),
+                        "us": dur[k][1] / max(dur[k][0], 1)}
+        return table, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child processes) over "
+                       f"tools/group_profile.py 1 {refs} (a warm-up group + one serial group of {refs} refs: launches / 2 / {refs} = "
+                       "launches per ref), FETCH x2 x1024 and WRITE x1024 bytes per launch")
     except Exception as e:
         return None, repr(e)[:200]
     finally:
         shutil.rmtree(out, ignore_errors=True)
+
+
+def live_pmc_traffic(table, note, prefix):
+    """HBM bytes per launch of the kernels whose name starts with `prefix`, launch-weighted over the template instantiations."""
+    if table is None:
+        return None, note
+    ks = [k for k in table if k.startswith(prefix)]
+    n = sum(table[k]["launches"] for k in ks)
+    if n == 0:
+        return None, f"no launch of {prefix} in the counter pass"
+    fetch = sum(table[k]["launches"] * table[k]["fetch_bytes"] for k in ks) / n
+    write = sum(table[k]["launches"] * table[k]["write_bytes"] for k in ks) / n
+    return fetch + write, (f"{note}; {n} launches of {prefix}...> (fetch {fetch / 1e9:.3f} GB + write {write / 1e9:.3f} GB per launch)")
+
+
+# The HBM-bound kernels north_star names (per-mask pooling / reductions, post-processing, view synthesis, clean-up): ALGORITHMIC
+# bytes per launch at the benchmarked shape (SURVEY.md 8d: N = 64 proposals, 640 x 640, S = 3 sentences, 192 candidates of
+# 256 x 256 low-res logits; `g` = refs per launch for the group-wide tail), stated per kernel in DESIGN.md section 5.
+def hbm_kernel_specs(N=64, H=640, W=640, S=3, K=192, g=1):
+    px = H * W
+    return {
+        "grp_masked_pool_kernel": (g * (N * px + S * 4 * px), f"the group's {g} refs in one launch: N*H*W mask bytes + S heat-maps of 4*H*W "
+                                                             "each (K10: 31.1 MB per ref)"),
+        "grp_minmax_kernel": (g * S * 4 * px, "S heat-maps per ref read once"),
+        "grp_iou_kernel": (g * S * 2 * 2 * px, "two winners x (mask + target) bytes per sentence (K12)"),
+        "ref_masked_pool_kernel": (N * px + S * 4 * px, "N*H*W mask bytes + S heat-maps of 4*H*W (K10: 31.1 MB per ref)"),
+        "ref_minmax_kernel": (S * 4 * px, "S heat-maps read once"),
+        "ref_iou_kernel": (S * 2 * 2 * px, "two winners x (mask + target) bytes per sentence (K12)"),
+        "sam_postprocess_sep_kernel": (K * 256 * 256 * 4 + K * px // 8, "read K*256^2*4 B of low-res logits, write K*H*W mask BITS (K18 "
+                                                                       "minimal: 50.3 + 9.8 MB; the kernel writes bytes: 78.6 MB)"),
+        "synth_views_kernel": (2 * N * 3 * 224 * 224 * 4 + 2 * px * 3 + N * px // 8, "write both views (77 MB) + sharp / blurred image + mask bits (K9)"),
+        "ccl_rows_kernel": (N * px, "mask bytes read once per pass"),
+        "ccl_merge_kernel": (N * px, "mask bytes read once per pass (two rows per wave: x2 through L2)"),
+        "ccl_compress_kernel": (N * px, "mask bytes read once per pass"),
+        "ccl_count_kernel": (N * px, "mask bytes read once per pass"),
+        "ccl_stats_kernel": (N * px, "mask bytes read once per pass"),
+        "ccl_apply_kernel": (2 * N * px, "mask bytes read + cleaned bytes written (+ the boxes, from this round on)"),
+        "blur_q8_h_kernel": (3 * px + 2 * 3 * px, "u8 image read, 16-bit row sums written"),
+        "blur_q8_v_kernel": (2 * 3 * px + 3 * px, "16-bit row sums read, u8 image written"),
+        "mask_resize_kernel": (N * 14 * 14 * 4 * 2, "4 taps per output of the 14 x 14 CLS keep maps (never the 26 MB of masks)"),
+    }
+
+
+def hbm_kernel_table(table, refs=16, tail_group=1):
+    """roofline.hbm_kernels: per kernel launches per ref, us per launch (profiled pass), measured bytes per launch (PMC),
+    algorithmic bytes per launch, TB/s on both, fraction of the 8 TB/s HBM3E peak on the algorithmic bytes."""
+    if table is None:
+        return None
+    out = {}
+    specs = hbm_kernel_specs(g=tail_group)
+    for k, (alg, what) in specs.items():
+        ks = [t for t in table if t == k or t.startswith(k + "<")]
+        n = sum(table[t]["launches"] for t in ks)
+        if n == 0:
+            continue
+        us = sum(table[t]["launches"] * table[t]["us"] for t in ks) / n
+        meas = sum(table[t]["launches"] * (table[t]["fetch_bytes"] + table[t]["write_bytes"]) for t in ks) / n
+        out[k] = {"launches_per_ref": n / 2.0 / refs, "us_per_launch": us, "measured_bytes_per_launch": meas,
+                  "algorithmic_bytes_per_launch": alg, "algorithmic_bytes": what,
+                  "TBps_measured": meas / us / 1e6 if us > 0 else None, "TBps_algorithmic": alg / us / 1e6 if us > 0 else None,
+                  "frac_of_hbm_peak": alg / us / 1e6 / PEAK_HBM_TBPS if us > 0 else None,
+                  "ms_per_ref": n / 2.0 / refs * us / 1e3}
+    if out:
+        out["_sum_ms_per_ref"] = sum(v["ms_per_ref"] for v in out.values() if isinstance(v, dict))
+        out["_note"] = ("bound: hbm; peak 8 TB/s (MI355X_MICROARCH.md; 6.3 TB/s is what a streaming copy reaches).  us_per_launch comes from "
+                        "the kernel trace of the FETCH_SIZE pass (profiled: a few per cent slow).  Kernels of a few tens of "
+                        "microseconds on a few tens of MB are launch- / latency-bound, not bandwidth-bound: the fraction says how "
+                        "far, the measured bytes say whether bytes are wasted")
+    return out
 
 
 def evaluator_from_disk(args, model, gen, gem_model, dev, group, n_images=208, keep_root=None, host_cores=None):
@@ -691,6 +768,7 @@ def main():
     if rank == 0:
         total_refs = args.steps * world
         traffic, traffic_src = None, None
+        pmc_table = None
         for cand in ("r03_pmc_traffic.json", "pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(tpath):
@@ -702,7 +780,8 @@ def main():
             else:
                 live_prefix = "gemm_f32_kernel<"
             torch.cuda.empty_cache()      # the child processes build their own models on this GPU
-            live = live_pmc_traffic(live_prefix)
+            pmc_table, pmc_note = live_pmc_table()
+            live = live_pmc_traffic(pmc_table, pmc_note, live_prefix)
         if live is not None and live[0] is not None:
             traffic, traffic_src = live
         elif os.path.exists(tpath):
@@ -783,6 +862,8 @@ def main():
             "metrics": m,
         }
         rec["roofline"]["traffic_source"] = traffic_src
+        if pmc_table is not None:
+            rec["roofline"]["hbm_kernels"] = hbm_kernel_table(pmc_table, tail_group=TAIL_GROUP_REFS)
         if also is not None:
             rec["also"] = also
         if rccl is not None:

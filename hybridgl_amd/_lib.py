@@ -27,6 +27,14 @@ class HglSentence(C.Structure):
                 ("imgattn", C.c_void_p), ("target", C.c_void_p)]
 
 
+class HglGroupRef(C.Structure):
+    """include/hybridgl.h HglGroupRef: one ref of a group for hgl_score_group"""
+    _fields_ = [("hybrid", C.c_void_p), ("text", C.c_void_p), ("T", C.c_int), ("boxes", C.c_void_p), ("masks", C.c_void_p),
+                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("sentences", C.POINTER(HglSentence)), ("S", C.c_int),
+                ("k1", C.c_int), ("k2", C.c_int), ("idx", C.c_void_p), ("iu", C.c_void_p), ("score_clip", C.c_void_p),
+                ("score_neg", C.c_void_p), ("gem_score", C.c_void_p)]
+
+
 class HglResBlockW(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln1_w", "ln1_b", "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b",
@@ -187,6 +195,8 @@ PROTOTYPES = {
     "hgl_score_ref_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "hgl_score_ref": (_I, [_VP, _VP, _I, _VP, _VP, _I, _I, _I, _I, C.POINTER(HglSentence), _I, C.c_float, C.c_float, _I, _I, C.c_float,
                            _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "hgl_score_group_workspace_bytes": (_SZ, [C.POINTER(HglGroupRef), _I, _I]),
+    "hgl_score_group": (_I, [C.POINTER(HglGroupRef), _I, _I, C.c_float, C.c_float, C.c_float, _VP, _VP, _SZ, _VP]),
     "hgl_u8_to_chw_lut": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP]),
     "hgl_gt_mask_from_polygons": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP]),
     "hgl_gt_mask_from_rle_counts": (_I, [_VP, _I, _I, _I, _VP, _VP]),

@@ -675,9 +675,22 @@ constexpr int PR = 48;              // max staged low-res patch side
 __global__ __launch_bounds__(256) void sam_postprocess_kernel(PostArgs a) {
   __shared__ float patch[PR * PR];
   __shared__ unsigned red[6 * 4];
-  const int k = blockIdx.z;
+  // XCD-aware tile map.  Workgroups go to the eight XCDs round-robin in linear order (x fastest), so the ~100 tiles of ONE
+  // candidate -- whose low-res patches overlap by their bilinear halos and share 128-byte lines -- sat on all eight L2s and
+  // every L2 fetched the lines for itself: 120.5 MB fetched for 50.3 MB of low-res logits (profiles/r04i_pmc_traffic.json).
+  // Remapped so that an XCD works through whole candidates: consecutive slots of one XCD are the tiles of one candidate.
+  int bx = blockIdx.x, by = blockIdx.y, k = blockIdx.z;
+  if ((gridDim.z & 7) == 0) {
+    const unsigned nt = gridDim.x * gridDim.y;
+    const unsigned Lb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned c = Lb & 7u, j = Lb >> 3;
+    const unsigned t = j % nt;
+    k = (int)((j / nt) * 8u + c);
+    by = (int)(t / gridDim.x);
+    bx = (int)(t - (unsigned)by * gridDim.x);
+  }
   const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;
-  const int X0 = blockIdx.x * PTW, Y0 = blockIdx.y * PTH;
+  const int X0 = bx * PTW, Y0 = by * PTH;
   const int Xb = X0 + tx * PPX, Y = Y0 + ty;
   if (a.iou && a.iou_thresh > 0.f && !(a.iou[k] > a.iou_thresh)) {   // the filter exists only for thresholds > 0 (:287)
     // filtered before any pixel work (uniform): the candidate keeps an all-zero mask
@@ -834,9 +847,19 @@ __global__ __launch_bounds__(256) void sam_postprocess_sep_kernel(PostArgs a) {
   __shared__ int xc0[PTW], xc1[PTW];
   __shared__ float xl0[PTW], xl1[PTW];
   __shared__ unsigned red[6 * 4];
-  const int k = blockIdx.z;
+  // XCD-aware tile map (see sam_postprocess_kernel): an XCD works through whole candidates
+  int bx = blockIdx.x, by = blockIdx.y, k = blockIdx.z;
+  if ((gridDim.z & 7) == 0) {
+    const unsigned nt = gridDim.x * gridDim.y;
+    const unsigned Lb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned c = Lb & 7u, j = Lb >> 3;
+    const unsigned t = j % nt;
+    k = (int)((j / nt) * 8u + c);
+    by = (int)(t / gridDim.x);
+    bx = (int)(t - (unsigned)by * gridDim.x);
+  }
   const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;
-  const int X0 = blockIdx.x * PTW, Y0 = blockIdx.y * PTH;
+  const int X0 = bx * PTW, Y0 = by * PTH;
   const int Xb = X0 + tx * PPX, Y = Y0 + ty;
   if (a.iou && a.iou_thresh > 0.f && !(a.iou[k] > a.iou_thresh)) {
     if (Xb < a.W && Y < a.H) {

@@ -5,6 +5,7 @@
 //   score_sentence       Hybridgl_main.py:153-196,225-228 (+ relation_boxes utils.py:240-268)
 //   synthesize_views     Hybridgl_main.py:93-125
 #include "hgl_common.h"
+#include <mutex>
 #include <math.h>
 #include <string.h>
 
@@ -551,9 +552,7 @@ struct RefSentences {
   float black[REF_MAXS];
 };
 
-__global__ __launch_bounds__(256) void ref_minmax_kernel(RefSentences rs, long long n, float* __restrict__ part_mm) {
-  const int s = blockIdx.y;
-  const float* a = rs.attn[s];
+__device__ __forceinline__ void ref_minmax_body(const float* __restrict__ a, int s, long long n, float* __restrict__ part_mm) {
   float mn = INFINITY, mx = -INFINITY;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float v = a[i];
@@ -577,6 +576,9 @@ __global__ __launch_bounds__(256) void ref_minmax_kernel(RefSentences rs, long l
     p[1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
   }
 }
+__global__ __launch_bounds__(256) void ref_minmax_kernel(RefSentences rs, long long n, float* __restrict__ part_mm) {
+  ref_minmax_body(rs.attn[blockIdx.y], blockIdx.y, n, part_mm);
+}
 
 // min / max are exact in any order: every wave folds the 64 partial pairs of a map itself (one pair per lane)
 __device__ __forceinline__ void ref_fold_minmax(const float* __restrict__ part_mm, int s, int lane, float& mn, float& mx) {
@@ -596,11 +598,10 @@ __device__ __forceinline__ void ref_fold_minmax(const float* __restrict__ part_m
 // by its instructions and round trips, not by the 26 MB of mask bytes.  Now every (block, group, map) is a small workgroup of
 // the per-sentence kernel's code (79 VGPRs, six waves per SIMD); the masks of the second and third map come from L2 / the
 // Infinity Cache.  Partials in the layout and order of masked_pool_kernel: identical sums.
-__global__ __launch_bounds__(256) void ref_masked_pool_kernel(RefSentences rs, int S, const uint8_t* __restrict__ masks, int N, int H,
-                                                              int W, const float* __restrict__ part_mm, double* __restrict__ part_sum,
-                                                              unsigned* __restrict__ part_cnt, double* __restrict__ part_tot,
-                                                              int nparts) {
-  const int sidx = blockIdx.z;
+__device__ __forceinline__ void ref_masked_pool_body(const float* __restrict__ attn, int dirflag, int sidx, int mask_group,
+                                                     const uint8_t* __restrict__ masks, int N, int H, int W,
+                                                     const float* __restrict__ part_mm, double* __restrict__ part_sum,
+                                                     unsigned* __restrict__ part_cnt, double* __restrict__ part_tot, int nparts) {
   const long long HW = (long long)H * W;
   const long long p0 = (long long)blockIdx.x * PIX_PER_BLOCK + threadIdx.x * PX_LANE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -609,8 +610,6 @@ __global__ __launch_bounds__(256) void ref_masked_pool_kernel(RefSentences rs, i
   float mn, mx;
   ref_fold_minmax(part_mm, sidx, lane, mn, mx);
   const float range = mx - mn;
-  const float* attn = rs.attn[sidx];
-  const int dirflag = rs.dirflag[sidx];
   float v[PX_LANE];
   double tot = 0.0;
   float raw[PX_LANE];      // four 16-byte loads issued together
@@ -633,11 +632,11 @@ __global__ __launch_bounds__(256) void ref_masked_pool_kernel(RefSentences rs, i
     tot += (double)val;
     if (++xcol >= W) xcol = 0;
   }
-  if (blockIdx.y == 0) {
+  if (mask_group == 0) {
     tot = wave_sum_d(tot);
     if (lane == 0) part_tot[(long long)sidx * nparts + part] = tot;
   }
-  const int n0 = blockIdx.y * MASK_GROUP;
+  const int n0 = mask_group * MASK_GROUP;
   const int n1 = min(N, n0 + MASK_GROUP);
   for (int n = n0; n < n1; ++n) {
     const uint8_t* m = masks + (long long)n * HW + p0;
@@ -670,16 +669,23 @@ __global__ __launch_bounds__(256) void ref_masked_pool_kernel(RefSentences rs, i
   }
 }
 
+__global__ __launch_bounds__(256) void ref_masked_pool_kernel(RefSentences rs, int S, const uint8_t* __restrict__ masks, int N, int H,
+                                                              int W, const float* __restrict__ part_mm, double* __restrict__ part_sum,
+                                                              unsigned* __restrict__ part_cnt, double* __restrict__ part_tot,
+                                                              int nparts) {
+  ref_masked_pool_body(rs.attn[blockIdx.z], rs.dirflag[blockIdx.z], blockIdx.z, blockIdx.y, masks, N, H, W, part_mm, part_sum, part_cnt,
+                       part_tot, nparts);
+}
+
 // one workgroup per sentence: coherence_final_kernel's reduction for its N masks, then the sentence's scoring
-__global__ __launch_bounds__(256) void ref_score_kernel(RefSentences rs, const float* __restrict__ hybrid, const float* __restrict__ text,
-                                                        const long long* __restrict__ boxes, int N, int E, int H, int W,
-                                                        float logit_scale, float r_mix, int k1, int k2, float alpha,
-                                                        const double* __restrict__ part_sum, const unsigned* __restrict__ part_cnt,
-                                                        const double* __restrict__ part_tot, int nparts, float* __restrict__ gem_all,
-                                                        float* __restrict__ clip_all, float* __restrict__ neg_all,
-                                                        float* __restrict__ soft_all, int* __restrict__ idx_all,
-                                                        unsigned long long* __restrict__ iu_all, unsigned* __restrict__ done) {
-  const int s = blockIdx.x;
+__device__ __forceinline__ void ref_score_body(const RefSentences& rs, int s, bool first, const float* __restrict__ hybrid,
+                                               const float* __restrict__ text, const long long* __restrict__ boxes, int N, int E, int H,
+                                               int W, float logit_scale, float r_mix, int k1, int k2, float alpha,
+                                               const double* __restrict__ part_sum, const unsigned* __restrict__ part_cnt,
+                                               const double* __restrict__ part_tot, int nparts, float* __restrict__ gem_all,
+                                               float* __restrict__ clip_all, float* __restrict__ neg_all, float* __restrict__ soft_all,
+                                               int* __restrict__ idx_all, unsigned long long* __restrict__ iu_all,
+                                               unsigned* __restrict__ done) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long HW = (long long)H * W;
   float* gem = gem_all + (long long)s * N;
@@ -740,7 +746,7 @@ __global__ __launch_bounds__(256) void ref_score_kernel(RefSentences rs, const f
     }
   }
   if (threadIdx.x < 4) iu_all[4 * s + threadIdx.x] = 0ull;
-  if (s == 0 && threadIdx.x == 0) *done = 0u;
+  if (first && threadIdx.x == 0) *done = 0u;
   __syncthreads();
   __threadfence_block();
   score_sentence_body(hybrid, text + (long long)rs.sent_row[s] * E, text + (long long)rs.nphr_row[s] * E,
@@ -749,14 +755,23 @@ __global__ __launch_bounds__(256) void ref_score_kernel(RefSentences rs, const f
                       soft_all + (long long)s * (2 * N + 2 * E));
 }
 
+__global__ __launch_bounds__(256) void ref_score_kernel(RefSentences rs, const float* __restrict__ hybrid, const float* __restrict__ text,
+                                                        const long long* __restrict__ boxes, int N, int E, int H, int W,
+                                                        float logit_scale, float r_mix, int k1, int k2, float alpha,
+                                                        const double* __restrict__ part_sum, const unsigned* __restrict__ part_cnt,
+                                                        const double* __restrict__ part_tot, int nparts, float* __restrict__ gem_all,
+                                                        float* __restrict__ clip_all, float* __restrict__ neg_all,
+                                                        float* __restrict__ soft_all, int* __restrict__ idx_all,
+                                                        unsigned long long* __restrict__ iu_all, unsigned* __restrict__ done) {
+  ref_score_body(rs, blockIdx.x, blockIdx.x == 0, hybrid, text, boxes, N, E, H, W, logit_scale, r_mix, k1, k2, alpha, part_sum, part_cnt,
+                 part_tot, nparts, gem_all, clip_all, neg_all, soft_all, idx_all, iu_all, done);
+}
+
 // Compute_IoU of both winners of every sentence: grid (blocks, 2 S); the last block to finish adds the ref's counts to
 // the running accumulators cum_I, cum_U, cum_I_final, cum_U_final (integers: order-free)
-__global__ __launch_bounds__(256) void ref_iou_kernel(RefSentences rs, int S, const uint8_t* __restrict__ masks, long long n,
-                                                      const int* __restrict__ idx_all, unsigned long long* __restrict__ iu_all,
-                                                      unsigned long long* __restrict__ cum, unsigned* __restrict__ done) {
-  const int s = blockIdx.y >> 1, which = blockIdx.y & 1;
-  const uint8_t* p = masks + (long long)idx_all[2 * s + which] * n;
-  const uint8_t* g = rs.target[s];
+// I / U of one block's share of a (mask, target) pair, reduced over the block: valid in thread 0
+__device__ __forceinline__ void ref_iou_block(const uint8_t* __restrict__ p, const uint8_t* __restrict__ g, long long n, unsigned& Iout,
+                                              unsigned& Uout) {
   unsigned I = 0, U = 0;
   const bool al = ((((uintptr_t)p) | ((uintptr_t)g)) & 15) == 0;
   const long long n16 = al ? n / 16 : 0;
@@ -782,17 +797,27 @@ __global__ __launch_bounds__(256) void ref_iou_kernel(RefSentences rs, int S, co
     I += __shfl_xor(I, o);
     U += __shfl_xor(U, o);
   }
-  // one pair of atomics per BLOCK (thousands of 64-bit atomics on two dozen addresses serialise in L2: 68 us for six IoUs)
   __shared__ unsigned sI[4], sU[4];
-  __shared__ int last;
   if ((threadIdx.x & 63) == 0) {
     sI[threadIdx.x >> 6] = I;
     sU[threadIdx.x >> 6] = U;
   }
   __syncthreads();
+  Iout = (sI[0] + sI[1]) + (sI[2] + sI[3]);
+  Uout = (sU[0] + sU[1]) + (sU[2] + sU[3]);
+}
+
+__global__ __launch_bounds__(256) void ref_iou_kernel(RefSentences rs, int S, const uint8_t* __restrict__ masks, long long n,
+                                                      const int* __restrict__ idx_all, unsigned long long* __restrict__ iu_all,
+                                                      unsigned long long* __restrict__ cum, unsigned* __restrict__ done) {
+  const int s = blockIdx.y >> 1, which = blockIdx.y & 1;
+  unsigned I, U;
+  ref_iou_block(masks + (long long)idx_all[2 * s + which] * n, rs.target[s], n, I, U);
+  // one pair of atomics per BLOCK (thousands of 64-bit atomics on two dozen addresses serialise in L2: 68 us for six IoUs)
+  __shared__ int last;
   if (threadIdx.x == 0) {
-    atomicAdd(&iu_all[4 * s + 2 * which], (unsigned long long)((sI[0] + sI[1]) + (sI[2] + sI[3])));
-    atomicAdd(&iu_all[4 * s + 2 * which + 1], (unsigned long long)((sU[0] + sU[1]) + (sU[2] + sU[3])));
+    atomicAdd(&iu_all[4 * s + 2 * which], (unsigned long long)I);
+    atomicAdd(&iu_all[4 * s + 2 * which + 1], (unsigned long long)U);
     __threadfence();
     last = atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1;
   }
@@ -800,6 +825,79 @@ __global__ __launch_bounds__(256) void ref_iou_kernel(RefSentences rs, int S, co
   if (last && cum != nullptr && threadIdx.x < 4) {
     unsigned long long a = 0;
     for (int j = 0; j < S; ++j) a += atomicAdd(&iu_all[4 * j + threadIdx.x], 0ull);   // coherent read of the other blocks' sums
+    cum[threadIdx.x] += a;
+  }
+}
+
+// ---- the tail of a whole GROUP of refs in the same four launches (hgl_score_group) -------------------------------------------
+// hgl_score_ref is four launches per ref of ~31 MB each: latency-bound by construction (pooling 33 us per ref = 0.9 TB/s on
+// its algorithmic bytes).  The grouped loop scores the refs of a group (16 images) back to back, so the same kernels run over
+// ALL of them at once: a table of per-ref descriptors in device memory (shapes differ from ref to ref), grids sized by the
+// largest ref with the others' surplus blocks leaving at once, ~0.5 GB per pooling launch.  A block executes the per-ref
+// kernels' bodies on its ref's operands: identical arithmetic and reduction order, identical rows.
+constexpr int GRP_MAXR = 16;       // refs per launch (the host loops over chunks)
+struct GroupRefDev {
+  RefSentences rs;
+  int S, N, H, W, k1, k2, nparts, nblk;
+  const float *hybrid, *text;
+  const long long* boxes;
+  const uint8_t* masks;
+  float* part_mm;
+  double* part_sum;
+  unsigned* part_cnt;
+  double* part_tot;
+  float *gem, *clip, *neg, *soft;
+  int* idx;
+  unsigned long long* iu;
+};
+
+__global__ __launch_bounds__(256) void grp_minmax_kernel(const GroupRefDev* __restrict__ tab) {
+  const GroupRefDev& g = tab[blockIdx.z];
+  const int s = blockIdx.y;
+  if (s >= g.S) return;
+  ref_minmax_body(g.rs.attn[s], s, (long long)g.H * g.W, g.part_mm);
+}
+
+__global__ __launch_bounds__(256) void grp_masked_pool_kernel(const GroupRefDev* __restrict__ tab, int maxS) {
+  const int ref = blockIdx.z / maxS, s = blockIdx.z - ref * maxS;
+  const GroupRefDev& g = tab[ref];
+  if (s >= g.S || (int)blockIdx.x >= g.nblk || (int)blockIdx.y * MASK_GROUP >= g.N) return;
+  ref_masked_pool_body(g.rs.attn[s], g.rs.dirflag[s], s, blockIdx.y, g.masks, g.N, g.H, g.W, g.part_mm, g.part_sum, g.part_cnt, g.part_tot,
+                       g.nparts);
+}
+
+__global__ __launch_bounds__(256) void grp_score_kernel(const GroupRefDev* __restrict__ tab, int E, float logit_scale, float r_mix,
+                                                        float alpha, unsigned* __restrict__ done) {
+  const GroupRefDev& g = tab[blockIdx.y];
+  const int s = blockIdx.x;
+  if (s >= g.S) return;
+  ref_score_body(g.rs, s, blockIdx.x == 0 && blockIdx.y == 0, g.hybrid, g.text, g.boxes, g.N, E, g.H, g.W, logit_scale, r_mix, g.k1, g.k2,
+                 alpha, g.part_sum, g.part_cnt, g.part_tot, g.nparts, g.gem, g.clip, g.neg, g.soft, g.idx, g.iu, done);
+}
+
+// grid (blocks, 2 maxS, R): every block counts on `done` (those beyond their ref's sentences do nothing else); the last one adds
+// all sentences' sums of all refs to the running accumulators (integers: order-free)
+__global__ __launch_bounds__(256) void grp_iou_kernel(const GroupRefDev* __restrict__ tab, int R, unsigned long long* __restrict__ cum,
+                                                      unsigned* __restrict__ done) {
+  const GroupRefDev& g = tab[blockIdx.z];
+  const int s = blockIdx.y >> 1, which = blockIdx.y & 1;
+  unsigned I = 0, U = 0;
+  const bool live = s < g.S;
+  if (live) ref_iou_block(g.masks + (long long)g.idx[2 * s + which] * g.H * g.W, g.rs.target[s], (long long)g.H * g.W, I, U);
+  __shared__ int last;
+  if (threadIdx.x == 0) {
+    if (live) {
+      atomicAdd(&g.iu[4 * s + 2 * which], (unsigned long long)I);
+      atomicAdd(&g.iu[4 * s + 2 * which + 1], (unsigned long long)U);
+    }
+    __threadfence();
+    last = atomicAdd(done, 1u) == gridDim.x * gridDim.y * gridDim.z - 1;
+  }
+  __syncthreads();
+  if (last && cum != nullptr && threadIdx.x < 4) {
+    unsigned long long a = 0;
+    for (int r = 0; r < R; ++r)
+      for (int j = 0; j < tab[r].S; ++j) a += atomicAdd(&tab[r].iu[4 * j + threadIdx.x], 0ull);
     cum[threadIdx.x] += a;
   }
 }
@@ -1134,6 +1232,150 @@ int hgl_score_ref(const float* hybrid, const float* text, int T, const int64_t* 
                        (unsigned long long*)iu + 4 * s0, (unsigned long long*)cum, done);
   }
   return hgl_check_launch("score_ref");
+}
+
+// ---- hgl_score_group: the refs of a group through ONE set of launches -------------------------------------------------------
+namespace {
+// workspace of one ref inside the group's workspace (the layout of hgl_score_ref's) + the descriptor table in front
+size_t grp_ws_layout(const HglGroupRef* refs, int R, int E, size_t* ref_off) {
+  size_t o = hgl_align_up((size_t)GRP_MAXR * sizeof(GroupRefDev), 256) + 256;     // table + the done counter
+  for (int i = 0; i < R; ++i) {
+    size_t off[7];
+    if (ref_off) ref_off[i] = o;
+    o += ref_ws_layout(refs[i].S, refs[i].N, E, refs[i].H, refs[i].W, off);
+  }
+  return o;
+}
+// pinned staging of the descriptor table: a ring of slots, a slot is reused only after the copy out of it has completed
+struct GrpStage {
+  static constexpr int SLOTS = 8;
+  void* buf[SLOTS] = {nullptr};
+  hipEvent_t ev[SLOTS];
+  bool used[SLOTS] = {false};
+  int next = 0;
+  std::mutex mu;
+};
+GrpStage g_grp_stage;
+}  // namespace
+
+size_t hgl_score_group_workspace_bytes(const HglGroupRef* refs, int R, int E) {
+  if (!refs || R <= 0 || E <= 0) return 0;
+  size_t total = 0;
+  for (int r0 = 0; r0 < R; r0 += GRP_MAXR) {
+    const size_t n = grp_ws_layout(refs + r0, R - r0 < GRP_MAXR ? R - r0 : GRP_MAXR, E, nullptr);
+    total = n > total ? n : total;
+  }
+  return total;
+}
+
+int hgl_score_group(const HglGroupRef* refs, int R, int E, float logit_scale, float r, float alpha, int64_t* cum, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  HGL_TRY(hgl_require_device());
+  HGL_REQUIRE(refs && R > 0 && E > 0, "score_group: bad arguments");
+  for (int i = 0; i < R; ++i) {
+    const HglGroupRef& q = refs[i];
+    HGL_REQUIRE(q.hybrid && q.text && q.boxes && q.masks && q.sentences && q.idx && q.iu, "score_group: ref %d: null argument", i);
+    HGL_REQUIRE(q.N > 0 && q.H > 0 && q.W > 0 && q.T > 0 && q.S > 0 && q.S <= REF_MAXS, "score_group: ref %d: bad shape (S %d: 1 .. %d)", i,
+                q.S, REF_MAXS);
+    HGL_REQUIRE((q.k1 < q.N ? q.k1 : q.N) >= 1 && q.k1 <= MAXK && (q.k2 < q.N ? q.k2 : q.N) >= 1 && q.k2 <= MAXK,
+                "score_group: ref %d: k1,k2 must be in [1,%d]", i, MAXK);
+    for (int s = 0; s < q.S; ++s) {
+      const HglSentence& t = q.sentences[s];
+      HGL_REQUIRE(t.imgattn && t.target, "score_group: ref %d sentence %d has no heat-map / target", i, s);
+      HGL_REQUIRE(t.sentence_row >= 0 && t.sentence_row < q.T && t.noun_phrase_row >= 0 && t.noun_phrase_row < q.T,
+                  "score_group: ref %d sentence %d: text row out of range", i, s);
+      HGL_REQUIRE(t.n_other >= 0 && (t.n_other == 0 || (t.other_row0 >= 0 && t.other_row0 + t.n_other <= q.T)),
+                  "score_group: ref %d sentence %d: other-noun rows out of range", i, s);
+      HGL_REQUIRE(t.dirflag >= 0 && t.dirflag <= 3 && t.relaword >= 0 && t.relaword <= 7, "score_group: ref %d sentence %d: bad dirflag / relaword", i, s);
+    }
+  }
+  if (!workspace || workspace_bytes < hgl_score_group_workspace_bytes(refs, R, E)) {
+    hgl_set_error("score_group: workspace too small (%zu < %zu)", workspace_bytes, hgl_score_group_workspace_bytes(refs, R, E));
+    return HGL_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  for (int r0 = 0; r0 < R; r0 += GRP_MAXR) {
+    const int rc = R - r0 < GRP_MAXR ? R - r0 : GRP_MAXR;
+    size_t ref_off[GRP_MAXR];
+    grp_ws_layout(refs + r0, rc, E, ref_off);
+    // the descriptor table, built in a pinned slot and copied in front of the workspace on the stream
+    GroupRefDev* host;
+    int slot;
+    {
+      std::lock_guard<std::mutex> lk(g_grp_stage.mu);
+      slot = g_grp_stage.next;
+      g_grp_stage.next = (slot + 1) % GrpStage::SLOTS;
+      if (!g_grp_stage.buf[slot]) {
+        if (hipHostMalloc(&g_grp_stage.buf[slot], GRP_MAXR * sizeof(GroupRefDev), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&g_grp_stage.ev[slot], hipEventDisableTiming) != hipSuccess) {
+          hgl_set_error("score_group: cannot allocate the pinned descriptor slot");
+          return HGL_ELAUNCH;
+        }
+      } else if (g_grp_stage.used[slot]) {
+        (void)hipEventSynchronize(g_grp_stage.ev[slot]);      // eight calls ago: long complete
+      }
+      host = (GroupRefDev*)g_grp_stage.buf[slot];
+    }
+    int maxS = 0, max_nblk = 0, max_groups = 0;
+    long long max_iou_blocks = 1;
+    for (int i = 0; i < rc; ++i) {
+      const HglGroupRef& q = refs[r0 + i];
+      GroupRefDev& d = host[i];
+      memset(&d, 0, sizeof(d));
+      for (int j = 0; j < q.S; ++j) {
+        const HglSentence& t = q.sentences[j];
+        d.rs.attn[j] = t.imgattn; d.rs.target[j] = t.target;
+        d.rs.sent_row[j] = t.sentence_row; d.rs.nphr_row[j] = t.noun_phrase_row;
+        d.rs.other_row0[j] = t.n_other > 0 ? t.other_row0 : 0; d.rs.n_other[j] = t.n_other;
+        d.rs.dirflag[j] = t.dirflag; d.rs.rela[j] = t.relaword; d.rs.has_other[j] = t.has_other_nouns; d.rs.black[j] = t.black;
+      }
+      d.S = q.S; d.N = q.N; d.H = q.H; d.W = q.W;
+      d.k1 = q.k1 < q.N ? q.k1 : q.N;       // Hybridgl_main.py:178-181
+      d.k2 = q.k2 < q.N ? q.k2 : q.N;
+      d.nparts = coh_nparts(q.H, q.W);
+      d.nblk = coh_nblk(q.H, q.W);
+      d.hybrid = q.hybrid; d.text = q.text; d.boxes = (const long long*)q.boxes; d.masks = q.masks;
+      size_t off[7];
+      ref_ws_layout(q.S, q.N, E, q.H, q.W, off);
+      char* rb = base + ref_off[i];
+      d.part_mm = (float*)(rb + off[0]);
+      d.part_sum = (double*)(rb + off[1]);
+      d.part_cnt = (unsigned*)(rb + off[2]);
+      d.part_tot = (double*)(rb + off[3]);
+      d.soft = (float*)(rb + off[4]);
+      float* spare = (float*)(rb + off[5]);
+      d.gem = q.gem_score ? q.gem_score : spare;
+      d.clip = q.score_clip ? q.score_clip : spare + (long long)q.S * q.N;
+      d.neg = q.score_neg ? q.score_neg : spare + 2ll * q.S * q.N;
+      d.idx = (int*)q.idx;
+      d.iu = (unsigned long long*)q.iu;
+      maxS = q.S > maxS ? q.S : maxS;
+      max_nblk = d.nblk > max_nblk ? d.nblk : max_nblk;
+      const int groups = (q.N + MASK_GROUP - 1) / MASK_GROUP;
+      max_groups = groups > max_groups ? groups : max_groups;
+      long long blocks = ((long long)q.H * q.W / 16 + 1023) / 1024;
+      blocks = blocks < 1 ? 1 : (blocks > 32 ? 32 : blocks);
+      max_iou_blocks = blocks > max_iou_blocks ? blocks : max_iou_blocks;
+    }
+    GroupRefDev* tab = (GroupRefDev*)base;
+    unsigned* done = (unsigned*)(base + hgl_align_up((size_t)GRP_MAXR * sizeof(GroupRefDev), 256));
+    if (hipMemcpyAsync(tab, host, (size_t)rc * sizeof(GroupRefDev), hipMemcpyHostToDevice, st) != hipSuccess) {
+      hgl_set_error("score_group: descriptor upload failed");
+      return HGL_ELAUNCH;
+    }
+    {
+      std::lock_guard<std::mutex> lk(g_grp_stage.mu);
+      (void)hipEventRecord(g_grp_stage.ev[slot], st);
+      g_grp_stage.used[slot] = true;
+    }
+    hipLaunchKernelGGL(grp_minmax_kernel, dim3(REF_MM_BLOCKS, maxS, rc), dim3(256), 0, st, (const GroupRefDev*)tab);
+    hipLaunchKernelGGL(grp_masked_pool_kernel, dim3(max_nblk, max_groups, rc * maxS), dim3(256), 0, st, (const GroupRefDev*)tab, maxS);
+    hipLaunchKernelGGL(grp_score_kernel, dim3(maxS, rc), dim3(256), 0, st, (const GroupRefDev*)tab, E, logit_scale, r, alpha, done);
+    hipLaunchKernelGGL(grp_iou_kernel, dim3((unsigned)max_iou_blocks, 2 * maxS, rc), dim3(256), 0, st, (const GroupRefDev*)tab, rc,
+                       (unsigned long long*)cum, done);
+  }
+  return hgl_check_launch("score_group");
 }
 
 int hgl_gen_dir_mask(int dirflag, int H, int W, float* out, void* stream) {

@@ -385,6 +385,60 @@ def score_ref(hybrid, text, boxes, masks, sentences, logit_scale=100.0, r=0.5, k
     return (idx, iu, sc, sn, gm) if want_scores else (idx, iu)
 
 
+SCORE_GROUP_MAX_SENTENCES = 16      # per ref and call (csrc/scoring.hip REF_MAXS)
+
+
+def score_group(refs, logit_scale=100.0, r=0.5, alpha=0.6, cum=None, want_scores=False):
+    """The tails of the R refs of a group (Hybridgl_main.py:153-230 each) in ONE set of four launches: hgl_score_group.
+    refs: list of dicts {hybrid [N,E], text [T,E], boxes [N,4] int64, masks [N,H,W], sentences (as for score_ref, at most
+    16), k1, k2}; shapes may differ from ref to ref.  cum as for score_ref.  Returns one tuple per ref, as score_ref would
+    (rows identical to its rows)."""
+    lib = _lib.load()
+    R = len(refs)
+    recs = (_lib.HglGroupRef * R)()
+    keep, outs = [], []
+    E = refs[0]["hybrid"].shape[1]
+    dev = refs[0]["hybrid"].device
+    for i, q in enumerate(refs):
+        hybrid, text = q["hybrid"], q["text"]
+        N, T = hybrid.shape[0], text.shape[0]
+        mp, masks = _u8(q["masks"], "masks")
+        _, H, W = masks.shape
+        S = len(q["sentences"])
+        if not 1 <= S <= SCORE_GROUP_MAX_SENTENCES:
+            raise ValueError(f"ref {i}: {S} sentences (1 .. {SCORE_GROUP_MAX_SENTENCES} per call)")
+        sent = (_lib.HglSentence * S)()
+        for j, t in enumerate(q["sentences"]):
+            a = t["imgattn"]
+            if tuple(a.shape) != (H, W):
+                raise ValueError(f"ref {i} sentence {j}: imgattn {tuple(a.shape)} != masks {(H, W)}")
+            tp, tt = _u8(t["target"], "target")
+            if tuple(tt.shape) != (H, W):
+                raise ValueError(f"ref {i} sentence {j}: target {tuple(tt.shape)} != masks {(H, W)}")
+            keep += [a, tt]
+            sent[j] = _lib.HglSentence(int(t["sentence_row"]), int(t["noun_phrase_row"]), int(t.get("other_row0", 0)), int(t.get("n_other", 0)),
+                                       DIRFLAG.get(t.get("dirflag", "none"), 0), RELAWORD.get(t.get("relaword", "none"), 0),
+                                       int(bool(t.get("has_other_nouns", False))), float(t.get("black", 1.8)),
+                                       _dev(a, torch.float32, "imgattn"), tp)
+        idx = torch.empty((S, 2), dtype=torch.int32, device=dev)
+        iu = torch.empty((S, 4), dtype=torch.int64, device=dev)
+        sc = sn = gm = None
+        if want_scores:
+            sc, sn, gm = (torch.empty((S, N), dtype=torch.float32, device=dev) for _ in range(3))
+        keep += [sent, masks]
+        recs[i] = _lib.HglGroupRef(_dev(hybrid, torch.float32, "hybrid"), _dev(text, torch.float32, "text"), T,
+                                   _dev(q["boxes"], torch.int64, "boxes"), mp, N, H, W, sent, S, int(q["k1"]), int(q["k2"]),
+                                   idx.data_ptr(), iu.data_ptr(), sc.data_ptr() if sc is not None else None,
+                                   sn.data_ptr() if sn is not None else None, gm.data_ptr() if gm is not None else None)
+        outs.append((idx, iu, sc, sn, gm) if want_scores else (idx, iu))
+    need = lib.hgl_score_group_workspace_bytes(recs, R, E)
+    ws = workspace(need, dev, "score_group")
+    check(lib.hgl_score_group(recs, R, E, float(logit_scale), float(r), float(alpha),
+                              _dev(cum, torch.int64, "cum") if cum is not None else None, ws.data_ptr(), ws.numel(), _stream()),
+          "hgl_score_group")
+    return outs
+
+
 def synthesize_views(sam_img, blurred, image_norm, masks, res=224, out=None):
     """Hybridgl_main.py:93-125 -> (local_imgs, global_imgs) [N,3,res,res] fp32 (written into `out` when given)."""
     lib = _lib.load()

@@ -138,6 +138,8 @@ class HybridGLPipeline:
         import os
         # the per-sentence tail as ONE hgl_score_ref call per ref (HYBRIDGL_FUSED_TAIL=0: the per-sentence launches)
         self.fused_tail = os.environ.get("HYBRIDGL_FUSED_TAIL", "1") != "0"
+        # run(): the tails of ALL refs of a group in one hgl_score_group call (HYBRIDGL_GROUP_TAIL=0: one hgl_score_ref per ref)
+        self.group_tail = os.environ.get("HYBRIDGL_GROUP_TAIL", "1") != "0"
         self.stagger = os.environ.get("HYBRIDGL_STAGGER", "decoder")   # which part of the next group's SAM stage the CLIP stage runs beside
         self._k0 = (k1, k2)
         self.model = model
@@ -252,8 +254,29 @@ class HybridGLPipeline:
         cur.wait_event(ev_text)
         return hybrid, text, self._score_ref(ref, hybrid, text, heat)
 
-    def _score_ref(self, ref, hybrid, text, heat):
-        """the per-sentence tail of Hybridgl_main.py:153-230 for one ref; returns the tensors of its last sentence"""
+    _DEFERRED = object()
+
+    def _log_tail(self, ref_index, n, idx, iu):
+        for j in range(n):
+            self.iu_log.append((iu[j, 0:2], iu[j, 2:4]))
+            self.iu_owner.append((ref_index, j))
+            self.idx_log.append(idx[j])
+
+    def _flush_tails(self, defer):
+        """the deferred tails of a group's refs in one hgl_score_group call; returns each ref's last-sentence tensors, in order"""
+        if not defer:
+            return []
+        outs = ops.score_group(defer, self.model.model._logit_scale_exp, self.r, self.alpha, cum=self.cum, want_scores=True)
+        last = []
+        for q, (idx, iu, sc, sn, gm) in zip(defer, outs):
+            self._log_tail(q["ref_index"], len(q["sentences"]), idx, iu)
+            last.append((idx[-1], sc[-1], sn[-1], gm[-1]))
+        defer.clear()
+        return last
+
+    def _score_ref(self, ref, hybrid, text, heat, defer=None):
+        """the per-sentence tail of Hybridgl_main.py:153-230 for one ref; returns the tensors of its last sentence.  defer (a
+        list): a ref whose tail the fused kernels serve is appended to it instead (for _flush_tails) and _DEFERRED returned"""
         m = self.model
         # the k1/k2 clamp of Hybridgl_main.py:178-181 persists across refs in the reference
         if self.k_clamp == "per_ref":
@@ -277,12 +300,13 @@ class HybridGLPipeline:
                          dirflag=s.dirflag, relaword=s.relaflag, has_other_nouns=s.n_nouns != 0, black=black_for(s.relaflag),
                          imgattn=a if a.is_contiguous() else a.contiguous(), target=s.target if s.target is not None else ref.target)
                     for s, a in zip(ref.sentences, attn)]
+            if defer is not None and 1 <= len(recs) <= ops.SCORE_GROUP_MAX_SENTENCES:
+                defer.append(dict(hybrid=hybrid, text=text, boxes=ref.boxes, masks=ref.masks, sentences=recs, k1=self.k1, k2=self.k2,
+                                  ref_index=ref_index))
+                return self._DEFERRED
             idx, iu, sc, sn, gm = ops.score_ref(hybrid, text, ref.boxes, ref.masks, recs, m.model._logit_scale_exp, self.r, self.k1,
                                                 self.k2, self.alpha, cum=self.cum, want_scores=True)
-            for j in range(len(recs)):
-                self.iu_log.append((iu[j, 0:2], iu[j, 2:4]))
-                self.iu_owner.append((ref_index, j))
-                self.idx_log.append(idx[j])
+            self._log_tail(ref_index, len(recs), idx, iu)
             return (idx[-1], sc[-1], sn[-1], gm[-1]) if recs else None
         last = None
         for sent_no, (s, imgattn) in enumerate(zip(ref.sentences, attn)):
@@ -560,15 +584,29 @@ class HybridGLPipeline:
                 live[i][3] = hybrid_all[moff[j]:moff[j + 1]]
         cur.wait_event(ev_text)
         k = 0
+        defer = [] if self.group_tail else None      # the refs whose tails go into ONE hgl_score_group call at the end
+        waiting = []                                 # their (hybrid, text) for `collected`, in order
         for refs, mk, bx, hybrid, gfeat in live:
             if self.image_cache > 0 and props is not None and refs[0].image_id is not None:
                 self._cache_put(refs[0].image_id, (mk, bx, hybrid, gfeat))
             for ref in refs:
                 text = text_all[offs[k]:offs[k + 1]]
-                out = self._score_ref(dataclasses.replace(ref, masks=mk, boxes=bx), hybrid, text, heats[k])
+                out = self._score_ref(dataclasses.replace(ref, masks=mk, boxes=bx), hybrid, text, heats[k], defer)
                 k += 1
+                if out is self._DEFERRED:
+                    waiting.append((hybrid, text))
+                    continue
+                if defer:      # a ref the group call does not serve: the deferred ones before it are logged first (order)
+                    for (h0, t0), o0 in zip(waiting, self._flush_tails(defer)):
+                        if self.collected is not None:
+                            self.collected.append((h0, t0, o0))
+                    waiting = []
                 if self.collected is not None:
                     self.collected.append((hybrid, text, out))
+        if defer:
+            for (h0, t0), o0 in zip(waiting, self._flush_tails(defer)):
+                if self.collected is not None:
+                    self.collected.append((h0, t0, o0))
         return len(all_refs)
 
     def _cache_put(self, image_id, entry):

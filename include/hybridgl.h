@@ -330,6 +330,29 @@ int hgl_score_ref(const float* hybrid, const float* text, int T, const int64_t* 
                   int32_t* idx, int64_t* iu, int64_t* cum, float* score_clip, float* score_neg, float* gem_score,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same tail for the R refs of a group in ONE set of launches (the grouped evaluation loop scores a group's refs back to
+ * back; four launches of ~31 MB per ref are latency-bound, one launch over the group streams ~0.5 GB).  Shapes may differ from
+ * ref to ref.  Per ref: the arguments of hgl_score_ref (S <= 16 sentences; k1 / k2 are this ref's values of the clamp of
+ * Hybridgl_main.py:178-181, which the caller carries from ref to ref) and its outputs idx [S,2], iu [S,4] and, optionally,
+ * score_clip / score_neg / gem_score [S,N].  cum as for hgl_score_ref (the sums of all refs' sentences are added once).
+ * Rows identical to hgl_score_ref's (same kernels' bodies on a per-ref descriptor table). */
+typedef struct HglGroupRef {
+  const float* hybrid;                /* [N,E] */
+  const float* text;                  /* [T,E] */
+  int T;
+  const int64_t* boxes;               /* [N,4] XYWH */
+  const uint8_t* masks;               /* [N,H*W] */
+  int N, H, W;
+  const HglSentence* sentences;       /* HOST array [S] */
+  int S, k1, k2;
+  int32_t* idx;                       /* [S,2] */
+  int64_t* iu;                        /* [S,4] */
+  float *score_clip, *score_neg, *gem_score;   /* [S,N] each, or NULL */
+} HglGroupRef;
+size_t hgl_score_group_workspace_bytes(const HglGroupRef* refs, int R, int E);
+int hgl_score_group(const HglGroupRef* refs, int R, int E, float logit_scale, float r, float alpha, int64_t* cum, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* Compute_IoU on a mask selected on the device: pred = masks[idx[which]] ([N,HW] uint8),
  * so the winning index never travels to the host (Hybridgl_main.py:169-171,227-230). */
 int hgl_iou_select(const uint8_t* masks, const int32_t* idx, int which, const uint8_t* gt,

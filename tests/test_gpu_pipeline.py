@@ -304,3 +304,35 @@ def test_fused_tail_equals_per_sentence_launches(cuda, N, H, W, n_sent):
     for x, y in zip(*outs):
         for u, v in zip(x, y):
             assert torch.equal(u, v, ) or (torch.isnan(u) == torch.isnan(v)).all() and torch.equal(torch.nan_to_num(u), torch.nan_to_num(v))
+
+
+def test_group_tail_equals_per_ref_tail(cuda):
+    """hgl_score_group (the tails of ALL refs of a group in one set of four launches, a per-ref descriptor table in device
+    memory, grids sized by the largest ref) against hgl_score_ref per ref through the grouped loop run(): rows, winning
+    indices, accumulators and the collected last-sentence tensors BIT FOR BIT -- refs of different image sizes, proposal
+    counts and sentence counts in one group, a ref with a single proposal (k clamp), more refs than one launch holds (16),
+    the persistent clamp of Hybridgl_main.py:178-181 carried from ref to ref."""
+    from hybridgl_amd.backbone import CLIPViTFM
+    from hybridgl_amd.pipeline import HybridGLPipeline, synthetic_ref
+    model = CLIPViTFM("tiny", seed=0, device=cuda)
+    shapes = [(13, 97, 131, 5), (7, 120, 160, 3), (30, 200, 150, 9), (1, 64, 64, 2), (5, 80, 72, 16)]
+    refs = []
+    for i in range(19):
+        N, H, W, n_sent = shapes[i % len(shapes)]
+        r = synthetic_ref(i, cuda, N=N, H=H, W=W, n_sent=n_sent, vocab=512, context=16)[0]
+        if n_sent > 1:
+            r.sentences[1].other_noun_rows = []
+            r.sentences[1].n_nouns = 0
+        refs.append(r)
+    for clamp in ("per_ref", "persistent"):
+        a, b = HybridGLPipeline(model, res=64, k_clamp=clamp), HybridGLPipeline(model, res=64, k_clamp=clamp)
+        a.group_tail, b.group_tail = True, False
+        for p in (a, b):
+            assert p.run(iter(refs), group=19, collect=True) == len(refs)
+        torch.cuda.synchronize()
+        assert np.array_equal(a.partial_rows(), b.partial_rows()) and a.partial_rows().shape[0] == sum(s[3] for s in shapes) * 3 + sum(s[3] for s in shapes[:4])
+        assert np.array_equal(a.winning_indices(), b.winning_indices())
+        assert torch.equal(a.cum, b.cum) and int(a.cum[1]) > 0
+        for (h0, t0, o0), (h1, t1, o1) in zip(a.collected, b.collected):
+            for u, v in zip(o0, o1):
+                assert torch.equal(torch.nan_to_num(u), torch.nan_to_num(v)) and torch.equal(torch.isnan(u), torch.isnan(v))

@@ -46,6 +46,27 @@ def per_sentence():
         cum[2:4] += ops.iou_select(ref.masks, idx, 1, ref.target)
 
 
+# sixteen refs with their own masks / heat-maps / targets (0.5 GB of mask planes: nothing is served from a cache twice)
+grp = []
+for i in range(16):
+    r, _ = synthetic_ref(i, dev, N=64)
+    grp.append(dict(hybrid=hybrid, text=text, boxes=r.boxes, masks=r.masks, k1=3, k2=6,
+                    sentences=[dict(sentence_row=3 * j, noun_phrase_row=3 * j + 1, other_row0=3 * j + 2, n_other=1, dirflag=s.dirflag,
+                                    relaword=s.relaflag, has_other_nouns=s.n_nouns != 0, black=1.8, imgattn=s.imgattn, target=r.target)
+                               for j, s in enumerate(r.sentences)]))
+
+
+def group16():
+    ops.score_group(grp, 100.0, 0.5, 0.6, cum=cum)
+
+
+def per_ref16():
+    for q in grp:
+        ops.score_ref(q["hybrid"], q["text"], q["boxes"], q["masks"], q["sentences"], 100.0, 0.5, 3, 6, 0.6, cum=cum)
+
+
+timed(group16, "hgl_score_group, 16 refs (4 launches), x16")
+timed(per_ref16, "hgl_score_ref x 16 refs (64 launches), x16")
 timed(fused, "hgl_score_ref (4 launches)")
 timed(per_sentence, "per-sentence launches (3 sentences)")
 timed(lambda: ops.coherence_scores(ref.sentences[0].imgattn, ref.masks, "left", 1.8), "hgl_coherence_scores, one sentence")
