@@ -578,8 +578,9 @@ constexpr size_t psp_lds_bytes() {
   return (size_t)PspGeom<HD>::E_OFF + (MODE == PS_WIN14 ? PSP_EBYTES : 0) + 256;
 }
 
-template <int HD, int MODE>
+template <int HD, int MODE, int QT = 1>
 __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsigned char* __restrict__ etab) {
+  static_assert(QT == 1 || (QT == 2 && MODE == PS_PLAIN), "two query tiles per wave: the plain mode only");
   using G = PspGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, KP = G::KP, VP = G::VP;
   extern __shared__ __attribute__((aligned(1024))) unsigned char ps_smem[];
@@ -690,34 +691,46 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
     keep_row = a.keep + (long long)((b - a.keep_b0) % a.keep_n) * (a.S - 1);
   if (keep_row && t < a.S - 1) keepL[t] = keep_row[t];
 
-  // ---- Q fragments ----
-  const int q0 = (bx * 4 + wave) * 32;
-  const int qi = q0 + r;
-  const bool qvalid = qi < a.S;
-  const bool wave_active = q0 < a.S;
-  h16x8 qh[KS], ql[KS];
-  {
-    const long long qo = ((long long)b * a.sb + (qvalid ? qi : 0)) * a.ld + a.qcol + hh * HD + 8 * h;
+  // ---- Q fragments of the wave's QT query tiles ----
+  const int q0 = (bx * 4 + wave) * QT * 32;
+  int qi[QT];
+  bool qvalid[QT], tile_active[QT];
+  h16x8 qh[QT][KS], ql[QT][KS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    qi[qt] = q0 + 32 * qt + r;
+    qvalid[qt] = qi[qt] < a.S;
+    tile_active[qt] = q0 + 32 * qt < a.S;
+    const long long qo = ((long long)b * a.sb + (qvalid[qt] ? qi[qt] : 0)) * a.ld + a.qcol + hh * HD + 8 * h;
 #pragma unroll
     for (int sx = 0; sx < KS; ++sx) {
-      qh[sx] = *(const h16x8*)(a.hi + qo + 16 * sx);
-      ql[sx] = *(const h16x8*)(a.lo + qo + 16 * sx);
+      qh[qt][sx] = *(const h16x8*)(a.hi + qo + 16 * sx);
+      ql[qt][sx] = *(const h16x8*)(a.lo + qo + 16 * sx);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (!qvalid) {
 #pragma unroll
-    for (int sx = 0; sx < KS; ++sx)
+  for (int qt = 0; qt < QT; ++qt) {
+    if (!qvalid[qt]) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { qh[sx][e] = (_Float16)0.f; ql[sx][e] = (_Float16)0.f; }
+      for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qh[qt][sx][e] = (_Float16)0.f; ql[qt][sx][e] = (_Float16)0.f; }
+    }
   }
+  const bool wave_active = tile_active[0];
 
-  f32x16 o[DT];
+  f32x16 o[QT][DT];
+  float m_run[QT], l_run[QT];
 #pragma unroll
-  for (int d = 0; d < DT; ++d)
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = NEG_INF;
+    l_run[qt] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-  float m_run = NEG_INF, l_run = 0.f;
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qt][d][e] = 0.f;
+  }
 
   // ---- PS_WIN14: R fragments of the MFMA bias (see attn_ps_kernel); the per-wave patch aliases ring stages that receive
   // their first DMA behind the loop's first barrier (waves 0-1: K stage 2, waves 2-3: V stage 1)
@@ -730,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
       for (int j = 0; j < 8; ++j) xs[c][j] = 0.f;
     if (wave_active && !(a.dbg & 16)) {
       float* const P0 = (float*)(ps_smem + (wave < 2 ? G::K_RING + 2 * G::KSTAGE : G::V_RING + G::VSTAGE)) + (wave & 1) * 32 * 32;
-      const int qq = qvalid ? qi : 0;
+      const int qq = qvalid[0] ? qi[0] : 0;
       const int qy = qq / 14, qx = qq - qy * 14;
 #pragma unroll
       for (int axis = 0; axis < 2; ++axis) {
@@ -748,9 +761,9 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int sx = 0; sx < KS; ++sx) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tlr[sx], qh[sx], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(thr[sx], ql[sx], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(thr[sx], qh[sx], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tlr[sx], qh[0][sx], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(thr[sx], ql[0][sx], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(thr[sx], qh[0][sx], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) P0[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[e];
@@ -801,22 +814,24 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
   // every compiler-counted load is waited for HERE (see attn_ps_kernel): chunk 0 of K and V, chunk 1 of K, the table and Q
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int sx = 0; sx < KS; ++sx) asm volatile("" : "+v"(qh[sx]), "+v"(ql[sx]));
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int sx = 0; sx < KS; ++sx) asm volatile("" : "+v"(qh[qt][sx]), "+v"(ql[qt][sx]));
   if constexpr (MODE == PS_RELT) {
     asm volatile("" : "+v"(rh_next), "+v"(rw_next[0]), "+v"(rw_next[1]), "+v"(rw_next[2]), "+v"(rw_next[3]));
   }
   __syncthreads();
 
   // QK^T of key chunk ci into a fresh accumulator (PS_RELT: started at the prefetched rel-pos terms)
-  auto qk = [&](int ci, f32x16& s) {
+  auto qk = [&](int ci, f32x16& s, const h16x8 (&QH)[KS], const h16x8 (&QL)[KS]) {
     const _Float16* krow = (const _Float16*)(ps_smem + G::K_RING + (ci % 3) * G::KSTAGE) + k_off;
 #pragma unroll
     for (int c = 0; c < KS; ++c) {
       const h16x8 kh8 = *(const h16x8*)(krow + 16 * c);
       const h16x8 kl8 = *(const h16x8*)(krow + HD + 16 * c);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[c], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, ql[c], s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh[c], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, QH[c], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, QL[c], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, QH[c], s, 0, 0, 0);
     }
     if constexpr (MODE == PS_WIN14) {
       const unsigned char* eb = ps_smem + G::E_OFF + ci * (PS_CHUNK * 64);
@@ -842,7 +857,7 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
   f32x16 s_cur;
   if (wave_active) {
     s_init(s_cur);
-    qk(0, s_cur);
+    qk(0, s_cur, qh[0], ql[0]);
     if (MODE == PS_RELT && nchunk > 1) rel_prefetch(32);
   }
 
@@ -863,170 +878,191 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
     if (!wave_active) continue;   // uniform
     const int kbase = ci * PS_CHUNK;
     const bool has_next = ci + 1 < nchunk;
-    if (kbase + 32 > a.S) {   // uniform: the tile that crosses the end of the sequence
+    // One (query tile, key tile) pair: masks, segment A = its soft-max beside the QK^T chain of the wave's NEXT pair (the other
+    // query tile on this chunk, or the first on the next chunk), the rare rescaling of O, segment B = its P V products.
+    //   cur      : the tile (a compile-time index: its O, running maximum and sum are registers)
+    //   nxt      : the query tile of the next pair
+    //   with_next: there is a next pair; nci its key chunk
+    auto tile = [&](auto cur_c, auto nxt_c, bool wn, int nci) {
+      constexpr int CUR = decltype(cur_c)::value, NXT = decltype(nxt_c)::value;
+      if (kbase + 32 > a.S) {   // uniform: the tile that crosses the end of the sequence
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-        s_cur[e] = kg >= a.S ? NEG_INF : s_cur[e];
+        for (int e = 0; e < 16; ++e) {
+          const int kg = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+          s_cur[e] = kg >= a.S ? NEG_INF : s_cur[e];
+        }
       }
-    }
-    if (MODE == PS_PLAIN && keep_row && bx == 0 && wave == 0) {   // uniform: the tile that owns query 0
-      const int kk = kbase + (lane & 31);
-      const unsigned kb = kk >= 1 && kk < a.S ? keepL[kk - 1] : 1u;
-      const unsigned bits = (unsigned)__builtin_amdgcn_ballot_w64(kb != 0) >> (4 * h);
+      if (MODE == PS_PLAIN && CUR == 0 && keep_row && bx == 0 && wave == 0) {   // uniform: the tile that owns query 0
+        const int kk = kbase + (lane & 31);
+        const unsigned kb = kk >= 1 && kk < a.S ? keepL[kk - 1] : 1u;
+        const unsigned bits = (unsigned)__builtin_amdgcn_ballot_w64(kb != 0) >> (4 * h);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const bool kept = (bits >> ((e & 3) + 8 * (e >> 2))) & 1u;
-        s_cur[e] = (qi == 0 && !kept) ? NEG_INF : s_cur[e];
+        for (int e = 0; e < 16; ++e) {
+          const bool kept = (bits >> ((e & 3) + 8 * (e >> 2))) & 1u;
+          s_cur[e] = (qi[0] == 0 && !kept) ? NEG_INF : s_cur[e];
+        }
       }
-    }
-    // ---- segment A: soft-max of tile ci beside the QK^T products of tile ci + 1 (one basic block) ----
-    f32x16 s_next;
-    h16x8 ph[2], pl[2];
-    float alpha = 1.0f;
-    bool need;
-    // The interleave is written out by hand: 19 groups of soft-max work (U: the max chain, the rescaling decision; E_k: two
-    // exponentials; F_k / G_k: the hi / lo split of a pair), each behind its share of the QK^T chain's matrix instructions,
-    // with __builtin_amdgcn_sched_barrier(0) between the groups -- sched_group_barrier pipelines are not honoured by this
-    // compiler for this block (it emits the 19 dependent MFMAs first and the soft-max behind them, round 2 found the same),
-    // and an in-order wave overlaps the two pipes only where they alternate in its instruction stream.
-    auto seg_a = [&](auto with_next) {
-      constexpr bool WN = decltype(with_next)::value;
-      constexpr int NM = WN ? 3 * KS + (MODE == PS_WIN14 ? 4 : 0) : 0;
-      constexpr int NG = 19;
-      const _Float16* krow = (const _Float16*)(ps_smem + G::K_RING + ((ci + 1) % 3) * G::KSTAGE) + k_off;
-      const unsigned char* eb = ps_smem + G::E_OFF + (ci + 1) * (PS_CHUNK * 64);
-      h16x8 fa, fb, fa2, fb2;       // fragments of the current k-step (hi, lo) and of the next
-      if constexpr (WN) {
-        s_init(s_next);
-        fa = *(const h16x8*)(krow);
-        fb = *(const h16x8*)(krow + HD);
-      }
-      // matrix instruction i of the chain: k-step c = i / 3 (lo*hi, hi*lo, hi*hi), then the two indicator steps (lo, hi of R)
-      auto mfma_i = [&](int i) {
+      // ---- segment A (one basic block).  The interleave is written out by hand: 19 groups of soft-max work (U: the max chain,
+      // the rescaling decision; E_k: two exponentials; F_k / G_k: the hi / lo split of a pair), each behind its share of the
+      // QK^T chain's matrix instructions, with __builtin_amdgcn_sched_barrier(0) between the groups -- sched_group_barrier
+      // pipelines are not honoured by this compiler for this block (it emits the dependent MFMAs first and the soft-max behind
+      // them, round 2 found the same), and an in-order wave overlaps the two pipes only where they alternate in its stream.
+      f32x16 s_next;
+      h16x8 ph[2], pl[2];
+      float alpha = 1.0f;
+      bool need;
+      auto seg_a = [&](auto with_next) {
+        constexpr bool WN = decltype(with_next)::value;
+        constexpr int NM = WN ? 3 * KS + (MODE == PS_WIN14 ? 4 : 0) : 0;
+        constexpr int NG = 19;
+        const _Float16* krow = (const _Float16*)(ps_smem + G::K_RING + (nci % 3) * G::KSTAGE) + k_off;
+        const unsigned char* eb = ps_smem + G::E_OFF + nci * (PS_CHUNK * 64);
+        h16x8 fa, fb, fa2, fb2;       // fragments of the current k-step (hi, lo) and of the next
         if constexpr (WN) {
-          if (i < 3 * KS) {
-            const int c = i / 3, term = i - 3 * c;
-            if (term == 0) {
-              // the next step's fragments travel under this step's three products
-              if (c + 1 < KS) {
-                fa2 = *(const h16x8*)(krow + 16 * (c + 1));
-                fb2 = *(const h16x8*)(krow + HD + 16 * (c + 1));
-              } else if (MODE == PS_WIN14) {
-                fa2 = *(const h16x8*)(eb + e_off[0]);
-                fb2 = *(const h16x8*)(eb + e_off[1]);
+          s_init(s_next);
+          fa = *(const h16x8*)(krow);
+          fb = *(const h16x8*)(krow + HD);
+        }
+        // matrix instruction i of the chain: k-step c = i / 3 (lo*hi, hi*lo, hi*hi), then the two indicator steps (lo, hi of R)
+        auto mfma_i = [&](int i) {
+          if constexpr (WN) {
+            if (i < 3 * KS) {
+              const int c = i / 3, term = i - 3 * c;
+              if (term == 0) {
+                // the next step's fragments travel under this step's three products
+                if (c + 1 < KS) {
+                  fa2 = *(const h16x8*)(krow + 16 * (c + 1));
+                  fb2 = *(const h16x8*)(krow + HD + 16 * (c + 1));
+                } else if (MODE == PS_WIN14) {
+                  fa2 = *(const h16x8*)(eb + e_off[0]);
+                  fb2 = *(const h16x8*)(eb + e_off[1]);
+                }
+                s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, qh[NXT][c], s_next, 0, 0, 0);
+              } else if (term == 1) {
+                s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, ql[NXT][c], s_next, 0, 0, 0);
+              } else {
+                s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, qh[NXT][c], s_next, 0, 0, 0);
+                fa = fa2;
+                fb = fb2;
               }
-              s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, qh[c], s_next, 0, 0, 0);
-            } else if (term == 1) {
-              s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, ql[c], s_next, 0, 0, 0);
-            } else {
-              s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, qh[c], s_next, 0, 0, 0);
-              fa = fa2;
-              fb = fb2;
-            }
-          } else if (MODE == PS_WIN14) {
-            const int j = i - 3 * KS;      // 0, 1: E step 0 with R lo, hi; 2, 3: E step 1
-            const h16x8 e8 = j < 2 ? fa : fb;
-            s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(e8, (j & 1) ? rbh[j >> 1] : rbl[j >> 1], s_next, 0, 0, 0);
-          }
-        }
-      };
-      float mxa = NEG_INF, mxb = NEG_INF, m_use0 = 0.f, mneg = 0.f, rs = 0.f;
-      float pe[16];
-      h16x2 hi2[8];
-      auto valu_g = [&](int g) {
-        if (g == 0) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) mxa = fmaxf(mxa, s_cur[e]);
-        } else if (g == 1) {
-#pragma unroll
-          for (int e = 8; e < 16; ++e) mxb = fmaxf(mxb, s_cur[e]);
-          mxa = ps_max_halves(fmaxf(mxa, mxb));
-        } else if (g == 2) {
-          const float m_cand = fmaxf(m_run, mxa);
-          need = __builtin_amdgcn_ballot_w64(m_cand > m_run + rescale_thr) != 0;
-          const float m_new = need ? m_cand : m_run;
-          m_use0 = (m_new == NEG_INF) ? 0.f : m_new;
-          alpha = __builtin_amdgcn_exp2f((m_run - m_use0) * sl2e);   // used only when `need`
-          m_run = m_new;
-          mneg = -m_use0 * sl2e;
-          l_run = need ? l_run * alpha : l_run;
-        } else {
-          // pair k: E_k in group 3 + 2k (k < 1) ... see the table: E_k at ge[k], F_k at gf[k], G_k at gg[k]
-          constexpr int ge[8] = {3, 4, 6, 8, 10, 12, 14, 16};
-          constexpr int gf[8] = {4, 6, 8, 10, 12, 14, 16, 17};
-          constexpr int gg[8] = {5, 7, 9, 11, 13, 15, 17, 18};
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            if (g == ge[k]) {
-              pe[2 * k] = __builtin_amdgcn_exp2f(fmaf(s_cur[2 * k], sl2e, mneg));
-              pe[2 * k + 1] = __builtin_amdgcn_exp2f(fmaf(s_cur[2 * k + 1], sl2e, mneg));
-            }
-            if (g == gf[k]) {
-              rs += pe[2 * k];
-              rs += pe[2 * k + 1];
-              hi2[k] = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(pe[2 * k], pe[2 * k + 1]));
-            }
-            if (g == gg[k]) {
-              const int e = 2 * k;
-              ph[e >> 3][e & 7] = hi2[k][0]; ph[e >> 3][(e & 7) + 1] = hi2[k][1];
-              pl[e >> 3][e & 7] = (_Float16)(pe[e] - (float)hi2[k][0]);
-              pl[e >> 3][(e & 7) + 1] = (_Float16)(pe[e + 1] - (float)hi2[k][1]);
+            } else if (MODE == PS_WIN14) {
+              const int j = i - 3 * KS;      // 0, 1: E step 0 with R lo, hi; 2, 3: E step 1
+              const h16x8 e8 = j < 2 ? fa : fb;
+              s_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(e8, (j & 1) ? rbh[j >> 1] : rbl[j >> 1], s_next, 0, 0, 0);
             }
           }
+        };
+        float mxa = NEG_INF, mxb = NEG_INF, m_use0 = 0.f, mneg = 0.f, rs = 0.f;
+        float pe[16];
+        h16x2 hi2[8];
+        auto valu_g = [&](int g) {
+          if (g == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mxa = fmaxf(mxa, s_cur[e]);
+          } else if (g == 1) {
+#pragma unroll
+            for (int e = 8; e < 16; ++e) mxb = fmaxf(mxb, s_cur[e]);
+            mxa = ps_max_halves(fmaxf(mxa, mxb));
+          } else if (g == 2) {
+            const float m_cand = fmaxf(m_run[CUR], mxa);
+            need = __builtin_amdgcn_ballot_w64(m_cand > m_run[CUR] + rescale_thr) != 0;
+            const float m_new = need ? m_cand : m_run[CUR];
+            m_use0 = (m_new == NEG_INF) ? 0.f : m_new;
+            alpha = __builtin_amdgcn_exp2f((m_run[CUR] - m_use0) * sl2e);   // used only when `need`
+            m_run[CUR] = m_new;
+            mneg = -m_use0 * sl2e;
+            l_run[CUR] = need ? l_run[CUR] * alpha : l_run[CUR];
+          } else {
+            // pair k of the scores: E_k in group ge[k], F_k in gf[k], G_k in gg[k]
+            constexpr int ge[8] = {3, 4, 6, 8, 10, 12, 14, 16};
+            constexpr int gf[8] = {4, 6, 8, 10, 12, 14, 16, 17};
+            constexpr int gg[8] = {5, 7, 9, 11, 13, 15, 17, 18};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              if (g == ge[k]) {
+                pe[2 * k] = __builtin_amdgcn_exp2f(fmaf(s_cur[2 * k], sl2e, mneg));
+                pe[2 * k + 1] = __builtin_amdgcn_exp2f(fmaf(s_cur[2 * k + 1], sl2e, mneg));
+              }
+              if (g == gf[k]) {
+                rs += pe[2 * k];
+                rs += pe[2 * k + 1];
+                hi2[k] = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(pe[2 * k], pe[2 * k + 1]));
+              }
+              if (g == gg[k]) {
+                const int e = 2 * k;
+                ph[e >> 3][e & 7] = hi2[k][0]; ph[e >> 3][(e & 7) + 1] = hi2[k][1];
+                pl[e >> 3][e & 7] = (_Float16)(pe[e] - (float)hi2[k][0]);
+                pl[e >> 3][(e & 7) + 1] = (_Float16)(pe[e + 1] - (float)hi2[k][1]);
+              }
+            }
+          }
+        };
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+          for (int i = g * NM / NG; i < (g + 1) * NM / NG; ++i) mfma_i(i);
+          valu_g(g);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        l_run[CUR] += rs;
       };
+      if (wn) seg_a(std::true_type());
+      else seg_a(std::false_type());
+      if (need) {   // uniform, rare: O follows the new maximum before this tile's products are added
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
+        for (int d = 0; d < DT; ++d)
 #pragma unroll
-        for (int i = g * NM / NG; i < (g + 1) * NM / NG; ++i) mfma_i(i);
-        valu_g(g);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int e = 0; e < 16; ++e) o[CUR][d][e] *= alpha;
       }
-      l_run += rs;
+      if (MODE == PS_RELT && ci + 2 < nchunk) rel_prefetch(kbase + 64);   // the terms of tile ci + 2 travel under P V
+      // ---- segment B: O^T += V^T P^T ----
+      if (!(a.dbg & 2)) {
+        const _Float16* Vh = (const _Float16*)(ps_smem + G::V_RING + (ci & 1) * G::VSTAGE);
+        const _Float16* Vl = (const _Float16*)(ps_smem + G::V_RING + (ci & 1) * G::VSTAGE + G::VL_OFF);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          if (kbase + 16 * s2 >= a.S) break;   // uniform
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const int off = (16 * s2) * VP + d * 32 + tr_off;
+            const h16x4 vh0 = ps_tr4(Vh + off), vh1 = ps_tr4(Vh + off + 8 * VP);
+            const h16x4 vl0 = ps_tr4(Vl + off), vl1 = ps_tr4(Vl + off + 8 * VP);
+            h16x8 vh8, vl8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vh8[e] = vh0[e]; vh8[4 + e] = vh1[e]; vl8[e] = vl0[e]; vl8[4 + e] = vl1[e]; }
+            o[CUR][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph[s2], o[CUR][d], 0, 0, 0);
+            o[CUR][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl[s2], o[CUR][d], 0, 0, 0);
+            o[CUR][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph[s2], o[CUR][d], 0, 0, 0);
+          }
+        }
+      }
+      if (wn) s_cur = s_next;
     };
-    if (has_next && !(a.dbg & 1)) seg_a(std::true_type());
-    else seg_a(std::false_type());
-    if (need) {   // uniform, rare: O follows the new maximum before this tile's products are added
-#pragma unroll
-      for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, QT - 1>;
+    const bool chain = !(a.dbg & 1);
+    if constexpr (QT == 2) {
+      // tile 0 beside the chain of tile 1 on THIS chunk; tile 1 beside the chain of tile 0 on the next.  (A wave whose second
+      // tile lies beyond the sequence -- the last wave of a 197-token item -- computes it on zero queries and stores nothing:
+      // its workgroup waits for the other waves' two tiles anyway.)
+      tile(I0(), I1(), true, ci);
+      tile(I1(), I0(), has_next, ci + 1);
+    } else {
+      tile(I0(), I0(), has_next && chain, ci + 1);
     }
-    if (MODE == PS_RELT && ci + 2 < nchunk) rel_prefetch(kbase + 64);   // the terms of tile ci + 2 travel under P V
-    // ---- segment B: O^T += V^T P^T ----
-    if (!(a.dbg & 2)) {
-      const _Float16* Vh = (const _Float16*)(ps_smem + G::V_RING + (ci & 1) * G::VSTAGE);
-      const _Float16* Vl = (const _Float16*)(ps_smem + G::V_RING + (ci & 1) * G::VSTAGE + G::VL_OFF);
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        if (kbase + 16 * s2 >= a.S) break;   // uniform
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-          const int off = (16 * s2) * VP + d * 32 + tr_off;
-          const h16x4 vh0 = ps_tr4(Vh + off), vh1 = ps_tr4(Vh + off + 8 * VP);
-          const h16x4 vl0 = ps_tr4(Vl + off), vl1 = ps_tr4(Vl + off + 8 * VP);
-          h16x8 vh8, vl8;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { vh8[e] = vh0[e]; vh8[4 + e] = vh1[e]; vl8[e] = vl0[e]; vl8[4 + e] = vl1[e]; }
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph[s2], o[d], 0, 0, 0);
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl[s2], o[d], 0, 0, 0);
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph[s2], o[d], 0, 0, 0);
-        }
-      }
-    }
-    if (has_next) s_cur = s_next;
   }
 
-  const float l_tot = ps_add_halves(l_run);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+  const float l_tot = ps_add_halves(l_run[qt]);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (wave_active && !(a.dbg & 8)) {
+  if (tile_active[qt] && !(a.dbg & 8)) {
     // Write-out.  A lane holds, per accumulator group g, four consecutive d of ITS query row (8 bytes as fp16); the two lanes
     // of a row hold alternating groups.  Stored as they lie that is 20 instructions of 8 bytes per lane, each to 32 different
     // rows -- and a store instruction whose adjacent lanes are not contiguous costs ~280 cycles of issue (knock-out timing:
     // the stores were 148 of the windowed launch's 768 us).  One v_permlane32_swap per dword pairs the groups (g, g + 1) of
     // the two lanes into 16 contiguous bytes per lane (cdna_hip_programming.md T21): half the instructions, 32 bytes per row.
-    const long long orow = b * a.sob + (long long)(qvalid ? qi : 0) * a.ldo + hh * HD;
+    const long long orow = b * a.sob + (long long)(qvalid[qt] ? qi[qt] : 0) * a.ldo + hh * HD;
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -1034,10 +1070,10 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
         if (d * 32 + 8 * g >= HD) continue;      // HD % 16 == 0: a pair of groups is inside the head or beyond it
         f32x4 w0, w1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { w0[e] = o[d][4 * g + e] * inv; w1[e] = o[d][4 * (g + 1) + e] * inv; }
+        for (int e = 0; e < 4; ++e) { w0[e] = o[qt][d][4 * g + e] * inv; w1[e] = o[qt][d][4 * (g + 1) + e] * inv; }
         if (a.out) {
           // fp32 rows: 16 bytes per lane and group as they lie
-          if (qvalid) {
+          if (qvalid[qt]) {
             *(f32x4*)(a.out + orow + d * 32 + 8 * g + 4 * h) = w0;
             *(f32x4*)(a.out + orow + d * 32 + 8 * (g + 1) + 4 * h) = w1;
           }
@@ -1060,7 +1096,7 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
             return u32x4s{(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
           };
           const u32x4s vh = pair16(hi0, hi1), vl = pair16(lo0, lo1);
-          if (qvalid) {
+          if (qvalid[qt]) {
             const long long off = orow + d * 32 + 8 * g + 8 * h;     // lower lanes: d 8g .. 8g+7 of the row, upper lanes: the next 8
             *(u32x4s*)(a.out_hi + off) = vh;
             *(u32x4s*)(a.out_lo + off) = vl;
@@ -1068,6 +1104,7 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
         }
       }
   }
+  }   // query tiles
   }   // units
 }
 
@@ -1093,14 +1130,14 @@ const unsigned char* psp_etab() {
   return tab[dev];
 }
 
-template <int HD, int MODE>
+template <int HD, int MODE, int QT = 1>
 int psp_launch(const PsArgs& a, hipStream_t st) {
   constexpr size_t lds = psp_lds_bytes<HD, MODE>();
   static bool set_for[64] = {false};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!set_for[dev]) {
-    if (hipFuncSetAttribute((const void*)attn_psp_kernel<HD, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)attn_psp_kernel<HD, MODE, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       hgl_set_error("attention_ps: cannot reserve %zu bytes of LDS", lds);
       return HGL_ELAUNCH;
     }
@@ -1123,7 +1160,7 @@ int psp_launch(const PsArgs& a, hipStream_t st) {
     const long long cap = ((long long)persist * ncu[dev]) & ~7ll;
     if (cap >= 8 && wgs > cap) wgs = cap;
   }
-  hipLaunchKernelGGL((attn_psp_kernel<HD, MODE>), dim3((unsigned)wgs), dim3(256), lds, st, a, et);
+  hipLaunchKernelGGL((attn_psp_kernel<HD, MODE, QT>), dim3((unsigned)wgs), dim3(256), lds, st, a, et);
   return hgl_check_launch("attention_ps");
 }
 
@@ -1205,7 +1242,9 @@ int hgl_launch_attention_ps(const void* qkv_hi, const void* qkv_lo, int ld, int 
   static const int dbg = getenv("HGL_ATTN_PS_DBG") ? atoi(getenv("HGL_ATTN_PS_DBG")) : 0;
   a.dbg = dbg;
   // the 197-token CLIP sequences: 1 = one workgroup per item with two query tiles per wave (K / V staged once),
-  // 2 = the pipelined persistent kernel with two workgroups per item
+  // 2 = the pipelined persistent kernel with two workgroups per item.  (The pipelined kernel with two query tiles per wave
+  // -- attn_psp_kernel<64, PS_PLAIN, 2>, which the template still admits -- needs 256 VGPRs + 19 spilled dwords whose scratch
+  // reloads wait on vmcnt in the middle of the DMA stream: 855 us against 742 for (1) on 1024 x 12 x 197 x 64; not instantiated.)
   static const int clip_kernel = getenv("HGL_ATTN_PS_CLIP") ? atoi(getenv("HGL_ATTN_PS_CLIP")) : 1;
   enum { K_NONE, K_WIN, K_RELT80, K_RELT64, K_CLIP, K_PLAIN80, K_PLAIN64 } kind = K_NONE;
   if (tab_h) {
