@@ -205,6 +205,8 @@ class RealRefs:
         t = lambda a: pin_upload(a, dev)
         for sent_id, raw in zip(ref["sent_ids"], sentences):
             rec = self.parse.get(str(sent_id), {})
+            # Hybridgl_main.py:131-141 tokenises the lower-cased sentence re-joined from spaCy's tokens; the record carries it
+            raw = rec.get("sentence_for_spacy", raw)
             row = len(strings)
             others = list(rec.get("other_nouns", []))   # extract_nouns' phrases, bare (utils.py:82-98)
             strings += sentence_strings(raw, rec)
