@@ -34,7 +34,8 @@ extern "C" {
 
 /* 2: + hgl_clip_hybrid_forward_segments, hgl_split_overflow_count, hgl_clip_encode_text_ex; hgl_gemm_f16x3_select
  * knows kinds -1, 0, 1 only
- * 5: + hgl_u8_to_chw_lut, hgl_split_overflow_peek_async, hgl_resize_bilinear, hgl_score_ref */
+ * 5: + hgl_u8_to_chw_lut, hgl_split_overflow_peek_async, hgl_resize_bilinear, hgl_score_ref
+ * 6: + hgl_attention_presplit, hgl_attention_presplit_f32, hgl_score_group, hgl_remove_small_regions_boxes */
 #define HGL_ABI_VERSION 6
 
 /* activation codes for hgl_gemm_f32 */
