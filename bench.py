@@ -745,6 +745,46 @@ def main():
                                         "area 100, thresholds open, 512 prompts per decoder launch: points_per_batch is a memory knob), <= 256 of SAM's masks into CLIP G2L&L2G, 8 phrases x (sentence + noun "
                                         "phrase + 1 other noun) + 8 GEM prompts")
         also["PhraseCut"]["unit"] = "images/s (8 phrases each)"
+        # algorithmic work of one PhraseCut-shaped image: 5 encoder passes (image + 4 crops), 4096 + 4 x 1024 prompts
+        # through the decoder, CLIP G2L&L2G (28 block evaluations per mask, minimal variant) on the <= 256 masks that go on,
+        # 24 + 8 strings, one GEM tower pass
+        g_ = CLIP_GEOM[args.clip]
+        blk_ = 2.0 * g_["S"] * g_["D"] * 12 * g_["D"] + 4.0 * g_["S"] * g_["S"] * g_["D"]
+        pc_fl = (5 * 5.961e12 + 8192 * 3.62e9 + 256 * (28 * blk_ + 2 * 2.0 * (g_["S"] - 1) * g_["patch_k"] * g_["D"])
+                 + 32 * 12 * (2.0 * text_S * g_["text_D"] * 12 * g_["text_D"]) + (gem_flops_per_image(g_["gem_S"], g_["D"], g_["layers"], 6, g_["patch_k"], g_["embed"]) if use_gem else 0.0))
+        also["PhraseCut"]["whole_step_algorithmic_tflops"] = pc_fl / t / 1e12
+        also["PhraseCut"]["algorithmic_flops_per_image"] = pc_fl
+        # the stage that carries this configuration: the mask decoder on 8192 prompts per image.  Timed alone here (512 prompts
+        # per call, HIP events); its HBM bytes per prompt come from the committed counter pass over the same call
+        emb_ = torch.randn(4096, 256, device=dev)
+        p01_ = torch.rand(512, 2, device=dev)
+        for _ in range(2):
+            sam.decode_points(emb_, p01_)
+        e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0_.record()
+        for _ in range(4):
+            sam.decode_points(emb_, p01_)
+        e1_.record()
+        torch.cuda.synchronize()
+        dec_ms = e0_.elapsed_time(e1_) / 4
+        dec = {"bound": "hbm / valu (see DESIGN.md section 5: dec_tail_kernel and dec_i2t_kernel are bound by element-wise arithmetic, the "
+                        "projections and the token -> image attention by the bytes of the per-prompt image tokens)",
+               "ms_per_64_prompts": dec_ms / 8, "algorithmic_gflop_per_prompt": 3.62,
+               "achieved": 512 * 3.62e9 / (dec_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+               "frac_of_fp16_mfma_peak": 512 * 3.62e9 / (dec_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
+               "ms_per_image_at_8192_prompts": dec_ms * 16}
+        dpath = os.path.join(ROOT, "profiles", "decoder_traffic.json")
+        if os.path.exists(dpath):
+            try:
+                dj = json.load(open(dpath))
+                dec["bytes_per_prompt"] = dj["bytes_per_prompt"]
+                dec["TBps"] = dj["bytes_per_prompt"] * 512 / (dec_ms * 1e-3) / 1e12
+                dec["frac_of_hbm_peak"] = dec["TBps"] / PEAK_HBM_TBPS
+                dec["bytes_source"] = "profiles/decoder_traffic.json (" + dj.get("source", "") + "), replayed -- not measured in this run"
+            except Exception:
+                pass
+        also["PhraseCut"]["decoder"] = dec
+        del emb_, p01_
         del gen_pc, pc_refs
         torch.cuda.empty_cache()
 

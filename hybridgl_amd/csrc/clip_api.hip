@@ -29,7 +29,8 @@ bool hgl_clip_block_uses_x3(const HglResBlockW& w, int M, int D) {
 // than 128 tokens, no causal mask, a CLS keep mask only up to 257 keys -- CLIP's image sequences and GEM's 785 tokens
 bool hgl_clip_block_presplit(const HglResBlockW& w, int B, int S, int D, int heads, int mask_kind) {
   const int hd = D / heads;
-  return hgl_clip_block_uses_x3(w, B * S, D) && hgl_attention_ps_enabled() && hd == 64 && S > 128 &&
+  static const int on = getenv("HGL_ATTN_PS_CLIPBLOCKS") ? atoi(getenv("HGL_ATTN_PS_CLIPBLOCKS")) : 1;   // 0: A/B timing
+  return on && hgl_clip_block_uses_x3(w, B * S, D) && hgl_attention_ps_enabled() && hd == 64 && S > 128 &&
          (mask_kind == HGL_MASK_NONE || (mask_kind == HGL_MASK_CLS_KEEP && S <= 257)) &&
          (size_t)B * S * 3 * D * 2 + (size_t)(S + 1) * 3 * D * 2 < (1ull << 32);
 }

@@ -802,10 +802,7 @@ class SamAutomaticMaskGenerator:
         st.n1.copy_(st.n1_dev, non_blocking=True)
         st.overflow = 0
         st.ovf = torch.zeros(2, dtype=torch.int32).pin_memory()
-        if self.model.precision == "f16x3":     # the counters only move in the split-fp16 mode
-            ops.split_overflow_peek(st.ovf)
-        else:
-            st.ovf.zero_()
+        ops.split_overflow_peek(st.ovf)     # (the counters are process-wide: the CLIP / GEM models of the loop may be f16x3 when this one is not)
         st.ev1 = torch.cuda.Event()
         st.ev1.record(torch.cuda.current_stream(m.device))
         return st
@@ -971,10 +968,7 @@ class SamAutomaticMaskGenerator:
         # this stream got here -- the caller stops at this group instead of finding out at the end of the dataset
         st.overflow = 0
         st.ovf = torch.zeros(2, dtype=torch.int32).pin_memory()
-        if self.model.precision == "f16x3":     # the counters only move in the split-fp16 mode
-            ops.split_overflow_peek(st.ovf)
-        else:
-            st.ovf.zero_()
+        ops.split_overflow_peek(st.ovf)     # (the counters are process-wide: the CLIP / GEM models of the loop may be f16x3 when this one is not)
         st.ev1 = torch.cuda.Event()
         st.ev1.record(torch.cuda.current_stream(dev))
         return st
