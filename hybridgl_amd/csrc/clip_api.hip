@@ -25,12 +25,15 @@ bool hgl_clip_block_uses_x3(const HglResBlockW& w, int M, int D) {
          hgl_use_x3(w.proj_w, 4 * D) && (D % 256) == 0;
 }
 
-// the attention of a block runs on q | k | v as fp16 hi / lo planes (attention_ps.hip): head dim 64, sequences of more
-// than 128 tokens, no causal mask, a CLS keep mask only up to 257 keys -- CLIP's image sequences and GEM's 785 tokens
+// the attention of a block runs on q | k | v as fp16 hi / lo planes (attention_ps.hip): head dim 64, no causal mask -- GEM's
+// 785-token blocks.  CLIP's 197-token sequences stay on attn_x3q_kernel: alone (1024 sequences) the pre-split kernel takes 742
+// against 868 us, but in the pipeline's launches (2048 sequences of a group) it is no faster (1771 against 1761 us) while the
+// in-projection's split write-out costs 3 % of that GEMM (tools/clip_ps_ab.sh: 31.77 against 31.79 ms of kernel time per ref);
+// HGL_ATTN_PS_CLIPBLOCKS=2 routes them here as well (A/B timing, the parity test)
 bool hgl_clip_block_presplit(const HglResBlockW& w, int B, int S, int D, int heads, int mask_kind) {
   const int hd = D / heads;
-  static const int on = getenv("HGL_ATTN_PS_CLIPBLOCKS") ? atoi(getenv("HGL_ATTN_PS_CLIPBLOCKS")) : 1;   // 0: A/B timing
-  return on && hgl_clip_block_uses_x3(w, B * S, D) && hgl_attention_ps_enabled() && hd == 64 && S > 128 &&
+  static const int on = getenv("HGL_ATTN_PS_CLIPBLOCKS") ? atoi(getenv("HGL_ATTN_PS_CLIPBLOCKS")) : 1;   // 0: never, 2: also S <= 256
+  return on && (S > 256 || on == 2) && hgl_clip_block_uses_x3(w, B * S, D) && hgl_attention_ps_enabled() && hd == 64 && S > 128 &&
          (mask_kind == HGL_MASK_NONE || (mask_kind == HGL_MASK_CLS_KEEP && S <= 257)) &&
          (size_t)B * S * 3 * D * 2 + (size_t)(S + 1) * 3 * D * 2 < (1ull << 32);
 }

@@ -74,14 +74,39 @@ def test_presplit_kernels_equal_the_fp32_input_kernels(cuda, B, H, S, hd, mask):
 
 def test_clip_hybrid_forward_presplit_equals_fp32_input_path(cuda):
     """CLIPViTFM.forward (G2L, ViT-B/16, 6 masks) with the residual blocks' attention on split planes against the path that
-    hands the attention an fp32 qkv tensor: equal to fp32 rounding through all twelve blocks."""
+    hands the attention an fp32 qkv tensor: equal to fp32 rounding through all twelve blocks.  (The 197-token blocks take the
+    pre-split kernel only with HGL_ATTN_PS_CLIPBLOCKS=2 -- read once per process: this test runs the forward in a child.)"""
+    import subprocess, sys, os
+    code = (
+        "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+        "from hybridgl_amd import _lib, weights\n"
+        "from hybridgl_amd.backbone import CLIPViTFM\n"
+        "from oracle.cases import views_for_case\n"
+        "dev = torch.device('cuda:0'); lib = _lib.load()\n"
+        "model = CLIPViTFM('ViT-B/16', state_dict=weights.clip_state_dict('ViT-B/16', 0), device=dev)\n"
+        "loc, glo, masks = views_for_case(6, 224, 160, 200)\n"
+        "args = (torch.from_numpy(loc).to(dev), torch.from_numpy(glo).to(dev), torch.from_numpy(masks).to(dev))\n"
+        "ys = []\n"
+        "for on in (0, 1):\n"
+        "    lib.hgl_attention_presplit(on); ys.append(model(*args, masking_block=9, fusion_mode='G2L').clone())\n"
+        "d = float((ys[0] - ys[1]).abs().max()); m = float(ys[0].abs().max())\n"
+        "assert torch.isfinite(ys[0]).all() and 0 < d <= 2e-5 * m, (d, m)\n"
+        "print('PS_CLIP_OK', d, m)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HGL_ATTN_PS_CLIPBLOCKS="2"))
+    assert r.returncode == 0 and "PS_CLIP_OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_gem_tower_presplit_equals_fp32_input_path(cuda):
+    """The GEM image tower at 448 x 448 (785 tokens: its plain residual blocks take the pre-split kernel by default) against
+    the path that hands the attention an fp32 qkv tensor: features equal to fp32 rounding."""
     if ops.default_precision() != "f16x3":
         pytest.skip("pre-split attention belongs to the split-fp16 mode")
+    from hybridgl_amd import gem as G
     from hybridgl_amd.backbone import CLIPViTFM
-    from oracle.cases import views_for_case
     model = CLIPViTFM("ViT-B/16", state_dict=weights.clip_state_dict("ViT-B/16", 0), device=cuda)
-    loc, glo, masks = views_for_case(6, 224, 160, 200)
-    args = (torch.from_numpy(loc).to(cuda), torch.from_numpy(glo).to(cuda), torch.from_numpy(masks).to(cuda))
-    y0, y1 = _ab(lambda: model(*args, masking_block=9, fusion_mode="G2L").clone())
-    assert torch.isfinite(y0).all()
-    assert float((y0 - y1).abs().max()) <= 2e-5 * float(y0.abs().max()), float((y0 - y1).abs().max())
+    gm = G.create_gem_model("ViT-B/16", clip=model)
+    x = torch.from_numpy(np.random.default_rng(3).standard_normal((3, 448, 448)).astype(np.float32)).to(cuda)
+    f0, f1 = _ab(lambda: gm.image_features(x).clone())
+    assert torch.isfinite(f0).all() and float(f0.abs().max()) > 0
+    assert float((f0 - f1).abs().max()) <= 2e-5 * float(f0.abs().max()), float((f0 - f1).abs().max())
