@@ -660,9 +660,9 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
   for (unsigned L = blockIdx.x; L < nunits; L += gridDim.x) {
   // Unit -> (batch element, head, query block).  The heads of one batch element are ADJACENT 2*HD-byte pieces of the same
   // rows of the planes: dealt to different XCDs (first version: item = batch * H + head round-robin over the XCDs) every L2
-  // fetched whole 128-byte lines for its two heads' 160-byte pieces -- FETCH_SIZE 2.1 GB for 1.2 GB of q | k | v, and the
-  // kernel sat at 3.6 TB/s of mostly wasted traffic whatever its instruction stream did.  So an XCD owns whole batch elements:
-  // XCD c works through elements c, c + 8, ...; consecutive slots are the query blocks of one head, then the next head.
+  // fetches whole 128-byte lines for its two heads' 160-byte pieces (FETCH_SIZE 2.1 GB for 1.2 GB of q | k | v on the
+  // windows).  So an XCD owns whole batch elements: XCD c works through elements c, c + 8, ...; consecutive slots are the
+  // query blocks of one head, then the next head.  (The launch time did not move with it: the kernel is not bound by HBM.)
   int item, bx;
   {
     const unsigned nqb = (unsigned)a.nqb;
