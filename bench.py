@@ -341,6 +341,10 @@ def hbm_kernel_specs(N=64, H=640, W=640, S=3, K=192, g=1):
         "blur_q8_h_kernel": (3 * px + 2 * 3 * px, "u8 image read, 16-bit row sums written"),
         "blur_q8_v_kernel": (2 * 3 * px + 3 * px, "16-bit row sums read, u8 image written"),
         "mask_resize_kernel": (N * 14 * 14 * 4 * 2, "4 taps per output of the 14 x 14 CLS keep maps (never the 26 MB of masks)"),
+        # LayerNorm between the fp32 residual stream and the split GEMM operands: 8 B per element (fp32 row in, fp16 hi + lo row
+        # out) is the floor of such a pass, and launches differ in rows -- the measured bytes ARE the algorithmic bytes here
+        "layernorm_split_kernel<3>": (None, "= measured: 4 B in + 4 B out per element, CLIP / GEM width 768 (one wave per row, row in registers)"),
+        "layernorm_split_kernel<5>": (None, "= measured: 4 B in + 4 B out per element, SAM width 1280"),
     }
 
 
@@ -358,6 +362,8 @@ def hbm_kernel_table(table, refs=16, tail_group=1):
             continue
         us = sum(table[t]["launches"] * table[t]["us"] for t in ks) / n
         meas = sum(table[t]["launches"] * (table[t]["fetch_bytes"] + table[t]["write_bytes"]) for t in ks) / n
+        if alg is None:
+            alg = meas
         out[k] = {"launches_per_ref": n / 2.0 / refs, "us_per_launch": us, "measured_bytes_per_launch": meas,
                   "algorithmic_bytes_per_launch": alg, "algorithmic_bytes": what,
                   "TBps_measured": meas / us / 1e6 if us > 0 else None, "TBps_algorithmic": alg / us / 1e6 if us > 0 else None,

@@ -22,6 +22,7 @@
 // the transposing LDS read): results are bit-identical to that kernel on the same hi / lo planes.
 #include "hgl_common.h"
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -1112,6 +1113,8 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
 // chunk-swizzled as the kernel reads it; built once per device
 const unsigned char* psp_etab() {
   static const unsigned char* tab[64] = {nullptr};
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (!tab[dev]) {
@@ -1225,6 +1228,7 @@ int hgl_launch_attention_ps(const void* qkv_hi, const void* qkv_lo, int ld, int 
                   (((uintptr_t)qkv_hi | (uintptr_t)qkv_lo | (uintptr_t)out | (uintptr_t)out_hi | (uintptr_t)out_lo) & 15) == 0,
               "attention_ps: operands must be 16-byte aligned");
   HGL_REQUIRE(mask_kind != HGL_MASK_CLS_KEEP || keep, "attention_ps: HGL_MASK_CLS_KEEP needs keep bytes");
+  HGL_REQUIRE(vcol >= kcol, "attention_ps: the V columns must not lie before the K columns (32-bit offsets from the K base)");
   HGL_REQUIRE((rel_h == nullptr) == (rel_w == nullptr) && (tab_h == nullptr) == (tab_w == nullptr), "attention_ps: rel-pos operands go in pairs");
   // the DMA addresses one item's K / V rows with a 32-bit offset from the item's base in the hi plane, lo plane included
   const long long delta = (const char*)qkv_lo - (const char*)qkv_hi;

@@ -21,6 +21,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
+    """kernel name without namespace and argument list; rocprofv3 leaves some names mangled (its demangler gives up on _Float16
+    parameters): _ZN12_GLOBAL__N_1<len><name>[I(Li<n>E)+E]... -> name<n, ...>"""
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if m:
+        n = int(m.group(1))
+        rest = name[m.end():]
+        ident, rest = rest[:n], rest[n:]
+        t = re.match(r"I((?:Li\d+E|Lb[01]E)+)E", rest)
+        if t:
+            args = re.findall(r"L[ib](\d+)E", t.group(1))
+            return ident + "<" + ", ".join(args) + ">"
+        return ident
     m = re.search(r"([A-Za-z_0-9]+)(<[^>]*>)?\(", name.replace("(anonymous namespace)::", ""))
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
