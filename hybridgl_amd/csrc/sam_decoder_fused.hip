@@ -21,7 +21,10 @@
 // expressions; the LayerNorm sums and the hyper-network dot products are associated differently (per lane first, then
 // across the four lanes that share a row: a first version reproduced the unfused kernels' butterfly order bit for bit and
 // spent a quarter of its time in 256 dependent ds_bpermute + wait pairs per wave).  Fused and unfused logits agree to
-// fp32 rounding (tests/test_gpu_sam.py); the kernel is bound by its element-wise arithmetic (192 GELUs per lane and tile).
+// fp32 rounding (tests/test_gpu_sam.py).  Round 5: eight waves per tile instead of four (see dec_tail_kernel), the GELUs two
+// values per instruction (hgl_gelu_erf4: v_pk_fma_f32), the epilogue vectors through LDS: 2.93 -> 2.56 ms per 529 prompts;
+// the vector pipe is then ~55 % and the matrix pipe ~23 % busy per SIMD with 3.8 waves resident
+// (profiles/r05c_sq_counters_dec_tail_*.json): the rest is the six barriers of a tile and the L2 round trips of the weight fragments.
 #include "hgl_common.h"
 
 bool hgl_get_split_weight(const float* W, const void** hi, const void** lo, int* scale_log2, int* N, int* K);
@@ -56,39 +59,53 @@ __device__ __forceinline__ float gelu_erf(float x) { return hgl_gelu_erf(x); }
 
 constexpr int TAIL_ROWS = 64;
 constexpr int TAIL_A_PLANE = TAIL_ROWS * 256 * 2;        // bytes of one plane of the source tile (32 KiB)
-constexpr int TAIL_G_PLANE = TAIL_ROWS * 64 * 2;         // bytes of one plane of a wave's 64 x 64 patch (8 KiB)
+constexpr int TAIL_G_PLANE = TAIL_ROWS * 64 * 2;         // bytes of one plane of a position's 64 x 64 patch (8 KiB)
 constexpr int TAIL_STAGE = 2 * TAIL_A_PLANE;             // output staging [3][64 pixels][16] floats behind the tile
-constexpr int TAIL_LDS = TAIL_STAGE + 3 * TAIL_ROWS * 16 * 4;
+constexpr int TAIL_RED = TAIL_STAGE;                     // LayerNorm partial sums [2 passes][4 positions][2 halves][64 rows] (4 KiB,
+                                                         // dead before the staging area that overlays them is written)
+constexpr int TAIL_CST = TAIL_STAGE + 3 * TAIL_ROWS * 16 * 4;   // b0[256] ln_w[64] ln_b[64] b3[128] hyper[3][32]: 608 floats
+constexpr int TAIL_LDS = TAIL_CST + 608 * 4;             // 78.4 KiB: two workgroups per CU
 
-__global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
+// Round 5: EIGHT waves per 64-row tile, <= 128 registers, so that sixteen waves (four per SIMD) are resident per CU.  The
+// four-wave version (one wave per position, 64 channels each, 247 registers, two waves per SIMD) spent 47 % of its wave
+// cycles waiting and kept the vector pipe 53 % busy (profiles/r05c_sq_counters_dec_tail.json): two waves per SIMD cannot
+// cover the L2 round trips of the weight fragments, the tile's HBM load and the barriers.  Wave (pos, half):
+//   first product   position pos, channels 32 half .. 32 half + 31 of its 64 (half of that position's weight rows: the
+//                   weight traffic from L2 stays 256 KiB per tile); the LayerNorm sums of a (row, position) are completed
+//                   through LDS between the two waves that share it (two passes: mean, then centred squares, as before)
+//   second product  position pos, sub-positions 2 half and 2 half + 1 (64 of the 128 output columns), all 64 rows
+__global__ __launch_bounds__(512, 4) void dec_tail_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 15, h = lane >> 4;
+  const int pos = wave & 3, half = wave >> 2;
   const int p = blockIdx.y, tile = blockIdx.x;
   const long long row0 = (long long)p * a.HW + (long long)tile * TAIL_ROWS;
 
   // ---- the tile's 64 rows x 256 channels, both planes, into the fragment image ----
-  // the first two K steps of this wave's W fragments and its epilogue vectors are requested before the tile itself
-  const _Float16* const wh = a.W0h + (long long)(wave * 64 + r) * 256 + 8 * h;
-  const _Float16* const wl = a.W0l + (long long)(wave * 64 + r) * 256 + 8 * h;
-  f16x8 bh[3][4], bl[3][4];
+  // the first two K steps of this wave's W fragments are requested before the tile itself
+  const _Float16* const wh = a.W0h + (long long)(pos * 64 + 32 * half + r) * 256 + 8 * h;
+  const _Float16* const wl = a.W0l + (long long)(pos * 64 + 32 * half + r) * 256 + 8 * h;
+  f16x8 bh[3][2], bl[3][2];
 #pragma unroll
   for (int pre = 0; pre < 2; ++pre)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
       bh[pre][j] = *(const f16x8*)(wh + j * 16 * 256 + pre * 32);
       bl[pre][j] = *(const f16x8*)(wl + j * 16 * 256 + pre * 32);
     }
-  f32x4 b0v[4], lw[4], lb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    b0v[j] = *(const f32x4*)(a.b0 + wave * 64 + 16 * j + 4 * h);
-    lw[j] = *(const f32x4*)(a.ln_w + 16 * j + 4 * h);
-    lb[j] = *(const f32x4*)(a.ln_b + 16 * j + 4 * h);
+  // the epilogues' vectors go through LDS with the tile (one exposed round trip to L2 instead of four, and no registers
+  // held across the products)
+  float* const cst = (float*)(smem + TAIL_CST);
+  if (t < 152) {
+    const float* src = t < 64 ? a.b0 + 4 * t : t < 80 ? a.ln_w + 4 * (t - 64) : t < 96 ? a.ln_b + 4 * (t - 80)
+                     : t < 128 ? a.b3 + 4 * (t - 96) : a.hyper + (long long)p * 4 * 32 + 32 * a.hrow0 + 4 * (t - 128);
+    *(f32x4*)(cst + 4 * t) = *(const f32x4*)src;
   }
   // four consecutive threads fetch the 64 contiguous bytes of one (row, K step), the next four the next ROW: consecutive
   // K steps of a row lie 4 KiB apart in the image (same banks: an 8-way conflict on the 16-byte stores when threads walk along a row)
-  for (int i = t; i < TAIL_ROWS * 32; i += 256) {
+#pragma unroll
+  for (int i = t; i < TAIL_ROWS * 32; i += 512) {
     const int row = (i >> 2) & 63, kc = 4 * (i >> 8) + (i & 3);
     const unsigned off = frag_off(kc >> 2, 4, row >> 4, row & 15, kc & 3);
     *(u32x4*)(smem + off) = *(const u32x4*)(a.Ah + (row0 + row) * 256 + kc * 8);
@@ -96,12 +113,12 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
   }
   __syncthreads();
 
-  // ---- ConvTranspose2d(256 -> 64, k2 s2): wave w computes position w = (ky, kx): rows x 64 channels ----
-  f32x4 acc[4][4];
+  // ---- ConvTranspose2d(256 -> 64, k2 s2), position pos = (ky, kx): rows x this wave's 32 channels ----
+  f32x4 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     // W fragments come straight from L2 (the 256 KiB of up0's halves stay resident), two K steps ahead of their use
 #pragma unroll
@@ -109,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
       const int cb = ks % 3, nb = (ks + 2) % 3;
       if (ks + 2 < 8) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
           bh[nb][j] = *(const f16x8*)(wh + j * 16 * 256 + (ks + 2) * 32);
           bl[nb][j] = *(const f16x8*)(wl + j * 16 * 256 + (ks + 2) * 32);
         }
@@ -126,126 +143,161 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < 2; ++j) {
             const f16x8 av = term == 0 ? al[i] : ah[i];
             const f16x8 bv = term == 1 ? bl[cb][j] : bh[cb][j];
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, acc[i][j], 0, 0, 0);
           }
     }
   }
-  __syncthreads();   // every wave has read the source tile: its LDS becomes the waves' 64 x 64 patches
+  // the weight fragments of the second product's first sub-position are requested now: they arrive during the LayerNorm
+  const _Float16* const w3h = a.W3h + (long long)(half * 64 + r) * 64 + 8 * h;
+  const _Float16* const w3l = a.W3l + (long long)(half * 64 + r) * 64 + 8 * h;
+  f16x8 qh[2][2][2], ql[2][2][2];      // [sub-position][K step][column block]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      qh[0][ks][j] = *(const f16x8*)(w3h + j * 16 * 64 + ks * 32);
+      ql[0][ks][j] = *(const f16x8*)(w3l + j * 16 * 64 + ks * 32);
+    }
+  __syncthreads();   // every wave has read the source tile: its LDS becomes the positions' 64 x 64 patches
 
-  // ---- + bias, LayerNorm2d over the 64 channels of (row, position), GELU, split, into the wave's patch ----
-  unsigned char* const patch = smem + wave * 2 * TAIL_G_PLANE;
+  // ---- + bias, LayerNorm2d over the 64 channels of (row, position), GELU, split, into the position's patch ----
+  unsigned char* const patch = smem + pos * 2 * TAIL_G_PLANE;
+  float* const red = (float*)(smem + TAIL_RED);
   {
+    f32x4 b0v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b0v[j] = *(const f32x4*)(cst + pos * 64 + 32 * half + 16 * j + 4 * h);
+    // sum over this wave's 32 channels of a row: this lane's 8, then the four lanes (h) that share the row; the other 32
+    // come from the partner wave through LDS (both waves add the two partial sums in the same order)
+    auto tree = [&](const f32x4 (&x)[2]) {
+      float t = ((x[0][0] + x[0][1]) + (x[0][2] + x[0][3])) + ((x[1][0] + x[1][1]) + (x[1][2] + x[1][3]));
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      return t;
+    };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f32x4 v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[j][e] = acc[i][j][e] * a.s0 + b0v[j][e];
-      // sum over the row's 64 channels: this lane's 16, then the four lanes (h) that share the row
-      auto tree = [&](const f32x4 (&x)[4]) {
-        float s4[4];
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = acc[i][j][e] * a.s0 + b0v[j][e];
+      const float s = tree(acc[i]);
+      if (h == 0) red[((0 * 4 + pos) * 2 + half) * TAIL_ROWS + 16 * i + r] = s;
+    }
+    __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s4[j] = (x[j][0] + x[j][1]) + (x[j][2] + x[j][3]);
-        float t = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-        t += __shfl_xor(t, 16);
-        t += __shfl_xor(t, 32);
-        return t;
-      };
-      const float mean = tree(v) * (1.f / 64.f);
-      f32x4 d[4], q[4];
+    for (int i = 0; i < 4; ++i) {
+      const float* rp = red + (0 * 4 + pos) * 2 * TAIL_ROWS + 16 * i + r;
+      const float mean = (rp[0] + rp[TAIL_ROWS]) * (1.f / 64.f);
+      f32x4 q[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { d[j][e] = v[j][e] - mean; q[j][e] = d[j][e] * d[j][e]; }
-      const float var = tree(q) * (1.f / 64.f);
+        for (int e = 0; e < 4; ++e) { acc[i][j][e] -= mean; q[j][e] = acc[i][j][e] * acc[i][j][e]; }
+      const float s = tree(q);
+      if (h == 0) red[((1 * 4 + pos) * 2 + half) * TAIL_ROWS + 16 * i + r] = s;
+    }
+    __syncthreads();
+    f32x4 lw[2], lb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      lw[j] = *(const f32x4*)(cst + 256 + 32 * half + 16 * j + 4 * h);
+      lb[j] = *(const f32x4*)(cst + 320 + 32 * half + 16 * j + 4 * h);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* rp = red + (1 * 4 + pos) * 2 * TAIL_ROWS + 16 * i + r;
+      const float var = (rp[0] + rp[TAIL_ROWS]) * (1.f / 64.f);
       const float rs = rsqrtf(var + a.eps);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 2; ++j) {
         f16x4 hi4, lo4;
+        hgl_f32x2 y0 = {acc[i][j][0] * rs * lw[j][0] + lb[j][0], acc[i][j][1] * rs * lw[j][1] + lb[j][1]};
+        hgl_f32x2 y1 = {acc[i][j][2] * rs * lw[j][2] + lb[j][2], acc[i][j][3] * rs * lw[j][3] + lb[j][3]};
+        hgl_gelu_erf4(y0, y1);
+        const float o[4] = {y0.x, y0.y, y1.x, y1.y};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float y = d[j][e] * rs * lw[j][e] + lb[j][e];
-          const float o = gelu_erf(y);
           _Float16 hh, ll;
-          hgl_split_hi_lo(o, hh, ll);
+          hgl_split_hi_lo(o[e], hh, ll);
           hi4[e] = hh;
           lo4[e] = ll;
         }
-        // channel c0 = 16 j + 4 h: K step c0 / 32, chunk (c0 % 32) / 8, half-chunk (c0 % 8) / 4
-        const int c0 = 16 * j + 4 * h;
+        // channel c0 = 32 half + 16 j + 4 h: K step c0 / 32 (= half), chunk (c0 % 32) / 8, half-chunk (c0 % 8) / 4
+        const int c0 = 32 * half + 16 * j + 4 * h;
         const unsigned off = frag_off(c0 >> 5, 4, i, r, (c0 & 31) >> 3) + (unsigned)((c0 & 7) * 2);
         *(f16x4*)(patch + off) = hi4;
         *(f16x4*)(patch + TAIL_G_PLANE + off) = lo4;
       }
     }
   }
-  __builtin_amdgcn_wave_barrier();
-  __threadfence_block();   // the patch is private to the wave: LDS operations of a wave execute in order
+  __syncthreads();   // both K steps of every position's patch are written
 
-  // ---- ConvTranspose2d(64 -> 32, k2 s2) + GELU, then the three hyper-network dot products, per pair of sub-positions ----
-  const float* hy = a.hyper + (long long)p * 4 * 32;
+  // ---- ConvTranspose2d(64 -> 32, k2 s2) + GELU, then the three hyper-network dot products: this wave's pair of
+  //      sub-positions, one at a time (32 output columns: the weight fragments of the next one are in flight during the
+  //      epilogue of the current one) ----
   float* const stage = (float*)(smem + TAIL_STAGE);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    f32x4 c2[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) c2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const _Float16* w3h = a.W3h + (long long)(pass * 64 + r) * 64 + 8 * h;
-    const _Float16* w3l = a.W3l + (long long)(pass * 64 + r) * 64 + 8 * h;
-    f16x8 qh[2][4], ql[2][4];      // both K steps of this pass's W fragments in one burst (one exposed L2 round trip, not two)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { qh[ks][j] = *(const f16x8*)(w3h + j * 16 * 64 + ks * 32); ql[ks][j] = *(const f16x8*)(w3l + j * 16 * 64 + ks * 32); }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f16x8 gh[4], gl[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const unsigned off = frag_off(ks, 4, i, r, h);
-        gh[i] = *(const f16x8*)(patch + off);
-        gl[i] = *(const f16x8*)(patch + TAIL_G_PLANE + off);
-      }
-#pragma unroll
-      for (int term = 0; term < 3; ++term)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const f16x8 av = term == 0 ? gl[i] : gh[i];
-            const f16x8 bv = term == 1 ? ql[ks][j] : qh[ks][j];
-            c2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, c2[i][j], 0, 0, 0);
-          }
-    }
-    // columns of this pass: n = 64 pass + 16 j + 4 h + e = sub-position (2 pass + (j >> 1)), channel 16 (j & 1) + 4 h + e.
+  {
+    const int pass = half;
+    // columns of this pass: n = 64 pass + 32 sp + 16 jj + 4 h + e = sub-position 2 pass + sp, channel 16 jj + 4 h + e.
     // part[sp][i][m]: this lane's share (8 of the 32 channels) of the dot product of row 16 i + r, sub-position 2 pass + sp
     float part[2][4][3];
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
-      f32x4 hv[3][2], b3v[2];
+      f32x4 c2[4][2];
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        b3v[jj] = *(const f32x4*)(a.b3 + pass * 64 + 32 * sp + 16 * jj + 4 * h);
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int m = 0; m < 3; ++m) hv[m][jj] = *(const f32x4*)(hy + 32 * (m + a.hrow0) + 16 * jj + 4 * h);
+        for (int j = 0; j < 2; ++j) c2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned off = frag_off(ks, 4, i, r, h);
+          const f16x8 gh = *(const f16x8*)(patch + off);
+          const f16x8 gl = *(const f16x8*)(patch + TAIL_G_PLANE + off);
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const f16x8 av = term == 0 ? gl : gh;
+              const f16x8 bv = term == 1 ? ql[sp][ks][j] : qh[sp][ks][j];
+              c2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv, av, c2[i][j], 0, 0, 0);
+            }
+        }
       }
+      if (sp == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            qh[1][ks][j] = *(const f16x8*)(w3h + (32 + j * 16) * 64 + ks * 32);
+            ql[1][ks][j] = *(const f16x8*)(w3l + (32 + j * 16) * 64 + ks * 32);
+          }
+      }
+      // (the hyper-network rows are re-read from LDS per row block: holding them would not fit beside the fragments in flight)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float d3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < 2; ++jj) {
+          const f32x4 c = c2[i][jj];
+          const f32x4 b3v1 = *(const f32x4*)(cst + 384 + pass * 64 + 32 * sp + 16 * jj + 4 * h);
+          f32x4 hv1[3];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float u = gelu_erf(c2[i][2 * sp + jj][e] * a.s3 + b3v[jj][e]);
+          for (int m = 0; m < 3; ++m) hv1[m] = *(const f32x4*)(cst + 512 + 32 * m + 16 * jj + 4 * h);
+          hgl_f32x2 u0 = {c[0] * a.s3 + b3v1[0], c[1] * a.s3 + b3v1[1]};
+          hgl_f32x2 u1 = {c[2] * a.s3 + b3v1[2], c[3] * a.s3 + b3v1[3]};
+          hgl_gelu_erf4(u0, u1);
+          const float u[4] = {u0.x, u0.y, u1.x, u1.y};
 #pragma unroll
-            for (int m = 0; m < 3; ++m) d3[m] = fmaf(u, hv[m][jj][e], d3[m]);
-          }
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) d3[m] = fmaf(u[e], hv1[m][e], d3[m]);
+        }
 #pragma unroll
         for (int m = 0; m < 3; ++m) part[sp][i][m] = d3[m];
       }
@@ -272,24 +324,26 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
         const float res = keep + __shfl_xor(send, 16);
         const int i = 2 * (h & 1) + ii;
         const int sub = 2 * pass + (h >> 1);                   // (ky2, kx2)
-        const int dy = 2 * (wave >> 1) + (sub >> 1), dx = 2 * (wave & 1) + (sub & 1);
+        const int dy = 2 * (pos >> 1) + (sub >> 1), dx = 2 * (pos & 1) + (sub & 1);
         stage[(m * TAIL_ROWS + 16 * i + r) * 16 + dy * 4 + dx] = res;
       }
   }
   __syncthreads();
 
   // ---- the tile's 3 x 64 x 16 logits to the [P, 3, 4g, 4g] layout, rows of 4 * min(g, 64) contiguous floats ----
+  // (the launcher admits g = a power of two <= 64 or a multiple of 64: the row length and the rows per tile are powers of two)
   const int g = a.g, S4 = 4 * g;
   const int gw = g < TAIL_ROWS ? g : TAIL_ROWS;          // pixels of one grid row inside the tile
-  const int nrow = TAIL_ROWS / gw;                       // grid rows the tile covers
+  const int lrow = 31 - __clz(4 * gw);                   // log2 of the floats of one output row of the tile
+  const int lnr = 31 - __clz(TAIL_ROWS / gw);            // log2 of the grid rows the tile covers
   const int pix0 = tile * TAIL_ROWS, y0 = pix0 / g, x0 = pix0 - y0 * g;
-  const int rowlen = 4 * gw;
-  for (int o = t; o < 3 * TAIL_ROWS * 16; o += 256) {
-    const int xx = o % rowlen;
-    int q = o / rowlen;
+#pragma unroll
+  for (int o = t; o < 3 * TAIL_ROWS * 16; o += 512) {
+    const int xx = o & ((1 << lrow) - 1);
+    int q = o >> lrow;
     const int dy = q & 3;
     q >>= 2;
-    const int yl = q % nrow, m = q / nrow;
+    const int yl = q & ((1 << lnr) - 1), m = q >> lnr;
     const int xl = xx >> 2, dx = xx & 3;
     const float v = stage[(m * TAIL_ROWS + yl * gw + xl) * 16 + dy * 4 + dx];
     a.out[(((long long)p * 3 + m) * S4 + 4 * (y0 + yl) + dy) * S4 + 4 * (x0 + xl) + dx] = v;
@@ -581,7 +635,7 @@ int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0
     set = true;
   }
   HglProfScope prof(HGL_PROF_OTHER, 2.0 * P * HW * (256.0 * 256 + 4 * 64.0 * 128), 0.0, st);
-  hipLaunchKernelGGL(dec_tail_kernel, dim3((unsigned)(HW / TAIL_ROWS), (unsigned)P), dim3(256), TAIL_LDS, st, a);
+  hipLaunchKernelGGL(dec_tail_kernel, dim3((unsigned)(HW / TAIL_ROWS), (unsigned)P), dim3(512), TAIL_LDS, st, a);
   return hgl_check_launch("dec_tail");
 }
 

@@ -20,7 +20,7 @@ recs = [dict(sentence_row=3 * j, noun_phrase_row=3 * j + 1, other_row0=3 * j + 2
              has_other_nouns=s.n_nouns != 0, black=1.8, imgattn=s.imgattn, target=ref.target) for j, s in enumerate(ref.sentences)]
 
 
-def timed(fn, name, n=20):
+def timed(fn, name, n=20, refs=1):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -30,7 +30,8 @@ def timed(fn, name, n=20):
         fn()
     b.record()
     torch.cuda.synchronize()
-    print(f"{name:44s} {a.elapsed_time(b) / n * 1e3:8.1f} us per ref")
+    us = a.elapsed_time(b) / n * 1e3
+    print(f"{name:52s} {us / refs:8.1f} us per ref" + (f"  ({us:8.1f} us per call over {refs} refs)" if refs > 1 else ""))
 
 
 def fused():
@@ -65,8 +66,8 @@ def per_ref16():
         ops.score_ref(q["hybrid"], q["text"], q["boxes"], q["masks"], q["sentences"], 100.0, 0.5, 3, 6, 0.6, cum=cum)
 
 
-timed(group16, "hgl_score_group, 16 refs (4 launches), x16")
-timed(per_ref16, "hgl_score_ref x 16 refs (64 launches), x16")
+timed(group16, "hgl_score_group, 16 distinct refs (4 launches)", refs=16)
+timed(per_ref16, "hgl_score_ref x 16 distinct refs (64 launches)", refs=16)
 timed(fused, "hgl_score_ref (4 launches)")
 timed(per_sentence, "per-sentence launches (3 sentences)")
 timed(lambda: ops.coherence_scores(ref.sentences[0].imgattn, ref.masks, "left", 1.8), "hgl_coherence_scores, one sentence")
