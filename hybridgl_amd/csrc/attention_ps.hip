@@ -542,21 +542,6 @@ __device__ __forceinline__ float ps_add_halves(float x) {
   const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
   return __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
 }
-// Scheduling pipeline of segment A (LLVM sched_group_barrier: MFMA 0x8, VALU 0x2, TRANS 0x400, DS read 0x100): after every
-// matrix instruction of the QK^T chain five vector instructions and one exponential of the soft-max, and the LDS read of a
-// later fragment -- an in-order wave overlaps the two pipes only where they alternate in its stream (without this the
-// compiler emits the 19 dependent MFMAs first and the soft-max behind them)
-template <int I, int N, int NREAD>
-__device__ __forceinline__ void ps_sgb_seg_a() {
-  if constexpr (I < N) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if constexpr (I < NREAD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-    if constexpr (I < 16) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
-    ps_sgb_seg_a<I + 1, N, NREAD>();
-  }
-}
-
 template <int HD>
 struct PspGeom {
   static constexpr int KS = HD / 16, DT = (HD + 31) / 32;

@@ -70,3 +70,34 @@ def test_postprocess_torch_cpu_equals_numpy_oracle():
     assert (b.numpy() != (ref.reshape(6, 120, 94) > 0)).mean() < 1e-3
     np.testing.assert_allclose(st.numpy(), st_ref, atol=2e-3)
     assert np.abs(boxes.numpy() - box_ref).max() <= 1
+
+
+def test_cpu_thread_calibration_walks_down_to_the_fastest_setting(monkeypatch):
+    """bench.py: the CPU leg runs at the best of {all, 1/2, 1/4 ...} threads (on the GPU box torch's pool at 256 threads took
+    five times the 8-vCPU container's time).  The probe is replaced by a clock that is fastest at 16 threads: the walk must
+    visit 256 .. 8, return 16, stop once the time has clearly turned, and restore nothing it did not set (the caller sets
+    the thread count afterwards)."""
+    import bench
+    cost = {256: 10.0, 128: 3.0, 64: 1.5, 32: 1.2, 16: 1.0, 8: 1.4, 4: 2.6}
+    now = [0.0]
+    seen = []
+
+    def fake_encoder(sd, x, cfg):
+        seen.append(torch.get_num_threads())
+        now[0] += cost.get(torch.get_num_threads(), 5.0)
+        return x
+
+    monkeypatch.setattr(T, "image_encoder", fake_encoder)
+    monkeypatch.setattr(T, "to_torch", lambda sd: sd)
+    monkeypatch.setattr(weights, "sam_state_dict", lambda name, seed: {})
+    monkeypatch.setattr(bench.time, "perf_counter", lambda: now[0])
+    set_calls = []
+    real_set = torch.set_num_threads
+    state = [torch.get_num_threads()]
+    monkeypatch.setattr(torch, "set_num_threads", lambda n: (set_calls.append(n), state.__setitem__(0, n))[0])
+    monkeypatch.setattr(torch, "get_num_threads", lambda: state[0])
+    best, tried = bench.cpu_thread_calibration(256)
+    assert best == 16
+    assert list(tried) == ["256", "128", "64", "32", "16", "8"] and tried["16"] == 1.0      # 8 is 1.4x the best: the walk stops
+    assert seen[0] == 128 and seen[1:] == [256, 128, 64, 32, 16, 8]                           # one untimed warm-up pass first
+    assert real_set is not None
