@@ -66,6 +66,9 @@ struct Args {
   int ksplit;    // applied by splitk_reduce_kernel, which sums the parts in a fixed order
   const int *amap, *cmap;   // optional row maps: A row m is read from row amap[m]; output / residual row m lives at cmap[m]
   int rmod;    // residual row = row % rmod when > 0 (a residual shared by every batch of rows), else row
+  int rp_p, rp_t;   // ping-pong kernel, rmod > 0: schedule slot s of the row tiles works on row tile (s % rp_p) * rp_t + s / rp_p --
+                    // consecutive slots are the SAME rows of the residual table in consecutive batches, so the 256 KiB of
+                    // table rows a tile adds stay in the XCD's L2 across the batches (rp_t = 0: identity)
   int vec4;    // N, ldc, ldr multiples of 4 and 16-byte aligned bases: the write-out moves 16-byte vectors
 };
 
@@ -415,7 +418,9 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
     const int gmn = min(g.tiles_m - first_m, GM);
     const int rem = bid - group * GM * g.tiles_n;
     TileOff o;
-    o.row0 = (first_m + rem % gmn) * TBM;
+    int rt = first_m + rem % gmn;
+    if (g.rp_t) rt = (rt % g.rp_p) * g.rp_t + rt / g.rp_p;
+    o.row0 = rt * TBM;
     o.col0 = (rem / gmn) * TBN;
     a0 = min(o.row0 + rgA0 * 16 + prow, mclamp);
     a1 = min(o.row0 + rgA1 * 16 + prow, mclamp);
@@ -1136,6 +1141,18 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
   g.bias = bias; g.R = R; g.C = C; g.Ch = (_Float16*)Ch; g.Cl = (_Float16*)Cl;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldr = ldr; g.ldc = ldc;
   g.rmod = rmod; g.amap = amap; g.cmap = cmap;
+  g.rp_p = g.rp_t = 0;
+  {
+    // The decoder's k | v | q projections add a positional table of rmod rows to P batches of rmod rows: in row order an
+    // XCD walks the WHOLE table (4 - 6 MB, more than its L2) once per batch and the table rows were re-fetched for every
+    // tile -- as many bytes as the A operand itself (profiles/r05b_decoder_traffic.json: 18.8 MB fetched per prompt for
+    // 8.4 MB of operands).  HGL_X3_RPERM=0 keeps the row order.
+    static const int rperm = getenv("HGL_X3_RPERM") ? atoi(getenv("HGL_X3_RPERM")) : 1;
+    if (rperm && R && rmod > 0 && (rmod % 256) == 0 && (M % rmod) == 0 && M / rmod > 1 && !amap && !cmap) {
+      g.rp_p = M / rmod;
+      g.rp_t = rmod / 256;
+    }
+  }
   g.part = nullptr; g.ksplit = 1;
   g.out_scale = ldexpf(1.0f, -sw.scale_log2);
   g.lo_zero = x3_two_terms(sw) ? 1 : 0;
@@ -1225,7 +1242,7 @@ int hgl_launch_gemm_f16x3_splitk(const void* Ah, const void* Al, int lda, const 
   g.Ah = (const _Float16*)Ah; g.Al = (const _Float16*)Al; g.Wh = sw.hi; g.Wl = sw.lo;
   g.bias = nullptr; g.R = nullptr; g.C = nullptr; g.Ch = nullptr; g.Cl = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldr = 0; g.ldc = N;
-  g.rmod = 0; g.amap = amap; g.cmap = nullptr; g.part = part; g.ksplit = ksplit; g.vec4 = 1;
+  g.rmod = 0; g.rp_p = g.rp_t = 0; g.amap = amap; g.cmap = nullptr; g.part = part; g.ksplit = ksplit; g.vec4 = 1;
   g.out_scale = ldexpf(1.0f, -sw.scale_log2);
   g.lo_zero = x3_two_terms(sw) ? 1 : 0;
   g.gm = 8;
