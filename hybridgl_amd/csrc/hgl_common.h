@@ -77,75 +77,6 @@ __device__ __forceinline__ float hgl_gelu_erf(float x) {
   q = fabsf(x) > 5.65685424949238f ? 0.f : q;
   return 0.5f * x * (x < 0.f ? q : 2.0f - q);
 }
-// Two evaluations of hgl_gelu_erf at once, element for element the same operations in the same order (bit-identical): the
-// polynomial and the products as v_pk_fma_f32 / v_pk_mul_f32 (two fp32 lanes per instruction at the rate of one), 12 instead
-// of 19 instructions per value -- for the kernels whose bound IS this arithmetic (dec_tail_kernel: 768 GELUs per image token).
-typedef float hgl_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ hgl_f32x2 hgl_gelu_erf2(hgl_f32x2 x) {
-  const hgl_f32x2 xs = x * 0.70710678118654752440f;
-  hgl_f32x2 t;
-  t.x = fminf(fabsf(xs.x), 4.0f);
-  t.y = fminf(fabsf(xs.y), 4.0f);
-  hgl_f32x2 p = {4.582141628e-05f, 4.582141628e-05f};
-  p = __builtin_elementwise_fma(p, t, hgl_f32x2{-4.491848231e-04f, -4.491848231e-04f});
-  p = __builtin_elementwise_fma(p, t, hgl_f32x2{1.500873244e-03f, 1.500873244e-03f});
-  p = __builtin_elementwise_fma(p, t, hgl_f32x2{7.568532601e-04f, 7.568532601e-04f});
-  p = __builtin_elementwise_fma(p, t, hgl_f32x2{-2.823902667e-02f, -2.823902667e-02f});
-  p = __builtin_elementwise_fma(p, t, hgl_f32x2{1.484753788e-01f, 1.484753788e-01f});
-  p = __builtin_elementwise_fma(p, t, hgl_f32x2{9.184176326e-01f, 9.184176326e-01f});
-  p = __builtin_elementwise_fma(p, t, hgl_f32x2{1.627908468e+00f, 1.627908468e+00f});
-  const hgl_f32x2 a = p * t;
-  hgl_f32x2 q;
-  q.x = __builtin_amdgcn_exp2f(-a.x);
-  q.y = __builtin_amdgcn_exp2f(-a.y);
-  q.x = fabsf(x.x) > 5.65685424949238f ? 0.f : q.x;
-  q.y = fabsf(x.y) > 5.65685424949238f ? 0.f : q.y;
-  const hgl_f32x2 r = hgl_f32x2{2.0f, 2.0f} - q;
-  hgl_f32x2 s;
-  s.x = x.x < 0.f ? q.x : r.x;
-  s.y = x.y < 0.f ? q.y : r.y;
-  return (x * 0.5f) * s;
-}
-// Two independent pairs with their dependent chains written interleaved (a v_pk_*_f32 result is not available to the next
-// instruction: a lone chain costs one s_nop per step)
-__device__ __forceinline__ void hgl_gelu_erf4(hgl_f32x2& x0, hgl_f32x2& x1) {
-  const hgl_f32x2 xs0 = x0 * 0.70710678118654752440f, xs1 = x1 * 0.70710678118654752440f;
-  hgl_f32x2 t0, t1;
-  t0.x = fminf(fabsf(xs0.x), 4.0f);
-  t0.y = fminf(fabsf(xs0.y), 4.0f);
-  t1.x = fminf(fabsf(xs1.x), 4.0f);
-  t1.y = fminf(fabsf(xs1.y), 4.0f);
-  hgl_f32x2 p0 = {4.582141628e-05f, 4.582141628e-05f}, p1 = p0;
-#define HGL_GELU_STEP(c)                                            \
-  p0 = __builtin_elementwise_fma(p0, t0, hgl_f32x2{c, c});          \
-  p1 = __builtin_elementwise_fma(p1, t1, hgl_f32x2{c, c});
-  HGL_GELU_STEP(-4.491848231e-04f)
-  HGL_GELU_STEP(1.500873244e-03f)
-  HGL_GELU_STEP(7.568532601e-04f)
-  HGL_GELU_STEP(-2.823902667e-02f)
-  HGL_GELU_STEP(1.484753788e-01f)
-  HGL_GELU_STEP(9.184176326e-01f)
-  HGL_GELU_STEP(1.627908468e+00f)
-#undef HGL_GELU_STEP
-  const hgl_f32x2 a0 = p0 * t0, a1 = p1 * t1;
-  hgl_f32x2 q0, q1;
-  q0.x = __builtin_amdgcn_exp2f(-a0.x);
-  q0.y = __builtin_amdgcn_exp2f(-a0.y);
-  q1.x = __builtin_amdgcn_exp2f(-a1.x);
-  q1.y = __builtin_amdgcn_exp2f(-a1.y);
-  q0.x = fabsf(x0.x) > 5.65685424949238f ? 0.f : q0.x;
-  q0.y = fabsf(x0.y) > 5.65685424949238f ? 0.f : q0.y;
-  q1.x = fabsf(x1.x) > 5.65685424949238f ? 0.f : q1.x;
-  q1.y = fabsf(x1.y) > 5.65685424949238f ? 0.f : q1.y;
-  const hgl_f32x2 r0 = hgl_f32x2{2.0f, 2.0f} - q0, r1 = hgl_f32x2{2.0f, 2.0f} - q1;
-  hgl_f32x2 s0, s1;
-  s0.x = x0.x < 0.f ? q0.x : r0.x;
-  s0.y = x0.y < 0.f ? q0.y : r0.y;
-  s1.x = x1.x < 0.f ? q1.x : r1.x;
-  s1.y = x1.y < 0.f ? q1.y : r1.y;
-  x0 = (x0 * 0.5f) * s0;
-  x1 = (x1 * 0.5f) * s1;
-}
 // QuickGELU (clip/model.py:198-200): x * sigmoid(1.702 x) with the hardware exponential and reciprocal (1 ulp each)
 // instead of an IEEE division sequence
 __device__ __forceinline__ float hgl_quick_gelu(float x) {

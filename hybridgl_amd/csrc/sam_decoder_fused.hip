@@ -21,10 +21,11 @@
 // expressions; the LayerNorm sums and the hyper-network dot products are associated differently (per lane first, then
 // across the four lanes that share a row: a first version reproduced the unfused kernels' butterfly order bit for bit and
 // spent a quarter of its time in 256 dependent ds_bpermute + wait pairs per wave).  Fused and unfused logits agree to
-// fp32 rounding (tests/test_gpu_sam.py).  Round 5: eight waves per tile instead of four (see dec_tail_kernel), the GELUs two
-// values per instruction (hgl_gelu_erf4: v_pk_fma_f32), the epilogue vectors through LDS: 2.93 -> 2.56 ms per 529 prompts;
-// the vector pipe is then ~55 % and the matrix pipe ~23 % busy per SIMD with 3.8 waves resident
-// (profiles/r05c_sq_counters_dec_tail_*.json): the rest is the six barriers of a tile and the L2 round trips of the weight fragments.
+// fp32 rounding (tests/test_gpu_sam.py).  Round 5: eight waves per tile instead of four (see dec_tail_kernel), the epilogue
+// vectors through LDS, no register spilled: 2.93 -> 2.36 ms per 529 prompts; the vector pipe is then ~55 % and the matrix pipe
+// ~23 % busy per SIMD with 3.8 waves resident (profiles/r05c_sq_counters_dec_tail_*.json): the rest is the six barriers of a tile
+// and the L2 round trips of the weight fragments.  (The GELU polynomial two values per instruction -- v_pk_fma_f32 -- was built and
+// measured: a quarter fewer vector instructions, 1.5 % SLOWER: the packed fp32 forms issue at half rate on gfx950.)
 #include "hgl_common.h"
 
 bool hgl_get_split_weight(const float* W, const void** hi, const void** lo, int* scale_log2, int* N, int* K);
@@ -150,17 +151,6 @@ __global__ __launch_bounds__(512, 4) void dec_tail_kernel(TailArgs a) {
           }
     }
   }
-  // the weight fragments of the second product's first sub-position are requested now: they arrive during the LayerNorm
-  const _Float16* const w3h = a.W3h + (long long)(half * 64 + r) * 64 + 8 * h;
-  const _Float16* const w3l = a.W3l + (long long)(half * 64 + r) * 64 + 8 * h;
-  f16x8 qh[2][2][2], ql[2][2][2];      // [sub-position][K step][column block]
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      qh[0][ks][j] = *(const f16x8*)(w3h + j * 16 * 64 + ks * 32);
-      ql[0][ks][j] = *(const f16x8*)(w3l + j * 16 * 64 + ks * 32);
-    }
   __syncthreads();   // every wave has read the source tile: its LDS becomes the positions' 64 x 64 patches
 
   // ---- + bias, LayerNorm2d over the 64 channels of (row, position), GELU, split, into the position's patch ----
@@ -215,14 +205,11 @@ __global__ __launch_bounds__(512, 4) void dec_tail_kernel(TailArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         f16x4 hi4, lo4;
-        hgl_f32x2 y0 = {acc[i][j][0] * rs * lw[j][0] + lb[j][0], acc[i][j][1] * rs * lw[j][1] + lb[j][1]};
-        hgl_f32x2 y1 = {acc[i][j][2] * rs * lw[j][2] + lb[j][2], acc[i][j][3] * rs * lw[j][3] + lb[j][3]};
-        hgl_gelu_erf4(y0, y1);
-        const float o[4] = {y0.x, y0.y, y1.x, y1.y};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+          const float o = gelu_erf(acc[i][j][e] * rs * lw[j][e] + lb[j][e]);
           _Float16 hh, ll;
-          hgl_split_hi_lo(o[e], hh, ll);
+          hgl_split_hi_lo(o, hh, ll);
           hi4[e] = hh;
           lo4[e] = ll;
         }
@@ -242,6 +229,18 @@ __global__ __launch_bounds__(512, 4) void dec_tail_kernel(TailArgs a) {
   float* const stage = (float*)(smem + TAIL_STAGE);
   {
     const int pass = half;
+    // the weight fragments of the first sub-position (requested here: held across the LayerNorm they cost 15 spilled registers,
+    // whose scratch traffic showed as 2.4 MB written per prompt)
+    const _Float16* const w3h = a.W3h + (long long)(half * 64 + r) * 64 + 8 * h;
+    const _Float16* const w3l = a.W3l + (long long)(half * 64 + r) * 64 + 8 * h;
+    f16x8 qh[2][2][2], ql[2][2][2];      // [sub-position][K step][column block]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        qh[0][ks][j] = *(const f16x8*)(w3h + j * 16 * 64 + ks * 32);
+        ql[0][ks][j] = *(const f16x8*)(w3l + j * 16 * 64 + ks * 32);
+      }
     // columns of this pass: n = 64 pass + 32 sp + 16 jj + 4 h + e = sub-position 2 pass + sp, channel 16 jj + 4 h + e.
     // part[sp][i][m]: this lane's share (8 of the 32 channels) of the dot product of row 16 i + r, sub-position 2 pass + sp
     float part[2][4][3];
@@ -252,6 +251,17 @@ __global__ __launch_bounds__(512, 4) void dec_tail_kernel(TailArgs a) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) c2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (sp == 1) {      // (held across the first sub-position's epilogue these fragments spill: 16 - 128 B of scratch per lane;
+                          //  the fence keeps the compiler from hoisting the loads there by itself)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            qh[1][ks][j] = *(const f16x8*)(w3h + (32 + j * 16) * 64 + ks * 32);
+            ql[1][ks][j] = *(const f16x8*)(w3l + (32 + j * 16) * 64 + ks * 32);
+          }
+      }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -269,15 +279,6 @@ __global__ __launch_bounds__(512, 4) void dec_tail_kernel(TailArgs a) {
             }
         }
       }
-      if (sp == 0) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            qh[1][ks][j] = *(const f16x8*)(w3h + (32 + j * 16) * 64 + ks * 32);
-            ql[1][ks][j] = *(const f16x8*)(w3l + (32 + j * 16) * 64 + ks * 32);
-          }
-      }
       // (the hyper-network rows are re-read from LDS per row block: holding them would not fit beside the fragments in flight)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -289,14 +290,12 @@ __global__ __launch_bounds__(512, 4) void dec_tail_kernel(TailArgs a) {
           f32x4 hv1[3];
 #pragma unroll
           for (int m = 0; m < 3; ++m) hv1[m] = *(const f32x4*)(cst + 512 + 32 * m + 16 * jj + 4 * h);
-          hgl_f32x2 u0 = {c[0] * a.s3 + b3v1[0], c[1] * a.s3 + b3v1[1]};
-          hgl_f32x2 u1 = {c[2] * a.s3 + b3v1[2], c[3] * a.s3 + b3v1[3]};
-          hgl_gelu_erf4(u0, u1);
-          const float u[4] = {u0.x, u0.y, u1.x, u1.y};
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; ++e) {
+            const float u = gelu_erf(c[e] * a.s3 + b3v1[e]);
 #pragma unroll
-            for (int m = 0; m < 3; ++m) d3[m] = fmaf(u[e], hv1[m][e], d3[m]);
+            for (int m = 0; m < 3; ++m) d3[m] = fmaf(u, hv1[m][e], d3[m]);
+          }
         }
 #pragma unroll
         for (int m = 0; m < 3; ++m) part[sp][i][m] = d3[m];

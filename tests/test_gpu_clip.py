@@ -220,6 +220,37 @@ def test_baseline_size_rows_vs_oracle(cuda, b16, mode):
     np.testing.assert_allclose(sub, y[rest], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("mode", ["L2G", "G2L&L2G", "G2L"])
+def test_baseline_size_all_rows_vs_torch_cpu_restatement(cuda, b16, mode):
+    """The same shape with NO sampling: all 64 rows of the device run against oracle/torch_cpu.py -- the plain-PyTorch CPU
+    restatement of the reference's operators that tests/test_torch_cpu_baseline.py pins to the numpy oracle (which the
+    imported reference pins: tests/test_oracle_golden.py) -- ten seconds for 64 masks where the numpy oracle takes minutes.
+    Tolerances as in the sampled test: rows 1e-4, logits (x100) 1e-3, winners identical."""
+    from oracle import torch_cpu as TC
+    sd, model = b16
+    N = 64
+    rng = np.random.default_rng(7)
+    loc = rng.standard_normal((N, 3, 224, 224)).astype(np.float32)
+    glo = rng.standard_normal((N, 3, 224, 224)).astype(np.float32)
+    from hybridgl_amd.synth import synth_masks
+    masks = synth_masks(N, 640, 640, 11)
+    y = model(T(loc, cuda), T(glo, cuda), T(masks, cuda), masking_block=9, fusion_mode=mode).cpu().numpy()
+    before = torch.get_num_threads()
+    torch.set_num_threads(min(16, before))      # torch's pool at every hardware thread of a 256-thread host is 10x slower
+    try:
+        with torch.no_grad():
+            ref = TC.clip_hybrid_forward(TC.to_torch(sd), torch.from_numpy(loc), torch.from_numpy(glo), torch.from_numpy(masks),
+                                         9, mode, 10).numpy()
+    finally:
+        torch.set_num_threads(before)
+    np.testing.assert_allclose(y, ref, rtol=0, atol=1e-4)
+    txt = rng.standard_normal((3, 512)).astype(np.float32)
+    lg = ops.calculate_score(T(y, cuda), T(txt, cuda), 100.0).cpu().numpy()
+    rl = O.calculate_score(ref, txt, 100.0)
+    np.testing.assert_allclose(lg, rl, rtol=0, atol=1e-3)
+    assert np.array_equal(lg.argmax(0), rl.argmax(0))
+
+
 def test_pipeline_image_cache_identical(cuda, b16):
     """two refs of the same image: the cached second ref gives the same indices/metrics as recomputing"""
     import dataclasses

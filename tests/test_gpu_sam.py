@@ -610,6 +610,40 @@ def test_full_size_decoder_properties(cuda):
     assert ((got != (full > 0)).mean(axis=(1, 2)) < 1e-4).all()
 
 
+def test_full_size_decoder_all_prompts_vs_torch_cpu_restatement(cuda):
+    """The 64 prompts x 64x64 embedding of BASELINE's size with NO sampling: every prompt's three low-res logit planes and IoU
+    predictions against oracle/torch_cpu.py (pinned to the numpy oracle by tests/test_torch_cpu_baseline.py), then all 192
+    post-processed candidates: masks (<= 1e-4 of the pixels of any candidate may differ: a logit within rounding of the
+    threshold), stability scores and boxes of the candidates whose masks agree exactly."""
+    from oracle import torch_cpu as TC
+    cfg = weights.SAM_CONFIGS["vit_h_d2"]
+    sd = weights.sam_state_dict("vit_h_d2", 0)
+    m = hsam.Sam(sd, cfg, cuda)
+    rng = np.random.default_rng(7)
+    emb = rng.standard_normal((4096, 256)).astype(np.float32)
+    pts = hsam.build_point_grid(8) * 1024.0
+    p01 = T(((pts + 0.5) / 1024.0).astype(np.float32), cuda)
+    low, iou = m.decode_points(T(emb, cuda), p01)
+    before = torch.get_num_threads()
+    torch.set_num_threads(min(16, before))
+    try:
+        with torch.no_grad():
+            rl, ri = TC.mask_decoder(TC.to_torch(sd), torch.from_numpy(emb.reshape(64, 64, 256)),
+                                     torch.from_numpy(S.embed_points(sd, pts, 1024)))
+            rb, rstab, rbox = TC.postprocess_and_stats(rl, (1024, 1024), (640, 640))
+    finally:
+        torch.set_num_threads(before)
+    np.testing.assert_allclose(low.cpu().numpy(), rl.numpy(), rtol=0, atol=5e-4)
+    np.testing.assert_allclose(iou.cpu().numpy(), ri.numpy(), rtol=0, atol=2e-4)
+    masks, boxes, stab, keep, _ = m.postprocess(low.flatten(0, 1), iou.flatten(), (1024, 1024), (640, 640))
+    got = masks.cpu().numpy().astype(bool)
+    diff = (got != rb.numpy()).mean(axis=(1, 2))
+    assert (diff < 1e-4).all(), diff.max()
+    same = diff == 0
+    assert same.sum() >= 150                       # nearly all of the 192 candidates agree in every pixel
+    np.testing.assert_allclose(stab.cpu().numpy()[same], rstab.numpy()[same], rtol=0, atol=1e-3)
+
+
 @pytest.mark.parametrize("mode", ["holes", "islands"])
 def test_remove_small_regions_vs_oracle(cuda, mode):
     """device connected components (8-connectivity) vs the oracle on noisy + structured masks,
