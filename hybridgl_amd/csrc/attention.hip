@@ -1740,18 +1740,7 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
           ((a.Sk & 31) == 0 || !a.rel_h)) {
         constexpr int KROW_ = 2 * HD + 8, VP_ = 96;
         constexpr size_t lds = (size_t)2 * KV_CHUNK * (KROW_ + 2 * VP_) * sizeof(_Float16);
-        // the attribute is per device (a second device, or this one after a reset, would otherwise fail every launch of a
-        // 2048-token block): keyed by the device, result checked
-        static bool set_for[64] = {false};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-        if (!set_for[dev]) {
-          if (hipFuncSetAttribute((const void*)attn_x3pp_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            hgl_set_error("attention: cannot reserve %zu bytes of LDS for the ping-pong kernel", lds);
-            return HGL_ELAUNCH;
-          }
-          set_for[dev] = true;
-        }
+        HGL_RESERVE_LDS((attn_x3pp_kernel<HD>), lds, "attention (ping-pong kernel)");
         hipLaunchKernelGGL((attn_x3pp_kernel<HD>), dim3((a.Sq + 255) / 256, a.B * a.H), dim3(512), lds, st, a);
         return hgl_check_launch("attention");
       }

@@ -1121,22 +1121,15 @@ const unsigned char* psp_etab() {
 template <int HD, int MODE, int QT = 1>
 int psp_launch(const PsArgs& a, hipStream_t st) {
   constexpr size_t lds = psp_lds_bytes<HD, MODE>();
-  static bool set_for[64] = {false};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!set_for[dev]) {
-    if (hipFuncSetAttribute((const void*)attn_psp_kernel<HD, MODE, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      hgl_set_error("attention_ps: cannot reserve %zu bytes of LDS", lds);
-      return HGL_ELAUNCH;
-    }
-    set_for[dev] = true;
-  }
+  HGL_RESERVE_LDS((attn_psp_kernel<HD, MODE, QT>), lds, "attention_ps");
   const unsigned char* et = nullptr;
   if (MODE == PS_WIN14) {
     et = psp_etab();
     if (!et) { hgl_set_error("attention_ps: cannot allocate the indicator table"); return HGL_ELAUNCH; }
   }
   // persistent: two workgroups per CU (a multiple of 8, so that a workgroup's units stay on its XCD)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   static int ncu[64] = {0};
   if (ncu[dev] == 0) {
     hipDeviceProp_t prop;
@@ -1155,17 +1148,7 @@ int psp_launch(const PsArgs& a, hipStream_t st) {
 template <int HD, int MODE, int QT>
 int ps_launch(const PsArgs& a, hipStream_t st) {
   constexpr size_t lds = ps_lds_bytes<HD, MODE>();
-  // the attribute is per device: keyed by the device, result checked
-  static bool set_for[64] = {false};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!set_for[dev]) {
-    if (hipFuncSetAttribute((const void*)attn_ps_kernel<HD, MODE, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      hgl_set_error("attention_ps: cannot reserve %zu bytes of LDS", lds);
-      return HGL_ELAUNCH;
-    }
-    set_for[dev] = true;
-  }
+  HGL_RESERVE_LDS((attn_ps_kernel<HD, MODE, QT>), lds, "attention_ps");
   const long long wgs = (long long)a.B * a.H * a.nqb;
   hipLaunchKernelGGL((attn_ps_kernel<HD, MODE, QT>), dim3((unsigned)wgs), dim3(256), lds, st, a);
   return hgl_check_launch("attention_ps");

@@ -252,12 +252,7 @@ int hgl_launch_gemm(const float* A, const float* W, const float* bias, const flo
 #define HGL_GEMM_LAUNCH(ACT_, BK_, NBUF_, OCC_)                                                            \
   do {                                                                                                  \
     const size_t lds_ = (size_t)NBUF_ * (BM + BN) * (BK_ + 4) * sizeof(float);                          \
-    static bool set_ = false;                                                                           \
-    if (!set_) {                                                                                        \
-      (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<ACT_, BK_, NBUF_, OCC_>,                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                 \
-      set_ = true;                                                                                      \
-    }                                                                                                   \
+    HGL_RESERVE_LDS((gemm_f32_kernel<ACT_, BK_, NBUF_, OCC_>), lds_, "gemm_f32");                        \
     hipLaunchKernelGGL((gemm_f32_kernel<ACT_, BK_, NBUF_, OCC_>), dim3((unsigned)nwg), dim3(NTHREADS), lds_,  \
                        st, g);                                                                          \
   } while (0)

@@ -1057,11 +1057,7 @@ int launch_x3_v1(Args& g, hipStream_t st) {
   const long long nwg = (long long)g.tiles_m * g.tiles_n;
   HGL_REQUIRE(nwg < (1ll << 31), "gemm_f16x3: grid too large");
   const size_t lds = (size_t)(BM + BN) * (2 * BK + 8) * sizeof(_Float16);
-  static bool set = false;
-  if (!set) {
-    (void)hipFuncSetAttribute((const void*)gemm_f16x3_kernel<ACT, BK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    set = true;
-  }
+  HGL_RESERVE_LDS((gemm_f16x3_kernel<ACT, BK, 2>), lds, "gemm_f16x3");
   hipLaunchKernelGGL((gemm_f16x3_kernel<ACT, BK, 2>), dim3((unsigned)nwg), dim3(NTHREADS), lds, st, g);
   return HGL_OK;
 }
@@ -1073,11 +1069,7 @@ int launch_x3_p3(Args& g, hipStream_t st) {
   const long long nwg = (long long)g.tiles_m * g.tiles_n;
   HGL_REQUIRE(nwg < (1ll << 31), "gemm_f16x3: grid too large");
   const size_t lds = (size_t)2 * 4 * 256 * 64 + 8 * 4096;   // two stages + the write-out patches: all 160 KiB
-  static bool set = false;
-  if (!set) {
-    (void)hipFuncSetAttribute((const void*)gemm_x3p_kernel<ACT, WLOADS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    set = true;
-  }
+  HGL_RESERVE_LDS((gemm_x3p_kernel<ACT, WLOADS, NT>), lds, "gemm_f16x3 (ping-pong)");
   const long long grid = g.ksplit > 1 ? nwg : x3p_grid(nwg);
   hipLaunchKernelGGL((gemm_x3p_kernel<ACT, WLOADS, NT>), dim3((unsigned)grid, (unsigned)(g.ksplit > 1 ? g.ksplit : 1)), dim3(512), lds, st, g);
   return HGL_OK;

@@ -101,6 +101,23 @@ int hgl_require_device();                // HGL_ENODEVICE when no GPU is visible
     }                                   \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (function, device) pair: remembered per device at every call
+// site, the result checked (a process that uses a second GPU would otherwise launch there with the default 64 KiB limit and
+// fail in the launch).  KERNEL: a parenthesised function expression; use inside a function that returns an hgl status.
+#define HGL_RESERVE_LDS(KERNEL, BYTES, WHAT)                                                                        \
+  do {                                                                                                              \
+    static bool hgl_lds_set_[64] = {false};                                                                         \
+    int hgl_dev_ = 0;                                                                                               \
+    if (hipGetDevice(&hgl_dev_) != hipSuccess || hgl_dev_ < 0 || hgl_dev_ >= 64) hgl_dev_ = 0;                      \
+    if (!hgl_lds_set_[hgl_dev_]) {                                                                                  \
+      if (hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)) != hipSuccess) { \
+        hgl_set_error("%s: cannot reserve %d bytes of LDS", WHAT, (int)(BYTES));                                    \
+        return HGL_ELAUNCH;                                                                                         \
+      }                                                                                                             \
+      hgl_lds_set_[hgl_dev_] = true;                                                                                \
+    }                                                                                                               \
+  } while (0)
+
 #define HGL_TRY(expr)            \
   do {                           \
     int _rc = (expr);            \

@@ -628,11 +628,7 @@ int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0
   a.b0 = up0_b; a.ln_w = ln_w; a.ln_b = ln_b; a.b3 = up3_b; a.hyper = hyper;
   a.s0 = ldexpf(1.0f, -s0); a.s3 = ldexpf(1.0f, -s3); a.eps = eps;
   a.g = g; a.HW = HW; a.hrow0 = row0; a.out = low_res;
-  static bool set = false;
-  if (!set) {
-    (void)hipFuncSetAttribute((const void*)dec_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS);
-    set = true;
-  }
+  HGL_RESERVE_LDS((dec_tail_kernel), TAIL_LDS, "dec_tail");
   HglProfScope prof(HGL_PROF_OTHER, 2.0 * P * HW * (256.0 * 256 + 4 * 64.0 * 128), 0.0, st);
   hipLaunchKernelGGL(dec_tail_kernel, dim3((unsigned)(HW / TAIL_ROWS), (unsigned)P), dim3(512), TAIL_LDS, st, a);
   return hgl_check_launch("dec_tail");

@@ -1279,11 +1279,7 @@ int hgl_launch_relpos_direct(const float* qkv, int ldq, int B, int heads, int S,
     const size_t ldsm = (size_t)2 * NT * 32 * (hd + 8) * sizeof(_Float16) + (size_t)4 * 32 * (NT * 32 + 1) * sizeof(float);
 #define HGL_RP_LAUNCH(HD_, NT_)                                                                                          \
   do {                                                                                                                 \
-    static bool set_ = false;                                                                                          \
-    if (!set_) {                                                                                                       \
-      (void)hipFuncSetAttribute((const void*)relpos_mfma_kernel<HD_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm); \
-      set_ = true;                                                                                                     \
-    }                                                                                                                  \
+    HGL_RESERVE_LDS((relpos_mfma_kernel<HD_, NT_>), ldsm, "relpos");                                                    \
     hipLaunchKernelGGL((relpos_mfma_kernel<HD_, NT_>), gridm, dim3(256), ldsm, st, qkv, ldq, heads, S, size, Rh, Rw, rel_h, rel_w); \
   } while (0)
     if (hd == 80 && NT == 1) HGL_RP_LAUNCH(80, 1);
@@ -1309,10 +1305,7 @@ int hgl_launch_relpos_split(const void* q_hi, const void* q_lo, int ldq, int B, 
   const size_t ldsm = (size_t)2 * NT * 32 * (hd + 8) * sizeof(_Float16) + (size_t)4 * 32 * (NT * 32 + 1) * sizeof(float);
 #define HGL_RPS_LAUNCH(HD_, NT_)                                                                                         \
   do {                                                                                                                 \
-    if (hipFuncSetAttribute((const void*)relpos_mfma_kernel<HD_, NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm) != hipSuccess) { \
-      hgl_set_error("relpos_split: cannot reserve %zu bytes of LDS", ldsm);                                           \
-      return HGL_ELAUNCH;                                                                                              \
-    }                                                                                                                  \
+    HGL_RESERVE_LDS((relpos_mfma_kernel<HD_, NT_, true>), ldsm, "relpos_split");                                        \
     hipLaunchKernelGGL((relpos_mfma_kernel<HD_, NT_, true>), gridm, dim3(256), ldsm, st, (const float*)nullptr, ldq, heads, S, size, Rh, \
                        Rw, rel_h, rel_w, (const _Float16*)q_hi, (const _Float16*)q_lo);                                \
   } while (0)
