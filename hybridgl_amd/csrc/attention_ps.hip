@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void attn_ps_kernel(PsArgs a) {
   using G = PsGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, KP = G::KP, VP = G::VP;
   extern __shared__ __attribute__((aligned(1024))) unsigned char ps_smem[];
-  unsigned char* const Ebase = ps_smem + 2 * G::STAGE;
-  uint8_t* const keepL = ps_smem + 2 * G::STAGE + (MODE == PS_WIN14 ? PS_EROWS * PS_EP * 2 : 0);
+  static_assert(MODE == PS_PLAIN, "the un-pipelined kernel serves the plain / CLS-keep shapes only (rel-pos: attn_psp_kernel)");
+  uint8_t* const keepL = ps_smem + 2 * G::STAGE;
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -191,17 +191,6 @@ __global__ __launch_bounds__(256, 2) void attn_ps_kernel(PsArgs a) {
   if (MODE == PS_PLAIN && a.mask_kind == HGL_MASK_CLS_KEEP && b >= a.keep_b0)
     keep_row = a.keep + (long long)((b - a.keep_b0) % a.keep_n) * (a.S - 1);
   if (keep_row && t < a.S - 1) keepL[t] = keep_row[t];
-  if constexpr (MODE == PS_WIN14) {
-    // E[key][j] = 1 at j = key / 14 and j = 14 + key % 14 (32 columns): the rel-pos bias is two more k-steps R[q] . E[key]
-    for (int idx = t; idx < PS_EROWS * 4; idx += 256) {
-      const int row = idx >> 2, j0 = 8 * (idx & 3);
-      const int ih = row / 14, iw = 14 + row - ih * 14;
-      h16x8 e;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) e[j] = (j0 + j == ih || j0 + j == iw) ? (_Float16)1.f : (_Float16)0.f;
-      *(h16x8*)(Ebase + (row * PS_EP + j0) * 2) = e;
-    }
-  }
 
   // ---- Q fragments: lane (r, h) element j of k-step s = Q[q][16 s + 8 h + j], straight from the planes ----
   int qi[QT];
@@ -245,96 +234,6 @@ __global__ __launch_bounds__(256, 2) void attn_ps_kernel(PsArgs a) {
       for (int e = 0; e < 16; ++e) o[qt][d][e] = 0.f;
   }
 
-  // ---- PS_WIN14: R fragments of the MFMA bias.  rel_h[q][k] = q . Rh[qy - k + 13] (image_encoder.py:325-361, UNSCALED q):
-  // T^T = R . Q^T on the matrix cores with the split scheme and summation order of attn_x3_kernel, per wave, through an LDS
-  // patch [table index][query] that aliases the second K / V stage (its first DMA is issued behind the loop's first barrier).
-  h16x8 rbh[2], rbl[2];
-  if constexpr (MODE == PS_WIN14) {
-    float xs[2][8];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xs[c][j] = 0.f;
-    if (wave_active) {
-      float* const P0 = (float*)(ps_smem + G::STAGE) + wave * 32 * 32;
-      const int qq = qvalid[0] ? qi[0] : 0;
-      const int qy = qq / 14, qx = qq - qy * 14;
-#pragma unroll
-      for (int axis = 0; axis < 2; ++axis) {
-        const _Float16* Th = axis ? a.tabw_hi : a.tabh_hi;
-        const _Float16* Tl = axis ? a.tabw_lo : a.tabh_lo;
-        const long long to = (long long)min(r, 26) * HD + 8 * h;
-        h16x8 thr[KS], tlr[KS];
-#pragma unroll
-        for (int sx = 0; sx < KS; ++sx) {
-          thr[sx] = *(const h16x8*)(Th + to + 16 * sx);
-          tlr[sx] = *(const h16x8*)(Tl + to + 16 * sx);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (r >= 27) {
-#pragma unroll
-          for (int sx = 0; sx < KS; ++sx)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { thr[sx][e] = (_Float16)0.f; tlr[sx][e] = (_Float16)0.f; }
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int sx = 0; sx < KS; ++sx) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tlr[sx], qh[0][sx], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(thr[sx], ql[0][sx], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(thr[sx], qh[0][sx], acc, 0, 0, 0);
-        }
-        // acc[e] = T[table index (e&3) + 8*(e>>2) + 4*h][query r]
-#pragma unroll
-        for (int e = 0; e < 16; ++e) P0[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[e];
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        // R[q][idx]: idx < 14 -> rel_h[q][k = idx] (axis 0), 14 <= idx < 28 -> rel_w[q][k = idx - 14] (axis 1), else 0
-        const int qc = axis ? qx : qy;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int k = 16 * c + 8 * h + j - 14 * axis;
-            if (k >= 0 && k < 14) xs[c][j] = P0[(qc + 13 - k) * 32 + r];
-          }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float x = xs[c][j] * inv_scale;
-        _Float16 hi, lo;
-        hgl_split_hi_lo(x, hi, lo);
-        rbh[c][j] = hi;
-        rbl[c][j] = lo;
-      }
-  }
-
-  // ---- PS_RELT: the 17 rel-pos values a lane adds to the scores of a key tile, fetched ONE TILE AHEAD (attn_x3_kernel) ----
-  float rh_next = 0.f;
-  f32x4 rw_next[4];
-  const int rel_q0 = (bx * 4 + wave) * QT * 32;
-  auto rel_prefetch = [&](int kb) {
-    if constexpr (MODE == PS_RELT) {
-      int ln;
-      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-      const unsigned row = (unsigned)item * (unsigned)a.S + (unsigned)min(rel_q0 + (ln & 31), a.S - 1);
-      const unsigned relh_off = row * (unsigned)a.kh;
-      const unsigned relw_off = row * (unsigned)a.kw + 4u * (unsigned)(ln >> 5);
-      kb = min(kb, a.S - 32);
-      rh_next = a.rel_h[relh_off + (unsigned)(kb / a.kw)];
-      const unsigned o2 = relw_off + (unsigned)(kb % a.kw);
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) rw_next[g4] = *(const f32x4*)(a.rel_w + o2 + 8 * g4);
-    }
-  };
-  if (MODE == PS_RELT && wave_active) rel_prefetch(0);
   PS_STAMP(4);
 
   // The compiler does not see the DMA pieces on vmcnt: wherever IT waits for one of its own loads inside the loop it waits
@@ -346,9 +245,6 @@ __global__ __launch_bounds__(256, 2) void attn_ps_kernel(PsArgs a) {
   for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
     for (int sx = 0; sx < KS; ++sx) asm volatile("" : "+v"(qh[qt][sx]), "+v"(ql[qt][sx]));
-  if constexpr (MODE == PS_RELT) {
-    asm volatile("" : "+v"(rh_next), "+v"(rw_next[0]), "+v"(rw_next[1]), "+v"(rw_next[2]), "+v"(rw_next[3]));
-  }
 
   // transposed-read addressing (attn_x3_kernel): lane = 16*grp + 4*q + p supplies row q, columns 4p..4p+3 of its group's block
   const int tr_off = (((lane >> 2) & 3) + 4 * h) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -360,9 +256,6 @@ __global__ __launch_bounds__(256, 2) void attn_ps_kernel(PsArgs a) {
     PS_STAMP(10);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PS_STAMP(11);
-    if constexpr (MODE == PS_RELT) {   // the compiler's wait for the rel-pos terms requested during the previous tile: here, not behind the DMA
-      asm volatile("" : "+v"(rh_next), "+v"(rw_next[0]), "+v"(rw_next[1]), "+v"(rw_next[2]), "+v"(rw_next[3]));
-    }
     __syncthreads();
     PS_STAMP(12);
     if (ci + 1 < nchunk) issue_chunk(ci + 1);
@@ -377,14 +270,8 @@ __global__ __launch_bounds__(256, 2) void attn_ps_kernel(PsArgs a) {
     for (int qt = 0; qt < QT; ++qt) {
       if (!tile_active[qt]) continue;   // uniform per wave
       f32x16 s;
-      if constexpr (MODE == PS_RELT) {   // the score accumulators START at the rel-pos terms
-        const float rhs = rh_next * inv_scale;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = fmaf(rw_next[e >> 2][e & 3], inv_scale, rhs);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
-      }
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
       const _Float16* krow = Ks + r * KP + 8 * h;
 #pragma unroll
       for (int c = 0; c < KS; ++c) {
@@ -393,15 +280,6 @@ __global__ __launch_bounds__(256, 2) void attn_ps_kernel(PsArgs a) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[qt][c], s, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, ql[qt][c], s, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh[qt][c], s, 0, 0, 0);
-      }
-      if constexpr (MODE == PS_WIN14) {
-        const _Float16* erow = (const _Float16*)Ebase + (kbase + r) * PS_EP + 8 * h;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const h16x8 e8 = *(const h16x8*)(erow + 16 * c);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(e8, rbl[c], s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(e8, rbh[c], s, 0, 0, 0);
-        }
       }
       // s[e] = S^T[key = kbase + (e&3) + 8*(e>>2) + 4*h][query], unscaled; scale and log2(e) are folded into the exponent's fma
       PS_STAMP(14);
@@ -459,7 +337,6 @@ __global__ __launch_bounds__(256, 2) void attn_ps_kernel(PsArgs a) {
       l_run[qt] += rs;
       PS_STAMP(15);
       // the scores are dead from here on: the next tile's rel-pos terms travel under the P V products
-      if (MODE == PS_RELT && qt == QT - 1) rel_prefetch(kbase + 32);
       // O^T += V^T P^T ; A operand element j of lane (d, h) = V^T[d][16*s2 + 8*(j>>2) + 4*h + (j&3)]
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -1244,24 +1121,13 @@ int hgl_launch_attention_ps(const void* qkv_hi, const void* qkv_lo, int ld, int 
   }
   if (kind == K_NONE) return 1;
   HglProfScope prof(HGL_PROF_ATTN, 4.0 * B * H * (double)S * S * hd, 0.0, st);
-  static const int pipelined = getenv("HGL_ATTN_PSP") ? atoi(getenv("HGL_ATTN_PSP")) : 1;
-  if (pipelined) {
-    switch (kind) {
-      case K_WIN: return psp_launch<80, PS_WIN14>(a, st);
-      case K_RELT80: return psp_launch<80, PS_RELT>(a, st);
-      case K_RELT64: return psp_launch<64, PS_RELT>(a, st);
-      case K_PLAIN80: return psp_launch<80, PS_PLAIN>(a, st);
-      case K_PLAIN64: return psp_launch<64, PS_PLAIN>(a, st);
-      default: break;
-    }
-  }
   switch (kind) {
-    case K_WIN: return ps_launch<80, PS_WIN14, 1>(a, st);
-    case K_RELT80: return ps_launch<80, PS_RELT, 1>(a, st);
-    case K_RELT64: return ps_launch<64, PS_RELT, 1>(a, st);
-    case K_CLIP: return ps_launch<64, PS_PLAIN, 2>(a, st);
-    case K_PLAIN80: return ps_launch<80, PS_PLAIN, 1>(a, st);
-    default: return ps_launch<64, PS_PLAIN, 1>(a, st);
+    case K_WIN: return psp_launch<80, PS_WIN14>(a, st);
+    case K_RELT80: return psp_launch<80, PS_RELT>(a, st);
+    case K_RELT64: return psp_launch<64, PS_RELT>(a, st);
+    case K_PLAIN80: return psp_launch<80, PS_PLAIN>(a, st);
+    case K_PLAIN64: return psp_launch<64, PS_PLAIN>(a, st);
+    default: return ps_launch<64, PS_PLAIN, 2>(a, st);     // K_CLIP: the un-pipelined kernel, two query tiles per wave
   }
 }
 
