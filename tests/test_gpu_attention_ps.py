@@ -77,6 +77,8 @@ def test_clip_hybrid_forward_presplit_equals_fp32_input_path(cuda):
     hands the attention an fp32 qkv tensor: equal to fp32 rounding through all twelve blocks.  (The 197-token blocks take the
     pre-split kernel only with HGL_ATTN_PS_CLIPBLOCKS=2 -- read once per process: this test runs the forward in a child.)"""
     import subprocess, sys, os
+    if ops.default_precision() != "f16x3":
+        pytest.skip("pre-split attention belongs to the split-fp16 mode")
     code = (
         "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
         "from hybridgl_amd import _lib, weights\n"
