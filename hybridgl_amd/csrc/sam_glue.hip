@@ -1149,6 +1149,97 @@ __device__ __forceinline__ bool nms_overlap(const int4 a, const int4 b, float th
   return iou > thr;
 }
 
+// nms_kernel's semantics for K <= 512 without its serial loop of K iterations x (two barriers + global loads of the current
+// box: 82 us for the 192 candidates of an image): ranks by counting, the boxes in rank order in LDS, every thread the
+// suppression words of its row (the same IoU expression: nms_overlap), then ONE thread walks the rows OR-ing the kept ones
+// into the removed set -- the scheme of the any-K path below in one workgroup.
+__global__ __launch_bounds__(512) void nms_bits_kernel(const int* __restrict__ boxes, const float* __restrict__ scores,
+                                                       const uint8_t* __restrict__ keep, int K, float thr,
+                                                       int* __restrict__ out_idx, int* __restrict__ out_n) {
+  __shared__ int4 sbox[512];
+  __shared__ int order[512];
+  __shared__ float ssc[512];
+  __shared__ unsigned char skeep[512];
+  __shared__ unsigned long long mask[512][8];
+  __shared__ unsigned long long removed[8];
+  __shared__ unsigned long long kept_word;
+  __shared__ int nv, nkept_s;
+  const int t = threadIdx.x, lane = t & 63;
+  const bool valid = t < K && keep[t];
+  const float sc = valid ? scores[t] : 0.f;
+  ssc[t] = sc;
+  skeep[t] = valid ? 1 : 0;
+  order[t] = -1;
+  if (t < 8) removed[t] = 0;
+  if (t == 0) { nv = 0; nkept_s = 0; }
+  __syncthreads();
+  if (valid) {      // rank by counting: position among the valid candidates (descending score, the index breaks ties)
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < K; ++j) {
+      const float sj = ssc[j];
+      rank += (skeep[j] && (sj > sc || (sj == sc && j < t))) ? 1 : 0;
+    }
+    order[rank] = t;
+    atomicAdd(&nv, 1);
+  }
+  __syncthreads();
+  const int n = nv;
+  if (t < n) sbox[t] = ((const int4*)boxes)[order[t]];
+  __syncthreads();
+  const int nw = (n + 63) >> 6;
+  // word w is needed of rows 0 .. min(n, 64 (w + 1)) - 1 (words left of a row's diagonal block are never read): the (word, row)
+  // pairs are dealt to all 512 threads -- 384 pairs of 64 IoUs for 192 boxes, not three words for each of 192 threads
+  for (int w = 0, q0 = 0; w < nw; ++w) {
+    const int rows = min(n, 64 * (w + 1));
+    for (int q = t - (q0 & 511); q < rows; q += 512) {
+      if (q < 0) continue;
+      const int4 me = sbox[q];
+      unsigned long long word = 0;
+      const int b0 = 64 * w, jn = min(64, n - b0);
+#pragma unroll 4
+      for (int j = 0; j < jn; ++j)
+        if (b0 + j > q && nms_overlap(me, sbox[b0 + j], thr)) word |= 1ull << j;
+      mask[q][w] = word;
+    }
+    q0 += rows;
+  }
+  __syncthreads();
+  // nms_scan_kernel's walk on the LDS-resident words: wave 0 resolves a block of 64 rows with shuffles, then every later word
+  // takes the OR of the kept rows
+  for (int rb = 0; rb < nw; ++rb) {
+    if (t < 64) {
+      const int a = rb * 64 + lane;
+      const unsigned long long d = a < n ? mask[a][rb] : 0ull;
+      unsigned long long rem = removed[rb], km = 0;
+      for (int s2 = 0; s2 < 64; ++s2) {
+        const unsigned lo = __shfl((unsigned)(d & 0xffffffffull), s2), hi = __shfl((unsigned)(d >> 32), s2);
+        if (rb * 64 + s2 < n && !((rem >> s2) & 1ull)) {
+          km |= 1ull << s2;
+          rem |= ((unsigned long long)hi << 32) | lo;
+        }
+      }
+      const int base = nkept_s;
+      if ((km >> lane) & 1ull) out_idx[base + __popcll(km & ((1ull << lane) - 1ull))] = order[a];
+      if (lane == 0) { kept_word = km; nkept_s = base + __popcll(km); }
+    }
+    __syncthreads();
+    const unsigned long long km = kept_word;
+    if (t > rb && t < nw) {
+      unsigned long long acc = removed[t];
+      unsigned long long bits = km;
+      while (bits) {
+        const int s2 = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        acc |= mask[rb * 64 + s2][t];
+      }
+      removed[t] = acc;
+    }
+    __syncthreads();
+  }
+  if (t == 0) *out_n = nkept_s;
+}
+
 // grid (W, W), 64 threads: word (row a = 64*by + t, column block bx) of the upper triangle
 __global__ __launch_bounds__(64) void nms_mask_kernel(const int* __restrict__ boxes, const int* __restrict__ order,
                                                       const int* __restrict__ nvalid, int W, float thr,
@@ -1472,7 +1563,10 @@ int hgl_nms(const int32_t* boxes_xyxy, const float* scores, const uint8_t* keep,
   HGL_TRY(hgl_require_device());
   HGL_REQUIRE(boxes_xyxy && scores && keep && out_idx && out_n, "nms: null argument");
   HGL_REQUIRE(K > 0 && K <= 1024, "nms: K must be in [1,1024] (got %d)", K);
-  hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)boxes_xyxy, scores, keep, K, iou_threshold, (int*)out_idx, (int*)out_n);
+  if (K <= 512 && ((uintptr_t)boxes_xyxy & 15) == 0)
+    hipLaunchKernelGGL(nms_bits_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, (const int*)boxes_xyxy, scores, keep, K, iou_threshold, (int*)out_idx, (int*)out_n);
+  else
+    hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)boxes_xyxy, scores, keep, K, iou_threshold, (int*)out_idx, (int*)out_n);
   return hgl_check_launch("nms");
 }
 

@@ -262,7 +262,7 @@ def test_postprocess_tile_paths_vs_oracle(cuda, tiny, orig, inp):
 
 def test_nms_vs_oracle(cuda):
     rng = np.random.default_rng(2)
-    for K in [1, 7, 192, 700]:
+    for K in [1, 7, 64, 192, 512, 513, 700]:      # <= 512: the bit-matrix kernel, above: the serial one
         xy = rng.integers(0, 500, size=(K, 2))
         wh = rng.integers(1, 200, size=(K, 2))
         boxes = np.concatenate([xy, xy + wh], 1).astype(np.int32)
