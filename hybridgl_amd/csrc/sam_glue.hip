@@ -204,10 +204,33 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const float* __restric
   const int nrow = 2 * size - 1;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
-  // the wave's 32 query vectors, split once and used for both axes
-  const int q = (blockIdx.x * 4 + wave) * 32 + r;
-  const bool qvalid = q < S;
-  rp_h8 qh[KS], ql[KS];
+  // Query blocks per workgroup: the global blocks' tables (127 x HD, split to fp16 hi / lo here) are staged ONCE per axis for
+  // QB blocks of 128 queries (round 5: one block per workgroup spent as long splitting the table as multiplying)
+  constexpr int QB = (PS && NT == 4) ? 4 : 1;
+  float* Gw = G + (wave * 32 + r) * GP;
+  for (int axis = 0; axis < 2; ++axis) {
+    const float* R = axis ? Rw : Rh;
+    if (axis) __syncthreads();                             // every wave has gathered from its patch / read the table
+    for (int i = t; i < NT * 32 * (HD / 4); i += 256) {
+      const int rr = i / (HD / 4), c = i % (HD / 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (rr < nrow) v = *(const f32x4*)(R + (long long)rr * HD + 4 * c);
+      rp_h4 a, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        _Float16 h0, l0;
+        hgl_split_hi_lo(v[e], h0, l0);
+        a[e] = h0;
+        l[e] = l0;
+      }
+      *(rp_h4*)(Th + rr * TP + 4 * c) = a;
+      *(rp_h4*)(Tl + rr * TP + 4 * c) = l;
+    }
+    __syncthreads();
+    for (int qb = 0; qb < QB; ++qb) {
+    const int q = ((blockIdx.x * QB + qb) * 4 + wave) * 32 + r;
+    const bool qvalid = q < S;
+    rp_h8 qh[KS], ql[KS];
   if constexpr (PS) {
     const long long qo = ((long long)b * S + (qvalid ? q : 0)) * ldq + hh * HD + 8 * h;
 #pragma unroll
@@ -251,26 +274,11 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const float* __restric
     }
   }
   }
-  float* Gw = G + (wave * 32 + r) * GP;
-  for (int axis = 0; axis < 2; ++axis) {
-    const float* R = axis ? Rw : Rh;
-    if (axis) __syncthreads();                             // every wave has gathered from its patch / read the table
-    for (int i = t; i < NT * 32 * (HD / 4); i += 256) {
-      const int rr = i / (HD / 4), c = i % (HD / 4);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (rr < nrow) v = *(const f32x4*)(R + (long long)rr * HD + 4 * c);
-      rp_h4 a, l;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        _Float16 h0, l0;
-        hgl_split_hi_lo(v[e], h0, l0);
-        a[e] = h0;
-        l[e] = l0;
-      }
-      *(rp_h4*)(Th + rr * TP + 4 * c) = a;
-      *(rp_h4*)(Tl + rr * TP + 4 * c) = l;
+    if (QB > 1) {      // the previous block's gather reads of this wave's patch are done (LDS operations of a wave are in order)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __syncthreads();
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
       f32x16 acc;
@@ -290,8 +298,32 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const float* __restric
 #pragma unroll
       for (int e = 0; e < 16; ++e) Gw[tt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[e];
     }
-    __syncthreads();
-    if (qvalid) {
+    if (QB > 1) {      // the patch is private to the wave
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+      __syncthreads();
+    }
+    if ((size & 63) == 0) {
+      // rows of `size` floats, written as rows: 16 consecutive lanes store the 256 contiguous bytes of 64 entries of ONE query
+      // (the wave's patch holds T[query][table index]; entry k of query qq is index qc + size - 1 - k).  The first version
+      // stored 8 bytes per lane at the stride of a row -- 64 separate 8-byte writes per instruction: 0.6 TB/s for the
+      // 537 MB a global block writes.
+      const int q0w = ((blockIdx.x * QB + qb) * 4 + wave) * 32;
+      const float* Gq = G + wave * 32 * GP;
+      const int per = size >> 2;                            // 16-byte pieces per row
+      for (int i = lane; i < 32 * per; i += 64) {
+        const int ql = i / per, k4 = 4 * (i - ql * per);
+        const int qq = q0w + ql;
+        if (qq < S) {
+          const int qc = axis ? qq % size : qq / size;
+          const float* src = Gq + ql * GP + qc + size - 1 - k4;
+          const f32x4 o = {src[0], src[-1], src[-2], src[-3]};
+          *(f32x4*)((axis ? rel_w : rel_h) + ((long long)bh * S + qq) * size + k4) = o;
+        }
+      }
+    } else if (qvalid) {
       const int qc = axis ? q % size : q / size;
       float* out = (axis ? rel_w : rel_h) + ((long long)bh * S + q) * size;
       // the two lanes of a query share its row: k in [0, sp) and [sp, size), sp even so that both write aligned pairs
@@ -305,6 +337,7 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const float* __restric
         *(f32x2*)(out + k) = o;
       }
     }
+    }   // query blocks
   }
 }
 
@@ -1392,7 +1425,8 @@ int hgl_launch_relpos_split(const void* q_hi, const void* q_lo, int ldq, int B, 
   HGL_REQUIRE((hd == 80 || hd == 64) && (size == 14 || size == 64) && q_hi && q_lo && (ldq & 7) == 0,
               "relpos_split: unsupported shape (hd %d, size %d)", hd, size);
   const int NT = size == 14 ? 1 : 4;
-  const dim3 gridm((unsigned)((S + 127) / 128), (unsigned)(B * heads), 1);
+  const int qpw = NT == 4 ? 512 : 128;       // queries per workgroup (relpos_mfma_kernel: QB)
+  const dim3 gridm((unsigned)((S + qpw - 1) / qpw), (unsigned)(B * heads), 1);
   const size_t ldsm = (size_t)2 * NT * 32 * (hd + 8) * sizeof(_Float16) + (size_t)4 * 32 * (NT * 32 + 1) * sizeof(float);
 #define HGL_RPS_LAUNCH(HD_, NT_)                                                                                         \
   do {                                                                                                                 \
