@@ -367,7 +367,6 @@ def hbm_kernel_specs(N=64, H=640, W=640, S=3, K=192, g=1):
         "synth_views_kernel": (2 * N * 3 * 224 * 224 * 4 + 2 * px * 3 + N * px // 8, "write both views (77 MB) + sharp / blurred image + mask bits (K9)"),
         "ccl_rows_kernel": (N * px, "mask bytes read once per pass"),
         "ccl_merge_kernel": (N * px, "mask bytes read once per pass (two rows per wave: x2 through L2)"),
-        "ccl_compress_kernel": (N * px, "mask bytes read once per pass"),
         "ccl_count_kernel": (N * px, "mask bytes read once per pass"),
         "ccl_stats_kernel": (N * px, "mask bytes read once per pass"),
         "ccl_apply_kernel": (2 * N * px, "mask bytes read + cleaned bytes written (+ the boxes, from this round on)"),

@@ -164,27 +164,6 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t* __restric
   })
 }
 
-// Pass C -- every run start is pointed at its root (find with path halving: the chains the unions left behind collapse as
-// the pass goes), so the passes after it read a run's component with ONE load.
-__global__ __launch_bounds__(256) void ccl_compress_kernel(const uint8_t* __restrict__ masks, int holes, int* __restrict__ L,
-                                                           int W, long long rows) {
-  const int lane = threadIdx.x & 63;
-  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const long long base = row * W;
-  RowScan c;
-  c.init(masks + base, W, holes, lane);
-  CCL_FOR_STEPS(c.load(g0, lane), {
-    c.step(k, x0, lane);
-    if (c.work && !c.left) {
-      const int i = (int)(base + x0 + lane);
-      const int r = uf_find_compress(L, i);
-      if (r != i) L[i] = r;      // (a plain store: links only ever move towards the root, and r IS the root now)
-    }
-    c.advance(x0);
-  })
-}
-
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -196,7 +175,11 @@ __device__ __forceinline__ int wave_sum(int v) {
 // a (root, sum) pair across the steps of its row: lanes whose run belongs to the carried root are summed with shuffles,
 // the pair is flushed with one atomic when another root takes over or the row ends.  Two candidate roots per step at most;
 // what is left adds on its own.
-__global__ __launch_bounds__(256) void ccl_count_kernel(const uint8_t* __restrict__ masks, int holes, const int* __restrict__ L,
+// The pass also points every run start at its root (find with path halving: the chains the unions left behind collapse as the
+// pass goes; the passes after it read a run's component with ONE load).  Until round 5 that was a pass of its own ("C"): one
+// scan of the mask bytes and one launch more per call, 0.96 against 0.86 ms per ref for the six / five passes.  The unions are
+// over when this pass runs, so roots no longer move; concurrent halving by other waves only shortens chains.
+__global__ __launch_bounds__(256) void ccl_count_kernel(const uint8_t* __restrict__ masks, int holes, int* __restrict__ L,
                                                         int* __restrict__ area, int W, long long rows) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
@@ -208,7 +191,12 @@ __global__ __launch_bounds__(256) void ccl_count_kernel(const uint8_t* __restric
   CCL_FOR_STEPS(c.load(g0, lane), {
     c.step(k, x0, lane);
     bool act = c.work && !c.right;
-    const int r = act ? L[base + c.start] : -1;
+    int r = -1;
+    if (act) {
+      const int i = (int)(base + c.start);
+      r = uf_find_compress(L, i);
+      if (r != i) L[i] = r;      // (a plain store: links only ever move towards the root, and r IS the root now)
+    }
     const int len = x0 + lane - c.start + 1;
     unsigned long long todo = __ballot(act);
     if (todo) {
@@ -468,8 +456,7 @@ static int remove_small_regions_impl(const uint8_t* masks, int N, int H, int W, 
   hipLaunchKernelGGL(ccl_rows_kernel, grid, dim3(256), 0, st, masks, holes, W, rows, L, area);
   hipLaunchKernelGGL(ccl_stats_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stats, N, (int*)nullptr);
   hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, st, masks, holes, L, H, W, rows);
-  hipLaunchKernelGGL(ccl_compress_kernel, grid, dim3(256), 0, st, masks, holes, L, W, rows);
-  hipLaunchKernelGGL(ccl_count_kernel, grid, dim3(256), 0, st, masks, holes, (const int*)L, area, W, rows);
+  hipLaunchKernelGGL(ccl_count_kernel, grid, dim3(256), 0, st, masks, holes, L, area, W, rows);
   hipLaunchKernelGGL(ccl_stats_kernel, grid, dim3(256), 0, st, masks, holes, (const int*)L, (const int*)area, W, HW, rows,
                      area_thresh, stats);
   hipLaunchKernelGGL(ccl_apply_kernel, grid, dim3(256), 0, st, masks, (const int*)L, (const int*)area, (const int*)stats, holes,
