@@ -237,11 +237,13 @@ def cpu_baseline(fusion_mode, with_sam=True, with_gem=False, clip_name="ViT-B/16
                 from hybridgl_amd.gem import get_gem_img_transform
                 from oracle import gem_oracle as GO
                 timg = get_gem_img_transform()(img).numpy()
+                # the position embedding interpolated to the 28 x 28 grid: a table, computed once per resolution, not timed
+                pos = torch.from_numpy(GO.interpolate_pos_encoding(sd["visual.positional_embedding"], 448 // sd["visual.conv1.weight"].shape[2], 448 // sd["visual.conv1.weight"].shape[2]))
                 t = time.perf_counter()
-                feat, _ = GO.gem_vit_forward(sd, timg[None])
-                heat = GO.gem_heatmap(feat[0], text[:3], 448)
+                feat = T.gem_vit_forward(sdt, torch.from_numpy(timg[None]), pos)
+                heat = T.gem_heatmap(feat[0], torch.from_numpy(text[:3]), 448).numpy()
                 GO.resize_bilinear_aa(heat, H, W)
-                stages["GEM heat-maps: 1 image at 448 + 3 maps (numpy; the reference re-encodes per sentence)"] = time.perf_counter() - t
+                stages["GEM heat-maps: 1 image at 448 (torch CPU) + 3 maps (the reference re-encodes per sentence)"] = time.perf_counter() - t
             if with_sam:
                 cfg = weights.SAM_CONFIGS["vit_h"]
                 ssd = weights.sam_state_dict("vit_h", 0)
@@ -276,10 +278,13 @@ def cpu_baseline(fusion_mode, with_sam=True, with_gem=False, clip_name="ViT-B/16
             "sample": "ONE ref of the benchmarked workload through oracle/torch_cpu.py (plain PyTorch fp32 on the CPU, pinned to the numpy "
                       "oracle by tests/test_torch_cpu_baseline.py): CLIP hybrid on all 64 masks, all text strings, all 32 SAM encoder "
                       "blocks, the decoder on all 64 prompts and the post-processing of all 192 candidates, nothing sampled or "
-                      "extrapolated; blur, views, tail and the GEM stage through the numpy oracle"}
+                      "extrapolated; the GEM tower likewise (oracle/torch_cpu.py gem_vit_forward); blur, views, tail and the final resize of the heat-maps through the numpy oracle"}
 
 
-def live_pmc_table(timeout_s=150.0, refs=16):
+PMC_PASS = {"groups": 2, "refs_per_group": 16}      # what the counter pass ran (set by live_pmc_table): launches per ref derive from it
+
+
+def live_pmc_table(timeout_s=150.0, refs=16, groups=1):
     """Per-kernel HBM bytes and launch times of the headline's loop, measured NOW: two child processes `rocprofv3 --pmc
     FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only, as MI355X_MICROARCH.md prescribes) over
     tools/group_profile.py (one serial group of `refs` refs after a warm-up group, same models and shapes), corrected as that
@@ -304,7 +309,7 @@ def live_pmc_table(timeout_s=150.0, refs=16):
             d = os.path.join(out, ctr)
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-                                sys.executable, os.path.join(ROOT, "tools", "group_profile.py"), "1", str(refs)],
+                                sys.executable, os.path.join(ROOT, "tools", "group_profile.py"), str(groups), str(refs)],
                                cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {ctr} exited {r.returncode}"
@@ -323,13 +328,14 @@ def live_pmc_table(timeout_s=150.0, refs=16):
                         dur[k][0] += 1
                         dur[k][1] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
         table = {}
+        PMC_PASS["groups"], PMC_PASS["refs_per_group"] = groups + 1, refs      # group_profile.py runs a warm-up group first
         for k, (n, v) in sums["FETCH_SIZE"].items():
             nw, vw = sums["WRITE_SIZE"].get(k, [0, 0.0])
             table[k] = {"launches": n, "fetch_bytes": 2.0 * 1024.0 * v / max(n, 1), "write_bytes": 1024.0 * vw / max(nw, 1),
                         "us": dur[k][1] / max(dur[k][0], 1)}
         return table, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child processes) over "
-                       f"tools/group_profile.py 1 {refs} (a warm-up group + one serial group of {refs} refs: launches / 2 / {refs} = "
-                       "launches per ref), FETCH x2 x1024 and WRITE x1024 bytes per launch")
+                       f"tools/group_profile.py {groups} {refs} (a warm-up group + {groups} serial group(s) of {refs} refs: launches / "
+                       f"{(groups + 1) * refs} = launches per ref), FETCH x2 x1024 and WRITE x1024 bytes per launch")
     except Exception as e:
         return None, repr(e)[:200]
     finally:
@@ -380,12 +386,14 @@ def hbm_kernel_specs(N=64, H=640, W=640, S=3, K=192, g=1):
     }
 
 
-def hbm_kernel_table(table, refs=16, tail_group=1):
+def hbm_kernel_table(table, refs_in_pass=None, tail_group=1):
     """roofline.hbm_kernels: per kernel launches per ref, us per launch (profiled pass), measured bytes per launch (PMC),
     algorithmic bytes per launch, TB/s on both, fraction of the 8 TB/s HBM3E peak on the algorithmic bytes."""
     if table is None:
         return None
     out = {}
+    if refs_in_pass is None:
+        refs_in_pass = PMC_PASS["groups"] * PMC_PASS["refs_per_group"]
     specs = hbm_kernel_specs(g=tail_group)
     for k, (alg, what) in specs.items():
         ks = [t for t in table if t == k or t.startswith(k + "<")]
@@ -396,11 +404,11 @@ def hbm_kernel_table(table, refs=16, tail_group=1):
         meas = sum(table[t]["launches"] * (table[t]["fetch_bytes"] + table[t]["write_bytes"]) for t in ks) / n
         if alg is None:
             alg = meas
-        out[k] = {"launches_per_ref": n / 2.0 / refs, "us_per_launch": us, "measured_bytes_per_launch": meas,
+        out[k] = {"launches_per_ref": n / float(refs_in_pass), "us_per_launch": us, "measured_bytes_per_launch": meas,
                   "algorithmic_bytes_per_launch": alg, "algorithmic_bytes": what,
                   "TBps_measured": meas / us / 1e6 if us > 0 else None, "TBps_algorithmic": alg / us / 1e6 if us > 0 else None,
                   "frac_of_hbm_peak": alg / us / 1e6 / PEAK_HBM_TBPS if us > 0 else None,
-                  "ms_per_ref": n / 2.0 / refs * us / 1e3}
+                  "ms_per_ref": n / float(refs_in_pass) * us / 1e3}
     if out:
         out["_sum_ms_per_ref"] = sum(v["ms_per_ref"] for v in out.values() if isinstance(v, dict))
         out["_note"] = ("bound: hbm; peak 8 TB/s (MI355X_MICROARCH.md; 6.3 TB/s is what a streaming copy reaches).  us_per_launch comes from "
@@ -498,7 +506,10 @@ def evaluator_from_disk(args, model, gen, gem_model, dev, group, n_images=208, k
         })
         # the same evaluator as EIGHT ranks sharing this GPU (tools/evaluator_ranks.py: python -m hybridgl_amd.main --real x 8, gloo,
         # 32 cores each): a separate tool run (8 model sets, ~45 s), REPLAYED here from the tracked file of the last evidence pass
-        for tag in ("r04i", "r04h", "r04f", "r04a"):
+        import glob as _glob
+        tags = sorted({os.path.basename(f).split("_evaluator_8ranks_gloo.json")[0]
+                       for f in _glob.glob(os.path.join(ROOT, "profiles", "r*_evaluator_8ranks_gloo.json"))}, reverse=True)
+        for tag in tags:      # the newest evidence pass that has both files (tags sort by round, then by letter)
             p8 = os.path.join(ROOT, "profiles", f"{tag}_evaluator_8ranks_gloo.json")
             p1 = os.path.join(ROOT, "profiles", f"{tag}_evaluator_1rank.json")
             if os.path.exists(p8) and os.path.exists(p1):
@@ -554,6 +565,8 @@ def main():
                          "seeded proposal-shaped masks (no count read-back)")
     ap.add_argument("--scope", default="B", choices=["A", "B"],
                     help="A: proposals given (CLIP + scoring only); B: + SAM ViT-H proposal stage (full path)")
+    ap.add_argument("--no-balance", action="store_true", help="full groups of --sam-batch and a remainder instead of equally full groups (A/B)")
+    ap.add_argument("--no-prepare", action="store_true", help="skip HybridGLPipeline.prepare before the warm-up (A/B of the first-use cost)")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the short secondary timings (seeded masks, L2G, G2L&L2G, strict fp32, ViT-L/14, PhraseCut) that are "
                          "attached under the `also` key at N = 1")
@@ -656,9 +669,19 @@ def main():
                 p.step(pool[i % len(pool)])
             return
         n = p.run((pool[i % len(pool)] for i in range(k)), group=group or nbatch, proposal_cap=cap if p.use_sam_masks else None,
-                  serial=args.no_overlap)
+                  serial=args.no_overlap, total=None if args.no_balance else k)
         assert n == k, f"{k - n} refs were skipped (no proposals)"
 
+    prepared = None
+    if nbatch >= 2 and not args.no_prepare:
+        # the product's own set-up call (HybridGLPipeline.prepare: workspaces, allocator blocks and kernel instantiations
+        # of the group sizes the loop will meet), part of building the pipeline like loading the weights: the length of the
+        # warm-up then decides nothing
+        t_p = time.perf_counter()
+        g_timed = nbatch if args.no_balance else HybridGLPipeline.balanced_group(args.steps, nbatch)
+        pipe.prepare(group=g_timed, H=640, W=640, proposals=args.masks, n_sent=3,
+                     tail=HybridGLPipeline.balanced_group(max(args.warmup, 1), nbatch), serial=args.no_overlap)
+        prepared = {"group": g_timed, "seconds": time.perf_counter() - t_p}
     do_steps(args.warmup)
     torch.cuda.synchronize()
     # the metric rows of the report are those of the timed steps only
@@ -666,12 +689,27 @@ def main():
     ops.split_overflow_count(reset=True)
     barrier()
     torch.cuda.synchronize()
+    # diagnostics of the timed region that cost nothing inside it: the allocator's device-malloc counter before / after, a
+    # host-side stamp per group boundary (HybridGLPipeline.group_marks) and the host time at which the last launch was enqueued
+    mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+    pipe.group_marks = []
+    pipe.stage_marks = []
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
     t0 = time.perf_counter()
     do_steps(args.steps)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    timed_region = {"seconds": dt, "host_enqueue_seconds": t_enq,
+                    "group_start_ms": [round((g - t0) * 1e3, 2) for g in pipe.group_marks],
+                    "device_mallocs": torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mallocs0,
+                    "reserved_GiB": round(torch.cuda.memory_reserved(dev) / 2**30, 2),
+                    # (stage, group, device ms, host ms): the proposal stage of group g+1 should lie beside the CLIP stage of group g
+                    "stages": pipe.stage_timeline(ev0, t0)}
+    pipe.group_marks = pipe.stage_marks = None
     rows = pipe.partial_rows()
     # fp16 range guard of the f16x3 mode (ops.check_split_overflow): GPU threads that met |x| > 65504 in the timed steps
     overflow = ops.split_overflow_count(reset=True)
@@ -811,16 +849,20 @@ def main():
                "achieved": 512 * 3.62e9 / (dec_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
                "frac_of_fp16_mfma_peak": 512 * 3.62e9 / (dec_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
                "ms_per_image_at_8192_prompts": dec_ms * 16}
-        dpath = os.path.join(ROOT, "profiles", "decoder_traffic.json")
-        if os.path.exists(dpath):
+        # HBM bytes per prompt: the newest tracked counter pass (profiles/r*_decoder_traffic.json, tools/decoder_traffic.py)
+        import glob as _glob
+        dpaths = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_decoder_traffic.json")), reverse=True)
+        if not dpaths:
+            dec["bytes_source"] = "no profiles/r*_decoder_traffic.json in this checkout: bytes per prompt not reported"
+        else:
             try:
-                dj = json.load(open(dpath))
+                dj = json.load(open(dpaths[0]))
                 dec["bytes_per_prompt"] = dj["bytes_per_prompt"]
                 dec["TBps"] = dj["bytes_per_prompt"] * 512 / (dec_ms * 1e-3) / 1e12
                 dec["frac_of_hbm_peak"] = dec["TBps"] / PEAK_HBM_TBPS
-                dec["bytes_source"] = "profiles/decoder_traffic.json (" + dj.get("source", "") + "), replayed -- not measured in this run"
-            except Exception:
-                pass
+                dec["bytes_source"] = (f"profiles/{os.path.basename(dpaths[0])} (" + dj.get("source", "") + "), replayed -- not measured in this run")
+            except Exception as e:
+                dec["bytes_source"] = f"profiles/{os.path.basename(dpaths[0])} unreadable: {e!r}"
         also["PhraseCut"]["decoder"] = dec
         del emb_, p01_
         del gen_pc, pc_refs
@@ -896,8 +938,9 @@ def main():
                     + (f"GEM heat-map stage ({args.clip} at 448x448, self-self attention in the last 6 blocks, once "
                        "per image; 3 prompts -> 3 maps, antialiased resize to the image) + " if use_gem else "heat-maps given + ")
                     + "scoring tail + IoU"
-                    + (f"; timed through HybridGLPipeline.run (the evaluator's loop, hybridgl_amd/main.py) in groups of {nbatch} "
-                       "images: one SAM encoder pass over the images of group g+1 beside one text-encoder batch, one GEM tower "
+                    + (f"; timed through HybridGLPipeline.run (the evaluator's loop, hybridgl_amd/main.py) in groups of at most {nbatch} "
+                       f"images, equally full ({args.steps} refs = {-(-args.steps // HybridGLPipeline.balanced_group(args.steps, nbatch))} x "
+                       f"{HybridGLPipeline.balanced_group(args.steps, nbatch)}): one SAM encoder pass over the images of group g+1 beside one text-encoder batch, one GEM tower "
                        "pass and one hybrid forward over the proposals of group g; pipeline fill and drain are inside the timed "
                        "region" if nbatch >= 2 else "; ref by ref (HybridGLPipeline.step)"))
         rec = {
@@ -924,8 +967,10 @@ def main():
                 "proposals_from": args.proposals_from if args.scope == "B" else "given",
                 "heatmap": args.heatmap,
                 "stage_overlap": bool(gen is not None and not args.no_overlap and nbatch >= 2),
-                "sam_images_per_encoder_pass": nbatch,
-                "refs_per_clip_forward": nbatch,
+                "sam_images_per_encoder_pass": HybridGLPipeline.balanced_group(args.steps, nbatch) if nbatch >= 2 else 1,
+                "refs_per_clip_forward": HybridGLPipeline.balanced_group(args.steps, nbatch) if nbatch >= 2 else 1,
+                "group_max": nbatch,
+                "prepared": prepared,
                 "host_syncs_per_group": (2 if dependent else 0) if nbatch >= 2 else None,
                 "clip": args.clip,
                 "fusion_mode": args.fusion, "proposals": args.masks, "image": "640x640", "queries": 3,
@@ -938,6 +983,7 @@ def main():
             "precision": precision,
             "split_overflow_count": overflow,
             "metrics": m,
+            "timed_region": timed_region,
         }
         rec["roofline"]["traffic_source"] = traffic_src
         if pmc_table is not None:

@@ -2,6 +2,14 @@
 #include "hgl_common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+
+// the ONLY reads of the environment in the library (see hgl_common.h for the list of switches)
+const char* hgl_env_str(const char* name) { return getenv(name); }
+int hgl_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 
 static thread_local char g_err[512] = "";
 

@@ -1723,15 +1723,15 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
                     4.0 * a.B * a.H * HD * (2.0 * a.Sq + 2.0 * a.Sk), st);
   if (hgl_precision() == HGL_PREC_F16X3) {
     // sequences of 129..256 queries (a 14 x 14 window, a 197-token CLIP sequence): one 8-wave workgroup per (batch, head)
-    static const int wide = getenv("HGL_ATTN_WIDE") ? atoi(getenv("HGL_ATTN_WIDE")) : 1;
-    static const int dual = getenv("HGL_ATTN_DUAL") ? atoi(getenv("HGL_ATTN_DUAL")) : 1;
+    static const int wide = HGL_DIAG_SWITCH("HGL_ATTN_WIDE", 1);
+    static const int dual = HGL_DIAG_SWITCH("HGL_ATTN_DUAL", 1);
     // (longer sequences measured neutral for 785 queries, slower for the 4096-query global blocks: two independent
     // 4-wave workgroups per CU interleave their phases, one 8-wave workgroup meets at every barrier)
     // the persistent kernel parks the CLS-keep row of an item in a 256-byte LDS tail: keys beyond 257 do not fit there
     const bool w8 = wide && HD >= 64 && a.Sq > 128 && a.Sq <= 256 && a.mask_kind != HGL_MASK_CAUSAL &&
                     (a.mask_kind != HGL_MASK_CLS_KEEP || a.Sk <= 257);
     // long unmasked sequences (SAM's global blocks, GEM's 785 tokens): the ping-pong kernel, one 8-wave workgroup per 256 queries
-    static const int pp = getenv("HGL_ATTN_PP") ? atoi(getenv("HGL_ATTN_PP")) : 1;
+    static const int pp = hgl_env_int("HGL_ATTN_PP", 1);
     if constexpr (HD == 64 || HD == 80) {
       // (measured, tools/attn_pp_ab.py: 4096 x 4096 x 80 with rel-pos 1690 against 1745 us; 785- and 1000-token sequences
       // 15-25 % SLOWER than two 4-wave workgroups per CU -- few query blocks per head, and the co-execution the schedule
@@ -1771,8 +1771,8 @@ int launch_hd(const AttnArgs& a, hipStream_t st) {
 int hgl_launch_attention_win14(const float* q, const float* k, const float* v, void* out_hi, void* out_lo, int B, int H, int hd,
                                int ldq, int ldk, int ldv, int ldo, long long sqb, long long skb, long long svb, long long sob,
                                float scale, const float* Rh, const float* Rw, hipStream_t st) {
-  static const int wide = getenv("HGL_ATTN_WIDE") ? atoi(getenv("HGL_ATTN_WIDE")) : 1;
-  static const int fused = getenv("HGL_ATTN_RELPOS_FUSED") ? atoi(getenv("HGL_ATTN_RELPOS_FUSED")) : 1;
+  static const int wide = HGL_DIAG_SWITCH("HGL_ATTN_WIDE", 1);
+  static const int fused = HGL_DIAG_SWITCH("HGL_ATTN_RELPOS_FUSED", 1);
   if (!wide || !fused || hd != 80 || hgl_precision() != HGL_PREC_F16X3 || !out_hi || !out_lo || !Rh || !Rw) return 1;
   HGL_REQUIRE(q && k && v && B > 0 && H > 0 && (long long)B * H <= 65535, "attention_win14: bad arguments");
   AttnArgs a;

@@ -55,8 +55,15 @@ struct PsArgs {
   int kh, kw;
   const _Float16 *tabh_hi, *tabh_lo, *tabw_hi, *tabw_lo;   // PS_WIN14: the [27, 80] tables split once per model (scale 2^0)
   int nqb;                      // workgroups (blocks of 128 * QT queries) per item
-  int dbg;                      // HGL_ATTN_PS_DBG: timing experiments only (bit 0: no QK^T products, 1: no P V products, 2: no K / V requests, 3: no stores, 4: no rel-pos prologue)
+  int dbg;                      // diagnostic build only (HGL_ATTN_PS_DBG; bit 0: no QK^T products, 1: no P V products, 2: no K / V requests, 3: no stores, 4: no rel-pos prologue)
 };
+// The knock-outs for timing experiments are compiled into the diagnostic twin only (make diag): in the product PS_DBG is the
+// constant 0, the kernels carry no such branch and no environment variable can make them skip work.
+#ifdef HGL_DIAG
+#define PS_DBG(a) ((a).dbg)
+#else
+#define PS_DBG(a) 0
+#endif
 
 // ds_read_b64_tr_b16 (EXEC must be all ones at the call)
 __device__ __forceinline__ h16x4 ps_tr4(const _Float16* p) {
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
   const int b = item / a.H, hh = item - b * a.H;
   kv_base = (const char*)a.hi + ((long long)b * a.sb * (long long)a.ld + a.kcol + hh * HD) * 2;
   if (L != blockIdx.x) __syncthreads();   // every wave has left the previous unit: its V stage and the rel-pos patches are free
-  if (!(a.dbg & 4)) {
+  if (!(PS_DBG(a) & 4)) {
   issue_k(0);
   issue_v(0);
   if (nchunk > 1) issue_k(1);
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int j = 0; j < 8; ++j) xs[c][j] = 0.f;
-    if (wave_active && !(a.dbg & 16)) {
+    if (wave_active && !(PS_DBG(a) & 16)) {
       float* const P0 = (float*)(ps_smem + (wave < 2 ? G::K_RING + 2 * G::KSTAGE : G::V_RING + G::VSTAGE)) + (wave & 1) * 32 * 32;
       const int qq = qvalid[0] ? qi[0] : 0;
       const int qy = qq / 14, qx = qq - qy * 14;
@@ -734,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
       }
       __syncthreads();
     }
-    if (!(a.dbg & 4)) {
+    if (!(PS_DBG(a) & 4)) {
     if (ci + 2 < nchunk) issue_k(ci + 2);
     if (ci + 1 < nchunk) issue_v(ci + 1);
     }
@@ -879,7 +886,7 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
       }
       if (MODE == PS_RELT && ci + 2 < nchunk) rel_prefetch(kbase + 64);   // the terms of tile ci + 2 travel under P V
       // ---- segment B: O^T += V^T P^T ----
-      if (!(a.dbg & 2)) {
+      if (!(PS_DBG(a) & 2)) {
         const _Float16* Vh = (const _Float16*)(ps_smem + G::V_RING + (ci & 1) * G::VSTAGE);
         const _Float16* Vl = (const _Float16*)(ps_smem + G::V_RING + (ci & 1) * G::VSTAGE + G::VL_OFF);
 #pragma unroll
@@ -903,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, QT - 1>;
-    const bool chain = !(a.dbg & 1);
+    const bool chain = !(PS_DBG(a) & 1);
     if constexpr (QT == 2) {
       // tile 0 beside the chain of tile 1 on THIS chunk; tile 1 beside the chain of tile 0 on the next.  (A wave whose second
       // tile lies beyond the sequence -- the last wave of a 197-token item -- computes it on zero queries and stores nothing:
@@ -919,7 +926,7 @@ __global__ __launch_bounds__(256, 2) void attn_psp_kernel(PsArgs a, const unsign
   for (int qt = 0; qt < QT; ++qt) {
   const float l_tot = ps_add_halves(l_run[qt]);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (tile_active[qt] && !(a.dbg & 8)) {
+  if (tile_active[qt] && !(PS_DBG(a) & 8)) {
     // Write-out.  A lane holds, per accumulator group g, four consecutive d of ITS query row (8 bytes as fp16); the two lanes
     // of a row hold alternating groups.  Stored as they lie that is 20 instructions of 8 bytes per lane, each to 32 different
     // rows -- and a store instruction whose adjacent lanes are not contiguous costs ~280 cycles of issue (knock-out timing:
@@ -1012,7 +1019,7 @@ int psp_launch(const PsArgs& a, hipStream_t st) {
     hipDeviceProp_t prop;
     ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  static const int persist = getenv("HGL_ATTN_PS_PERSIST") ? atoi(getenv("HGL_ATTN_PS_PERSIST")) : 2;
+  static const int persist = HGL_DIAG_SWITCH("HGL_ATTN_PS_PERSIST", 2);
   long long wgs = (long long)a.B * a.H * a.nqb;
   if (persist > 0) {
     const long long cap = ((long long)persist * ncu[dev]) & ~7ll;
@@ -1033,9 +1040,9 @@ int ps_launch(const PsArgs& a, hipStream_t st) {
 
 }  // namespace
 
-static int g_attn_ps = -1;   // -1: read HGL_ATTN_PS on first use (default on)
+static int g_attn_ps = -1;   // -1: default (on) at first use
 static int attn_ps_flag() {
-  if (g_attn_ps < 0) { const char* v = getenv("HGL_ATTN_PS"); g_attn_ps = v ? (atoi(v) != 0) : 1; }
+  if (g_attn_ps < 0) g_attn_ps = HGL_DIAG_SWITCH("HGL_ATTN_PS", 1) != 0;   // product: hgl_attention_presplit() is the switch
   return g_attn_ps;
 }
 #ifdef HGL_PS_STAMPS
@@ -1057,6 +1064,44 @@ extern "C" int hgl_attention_presplit(int on) {
   return prev;
 }
 
+// THE predicate of this file: does hgl_launch_attention_ps serve this call?  The callers that must decide BEFORE the
+// in-projection whether it writes split planes (sam_api.hip, clip_api.hip: afterwards there is no fp32 qkv to fall back to) ask
+// exactly what the launch asks.  plane_delta = byte distance from the hi to the lo plane; rel_kh / rel_kw != 0: rel-pos terms
+// given as tensors; tab_h / tab_w: the windowed blocks' tables.  Returns the kernel kind (> 0) or 0.
+enum { PS_K_NONE = 0, PS_K_WIN, PS_K_RELT80, PS_K_RELT64, PS_K_CLIP, PS_K_PLAIN80, PS_K_PLAIN64 };
+int hgl_attention_ps_serves(long long plane_delta, int ld, int B, int H, int S, int hd, int mask_kind, int rel_kh, int rel_kw,
+                            const float* tab_h, const float* tab_w) {
+  if (!hgl_attention_ps_enabled()) return PS_K_NONE;
+  if (!(hd == 80 || hd == 64) || mask_kind == HGL_MASK_CAUSAL || B <= 0 || H <= 0 || S <= 0) return PS_K_NONE;
+  // the DMA addresses one item's K / V rows with a 32-bit offset from the item's base in the hi plane, lo plane included
+  const long long span = (long long)S * ld * 2 + (long long)ld * 2;
+  if (plane_delta < 0 || plane_delta + span >= (1ll << 32)) return PS_K_NONE;
+  // the 197-token CLIP sequences: 1 = one workgroup per item with two query tiles per wave (K / V staged once),
+  // 2 = the pipelined persistent kernel with two workgroups per item.  (The pipelined kernel with two query tiles per wave
+  // -- attn_psp_kernel<64, PS_PLAIN, 2>, which the template still admits -- needs 256 VGPRs + 19 spilled dwords whose scratch
+  // reloads wait on vmcnt in the middle of the DMA stream: 855 us against 742 for (1) on 1024 x 12 x 197 x 64; not instantiated.)
+  static const int clip_kernel = HGL_DIAG_SWITCH("HGL_ATTN_PS_CLIP", 1);
+  if (tab_h || tab_w) {
+    const void *hh = nullptr, *hl = nullptr;
+    int sh = 1, n1 = 0, k1 = 0;
+    if (tab_h && tab_w && hd == 80 && S == 196 && mask_kind == HGL_MASK_NONE && !rel_kh &&
+        hgl_get_split_weight(tab_h, &hh, &hl, &sh, &n1, &k1) && sh == 0 && n1 == 27 && k1 == 80 &&
+        hgl_get_split_weight(tab_w, &hh, &hl, &sh, &n1, &k1) && sh == 0 && n1 == 27 && k1 == 80)
+      return PS_K_WIN;
+    return PS_K_NONE;
+  }
+  if (rel_kh || rel_kw) {
+    // 32-bit element offsets into the rel-pos tensors
+    if (mask_kind == HGL_MASK_NONE && (rel_kw & 31) == 0 && (S & 31) == 0 && rel_kh * rel_kw == S &&
+        (long long)B * H * S * (long long)(rel_kh > rel_kw ? rel_kh : rel_kw) < (1ll << 32))
+      return hd == 80 ? PS_K_RELT80 : PS_K_RELT64;
+    return PS_K_NONE;
+  }
+  if (hd == 64 && S > 128 && S <= 256 && clip_kernel == 1 && (mask_kind != HGL_MASK_CLS_KEEP || S <= 257)) return PS_K_CLIP;
+  if (mask_kind == HGL_MASK_NONE || (mask_kind == HGL_MASK_CLS_KEEP && S <= 257)) return hd == 80 ? PS_K_PLAIN80 : PS_K_PLAIN64;
+  return PS_K_NONE;
+}
+
 // Attention on the split qkv planes.  Returns 1 ("not applicable": the caller takes the fp32-input path) when the shape is
 // not one this kernel serves, 0 on success, < 0 on error.
 //   qkv_hi / qkv_lo : fp16 planes, row (b * sb + s), columns qcol / kcol / vcol + head * hd, leading dimension ld (halfs)
@@ -1066,8 +1111,9 @@ int hgl_launch_attention_ps(const void* qkv_hi, const void* qkv_lo, int ld, int 
                             int H, int S, int hd, float* out, void* out_hi, void* out_lo, int ldo, long long sob, float scale,
                             int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, const float* rel_h, const float* rel_w,
                             int kh, int kw, const float* tab_h, const float* tab_w, hipStream_t st) {
-  if (!hgl_attention_ps_enabled()) return 1;
-  if (!(hd == 80 || hd == 64) || mask_kind == HGL_MASK_CAUSAL) return 1;
+  const long long delta = (const char*)qkv_lo - (const char*)qkv_hi;
+  const int kind = hgl_attention_ps_serves(delta, ld, B, H, S, hd, mask_kind, rel_h ? kh : 0, rel_h ? kw : 0, tab_h, tab_w);
+  if (kind == PS_K_NONE) return 1;
   HGL_REQUIRE(qkv_hi && qkv_lo && (out || (out_hi && out_lo)) && B > 0 && H > 0 && S > 0, "attention_ps: bad arguments");
   HGL_REQUIRE((ld & 7) == 0 && (qcol & 7) == 0 && (kcol & 7) == 0 && (vcol & 7) == 0 && (ldo & 3) == 0 && (sob & 3) == 0 &&
                   (((uintptr_t)qkv_hi | (uintptr_t)qkv_lo | (uintptr_t)out | (uintptr_t)out_hi | (uintptr_t)out_lo) & 15) == 0,
@@ -1075,10 +1121,6 @@ int hgl_launch_attention_ps(const void* qkv_hi, const void* qkv_lo, int ld, int 
   HGL_REQUIRE(mask_kind != HGL_MASK_CLS_KEEP || keep, "attention_ps: HGL_MASK_CLS_KEEP needs keep bytes");
   HGL_REQUIRE(vcol >= kcol, "attention_ps: the V columns must not lie before the K columns (32-bit offsets from the K base)");
   HGL_REQUIRE((rel_h == nullptr) == (rel_w == nullptr) && (tab_h == nullptr) == (tab_w == nullptr), "attention_ps: rel-pos operands go in pairs");
-  // the DMA addresses one item's K / V rows with a 32-bit offset from the item's base in the hi plane, lo plane included
-  const long long delta = (const char*)qkv_lo - (const char*)qkv_hi;
-  const long long span = (long long)S * ld * 2 + (long long)ld * 2;
-  if (delta < 0 || delta + span >= (1ll << 32)) return 1;
   PsArgs a;
   a.hi = (const _Float16*)qkv_hi; a.lo = (const _Float16*)qkv_lo;
   a.ld = ld; a.qcol = qcol; a.kcol = kcol; a.vcol = vcol; a.sb = sb;
@@ -1088,46 +1130,26 @@ int hgl_launch_attention_ps(const void* qkv_hi, const void* qkv_lo, int ld, int 
   a.rel_h = rel_h; a.rel_w = rel_w; a.kh = kh; a.kw = kw;
   a.tabh_hi = a.tabh_lo = a.tabw_hi = a.tabw_lo = nullptr;
   a.nqb = 1;
-  static const int dbg = getenv("HGL_ATTN_PS_DBG") ? atoi(getenv("HGL_ATTN_PS_DBG")) : 0;
-  a.dbg = dbg;
-  // the 197-token CLIP sequences: 1 = one workgroup per item with two query tiles per wave (K / V staged once),
-  // 2 = the pipelined persistent kernel with two workgroups per item.  (The pipelined kernel with two query tiles per wave
-  // -- attn_psp_kernel<64, PS_PLAIN, 2>, which the template still admits -- needs 256 VGPRs + 19 spilled dwords whose scratch
-  // reloads wait on vmcnt in the middle of the DMA stream: 855 us against 742 for (1) on 1024 x 12 x 197 x 64; not instantiated.)
-  static const int clip_kernel = getenv("HGL_ATTN_PS_CLIP") ? atoi(getenv("HGL_ATTN_PS_CLIP")) : 1;
-  enum { K_NONE, K_WIN, K_RELT80, K_RELT64, K_CLIP, K_PLAIN80, K_PLAIN64 } kind = K_NONE;
-  if (tab_h) {
+  a.dbg = HGL_DIAG_SWITCH("HGL_ATTN_PS_DBG", 0);
+  if (kind == PS_K_WIN) {
     const void *hh = nullptr, *hl = nullptr, *wh = nullptr, *wl = nullptr;
     int sh = 1, sw = 1, n1 = 0, k1 = 0, n2 = 0, k2 = 0;
-    if (hd == 80 && S == 196 && mask_kind == HGL_MASK_NONE && !rel_h && hgl_get_split_weight(tab_h, &hh, &hl, &sh, &n1, &k1) &&
-        hgl_get_split_weight(tab_w, &wh, &wl, &sw, &n2, &k2) && sh == 0 && sw == 0 && n1 == 27 && n2 == 27 && k1 == 80 && k2 == 80) {
-      a.tabh_hi = (const _Float16*)hh; a.tabh_lo = (const _Float16*)hl;
-      a.tabw_hi = (const _Float16*)wh; a.tabw_lo = (const _Float16*)wl;
-      a.nqb = 2;
-      kind = K_WIN;
-    }
-  } else if (rel_h) {
-    // 32-bit element offsets into the rel-pos tensors
-    if (mask_kind == HGL_MASK_NONE && (kw & 31) == 0 && (S & 31) == 0 && kh * kw == S &&
-        (long long)B * H * S * (long long)(kh > kw ? kh : kw) < (1ll << 32)) {
-      a.nqb = (S + 127) / 128;
-      kind = hd == 80 ? K_RELT80 : K_RELT64;
-    }
-  } else if (hd == 64 && S > 128 && S <= 256 && clip_kernel == 1) {
-    kind = K_CLIP;    // one 4-wave workgroup per item, two query tiles per wave
-  } else if (mask_kind == HGL_MASK_NONE || (mask_kind == HGL_MASK_CLS_KEEP && S <= 257)) {
+    (void)hgl_get_split_weight(tab_h, &hh, &hl, &sh, &n1, &k1);
+    (void)hgl_get_split_weight(tab_w, &wh, &wl, &sw, &n2, &k2);
+    a.tabh_hi = (const _Float16*)hh; a.tabh_lo = (const _Float16*)hl;
+    a.tabw_hi = (const _Float16*)wh; a.tabw_lo = (const _Float16*)wl;
+    a.nqb = 2;
+  } else if (kind != PS_K_CLIP) {
     a.nqb = (S + 127) / 128;   // blocks of 128 queries (the CLS keep row of an item sits in 256 bytes of LDS)
-    kind = hd == 80 ? K_PLAIN80 : K_PLAIN64;
   }
-  if (kind == K_NONE) return 1;
   HglProfScope prof(HGL_PROF_ATTN, 4.0 * B * H * (double)S * S * hd, 0.0, st);
   switch (kind) {
-    case K_WIN: return psp_launch<80, PS_WIN14>(a, st);
-    case K_RELT80: return psp_launch<80, PS_RELT>(a, st);
-    case K_RELT64: return psp_launch<64, PS_RELT>(a, st);
-    case K_PLAIN80: return psp_launch<80, PS_PLAIN>(a, st);
-    case K_PLAIN64: return psp_launch<64, PS_PLAIN>(a, st);
-    default: return ps_launch<64, PS_PLAIN, 2>(a, st);     // K_CLIP: the un-pipelined kernel, two query tiles per wave
+    case PS_K_WIN: return psp_launch<80, PS_WIN14>(a, st);
+    case PS_K_RELT80: return psp_launch<80, PS_RELT>(a, st);
+    case PS_K_RELT64: return psp_launch<64, PS_RELT>(a, st);
+    case PS_K_PLAIN80: return psp_launch<80, PS_PLAIN>(a, st);
+    case PS_K_PLAIN64: return psp_launch<64, PS_PLAIN>(a, st);
+    default: return ps_launch<64, PS_PLAIN, 2>(a, st);     // PS_K_CLIP: the un-pipelined kernel, two query tiles per wave
   }
 }
 

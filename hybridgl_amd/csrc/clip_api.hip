@@ -20,7 +20,7 @@ typedef HglBlockBufs BlockBufs;
 // on a side stream underneath the SAM / CLIP kernels (text encoder: 12 x 77 rows, GEM: 785 rows): measured
 // 49.05 -> 47.8 ms per benchmark step.
 bool hgl_clip_block_uses_x3(const HglResBlockW& w, int M, int D) {
-  static const int min_m = getenv("HGL_X3_MIN_M") ? atoi(getenv("HGL_X3_MIN_M")) : 512;
+  static const int min_m = HGL_DIAG_SWITCH("HGL_X3_MIN_M", 512);
   return M > min_m && hgl_use_x3(w.in_proj_w, D) && hgl_use_x3(w.out_proj_w, D) && hgl_use_x3(w.fc_w, D) &&
          hgl_use_x3(w.proj_w, 4 * D) && (D % 256) == 0;
 }
@@ -32,10 +32,9 @@ bool hgl_clip_block_uses_x3(const HglResBlockW& w, int M, int D) {
 // HGL_ATTN_PS_CLIPBLOCKS=2 routes them here as well (A/B timing, the parity test)
 bool hgl_clip_block_presplit(const HglResBlockW& w, int B, int S, int D, int heads, int mask_kind) {
   const int hd = D / heads;
-  static const int on = getenv("HGL_ATTN_PS_CLIPBLOCKS") ? atoi(getenv("HGL_ATTN_PS_CLIPBLOCKS")) : 1;   // 0: never, 2: also S <= 256
-  return on && (S > 256 || on == 2) && hgl_clip_block_uses_x3(w, B * S, D) && hgl_attention_ps_enabled() && hd == 64 && S > 128 &&
-         (mask_kind == HGL_MASK_NONE || (mask_kind == HGL_MASK_CLS_KEEP && S <= 257)) &&
-         (size_t)B * S * 3 * D * 2 + (size_t)(S + 1) * 3 * D * 2 < (1ull << 32);
+  static const int on = hgl_env_int("HGL_ATTN_PS_CLIPBLOCKS", 1);   // 0: never, 2: also S <= 256
+  return on && (S > 256 || on == 2) && hgl_clip_block_uses_x3(w, B * S, D) && hd == 64 && S > 128 &&
+         hgl_attention_ps_serves((long long)B * S * 3 * D * 2, 3 * D, B, heads, S, hd, mask_kind, 0, 0, nullptr, nullptr) != 0;
 }
 
 // first half of a block: H = ln_1(X) (fp32, or the fp16 hi+lo pair aliasing bf.H on the split path), QKV = H W_in + b
@@ -91,7 +90,7 @@ int hgl_clip_block_rest(const HglResBlockW& w, float* X, int B, int S, int D, in
                                   HGL_ACT_QUICKGELU, st));
     // mlp.c_proj with few output tiles and K = 4D (GEM at 785 rows, the text encoder, small batches): split-K over the
     // idle CUs; the partial sums borrow the qkv buffer (dead after the attention; it holds three slices)
-    static const int splitk_on = getenv("HGL_CLIP_SPLITK") ? atoi(getenv("HGL_CLIP_SPLITK")) : 1;
+    static const int splitk_on = HGL_DIAG_SWITCH("HGL_CLIP_SPLITK", 1);
     int ks = splitk_on ? hgl_gemm_f16x3_splitk_factor(M, D, 4 * D) : 1;
     if (ks > 3) ks = 3;
     if (ks > 1) {

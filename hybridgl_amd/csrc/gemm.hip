@@ -241,11 +241,10 @@ int hgl_launch_gemm(const float* A, const float* W, const float* bias, const flo
   HGL_REQUIRE(nwg < (1ll << 31), "gemm: grid too large");
   // default: single LDS buffer (36.9 KB) -> 3 workgroups per CU (3 waves/SIMD); measured on MI355X
   // 104-121 TF/s on the CLIP shapes vs 87-108 for the double-buffered 2-workgroup variant, which
-  // HGL_GEMM_VARIANT=bk32x2 keeps selectable for A/B runs.
+  // HGL_GEMM_BK32X2=1 keeps selectable in the diagnostic build (make diag).
   static int variant = -1;
   if (variant < 0) {
-    const char* v = getenv("HGL_GEMM_VARIANT");
-    variant = (v && !strcmp(v, "bk32x2")) ? 1 : 0;
+    variant = HGL_DIAG_SWITCH("HGL_GEMM_BK32X2", 0) ? 1 : 0;
   }
   HglProfScope prof(HGL_PROF_GEMM, 2.0 * M * (double)N * K * batch,
                     4.0 * batch * ((double)M * K + (double)N * K + (double)M * N * (R ? 2 : 1)), st);

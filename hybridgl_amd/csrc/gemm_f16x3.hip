@@ -72,7 +72,7 @@ struct Args {
   int vec4;    // N, ldc, ldr multiples of 4 and 16-byte aligned bases: the write-out moves 16-byte vectors
 };
 
-int g_x3_kernel = -2;   // -2: read HGL_X3_KERNEL on first use; -1: cost model; >= 0: forced
+int g_x3_kernel = -2;   // -2: not yet chosen (-> -1); -1: cost model; >= 0: forced by hgl_gemm_f16x3_select
 
 // grid of the persistent ping-pong kernel: one workgroup per CU (HGL_X3_PERSIST=0: one per tile)
 int x3_num_cus() {
@@ -88,8 +88,7 @@ int x3_num_cus() {
 long long x3p_grid(long long tiles) {
   static int persist = -1;
   if (persist < 0) {
-    const char* v = getenv("HGL_X3_PERSIST");
-    persist = v ? atoi(v) : 1;
+    persist = HGL_DIAG_SWITCH("HGL_X3_PERSIST", 1);
   }
   const int ncu = x3_num_cus();
   return persist && tiles > ncu ? ncu : tiles;
@@ -1094,13 +1093,13 @@ int launch_x3(int kind, Args& g, hipStream_t st) {
 
 // HGL_X3_TERMS=3 keeps the third product for fp16-valued weights too (A/B; the results are the same bit for bit)
 bool x3_two_terms(const SplitW& sw) {
-  const char* v = getenv("HGL_X3_TERMS");      // read per launch: tests flip it inside one process
+  const char* v = hgl_env_str("HGL_X3_TERMS");      // read per launch: tests flip it inside one process
   return sw.lo_zero && !(v && v[0] == '3');
 }
 
 int x3_gm() {
   static int gmv = -1;
-  if (gmv < 0) { const char* v = getenv("HGL_X3_GM"); gmv = v ? atoi(v) : 8; if (gmv < 1) gmv = 8; }
+  if (gmv < 0) { gmv = HGL_DIAG_SWITCH("HGL_X3_GM", 8); if (gmv < 1) gmv = 8; }
   return gmv;
 }
 
@@ -1139,7 +1138,7 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
     // XCD walks the WHOLE table (4 - 6 MB, more than its L2) once per batch and the table rows were re-fetched for every
     // tile -- as many bytes as the A operand itself (profiles/r05b_decoder_traffic.json: 18.8 MB fetched per prompt for
     // 8.4 MB of operands).  HGL_X3_RPERM=0 keeps the row order.
-    static const int rperm = getenv("HGL_X3_RPERM") ? atoi(getenv("HGL_X3_RPERM")) : 1;
+    static const int rperm = HGL_DIAG_SWITCH("HGL_X3_RPERM", 1);
     if (rperm && R && rmod > 0 && (rmod % 256) == 0 && (M % rmod) == 0 && M / rmod > 1 && !amap && !cmap) {
       g.rp_p = M / rmod;
       g.rp_t = rmod / 256;
@@ -1150,15 +1149,10 @@ int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const in
   g.lo_zero = x3_two_terms(sw) ? 1 : 0;
   g.gm = x3_gm();
   g.vec4 = x3_vec4_ok(bias, R, ldr, C, Ch, Cl, ldc, N) ? 1 : 0;
-  // kernel selection (hgl_gemm_f16x3_select / HGL_X3_KERNEL={v1,P,auto}); both tilings accumulate in the same order
+  // kernel selection (hgl_gemm_f16x3_select); both tilings accumulate in the same order
   // and give bit-identical results
   if (g_x3_kernel == -2) {
-    const char* v = getenv("HGL_X3_KERNEL");
-    g_x3_kernel = -1;
-    if (v) {
-      if (!strcmp(v, "v1")) g_x3_kernel = HGL_X3_V1;
-      else if (!strcmp(v, "P")) g_x3_kernel = HGL_X3_P;
-    }
+    g_x3_kernel = -1;      // automatic (the cost model); hgl_gemm_f16x3_select() pins a tiling
   }
   // the LDS-DMA kernel addresses the operands with 32-bit byte offsets from the plane bases and writes 16-byte vectors
   const bool small_offsets = (double)M * lda * (amap ? 4.0 : 2.0) < 4.0e9 && (double)N * K * 2.0 < 4.0e9;   // gathered rows: <= 2M

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include "../../include/hybridgl.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -106,15 +107,15 @@ int hgl_require_device();                // HGL_ENODEVICE when no GPU is visible
 // fail in the launch).  KERNEL: a parenthesised function expression; use inside a function that returns an hgl status.
 #define HGL_RESERVE_LDS(KERNEL, BYTES, WHAT)                                                                        \
   do {                                                                                                              \
-    static bool hgl_lds_set_[64] = {false};                                                                         \
+    static std::atomic<bool> hgl_lds_set_[64];       /* zero-initialised; set after the attribute call returned */       \
     int hgl_dev_ = 0;                                                                                               \
     if (hipGetDevice(&hgl_dev_) != hipSuccess || hgl_dev_ < 0 || hgl_dev_ >= 64) hgl_dev_ = 0;                      \
-    if (!hgl_lds_set_[hgl_dev_]) {                                                                                  \
+    if (!hgl_lds_set_[hgl_dev_].load(std::memory_order_acquire)) {                                                  \
       if (hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)) != hipSuccess) { \
         hgl_set_error("%s: cannot reserve %d bytes of LDS", WHAT, (int)(BYTES));                                    \
         return HGL_ELAUNCH;                                                                                         \
       }                                                                                                             \
-      hgl_lds_set_[hgl_dev_] = true;                                                                                \
+      hgl_lds_set_[hgl_dev_].store(true, std::memory_order_release);                                                \
     }                                                                                                               \
   } while (0)
 
@@ -123,6 +124,24 @@ int hgl_require_device();                // HGL_ENODEVICE when no GPU is visible
     int _rc = (expr);            \
     if (_rc != HGL_OK) return _rc; \
   } while (0)
+
+// ---- environment switches
+// The product library reads exactly four HGL_* variables, each an A/B switch between two paths that give the same bits and
+// each flipped by a -m gpu test (tests/test_abi.py checks the library's strings against this list):
+//   HGL_ATTN_PP=0            long unmasked sequences on the tile kernel instead of the ping-pong kernel
+//   HGL_X3_TERMS=3           the third split product kept for fp16-valued weights
+//   HGL_SAM_POST_SEP=0       the per-pixel post-processing kernel instead of the shared-table one
+//   HGL_ATTN_PS_CLIPBLOCKS   which CLIP residual blocks take the pre-split attention (0 never, 1 default, 2 also 197 tokens)
+// Everything else that used to be an environment variable (tile-shape experiments, knock-outs for timing) exists only in the
+// diagnostic twin `make diag` builds with -DHGL_DIAG (libhybridgl_diag.so, never loaded by the package): there
+// HGL_DIAG_SWITCH reads the variable, here it IS its default and the compiler drops the other branch.
+const char* hgl_env_str(const char* name);
+int hgl_env_int(const char* name, int dflt);
+#ifdef HGL_DIAG
+#define HGL_DIAG_SWITCH(NAME, DFLT) hgl_env_int(NAME, DFLT)
+#else
+#define HGL_DIAG_SWITCH(NAME, DFLT) (DFLT)
+#endif
 
 static inline size_t hgl_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -161,6 +180,9 @@ int hgl_launch_attention_win14(const float* q, const float* k, const float* v, v
                                float scale, const float* Rh, const float* Rw, hipStream_t st);
 // attention on the split qkv planes the in-projection GEMM emits (attention_ps.hip); returns 1 when the shape is not served
 bool hgl_attention_ps_enabled();
+// would hgl_launch_attention_ps serve this call (0 = no)?  For callers that choose the in-projection's output form first
+int hgl_attention_ps_serves(long long plane_delta, int ld, int B, int H, int S, int hd, int mask_kind, int rel_kh, int rel_kw,
+                            const float* tab_h, const float* tab_w);
 int hgl_launch_attention_ps(const void* qkv_hi, const void* qkv_lo, int ld, int qcol, int kcol, int vcol, long long sb, int B,
                             int H, int S, int hd, float* out, void* out_hi, void* out_lo, int ldo, long long sob, float scale,
                             int mask_kind, const uint8_t* keep, int keep_b0, int keep_n, const float* rel_h, const float* rel_w,

@@ -83,7 +83,7 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
   const bool x3 = hgl_use_x3(b.qkv_w, D) && hgl_use_x3(b.proj_w, D) && hgl_use_x3(b.lin1_w, D) &&
                   hgl_use_x3(b.lin2_w, 4 * D) && (D % 256) == 0;
   static int padskip = -1;   // HGL_SAM_PADSKIP=0: run the windowed GEMMs over the padded rows as well (A/B timing)
-  if (padskip < 0) { const char* v = getenv("HGL_SAM_PADSKIP"); padskip = (v && v[0] == '0') ? 0 : 1; }
+  if (padskip < 0) padskip = HGL_DIAG_SWITCH("HGL_SAM_PADSKIP", 1) ? 1 : 0;
   uint16_t* Ah = (uint16_t*)p.Hw;                   // split GEMM input (aliases the window buffer)
   uint16_t* Al = Ah + (size_t)M * D;
   uint16_t* Hh = (uint16_t*)p.H;
@@ -94,16 +94,14 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
   uint16_t* Ql = Qh + (size_t)M * 3 * D;
   // global blocks (the whole 64 x 64 grid, rel-pos terms as tensors): the same split planes, the terms from the split q
   static int ps_glob_on = -1;     // HGL_ATTN_PS_GLOBAL=0: the global blocks keep the fp32-input kernels (A/B timing)
-  if (ps_glob_on < 0) { const char* v = getenv("HGL_ATTN_PS_GLOBAL"); ps_glob_on = (v && v[0] == '0') ? 0 : 1; }
-  const bool ps_glob = x3 && ws == 0 && (hd == 80 || hd == 64) && size == 64 && ps_glob_on && hgl_attention_ps_enabled() &&
-                       (size_t)M * 3 * D * 2 + (size_t)(S + 1) * 3 * D * 2 < (1ull << 32);
-  bool ps_win = false;
-  if (x3 && ws == 14 && hd == 80 && S == 196 && hgl_attention_ps_enabled()) {
-    const void *th = nullptr, *tl = nullptr;
-    int sc = 1, n1 = 0, k1 = 0;
-    ps_win = hgl_get_split_weight(b.rel_pos_h, &th, &tl, &sc, &n1, &k1) && sc == 0 && n1 == 27 && k1 == 80 &&
-             hgl_get_split_weight(b.rel_pos_w, &th, &tl, &sc, &n1, &k1) && sc == 0 && n1 == 27 && k1 == 80;
-  }
+  if (ps_glob_on < 0) ps_glob_on = HGL_DIAG_SWITCH("HGL_ATTN_PS_GLOBAL", 1) ? 1 : 0;
+  // both decisions are hgl_attention_ps_serves' (the predicate the launch itself applies: plane distance + one item's rows
+  // within 32 bits, shapes, registered tables), taken here because the in-projection below writes split planes only
+  const long long plane_delta = (long long)M * 3 * D * 2;
+  const bool ps_glob = x3 && ws == 0 && size == 64 && ps_glob_on &&
+                       hgl_attention_ps_serves(plane_delta, 3 * D, B, heads, S, hd, HGL_MASK_NONE, size, size, nullptr, nullptr) != 0;
+  const bool ps_win = x3 && ws == 14 &&
+                      hgl_attention_ps_serves(plane_delta, 3 * D, B, heads, S, hd, HGL_MASK_NONE, 0, 0, b.rel_pos_h, b.rel_pos_w) != 0;
   if (x3) {
     if (ws > 0 && M > T && padskip) {
       // norm1 of the real tokens written straight to their rows of the padded window layout (the pad rows are never
@@ -193,7 +191,7 @@ int enc_block(const HglSamEncoderW* w, const HglSamBlockW& b, const EncPlan& p, 
 attention_done:
   if (x3) {
     static int splitk_proj = -1;   // HGL_SAM_SPLITK_PROJ=1 enables split-K for the projection too (measured neutral: K is short)
-    if (splitk_proj < 0) { const char* v = getenv("HGL_SAM_SPLITK_PROJ"); splitk_proj = (v && v[0] == '1') ? 1 : 0; }
+    if (splitk_proj < 0) splitk_proj = HGL_DIAG_SWITCH("HGL_SAM_SPLITK_PROJ", 0) ? 1 : 0;
     const int ksp = splitk_proj ? hgl_gemm_f16x3_splitk_factor(T, D, D) : 1;
     const size_t qkv_cap = (size_t)M * 3 * D * sizeof(float);     // q, k, v are dead after the attention
     const bool proj_splitk = ksp > 1 && (size_t)ksp * T * D * sizeof(float) <= qkv_cap && (ws == 0 || (M > T && padskip));
@@ -220,7 +218,7 @@ attention_done:
                                   HGL_ACT_GELU, st));
     // mlp.lin2: few output tiles, K = 4D -> split-K over the idle CUs; the partial sums borrow the qkv buffer
     static int splitk_on = -1;   // HGL_SAM_SPLITK=0 disables (A/B timing)
-    if (splitk_on < 0) { const char* v = getenv("HGL_SAM_SPLITK"); splitk_on = (v && v[0] == '0') ? 0 : 1; }
+    if (splitk_on < 0) splitk_on = HGL_DIAG_SWITCH("HGL_SAM_SPLITK", 1) ? 1 : 0;
     const int ks = splitk_on ? hgl_gemm_f16x3_splitk_factor(T, D, 4 * D) : 1;
     const size_t qkv_bytes = (size_t)M * 3 * D * sizeof(float);
     if (ks > 1 && (size_t)ks * T * D * sizeof(float) <= qkv_bytes) {
@@ -316,10 +314,10 @@ inline int lin(const float* A, int lda, const HglLinearW& l, const float* R, int
 
 // which fused decoder stages are in use (bit 0: upscaling + hyper-network products, bit 1: merged image-side projections,
 // bit 2: image -> token attention + out-projection + norm4, bit 3: unused, bit 4: chunked token -> image attention);
-// default from HGL_SAM_DEC_FUSED
+// default: all stages fused
 int g_dec_fusion = -1;
 int dec_fusion_mask() {
-  if (g_dec_fusion < 0) { const char* v = getenv("HGL_SAM_DEC_FUSED"); g_dec_fusion = v ? atoi(v) : 0x7fffffff; }
+  if (g_dec_fusion < 0) g_dec_fusion = HGL_DIAG_SWITCH("HGL_SAM_DEC_FUSED", 0x7fffffff);   // product: hgl_sam_decoder_fusion()
   return g_dec_fusion;
 }
 

@@ -1100,6 +1100,16 @@ __global__ void sam_finalize_kernel(const unsigned* __restrict__ c, const float*
   keep[k] = (pass_iou && (!(stab_thresh > 0.f) || s >= stab_thresh)) ? 1 : 0;  // NaN >= x is false
 }
 
+// The ranking order of every NMS kernel below: descending score, the original index breaks ties, and a NaN score ranks ABOVE
+// every number (where torch.sort(descending=True) -- batched_nms's argsort, automatic_mask_generator.py:251-257 -- puts it).
+// A total order: ranks by counting never collide, order[] has no holes below the number of valid candidates.  (With a plain
+// `sj > sc || (sj == sc && j < i)` two NaN scores -- an f16x3 overflow with the thresholds open -- both got rank 0.)
+__device__ __forceinline__ bool nms_before(float sj, int j, float si, int i) {
+  const bool nj = sj != sj, ni = si != si;
+  if (nj || ni) return nj && (!ni || j < i);
+  return sj > si || (sj == si && j < i);
+}
+
 // Greedy NMS in one workgroup (K <= 1024): candidates with keep[k]!=0, descending score with the
 // original index as tie-break (stable sort), suppress IoU > thr.  out_idx[0..n) in kept order.
 __global__ __launch_bounds__(1024) void nms_kernel(const int* __restrict__ boxes,
@@ -1121,7 +1131,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const int* __restrict__ boxes
     for (int j = 0; j < K; ++j) {
       if (!keep[j]) continue;
       const float sj = scores[j];
-      if (sj > sc || (sj == sc && j < t)) ++rank;
+      if (nms_before(sj, j, sc, t)) ++rank;
     }
     order[rank] = t;
   }
@@ -1166,7 +1176,7 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__
   for (int j = 0; j < K; ++j) {
     if (!keep[j]) continue;
     const float sj = scores[j];
-    rank += (sj > sc || (sj == sc && j < i)) ? 1 : 0;
+    rank += nms_before(sj, j, sc, i) ? 1 : 0;
   }
   order[rank] = i;
   atomicAdd(nvalid, 1);
@@ -1211,7 +1221,7 @@ __global__ __launch_bounds__(512) void nms_bits_kernel(const int* __restrict__ b
 #pragma unroll 8
     for (int j = 0; j < K; ++j) {
       const float sj = ssc[j];
-      rank += (skeep[j] && (sj > sc || (sj == sc && j < t))) ? 1 : 0;
+      rank += (skeep[j] && nms_before(sj, j, sc, t)) ? 1 : 0;
     }
     order[rank] = t;
     atomicAdd(&nv, 1);
@@ -1580,7 +1590,7 @@ int hgl_sam_postprocess(const float* low_res, const float* iou_pred, int K, int 
   a.K = K; a.hl = hl; a.wl = wl; a.S = img_size; a.hi = in_h; a.wi = in_w; a.H = H; a.W = W;
   a.thr = mask_threshold; a.off = stability_offset;
   a.masks = masks; a.counters = counters; a.full_logits = full_logits;
-  const char* sep_env = getenv("HGL_SAM_POST_SEP");     // "0": the per-pixel kernel (A/B in tests: bit-identical outputs)
+  const char* sep_env = hgl_env_str("HGL_SAM_POST_SEP");     // "0": the per-pixel kernel (A/B in tests: bit-identical outputs)
   const bool sep_on = !(sep_env && sep_env[0] == '0');
   const dim3 grid((W + PTW - 1) / PTW, (H + PTH - 1) / PTH, K);
   if (sep_on && postprocess_sep_fits(W, in_w, wl, img_size) && postprocess_sep_fits(H, in_h, hl, img_size))

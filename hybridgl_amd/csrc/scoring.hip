@@ -6,6 +6,7 @@
 //   synthesize_views     Hybridgl_main.py:93-125
 #include "hgl_common.h"
 #include <mutex>
+#include <condition_variable>
 #include <math.h>
 #include <string.h>
 
@@ -1252,15 +1253,86 @@ size_t grp_ws_layout(const HglGroupRef* refs, int R, int E, size_t* ref_off) {
   return o;
 }
 // pinned staging of the descriptor table: a ring of slots, a slot is reused only after the copy out of it has completed
+// Pinned staging slots of hgl_score_group's descriptor table: one ring PER DEVICE (an event belongs to the device it was
+// created on), a slot is held (busy) by one host thread from the moment it is picked until its event has been recorded behind
+// the upload, and every event call is checked -- a failed record must not leave a slot looking reusable.
 struct GrpStage {
-  static constexpr int SLOTS = 8;
-  void* buf[SLOTS] = {nullptr};
-  hipEvent_t ev[SLOTS];
-  bool used[SLOTS] = {false};
-  int next = 0;
+  static constexpr int SLOTS = 8, DEVS = 64;
+  struct Ring {
+    void* buf[SLOTS] = {nullptr};
+    hipEvent_t ev[SLOTS];
+    bool used[SLOTS] = {false};     // the event has been recorded at least once
+    bool busy[SLOTS] = {false};     // picked by a thread that has not recorded yet
+    int next = 0;
+  };
+  Ring ring[DEVS];
   std::mutex mu;
+  std::condition_variable freed;
 };
 GrpStage g_grp_stage;
+
+// picks a slot of the current device's ring (waits while all eight are held by other threads); < 0 on error
+int grp_stage_acquire(int* dev_out, void** host) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GrpStage::DEVS) {
+    hgl_set_error("score_group: cannot tell the current device");
+    return -1;
+  }
+  GrpStage::Ring& rg = g_grp_stage.ring[dev];
+  int slot = -1;
+  {
+    std::unique_lock<std::mutex> lk(g_grp_stage.mu);
+    for (;;) {
+      for (int i = 0; i < GrpStage::SLOTS && slot < 0; ++i) {
+        const int c = (rg.next + i) % GrpStage::SLOTS;
+        if (!rg.busy[c]) slot = c;
+      }
+      if (slot >= 0) break;
+      g_grp_stage.freed.wait(lk);
+    }
+    rg.busy[slot] = true;
+    rg.next = (slot + 1) % GrpStage::SLOTS;
+  }
+  bool ok = true;
+  if (!rg.buf[slot]) {       // only the holder of a busy slot touches its buffer and event
+    ok = hipHostMalloc(&rg.buf[slot], GRP_MAXR * sizeof(GroupRefDev), hipHostMallocDefault) == hipSuccess;
+    if (ok && hipEventCreateWithFlags(&rg.ev[slot], hipEventDisableTiming) != hipSuccess) {
+      (void)hipHostFree(rg.buf[slot]);
+      rg.buf[slot] = nullptr;
+      ok = false;
+    }
+    if (!ok) hgl_set_error("score_group: cannot allocate the pinned descriptor slot");
+  } else if (rg.used[slot]) {
+    ok = hipEventSynchronize(rg.ev[slot]) == hipSuccess;      // the upload that last read this slot: eight calls ago
+    if (!ok) hgl_set_error("score_group: waiting for a descriptor slot failed");
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(g_grp_stage.mu);
+    rg.busy[slot] = false;
+    g_grp_stage.freed.notify_one();
+    return -1;
+  }
+  *dev_out = dev;
+  *host = rg.buf[slot];
+  return slot;
+}
+
+// records the slot's event behind the upload on `st` and hands the slot back; false when the record failed (the caller then
+// synchronises the stream itself before the slot can be rewritten)
+bool grp_stage_release(int dev, int slot, hipStream_t st) {
+  GrpStage::Ring& rg = g_grp_stage.ring[dev];
+  bool ok = hipEventRecord(rg.ev[slot], st) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    ok = hipStreamSynchronize(st) == hipSuccess;      // no event to wait on later: make the upload complete now
+  }
+  std::lock_guard<std::mutex> lk(g_grp_stage.mu);
+  rg.used[slot] = ok ? true : rg.used[slot];     // a failed record left the earlier event (if any) in place, and the stream was drained
+  rg.busy[slot] = false;
+  g_grp_stage.freed.notify_one();
+  return ok;
+}
 }  // namespace
 
 size_t hgl_score_group_workspace_bytes(const HglGroupRef* refs, int R, int E) {
@@ -1305,23 +1377,11 @@ int hgl_score_group(const HglGroupRef* refs, int R, int E, float logit_scale, fl
     size_t ref_off[GRP_MAXR];
     grp_ws_layout(refs + r0, rc, E, ref_off);
     // the descriptor table, built in a pinned slot and copied in front of the workspace on the stream
-    GroupRefDev* host;
-    int slot;
-    {
-      std::lock_guard<std::mutex> lk(g_grp_stage.mu);
-      slot = g_grp_stage.next;
-      g_grp_stage.next = (slot + 1) % GrpStage::SLOTS;
-      if (!g_grp_stage.buf[slot]) {
-        if (hipHostMalloc(&g_grp_stage.buf[slot], GRP_MAXR * sizeof(GroupRefDev), hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&g_grp_stage.ev[slot], hipEventDisableTiming) != hipSuccess) {
-          hgl_set_error("score_group: cannot allocate the pinned descriptor slot");
-          return HGL_ELAUNCH;
-        }
-      } else if (g_grp_stage.used[slot]) {
-        (void)hipEventSynchronize(g_grp_stage.ev[slot]);      // eight calls ago: long complete
-      }
-      host = (GroupRefDev*)g_grp_stage.buf[slot];
-    }
+    void* host_v = nullptr;
+    int stage_dev = 0;
+    const int slot = grp_stage_acquire(&stage_dev, &host_v);
+    if (slot < 0) return HGL_ELAUNCH;
+    GroupRefDev* host = (GroupRefDev*)host_v;
     int maxS = 0, max_nblk = 0, max_groups = 0;
     long long max_iou_blocks = 1;
     for (int i = 0; i < rc; ++i) {
@@ -1365,14 +1425,10 @@ int hgl_score_group(const HglGroupRef* refs, int R, int E, float logit_scale, fl
     }
     GroupRefDev* tab = (GroupRefDev*)base;
     unsigned* done = (unsigned*)(base + hgl_align_up((size_t)GRP_MAXR * sizeof(GroupRefDev), 256));
-    if (hipMemcpyAsync(tab, host, (size_t)rc * sizeof(GroupRefDev), hipMemcpyHostToDevice, st) != hipSuccess) {
+    const bool uploaded = hipMemcpyAsync(tab, host, (size_t)rc * sizeof(GroupRefDev), hipMemcpyHostToDevice, st) == hipSuccess;
+    if (!grp_stage_release(stage_dev, slot, st) || !uploaded) {
       hgl_set_error("score_group: descriptor upload failed");
       return HGL_ELAUNCH;
-    }
-    {
-      std::lock_guard<std::mutex> lk(g_grp_stage.mu);
-      (void)hipEventRecord(g_grp_stage.ev[slot], st);
-      g_grp_stage.used[slot] = true;
     }
     hipLaunchKernelGGL(grp_minmax_kernel, dim3(REF_MM_BLOCKS, maxS, rc), dim3(256), 0, st, (const GroupRefDev*)tab);
     hipLaunchKernelGGL(grp_masked_pool_kernel, dim3(max_nblk, max_groups, rc * maxS), dim3(256), 0, st, (const GroupRefDev*)tab, maxS);

@@ -358,7 +358,61 @@ class HybridGLPipeline:
         if units:
             yield units
 
-    def run(self, loader, group=16, proposal_cap=None, collect=False, serial=False):
+    @staticmethod
+    def balanced_group(total, group):
+        """The group size run() uses for `total` items at most `group` at a time: the same number of groups, equally
+        full (20 refs, group 16 -> 10 + 10 instead of 16 + 4: the proposal stage of the second group then has a CLIP stage
+        of its own size beside it, and no stage meets a shape it has not seen)."""
+        total, group = int(total), max(int(group), 1)
+        if total <= group:
+            return max(total, 1)
+        n_groups = -(-total // group)
+        return -(-total // n_groups)
+
+    def prepare(self, group=16, H=640, W=640, proposals=64, n_sent=3, tail=None, serial=False):
+        """Everything run() would otherwise do on first use, done once, up front: every grow-only workspace (ops.workspace,
+        one arena per stage and stream) and every block of the caching allocator sized for a full group of `group` images
+        of H x W with up to `proposals` masks each AND for a ragged last group of `tail` images (default: a quarter of a
+        group); every kernel instantiation, LDS reservation and per-shape table of those two group sizes touched.  After
+        it, the first run() costs what the hundredth does, whatever the length of the caller's warm-up.  It runs the
+        product loop itself on seeded synthetic items (synthetic_ref), so nothing can be missed by construction; metric
+        rows, logs and the image cache are restored afterwards.  ~1 s per call at the benchmark geometry."""
+        dev = self.model.device
+        gen = self.mask_generator
+        tail = max(1, group // 4) if tail is None else int(tail)
+        use_gem = self.gem_model is not None
+        items = [synthetic_ref(90000 + j, dev, N=proposals, H=H, W=W, n_sent=n_sent, sam_img_size=1024 if gen is not None else 0,
+                               gem=use_gem, device_blur=True)[0] for j in range(min(group, 4))]
+        keep = (self.cum.clone(), list(self.iu_log), list(self.iu_owner), list(self.idx_log), self._n_refs,
+                getattr(self, "skipped", 0), getattr(self, "groups_run", 0), dict(self._img_cache), self.cache_hits,
+                (self.k1, self.k2), getattr(self, "group_marks", None), getattr(self, "stage_marks", None))
+        self.group_marks = self.stage_marks = None
+        cap = proposals if (gen is not None and self.use_sam_masks) else None
+        try:
+            # two full groups (the second one's proposal stage runs beside the first one's CLIP stage: both streams' arenas
+            # reach their steady size), then a ragged group
+            for n in (2 * group, tail):
+                self.run((items[i % len(items)] for i in range(n)), group=group, proposal_cap=cap, serial=serial)
+            if cap is not None:
+                # the generator decides how many masks the synthetic images yield; the CLIP stage is sized for the full
+                # `proposals` per image by one more pass over the items' own (seeded) masks
+                self.use_sam_masks = False
+                try:
+                    for n in (group, tail):
+                        self.run((items[i % len(items)] for i in range(n)), group=group, serial=serial)
+                finally:
+                    self.use_sam_masks = True
+            torch.cuda.synchronize(dev)
+        finally:
+            self.cum.copy_(keep[0])
+            self.iu_log[:], self.iu_owner[:], self.idx_log[:] = keep[1], keep[2], keep[3]
+            self._n_refs, self.skipped, self.groups_run = keep[4], keep[5], keep[6]
+            self._img_cache, self.cache_hits = keep[7], keep[8]
+            self.k1, self.k2 = keep[9]
+            self.group_marks, self.stage_marks = keep[10], keep[11]
+        return self
+
+    def run(self, loader, group=16, proposal_cap=None, collect=False, serial=False, total=None):
         """The loop of Hybridgl_main.py:79-230 over a whole loader, taken `group` images at a time on two streams:
 
             SAM stream   group g+1: ONE encoder pass over its images, per image decoder + post-processing + NMS, small-region
@@ -376,8 +430,11 @@ class HybridGLPipeline:
         RefBatch.masks / boxes.  Images for which the generator keeps no mask are skipped and counted (self.skipped; the
         reference would fail on them).  Returns the number of refs scored; collect=True also keeps step()'s per-ref
         return values in self.collected.  serial=True: the same work with every stage on the CURRENT stream, back to back
-        (per-kernel timing with events on one stream)."""
+        (per-kernel timing with events on one stream).  total: the number of items the loader will yield, when known -- the
+        groups are then equally full (balanced_group) instead of full groups and a remainder."""
         gen = self.mask_generator
+        if total is not None:
+            group = self.balanced_group(total, group)
         cur = torch.cuda.current_stream()
         self._serial = bool(serial)
         if serial:
@@ -396,6 +453,9 @@ class HybridGLPipeline:
         # of the image); with given proposals every item keeps its own masks / boxes, as step() does
         for units in self._units(loader, group, merge=gen is not None and self.use_sam_masks):
             self.groups_run += 1
+            if getattr(self, "group_marks", None) is not None:      # host-side stamp of every group boundary (tools/first_use.py)
+                import time
+                self.group_marks.append(time.perf_counter())
             produced = None
             if not serial:      # items a lazy loader built on the caller's stream just now
                 produced = torch.cuda.Event()
@@ -423,6 +483,7 @@ class HybridGLPipeline:
             fresh = [i for i, c in enumerate(cached) if not c]
             if gen is not None and fresh:
                 with torch.cuda.stream(s_sam):
+                    self._stage_mark("sam_begin")
                     imgs = [units[i][0].sam_img for i in fresh]
                     if self.use_sam_masks:
                         if getattr(gen, "crop_n_layers", 0) > 0:
@@ -473,6 +534,7 @@ class HybridGLPipeline:
                                for p in gen.crops_finish(gen.crops_post(stc))]
                     ready = torch.cuda.Event()
                     ready.record(s_sam)
+                    self._stage_mark("sam_end")
                 props = [None] * len(units)          # None = take it from the image cache
                 for i, pr in zip(fresh, got):
                     props[i] = pr
@@ -494,6 +556,7 @@ class HybridGLPipeline:
         cur = torch.cuda.current_stream()
         if ready is not None:
             cur.wait_event(ready)
+        self._stage_mark("clip_begin")
         gen = self.mask_generator
         live = []     # [refs of the unit, masks bool [n,H,W], boxes, hybrid features or None, GEM features or None]
         for i, refs in enumerate(units):
@@ -607,7 +670,23 @@ class HybridGLPipeline:
             for (h0, t0), o0 in zip(waiting, self._flush_tails(defer)):
                 if self.collected is not None:
                     self.collected.append((h0, t0, o0))
+        self._stage_mark("clip_end")
         return len(all_refs)
+
+    def _stage_mark(self, label, stream=None):
+        """opt-in timeline of the loop (self.stage_marks = [] before run(); bench.py's timed_region, tools/first_use.py): a
+        timing event on `stream` (default: the current one) plus the host time of the call"""
+        marks = getattr(self, "stage_marks", None)
+        if marks is None:
+            return
+        import time
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream if stream is not None else torch.cuda.current_stream())
+        marks.append((label, self.groups_run, ev, time.perf_counter()))
+
+    def stage_timeline(self, base_event, t0):
+        """[(label, group number, device ms since base_event, host ms since t0)] of the marks; call after a synchronize"""
+        return [(lb, g, round(base_event.elapsed_time(ev), 2), round((th - t0) * 1e3, 2)) for lb, g, ev, th in (self.stage_marks or [])]
 
     def _cache_put(self, image_id, entry):
         """most recently used last; the oldest entry leaves when the cache is full"""

@@ -313,9 +313,12 @@ def box_iou(a, b):
 
 
 def nms(boxes, scores, thr):
-    """torchvision.ops.nms: greedy, descending score (stable order), suppress IoU > thr."""
+    """torchvision.ops.nms: greedy, descending score (stable order), suppress IoU > thr.  A NaN score sorts FIRST, as
+    torch.sort(descending=True) places it (the order nms takes: scores.sort(0, descending=True))."""
     boxes = boxes.astype(F32)
-    order = np.argsort(-scores.astype(np.float64), kind="stable")
+    sc = scores.astype(np.float64)
+    nan = np.isnan(sc)
+    order = np.lexsort((-np.where(nan, 0.0, sc), ~nan))      # stable; last key first: NaNs, then descending score
     keep = []
     alive = np.ones(len(boxes), bool)
     with np.errstate(divide="ignore", invalid="ignore"):

@@ -104,6 +104,67 @@ def clip_hybrid_forward(sd, local_imgs, global_imgs, pred_masks, masking_block=N
     return x
 
 
+# ----------------------------------------------------------------------------- GEM (gem_torch 1.0.1, restated in gem_oracle.py)
+def _ss_attention(x, sd, p, heads):
+    """gem SelfSelfAttention.forward on x = ln_1(tokens) [B, S, D] -> (x_gem, x_ori) after the out-projection
+    (oracle/gem_oracle.py self_self_attention: ss_attn_iter = 1, temperature from the mean token norm)."""
+    B, S_, D = x.shape
+    hd = D // heads
+    scale = hd ** -0.5
+    qkv = F.linear(x, sd[f"{p}.attn.in_proj_weight"], sd[f"{p}.attn.in_proj_bias"])
+    q, k, v = (t.reshape(B, S_, heads, hd).transpose(1, 2) for t in qkv.split(D, dim=-1))
+    out = lambda t: F.linear(t.transpose(1, 2).reshape(B, S_, D), sd[f"{p}.attn.out_proj.weight"], sd[f"{p}.attn.out_proj.bias"])
+    x_ori = out(torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1) @ v)
+    inv_temp = (x.norm(dim=-1).mean(dim=-1) * scale).reshape(B, 1, 1, 1)
+    acc = 0
+    for xs in (v, k, q):
+        xs = F.normalize(xs, dim=-1)
+        xs = torch.softmax((xs @ xs.transpose(-1, -2)) * inv_temp, dim=-1) @ xs
+        xs = F.normalize(xs, dim=-1)
+        acc = acc + torch.softmax((xs @ xs.transpose(-1, -2)) * inv_temp, dim=-1) @ v
+    return out(acc / 3), x_ori
+
+
+def gem_vit_forward(sd, imgs, pos, gem_depth=7, heads=None):
+    """GEMViT.forward (gem_oracle.gem_vit_forward): imgs [B, 3, R, R] torch, pos = the position embedding already interpolated to
+    the (R / patch)^2 grid (gem_oracle.interpolate_pos_encoding: a table computed once per resolution) -> feat_gem [B, S, E]."""
+    w = sd["visual.conv1.weight"]
+    D = w.shape[0]
+    heads = heads or D // 64
+    layers = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    x = vit_embed(dict(sd, **{"visual.positional_embedding": pos}), imgs)
+    n_gem = max(0, min(layers, gem_depth - 1))
+    x_gem = None
+    for i in range(layers):
+        p = f"visual.transformer.resblocks.{i}"
+        if i < layers - n_gem:
+            x = resblock(x, sd, p, heads)
+            continue
+        if x_gem is None:
+            x_gem = x
+        r_gem, r_ori = _ss_attention(F.layer_norm(x, (D,), sd[f"{p}.ln_1.weight"], sd[f"{p}.ln_1.bias"], 1e-5), sd, p, heads)
+        x = x + r_ori
+        h = F.layer_norm(x, (D,), sd[f"{p}.ln_2.weight"], sd[f"{p}.ln_2.bias"], 1e-5)
+        h = F.linear(h, sd[f"{p}.mlp.c_fc.weight"], sd[f"{p}.mlp.c_fc.bias"])
+        x = x + F.linear(h * torch.sigmoid(1.702 * h), sd[f"{p}.mlp.c_proj.weight"], sd[f"{p}.mlp.c_proj.bias"])
+        x_gem = x_gem + r_gem
+    if x_gem is None:
+        x_gem = x
+    return F.layer_norm(x_gem, (D,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"], 1e-5) @ sd["visual.proj"]
+
+
+def gem_heatmap(feat, text, res):
+    """GEMWrapper.forward after the encoders (gem_oracle.gem_heatmap): feat [S, E] (row 0 = CLS), text [T, E] -> [T, res, res]."""
+    f = F.normalize(feat[1:], dim=-1)
+    t = F.normalize(text, dim=-1)
+    g = int(round(math.sqrt(f.shape[0])))
+    m = (100.0 * (f @ t.T)).T.reshape(1, -1, g, g)
+    up = F.interpolate(m, size=(res, res), mode="bilinear", align_corners=False)[0]
+    mn = up.flatten(1).min(dim=1)[0][:, None, None]
+    mx = up.flatten(1).max(dim=1)[0][:, None, None]
+    return (up - mn) / (mx - mn)
+
+
 def encode_text(sd, tokens):
     """CLIP.encode_text (clip/model.py:414-431), causal mask of :396-402.  tokens [B,77] int -> [B, embed]."""
     tokens = torch.as_tensor(np.asarray(tokens)).long()

@@ -280,6 +280,36 @@ def test_nms_vs_oracle(cuda):
         assert got.tolist() == ref.tolist()
 
 
+def test_nms_with_nan_scores(cuda):
+    """Several NaN scores among the valid candidates (an f16x3 overflow with the filters open): every kernel ranks them as
+    torch.sort(descending=True) does -- first, by index -- so the ranks never collide, no index is negative and the kept
+    list is the oracle's.  K = 192 / 512: bit-matrix kernel; 700: serial kernel; 1500: the any-K path."""
+    rng = np.random.default_rng(12)
+    for K in [5, 192, 512, 700, 1500]:
+        xy = rng.integers(0, 700, size=(K, 2))
+        wh = rng.integers(1, 200, size=(K, 2))
+        boxes = np.concatenate([xy, xy + wh], 1).astype(np.int32)
+        scores = rng.random(K).astype(np.float32)
+        scores[rng.choice(K, size=min(K // 2, 7), replace=False)] = np.nan
+        scores[0] = np.nan
+        keep = (rng.random(K) > 0.2).astype(np.uint8)
+        keep[0] = keep[K - 1] = 1
+        sel = np.nonzero(keep)[0]
+        ref = sel[S.nms(boxes[sel].astype(np.int64), scores[sel], 0.7)].tolist()
+        assert ref[0] == 0                                   # the first NaN leads
+        fn = hsam.nms if K <= 1024 else hsam.nms_large
+        idx, n = fn(T(boxes, cuda), T(scores, cuda), T(keep, cuda), 0.7)
+        got = idx.cpu().numpy()[: int(n.item())].tolist()
+        assert min(got) >= 0 and got == ref, K
+        if K <= 1024:
+            idx2, n2 = hsam.nms_large(T(boxes, cuda), T(scores, cuda), T(keep, cuda), 0.7)
+            assert idx2.cpu().numpy()[: int(n2.item())].tolist() == ref, K
+    # keep = 1 everywhere, all scores NaN: index order
+    boxes = np.array([[0, 0, 10, 10], [1, 1, 11, 11], [50, 50, 60, 60], [0, 0, 10, 10]], np.int32)
+    idx, n = hsam.nms(T(boxes, cuda), T(np.full(4, np.nan, np.float32), cuda), T(np.ones(4, np.uint8), cuda), 0.5)
+    assert idx.cpu().numpy()[: int(n.item())].tolist() == [0, 2]
+
+
 def test_tiny_generate_vs_reference(cuda, g, tiny):
     c = sam_tiny_case()
     gen = hsam.SamAutomaticMaskGenerator(tiny[1], points_per_side=4, pred_iou_thresh=-1e9,

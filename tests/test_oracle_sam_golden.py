@@ -174,3 +174,12 @@ def test_three_token_prompts_and_mask_inputs_vs_reference_predictor(sd, emb):
     low, iou = S.mask_decoder(sd, emb, S.embed_prompts(sd, bx, np.tile([2, 3], (4, 1)), 256), dense=dense)
     np.testing.assert_allclose(low[:, :, ::2, ::2], gp["maskin_low"], rtol=0, atol=3e-4)
     np.testing.assert_allclose(iou, gp["maskin_iou"], rtol=0, atol=1e-4)
+
+
+def test_nms_order_with_nan_scores_is_torch_sort_descending():
+    """the oracle's NMS takes candidates in the order torch.sort(descending=True) gives (torchvision.ops.nms): NaN first"""
+    import torch
+    from oracle import sam_oracle as S
+    s = np.array([0.3, np.nan, 0.9, 0.3, np.nan, np.inf, -np.inf, 0.1], np.float32)
+    far = np.array([[100 * i, 0, 100 * i + 10, 10] for i in range(len(s))], np.int64)      # nothing overlaps: kept = order
+    assert S.nms(far, s, 0.5).tolist() == torch.argsort(torch.from_numpy(s), descending=True, stable=True).tolist()

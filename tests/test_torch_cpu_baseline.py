@@ -101,3 +101,20 @@ def test_cpu_thread_calibration_walks_down_to_the_fastest_setting(monkeypatch):
     assert list(tried) == ["256", "128", "64", "32", "16", "8"] and tried["16"] == 1.0      # 8 is 1.4x the best: the walk stops
     assert seen[0] == 128 and seen[1:] == [256, 128, 64, 32, 16, 8]                           # one untimed warm-up pass first
     assert real_set is not None
+
+
+def test_gem_tower_and_heatmap_torch_cpu_equal_numpy_oracle():
+    """the GEM stage of the CPU baseline (self-self attention in the last six blocks, heat-map, min-max) against gem_oracle"""
+    from oracle import gem_oracle as GO
+    sd = weights.clip_state_dict("tiny", 0)
+    rng = np.random.default_rng(5)
+    img = rng.standard_normal((2, 3, 128, 128)).astype(np.float32)
+    txt = rng.standard_normal((3, sd["visual.proj"].shape[1])).astype(np.float32)
+    ref_feat, _ = GO.gem_vit_forward(sd, img)
+    p = sd["visual.conv1.weight"].shape[2]
+    pos = torch.from_numpy(GO.interpolate_pos_encoding(sd["visual.positional_embedding"], 128 // p, 128 // p))
+    with torch.no_grad():
+        feat = T.gem_vit_forward(T.to_torch(sd), torch.from_numpy(img), pos)
+        heat = T.gem_heatmap(feat[0], torch.from_numpy(txt), 128)
+    np.testing.assert_allclose(feat.numpy(), ref_feat, rtol=0, atol=2e-5 * max(1.0, float(np.abs(ref_feat).max())))
+    np.testing.assert_allclose(heat.numpy(), GO.gem_heatmap(ref_feat[0], txt, 128), rtol=0, atol=2e-4)

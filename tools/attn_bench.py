@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel timing of the attention shapes of the pipeline (groups of 8 refs): CLIP 197 x 64, SAM window 196 x 80 (rel-pos
-tables in the kernel), SAM global 4096 x 80, GEM 785 x 64, text (causal).  HGL_ATTN_WIDE=0 selects the 4-wave kernels."""
+tables in the kernel), SAM global 4096 x 80, GEM 785 x 64, text (causal).  HGL_ATTN_WIDE=0 (diagnostic library only) selects the 4-wave kernels."""
 import ctypes as C
 import os
 import sys

@@ -7,6 +7,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+from _diag import use_lib_from_env
+
+use_lib_from_env()      # HGL_LIB_NAME=libhybridgl_diag.so: HGL_ATTN_PS_DBG is read
 from hybridgl_amd import sam as hsam, weights
 from hybridgl_amd.synth import synth_image
 

@@ -7,7 +7,8 @@ tag=$1
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-export HGL_X3_KERNEL=P
+export X3_KERNEL=P
+export HGL_LIB_NAME=libhybridgl_diag.so     # make -C hybridgl_amd/csrc diag: HGL_X3_GM is a diagnostic switch
 out=$O/${tag}_gm_sweep.txt
 : > $out
 for shape in "201728 2304 768" "65536 5120 1280" "65536 3840 1280"; do

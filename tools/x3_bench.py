@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel-only timing of the f16x3 GEMM variants (HGL_X3_KERNEL=v1|L|M|S) on the hot-path shapes.
+"""Kernel-only timing of the f16x3 GEMM variants (X3_KERNEL=v1|P|auto) on the hot-path shapes.
 
 Uses the library's HIP-event profiler (class 3 = the f16x3 GEMM launch alone, without the A split) and checks
 every variant against the fp32-MFMA GEMM.  Run one process per variant: the choice is read once.
@@ -71,7 +71,8 @@ if os.environ.get("X3_SHAPES") == "sam2":
 def main():
     dev = torch.device("cuda:0")
     lib = _lib.load()
-    kind = os.environ.get("HGL_X3_KERNEL", "auto")
+    kind = os.environ.get("X3_KERNEL", "auto")      # v1 | P | auto, through hgl_gemm_f16x3_select
+    ops.select_x3_kernel(kind)
     tot_ms = tot_fl = 0.0
     for name, M, N, K, act, res in SHAPES:
         torch.manual_seed(0)

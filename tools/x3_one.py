@@ -7,6 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from hybridgl_amd import ops
+from _diag import use_lib_from_env
+
+use_lib_from_env()      # HGL_LIB_NAME=libhybridgl_diag.so: HGL_X3_GM and friends are read
+ops.select_x3_kernel(os.environ.get("X3_KERNEL", "auto"))
 
 M, N, K = (int(v) for v in sys.argv[1:4])
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
