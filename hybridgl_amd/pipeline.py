@@ -369,7 +369,7 @@ class HybridGLPipeline:
         n_groups = -(-total // group)
         return -(-total // n_groups)
 
-    def prepare(self, group=16, H=640, W=640, proposals=64, n_sent=3, tail=None, serial=False):
+    def prepare(self, group=16, H=640, W=640, proposals=64, n_sent=3, tail=None, serial=False, slack=1 << 30):
         """Everything run() would otherwise do on first use, done once, up front: every grow-only workspace (ops.workspace,
         one arena per stage and stream) and every block of the caching allocator sized for a full group of `group` images
         of H x W with up to `proposals` masks each AND for a ragged last group of `tail` images (default: a quarter of a
@@ -402,6 +402,17 @@ class HybridGLPipeline:
                         self.run((items[i % len(items)] for i in range(n)), group=group, serial=serial)
                 finally:
                     self.use_sam_masks = True
+            torch.cuda.synchronize(dev)
+            # The caching allocator keeps one pool per stream and the loop's tensors differ a little from group to group (the
+            # number of proposals is data): leave `slack` bytes of cached, splittable blocks behind on every stream of the loop
+            # so that a request a few MB above anything seen here is served from the pool, not by hipMalloc in the middle of a
+            # group (sized for 288 GB of HBM: 4 x 1 GiB is 1.4 % of the device)
+            if slack > 0:
+                streams = [torch.cuda.current_stream(dev)] + ([] if serial else list(self._streams()) + [self._s_text])
+                for st in streams:
+                    with torch.cuda.stream(st):
+                        blocks = [torch.empty(int(slack) // 2, dtype=torch.uint8, device=dev) for _ in range(2)]
+                        del blocks
             torch.cuda.synchronize(dev)
         finally:
             self.cum.copy_(keep[0])

@@ -20,10 +20,14 @@ def T(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-@pytest.fixture(scope="module")
-def tiny(cuda):
+from conftest import PRECISIONS  # noqa: E402
+
+
+@pytest.fixture(scope="module", params=PRECISIONS)
+def tiny(cuda, request):
+    """the tiny-geometry model in BOTH arithmetic modes: every golden / oracle test below that takes it runs twice"""
     sd = weights.clip_state_dict("tiny", 0)
-    return sd, CLIPViTFM("tiny", state_dict=sd, device=cuda)
+    return sd, CLIPViTFM("tiny", state_dict=sd, device=cuda, precision=request.param)
 
 
 @pytest.fixture(scope="module")
@@ -54,6 +58,15 @@ def test_b16_vs_reference_golden(cuda, golden_dir, b16, mode):
     loc, glo, masks = views_for_case(4, 224, H, W)
     y = _run(b16[1], loc, glo, masks, mode, cuda)
     np.testing.assert_allclose(y, g[f"N4_{mode}"], rtol=0, atol=1e-4)
+
+
+def test_b16_vs_reference_golden_f32_mode(cuda, golden_dir):
+    """ViT-B/16, G2L, against the reference's output through the exact-fp32 matrix-core path (precision='f32')"""
+    g = np.load(os.path.join(golden_dir, "clip_b16.npz"))
+    _, H, W = (int(v) for v in g["meta"])
+    loc, glo, masks = views_for_case(4, 224, H, W)
+    m = CLIPViTFM("ViT-B/16", state_dict=weights.clip_state_dict("ViT-B/16", 0), device=cuda, precision="f32")
+    np.testing.assert_allclose(_run(m, loc, glo, masks, "G2L", cuda), g["N4_G2L"], rtol=0, atol=1e-4)
 
 
 @pytest.mark.parametrize("name,last_layer,mb", [("ViT-B/32", 10, 9), ("ViT-L/14", 22, 18)])

@@ -34,13 +34,17 @@ def _ref(case, tag, g, cuda, index):
                     token_len=int(tok.argmax(axis=1).max()) + 1, index=index)
 
 
-@pytest.fixture(scope="module")
-def world(cuda, golden_dir):
+from conftest import PRECISIONS   # noqa: E402
+
+
+@pytest.fixture(scope="module", params=PRECISIONS)
+def world(cuda, golden_dir, request):
+    """CLIP tiny + SAM tiny + generator in BOTH arithmetic modes: whole refs against the reference once per mode"""
     from hybridgl_amd import sam as hsam, weights
     from hybridgl_amd.backbone import CLIPViTFM
     g = np.load(os.path.join(golden_dir, "e2e_tiny.npz"))
-    model = CLIPViTFM("tiny", state_dict=weights.clip_state_dict("tiny", 0), device=cuda)
-    sam = hsam.sam_model_registry["tiny"](device=cuda)
+    model = CLIPViTFM("tiny", state_dict=weights.clip_state_dict("tiny", 0), device=cuda, precision=request.param)
+    sam = hsam.sam_model_registry["tiny"](device=cuda, precision=request.param)
     sam.mask_threshold = float(g["mask_threshold"][0])
     pps, iou_thr, stab_thr, nms_thr, area = g["amg"]
     gen = hsam.SamAutomaticMaskGenerator(sam, points_per_side=int(pps), pred_iou_thresh=float(iou_thr),

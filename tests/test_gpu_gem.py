@@ -18,10 +18,14 @@ from oracle import gem_oracle as GO
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def tiny(cuda):
+from conftest import PRECISIONS  # noqa: E402
+
+
+@pytest.fixture(scope="module", params=PRECISIONS)
+def tiny(cuda, request):
+    """the tiny-geometry tower in BOTH arithmetic modes"""
     sd = weights.clip_state_dict("tiny", 0)
-    clip = CLIPViTFM("tiny", state_dict=sd, device=cuda)
+    clip = CLIPViTFM("tiny", state_dict=sd, device=cuda, precision=request.param)
     return sd, clip
 
 

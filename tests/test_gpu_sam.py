@@ -23,10 +23,14 @@ def g(golden_dir):
     return np.load(os.path.join(golden_dir, "sam_tiny.npz"))
 
 
-@pytest.fixture(scope="module")
-def tiny(cuda):
+from conftest import PRECISIONS  # noqa: E402
+
+
+@pytest.fixture(scope="module", params=PRECISIONS)
+def tiny(cuda, request):
+    """the tiny-geometry SAM in BOTH arithmetic modes: every test below that takes it runs twice"""
     sd = weights.sam_state_dict("tiny", 0)
-    return sd, hsam.Sam(sd, weights.SAM_CONFIGS["tiny"], cuda)
+    return sd, hsam.Sam(sd, weights.SAM_CONFIGS["tiny"], cuda, precision=request.param)
 
 
 @pytest.fixture(scope="module")

@@ -60,6 +60,16 @@ GROUP8_SHAPES = [  # the GEMMs of the grouped pipeline (8 refs per group)
     ("text qkv", 7392, 1536, 512, "none", False), ("text fc1", 7392, 2048, 512, "quickgelu", False),
     ("gem qkv", 6280, 2304, 768, "none", False), ("gem fc2", 6280, 768, 3072, "none", True),
 ]
+GROUP16_SHAPES = [  # the residual GEMMs of a group of 16 refs next to their twins WITHOUT the residual (same M, N, K)
+    ("clip out", 201728, 768, 768, "none", True), ("clip out -R", 201728, 768, 768, "none", False),
+    ("clip fc2", 201728, 768, 3072, "none", True), ("clip fc2 -R", 201728, 768, 3072, "none", False),
+    ("sam proj", 65536, 1280, 1280, "none", True), ("sam proj -R", 65536, 1280, 1280, "none", False),
+    ("sam lin2", 65536, 1280, 5120, "none", True), ("sam lin2 -R", 65536, 1280, 5120, "none", False),
+    ("clip qkv", 201728, 2304, 768, "none", False), ("clip fc1", 201728, 3072, 768, "quickgelu", False),
+    ("sam qkv", 65536, 3840, 1280, "none", False), ("sam lin1", 65536, 5120, 1280, "gelu", False),
+]
+if os.environ.get("X3_SHAPES") == "group16":
+    SHAPES = GROUP16_SHAPES
 if os.environ.get("X3_SHAPES") == "group8":
     SHAPES = GROUP8_SHAPES
 if os.environ.get("X3_SHAPES") == "gem":
@@ -101,7 +111,7 @@ def main():
         if n.value == 0:
             lib.hgl_prof_read(5, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))   # launches with < 256 tiles
         tf = fl.value / ms.value / 1e9
-        if not name.startswith(("text", "ragged", "k", "h")):
+        if not name.startswith(("text", "ragged", "k", "h")) and not name.endswith("-R"):
             tot_ms += ms.value / n.value
             tot_fl += fl.value / n.value
         print(f"x3[{kind}] {name:14s} M={M:6d} N={N:5d} K={K:5d} {ms.value / n.value * 1e3:8.1f} us {tf:7.1f} TF/s relerr {err:.1e}"
