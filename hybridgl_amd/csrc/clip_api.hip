@@ -83,8 +83,10 @@ int hgl_clip_block_rest(const HglResBlockW& w, float* X, int B, int S, int D, in
                                        3 * D, D, sQKV, sQKV, sQKV, (long long)S * D, 1.0f / sqrtf((float)hd), mask_kind, keep,
                                        keep_b0, keep_n, nullptr, nullptr, 0, 0, st));
     }
-    HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, w.out_proj_w, w.out_proj_b, X, D, X, nullptr, nullptr, D, M, D, D,
-                                  HGL_ACT_NONE, st));
+    // (balanced: whole rounds of the persistent tiling + a split-K tail when the last round would be mostly empty; the
+    // partial sums borrow the qkv buffer, dead after the attention)
+    HGL_TRY(hgl_launch_gemm_f16x3_balanced(Hh, Hl, D, nullptr, w.out_proj_w, w.out_proj_b, X, D, nullptr, X, D, M, D, D, HGL_ACT_NONE,
+                                           bf.QKV, (size_t)M * 3 * D * sizeof(float), st));
     HGL_TRY(hgl_launch_layernorm_split(X, w.ln2_w, w.ln2_b, Hh, Hl, M, D, 1e-5f, st));
     HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, w.fc_w, w.fc_b, nullptr, 0, nullptr, Fh, Fl, 4 * D, M, 4 * D, D,
                                   HGL_ACT_QUICKGELU, st));
@@ -97,8 +99,8 @@ int hgl_clip_block_rest(const HglResBlockW& w, float* X, int B, int S, int D, in
       HGL_TRY(hgl_launch_gemm_f16x3_splitk(Fh, Fl, 4 * D, nullptr, w.proj_w, w.proj_b, X, D, nullptr, X, D, M, D, 4 * D,
                                            HGL_ACT_NONE, ks, bf.QKV, (size_t)M * 3 * D * sizeof(float), st));
     } else {
-      HGL_TRY(hgl_launch_gemm_f16x3(Fh, Fl, 4 * D, w.proj_w, w.proj_b, X, D, X, nullptr, nullptr, D, M, D, 4 * D,
-                                    HGL_ACT_NONE, st));
+      HGL_TRY(hgl_launch_gemm_f16x3_balanced(Fh, Fl, 4 * D, nullptr, w.proj_w, w.proj_b, X, D, nullptr, X, D, M, D, 4 * D, HGL_ACT_NONE,
+                                             bf.QKV, (size_t)M * 3 * D * sizeof(float), st));
     }
     return HGL_OK;
   }

@@ -1250,6 +1250,59 @@ int hgl_launch_gemm_f16x3_splitk(const void* Ah, const void* Al, int lda, const 
   return hgl_check_launch("gemm_f16x3_splitk");
 }
 
+// A GEMM whose LAST round of the persistent 256 x 256 tiling is mostly empty (CLIP's out / fc2 over a group of 16 refs: 2364
+// tiles on 256 CUs = 9.23 rounds, i.e. ten, the last one with 60 tiles; SAM's proj / lin2 over 10 images: 3.125 -> four) pays a
+// whole round for the remainder.  Rows are independent, so the GEMM is cut BY ROWS into a main part that fills whole rounds and
+// a tail of a few row tiles that runs split-K over all CUs (the existing split-K path: K slices as grid.y, partial sums through
+// `part`, summed in index order with bias / activation / residual by splitk_reduce_kernel: deterministic).  A tail row's sum
+// is associated differently from a main row's (K slices), as any split-K row's is: equal to fp32 rounding, not bit for bit
+// -- which rows form the tail depends on M alone.  Falls through to the plain launch when the plan does not pay.
+bool x3_tail_plan(int M, int N, int K, bool has_r, size_t part_bytes, int* m_main, int* ksplit) {
+  if ((N & 3) || K < 1024 || (K % 64)) return false;      // (K = 768, CLIP's out-projection: measured no gain -- six-K-tile slices cost what the round costs)
+  const int ncu = x3_num_cus();
+  const long long tiles_n = (N + 255) / 256, tiles_m = (M + 255) / 256, tiles = tiles_m * tiles_n;
+  const long long rounds = (tiles + ncu - 1) / ncu;
+  if (rounds < 3) return false;
+  const long long rem = tiles - (rounds - 1) * ncu;
+  if (rem * 2 > ncu) return false;                       // the last round is at least half full: leave it
+  const long long main_rows = ((rounds - 1) * ncu) / tiles_n;      // row tiles that fit in rounds - 1 rounds
+  const long long tail_tiles = (tiles_m - main_rows) * tiles_n;
+  if (main_rows <= 0 || tail_tiles <= 0 || tail_tiles * 2 > ncu) return false;
+  const int nk = K / 32;
+  int ks = (int)(ncu / tail_tiles);
+  if (ks > 8) ks = 8;
+  while (ks > 1 && ((nk / ks) & ~1) < 12) --ks;          // every slice at least twelve K tiles (the DMA prologue alone is seven units)
+  if (ks < 2) return false;
+  const long long m_tail = (long long)M - main_rows * 256;
+  if ((size_t)ks * (size_t)m_tail * (size_t)N * sizeof(float) > part_bytes) return false;
+  // cost model of pick_x3_kernel: one more round against a split-K launch (its slices, the reduce pass, two launch gaps)
+  const double t_round = 14.0 + 2.08 * nk + (has_r ? 12.0 : 0.0);
+  const double t_tail = 14.0 + 2.08 * ((nk / ks) & ~1) + 22.0;
+  if (t_tail > 0.8 * t_round) return false;
+  *m_main = (int)(main_rows * 256);
+  *ksplit = ks;
+  return true;
+}
+
+int hgl_launch_gemm_f16x3_balanced(const void* Ah, const void* Al, int lda, const int* amap, const float* W32, const float* bias,
+                                   const float* R, int ldr, const int* cmap, float* C, int ldc, int M, int N, int K, int act,
+                                   float* part, size_t part_bytes, hipStream_t st) {
+  int m_main = 0, ks = 1;
+  static const int on = HGL_DIAG_SWITCH("HGL_X3_TAIL", 1);
+  const bool p_kernel = g_x3_kernel < 0 ? pick_x3_kernel(M, N, K, R != nullptr) == HGL_X3_P : g_x3_kernel == HGL_X3_P;
+  if (!on || !C || !part || !p_kernel || (((size_t)part) & 15) || !x3_tail_plan(M, N, K, R != nullptr, part_bytes, &m_main, &ks))
+    return hgl_launch_gemm_f16x3_maps(Ah, Al, lda, amap, W32, bias, R, ldr, 0, cmap, C, nullptr, nullptr, ldc, M, N, K, act, st);
+  HGL_TRY(hgl_launch_gemm_f16x3_maps(Ah, Al, lda, amap, W32, bias, R, ldr, 0, cmap, C, nullptr, nullptr, ldc, m_main, N, K, act, st));
+  const int m_tail = M - m_main;
+  // the tail's rows: through the maps when there are any (their entries are absolute rows), by pointer offset otherwise
+  const _Float16* th = (const _Float16*)Ah + (amap ? 0 : (long long)m_main * lda);
+  const _Float16* tl = (const _Float16*)Al + (amap ? 0 : (long long)m_main * lda);
+  const float* tr = R ? R + (cmap ? 0 : (long long)m_main * ldr) : nullptr;
+  float* tc = C + (cmap ? 0 : (long long)m_main * ldc);
+  return hgl_launch_gemm_f16x3_splitk(th, tl, lda, amap ? amap + m_main : nullptr, W32, bias, tr, ldr, cmap ? cmap + m_main : nullptr,
+                                      tc, ldc, m_tail, N, K, act, ks, part, part_bytes, st);
+}
+
 extern "C" {
 
 int hgl_set_precision(int mode) {
@@ -1317,6 +1370,12 @@ int hgl_gemm_f16x3(const float* A, const float* W, const float* bias, const floa
   _Float16* ah = (_Float16*)scratch;
   _Float16* al = ah + (size_t)M * K;
   HGL_TRY(hgl_launch_split_f16(A, 1.0f, ah, al, (long long)M * K, st));
+  // scratch beyond the split A: room for the partial sums of the row-balanced launch (whole rounds + split-K tail), which the
+  // model code uses for its residual GEMMs; without it, the plain launch
+  const size_t a_bytes = hgl_align_up((size_t)M * K * 4, 256);
+  if (scratch_bytes > a_bytes + 256)
+    return hgl_launch_gemm_f16x3_balanced(ah, al, K, nullptr, W, bias, R, N, nullptr, C, N, M, N, K, act,
+                                          (float*)((char*)scratch + a_bytes), scratch_bytes - a_bytes, st);
   return hgl_launch_gemm_f16x3(ah, al, K, W, bias, R, N, C, nullptr, nullptr, N, M, N, K, act, st);
 }
 

@@ -301,6 +301,10 @@ int hgl_gemm_f16x3_splitk_factor(int M, int N, int K);
 int hgl_launch_gemm_f16x3_splitk(const void* Ah, const void* Al, int lda, const int* amap, const float* W32, const float* bias,
                                  const float* R, int ldr, const int* cmap, float* C, int ldc, int M, int N, int K, int act,
                                  int ksplit, float* part, size_t part_bytes, hipStream_t st);
+// row-balanced launch: whole rounds of the persistent tiling + a split-K tail (gemm_f16x3.hip); `part`: scratch for the tail's partial sums
+int hgl_launch_gemm_f16x3_balanced(const void* Ah, const void* Al, int lda, const int* amap, const float* W32, const float* bias,
+                                   const float* R, int ldr, const int* cmap, float* C, int ldc, int M, int N, int K, int act,
+                                   float* part, size_t part_bytes, hipStream_t st);
 int hgl_launch_gemm_f16x3_maps(const void* Ah, const void* Al, int lda, const int* amap, const float* W32, const float* bias,
                                const float* R, int ldr, int rmod, const int* cmap, float* C, void* Ch, void* Cl, int ldc,
                                int M, int N, int K, int act, hipStream_t st);

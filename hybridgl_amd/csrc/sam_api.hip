@@ -202,16 +202,16 @@ attention_done:
     } else if (ws > 0 && M > T && padskip) {
       // projection of the real tokens only, written straight back to token order with the residual added
       // (window_unpartition + shortcut, image_encoder.py:178-180)
-      HGL_TRY(hgl_launch_gemm_f16x3_maps(Ah, Al, D, p.pad_of, b.proj_w, b.proj_b, p.X, D, 0, p.tok_of, p.X, nullptr, nullptr,
-                                         D, T, D, D, HGL_ACT_NONE, st));
+      HGL_TRY(hgl_launch_gemm_f16x3_balanced(Ah, Al, D, p.pad_of, b.proj_w, b.proj_b, p.X, D, p.tok_of, p.X, D, T, D, D, HGL_ACT_NONE,
+                                             p.QKV, qkv_cap, st));
     } else if (ws > 0) {
       HGL_TRY(hgl_launch_gemm_f16x3(Ah, Al, D, b.proj_w, b.proj_b, nullptr, 0, p.P, nullptr, nullptr, D, M, D, D,
                                     HGL_ACT_NONE, st));
       for (int i = 0; i < p.nb; ++i)
         HGL_TRY(hgl_launch_win_unpartition_add(p.X + (size_t)i * T1 * D, g, ws, nw, D, p.P + (size_t)i * M1 * D, st));
     } else {
-      HGL_TRY(hgl_launch_gemm_f16x3(Ah, Al, D, b.proj_w, b.proj_b, p.X, D, p.X, nullptr, nullptr, D, T, D, D,
-                                    HGL_ACT_NONE, st));
+      HGL_TRY(hgl_launch_gemm_f16x3_balanced(Ah, Al, D, nullptr, b.proj_w, b.proj_b, p.X, D, nullptr, p.X, D, T, D, D, HGL_ACT_NONE,
+                                             p.QKV, qkv_cap, st));
     }
     HGL_TRY(hgl_launch_layernorm_split(p.X, b.norm2_w, b.norm2_b, Hh, Hl, T, D, 1e-6f, st));
     HGL_TRY(hgl_launch_gemm_f16x3(Hh, Hl, D, b.lin1_w, b.lin1_b, nullptr, 0, nullptr, Fh, Fl, 4 * D, T, 4 * D, D,
@@ -225,8 +225,8 @@ attention_done:
       HGL_TRY(hgl_launch_gemm_f16x3_splitk(Fh, Fl, 4 * D, nullptr, b.lin2_w, b.lin2_b, p.X, D, nullptr, p.X, D, T, D, 4 * D,
                                            HGL_ACT_NONE, ks, p.QKV, qkv_bytes, st));
     } else {
-      HGL_TRY(hgl_launch_gemm_f16x3(Fh, Fl, 4 * D, b.lin2_w, b.lin2_b, p.X, D, p.X, nullptr, nullptr, D, T, D, 4 * D,
-                                    HGL_ACT_NONE, st));
+      HGL_TRY(hgl_launch_gemm_f16x3_balanced(Fh, Fl, 4 * D, nullptr, b.lin2_w, b.lin2_b, p.X, D, nullptr, p.X, D, T, D, 4 * D, HGL_ACT_NONE,
+                                             p.QKV, qkv_bytes, st));
     }
     return HGL_OK;
   }

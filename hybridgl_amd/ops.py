@@ -160,19 +160,24 @@ def select_x3_kernel(kind="auto"):
     check(_lib.load().hgl_gemm_f16x3_select(X3_KERNELS[kind]), "hgl_gemm_f16x3_select")
 
 
-def gemm_f16x3(a, w, bias=None, residual=None, act="none", out=None):
-    """gemm() through the split-fp16 matrix-core path (registers w on first use)."""
+def gemm_f16x3(a, w, bias=None, residual=None, act="none", out=None, balanced=False):
+    """gemm() through the split-fp16 matrix-core path (registers w on first use).  balanced=True: the row-balanced launch of
+    the model code's residual GEMMs (whole rounds of the persistent tiling + a split-K tail; hgl_gemm_f16x3 with scratch for
+    the tail's partial sums)."""
     lib = _lib.load()
     M, K = a.shape
     N = w.shape[0]
     register_split_weight(w)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    ws = workspace(M * K * 4, a.device, "gemm_f16x3")
+    # the tail is at most half a round of 256 x 256 tiles in k K slices with k x tiles <= CUs: <= 256 slice-tiles of 256 KiB
+    extra = (2 * 256 * 256 * 256 * 4 + 4096) if balanced else 0
+    need = (M * K * 4 + 255) // 256 * 256 + extra      # the SIZE handed over selects the launch, not the (grow-only) buffer's
+    ws = workspace(need, a.device, "gemm_f16x3")
     check(lib.hgl_gemm_f16x3(_dev(a, torch.float32, "a"), _dev(w, torch.float32, "w"),
                              _dev(bias, torch.float32, "bias") if bias is not None else None,
                              _dev(residual, torch.float32, "residual") if residual is not None else None,
-                             _dev(out, torch.float32, "out"), M, N, K, ACT[act], ws.data_ptr(), ws.numel(),
+                             _dev(out, torch.float32, "out"), M, N, K, ACT[act], ws.data_ptr(), need,
                              _stream()), "hgl_gemm_f16x3")
     return out
 

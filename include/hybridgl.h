@@ -105,7 +105,10 @@ int hgl_unregister_split_weight(const float* w_fp32);
  * HGL_X3_TERMS=3 keeps them).  0: a genuine fp32 weight.  -1: not registered. */
 int hgl_split_weight_is_fp16_valued(const float* w_fp32);
 /* hgl_gemm_f32 semantics (no batch, dense leading dims) through the split path; A is split into
- * `scratch` (>= M*K*4 bytes) first.  W must be registered. */
+ * `scratch` (>= M*K*4 bytes) first.  W must be registered.  A scratch LARGER than align256(M*K*4) + 256 bytes selects the
+ * row-balanced launch the model code uses for its residual GEMMs (whole rounds of the persistent tiling + a split-K tail over
+ * the rows of a mostly empty last round, partial sums in the extra scratch: up to 4 * 256 * ceil(256 CUs / tiles_n) * N * 4
+ * bytes are used); rows of the tail then equal the plain launch to fp32 rounding, all others bit for bit. */
 int hgl_gemm_f16x3(const float* A, const float* W, const float* bias, const float* R, float* C,
                    int M, int N, int K, int act, void* scratch, size_t scratch_bytes, void* stream);
 

@@ -146,6 +146,52 @@ def test_gemm_f16x3_inplace_residual(cuda):
     assert np.abs(ref - z).max() < 3e-5
 
 
+@pytest.mark.parametrize("M,N,K,act", [(2364 // 3 * 256 - 128, 768, 768, "none"),       # CLIP out over 16 refs: 9.23 rounds, but K < 1024: plain
+                                        (2364 // 3 * 256 - 128, 768, 3072, "none"),      # CLIP fc2 over 16 refs: 788 x 3 tiles = 9.23 rounds
+                                        (160 * 256, 1280, 1280, "none"),               # SAM proj over 10 images: 800 tiles = 3.125 rounds
+                                        (160 * 256, 1280, 5120, "gelu"),               # lin2's shape (with an activation, for the reduce pass)
+                                        (256 * 256, 1280, 1280, "none")])              # 1280 tiles = 5 rounds exactly: the plain launch
+def test_gemm_f16x3_row_balanced_launch(cuda, M, N, K, act):
+    """hgl_launch_gemm_f16x3_balanced (the residual GEMMs of the CLIP / SAM blocks): a GEMM whose last round of the persistent
+    256 x 256 tiling would be mostly empty runs as whole rounds + a split-K tail over the last row tiles.  Against the plain
+    launch: the main rows bit for bit, the tail rows (K slices summed in index order) to fp32 rounding; in place on the
+    residual, as the blocks call it; and against a float64 product on a sample of rows."""
+    if ops.default_precision() != "f16x3":
+        pytest.skip("the split-fp16 GEMM")
+    g = torch.Generator(device=cuda).manual_seed(M % 1000 + K)
+    a = torch.randn((M, K), device=cuda, generator=g)
+    w = torch.randn((N, K), device=cuda, generator=g) / K ** 0.5
+    b = torch.randn((N,), device=cuda, generator=g)
+    r = torch.randn((M, N), device=cuda, generator=g)
+    try:
+        plain = ops.gemm_f16x3(a, w, b, r, act)
+        x = r.clone()
+        ops.gemm_f16x3(a, w, b, x, act, out=x, balanced=True)           # x = act(a w^T + b) + x
+        torch.cuda.synchronize()
+        same = (x == plain).all(dim=1)
+        n_diff = int((~same).sum())
+        tiles_n, ncu = (N + 255) // 256, torch.cuda.get_device_properties(cuda).multi_processor_count
+        tiles = (M + 255) // 256 * tiles_n
+        rounds = -(-tiles // ncu)
+        rem = tiles - (rounds - 1) * ncu
+        if rem * 2 > ncu or rem == 0 or K < 1024 or rounds < 3:
+            assert n_diff == 0                                           # no tail: the plain launch
+        else:
+            m_main = (rounds - 1) * ncu // tiles_n * 256
+            assert same[:m_main].all()                                   # main rows: the same kernel on the same rows
+            assert 0 < n_diff <= M - m_main                              # the tail went through K slices
+            scale = float(plain.abs().max())
+            assert float((x - plain).abs().max()) <= 4e-6 * scale
+        rows = torch.tensor([0, 1, M // 2, M - 300, M - 2, M - 1], device=cuda)
+        z = a[rows].double() @ w.double().T + b.double()
+        if act == "gelu":
+            z = torch.nn.functional.gelu(z)
+        z = z + r[rows].double()
+        assert float((x[rows].double() - z).abs().max()) < 3e-5 * max(1.0, float(z.abs().max()))
+    finally:
+        ops.release_split_weights([w.data_ptr()])
+
+
 def test_gemm_f16x3_operand_planes_beyond_4gb(cuda):
     """an A plane of 4 GB or more (CLIP ViT-L/14 fc2 over a group of 16 refs) runs as row chunks on the LDS-DMA kernel, whose
     operand offsets are 32-bit: every row equals the row of a small GEMM over its neighbourhood, at the chunk borders too"""

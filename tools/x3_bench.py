@@ -68,6 +68,13 @@ GROUP16_SHAPES = [  # the residual GEMMs of a group of 16 refs next to their twi
     ("clip qkv", 201728, 2304, 768, "none", False), ("clip fc1", 201728, 3072, 768, "quickgelu", False),
     ("sam qkv", 65536, 3840, 1280, "none", False), ("sam lin1", 65536, 5120, 1280, "gelu", False),
 ]
+GROUP10_SHAPES = [  # the residual GEMMs of a group of 10 refs (the driver's 20 timed steps = 10 + 10)
+    ("clip out", 126080, 768, 768, "none", True), ("clip fc2", 126080, 768, 3072, "none", True),
+    ("sam proj", 40960, 1280, 1280, "none", True), ("sam lin2", 40960, 1280, 5120, "none", True),
+    ("sam qkv", 40960, 3840, 1280, "none", False), ("sam lin1", 40960, 5120, 1280, "gelu", False),
+]
+if os.environ.get("X3_SHAPES") == "group10":
+    SHAPES = GROUP10_SHAPES
 if os.environ.get("X3_SHAPES") == "group16":
     SHAPES = GROUP16_SHAPES
 if os.environ.get("X3_SHAPES") == "group8":
@@ -91,30 +98,45 @@ def main():
         b = torch.randn(N, device=dev)
         R = torch.randn(M, N, device=dev) if res else None
         ref = ops.gemm(A, W, b, R, act)
-        out = ops.gemm_f16x3(A, W, b, R, act)
+        bal = os.environ.get("X3_BALANCED") == "1"      # the row-balanced launch (whole rounds + split-K tail) of the model code
+        out = ops.gemm_f16x3(A, W, b, R, act, balanced=bal)
         err = float((out - ref).abs().max() / ref.abs().max())
         for _ in range(3):
-            ops.gemm_f16x3(A, W, b, R, act, out=out)
+            ops.gemm_f16x3(A, W, b, R, act, out=out, balanced=bal)
         torch.cuda.synchronize()
+        # stream time of 10 back-to-back GEMMs (events around the loop: launch gaps, split-K tail and its reduce pass included)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.gemm_f16x3(A, W, b, R, act, out=out, balanced=bal)
+        e1.record()
+        torch.cuda.synchronize()
+        wall_us = e0.elapsed_time(e1) * 100.0
         lib.hgl_prof_enable(1)
         flush = torch.empty(1 << 28, device=dev) if os.environ.get("X3_COLD") else None   # 1 GiB: evicts L2 + MALL
         for _ in range(10):
             if flush is not None:
                 flush.fill_(1.0)
-            ops.gemm_f16x3(A, W, b, R, act, out=out)
+            ops.gemm_f16x3(A, W, b, R, act, out=out, balanced=bal)
         torch.cuda.synchronize()
         lib.hgl_prof_enable(0)
-        n, ms, fl, by = C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
-        lib.hgl_prof_read(3, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))   # register-staged kernel
-        if n.value == 0:
-            lib.hgl_prof_read(4, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))   # LDS-DMA kernels
-        if n.value == 0:
-            lib.hgl_prof_read(5, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))   # launches with < 256 tiles
+        # classes 3 (register-staged), 4 (LDS-DMA), 5 (< 256 tiles: the split-K tail of a balanced launch lands here) summed:
+        # kernel time of ONE GEMM = all its launches (the reduce pass of a split-K tail is not a GEMM launch: its ~10 us are
+        # not in this figure -- the pipeline numbers are the judge of the balanced launch)
+        class V:
+            value = 0.0
+        n, ms, fl = V(), V(), V()
+        for cls in (3, 4, 5):
+            n_, ms_, fl_, by_ = C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
+            lib.hgl_prof_read(cls, C.byref(n_), C.byref(ms_), C.byref(fl_), C.byref(by_))
+            ms.value += ms_.value
+            fl.value += fl_.value
+        n.value = 10
         tf = fl.value / ms.value / 1e9
         if not name.startswith(("text", "ragged", "k", "h")) and not name.endswith("-R"):
             tot_ms += ms.value / n.value
             tot_fl += fl.value / n.value
-        print(f"x3[{kind}] {name:14s} M={M:6d} N={N:5d} K={K:5d} {ms.value / n.value * 1e3:8.1f} us {tf:7.1f} TF/s relerr {err:.1e}"
+        print(f"x3[{kind}] {name:14s} M={M:6d} N={N:5d} K={K:5d} {ms.value / n.value * 1e3:8.1f} us {tf:7.1f} TF/s  stream {wall_us:8.1f} us {2.0 * M * N * K / wall_us / 1e6:7.1f} TF/s  relerr {err:.1e}"
               + ("  MISMATCH" if not err < 2e-6 else ""))
     print(f"x3[{kind}] total {tot_ms * 1e3:8.1f} us  {tot_fl / tot_ms / 1e9:7.1f} TF/s")
 
