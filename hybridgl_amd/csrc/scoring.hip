@@ -112,81 +112,203 @@ constexpr int MASK_GROUP = 8;  // masks per blockIdx.y
 // computed once per 32 masks instead of once per 8.  The partial sums per (mask, part) do not depend on the grouping.
 constexpr int REF_MASK_GROUP = 32;
 
+// ---- the pooling of a block, shared by the three pooling kernels (one heat-map / the maps of a ref / of a group of refs) -----
+// One workgroup = PIX_PER_BLOCK consecutive pixels x a group of masks x UP TO FOUR heat-maps at once: the normalised values of
+// the maps at the lane's 16 pixels live in registers (16 VGPRs per map), and a mask's 16 bytes are loaded ONCE, turned into
+// sixteen 0.0 / 1.0 floats once, and multiplied into all the maps: cvt + one fma per (pixel, map) instead of a 64-bit select
+// and a double-precision add per (pixel, map) and a re-read of the bytes per map.  (Until round 5 every (block, group, map) was
+// its own workgroup with a double-precision sum per pixel: 130 vector instructions per KiB of mask bytes and map, the bytes
+// fetched S times -- 1.37 TB/s on the algorithmic bytes, instruction-bound.)
+// Arithmetic of one (map, mask, wave) partial -- THE definition all three kernels share, so their results are the same bits:
+//   lane: a = 0; for e = 0..15 in order: a = fma(m_e, v_e, a) in fp32 (m_e is 0 or 1: the products are exact, the 16-term sum
+//   carries at most a few 1e-8 of relative error); the 64 lane sums folded in fp32 by pool_sum_f's fixed DPP tree; the wave's
+//   sum widened to double; partials over a mask's waves are added in double by the scoring kernels as before.
+struct PoolMap {
+  const float* attn;   // the heat-map
+  int dirflag, sidx;   // gen_dir_mask weight; index of the map in the partial arrays
+  float mn, range;     // min and (max - min) of the map
+};
+
+// dir_weight(dirflag, x, W) with everything that does not depend on x computed once per map: the weight of a column is
+// linspace_at on one of at most two segments (dirflag 3: the two ramps of `middle`; 0: the constant 1 as a ramp of step 0).
+// Same operations on the same values as dir_weight / linspace_at: same bits.
+struct DirRamp {
+  int xsplit;                       // columns < xsplit lie on segment A, the others on segment B (index x - xsplit)
+  float stepA, startA, endA, stepB, startB, endB;
+  int stepsA, halfA, stepsB, halfB;
+  __device__ __forceinline__ void seg(float start, float end, int steps, float& st, float& s0, float& e0, int& n, int& h) {
+    if (steps <= 1) { st = 0.f; s0 = start; e0 = start; n = 1; h = 1; return; }     // linspace_at: steps == 1 -> start
+    st = (end - start) / (float)(steps - 1);
+    s0 = start; e0 = end; n = steps; h = steps / 2;
+  }
+  __device__ __forceinline__ void init(int dirflag, int W) {
+    xsplit = W;
+    seg(1.f, 1.f, W, stepB, startB, endB, stepsB, halfB);
+    if (dirflag == 1) seg(1.f, 0.f, W, stepA, startA, endA, stepsA, halfA);
+    else if (dirflag == 2) seg(0.f, 1.f, W, stepA, startA, endA, stepsA, halfA);
+    else if (dirflag == 3) {
+      const int w1 = W / 2;
+      xsplit = w1;
+      seg(0.f, 1.f, w1, stepA, startA, endA, stepsA, halfA);
+      seg(1.f, 0.f, W - w1, stepB, startB, endB, stepsB, halfB);
+    } else {
+      stepA = 0.f; startA = 1.f; endA = 1.f; stepsA = W; halfA = W;      // fma(0, i, 1) == 1
+    }
+  }
+  __device__ __forceinline__ float at(int x) const {
+    const bool a = x < xsplit;
+    const int i = a ? x : x - xsplit;
+    const float st = a ? stepA : stepB, s0 = a ? startA : startB, e0 = a ? endA : endB;
+    const int n = a ? stepsA : stepsB, h = a ? halfA : halfB;
+    return i < h ? fmaf(st, (float)i, s0) : fmaf(-st, (float)(n - i - 1), e0);
+  }
+};
+
+// Sum over the 64 lanes for the pooling loop (EXEC all ones there), on the VALU alone, in fp32: six adds whose second operand
+// comes through DPP (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: every lane then holds its row's sum; row_bcast:15 into
+// rows 1 and 3, row_bcast:31 into rows 2 and 3) -- the total, ((r2 + r3) + (r0 + r1)), ends in lanes 48..63.  One instruction
+// per step (v_add_f32 with a DPP operand).  (__shfl_xor compiles to ds_bpermute_b32: a double-precision butterfly was twelve
+// LDS-crossbar operations and six adds per (mask, map), as much of the loop as its arithmetic; the DPP form in double costs three
+// instructions per step.)  The wave's 1024 products are thus summed in fp32 -- as the reference sums ALL its products
+// (Hybridgl_main.py:221, torch.sum of an fp32 tensor) -- in a fixed tree: deterministic, and the same function in all three
+// pooling kernels; partials of different waves are added in double by the scoring kernels.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float pool_dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false));
+}
+__device__ __forceinline__ float pool_sum_f(float v) {      // valid in lanes 48..63 (read it in lane 63)
+  v += pool_dpp_f<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+  v += pool_dpp_f<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+  v += pool_dpp_f<0x141, 0xf>(v);     // row_half_mirror
+  v += pool_dpp_f<0x140, 0xf>(v);     // row_mirror
+  v += pool_dpp_f<0x142, 0xa>(v);     // row_bcast:15 -> rows 1, 3 (the other rows add 0)
+  v += pool_dpp_f<0x143, 0xc>(v);     // row_bcast:31 -> rows 2, 3
+  return v;
+}
+__device__ __forceinline__ unsigned pool_sum_u(unsigned v) {   // valid in lanes 48..63
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
+typedef unsigned pool_u32x4 __attribute__((ext_vector_type(4)));
+typedef pool_u32x4 pool_u32x4_u __attribute__((aligned(1)));     // 16 bytes at ANY address: one global_load_dwordx4 (the hardware takes
+typedef f32x4 pool_f32x4_u __attribute__((aligned(4)));          // unaligned vector loads; a plane of an odd-sized image starts anywhere)
+
+// FULL: the whole block of PIX_PER_BLOCK pixels lies inside the plane (wave-uniform; every block but the last one of a plane):
+// no per-pixel predicate anywhere.  !FULL: the last block, pixel by pixel with predicates -- instantiated for one map only.
+template <int NS, bool FULL>
+__device__ __forceinline__ void pool_block(int blk, const PoolMap (&pm)[NS], int n0, int n1, const uint8_t* __restrict__ masks, int N, int H,
+                                           int W, bool write_tot, double* __restrict__ part_sum, unsigned* __restrict__ part_cnt,
+                                           double* __restrict__ part_tot, int nparts) {
+  const long long HW = (long long)H * W;
+  const long long p0 = (long long)blk * PIX_PER_BLOCK + threadIdx.x * PX_LANE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long part = (long long)blk * 4 + wave;      // one partial per wave: no block sync
+  float v[NS][PX_LANE];
+  const int xcol0 = (int)(p0 % W);      // ONE 64-bit division per lane; the pixels' columns follow by increment and wrap
+  int cnt_map = -1;                     // the map (if any of these) that files the pixel counts: sidx == 0
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const float* attn = pm[j].attn;
+    float raw[PX_LANE];      // four 16-byte loads issued together (sixteen conditional scalar loads are sixteen round trips)
+    if (FULL) {
+      const f32x4 r0 = *(const pool_f32x4_u*)(attn + p0), r1 = *(const pool_f32x4_u*)(attn + p0 + 4);
+      const f32x4 r2 = *(const pool_f32x4_u*)(attn + p0 + 8), r3 = *(const pool_f32x4_u*)(attn + p0 + 12);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { raw[e] = r0[e]; raw[4 + e] = r1[e]; raw[8 + e] = r2[e]; raw[12 + e] = r3[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < PX_LANE; ++e) raw[e] = attn[min(p0 + e, HW - 1)];
+    }
+    int xcol = xcol0;
+    DirRamp ramp;
+    ramp.init(pm[j].dirflag, W);
+    // the map's total over the wave's pixels in EXACTLY the arithmetic of a mask that covers them all (fma by 1.0 in order, the
+    // same fold over the lanes): for a full mask  total - sum  is then 0 and the "outside" mean 0 / 0 = NaN, as in the reference
+    // (Hybridgl_main.py:221: every term of its sum is x * 0 / 0) -- not +-inf from two roundings of the same sum
+    float ta = 0.f;
+#pragma unroll
+    for (int e = 0; e < PX_LANE; ++e) {
+      float val = ((raw[e] - pm[j].mn) / pm[j].range) * ramp.at(xcol);
+      if (!FULL && p0 + e >= HW) val = 0.f;
+      v[j][e] = val;
+      ta = __builtin_fmaf(1.0f, val, ta);
+      if (++xcol >= W) xcol = 0;
+    }
+    if (write_tot) {
+      const float tot = pool_sum_f(ta);
+      if (lane == 63) part_tot[(long long)pm[j].sidx * nparts + part] = (double)tot;
+    }
+    if (pm[j].sidx == 0) cnt_map = j;
+  }
+  for (int n = n0; n < n1; ++n) {
+    const uint8_t* m = masks + (long long)n * HW + p0;
+    unsigned w4[4] = {0u, 0u, 0u, 0u};
+    if (FULL) {
+      const pool_u32x4 mv = *(const pool_u32x4_u*)m;
+      w4[0] = mv.x; w4[1] = mv.y; w4[2] = mv.z; w4[3] = mv.w;
+    } else {      // byte loads at clamped addresses, pixels beyond the plane count as 0
+#pragma unroll
+      for (int e = 0; e < PX_LANE; ++e) {
+        const long long pe = min(p0 + e, HW - 1) - p0;
+        const unsigned byte = p0 + e < HW ? (unsigned)m[pe] : 0u;
+        w4[e >> 2] |= byte << (8 * (e & 3));
+      }
+    }
+    unsigned c = 0;
+    float mf[PX_LANE];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // every byte -> (byte != 0): bit 7 of ((b & 0x7f) + 0x7f) | b is set exactly for b != 0 (no carry crosses a byte)
+      const unsigned w = w4[q];
+      const unsigned nz = ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) >> 7) & 0x01010101u;
+      c += (unsigned)__popc(nz);
+      mf[4 * q + 0] = (float)(nz & 0xffu);
+      mf[4 * q + 1] = (float)((nz >> 8) & 0xffu);
+      mf[4 * q + 2] = (float)((nz >> 16) & 0xffu);
+      mf[4 * q + 3] = (float)(nz >> 24);
+    }
+    float sum[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < PX_LANE; ++e) a = __builtin_fmaf(mf[e], v[j][e], a);
+      sum[j] = a;
+    }
+    // the folds of the maps and of the count in ONE basic block (their DPP steps interleave and fill each other's wait states),
+    // then all the stores of lane 63 behind one branch
+#pragma unroll
+    for (int j = 0; j < NS; ++j) sum[j] = pool_sum_f(sum[j]);
+    c = pool_sum_u(c);
+    if (lane == 63) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) part_sum[((long long)pm[j].sidx * nparts + part) * N + n] = (double)sum[j];
+      if (cnt_map >= 0) part_cnt[part * N + n] = c;
+    }
+  }
+}
+
+// The kernels below come in pairs: the main launch covers the blocks that lie wholly inside the plane (FULL: HW / PIX_PER_BLOCK
+// of them -- all 100 of a 640 x 640 plane), a second, small launch the partial last block when there is one (!FULL, one map at a
+// time; its 16 byte loads per lane and predicates would otherwise set the register count of the main kernel).
+template <bool FULL>
 __global__ __launch_bounds__(256) void masked_pool_kernel(const float* __restrict__ attn,
                                                           const uint8_t* __restrict__ masks, int N,
                                                           int H, int W, int dirflag,
                                                           const int* __restrict__ stats,
                                                           double* __restrict__ part_sum,
                                                           unsigned* __restrict__ part_cnt,
-                                                          double* __restrict__ part_tot) {
-  const long long HW = (long long)H * W;
-  const long long p0 = (long long)blockIdx.x * PIX_PER_BLOCK + threadIdx.x * PX_LANE;
+                                                          double* __restrict__ part_tot, int blk0) {
   const float mn = ord2f(stats[0]), mx = ord2f(stats[1]);
-  const float range = mx - mn;
-  float v[PX_LANE];
-  double tot = 0.0;
-  const bool inb = p0 + PX_LANE <= HW;
-  // the lane's 16 heat-map values as four 16-byte loads issued together (sixteen conditional scalar loads compiled to
-  // sixteen serial round trips: tools/isa_serial_loads.py)
-  float raw[PX_LANE];
-  if (inb && ((((uintptr_t)(attn + p0)) & 15) == 0)) {
-    const f32x4 r0 = *(const f32x4*)(attn + p0), r1 = *(const f32x4*)(attn + p0 + 4);
-    const f32x4 r2 = *(const f32x4*)(attn + p0 + 8), r3 = *(const f32x4*)(attn + p0 + 12);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { raw[e] = r0[e]; raw[4 + e] = r1[e]; raw[8 + e] = r2[e]; raw[12 + e] = r3[e]; }
-  } else {
-#pragma unroll
-    for (int e = 0; e < PX_LANE; ++e) raw[e] = attn[min(p0 + e, HW - 1)];
-  }
-  // the column of the lane's first pixel by ONE 64-bit division; the others follow by increment and wrap (a 64-bit modulo per
-  // pixel was most of this kernel's instructions: it ran at 0.4 TB/s of mask bytes)
-  int xcol = (int)(p0 % W);
-#pragma unroll
-  for (int e = 0; e < PX_LANE; ++e) {
-    const long long p = p0 + e;
-    float val = 0.f;
-    if (p < HW) val = ((raw[e] - mn) / range) * dir_weight(dirflag, xcol, W);
-    v[e] = val;
-    tot += (double)val;
-    if (++xcol >= W) xcol = 0;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long part = (long long)blockIdx.x * 4 + wave;  // one partial per wave: no block sync
-  if (blockIdx.y == 0) {
-    tot = wave_sum_d(tot);
-    if (lane == 0) part_tot[part] = tot;
-  }
+  const PoolMap pm[1] = {{attn, dirflag, 0, mn, mx - mn}};
   const int n0 = blockIdx.y * MASK_GROUP;
-  const int n1 = min(N, n0 + MASK_GROUP);
-  for (int n = n0; n < n1; ++n) {
-    const uint8_t* m = masks + (long long)n * HW + p0;
-    double s = 0.0;
-    unsigned c = 0;
-    if (inb && (((uintptr_t)m) & 15) == 0) {
-      const uint4 mv = *(const uint4*)m;
-      const unsigned w4[4] = {mv.x, mv.y, mv.z, mv.w};
-#pragma unroll
-      for (int e = 0; e < PX_LANE; ++e) {
-        const bool on = ((w4[e >> 2] >> (8 * (e & 3))) & 0xff) != 0;
-        s += on ? (double)v[e] : 0.0;
-        c += on ? 1u : 0u;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < PX_LANE; ++e) {
-        const bool on = (p0 + e < HW) && m[e] != 0;
-        s += on ? (double)v[e] : 0.0;
-        c += on ? 1u : 0u;
-      }
-    }
-    s = wave_sum_d(s);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if (lane == 0) {
-      part_sum[part * N + n] = s;
-      part_cnt[part * N + n] = c;
-    }
-  }
+  pool_block<1, FULL>(blk0 + blockIdx.x, pm, n0, min(N, n0 + MASK_GROUP), masks, N, H, W, blockIdx.y == 0, part_sum, part_cnt, part_tot, 0);
 }
 
 // one wave per mask: lanes stride over the per-wave partials in a fixed pattern, then a fixed-order
@@ -597,90 +719,75 @@ __device__ __forceinline__ void ref_fold_minmax(const float* __restrict__ part_m
   }
 }
 
-// masked_pool_kernel for the S heat-maps of a ref in ONE launch: grid (pixel blocks, mask groups, S).  A first version kept the
-// tiles of up to four heat-maps in registers and read every mask byte once for all of them: 260 VGPRs (one wave per SIMD) and
-// 8.5 k instructions -- 108 us per ref, slower than three launches of the per-sentence kernel (3 x 21 us): this pass is bound
-// by its instructions and round trips, not by the 26 MB of mask bytes.  Now every (block, group, map) is a small workgroup of
-// the per-sentence kernel's code (79 VGPRs, six waves per SIMD); the masks of the second and third map come from L2 / the
-// Infinity Cache.  Partials in the layout and order of masked_pool_kernel: identical sums.
-template <int MG>
-__device__ __forceinline__ void ref_masked_pool_body(const float* __restrict__ attn, int dirflag, int sidx, int mask_group,
+// masked_pool_kernel for the S heat-maps of a ref in ONE launch: grid (pixel blocks, mask groups); the maps are looped INSIDE
+// the workgroup (pool_block, four at a time).  History: a first version (round 3) kept four maps' tiles in registers with a
+// double-precision sum per pixel and map -- 260 VGPRs, 8.5 k instructions, slower than three launches; rounds 4-5 made every
+// (block, group, map) its own small workgroup and re-read the mask bytes per map from L2; the fp32 fma form of pool_block needs
+// 16 VGPRs per map and fetches every mask byte once.  Partials in the layout of masked_pool_kernel.
+// the S heat-maps of a ref over one FULL pixel block and one group of MG masks: the maps go through pool_block four at a time
+// (the mask bytes of the block are fetched once per four maps: once for the three sentences of a RefCOCO ref)
+// CH = maps per pass: 4, or 3 for the launches whose refs have at most three sentences (RefCOCO: 16 VGPRs fewer per map held
+// -> 4 instead of 3 waves per SIMD)
+template <int MG, int CH>
+__device__ __forceinline__ void ref_masked_pool_body(int blk, const float* const* __restrict__ attn, const int* __restrict__ dirflag, int S, int mask_group,
                                                      const uint8_t* __restrict__ masks, int N, int H, int W,
                                                      const float* __restrict__ part_mm, double* __restrict__ part_sum,
                                                      unsigned* __restrict__ part_cnt, double* __restrict__ part_tot, int nparts) {
-  const long long HW = (long long)H * W;
-  const long long p0 = (long long)blockIdx.x * PIX_PER_BLOCK + threadIdx.x * PX_LANE;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long part = (long long)blockIdx.x * 4 + wave;
-  const bool inb = p0 + PX_LANE <= HW;
-  float mn, mx;
-  ref_fold_minmax(part_mm, sidx, lane, mn, mx);
-  const float range = mx - mn;
-  float v[PX_LANE];
-  double tot = 0.0;
-  float raw[PX_LANE];      // four 16-byte loads issued together
-  if (inb && ((((uintptr_t)(attn + p0)) & 15) == 0)) {
-    const f32x4 r0 = *(const f32x4*)(attn + p0), r1 = *(const f32x4*)(attn + p0 + 4);
-    const f32x4 r2 = *(const f32x4*)(attn + p0 + 8), r3 = *(const f32x4*)(attn + p0 + 12);
+  const int lane = threadIdx.x & 63;
+  const int n0 = mask_group * MG, n1 = min(N, n0 + MG);
+  const bool wt = mask_group == 0;
+  for (int s0 = 0; s0 < S; s0 += CH) {
+    const int ns = min(CH, S - s0);
+    PoolMap pm[CH];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { raw[e] = r0[e]; raw[4 + e] = r1[e]; raw[8 + e] = r2[e]; raw[12 + e] = r3[e]; }
-  } else {
-#pragma unroll
-    for (int e = 0; e < PX_LANE; ++e) raw[e] = attn[min(p0 + e, HW - 1)];
-  }
-  int xcol = (int)(p0 % W);      // one 64-bit division per lane; the pixels' columns follow by increment and wrap
-#pragma unroll
-  for (int e = 0; e < PX_LANE; ++e) {
-    const long long p = p0 + e;
-    float val = 0.f;
-    if (p < HW) val = ((raw[e] - mn) / range) * dir_weight(dirflag, xcol, W);
-    v[e] = val;
-    tot += (double)val;
-    if (++xcol >= W) xcol = 0;
-  }
-  if (mask_group == 0) {
-    tot = wave_sum_d(tot);
-    if (lane == 0) part_tot[(long long)sidx * nparts + part] = tot;
-  }
-  const int n0 = mask_group * MG;
-  const int n1 = min(N, n0 + MG);
-  for (int n = n0; n < n1; ++n) {
-    const uint8_t* m = masks + (long long)n * HW + p0;
-    double sum = 0.0;
-    unsigned c = 0;
-    if (inb && (((uintptr_t)m) & 15) == 0) {
-      const uint4 mv = *(const uint4*)m;
-      const unsigned w4[4] = {mv.x, mv.y, mv.z, mv.w};
-#pragma unroll
-      for (int e = 0; e < PX_LANE; ++e) {
-        const bool on = ((w4[e >> 2] >> (8 * (e & 3))) & 0xff) != 0;
-        sum += on ? (double)v[e] : 0.0;
-        c += on ? 1u : 0u;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < PX_LANE; ++e) {
-        const bool on = (p0 + e < HW) && m[e] != 0;
-        sum += on ? (double)v[e] : 0.0;
-        c += on ? 1u : 0u;
-      }
+    for (int j = 0; j < CH; ++j) {
+      const int sj = min(s0 + j, S - 1);
+      float mn, mx;
+      ref_fold_minmax(part_mm, sj, lane, mn, mx);
+      pm[j].attn = attn[sj]; pm[j].dirflag = dirflag[sj]; pm[j].sidx = sj; pm[j].mn = mn; pm[j].range = mx - mn;
     }
-    sum = wave_sum_d(sum);
-    if (lane == 0) part_sum[((long long)sidx * nparts + part) * N + n] = sum;
-    if (sidx == 0) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-      if (lane == 0) part_cnt[part * N + n] = c;
+    if (CH == 4 && ns == 4) {
+      if constexpr (CH == 4) pool_block<4, true>(blk, pm, n0, n1, masks, N, H, W, wt, part_sum, part_cnt, part_tot, nparts);
+    } else if (ns == 3) {
+      const PoolMap p3[3] = {pm[0], pm[1], pm[2]};
+      pool_block<3, true>(blk, p3, n0, n1, masks, N, H, W, wt, part_sum, part_cnt, part_tot, nparts);
+    } else if (ns == 2) {
+      const PoolMap p2[2] = {pm[0], pm[1]};
+      pool_block<2, true>(blk, p2, n0, n1, masks, N, H, W, wt, part_sum, part_cnt, part_tot, nparts);
+    } else {
+      const PoolMap p1[1] = {pm[0]};
+      pool_block<1, true>(blk, p1, n0, n1, masks, N, H, W, wt, part_sum, part_cnt, part_tot, nparts);
     }
   }
 }
+// ... and over the partial LAST block of the plane, one map at a time
+template <int MG>
+__device__ __forceinline__ void ref_masked_pool_last(int blk, const float* const* __restrict__ attn, const int* __restrict__ dirflag, int S, int mask_group,
+                                                     const uint8_t* __restrict__ masks, int N, int H, int W,
+                                                     const float* __restrict__ part_mm, double* __restrict__ part_sum,
+                                                     unsigned* __restrict__ part_cnt, double* __restrict__ part_tot, int nparts) {
+  const int lane = threadIdx.x & 63;
+  const int n0 = mask_group * MG, n1 = min(N, n0 + MG);
+  for (int sj = 0; sj < S; ++sj) {
+    float mn, mx;
+    ref_fold_minmax(part_mm, sj, lane, mn, mx);
+    const PoolMap pm[1] = {{attn[sj], dirflag[sj], sj, mn, mx - mn}};
+    pool_block<1, false>(blk, pm, n0, n1, masks, N, H, W, mask_group == 0, part_sum, part_cnt, part_tot, nparts);
+  }
+}
 
+template <int CH>
 __global__ __launch_bounds__(256) void ref_masked_pool_kernel(RefSentences rs, int S, const uint8_t* __restrict__ masks, int N, int H,
                                                               int W, const float* __restrict__ part_mm, double* __restrict__ part_sum,
                                                               unsigned* __restrict__ part_cnt, double* __restrict__ part_tot,
                                                               int nparts) {
-  ref_masked_pool_body<MASK_GROUP>(rs.attn[blockIdx.z], rs.dirflag[blockIdx.z], blockIdx.z, blockIdx.y, masks, N, H, W, part_mm, part_sum, part_cnt,
-                       part_tot, nparts);
+  ref_masked_pool_body<MASK_GROUP, CH>(blockIdx.x, rs.attn, rs.dirflag, S, blockIdx.y, masks, N, H, W, part_mm, part_sum, part_cnt, part_tot, nparts);
+}
+__global__ __launch_bounds__(256) void ref_masked_pool_last_kernel(RefSentences rs, int S, const uint8_t* __restrict__ masks, int N, int H,
+                                                                   int W, const float* __restrict__ part_mm, double* __restrict__ part_sum,
+                                                                   unsigned* __restrict__ part_cnt, double* __restrict__ part_tot,
+                                                                   int nparts, int blk) {
+  ref_masked_pool_last<MASK_GROUP>(blk, rs.attn, rs.dirflag, S, blockIdx.y, masks, N, H, W, part_mm, part_sum, part_cnt, part_tot, nparts);
 }
 
 // one workgroup per sentence: coherence_final_kernel's reduction for its N masks, then the sentence's scoring
@@ -864,12 +971,20 @@ __global__ __launch_bounds__(256) void grp_minmax_kernel(const GroupRefDev* __re
   ref_minmax_body(g.rs.attn[s], s, (long long)g.H * g.W, g.part_mm);
 }
 
-__global__ __launch_bounds__(256) void grp_masked_pool_kernel(const GroupRefDev* __restrict__ tab, int maxS) {
-  const int ref = blockIdx.z / maxS, s = blockIdx.z - ref * maxS;
-  const GroupRefDev& g = tab[ref];
-  if (s >= g.S || (int)blockIdx.x >= g.nblk || (int)blockIdx.y * REF_MASK_GROUP >= g.N) return;
-  ref_masked_pool_body<REF_MASK_GROUP>(g.rs.attn[s], g.rs.dirflag[s], s, blockIdx.y, g.masks, g.N, g.H, g.W, g.part_mm, g.part_sum, g.part_cnt, g.part_tot,
-                       g.nparts);
+template <int CH>
+__global__ __launch_bounds__(256) void grp_masked_pool_kernel(const GroupRefDev* __restrict__ tab) {
+  const GroupRefDev& g = tab[blockIdx.z];
+  const int nfull = (int)(((long long)g.H * g.W) / PIX_PER_BLOCK);
+  if ((int)blockIdx.x >= nfull || (int)blockIdx.y * REF_MASK_GROUP >= g.N) return;
+  ref_masked_pool_body<REF_MASK_GROUP, CH>(blockIdx.x, g.rs.attn, g.rs.dirflag, g.S, blockIdx.y, g.masks, g.N, g.H, g.W, g.part_mm, g.part_sum,
+                                       g.part_cnt, g.part_tot, g.nparts);
+}
+__global__ __launch_bounds__(256) void grp_masked_pool_last_kernel(const GroupRefDev* __restrict__ tab) {
+  const GroupRefDev& g = tab[blockIdx.z];
+  const long long HW = (long long)g.H * g.W;
+  if (HW % PIX_PER_BLOCK == 0 || (int)blockIdx.y * REF_MASK_GROUP >= g.N) return;
+  ref_masked_pool_last<REF_MASK_GROUP>((int)(HW / PIX_PER_BLOCK), g.rs.attn, g.rs.dirflag, g.S, blockIdx.y, g.masks, g.N, g.H, g.W, g.part_mm,
+                                       g.part_sum, g.part_cnt, g.part_tot, g.nparts);
 }
 
 __global__ __launch_bounds__(256) void grp_score_kernel(const GroupRefDev* __restrict__ tab, int E, float logit_scale, float r_mix,
@@ -1094,7 +1209,13 @@ int hgl_coherence_scores(const float* imgattn, const uint8_t* masks, int N, int 
   const long long HW = (long long)H * W;
   hipLaunchKernelGGL(init_stats_kernel, dim3(1), dim3(1), 0, st, stats);
   hipLaunchKernelGGL(minmax_kernel, dim3(256), dim3(256), 0, st, imgattn, HW, stats);
-  hipLaunchKernelGGL(masked_pool_kernel, dim3(coh_nblk(H, W), (N + MASK_GROUP - 1) / MASK_GROUP), dim3(256), 0, st, imgattn, masks, N, H, W, dirflag, stats, psum, pcnt, ptot);
+  {
+    const int nfull = (int)(((long long)H * W) / PIX_PER_BLOCK), ngrp = (N + MASK_GROUP - 1) / MASK_GROUP;
+    if (nfull > 0)
+      hipLaunchKernelGGL(masked_pool_kernel<true>, dim3(nfull, ngrp), dim3(256), 0, st, imgattn, masks, N, H, W, dirflag, stats, psum, pcnt, ptot, 0);
+    if (coh_nblk(H, W) > nfull)
+      hipLaunchKernelGGL(masked_pool_kernel<false>, dim3(1, ngrp), dim3(256), 0, st, imgattn, masks, N, H, W, dirflag, stats, psum, pcnt, ptot, nfull);
+  }
   hipLaunchKernelGGL(coherence_final_kernel, dim3((N + 3) / 4), dim3(256), 0, st, psum, pcnt, ptot, nb, N, HW, black, score);
   return hgl_check_launch("coherence_scores");
 }
@@ -1226,8 +1347,15 @@ int hgl_score_ref(const float* hybrid, const float* text, int T, const int64_t* 
     float* clip = score_clip ? score_clip + (long long)s0 * N : spare + (long long)sc * N;
     float* neg = score_neg ? score_neg + (long long)s0 * N : spare + 2ll * sc * N;
     hipLaunchKernelGGL(ref_minmax_kernel, dim3(REF_MM_BLOCKS, sc), dim3(256), 0, st, rs, HW, part_mm);
-    hipLaunchKernelGGL(ref_masked_pool_kernel, dim3(coh_nblk(H, W), (N + MASK_GROUP - 1) / MASK_GROUP, sc), dim3(256), 0, st, rs, sc,
-                       masks, N, H, W, part_mm, psum, pcnt, ptot, nparts);
+    {
+      const int nfull = (int)(HW / PIX_PER_BLOCK), ngrp = (N + MASK_GROUP - 1) / MASK_GROUP;
+      if (nfull > 0 && sc <= 3)
+        hipLaunchKernelGGL(ref_masked_pool_kernel<3>, dim3(nfull, ngrp), dim3(256), 0, st, rs, sc, masks, N, H, W, part_mm, psum, pcnt, ptot, nparts);
+      else if (nfull > 0)
+        hipLaunchKernelGGL(ref_masked_pool_kernel<4>, dim3(nfull, ngrp), dim3(256), 0, st, rs, sc, masks, N, H, W, part_mm, psum, pcnt, ptot, nparts);
+      if (coh_nblk(H, W) > nfull)
+        hipLaunchKernelGGL(ref_masked_pool_last_kernel, dim3(1, ngrp), dim3(256), 0, st, rs, sc, masks, N, H, W, part_mm, psum, pcnt, ptot, nparts, nfull);
+    }
     hipLaunchKernelGGL(ref_score_kernel, dim3(sc), dim3(256), 0, st, rs, hybrid, text, (const long long*)boxes, N, E, H, W, logit_scale,
                        r, k1, k2, alpha, psum, pcnt, ptot, nparts, gem, clip, neg, soft, (int*)idx + 2 * s0,
                        (unsigned long long*)iu + 4 * s0, done);
@@ -1383,6 +1511,7 @@ int hgl_score_group(const HglGroupRef* refs, int R, int E, float logit_scale, fl
     if (slot < 0) return HGL_ELAUNCH;
     GroupRefDev* host = (GroupRefDev*)host_v;
     int maxS = 0, max_nblk = 0, max_groups = 0;
+    bool any_partial = false;      // a ref whose plane does not end on a block boundary: the pooling's second, small launch
     long long max_iou_blocks = 1;
     for (int i = 0; i < rc; ++i) {
       const HglGroupRef& q = refs[r0 + i];
@@ -1417,6 +1546,7 @@ int hgl_score_group(const HglGroupRef* refs, int R, int E, float logit_scale, fl
       d.iu = (unsigned long long*)q.iu;
       maxS = q.S > maxS ? q.S : maxS;
       max_nblk = d.nblk > max_nblk ? d.nblk : max_nblk;
+      any_partial = any_partial || ((long long)q.H * q.W) % PIX_PER_BLOCK != 0;
       const int groups = (q.N + REF_MASK_GROUP - 1) / REF_MASK_GROUP;
       max_groups = groups > max_groups ? groups : max_groups;
       long long blocks = ((long long)q.H * q.W / 16 + 1023) / 1024;
@@ -1431,7 +1561,12 @@ int hgl_score_group(const HglGroupRef* refs, int R, int E, float logit_scale, fl
       return HGL_ELAUNCH;
     }
     hipLaunchKernelGGL(grp_minmax_kernel, dim3(REF_MM_BLOCKS, maxS, rc), dim3(256), 0, st, (const GroupRefDev*)tab);
-    hipLaunchKernelGGL(grp_masked_pool_kernel, dim3(max_nblk, max_groups, rc * maxS), dim3(256), 0, st, (const GroupRefDev*)tab, maxS);
+    if (maxS <= 3)
+      hipLaunchKernelGGL(grp_masked_pool_kernel<3>, dim3(max_nblk, max_groups, rc), dim3(256), 0, st, (const GroupRefDev*)tab);
+    else
+      hipLaunchKernelGGL(grp_masked_pool_kernel<4>, dim3(max_nblk, max_groups, rc), dim3(256), 0, st, (const GroupRefDev*)tab);
+    if (any_partial)
+      hipLaunchKernelGGL(grp_masked_pool_last_kernel, dim3(1, max_groups, rc), dim3(256), 0, st, (const GroupRefDev*)tab);
     hipLaunchKernelGGL(grp_score_kernel, dim3(maxS, rc), dim3(256), 0, st, (const GroupRefDev*)tab, E, logit_scale, r, alpha, done);
     hipLaunchKernelGGL(grp_iou_kernel, dim3((unsigned)max_iou_blocks, 2 * maxS, rc), dim3(256), 0, st, (const GroupRefDev*)tab, rc,
                        (unsigned long long*)cum, done);
