@@ -62,19 +62,14 @@ struct RowScan {
   int prev_last_start;    // its run start (valid when prev_last)
   uint8_t v[CCL_STEPS + 1];   // working flags of this lane's pixel in each step of the group (+ the first of the next group)
   unsigned lo_mask, hi_mask;  // bits of the lanes below this one, per 32-bit half of a ballot
-  int nsb;                // run starts of this row in the steps done so far (wave-uniform)
-  int prev_last_ord;      // run ordinal of the column just left of the current step (valid when prev_last)
   // per step
   bool work;              // this lane's pixel is a working pixel
   unsigned long long wb;  // ballot of `work`
   int start;              // run start column of this lane's pixel (valid when work)
   bool left, right;       // working bits of the columns just left / right of this lane's pixel
-  unsigned long long sb;  // ballot of "a run starts at this lane's pixel"
-  int ord;                // ordinal of this lane's run within its row, 0-based (valid when work): run id = rowbase[row] + ord
-  int ord_next;           // ordinal a run starting at the NEXT column would have (= run starts up to and including this column)
 
   __device__ __forceinline__ void init(const uint8_t* r, int W_, int holes_, int lane) {
-    row = r; W = W_; holes = holes_; carry = -1; prev_last = false; prev_last_start = 0; nsb = 0; prev_last_ord = 0;
+    row = r; W = W_; holes = holes_; carry = -1; prev_last = false; prev_last_start = 0;
     lo_mask = lane < 32 ? (1u << lane) - 1u : 0xffffffffu;
     hi_mask = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
   }
@@ -101,18 +96,11 @@ struct RowScan {
     const bool next0 = (__shfl((int)v[k + 1], 0) != 0) != (holes != 0);   // lane 0 of the next step (or the look-ahead byte)
     left = lane > 0 ? up != 0 : prev_last;
     right = lane < 63 ? dn != 0 : next0;
-    const bool st = work && !left;
-    sb = __ballot(st);
-    const int lt = __popc((unsigned)sb & lo_mask) + __popc((unsigned)(sb >> 32) & hi_mask);
-    ord_next = nsb + lt + (st ? 1 : 0);
-    ord = ord_next - 1;
   }
   __device__ __forceinline__ void advance(int x0) {
     const unsigned long long nb = ~wb;
     prev_last = (wb >> 63) != 0;
     prev_last_start = __shfl(start, 63);
-    prev_last_ord = __shfl(ord, 63);
-    nsb += __popcll(sb);
     if (nb) carry = x0 + 63 - __clzll(nb);                 // (all 64 working: the carry stays)
   }
 };
@@ -126,89 +114,49 @@ struct RowScan {
     }                                                                     \
   }
 
-// Run ids.  The union-find and the areas live in arrays indexed by RUN, not by pixel: run k of row r has the id
-// rowbase[r] + k, rowbase = the exclusive prefix sum of the rows' run counts -- ids ascend in raster order of the runs' first
-// pixels, which is the order the reference's labels have.  (Until round 5 a run was identified by the pixel index of its first
-// pixel: two int planes of N*H*W entries, 105 MB each at 64 x 640 x 640, touched wherever a run starts -- the passes moved 3-6
-// times the mask bytes, almost all of it those planes.  The dense arrays are 4 bytes per run and stay in L2 / the Infinity
-// Cache.)
-// Pass A -- the number of runs of every row.
-__global__ __launch_bounds__(256) void ccl_runs_kernel(const uint8_t* __restrict__ masks, int holes, int W, long long rows,
-                                                       int* __restrict__ rowcnt) {
+// Pass A -- every run start becomes its own parent and gets a zero area.
+__global__ __launch_bounds__(256) void ccl_rows_kernel(const uint8_t* __restrict__ masks, int holes, int W,
+                                                       long long rows, int* __restrict__ L,
+                                                       int* __restrict__ area) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const long long base = row * W;
   RowScan c;
-  c.init(masks + row * W, W, holes, lane);
+  c.init(masks + base, W, holes, lane);
   CCL_FOR_STEPS(c.load(g0, lane), {
     c.step(k, x0, lane);
+    if (c.work && !c.left) {
+      L[base + x0 + lane] = (int)(base + x0 + lane);
+      area[base + x0 + lane] = 0;
+    }
     c.advance(x0);
   })
-  if (lane == 0) rowcnt[row] = c.nsb;
-}
-
-// exclusive prefix sum of rowcnt over all rows (ONE workgroup of 1024 threads walks the rows in chunks of 1024; 40 960 rows at
-// 64 x 640: forty chunks); rowbase[rows] = the number of runs
-__global__ __launch_bounds__(1024) void ccl_scan_kernel(const int* __restrict__ rowcnt, long long rows, int* __restrict__ rowbase) {
-  __shared__ int wsum[16];
-  __shared__ int carry_s;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t == 0) carry_s = 0;
-  __syncthreads();
-  for (long long r0 = 0; r0 < rows; r0 += 1024) {
-    const long long r = r0 + t;
-    const int v = r < rows ? rowcnt[r] : 0;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o);
-      if (lane >= o) incl += u;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int before = carry_s;
-    for (int w = 0; w < wave; ++w) before += wsum[w];
-    if (r < rows) rowbase[r] = before + incl - v;
-    __syncthreads();
-    if (t == 1023) carry_s = before + incl;
-    __syncthreads();
-  }
-  if (t == 0) rowbase[rows] = carry_s;
-}
-
-// every run its own parent, zero area (grid-stride over the run count, which only the device knows)
-__global__ __launch_bounds__(256) void ccl_init_kernel(const int* __restrict__ nruns, int* __restrict__ L, int* __restrict__ area) {
-  const int n = *nruns;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    L[i] = i;
-    area[i] = 0;
-  }
 }
 
 // Pass B -- links between the runs of adjacent rows (8-connectivity).  A link is issued only at the first column
 // where two runs touch (not implied by a contact one column to the left), so a blob costs O(1) unions per row.
 __global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t* __restrict__ masks, int holes, int* __restrict__ L, int H,
-                                                        int W, long long rows, const int* __restrict__ rowbase) {
+                                                        int W, long long rows) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
   if (row >= rows || (int)(row % H) + 1 >= H) return;
   const long long base = row * W;
-  const int cb = rowbase[row], db = rowbase[row + 1];      // ids of the first runs of this row and of the row below
   RowScan c, d;
   c.init(masks + base, W, holes, lane);
   d.init(masks + base + W, W, holes, lane);
   CCL_FOR_STEPS(c.load(g0, lane); d.load(g0, lane), {
     c.step(k, x0, lane);
     d.step(k, x0, lane);
-    const int d_up = __shfl_up(d.ord, 1);                                  // (every lane takes part in the shuffle)
-    const int d_left_ord = lane > 0 ? d_up : d.prev_last_ord;               // run of the below-left pixel
+    const int d_up = __shfl_up(d.start, 1);                                // (every lane takes part in the shuffle)
+    const int d_left_start = lane > 0 ? d_up : d.prev_last_start;           // run start of the below-left pixel
     if (c.work) {
-      const int me = cb + c.ord;
+      const int me = (int)(base + c.start);
       const bool s = d.work, sw = d.left, se = d.right, w = c.left, e = c.right;
-      if (s && !(w && sw)) uf_union(L, me, db + d.ord);
+      if (s && !(w && sw)) uf_union(L, me, (int)(base + W + d.start));
       if (!s) {
-        if (sw && !w) uf_union(L, me, db + d_left_ord);
-        if (se && !e) uf_union(L, me, db + d.ord_next);   // below is not working: a run starts at the next column, with this ordinal
+        if (sw && !w) uf_union(L, me, (int)(base + W + d_left_start));
+        if (se && !e) uf_union(L, me, (int)(base + W + x0 + lane + 1));   // below is not working: the run starts there
       }
     }
     c.advance(x0);
@@ -232,12 +180,11 @@ __device__ __forceinline__ int wave_sum(int v) {
 // scan of the mask bytes and one launch more per call, 0.96 against 0.86 ms per ref for the six / five passes.  The unions are
 // over when this pass runs, so roots no longer move; concurrent halving by other waves only shortens chains.
 __global__ __launch_bounds__(256) void ccl_count_kernel(const uint8_t* __restrict__ masks, int holes, int* __restrict__ L,
-                                                        int* __restrict__ area, int W, long long rows, const int* __restrict__ rowbase) {
+                                                        int* __restrict__ area, int W, long long rows) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
   if (row >= rows) return;
   const long long base = row * W;
-  const int rb = rowbase[row];
   RowScan c;
   c.init(masks + base, W, holes, lane);
   int acc_root = -1, acc_sum = 0;      // wave-uniform
@@ -246,7 +193,7 @@ __global__ __launch_bounds__(256) void ccl_count_kernel(const uint8_t* __restric
     bool act = c.work && !c.right;
     int r = -1;
     if (act) {
-      const int i = rb + c.ord;
+      const int i = (int)(base + c.start);
       r = uf_find_compress(L, i);
       if (r != i) L[i] = r;      // (a plain store: links only ever move towards the root, and r IS the root now)
     }
@@ -283,12 +230,11 @@ __global__ __launch_bounds__(256) void ccl_count_kernel(const uint8_t* __restric
 // three atomics per row, not three per component (a speckled mask has tens of thousands).
 __global__ __launch_bounds__(256) void ccl_stats_kernel(const uint8_t* __restrict__ masks, int holes, const int* __restrict__ L,
                                                         const int* __restrict__ area, int W, long long HW, long long rows,
-                                                        int thresh, int* __restrict__ stats, const int* __restrict__ rowbase) {
+                                                        int thresh, int* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
   if (row >= rows) return;
   const long long base = row * W;
-  const int rb = rowbase[row];
   RowScan c;
   c.init(masks + base, W, holes, lane);
   int n_small = 0, n_large = 0;
@@ -296,7 +242,7 @@ __global__ __launch_bounds__(256) void ccl_stats_kernel(const uint8_t* __restric
   CCL_FOR_STEPS(c.load(g0, lane), {
     c.step(k, x0, lane);
     if (c.work && !c.left) {
-      const int i = rb + c.ord;
+      const int i = (int)(base + x0 + lane);
       if (L[i] == i) {
         const int a = area[i];
         if (a < thresh) ++n_small; else ++n_large;
@@ -335,7 +281,7 @@ __global__ __launch_bounds__(256) void ccl_apply_kernel(const uint8_t* __restric
                                                         const int* __restrict__ area, const int* __restrict__ stats,
                                                         int holes, int H, int W, long long rows, int thresh,
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ changed,
-                                                        int* __restrict__ boxes, const int* __restrict__ rowbase) {
+                                                        int* __restrict__ boxes) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -373,7 +319,6 @@ __global__ __launch_bounds__(256) void ccl_apply_kernel(const uint8_t* __restric
   }
   const bool any_large = stats[n * 4 + 1] > 0;
   const int best = 0x7fffffff - stats[n * 4 + 2];
-  const int rb = rowbase[row];
   RowScan c;
   c.init(masks + base, W, holes, lane);
   CCL_FOR_STEPS(c.load(g0, lane), {
@@ -383,7 +328,7 @@ __global__ __launch_bounds__(256) void ccl_apply_kernel(const uint8_t* __restric
     if (x < W) {
       const bool m = c.v[k] != 0;
       int r = -1;
-      if (c.work) r = L[rb + c.ord];         // the run's entry holds the root (or is the root)
+      if (c.work) r = L[base + c.start];     // the run start holds the root (or is the root)
       if (holes) o = m || (r >= 0 && area[r] < thresh);
       else o = r >= 0 && (any_large ? area[r] >= thresh : r == best);
       out[base + x] = o ? 1 : 0;
@@ -470,10 +415,8 @@ extern "C" {
 
 size_t hgl_remove_small_regions_workspace_bytes(int N, int H, int W) {
   const size_t px = (size_t)N * H * W;
-  // L and area per RUN (at most ceil(W / 2) runs per row; the old per-pixel planes' size is kept as the query's answer: callers
-  // sized their arenas with it), stats, the per-row box words, the rows' run counts and their prefix sums
   return hgl_align_up(px * sizeof(int), 256) * 2 + hgl_align_up((size_t)N * 4 * sizeof(int), 256) +
-         hgl_align_up((size_t)N * H * sizeof(unsigned), 256) + 2 * hgl_align_up(((size_t)N * H + 1) * sizeof(int), 256);
+         hgl_align_up((size_t)N * H * sizeof(unsigned), 256);      // L, area, stats, the per-row box words
 }
 
 static int remove_small_regions_impl(const uint8_t* masks, int N, int H, int W, int area_thresh, int holes, uint8_t* out,
@@ -509,19 +452,15 @@ static int remove_small_regions_impl(const uint8_t* masks, int N, int H, int W, 
   unsigned* rowbox = ar.take<unsigned>((size_t)N * H);
   const long long HW = (long long)H * W;
   const long long rows = (long long)N * H;
-  int* rowcnt = ar.take<int>((size_t)rows + 1);
-  int* rowbase = ar.take<int>((size_t)rows + 1);
   const dim3 grid((unsigned)((rows + 3) / 4));
-  hipLaunchKernelGGL(ccl_runs_kernel, grid, dim3(256), 0, st, masks, holes, W, rows, rowcnt);
-  hipLaunchKernelGGL(ccl_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)rowcnt, rows, rowbase);
-  hipLaunchKernelGGL(ccl_init_kernel, dim3(1024), dim3(256), 0, st, (const int*)(rowbase + rows), L, area);
+  hipLaunchKernelGGL(ccl_rows_kernel, grid, dim3(256), 0, st, masks, holes, W, rows, L, area);
   hipLaunchKernelGGL(ccl_stats_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stats, N, (int*)nullptr);
-  hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, st, masks, holes, L, H, W, rows, (const int*)rowbase);
-  hipLaunchKernelGGL(ccl_count_kernel, grid, dim3(256), 0, st, masks, holes, L, area, W, rows, (const int*)rowbase);
+  hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, st, masks, holes, L, H, W, rows);
+  hipLaunchKernelGGL(ccl_count_kernel, grid, dim3(256), 0, st, masks, holes, L, area, W, rows);
   hipLaunchKernelGGL(ccl_stats_kernel, grid, dim3(256), 0, st, masks, holes, (const int*)L, (const int*)area, W, HW, rows,
-                     area_thresh, stats, (const int*)rowbase);
+                     area_thresh, stats);
   hipLaunchKernelGGL(ccl_apply_kernel, grid, dim3(256), 0, st, masks, (const int*)L, (const int*)area, (const int*)stats, holes,
-                     H, W, rows, area_thresh, out, changed, boxes_xyxy ? (int*)rowbox : nullptr, (const int*)rowbase);
+                     H, W, rows, area_thresh, out, changed, boxes_xyxy ? (int*)rowbox : nullptr);
   if (boxes_xyxy) hipLaunchKernelGGL(box_rows_kernel, dim3(N), dim3(64), 0, st, (const unsigned*)rowbox, H, (int*)boxes_xyxy);
   return hgl_check_launch("remove_small_regions");
 }
