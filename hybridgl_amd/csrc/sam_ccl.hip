@@ -114,14 +114,56 @@ struct RowScan {
     }                                                                     \
   }
 
-// Pass A -- every run start becomes its own parent and gets a zero area.
+// The same scan over a row of WORKING BITS (64 pixels per 8-byte word, written once by pass A): the passes after the first read
+// an eighth of the bytes, the wave fetches a step's word with one scalar load, and a lane's neighbours come out of the word
+// by shifts -- no ballot, no wave shuffles.  Bits beyond the row's width are 0 (not working).  Same fields as RowScan.
+struct BitScan {
+  const unsigned long long* bits;   // the row's words (wave-uniform pointer)
+  int W, carry;
+  bool prev_last;
+  int prev_last_start;
+  unsigned lo_mask, hi_mask;
+  bool work;
+  unsigned long long wb;
+  int start;
+  bool left, right;
+  __device__ __forceinline__ void init(const unsigned long long* b, int W_, int lane) {
+    bits = b; W = W_; carry = -1; prev_last = false; prev_last_start = 0;
+    lo_mask = lane < 32 ? (1u << lane) - 1u : 0xffffffffu;
+    hi_mask = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
+  }
+  __device__ __forceinline__ void load(int, int) {}
+  __device__ __forceinline__ void step(int, int x0, int lane) {
+    const int wi = x0 >> 6;
+    wb = bits[wi];
+    const unsigned long long nextw = x0 + 64 < W ? bits[wi + 1] : 0ull;
+    work = ((wb >> lane) & 1ull) != 0;
+    const unsigned blo = ~(unsigned)wb & lo_mask, bhi = ~(unsigned)(wb >> 32) & hi_mask;
+    int last = carry;
+    if (blo) last = x0 + 31 - __clz(blo);
+    if (bhi) last = x0 + 63 - __clz(bhi);
+    start = last + 1;
+    left = lane > 0 ? ((wb >> (lane - 1)) & 1ull) != 0 : prev_last;
+    right = lane < 63 ? ((wb >> (lane + 1)) & 1ull) != 0 : (nextw & 1ull) != 0;
+  }
+  __device__ __forceinline__ void advance(int x0) {
+    const unsigned long long nb = ~wb;
+    prev_last = (wb >> 63) != 0;
+    prev_last_start = __builtin_amdgcn_readlane(start, 63);
+    if (nb) carry = x0 + 63 - __clzll(nb);
+  }
+};
+__device__ __forceinline__ long long ccl_words(int W) { return (W + 63) >> 6; }
+
+// Pass A -- every run start becomes its own parent and gets a zero area; the row's working bits go to the bit plane.
 __global__ __launch_bounds__(256) void ccl_rows_kernel(const uint8_t* __restrict__ masks, int holes, int W,
                                                        long long rows, int* __restrict__ L,
-                                                       int* __restrict__ area) {
+                                                       int* __restrict__ area, unsigned long long* __restrict__ bits) {
   const int lane = threadIdx.x & 63;
   const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
   if (row >= rows) return;
   const long long base = row * W;
+  unsigned long long* brow = bits + row * ccl_words(W);
   RowScan c;
   c.init(masks + base, W, holes, lane);
   CCL_FOR_STEPS(c.load(g0, lane), {
@@ -130,21 +172,22 @@ __global__ __launch_bounds__(256) void ccl_rows_kernel(const uint8_t* __restrict
       L[base + x0 + lane] = (int)(base + x0 + lane);
       area[base + x0 + lane] = 0;
     }
+    if (lane == 0) brow[x0 >> 6] = c.wb;      // (pixels beyond the row are non-working: RowScan::load)
     c.advance(x0);
   })
 }
 
 // Pass B -- links between the runs of adjacent rows (8-connectivity).  A link is issued only at the first column
 // where two runs touch (not implied by a contact one column to the left), so a blob costs O(1) unions per row.
-__global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t* __restrict__ masks, int holes, int* __restrict__ L, int H,
+__global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned long long* __restrict__ bits, int* __restrict__ L, int H,
                                                         int W, long long rows) {
   const int lane = threadIdx.x & 63;
-  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  const long long row = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (row >= rows || (int)(row % H) + 1 >= H) return;
   const long long base = row * W;
-  RowScan c, d;
-  c.init(masks + base, W, holes, lane);
-  d.init(masks + base + W, W, holes, lane);
+  BitScan c, d;
+  c.init(bits + row * ccl_words(W), W, lane);
+  d.init(bits + (row + 1) * ccl_words(W), W, lane);
   CCL_FOR_STEPS(c.load(g0, lane); d.load(g0, lane), {
     c.step(k, x0, lane);
     d.step(k, x0, lane);
@@ -179,14 +222,14 @@ __device__ __forceinline__ int wave_sum(int v) {
 // pass goes; the passes after it read a run's component with ONE load).  Until round 5 that was a pass of its own ("C"): one
 // scan of the mask bytes and one launch more per call, 0.96 against 0.86 ms per ref for the six / five passes.  The unions are
 // over when this pass runs, so roots no longer move; concurrent halving by other waves only shortens chains.
-__global__ __launch_bounds__(256) void ccl_count_kernel(const uint8_t* __restrict__ masks, int holes, int* __restrict__ L,
+__global__ __launch_bounds__(256) void ccl_count_kernel(const unsigned long long* __restrict__ bits, int* __restrict__ L,
                                                         int* __restrict__ area, int W, long long rows) {
   const int lane = threadIdx.x & 63;
-  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  const long long row = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (row >= rows) return;
   const long long base = row * W;
-  RowScan c;
-  c.init(masks + base, W, holes, lane);
+  BitScan c;
+  c.init(bits + row * ccl_words(W), W, lane);
   int acc_root = -1, acc_sum = 0;      // wave-uniform
   CCL_FOR_STEPS(c.load(g0, lane), {
     c.step(k, x0, lane);
@@ -228,15 +271,15 @@ __global__ __launch_bounds__(256) void ccl_count_kernel(const uint8_t* __restric
 // largest area and, among equals, the smallest root -- the reference's "first largest" component (label order = raster
 // order of first pixels).  A wave's row belongs to ONE mask, so the counts and the key are reduced over the row first:
 // three atomics per row, not three per component (a speckled mask has tens of thousands).
-__global__ __launch_bounds__(256) void ccl_stats_kernel(const uint8_t* __restrict__ masks, int holes, const int* __restrict__ L,
+__global__ __launch_bounds__(256) void ccl_stats_kernel(const unsigned long long* __restrict__ bits, const int* __restrict__ L,
                                                         const int* __restrict__ area, int W, long long HW, long long rows,
                                                         int thresh, int* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
-  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  const long long row = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (row >= rows) return;
   const long long base = row * W;
-  RowScan c;
-  c.init(masks + base, W, holes, lane);
+  BitScan c;
+  c.init(bits + row * ccl_words(W), W, lane);
   int n_small = 0, n_large = 0;
   unsigned long long key = 0;
   CCL_FOR_STEPS(c.load(g0, lane), {
@@ -277,15 +320,16 @@ __global__ void ccl_stats_init_kernel(int* stats, int N, int* boxes) {
 
 // Pass F -- holes:   out = mask | (working && area < thresh)                      (fill small holes)
 //           islands: out = working && area >= thresh ; if no component is large, keep the (first) largest
-__global__ __launch_bounds__(256) void ccl_apply_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ L,
+__global__ __launch_bounds__(256) void ccl_apply_kernel(const unsigned long long* __restrict__ bits, const int* __restrict__ L,
                                                         const int* __restrict__ area, const int* __restrict__ stats,
                                                         int holes, int H, int W, long long rows, int thresh,
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ changed,
                                                         int* __restrict__ boxes) {
   const int lane = threadIdx.x & 63;
-  const long long row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  const long long row = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (row >= rows) return;
   const long long base = row * W;
+  const unsigned long long* brow = bits + row * ccl_words(W);
   const int n = (int)(row / H);
   const int n_small = stats[n * 4 + 0];
   if (row % H == 0 && lane == 0) changed[n] = n_small != 0;
@@ -310,7 +354,8 @@ __global__ __launch_bounds__(256) void ccl_apply_kernel(const uint8_t* __restric
   if (n_small == 0) {            // nothing below the threshold: mask unchanged (utils/amg.py:281-282)
     for (int x0 = 0; x0 < W; x0 += 64) {
       const int x = x0 + lane;
-      const bool o = x < W && masks[base + x] != 0;
+      const bool wk = ((brow[x0 >> 6] >> lane) & 1ull) != 0;      // the mask bit is the working bit (islands) or its complement (holes)
+      const bool o = x < W && (wk != (holes != 0));
       if (x < W) out[base + x] = o ? 1 : 0;
       if (boxes) row_bits(o, x0);
     }
@@ -319,14 +364,14 @@ __global__ __launch_bounds__(256) void ccl_apply_kernel(const uint8_t* __restric
   }
   const bool any_large = stats[n * 4 + 1] > 0;
   const int best = 0x7fffffff - stats[n * 4 + 2];
-  RowScan c;
-  c.init(masks + base, W, holes, lane);
+  BitScan c;
+  c.init(brow, W, lane);
   CCL_FOR_STEPS(c.load(g0, lane), {
     c.step(k, x0, lane);
     const int x = x0 + lane;
     bool o = false;
     if (x < W) {
-      const bool m = c.v[k] != 0;
+      const bool m = c.work != (holes != 0);
       int r = -1;
       if (c.work) r = L[base + c.start];     // the run start holds the root (or is the root)
       if (holes) o = m || (r >= 0 && area[r] < thresh);
@@ -416,7 +461,8 @@ extern "C" {
 size_t hgl_remove_small_regions_workspace_bytes(int N, int H, int W) {
   const size_t px = (size_t)N * H * W;
   return hgl_align_up(px * sizeof(int), 256) * 2 + hgl_align_up((size_t)N * 4 * sizeof(int), 256) +
-         hgl_align_up((size_t)N * H * sizeof(unsigned), 256);      // L, area, stats, the per-row box words
+         hgl_align_up((size_t)N * H * sizeof(unsigned), 256) +                        // L, area, stats, the per-row box words,
+         hgl_align_up((size_t)N * H * ((W + 63) / 64) * sizeof(unsigned long long), 256);   // the working-bit plane
 }
 
 static int remove_small_regions_impl(const uint8_t* masks, int N, int H, int W, int area_thresh, int holes, uint8_t* out,
@@ -450,16 +496,18 @@ static int remove_small_regions_impl(const uint8_t* masks, int N, int H, int W, 
   int* area = ar.take<int>((size_t)total);
   int* stats = ar.take<int>((size_t)N * 4);
   unsigned* rowbox = ar.take<unsigned>((size_t)N * H);
+  unsigned long long* bits = ar.take<unsigned long long>((size_t)N * H * ((W + 63) / 64));
   const long long HW = (long long)H * W;
   const long long rows = (long long)N * H;
   const dim3 grid((unsigned)((rows + 3) / 4));
-  hipLaunchKernelGGL(ccl_rows_kernel, grid, dim3(256), 0, st, masks, holes, W, rows, L, area);
+  const unsigned long long* cbits = bits;
+  hipLaunchKernelGGL(ccl_rows_kernel, grid, dim3(256), 0, st, masks, holes, W, rows, L, area, bits);
   hipLaunchKernelGGL(ccl_stats_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stats, N, (int*)nullptr);
-  hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, st, masks, holes, L, H, W, rows);
-  hipLaunchKernelGGL(ccl_count_kernel, grid, dim3(256), 0, st, masks, holes, L, area, W, rows);
-  hipLaunchKernelGGL(ccl_stats_kernel, grid, dim3(256), 0, st, masks, holes, (const int*)L, (const int*)area, W, HW, rows,
+  hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, st, cbits, L, H, W, rows);
+  hipLaunchKernelGGL(ccl_count_kernel, grid, dim3(256), 0, st, cbits, L, area, W, rows);
+  hipLaunchKernelGGL(ccl_stats_kernel, grid, dim3(256), 0, st, cbits, (const int*)L, (const int*)area, W, HW, rows,
                      area_thresh, stats);
-  hipLaunchKernelGGL(ccl_apply_kernel, grid, dim3(256), 0, st, masks, (const int*)L, (const int*)area, (const int*)stats, holes,
+  hipLaunchKernelGGL(ccl_apply_kernel, grid, dim3(256), 0, st, cbits, (const int*)L, (const int*)area, (const int*)stats, holes,
                      H, W, rows, area_thresh, out, changed, boxes_xyxy ? (int*)rowbox : nullptr);
   if (boxes_xyxy) hipLaunchKernelGGL(box_rows_kernel, dim3(N), dim3(64), 0, st, (const unsigned*)rowbox, H, (int*)boxes_xyxy);
   return hgl_check_launch("remove_small_regions");
