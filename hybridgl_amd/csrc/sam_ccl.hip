@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void ccl_rows_kernel(const uint8_t* __restrict
   c.init(masks + base, W, holes, lane);
   CCL_FOR_STEPS(c.load(g0, lane), {
     c.step(k, x0, lane);
-    if (c.work && !c.left) {
+    if (L != nullptr && c.work && !c.left) {      // (nullptr: ccl_strip_kernel files the run starts)
       L[base + x0 + lane] = (int)(base + x0 + lane);
       area[base + x0 + lane] = 0;
     }
@@ -177,12 +177,81 @@ __global__ __launch_bounds__(256) void ccl_rows_kernel(const uint8_t* __restrict
   })
 }
 
+// Pass A' -- a STRIP of up to CCL_STRIP rows of one mask per workgroup: the runs of the strip are linked among themselves in
+// LDS (the same lock-free union-find, on an int array indexed by the pixel's offset in the strip), then every run start gets
+// its strip-local root as its parent in the global plane.  What is left for the global pass B are the row pairs that straddle
+// two strips: a sixteenth of the unions, and the chains the later finds walk start flattened.  (Pass B over ALL row pairs was
+// the longest kernel of the clean-up: 185 us per call on speckle masks, every union a chain of device-scope atomic round trips.)
+constexpr int CCL_STRIP = 16;
+constexpr int CCL_STRIP_PIX = 12288;      // LDS ints (48 KiB): strips of rows up to 768 pixels hold 16 rows, wider rows fewer
+__global__ __launch_bounds__(256) void ccl_strip_kernel(const unsigned long long* __restrict__ bits, int H, int W, int strip_rows,
+                                                        int strips_per_mask, int* __restrict__ L, int* __restrict__ area) {
+  __shared__ int Ls[CCL_STRIP_PIX];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n = blockIdx.x / strips_per_mask, sidx = blockIdx.x - n * strips_per_mask;
+  const int r0 = sidx * strip_rows, nr = min(strip_rows, H - r0);
+  const long long srow = (long long)n * H + r0;             // the strip's first row
+  const long long sbase = srow * W;                         // ... and first pixel
+  const long long wq = ccl_words(W);
+  for (int i = threadIdx.x; i < nr * W; i += 256) Ls[i] = i;      // every pixel its own parent (only run starts are ever read)
+  __syncthreads();
+  // the row pairs inside the strip (pass B's contact rules)
+  for (int r = wave; r + 1 < nr; r += 4) {
+    const int base = r * W;
+    BitScan c, d;
+    c.init(bits + (srow + r) * wq, W, lane);
+    d.init(bits + (srow + r + 1) * wq, W, lane);
+    CCL_FOR_STEPS(c.load(g0, lane); d.load(g0, lane), {
+      c.step(k, x0, lane);
+      d.step(k, x0, lane);
+      const int d_up = __shfl_up(d.start, 1);
+      const int d_left_start = lane > 0 ? d_up : d.prev_last_start;
+      if (c.work) {
+        const int me = base + c.start;
+        const bool s = d.work, sw = d.left, se = d.right, w = c.left, e = c.right;
+        if (s && !(w && sw)) uf_union(Ls, me, base + W + d.start);
+        if (!s) {
+          if (sw && !w) uf_union(Ls, me, base + W + d_left_start);
+          if (se && !e) uf_union(Ls, me, base + W + x0 + lane + 1);
+        }
+      }
+      c.advance(x0);
+      d.advance(x0);
+    })
+  }
+  __syncthreads();
+  // run start -> its strip-local root, as a global pixel index; zero areas
+  for (int r = wave; r < nr; r += 4) {
+    BitScan c;
+    c.init(bits + (srow + r) * wq, W, lane);
+    CCL_FOR_STEPS(c.load(g0, lane), {
+      c.step(k, x0, lane);
+      if (c.work && !c.left) {
+        const int i = r * W + x0 + lane;
+        L[sbase + i] = (int)(sbase + uf_find(Ls, i));
+        area[sbase + i] = 0;
+      }
+      c.advance(x0);
+    })
+  }
+}
+
 // Pass B -- links between the runs of adjacent rows (8-connectivity).  A link is issued only at the first column
 // where two runs touch (not implied by a contact one column to the left), so a blob costs O(1) unions per row.
+// strip_rows > 0: the row pairs inside a strip were linked by ccl_strip_kernel; wave w takes the w-th pair that straddles two
+// strips (rows strip_rows - 1 | strip_rows, 2 strip_rows - 1 | 2 strip_rows, ... of every mask).
 __global__ __launch_bounds__(256) void ccl_merge_kernel(const unsigned long long* __restrict__ bits, int* __restrict__ L, int H,
-                                                        int W, long long rows) {
+                                                        int W, long long rows, int strip_rows) {
   const int lane = threadIdx.x & 63;
-  const long long row = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  long long row = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (strip_rows > 0) {
+    const int per_mask = (H - 1) / strip_rows;             // strip boundaries inside one mask
+    if (per_mask <= 0) return;
+    const long long n = row / per_mask;
+    const int b = (int)(row - n * per_mask);
+    if (n * H >= rows) return;
+    row = n * H + (long long)(b + 1) * strip_rows - 1;
+  }
   if (row >= rows || (int)(row % H) + 1 >= H) return;
   const long long base = row * W;
   BitScan c, d;
@@ -501,9 +570,20 @@ static int remove_small_regions_impl(const uint8_t* masks, int N, int H, int W, 
   const long long rows = (long long)N * H;
   const dim3 grid((unsigned)((rows + 3) / 4));
   const unsigned long long* cbits = bits;
-  hipLaunchKernelGGL(ccl_rows_kernel, grid, dim3(256), 0, st, masks, holes, W, rows, L, area, bits);
+  // strips of rows linked in LDS, then only the pairs between strips globally (rows too wide for the LDS plane: the global pass alone)
+  const int strip_rows = W <= CCL_STRIP_PIX / 2 ? (CCL_STRIP_PIX / W < CCL_STRIP ? CCL_STRIP_PIX / W : CCL_STRIP) : 0;
   hipLaunchKernelGGL(ccl_stats_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stats, N, (int*)nullptr);
-  hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, st, cbits, L, H, W, rows);
+  if (strip_rows >= 2) {
+    const int strips = (H + strip_rows - 1) / strip_rows;
+    hipLaunchKernelGGL(ccl_rows_kernel, grid, dim3(256), 0, st, masks, holes, W, rows, (int*)nullptr, (int*)nullptr, bits);
+    hipLaunchKernelGGL(ccl_strip_kernel, dim3((unsigned)(N * strips)), dim3(256), 0, st, cbits, H, W, strip_rows, strips, L, area);
+    const long long pairs = (long long)N * ((H - 1) / strip_rows);
+    if (pairs > 0)
+      hipLaunchKernelGGL(ccl_merge_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, cbits, L, H, W, rows, strip_rows);
+  } else {
+    hipLaunchKernelGGL(ccl_rows_kernel, grid, dim3(256), 0, st, masks, holes, W, rows, L, area, bits);
+    hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, st, cbits, L, H, W, rows, 0);
+  }
   hipLaunchKernelGGL(ccl_count_kernel, grid, dim3(256), 0, st, cbits, L, area, W, rows);
   hipLaunchKernelGGL(ccl_stats_kernel, grid, dim3(256), 0, st, cbits, (const int*)L, (const int*)area, W, HW, rows,
                      area_thresh, stats);
