@@ -863,6 +863,26 @@ def main():
                 dec["bytes_source"] = (f"profiles/{os.path.basename(dpaths[0])} (" + dj.get("source", "") + "), replayed -- not measured in this run")
             except Exception as e:
                 dec["bytes_source"] = f"profiles/{os.path.basename(dpaths[0])} unreadable: {e!r}"
+        # the same call with the generator's IoU gate (hgl_sam_decode_points_gated) at the MEDIAN of the prompts' best
+        # prediction: what a real pred_iou_thresh (0.86 in Hybridgl_main_PhraseCut.py:56-62) does to the decoder when about half
+        # the prompts fail it -- random weights need the open filters of the leg above, so the threshold is placed, not given
+        try:
+            _, iou_ = sam.decode_points(emb_, p01_)
+            thr_ = float(iou_.max(dim=1).values.median())
+            for _ in range(2):
+                sam.decode_points(emb_, p01_, iou_gate=thr_)
+            e0_.record()
+            for _ in range(4):
+                sam.decode_points(emb_, p01_, iou_gate=thr_)
+            e1_.record()
+            torch.cuda.synchronize()
+            gms = e0_.elapsed_time(e1_) / 4
+            dec["iou_gate_at_median"] = {"ms_per_64_prompts": gms / 8, "ms_per_image_at_8192_prompts": gms * 16,
+                                         "prompts_skipping_the_upscaling": float((~(iou_ > thr_).any(dim=1)).float().mean()),
+                                         "note": "candidates identical with the gate on and off (tests/test_gpu_sam.py::"
+                                                 "test_decoder_iou_gate_leaves_the_candidates_unchanged)"}
+        except Exception as e:
+            dec["iou_gate_at_median"] = {"error": repr(e)[:200]}
         also["PhraseCut"]["decoder"] = dec
         del emb_, p01_
         del gen_pc, pc_refs

@@ -169,6 +169,7 @@ PROTOTYPES = {
     "hgl_sam_dense_pe": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _VP]),
     "hgl_sam_decode_workspace_bytes": (_SZ, [C.POINTER(HglSamDecoderW), _I]),
     "hgl_sam_decode_points": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "hgl_sam_decode_points_gated": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _I, C.c_float, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_sam_decode_prompts": (_I, [C.POINTER(HglSamDecoderW), _VP, _VP, _VP, _I, _VP, _I, _I, _VP, _VP, _VP, _SZ, _VP]),
     "hgl_sam_embed_masks": (_I, [C.POINTER(HglSamDecoderW), _VP, _I, _VP, _VP]),
     "hgl_sam_decoder_fusion": (_I, [_I]),
@@ -206,7 +207,7 @@ PROTOTYPES = {
 }
 
 _lib = None
-ABI_VERSION = 6   # include/hybridgl.h HGL_ABI_VERSION
+ABI_VERSION = 7   # include/hybridgl.h HGL_ABI_VERSION
 
 
 def load():

@@ -280,7 +280,7 @@ int hgl_launch_pe_labeled(const float* coords01, const int32_t* labels, const fl
 // fused decoder stages (sam_decoder_fused.hip)
 int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0_w, const float* up0_b, const float* ln_w,
                         const float* ln_b, const float* up3_w, const float* up3_b, const float* hyper, int row0, int P, int g,
-                        float eps, float* low_res, hipStream_t st);
+                        float eps, float* low_res, const uint8_t* skip, hipStream_t st);
 int hgl_launch_dec_i2t(const float* q, int ldq, long long q_bstride, const float* k1, const float* v1, const float* out_w,
                        const float* out_b, const float* R, long long r_bstride, const float* ln_w, const float* ln_b, float eps,
                        float scale, int P, int HW, float* out32, void* out_hi, void* out_lo, hipStream_t st);

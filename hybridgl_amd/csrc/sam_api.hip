@@ -251,6 +251,7 @@ attention_done:
 struct DecPlan {
   float *coords, *sparse, *tokens, *queries, *qpe, *q1, *k1, *v1, *att, *keys0, *kpe0, *keys, *kpe, *kp, *vp,
       *qi, *atti, *mlp, *u1, *u2, *hy_a, *hy_b, *hyper, *iou_a, *iou_b, *keysS;
+  uint8_t* skip;      // IoU gate: prompts whose upscaling is skipped
 };
 
 bool carve_dec(HglArena& ar, const HglSamDecoderW* w, int P, DecPlan& p) {
@@ -281,6 +282,7 @@ bool carve_dec(HglArena& ar, const HglSamDecoderW* w, int P, DecPlan& p) {
   p.keysS = ar.take<float>(P * HW * C);        // f16x3 mode: the normalised image tokens as fp16 hi | lo planes
   p.iou_a = ar.take<float>((size_t)P * C);
   p.iou_b = ar.take<float>((size_t)P * C);
+  p.skip = ar.take<uint8_t>((size_t)P);
   return ar.ok();
 }
 
@@ -566,9 +568,18 @@ int hgl_sam_decoder_fusion(int mask) {
 // SamAutomaticMaskGenerator issues); else coords01 [P,n_sparse,2] / labels [P,n_sparse] with n_sparse = 2 .. 11 and, optionally,
 // dense [P,HW,C]: per-prompt dense embeddings (mask inputs) instead of no_mask_embed.  first_mask = 1: the three multimask
 // outputs (mask tokens 1..3); 0: tokens 0..2 (token 0 is the single-mask output, mask_decoder.py:99-105).
+// IoU gate (hgl_sam_decode_points_gated): skip[p] = none of prompt p's three quality predictions exceeds `gate` (NaN counts as
+// failing, as `iou_preds > thresh` does in automatic_mask_generator.py:287-288)
+__global__ void iou_gate_kernel(const float* __restrict__ iou, int P, float gate, uint8_t* __restrict__ skip) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  skip[p] = (iou[3 * p] > gate || iou[3 * p + 1] > gate || iou[3 * p + 2] > gate) ? 0 : 1;
+}
+
 static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* points01, const float* coords01,
                        const int32_t* labels, int n_sparse, const float* dense, int first_mask, int P, float* low_res,
-                       float* iou_pred, void* workspace, size_t workspace_bytes, void* stream) {
+                       float* iou_pred, void* workspace, size_t workspace_bytes, void* stream, bool gated = false,
+                       float iou_gate = 0.f) {
   HGL_TRY(hgl_require_device());
   HGL_REQUIRE(valid_dec(w) && w->dense_pe, "sam_decode: invalid weight struct (dense_pe missing?)");
   HGL_REQUIRE(emb && (points01 || (coords01 && labels)) && low_res && iou_pred && P > 0, "sam_decode: null input");
@@ -695,6 +706,20 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
   }
   HGL_TRY(hgl_launch_layernorm(p.queries, w->norm_final.w, w->norm_final.b, p.queries, P * T, C, 1e-5f, st));
 
+  // ---- IoU head on the iou token (row 0); multimask output = columns 1..3.  BEFORE the upscaling: the predictions depend on
+  // the token outputs only (mask_decoder.py:132-149), and the automatic generator drops every mask whose prediction does not
+  // exceed pred_iou_thresh (automatic_mask_generator.py:287-291) -- a prompt whose three predictions all fail needs no
+  // upscaling at all (the gate of hgl_sam_decode_points_gated) ----
+  HGL_TRY(lin(p.queries, T * C, w->iou_head[0], nullptr, 0, p.iou_a, C, P, C, C, HGL_ACT_RELU, st));
+  HGL_TRY(lin(p.iou_a, C, w->iou_head[1], nullptr, 0, p.iou_b, C, P, C, C, HGL_ACT_RELU, st));
+  HGL_TRY(lin(p.iou_b, C, w->iou_head[2], nullptr, 0, p.iou_a, 4, P, 4, C, HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_gather_rows(p.iou_a + first_mask, 4, P, 3, iou_pred, st));
+  const uint8_t* skip = nullptr;
+  if (gated) {
+    hipLaunchKernelGGL(iou_gate_kernel, dim3((P + 255) / 256), dim3(256), 0, st, (const float*)iou_pred, P, iou_gate, p.skip);
+    skip = p.skip;
+  }
+
   // ---- output upscaling: two ConvTranspose2d(k=2,s=2) as GEMMs, columns ordered (pos, out_channel) ----
   const int C4 = C / 4, C8 = C / 8;
   HGL_REQUIRE(C4 == 64, "sam_decode: LayerNorm2d width %d unsupported (64 expected)", C4);
@@ -710,7 +735,7 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
   const bool fused_tail = x3 && (dec_fusion_mask() & 1) && (HW % 64) == 0 && (g % 64 == 0 || 64 % g == 0) && P <= 65535;
   if (fused_tail) {
     HGL_TRY(hgl_launch_dec_tail(keysS.hi, keysS.lo, w->up0_w, w->up0_b, w->up1.w, w->up1.b, w->up3_w, w->up3_b, p.hyper, first_mask,
-                                P, g, 1e-6f, low_res, st));
+                                P, g, 1e-6f, low_res, skip, st));
   } else {
     if (x3) {
       HGL_TRY(hgl_launch_gemm_f16x3(keysS.hi, keysS.lo, C, w->up0_w, w->up0_b, nullptr, 0, p.u1, nullptr, nullptr, 4 * C4,
@@ -730,11 +755,6 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
     // [P,3,4g,4g] by the same kernel
     HGL_TRY(hgl_launch_hyper_logits(p.u2, p.hyper, P, g, first_mask, low_res, st));
   }
-  // ---- IoU head on the iou token (row 0); multimask output = columns 1..3 ----
-  HGL_TRY(lin(p.queries, T * C, w->iou_head[0], nullptr, 0, p.iou_a, C, P, C, C, HGL_ACT_RELU, st));
-  HGL_TRY(lin(p.iou_a, C, w->iou_head[1], nullptr, 0, p.iou_b, C, P, C, C, HGL_ACT_RELU, st));
-  HGL_TRY(lin(p.iou_b, C, w->iou_head[2], nullptr, 0, p.iou_a, 4, P, 4, C, HGL_ACT_NONE, st));
-  HGL_TRY(hgl_launch_gather_rows(p.iou_a + first_mask, 4, P, 3, iou_pred, st));
   return HGL_OK;
 }
 
@@ -742,6 +762,13 @@ int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float
                           float* iou_pred, void* workspace, size_t workspace_bytes, void* stream) {
   HGL_REQUIRE(points01, "sam_decode: null input");
   return decode_impl(w, emb, points01, nullptr, nullptr, 2, nullptr, 1, P, low_res, iou_pred, workspace, workspace_bytes, stream);
+}
+
+int hgl_sam_decode_points_gated(const HglSamDecoderW* w, const float* emb, const float* points01, int P, float iou_gate,
+                                float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes, void* stream) {
+  HGL_REQUIRE(points01, "sam_decode: null input");
+  return decode_impl(w, emb, points01, nullptr, nullptr, 2, nullptr, 1, P, low_res, iou_pred, workspace, workspace_bytes, stream, true,
+                     iou_gate);
 }
 
 int hgl_sam_decode_prompts(const HglSamDecoderW* w, const float* emb, const float* coords01, const int32_t* labels, int n_sparse,

@@ -46,6 +46,7 @@ struct TailArgs {
   int g, HW;
   int hrow0;                   // first of the three hyper-network rows multiplied (1: multimask tokens 1..3; 0: tokens 0..2)
   float* out;                  // [P, 3, 4g, 4g]
+  const uint8_t* skip;         // optional [P]: prompts whose rows of `out` nobody will read (IoU gate): their workgroups leave at once
 };
 
 // LDS image of an operand tile for the 16-row x 4-chunk fragment reads of v_mfma_f32_16x16x32_f16 (a lane reads row r,
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(512, 4) void dec_tail_kernel(TailArgs a) {
   const int r = lane & 15, h = lane >> 4;
   const int pos = wave & 3, half = wave >> 2;
   const int p = blockIdx.y, tile = blockIdx.x;
+  if (a.skip != nullptr && a.skip[p]) return;      // (uniform over the workgroup, before any barrier)
   const long long row0 = (long long)p * a.HW + (long long)tile * TAIL_ROWS;
 
   // ---- the tile's 64 rows x 256 channels, both planes, into the fragment image ----
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(512, 2) void dec_i2t_kernel(I2TArgs a) {
 // error string) when the geometry or the weights do not fit the kernel: the caller then takes the unfused launches.
 int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0_w, const float* up0_b, const float* ln_w,
                         const float* ln_b, const float* up3_w, const float* up3_b, const float* hyper, int row0, int P, int g,
-                        float eps, float* low_res, hipStream_t st) {
+                        float eps, float* low_res, const uint8_t* skip, hipStream_t st) {
   const void *w0h, *w0l, *w3h, *w3l;
   int s0 = 0, s3 = 0, n0 = 0, k0 = 0, n3 = 0, k3 = 0;
   const int HW = g * g;
@@ -627,7 +629,7 @@ int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0
   a.W0h = (const _Float16*)w0h; a.W0l = (const _Float16*)w0l; a.W3h = (const _Float16*)w3h; a.W3l = (const _Float16*)w3l;
   a.b0 = up0_b; a.ln_w = ln_w; a.ln_b = ln_b; a.b3 = up3_b; a.hyper = hyper;
   a.s0 = ldexpf(1.0f, -s0); a.s3 = ldexpf(1.0f, -s3); a.eps = eps;
-  a.g = g; a.HW = HW; a.hrow0 = row0; a.out = low_res;
+  a.g = g; a.HW = HW; a.hrow0 = row0; a.out = low_res; a.skip = skip;
   HGL_RESERVE_LDS((dec_tail_kernel), TAIL_LDS, "dec_tail");
   HglProfScope prof(HGL_PROF_OTHER, 2.0 * P * HW * (256.0 * 256 + 4 * 64.0 * 128), 0.0, st);
   hipLaunchKernelGGL(dec_tail_kernel, dim3((unsigned)(HW / TAIL_ROWS), (unsigned)P), dim3(512), TAIL_LDS, st, a);

@@ -235,8 +235,11 @@ class Sam:
                                        ops._stream()), "hgl_sam_encode_batch")
         return emb
 
-    def decode_points(self, emb, points01):
-        """points01: [P,2] fp32 device ((point+0.5)/img_size) -> (low_res [P,3,4g,4g], iou [P,3])."""
+    def decode_points(self, emb, points01, iou_gate=None):
+        """points01: [P,2] fp32 device ((point+0.5)/img_size) -> (low_res [P,3,4g,4g], iou [P,3]).
+        iou_gate: a pred_iou_thresh the caller will filter with (automatic_mask_generator.py:287-291): prompts none of whose
+        three predictions exceeds it skip the output upscaling -- their rows of low_res are unwritten memory, which the caller's
+        filter never reads (hgl_sam_decode_points_gated)."""
         lib = _lib.load()
         ops.use_precision(self.precision)
         P = points01.shape[0]
@@ -245,6 +248,12 @@ class Sam:
         g4 = 4 * self.grid
         low = torch.empty((P, 3, g4, g4), dtype=torch.float32, device=self.device)
         iou = torch.empty((P, 3), dtype=torch.float32, device=self.device)
+        if iou_gate is not None:
+            check(lib.hgl_sam_decode_points_gated(C.byref(self.dec_w), ops._dev(emb, torch.float32, "emb"),
+                                                  ops._dev(points01, torch.float32, "points01"), P, float(iou_gate), low.data_ptr(),
+                                                  iou.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()),
+                  "hgl_sam_decode_points_gated")
+            return low, iou
         check(lib.hgl_sam_decode_points(C.byref(self.dec_w), ops._dev(emb, torch.float32, "emb"),
                                         ops._dev(points01, torch.float32, "points01"), P, low.data_ptr(),
                                         iou.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()),
@@ -684,8 +693,11 @@ class SamAutomaticMaskGenerator:
                 cache.clear()
             p01 = cache[key] = torch.from_numpy(((tp + 0.5) / float(m.img_size)).astype(np.float32)).to(m.device)
         lows, ious = [], []
+        # the post-processing below drops every candidate whose prediction does not exceed pred_iou_thresh (when that is > 0:
+        # automatic_mask_generator.py:287-291): prompts that fail with all three masks skip the decoder's upscaling
+        gate = float(self.pred_iou_thresh) if self.pred_iou_thresh > 0 and getattr(self, "iou_gate", True) else None
         for s in range(0, len(pts), self.points_per_batch):
-            low, iou = m.decode_points(emb, p01[s:s + self.points_per_batch].contiguous())
+            low, iou = m.decode_points(emb, p01[s:s + self.points_per_batch].contiguous(), iou_gate=gate)
             lows.append(low.flatten(0, 1))
             ious.append(iou.flatten())
         low = lows[0] if len(lows) == 1 else torch.cat(lows)

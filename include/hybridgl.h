@@ -35,8 +35,9 @@ extern "C" {
 /* 2: + hgl_clip_hybrid_forward_segments, hgl_split_overflow_count, hgl_clip_encode_text_ex; hgl_gemm_f16x3_select
  * knows kinds -1, 0, 1 only
  * 5: + hgl_u8_to_chw_lut, hgl_split_overflow_peek_async, hgl_resize_bilinear, hgl_score_ref
- * 6: + hgl_attention_presplit, hgl_attention_presplit_f32, hgl_score_group, hgl_remove_small_regions_boxes */
-#define HGL_ABI_VERSION 6
+ * 6: + hgl_attention_presplit, hgl_attention_presplit_f32, hgl_score_group, hgl_remove_small_regions_boxes
+ * 7: + hgl_sam_decode_points_gated */
+#define HGL_ABI_VERSION 7
 
 /* activation codes for hgl_gemm_f32 */
 #define HGL_ACT_NONE 0
@@ -501,6 +502,14 @@ size_t hgl_sam_decode_workspace_bytes(const HglSamDecoderW* w, int P);
 int hgl_sam_decode_points(const HglSamDecoderW* w, const float* emb, const float* points01, int P,
                           float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* hgl_sam_decode_points with the IoU gate of the automatic generator: iou_pred depends on the token outputs only
+ * (mask_decoder.py:132-149), and SamAutomaticMaskGenerator drops every mask whose prediction does not exceed pred_iou_thresh
+ * (automatic_mask_generator.py:287-291) -- so the quality head runs first and a prompt none of whose three predictions
+ * exceeds `iou_gate` (NaN fails) skips the output upscaling: its rows of low_res are NOT written (the caller's filter never
+ * looks at them; hgl_sam_postprocess with the same threshold zeroes its masks).  iou_pred is complete either way.  The gate
+ * acts in the fused upscaling of the split-fp16 mode; elsewhere every prompt is upscaled. */
+int hgl_sam_decode_points_gated(const HglSamDecoderW* w, const float* emb, const float* points01, int P, float iou_gate,
+                                float* low_res, float* iou_pred, void* workspace, size_t workspace_bytes, void* stream);
 /* The same for the other prompt kinds of SamPredictor.predict_torch (predictor.py:169-243; PromptEncoder._embed_points /
  * _embed_boxes / _embed_masks, prompt_encoder.py:73-127): n_sparse = 2 .. 11 sparse tokens per prompt, coords01
  * [P,n_sparse,2] ((coordinate + 0.5) / img_size, computed by the caller in the dtype the reference would use), labels

@@ -42,7 +42,7 @@ def test_binding_table_matches_header(lib):
 
 def test_abi_version_and_error_string(lib):
     from hybridgl_amd import _lib
-    assert lib.hgl_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.hgl_abi_version() == _lib.ABI_VERSION == 7
     assert isinstance(lib.hgl_last_error(), bytes)
 
 

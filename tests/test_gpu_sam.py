@@ -314,6 +314,35 @@ def test_nms_with_nan_scores(cuda):
     assert idx.cpu().numpy()[: int(n.item())].tolist() == [0, 2]
 
 
+def test_decoder_iou_gate_leaves_the_candidates_unchanged(cuda, tiny):
+    """hgl_sam_decode_points_gated: the quality head first, prompts whose three predictions all fail pred_iou_thresh skip the
+    output upscaling.  The generator with the threshold at the median prediction returns the SAME proposals with the gate on
+    and off (masks, boxes, predictions, order); the gated decoder's iou_pred equals the plain call's bit for bit, its logits
+    equal it on every prompt that passes, and about half the prompts are skipped."""
+    c = sam_tiny_case()
+    sd, m = tiny
+    emb = m.encode(T(c["resized"], cuda))
+    rng = np.random.default_rng(3)
+    p01 = T(rng.random((97, 2)).astype(np.float32), cuda)
+    low0, iou0 = m.decode_points(emb, p01)
+    thr = float(iou0.max(dim=1).values.median())
+    low1, iou1 = m.decode_points(emb, p01, iou_gate=thr)
+    assert torch.equal(iou0, iou1)
+    passing = (iou0 > thr).any(dim=1)
+    assert 0.25 < float(passing.float().mean()) < 0.75
+    assert torch.equal(low0[passing], low1[passing])
+    kw = dict(points_per_side=6, pred_iou_thresh=thr, stability_score_thresh=0.0, crop_n_layers=0, min_mask_region_area=20,
+              box_nms_thresh=0.7)
+    gen = hsam.SamAutomaticMaskGenerator(m, **kw)
+    a = gen.generate(c["image"])
+    gen.iou_gate = False
+    b = gen.generate(c["image"])
+    assert len(a) == len(b) > 0
+    for x, y in zip(a, b):
+        assert np.array_equal(x["segmentation"], y["segmentation"]) and x["bbox"] == y["bbox"]
+        assert x["predicted_iou"] == y["predicted_iou"] and x["point_coords"] == y["point_coords"]
+
+
 def test_tiny_generate_vs_reference(cuda, g, tiny):
     c = sam_tiny_case()
     gen = hsam.SamAutomaticMaskGenerator(tiny[1], points_per_side=4, pred_iou_thresh=-1e9,
