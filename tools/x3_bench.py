@@ -12,6 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from hybridgl_amd import _lib, ops
+from _diag import use_lib_from_env
+
+use_lib_from_env()      # HGL_LIB_NAME=libhybridgl_diag.so: the experiment switches (HGL_X3_STAGGER, HGL_X3_GM, ...) are read
 
 SHAPES = [  # (name, M, N, K, act, residual)
     ("clip qkv", 25216, 2304, 768, "none", False),
