@@ -371,11 +371,14 @@ def hbm_kernel_specs(N=64, H=640, W=640, S=3, K=192, g=1):
         "sam_postprocess_sep_kernel": (K * 256 * 256 * 4 + K * px // 8, "read K*256^2*4 B of low-res logits, write K*H*W mask BITS (K18 "
                                                                        "minimal: 50.3 + 9.8 MB; the kernel writes bytes: 78.6 MB)"),
         "synth_views_kernel": (2 * N * 3 * 224 * 224 * 4 + 2 * px * 3 + N * px // 8, "write both views (77 MB) + sharp / blurred image + mask bits (K9)"),
-        "ccl_rows_kernel": (N * px, "mask bytes read once per pass"),
-        "ccl_merge_kernel": (N * px, "mask bytes read once per pass (two rows per wave: x2 through L2)"),
-        "ccl_count_kernel": (N * px, "mask bytes read once per pass"),
-        "ccl_stats_kernel": (N * px, "mask bytes read once per pass"),
-        "ccl_apply_kernel": (2 * N * px, "mask bytes read + cleaned bytes written (+ the boxes, from this round on)"),
+        # the clean-up (round 6): the first pass packs the working bits (one eighth of the mask bytes), every later pass scans
+        # bit rows; run links / areas live in int planes touched at run starts only (data-dependent: not in the algorithmic figure)
+        "ccl_rows_kernel": (N * px + N * px // 8, "mask bytes read once, working bits written"),
+        "ccl_strip_kernel": (N * px // 8, "bit plane read (strips of 16 rows linked in LDS; run links written at run starts)"),
+        "ccl_merge_kernel": (N * px // 8 // 8, "bit rows of the row pairs BETWEEN strips (an eighth of the rows, read as pairs)"),
+        "ccl_count_kernel": (N * px // 8, "bit plane read once"),
+        "ccl_stats_kernel": (N * px // 8, "bit plane read once"),
+        "ccl_apply_kernel": (N * px // 8 + N * px, "bit plane read + cleaned mask bytes written (+ the per-row box words)"),
         "blur_q8_h_kernel": (3 * px + 2 * 3 * px, "u8 image read, 16-bit row sums written"),
         "blur_q8_v_kernel": (2 * 3 * px + 3 * px, "16-bit row sums read, u8 image written"),
         "mask_resize_kernel": (N * 14 * 14 * 4 * 2, "4 taps per output of the 14 x 14 CLS keep maps (never the 26 MB of masks)"),
