@@ -819,8 +819,8 @@ def test_encoder_batch_of_eight_equals_single_images(cuda):
 
 @pytest.mark.parametrize("mode", ["holes", "islands"])
 def test_remove_small_regions_boxes_equal_mask_boxes_of_the_output(cuda, mode):
-    """hgl_remove_small_regions_boxes: the boxes that come out of the clean-up's last pass (row ballots + four atomics per
-    row) are batched_mask_to_box (utils/amg.py:303-346) of the masks it wrote -- blobs, speckle, an empty mask, a mask that
+    """hgl_remove_small_regions_boxes: the boxes that come out of the clean-up's last pass (row ballots -> one word per row, folded
+    per mask by box_rows_kernel) are batched_mask_to_box (utils/amg.py:303-346) of the masks it wrote -- blobs, speckle, an empty mask, a mask that
     the clean-up empties, a full mask, ragged width (not a multiple of 64)."""
     rng = np.random.default_rng(5)
     H, W = 97, 150
