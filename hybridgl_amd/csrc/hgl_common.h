@@ -278,6 +278,11 @@ int hgl_launch_hyper_logits(const float* u2, const float* hyper, int P, int g, i
 int hgl_launch_pe_labeled(const float* coords01, const int32_t* labels, const float* G, int n, int F, const float* not_a_point,
                           const float* const* point_embed, float* out, hipStream_t st);
 // fused decoder stages (sam_decoder_fused.hip)
+// token -> image attention of the mask decoder on the raw image-token planes (sam_decoder_t2i.hip)
+int hgl_launch_t2i_fold_q(const float* q1, const float* Wk, float scale, float* Qk, int P, hipStream_t st);
+int hgl_launch_t2i_raw_attn(const void* Qh, const void* Ql, const float* bias, const void* Kh, const void* Kl, int P, int HW,
+                            float* out, hipStream_t st);
+int hgl_launch_t2i_unfold_v(const float* A, const float* Wv, const float* bv, float* att, int P, hipStream_t st);
 int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0_w, const float* up0_b, const float* ln_w,
                         const float* ln_b, const float* up3_w, const float* up3_b, const float* hyper, int row0, int P, int g,
                         float eps, float* low_res, const uint8_t* skip, hipStream_t st);

@@ -439,6 +439,26 @@ int dec_t2i_merged(const HglSamDecoderW* w, const HglSamAttnW& a, const float* q
   return lin(att, I, a.out, queries, C, queries, C, P * T, C, I, HGL_ACT_NONE, st);
 }
 
+// token -> image attention on the RAW image-token planes (sam_decoder_t2i.hip): the 7 tokens are projected through W_k / W_v
+// instead of the HW image tokens.  Scratch: `small` (>= P * 56 * 256 * 8 bytes: the folded queries' planes + the attended
+// rows), `bias` (P * 56 * HW floats).
+int dec_t2i_raw(const HglSamDecoderW* w, const HglSamAttnW& a, const float* qpe, const SplitPair& keysS, int P, int HW, int T,
+                float* q1, float* small, float* bias, float* att, float* queries, hipStream_t st) {
+  const int C = w->C, I = a.internal, heads = w->heads, hd = I / heads;
+  HGL_TRY(lin(qpe, C, a.q, nullptr, 0, q1, I, P * T, I, C, HGL_ACT_NONE, st));
+  uint16_t* Qh = (uint16_t*)small;
+  uint16_t* Ql = Qh + (size_t)P * 56 * C;
+  float* A = (float*)(Ql + (size_t)P * 56 * C);      // first the folded queries in fp32, then the attended rows
+  HGL_TRY(hgl_launch_t2i_fold_q(q1, a.k.w, 1.0f / sqrtf((float)hd), A, P, st));
+  HGL_TRY(hgl_launch_split_f16(A, 1.0f, Qh, Ql, (long long)P * 56 * C, st));
+  // bias[p*56 + r, key] = Qk[p*56 + r, :] . pe[key, :]: pe is the "weight" [HW, C] of a split-fp16 GEMM
+  HGL_TRY(hgl_launch_gemm_f16x3(Qh, Ql, C, w->dense_pe, nullptr, nullptr, 0, bias, nullptr, nullptr, HW, P * 56, HW, C,
+                                HGL_ACT_NONE, st));
+  HGL_TRY(hgl_launch_t2i_raw_attn(Qh, Ql, bias, keysS.hi, keysS.lo, P, HW, A, st));
+  HGL_TRY(hgl_launch_t2i_unfold_v(A, a.v.w, a.v.b, att, P, st));
+  return lin(att, I, a.out, queries, C, queries, C, P * T, C, I, HGL_ACT_NONE, st);
+}
+
 // image -> token attention on merged projections: q = kvq[:, 2I:3I]
 int dec_i2t_merged(const HglSamDecoderW* w, const HglSamAttnW& a, const float* kvq, int ld, const float* tok_k, const float* tok_v,
                    int P, int HW, int T, float* k1, float* v1, float* atti, const float* R, float* keys_out, hipStream_t st) {
@@ -623,6 +643,11 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
                       w->layer[1].t2i.internal == w->final_t2i.internal && 2 * w->final_t2i.internal == C;
   const int I1 = w->layer[1].t2i.internal;
   const SplitPair keysS = split_view(p.keysS, (size_t)P * HW * C), kpeS = split_view(p.kpe, (size_t)P * HW * C);
+  // fusion bit 5: the token -> image attention of layer 1 and the final one on the raw image-token planes (the 7 tokens go
+  // through W_k / W_v instead of the HW image tokens: no k | v projection GEMM; layer 1 projects q alone for its step 4)
+  const bool raw_t2i = merged && (dec_fusion_mask() & 32) && (dec_fusion_mask() & 4) && T == 7 && I1 == 128 && w->heads == 8 &&
+                       C == 256 && HW % 64 == 0 && P <= 65535 && !perprompt && hgl_has_split_weight(w->dense_pe) &&
+                       (size_t)P * 56 * C * 8 <= atti_bytes;
   for (int li = 0; li < 2; ++li) {
     const auto& L = w->layer[li];
     const bool shared = li == 0 && !perprompt;   // keys identical for every prompt in layer 0
@@ -643,7 +668,13 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
     HGL_TRY(hgl_launch_layernorm(p.queries, L.n1.w, L.n1.b, p.queries, P * T, C, 1e-5f, st));
     // (2) tokens attend to the image
     HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
-    if (merged && !shared && !plain0) {
+    if (raw_t2i && !shared && !plain0) {
+      // q of step (4) alone: [P*HW, I] = keys W_q^T + b_q + (pe W_q^T)[row % HW] (the q columns of the merged table);
+      // the token -> image attention reads the raw planes, its bias sits behind q in the (otherwise unused) k | v part
+      HGL_TRY(hgl_launch_gemm_f16x3_rmod(keysS.hi, keysS.lo, C, L.i2t.q.w, L.i2t.q.b, w->kvq1_pe + 2 * I1, 3 * I1, HW, p.kp,
+                                         nullptr, nullptr, I1, P * HW, I1, C, HGL_ACT_NONE, st));
+      HGL_TRY(dec_t2i_raw(w, L.t2i, p.qpe, keysS, P, HW, T, p.q1, p.atti, p.kp + (size_t)P * HW * I1, p.att, p.queries, st));
+    } else if (merged && !shared && !plain0) {
       // k, v of this step and q of step (4) read the same rows: one GEMM, the positional encoding as a per-position table
       HGL_TRY(dec_project_merged(keysS, w->kvq1_w, w->kvq1_b, w->kvq1_pe, P, HW, C, 3 * I1, p.kp, st));
       HGL_TRY(dec_t2i_merged(w, L.t2i, p.qpe, p.kp, 3 * I1, P, HW, T, p.q1, p.att, p.queries, p.atti, atti_bytes, st));
@@ -668,7 +699,9 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
       HGL_TRY(lin(p.qpe, C, L.i2t.k, nullptr, 0, p.k1, I1, P * T, I1, C, HGL_ACT_NONE, st));
       HGL_TRY(lin(p.queries, C, L.i2t.v, nullptr, 0, p.v1, I1, P * T, I1, C, HGL_ACT_NONE, st));
       if (shared) HGL_TRY(lin(p.kpe0, C, L.i2t.q, nullptr, 0, p.qi, I1, HW, I1, C, HGL_ACT_NONE, st));
-      HGL_TRY(hgl_launch_dec_i2t(shared ? p.qi : p.kp + 2 * I1, shared ? I1 : 3 * I1, shared ? 0 : (long long)HW * 3 * I1, p.k1,
+      const bool qonly = raw_t2i && !shared;      // layer 1 in raw mode: p.kp holds q alone, [P*HW, I]
+      HGL_TRY(hgl_launch_dec_i2t(shared ? p.qi : (qonly ? p.kp : p.kp + 2 * I1), shared || qonly ? I1 : 3 * I1,
+                                 shared ? 0 : (long long)HW * (qonly ? I1 : 3 * I1), p.k1,
                                  p.v1, L.i2t.out.w, L.i2t.out.b, keys, shared ? 0 : sK, L.n4.w, L.n4.b, 1e-5f,
                                  1.0f / sqrtf((float)(I1 / w->heads)), P, HW, li == 0 ? p.keys : nullptr, keysS.hi, keysS.lo, st));
     } else if (x3 && plain0) {
@@ -695,7 +728,9 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
   }
   // final token -> image attention
   HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
-  if (merged) {
+  if (raw_t2i) {
+    HGL_TRY(dec_t2i_raw(w, w->final_t2i, p.qpe, keysS, P, HW, T, p.q1, p.atti, p.kp, p.att, p.queries, st));
+  } else if (merged) {
     HGL_TRY(dec_project_merged(keysS, w->kvf_w, w->kvf_b, w->kvf_pe, P, HW, C, 2 * I1, p.kp, st));
     HGL_TRY(dec_t2i_merged(w, w->final_t2i, p.qpe, p.kp, 2 * I1, P, HW, T, p.q1, p.att, p.queries, p.atti, atti_bytes, st));
   } else if (x3) {

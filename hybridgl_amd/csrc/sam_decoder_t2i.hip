@@ -1,0 +1,288 @@
+// Token -> image attention of the SAM mask decoder ON THE RAW IMAGE TOKENS (split-fp16 matrix-core mode).
+//
+// Attention.forward (modeling/transformer.py:218-240) for the decoder's cross_attn_token_to_image / final_attn_token_to_image
+// (transformer.py:126-131, :97-105): 7 prompt tokens attend to the 4096 image tokens of THEIR prompt, 8 heads of 16 channels.
+// As written, k = (keys + pe) W_k and v = keys W_v are projections of all 4096 x 256 image tokens of every prompt: a GEMM that
+// reads the per-prompt token planes (4.2 MB per prompt) and writes k | v (4.2 MB), which the attention then reads (4.2 MB) --
+// 12.6 MB of HBM traffic per prompt and attention, at the 4 TB/s these kernels reach the time of the whole step.
+//
+// The algebra lets the 7 tokens be projected instead of the 4096.  Per head h (W_k[h] = rows 16h .. 16h+15 of W_k, [16, 256]):
+//   q_h k_h^T = q_h (W_k[h] (keys + pe)^T + b_k[h] 1^T) = (q_h W_k[h]) keys^T + (q_h W_k[h]) pe^T + const      (const: the same for
+//   every key -> cancels in the soft-max), and   P_h v_h = P_h (keys W_v[h]^T + 1 b_v[h]) = (P_h keys) W_v[h]^T + b_v[h]   (rows of P sum to 1).
+// So:  Qk[p, h*7 + t, :] = scale * q[p, t, 16h:16h+16] W_k[h]                     [P, 56, 256]   t2i_fold_q_kernel
+//      bias[p, r, key]   = Qk[p, r, :] . pe[key, :]                               [P, 56, HW]    one split-fp16 GEMM (pe as the weight)
+//      A[p, r, :]        = soft-max_key(Qk[p, r, :] . keys[p, key, :] + bias) . keys[p, :, :]     t2i_raw_attn_kernel: the planes read ONCE
+//      att[p, t, 16h+i]  = A[p, h*7 + t, :] . W_v[16h + i, :] + b_v[16h + i]      [P, 7, 128]    t2i_unfold_v_kernel
+// and the k | v projection GEMM, its 4.2 MB of output per prompt and their re-read disappear: 4.2 + 0.9 (bias) x 2 instead
+// of 12.6 MB per prompt and attention.  Exact in real arithmetic; in floating point every product is the split-fp16 triple
+// (hi*hi + hi*lo + lo*hi into fp32) as everywhere else: equal to the projected path to fp32 rounding (tests/test_gpu_sam.py).
+//
+// t2i_raw_attn_kernel.  One workgroup of four waves per prompt; wave w owns query rows 16w .. 16w+15 (of the 56) and ALL 256
+// channels: S^T = K Q'^T (v_mfma_f32_16x16x32_f16: first operand rows of the staged key chunk, second operand the wave's 16
+// query rows, register-resident for the whole prompt: 8 K steps x hi / lo = 64 VGPRs) -- the accumulator then holds, per lane,
+// query (lane & 15) and keys 4g .. 4g+3 (g = lane >> 4) of each 16-key tile, which is exactly the B operand of
+// O'^T = K^T P^T when the K step's eight key slots of lane group g are {4g..4g+3, 16+4g..16+4g+3}; the first operand K^T comes
+// out of the same LDS image through two transposing reads (ds_read_b64_tr_b16) per fragment with those rows.  No lane movement,
+// no second copy of the chunk, no exchange between the waves.  Key chunks of 32 go global -> LDS by LDS-DMA into two stages, one
+// barrier per chunk; two workgroups per CU (68 KB of LDS each) cover each other's waits.  Online soft-max in base 2 with the
+// rescaling skipped while no row's maximum moves.
+#include "hgl_common.h"
+
+bool hgl_get_split_weight(const float* W, const void** hi, const void** lo, int* scale_log2, int* N, int* K);
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+constexpr int T2I_ROWS = 56;                       // 8 heads x 7 tokens
+constexpr int T2I_C = 256;                         // channels of an image token
+constexpr int T2I_CHUNK = 32;                      // keys per staged chunk
+constexpr int T2I_SLOTS = 33;                      // 16-byte slots per staged key row: 32 + 1 pad (row pitch 528 B: the 16 rows of a
+constexpr int T2I_PITCH = T2I_SLOTS * 16;          //   ds_read_b128 lane group land in 16 different bank quads)
+constexpr int T2I_PLANE_NI = 17;                   // LDS-DMA wave-instructions per plane: 32 x 33 = 1056 slots -> 17 x 64
+constexpr int T2I_PLANE = T2I_PLANE_NI * 1024;     // bytes of one staged plane
+constexpr int T2I_STAGE = 2 * T2I_PLANE;           // hi | lo
+constexpr int T2I_NI = 2 * T2I_PLANE_NI;           // wave-instructions per chunk
+constexpr int T2I_NJ = (T2I_NI + 3) / 4;           // per wave
+constexpr size_t T2I_LDS = 2 * (size_t)T2I_STAGE;  // two stages: 69 632 B
+constexpr float T2I_LOG2E = 1.4426950408889634f;
+
+// ds_read_b64_tr_b16 (EXEC must be all ones at the call)
+__device__ __forceinline__ f16x4 t2i_tr4(const unsigned char* p) {
+  typedef __attribute__((address_space(3))) fp16x4v lds_v;
+  const fp16x4v v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_v*)p);
+  f16x4 r;
+  __builtin_memcpy(&r, &v, 8);
+  return r;
+}
+
+// One LDS-DMA wave-instruction: lane i copies 16 B from sbase + voff(i) to LDS byte lds_addr + 16 * i (see gemm_f16x3.hip).
+// Not counted by the compiler on vmcnt: the consumer waits with an explicit s_waitcnt.
+__device__ __forceinline__ void t2i_glds16(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+
+// Qk[p, h*T + t, c] = scale * sum_j q[p, t, 16h + j] * Wk[16h + j, c]   [P*56, 256] fp32 (the caller splits it into fp16 hi / lo
+// planes with the guarded split of gemm_f16x3.hip: its range counter is the one the evaluator watches)
+__global__ __launch_bounds__(256) void t2i_fold_q_kernel(const float* __restrict__ q, const float* __restrict__ Wk, float scale,
+                                                         float* __restrict__ Qk) {
+  __shared__ float qs[7 * 128];
+  const int p = blockIdx.x, c = threadIdx.x;
+  for (int i = threadIdx.x; i < 7 * 128; i += 256) qs[i] = q[(long long)p * 7 * 128 + i];
+  __syncthreads();
+  for (int h = 0; h < 8; ++h) {
+    float w[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[j] = Wk[(16 * h + j) * T2I_C + c];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a = fmaf(qs[t * 128 + 16 * h + j], w[j], a);
+      Qk[((long long)p * T2I_ROWS + h * 7 + t) * T2I_C + c] = a * scale;
+    }
+  }
+}
+
+// att[p, t, 16h + i] = A[p, h*7 + t, :] . Wv[16h + i, :] + bv[16h + i]
+__global__ __launch_bounds__(256) void t2i_unfold_v_kernel(const float* __restrict__ A, const float* __restrict__ Wv,
+                                                           const float* __restrict__ bv, float* __restrict__ att) {
+  __shared__ float As[T2I_ROWS * T2I_C];      // 57 344 B
+  const int p = blockIdx.x;
+  for (int i = threadIdx.x; i < T2I_ROWS * T2I_C / 4; i += 256)
+    ((f32x4*)As)[i] = ((const f32x4*)(A + (long long)p * T2I_ROWS * T2I_C))[i];
+  __syncthreads();
+  const int col = threadIdx.x & 127, h = col >> 4;
+  const float* wrow = Wv + (long long)col * T2I_C;
+  for (int t = threadIdx.x >> 7; t < 7; t += 2) {
+    const float* arow = As + (h * 7 + t) * T2I_C;
+    float a = 0.f;
+    for (int c0 = 0; c0 < T2I_C; c0 += 4) {
+      const f32x4 wv = *(const f32x4*)(wrow + c0);
+      const f32x4 av = *(const f32x4*)(arow + c0);
+      a = fmaf(av[0], wv[0], a); a = fmaf(av[1], wv[1], a); a = fmaf(av[2], wv[2], a); a = fmaf(av[3], wv[3], a);
+    }
+    att[((long long)p * 7 + t) * 128 + col] = a + bv[col];
+  }
+}
+
+struct T2IArgs {
+  const _Float16 *Qh, *Ql;     // [P*56, 256] scaled folded queries
+  const float* bias;           // [P*56, HW]  Qk . pe^T (scaled)
+  const _Float16 *Kh, *Kl;     // [P*HW, 256] image-token planes
+  float* out;                  // [P*56, 256]
+  int HW;
+};
+
+__global__ __launch_bounds__(256, 2) void t2i_raw_attn_kernel(T2IArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char t2i_smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int p = blockIdx.x;
+  const int nchunks = a.HW / T2I_CHUNK;
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)t2i_smem;
+
+  // ---- this wave's DMA pieces: instruction i (0 .. 33) = plane i / 17, slots 64 (i % 17) .. +63 of that plane ----
+  const unsigned char* const kh_p = (const unsigned char*)(a.Kh + (long long)p * a.HW * T2I_C);
+  const unsigned char* const kl_p = (const unsigned char*)(a.Kl + (long long)p * a.HW * T2I_C);
+  unsigned voff[T2I_NJ];
+#pragma unroll
+  for (int j = 0; j < T2I_NJ; ++j) {
+    const int i = wave + 4 * j;
+    const int slot = (i % T2I_PLANE_NI) * 64 + lane;
+    const int key = min(slot / T2I_SLOTS, T2I_CHUNK - 1), col = min(slot % T2I_SLOTS, 31);      // pad slots re-read a neighbour
+    voff[j] = (unsigned)(key * T2I_C + col * 8) * 2u;
+  }
+  auto issue = [&](int chunk, int stage) {
+#pragma unroll
+    for (int j = 0; j < T2I_NJ; ++j) {
+      const int i = wave + 4 * j;
+      if (i < T2I_NI) {
+        const int plane = i / T2I_PLANE_NI;
+        t2i_glds16(plane ? kl_p : kh_p, voff[j] + (unsigned)chunk * (T2I_CHUNK * T2I_C * 2),
+                   lds0 + stage * T2I_STAGE + plane * T2I_PLANE + (i % T2I_PLANE_NI) * 1024);
+      }
+    }
+  };
+  issue(0, 0);
+
+  // ---- the wave's 16 query rows: second operand of S^T = K Q'^T, lane (query r, group g) holds channels 32 ks + 8 g .. +7 ----
+  const int qrow = min(16 * wave + r, T2I_ROWS - 1);
+  const long long qbase = ((long long)p * T2I_ROWS + qrow) * T2I_C + 8 * g;
+  f16x8 qh[8], ql[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    qh[ks] = *(const f16x8*)(a.Qh + qbase + 32 * ks);
+    ql[ks] = *(const f16x8*)(a.Ql + qbase + 32 * ks);
+  }
+  const float* const brow = a.bias + ((long long)p * T2I_ROWS + qrow) * a.HW + 4 * g;
+  f32x4 bnext[2];
+  bnext[0] = *(const f32x4*)(brow);
+  bnext[1] = *(const f32x4*)(brow + 16);
+
+  f32x4 oacc[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, lsum = 0.f;
+
+  // LDS offsets of this lane's fragment reads inside a stage's hi plane
+  const unsigned row_off = (unsigned)(r * T2I_PITCH + 16 * g);                                   // + 16-row tile, + 64 ks
+  const unsigned tr_off = (unsigned)((4 * g + (r >> 2)) * T2I_PITCH + 8 * (r & 3));              // + 16 rows (second read), + 32 dt
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int stage = c & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk c has landed (and the bias vectors requested a chunk ago)
+    __syncthreads();                                      // ... for every wave; and nobody reads the other stage any more
+    if (c + 1 < nchunks) issue(c + 1, stage ^ 1);
+    const f32x4 b0 = bnext[0], b1 = bnext[1];
+    if (c + 1 < nchunks) {
+      bnext[0] = *(const f32x4*)(brow + (c + 1) * T2I_CHUNK);
+      bnext[1] = *(const f32x4*)(brow + (c + 1) * T2I_CHUNK + 16);
+    }
+    const unsigned char* const sh = t2i_smem + stage * T2I_STAGE;
+    const unsigned char* const sl = sh + T2I_PLANE;
+
+    // ---- S^T tiles (keys 0-15 / 16-31 of the chunk) x (the wave's 16 queries) ----
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const f16x8 k0h = *(const f16x8*)(sh + row_off + 64 * ks), k0l = *(const f16x8*)(sl + row_off + 64 * ks);
+      const f16x8 k1h = *(const f16x8*)(sh + row_off + 16 * T2I_PITCH + 64 * ks);
+      const f16x8 k1l = *(const f16x8*)(sl + row_off + 16 * T2I_PITCH + 64 * ks);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0l, qh[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1l, qh[ks], s1, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, ql[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, ql[ks], s1, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, qh[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, qh[ks], s1, 0, 0, 0);
+    }
+    // ---- soft-max of the lane's query over the chunk: its keys 4g .. 4g+3 and 16+4g .. 16+4g+3; the other 24 keys of the
+    // query sit in the lanes r + 16, r + 32, r + 48 ----
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[i] = s0[i] + b0[i]; x[4 + i] = s1[i] + b1[i]; }
+    float mx = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(m, mx);
+    if (__any(mnew > m)) {      // (wave-uniform: the branch is skipped once the maxima have settled)
+      const float alpha = exp2f((m - mnew) * T2I_LOG2E);
+      lsum *= alpha;
+#pragma unroll
+      for (int d = 0; d < 16; ++d)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oacc[d][i] *= alpha;
+      m = mnew;
+    }
+    f16x8 ph, pl;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float e = exp2f((x[i] - m) * T2I_LOG2E);
+      lsum += e;
+      _Float16 hh, ll;
+      hgl_split_hi_lo(e, hh, ll);
+      ph[i] = hh;
+      pl[i] = ll;
+    }
+    // ---- O'^T (channels x queries) += K^T P^T: first operand from the same image through the transposing read ----
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      const f16x4 a0h = t2i_tr4(sh + tr_off + 32 * d), a1h = t2i_tr4(sh + tr_off + 16 * T2I_PITCH + 32 * d);
+      const f16x4 a0l = t2i_tr4(sl + tr_off + 32 * d), a1l = t2i_tr4(sl + tr_off + 16 * T2I_PITCH + 32 * d);
+      const f16x8 kth = {a0h[0], a0h[1], a0h[2], a0h[3], a1h[0], a1h[1], a1h[2], a1h[3]};
+      const f16x8 ktl = {a0l[0], a0l[1], a0l[2], a0l[3], a1l[0], a1l[1], a1l[2], a1l[3]};
+      oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ktl, ph, oacc[d], 0, 0, 0);
+      oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kth, pl, oacc[d], 0, 0, 0);
+      oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kth, ph, oacc[d], 0, 0, 0);
+    }
+  }
+  // ---- normalise and store: lane (query r, group g) holds channels 16 d + 4 g .. +3 of its query ----
+  lsum += __shfl_xor(lsum, 16);
+  lsum += __shfl_xor(lsum, 32);
+  const float inv = 1.0f / lsum;
+  if (16 * wave + r < T2I_ROWS) {
+    float* const orow = a.out + ((long long)p * T2I_ROWS + 16 * wave + r) * T2I_C + 4 * g;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = oacc[d][i] * inv;
+      *(f32x4*)(orow + 16 * d) = o;
+    }
+  }
+}
+
+}  // namespace
+
+// The three launches around the bias GEMM (which the caller issues: it owns the GEMM entry and pe's registered split).
+int hgl_launch_t2i_fold_q(const float* q1, const float* Wk, float scale, float* Qk, int P, hipStream_t st) {
+  hipLaunchKernelGGL(t2i_fold_q_kernel, dim3((unsigned)P), dim3(256), 0, st, q1, Wk, scale, Qk);
+  return hgl_check_launch("t2i_fold_q");
+}
+
+int hgl_launch_t2i_raw_attn(const void* Qh, const void* Ql, const float* bias, const void* Kh, const void* Kl, int P, int HW,
+                            float* out, hipStream_t st) {
+  HGL_REQUIRE(HW % T2I_CHUNK == 0 && HW >= T2I_CHUNK && P > 0, "t2i_raw_attn: %d image tokens unsupported", HW);
+  HGL_REQUIRE((((uintptr_t)Qh | (uintptr_t)Ql | (uintptr_t)bias | (uintptr_t)Kh | (uintptr_t)Kl | (uintptr_t)out) & 15) == 0,
+              "t2i_raw_attn: operands must be 16-byte aligned");
+  T2IArgs a;
+  a.Qh = (const _Float16*)Qh; a.Ql = (const _Float16*)Ql; a.bias = bias;
+  a.Kh = (const _Float16*)Kh; a.Kl = (const _Float16*)Kl; a.out = out; a.HW = HW;
+  HGL_RESERVE_LDS((t2i_raw_attn_kernel), T2I_LDS, "t2i_raw_attn");
+  HglProfScope prof(HGL_PROF_ATTN, 4.0 * P * T2I_ROWS * (double)HW * T2I_C, 0.0, st);
+  hipLaunchKernelGGL(t2i_raw_attn_kernel, dim3((unsigned)P), dim3(256), T2I_LDS, st, a);
+  return hgl_check_launch("t2i_raw_attn");
+}
+
+int hgl_launch_t2i_unfold_v(const float* A, const float* Wv, const float* bv, float* att, int P, hipStream_t st) {
+  hipLaunchKernelGGL(t2i_unfold_v_kernel, dim3((unsigned)P), dim3(256), 0, st, A, Wv, bv, att);
+  return hgl_check_launch("t2i_unfold_v");
+}

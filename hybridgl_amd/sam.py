@@ -190,6 +190,9 @@ class Sam:
             wf, bf = cat_w(kf)
             dec.kvq1_w, dec.kvq1_b, dec.kvq1_pe = w1.data_ptr(), b1.data_ptr(), pe_table(k1, (True, False, True)).data_ptr()
             dec.kvf_w, dec.kvf_b, dec.kvf_pe = wf.data_ptr(), bf.data_ptr(), pe_table(kf, (True, False)).data_ptr()
+            # the token -> image attention on the raw image tokens (csrc/sam_decoder_t2i.hip) multiplies its folded queries with
+            # the positional encoding as a GEMM "weight" [HW, C]
+            ops.register_split_weight(self.dense_pe)
             torch.cuda.current_stream().synchronize()
         self.dec_w = dec
         # the fp16 splits registered above die with this model (library registry + hi/lo tensors)

@@ -529,7 +529,9 @@ int hgl_sam_embed_masks(const HglSamDecoderW* w, const float* mask_input, int P,
 /* Fused stages of the decoder (split-fp16 mode): bit 0 = output upscaling + hyper-network products in one launch; bit 1 =
  * merged image-side projections (kvq1 / kvf of HglSamDecoderW, when provided); bit 2 = image -> token attention +
  * out-projection + residual + norm4 in one launch (needs bit 1); bit 4 = token -> image attention as key chunks of 256 with
- * all heads per workgroup + a combine pass (either precision mode).  Sets the mask (mask >= 0; default all
+ * all heads per workgroup + a combine pass (either precision mode); bit 5 = the token -> image attention of layer 1 and the
+ * final one on the RAW image-token planes -- the 7 tokens are projected through W_k / W_v instead of the image tokens, no
+ * k | v projection GEMM (needs bits 1 and 2; one foreground point per prompt).  Sets the mask (mask >= 0; default all
  * stages, or HGL_SAM_DEC_FUSED) and returns the previous one; mask < 0 only queries.  Fused and unfused stages agree to
  * fp32 rounding: the switch exists for timing and for that test. */
 int hgl_sam_decoder_fusion(int mask);

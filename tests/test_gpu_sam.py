@@ -410,6 +410,15 @@ def test_fused_decoder_stages_equal_the_unfused_launches(cuda, name, P):
     _fusion(old)
     assert float((iou7 - iou23).abs().max()) <= 1e-5 * max(1.0, float(iou7.abs().max())), float((iou7 - iou23).abs().max())
     assert float((low7 - low23).abs().max()) <= 1e-5 * float(low7.abs().max()), float((low7 - low23).abs().max())
+    # bit 5: the token -> image attention of layer 1 and the final one on the RAW image-token planes (the 7 tokens projected
+    # through W_k / W_v instead of the image tokens: (q W_k)(keys + pe)^T and (P keys) W_v^T + b_v): the same quantities in real
+    # arithmetic, every product the split-fp16 triple -- equal to the projected path to fp32 rounding
+    _fusion(7 + 16 + 32)
+    low55, iou55 = m.decode_points(emb, p01)
+    _fusion(old)
+    assert torch.isfinite(low55).all()
+    assert float((iou23 - iou55).abs().max()) <= 2e-5 * max(1.0, float(iou23.abs().max())), float((iou23 - iou55).abs().max())
+    assert float((low23 - low55).abs().max()) <= 2e-5 * float(low23.abs().max()), float((low23 - low55).abs().max())
     # all stages: the merged projections add the positional encoding AFTER the product ((keys + pe) W = keys W + pe W)
     assert float((iou0 - iou1).abs().max()) <= 2e-5 * max(1.0, float(iou0.abs().max()))
     assert float((low0 - low1).abs().max()) <= 2e-5 * float(low0.abs().max()), float((low0 - low1).abs().max())
