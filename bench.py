@@ -846,8 +846,8 @@ def main():
         e1_.record()
         torch.cuda.synchronize()
         dec_ms = e0_.elapsed_time(e1_) / 4
-        dec = {"bound": "hbm / valu (see DESIGN.md section 5: dec_tail_kernel and dec_i2t_kernel are bound by element-wise arithmetic, the "
-                        "projections and the token -> image attention by the bytes of the per-prompt image tokens)",
+        dec = {"bound": "hbm / valu (see DESIGN.md section 5.4: dec_tail_kernel is bound by element-wise arithmetic, dec_i2t_kernel, the q "
+                        "projection and the token -> image attention on the raw token planes by the bytes of the per-prompt image tokens)",
                "ms_per_64_prompts": dec_ms / 8, "algorithmic_gflop_per_prompt": 3.62,
                "achieved": 512 * 3.62e9 / (dec_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
                "frac_of_fp16_mfma_peak": 512 * 3.62e9 / (dec_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
