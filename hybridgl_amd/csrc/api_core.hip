@@ -99,7 +99,7 @@ int hgl_prof_read(int cls, long long* launches, double* ms, double* flops, doubl
 int hgl_split_overflow_count(int reset, unsigned long long* count) {
   HGL_TRY(hgl_require_device());
   HGL_REQUIRE(count != nullptr, "split_overflow_count: null argument");
-  *count = hgl_split_overflow_gemm(reset) + hgl_split_overflow_attention(reset);
+  *count = hgl_split_overflow_gemm(reset) + hgl_split_overflow_attention(reset) + hgl_split_overflow_decoder(reset);
   return HGL_OK;
 }
 

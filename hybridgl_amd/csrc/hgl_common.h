@@ -282,6 +282,12 @@ int hgl_launch_pe_labeled(const float* coords01, const int32_t* labels, const fl
 int hgl_launch_t2i_fold_q(const float* q1, const float* Wk, float scale, float* Qk, int P, hipStream_t st);
 int hgl_launch_t2i_raw_attn(const void* Qh, const void* Ql, const float* bias, const void* Kh, const void* Kl, int P, int HW,
                             float* out, hipStream_t st);
+int hgl_launch_i2t_prep(const float* k1, const float* v1, const float* Wq, const float* bq, const float* Wo, float scale, void* Kh,
+                        void* Kl, float* cb, void* Uh, void* Ul, int P, hipStream_t st);
+unsigned long long hgl_split_overflow_decoder(int reset);
+int hgl_launch_dec_i2t_fold(const void* Xh, const void* Xl, const void* Kh, const void* Kl, const float* pek, const float* cb,
+                            const void* Uh, const void* Ul, const float* bo, const float* ln_w, const float* ln_b, float eps, int P,
+                            int HW, void* out_hi, void* out_lo, hipStream_t st);
 int hgl_launch_t2i_unfold_v(const float* A, const float* Wv, const float* bv, float* att, int P, hipStream_t st);
 int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0_w, const float* up0_b, const float* ln_w,
                         const float* ln_b, const float* up3_w, const float* up3_b, const float* hyper, int row0, int P, int g,

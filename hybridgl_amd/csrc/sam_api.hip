@@ -647,7 +647,8 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
   // through W_k / W_v instead of the HW image tokens: no k | v projection GEMM; layer 1 projects q alone for its step 4)
   const bool raw_t2i = merged && (dec_fusion_mask() & 32) && (dec_fusion_mask() & 4) && T == 7 && I1 == 128 && w->heads == 8 &&
                        C == 256 && HW % 64 == 0 && P <= 65535 && !perprompt && hgl_has_split_weight(w->dense_pe) &&
-                       (size_t)P * 56 * C * 8 <= atti_bytes;
+                       (size_t)P * (56 * C * 8) <= atti_bytes &&                       // dec_t2i_raw: Q' planes + attended rows
+                       (size_t)P * (56 * C * 4 + 16384 * 4 + 256) <= atti_bytes;      // step (4): K' and U planes + cb
   for (int li = 0; li < 2; ++li) {
     const auto& L = w->layer[li];
     const bool shared = li == 0 && !perprompt;   // keys identical for every prompt in layer 0
@@ -669,11 +670,9 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
     // (2) tokens attend to the image
     HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
     if (raw_t2i && !shared && !plain0) {
-      // q of step (4) alone: [P*HW, I] = keys W_q^T + b_q + (pe W_q^T)[row % HW] (the q columns of the merged table);
-      // the token -> image attention reads the raw planes, its bias sits behind q in the (otherwise unused) k | v part
-      HGL_TRY(hgl_launch_gemm_f16x3_rmod(keysS.hi, keysS.lo, C, L.i2t.q.w, L.i2t.q.b, w->kvq1_pe + 2 * I1, 3 * I1, HW, p.kp,
-                                         nullptr, nullptr, I1, P * HW, I1, C, HGL_ACT_NONE, st));
-      HGL_TRY(dec_t2i_raw(w, L.t2i, p.qpe, keysS, P, HW, T, p.q1, p.atti, p.kp + (size_t)P * HW * I1, p.att, p.queries, st));
+      // no projection of the image tokens at all: this attention reads the raw planes (its positional term in p.kp), and
+      // step (4) below folds W_q into the 7 token keys as well
+      HGL_TRY(dec_t2i_raw(w, L.t2i, p.qpe, keysS, P, HW, T, p.q1, p.atti, p.kp, p.att, p.queries, st));
     } else if (merged && !shared && !plain0) {
       // k, v of this step and q of step (4) read the same rows: one GEMM, the positional encoding as a per-position table
       HGL_TRY(dec_project_merged(keysS, w->kvq1_w, w->kvq1_b, w->kvq1_pe, P, HW, C, 3 * I1, p.kp, st));
@@ -693,17 +692,32 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
     HGL_TRY(hgl_launch_add_rows_bcast(p.queries, P * sQ, p.tokens, P * sQ, 1, p.qpe, st));
     const bool fuse_i2t = merged && (dec_fusion_mask() & 4) && L.i2t.internal == I1 && I1 == 128 && w->heads == 8 &&
                           HW % 64 == 0 && P <= 65535 && T == 7 && !plain0;
-    if (fuse_i2t) {
+    if (fuse_i2t && raw_t2i && !shared) {
+      // layer 1 on per-prompt image tokens: scores = (keys + pe) . (W_q^T k_tok) and update = P (W_o v_tok) by MFMA against
+      // per-prompt 56 x 256 matrices (sam_decoder_t2i.hip: dec_i2t_fold_kernel); the planes are updated in place
+      HGL_TRY(lin(p.qpe, C, L.i2t.k, nullptr, 0, p.k1, I1, P * T, I1, C, HGL_ACT_NONE, st));
+      HGL_TRY(lin(p.queries, C, L.i2t.v, nullptr, 0, p.v1, I1, P * T, I1, C, HGL_ACT_NONE, st));
+      uint16_t* Kh = (uint16_t*)p.atti;                            // [P*56, 256] K' hi / lo
+      uint16_t* Kl = Kh + (size_t)P * 56 * C;
+      uint16_t* Uh = Kl + (size_t)P * 56 * C;                      // [P, 16, 2, 64, 8] U fragments hi / lo
+      uint16_t* Ul = Uh + (size_t)P * 16384;
+      float* cbv = (float*)(Ul + (size_t)P * 16384);               // [P*56]
+      HGL_TRY(hgl_launch_i2t_prep(p.k1, p.v1, L.i2t.q.w, L.i2t.q.b, L.i2t.out.w, 1.0f / sqrtf((float)(I1 / w->heads)), Kh, Kl, cbv, Uh,
+                                  Ul, P, st));
+      HGL_TRY(hgl_launch_gemm_f16x3(Kh, Kl, C, w->dense_pe, nullptr, nullptr, 0, p.kp, nullptr, nullptr, HW, P * 56, HW, C,
+                                    HGL_ACT_NONE, st));
+      HGL_TRY(hgl_launch_dec_i2t_fold(keysS.hi, keysS.lo, Kh, Kl, p.kp, cbv, Uh, Ul, L.i2t.out.b, L.n4.w, L.n4.b, 1e-5f, P, HW,
+                                      keysS.hi, keysS.lo, st));
+    } else if (fuse_i2t) {
       // attention over the 7 tokens, out-projection, residual and norm4 in one launch: the image tokens leave it as the
       // split planes the next projections read (and, in layer 0, as the fp32 rows layer 1 adds its update to)
       HGL_TRY(lin(p.qpe, C, L.i2t.k, nullptr, 0, p.k1, I1, P * T, I1, C, HGL_ACT_NONE, st));
       HGL_TRY(lin(p.queries, C, L.i2t.v, nullptr, 0, p.v1, I1, P * T, I1, C, HGL_ACT_NONE, st));
       if (shared) HGL_TRY(lin(p.kpe0, C, L.i2t.q, nullptr, 0, p.qi, I1, HW, I1, C, HGL_ACT_NONE, st));
-      const bool qonly = raw_t2i && !shared;      // layer 1 in raw mode: p.kp holds q alone, [P*HW, I]
-      HGL_TRY(hgl_launch_dec_i2t(shared ? p.qi : (qonly ? p.kp : p.kp + 2 * I1), shared || qonly ? I1 : 3 * I1,
-                                 shared ? 0 : (long long)HW * (qonly ? I1 : 3 * I1), p.k1,
+      HGL_TRY(hgl_launch_dec_i2t(shared ? p.qi : p.kp + 2 * I1, shared ? I1 : 3 * I1, shared ? 0 : (long long)HW * 3 * I1, p.k1,
                                  p.v1, L.i2t.out.w, L.i2t.out.b, keys, shared ? 0 : sK, L.n4.w, L.n4.b, 1e-5f,
-                                 1.0f / sqrtf((float)(I1 / w->heads)), P, HW, li == 0 ? p.keys : nullptr, keysS.hi, keysS.lo, st));
+                                 1.0f / sqrtf((float)(I1 / w->heads)), P, HW, (li == 0 && !raw_t2i) ? p.keys : nullptr, keysS.hi,
+                                 keysS.lo, st));
     } else if (x3 && plain0) {
       HGL_TRY(dec_attn(w, L.i2t, kpe, false, HW, p.qpe, p.queries, false, T, P, p.qi, p.k1, p.v1, p.atti, keys, sK, p.keys, st));
       HGL_TRY(hgl_launch_ln256_pe_split(p.keys, L.n4.w, L.n4.b, w->dense_pe, HW, (long long)P * HW, 1e-5f, 1, keysS.hi, keysS.lo,

@@ -260,6 +260,233 @@ __global__ __launch_bounds__(256, 2) void t2i_raw_attn_kernel(T2IArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Image -> token attention of layer 1 with the SAME fold (transformer.py:139-150): per image token, 8 heads attend to the 7
+// prompt tokens; q = (keys + pe) W_q projected all 4096 x 256 image tokens of every prompt (a GEMM: 4.2 MB read + 2.1 MB written
+// + 2.1 MB re-read per prompt).  With n = j*8 + h (token j, head h):
+//   score[token, n] = (keys[token] + pe[token]) . K'[n] + cb[n],   K'[n, :] = scale * k_tok[j, 16h:16h+16] W_q[16h:16h+16, :],
+//                                                                   cb[n]    = scale * k_tok[j, 16h:16h+16] . b_q[16h:16h+16]
+//   out[token, :]   = sum_n P[token, n] U[n, :] + b_o,              U[n, :]  = W_o[:, 16h:16h+16] v_tok[j, 16h:16h+16]
+// (P = soft-max over j within a head).  Both products are [64 tokens x 256] x [256 x 56] / [64 x 56] x [56 x 256] per tile
+// against per-PROMPT matrices of 56 x 256: the q projection, its output and the 16-channel dot products disappear, the token
+// planes are read once (as the MFMA operand and, reconstructed as hi + lo, as the residual), nothing else per-prompt but the
+// positional term pek = K' pe^T (one GEMM, 0.9 MB per prompt).
+// i2t_prep_kernel: K' (rows n), cb, and U in the fragment order of the second product's first operand, K' and U as fp16 hi / lo
+// planes (guarded split: this file's range counter is part of hgl_split_overflow_count).
+__global__ __launch_bounds__(256) void i2t_prep_kernel(const float* __restrict__ k1, const float* __restrict__ v1,
+                                                       const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                       const float* __restrict__ Wo, float scale, _Float16* __restrict__ Kh,
+                                                       _Float16* __restrict__ Kl, float* __restrict__ cb,
+                                                       _Float16* __restrict__ Uh, _Float16* __restrict__ Ul) {
+  __shared__ float ks[7 * 128], vs[7 * 128];
+  const int p = blockIdx.x, c = threadIdx.x;
+  for (int i = threadIdx.x; i < 7 * 128; i += 256) {
+    ks[i] = k1[(long long)p * 7 * 128 + i];
+    vs[i] = v1[(long long)p * 7 * 128 + i];
+  }
+  __syncthreads();
+  if (c < 56) {      // cb[n], n = j*8 + h
+    const int j = c >> 3, h = c & 7;
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a = fmaf(ks[j * 128 + 16 * h + i], bq[16 * h + i], a);
+    cb[(long long)p * 56 + c] = a * scale;
+  }
+  const long long ub = (long long)p * 16 * 2 * 64 * 8;
+  float amax = 0.f;
+  for (int h = 0; h < 8; ++h) {
+    float wq[16], wo[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wq[i] = Wq[(16 * h + i) * T2I_C + c];
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const f32x4 w4 = *(const f32x4*)(Wo + (long long)c * 128 + 16 * h + 4 * i4);
+      wo[4 * i4] = w4[0]; wo[4 * i4 + 1] = w4[1]; wo[4 * i4 + 2] = w4[2]; wo[4 * i4 + 3] = w4[3];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int n = j * 8 + h;
+      float a = 0.f, u = 0.f;
+      if (j < 7) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          a = fmaf(ks[j * 128 + 16 * h + i], wq[i], a);
+          u = fmaf(vs[j * 128 + 16 * h + i], wo[i], u);
+        }
+        _Float16 x, y;
+        hgl_split_hi_lo(a * scale, x, y, amax);
+        Kh[((long long)p * 56 + n) * T2I_C + c] = x;
+        Kl[((long long)p * 56 + n) * T2I_C + c] = y;
+      }
+      // U[n, c] at its place in the fragment of (channel tile c >> 4, K step n >> 5): lane 16 g + (c & 15), slot jj, where
+      // the K step's 32 values of n sit as {4g .. 4g+3 | 16+4g .. 16+4g+3} in lane group g (the accumulator order of the
+      // first product); n >= 56 (j == 7) is padding: zeros
+      const int m = n & 31, hi16 = m >> 4, g = (m & 15) >> 2, jj = 4 * hi16 + (m & 3);
+      _Float16 x, y;
+      hgl_split_hi_lo(u, x, y, amax);
+      const long long o = ub + (((c >> 4) * 2 + (n >> 5)) * 64 + 16 * g + (c & 15)) * 8 + jj;
+      Uh[o] = x;
+      Ul[o] = y;
+    }
+  }
+  hgl_split_commit(amax);
+}
+
+struct I2TFArgs {
+  const _Float16 *Xh, *Xl;     // [P*HW, 256] image-token planes (input of the layer)
+  const _Float16 *Kh, *Kl;     // [P*56, 256] K' planes, rows n = j*8 + h
+  const float* pek;            // [P*56, HW]  K' pe^T
+  const float* cb;             // [P*56]
+  const _Float16 *Uh, *Ul;     // [P][16][2][64][8] U fragments
+  const float *bo, *ln_w, *ln_b;
+  float eps;
+  _Float16 *oh, *ol;           // [P*HW, 256] normalised rows as planes
+  int HW;
+};
+
+constexpr int I2TF_ROWS = 64;                       // tokens per workgroup (16 per wave)
+constexpr size_t I2TF_LDS = 4 * 2 * 16 * 512;       // per wave: 16 rows x 256 halfs, hi and lo (64 KiB)
+
+__global__ __launch_bounds__(256, 2) void dec_i2t_fold_kernel(I2TFArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char i2tf_smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int p = blockIdx.y;
+  const long long row0 = (long long)p * a.HW + (long long)blockIdx.x * I2TF_ROWS + 16 * wave;      // the wave's first token row
+  const int tok0 = blockIdx.x * I2TF_ROWS + 16 * wave;
+
+  // ---- first product: S^T[n, token] = K' X^T; second operand = the wave's 16 token rows ----
+  f16x8 xh[8], xl[8];
+  {
+    const long long xb = (row0 + r) * T2I_C + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      xh[ks] = *(const f16x8*)(a.Xh + xb + 32 * ks);
+      xl[ks] = *(const f16x8*)(a.Xl + xb + 32 * ks);
+    }
+  }
+  f32x4 s[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long long kb = ((long long)p * 56 + min(16 * nt + r, 55)) * T2I_C + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const f16x8 kh = *(const f16x8*)(a.Kh + kb + 32 * ks), kl = *(const f16x8*)(a.Kl + kb + 32 * ks);
+      s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, xh[ks], s[nt], 0, 0, 0);
+      s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, xl[ks], s[nt], 0, 0, 0);
+      s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, xh[ks], s[nt], 0, 0, 0);
+    }
+  }
+  // ---- + positional term + bias term; soft-max over the 7 tokens of a head.  The lane holds, for token r of the wave,
+  // n = 16 nt + 4 g + i: head 4 (g & 1) + i, token j = 2 nt + (g >> 1) -- the other parity of j sits 32 lanes away ----
+  f16x8 ph[2], pl[2];
+  {
+    float x[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = 16 * nt + 4 * g + i, nc = min(n, 55);
+        const float v = s[nt][i] + a.pek[((long long)p * 56 + nc) * a.HW + tok0 + r] + a.cb[(long long)p * 56 + nc];
+        x[nt][i] = n < 56 ? v : -INFINITY;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float m = fmaxf(fmaxf(x[0][i], x[1][i]), fmaxf(x[2][i], x[3][i]));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float l = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        x[nt][i] = exp2f((x[nt][i] - m) * T2I_LOG2E);
+        l += x[nt][i];
+      }
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        _Float16 hh, ll;
+        hgl_split_hi_lo(x[nt][i] * inv, hh, ll);
+        ph[nt >> 1][4 * (nt & 1) + i] = hh;      // K step nt >> 1: slots 0-3 from the even tile, 4-7 from the odd one
+        pl[nt >> 1][4 * (nt & 1) + i] = ll;
+      }
+    }
+  }
+  // ---- second product: D^T[channel, token] = U^T P^T; first operand from the fragment-ordered U planes ----
+  f32x4 acc[16];
+  {
+    const _Float16* const uh = a.Uh + (long long)p * 16 * 2 * 64 * 8 + lane * 8;
+    const _Float16* const ul = a.Ul + (long long)p * 16 * 2 * 64 * 8 + lane * 8;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const f16x8 fh = *(const f16x8*)(uh + (d * 2 + ks) * 512), fl = *(const f16x8*)(ul + (d * 2 + ks) * 512);
+        acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, ph[ks], acc[d], 0, 0, 0);
+        acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, pl[ks], acc[d], 0, 0, 0);
+        acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, ph[ks], acc[d], 0, 0, 0);
+      }
+    }
+  }
+  // ---- + b_o + residual (the token's own row, hi + lo); LayerNorm over its 256 channels: this lane holds channels
+  // 16 d + 4 g + i, the other three quarters sit 16 / 32 / 48 lanes away ----
+  float sum = 0.f;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) {
+    const int ch = 16 * d + 4 * g;
+    const f16x4 rh = *(const f16x4*)(a.Xh + (row0 + r) * T2I_C + ch), rl = *(const f16x4*)(a.Xl + (row0 + r) * T2I_C + ch);
+    const f32x4 bo = *(const f32x4*)(a.bo + ch);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[d][i] = (acc[d][i] + bo[i]) + ((float)rh[i] + (float)rl[i]);
+      sum += acc[d][i];
+    }
+  }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float mean = sum * (1.f / 256.f);
+  float var = 0.f;
+#pragma unroll
+  for (int d = 0; d < 16; ++d)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float dd = acc[d][i] - mean; var += dd * dd; }
+  var += __shfl_xor(var, 16);
+  var += __shfl_xor(var, 32);
+  const float rstd = rsqrtf(var * (1.f / 256.f) + a.eps);
+  // ---- normalise, split, and leave through LDS so that a store instruction writes whole rows: the wave's 16 rows x 512 B
+  // per plane, 8-byte chunks XOR-ed with the row ----
+  unsigned char* const sth = i2tf_smem + wave * (2 * 16 * 512);
+  unsigned char* const stl = sth + 16 * 512;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) {
+    const int ch = 16 * d + 4 * g;
+    const f32x4 lw = *(const f32x4*)(a.ln_w + ch), lb = *(const f32x4*)(a.ln_b + ch);
+    f16x4 hi4, lo4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float y = (acc[d][i] - mean) * rstd * lw[i] + lb[i];
+      _Float16 hh, ll;
+      hgl_split_hi_lo(y, hh, ll);
+      hi4[i] = hh;
+      lo4[i] = ll;
+    }
+    const unsigned off = (unsigned)(r * 512 + (((4 * d + g) ^ (4 * r)) & 63) * 8);
+    *(f16x4*)(sth + off) = hi4;
+    *(f16x4*)(stl + off) = lo4;
+  }
+  // (the staging area is private to the wave: LDS operations of a wave execute in order, no barrier)
+  typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int row = 2 * k + (lane >> 5), c16 = lane & 31;
+    const unsigned roff = (unsigned)(row * 512 + ((c16 ^ (2 * row)) & 31) * 16);
+    *(u32x4t*)(a.oh + (row0 + row) * T2I_C + c16 * 8) = *(const u32x4t*)(sth + roff);
+    *(u32x4t*)(a.ol + (row0 + row) * T2I_C + c16 * 8) = *(const u32x4t*)(stl + roff);
+  }
+}
+
 }  // namespace
 
 // The three launches around the bias GEMM (which the caller issues: it owns the GEMM entry and pe's registered split).
@@ -285,4 +512,28 @@ int hgl_launch_t2i_raw_attn(const void* Qh, const void* Ql, const float* bias, c
 int hgl_launch_t2i_unfold_v(const float* A, const float* Wv, const float* bv, float* att, int P, hipStream_t st) {
   hipLaunchKernelGGL(t2i_unfold_v_kernel, dim3((unsigned)P), dim3(256), 0, st, A, Wv, bv, att);
   return hgl_check_launch("t2i_unfold_v");
+}
+
+int hgl_launch_i2t_prep(const float* k1, const float* v1, const float* Wq, const float* bq, const float* Wo, float scale, void* Kh,
+                        void* Kl, float* cb, void* Uh, void* Ul, int P, hipStream_t st) {
+  hipLaunchKernelGGL(i2t_prep_kernel, dim3((unsigned)P), dim3(256), 0, st, k1, v1, Wq, bq, Wo, scale, (_Float16*)Kh, (_Float16*)Kl, cb,
+                     (_Float16*)Uh, (_Float16*)Ul);
+  return hgl_check_launch("i2t_prep");
+}
+
+HGL_DEFINE_SPLIT_OVERFLOW_READER(hgl_split_overflow_decoder)
+
+int hgl_launch_dec_i2t_fold(const void* Xh, const void* Xl, const void* Kh, const void* Kl, const float* pek, const float* cb,
+                            const void* Uh, const void* Ul, const float* bo, const float* ln_w, const float* ln_b, float eps, int P,
+                            int HW, void* out_hi, void* out_lo, hipStream_t st) {
+  HGL_REQUIRE(HW % I2TF_ROWS == 0 && P > 0 && P <= 65535, "dec_i2t_fold: %d image tokens / %d prompts unsupported", HW, P);
+  I2TFArgs a;
+  a.Xh = (const _Float16*)Xh; a.Xl = (const _Float16*)Xl; a.Kh = (const _Float16*)Kh; a.Kl = (const _Float16*)Kl;
+  a.pek = pek; a.cb = cb; a.Uh = (const _Float16*)Uh; a.Ul = (const _Float16*)Ul;
+  a.bo = bo; a.ln_w = ln_w; a.ln_b = ln_b; a.eps = eps;
+  a.oh = (_Float16*)out_hi; a.ol = (_Float16*)out_lo; a.HW = HW;
+  HGL_RESERVE_LDS((dec_i2t_fold_kernel), I2TF_LDS, "dec_i2t_fold");
+  HglProfScope prof(HGL_PROF_OTHER, 2.0 * P * (double)HW * 256.0 * 56 * 2, 0.0, st);
+  hipLaunchKernelGGL(dec_i2t_fold_kernel, dim3((unsigned)(HW / I2TF_ROWS), (unsigned)P), dim3(256), I2TF_LDS, st, a);
+  return hgl_check_launch("dec_i2t_fold");
 }
