@@ -714,12 +714,16 @@ __global__ __launch_bounds__(512, 1) void gemm_x3p_kernel(Args g) {
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) *(f32x4*)(tp + r * 256 + (((4 * nb + h) ^ r) & 15) * 16) = acc[mb][nb];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (no instruction: tells the compiler that the lanes
+          __builtin_amdgcn_wave_barrier();                            //  of the wave exchange data through the patch)
           f32x4 v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int rho = 4 * i + rl;
             v[i] = *(const f32x4*)(tp + rho * 256 + ((cl ^ rho) & 15) * 16);
           }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
           if (mb + 1 < MB) fetch(mb + 1, crow[(mb + 1) & 1], rv[(mb + 1) & 1]);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {

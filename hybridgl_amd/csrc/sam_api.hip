@@ -646,7 +646,7 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
   // fusion bit 5: the token -> image attention of layer 1 and the final one on the raw image-token planes (the 7 tokens go
   // through W_k / W_v instead of the HW image tokens: no k | v projection GEMM; layer 1 projects q alone for its step 4)
   const bool raw_t2i = merged && (dec_fusion_mask() & 32) && (dec_fusion_mask() & 4) && T == 7 && I1 == 128 && w->heads == 8 &&
-                       C == 256 && HW % 64 == 0 && P <= 65535 && !perprompt && hgl_has_split_weight(w->dense_pe) &&
+                       C == 256 && HW % 128 == 0 && P <= 65535 && !perprompt && hgl_has_split_weight(w->dense_pe) &&
                        (size_t)P * (56 * C * 8) <= atti_bytes &&                       // dec_t2i_raw: Q' planes + attended rows
                        (size_t)P * (56 * C * 4 + 16384 * 4 + 256) <= atti_bytes;      // step (4): K' and U planes + cb
   for (int li = 0; li < 2; ++li) {

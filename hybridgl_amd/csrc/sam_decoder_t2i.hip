@@ -344,10 +344,14 @@ struct I2TFArgs {
   int HW;
 };
 
-constexpr int I2TF_ROWS = 64;                       // tokens per workgroup (16 per wave)
-constexpr size_t I2TF_LDS = 4 * 2 * 16 * 512;       // per wave: 16 rows x 256 halfs, hi and lo (64 KiB)
+constexpr int I2TF_WAVES = 8;
+constexpr int I2TF_ROWS = 16 * I2TF_WAVES;          // tokens per workgroup: 16 per wave
+constexpr size_t I2TF_LDS = 65536;                  // 64 KiB, used three times over: K' (56 rows x 528 B x 2 planes), then the U
+                                                    // fragments (2 x 32 KiB), then per wave 8 output rows x 256 halfs, hi and lo
+constexpr int I2TF_KNI = 29;                        // LDS-DMA wave-instructions per K' plane: 56 x 33 = 1848 slots -> 29 x 64
+constexpr int I2TF_KPLANE = I2TF_KNI * 1024;
 
-__global__ __launch_bounds__(256, 2) void dec_i2t_fold_kernel(I2TFArgs a) {
+__global__ __launch_bounds__(64 * I2TF_WAVES, 2) void dec_i2t_fold_kernel(I2TFArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char i2tf_smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -356,6 +360,24 @@ __global__ __launch_bounds__(256, 2) void dec_i2t_fold_kernel(I2TFArgs a) {
   const long long row0 = (long long)p * a.HW + (long long)blockIdx.x * I2TF_ROWS + 16 * wave;      // the wave's first token row
   const int tok0 = blockIdx.x * I2TF_ROWS + 16 * wave;
 
+  // Every wave needs ALL of K' (first product) and ALL of U (second product): read from L2 by each wave of each tile that was
+  // 512 KB per 64 tokens and the launch ran at the L2's rate (3.4 ms per 529 prompts).  Both go through the one 64 KiB LDS
+  // region instead, one after the other (K' by per-lane gathers into rows of 33 slots, U linearly: it is stored in fragment
+  // order), each requested under work that does not need it: 121 KB per tile.
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)i2tf_smem;
+  {
+    const unsigned char* const kh_p = (const unsigned char*)(a.Kh + (long long)p * 56 * T2I_C);
+    const unsigned char* const kl_p = (const unsigned char*)(a.Kl + (long long)p * 56 * T2I_C);
+#pragma unroll
+    for (int j = 0; j < (2 * I2TF_KNI + I2TF_WAVES - 1) / I2TF_WAVES; ++j) {
+      const int i = wave + I2TF_WAVES * j;
+      if (i < 2 * I2TF_KNI) {
+        const int plane = i / I2TF_KNI, slot = (i % I2TF_KNI) * 64 + lane;
+        const int row = min(slot / T2I_SLOTS, 55), col = min(slot % T2I_SLOTS, 31);
+        t2i_glds16(plane ? kl_p : kh_p, (unsigned)(row * T2I_C + col * 8) * 2u, lds0 + plane * I2TF_KPLANE + (i % I2TF_KNI) * 1024);
+      }
+    }
+  }
   // ---- first product: S^T[n, token] = K' X^T; second operand = the wave's 16 token rows ----
   f16x8 xh[8], xl[8];
   {
@@ -366,17 +388,29 @@ __global__ __launch_bounds__(256, 2) void dec_i2t_fold_kernel(I2TFArgs a) {
       xl[ks] = *(const f16x8*)(a.Xl + xb + 32 * ks);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   f32x4 s[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const long long kb = ((long long)p * 56 + min(16 * nt + r, 55)) * T2I_C + 8 * g;
+    const unsigned char* const kb = i2tf_smem + min(16 * nt + r, 55) * T2I_PITCH + 16 * g;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const f16x8 kh = *(const f16x8*)(a.Kh + kb + 32 * ks), kl = *(const f16x8*)(a.Kl + kb + 32 * ks);
+      const f16x8 kh = *(const f16x8*)(kb + 64 * ks), kl = *(const f16x8*)(kb + I2TF_KPLANE + 64 * ks);
       s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, xh[ks], s[nt], 0, 0, 0);
       s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, xl[ks], s[nt], 0, 0, 0);
       s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, xh[ks], s[nt], 0, 0, 0);
+    }
+  }
+  __syncthreads();      // every wave is done with K': the region takes the U fragments (requested under the soft-max)
+  {
+    const unsigned char* const uh_p = (const unsigned char*)(a.Uh + (long long)p * 16384);
+    const unsigned char* const ul_p = (const unsigned char*)(a.Ul + (long long)p * 16384);
+#pragma unroll
+    for (int j = 0; j < 64 / I2TF_WAVES; ++j) {
+      const int i = wave + I2TF_WAVES * j;      // 64 pieces of 1 KiB: plane i / 32, fragment i % 32
+      t2i_glds16(i < 32 ? uh_p : ul_p, (unsigned)((i & 31) * 1024 + lane * 16), lds0 + i * 1024);
     }
   }
   // ---- + positional term + bias term; soft-max over the 7 tokens of a head.  The lane holds, for token r of the wave,
@@ -414,16 +448,17 @@ __global__ __launch_bounds__(256, 2) void dec_i2t_fold_kernel(I2TFArgs a) {
     }
   }
   // ---- second product: D^T[channel, token] = U^T P^T; first operand from the fragment-ordered U planes ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   f32x4 acc[16];
   {
-    const _Float16* const uh = a.Uh + (long long)p * 16 * 2 * 64 * 8 + lane * 8;
-    const _Float16* const ul = a.Ul + (long long)p * 16 * 2 * 64 * 8 + lane * 8;
+    const unsigned char* const uf = i2tf_smem + lane * 16;
 #pragma unroll
     for (int d = 0; d < 16; ++d) {
       acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const f16x8 fh = *(const f16x8*)(uh + (d * 2 + ks) * 512), fl = *(const f16x8*)(ul + (d * 2 + ks) * 512);
+        const f16x8 fh = *(const f16x8*)(uf + (d * 2 + ks) * 1024), fl = *(const f16x8*)(uf + 32768 + (d * 2 + ks) * 1024);
         acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, ph[ks], acc[d], 0, 0, 0);
         acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, pl[ks], acc[d], 0, 0, 0);
         acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, ph[ks], acc[d], 0, 0, 0);
@@ -457,33 +492,44 @@ __global__ __launch_bounds__(256, 2) void dec_i2t_fold_kernel(I2TFArgs a) {
   const float rstd = rsqrtf(var * (1.f / 256.f) + a.eps);
   // ---- normalise, split, and leave through LDS so that a store instruction writes whole rows: the wave's 16 rows x 512 B
   // per plane, 8-byte chunks XOR-ed with the row ----
-  unsigned char* const sth = i2tf_smem + wave * (2 * 16 * 512);
-  unsigned char* const stl = sth + 16 * 512;
+  __syncthreads();      // every wave is done with U: the region becomes the four waves' staging areas
+  unsigned char* const sth = i2tf_smem + wave * (2 * 8 * 512);      // 8 rows x 512 B, hi; then lo
+  unsigned char* const stl = sth + 8 * 512;
 #pragma unroll
-  for (int d = 0; d < 16; ++d) {
-    const int ch = 16 * d + 4 * g;
-    const f32x4 lw = *(const f32x4*)(a.ln_w + ch), lb = *(const f32x4*)(a.ln_b + ch);
-    f16x4 hi4, lo4;
+  for (int half = 0; half < 2; ++half) {      // rows 0-7, then 8-15 of the wave's 16 (the staging area holds eight)
+    if ((r >> 3) == half) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float y = (acc[d][i] - mean) * rstd * lw[i] + lb[i];
-      _Float16 hh, ll;
-      hgl_split_hi_lo(y, hh, ll);
-      hi4[i] = hh;
-      lo4[i] = ll;
+      for (int d = 0; d < 16; ++d) {
+        const int ch = 16 * d + 4 * g;
+        const f32x4 lw = *(const f32x4*)(a.ln_w + ch), lb = *(const f32x4*)(a.ln_b + ch);
+        f16x4 hi4, lo4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float y = (acc[d][i] - mean) * rstd * lw[i] + lb[i];
+          _Float16 hh, ll;
+          hgl_split_hi_lo(y, hh, ll);
+          hi4[i] = hh;
+          lo4[i] = ll;
+        }
+        const unsigned off = (unsigned)((r & 7) * 512 + (((4 * d + g) ^ (4 * (r & 7))) & 63) * 8);
+        *(f16x4*)(sth + off) = hi4;
+        *(f16x4*)(stl + off) = lo4;
+      }
     }
-    const unsigned off = (unsigned)(r * 512 + (((4 * d + g) ^ (4 * r)) & 63) * 8);
-    *(f16x4*)(sth + off) = hi4;
-    *(f16x4*)(stl + off) = lo4;
-  }
-  // (the staging area is private to the wave: LDS operations of a wave execute in order, no barrier)
-  typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
+    // The staging area is private to the wave and the LDS operations of a wave execute in order: no s_barrier.  The fence is
+    // for the compiler: without it the lanes' exchange through LDS is a race in its memory model (it moved the second pass's
+    // reads under the first pass's mask, "this lane has not written since").
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int row = 2 * k + (lane >> 5), c16 = lane & 31;
-    const unsigned roff = (unsigned)(row * 512 + ((c16 ^ (2 * row)) & 31) * 16);
-    *(u32x4t*)(a.oh + (row0 + row) * T2I_C + c16 * 8) = *(const u32x4t*)(sth + roff);
-    *(u32x4t*)(a.ol + (row0 + row) * T2I_C + c16 * 8) = *(const u32x4t*)(stl + roff);
+    for (int k = 0; k < 4; ++k) {
+      const int row = 2 * k + (lane >> 5), c16 = lane & 31;
+      const unsigned roff = (unsigned)(row * 512 + ((c16 ^ (2 * row)) & 31) * 16);
+      *(f16x8*)(a.oh + (row0 + 8 * half + row) * T2I_C + c16 * 8) = *(const f16x8*)(sth + roff);      // (read with the element
+      *(f16x8*)(a.ol + (row0 + 8 * half + row) * T2I_C + c16 * 8) = *(const f16x8*)(stl + roff);      // type it was written with)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -534,6 +580,6 @@ int hgl_launch_dec_i2t_fold(const void* Xh, const void* Xl, const void* Kh, cons
   a.oh = (_Float16*)out_hi; a.ol = (_Float16*)out_lo; a.HW = HW;
   HGL_RESERVE_LDS((dec_i2t_fold_kernel), I2TF_LDS, "dec_i2t_fold");
   HglProfScope prof(HGL_PROF_OTHER, 2.0 * P * (double)HW * 256.0 * 56 * 2, 0.0, st);
-  hipLaunchKernelGGL(dec_i2t_fold_kernel, dim3((unsigned)(HW / I2TF_ROWS), (unsigned)P), dim3(256), I2TF_LDS, st, a);
+  hipLaunchKernelGGL(dec_i2t_fold_kernel, dim3((unsigned)(HW / I2TF_ROWS), (unsigned)P), dim3(64 * I2TF_WAVES), I2TF_LDS, st, a);
   return hgl_check_launch("dec_i2t_fold");
 }
