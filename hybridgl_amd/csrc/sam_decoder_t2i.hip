@@ -403,6 +403,23 @@ __global__ __launch_bounds__(64 * I2TF_WAVES, 2) void dec_i2t_fold_kernel(I2TFAr
       s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, xh[ks], s[nt], 0, 0, 0);
     }
   }
+  // The residual (the token's own row, hi + lo) enters the accumulators of the second product here, while the row's
+  // fragments of the first product are still in registers: D^T[channel, token] = E X^T with E the 16 x 32 selection matrix
+  // of channel tile d inside K step d >> 1 (1.0 x fp16 into fp32: exact).  Loading the rows again in the accumulators'
+  // layout was 32 eight-byte loads per lane at a 512-byte stride.
+  f32x4 acc[16];
+  {
+    f16x8 sel[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sel[e][j] = (8 * g + j == 16 * e + r) ? (_Float16)1.0f : (_Float16)0.0f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel[d & 1], xl[d >> 1], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel[d & 1], xh[d >> 1], acc[d], 0, 0, 0);
+    }
+  }
   __syncthreads();      // every wave is done with K': the region takes the U fragments (requested under the soft-max)
   {
     const unsigned char* const uh_p = (const unsigned char*)(a.Uh + (long long)p * 16384);
@@ -450,12 +467,10 @@ __global__ __launch_bounds__(64 * I2TF_WAVES, 2) void dec_i2t_fold_kernel(I2TFAr
   // ---- second product: D^T[channel, token] = U^T P^T; first operand from the fragment-ordered U planes ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  f32x4 acc[16];
   {
     const unsigned char* const uf = i2tf_smem + lane * 16;
 #pragma unroll
     for (int d = 0; d < 16; ++d) {
-      acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const f16x8 fh = *(const f16x8*)(uf + (d * 2 + ks) * 1024), fl = *(const f16x8*)(uf + 32768 + (d * 2 + ks) * 1024);
@@ -465,17 +480,15 @@ __global__ __launch_bounds__(64 * I2TF_WAVES, 2) void dec_i2t_fold_kernel(I2TFAr
       }
     }
   }
-  // ---- + b_o + residual (the token's own row, hi + lo); LayerNorm over its 256 channels: this lane holds channels
-  // 16 d + 4 g + i, the other three quarters sit 16 / 32 / 48 lanes away ----
+  // ---- + b_o; LayerNorm over the token's 256 channels: this lane holds channels 16 d + 4 g + i, the other three quarters
+  // sit 16 / 32 / 48 lanes away ----
   float sum = 0.f;
 #pragma unroll
   for (int d = 0; d < 16; ++d) {
-    const int ch = 16 * d + 4 * g;
-    const f16x4 rh = *(const f16x4*)(a.Xh + (row0 + r) * T2I_C + ch), rl = *(const f16x4*)(a.Xl + (row0 + r) * T2I_C + ch);
-    const f32x4 bo = *(const f32x4*)(a.bo + ch);
+    const f32x4 bo = *(const f32x4*)(a.bo + 16 * d + 4 * g);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      acc[d][i] = (acc[d][i] + bo[i]) + ((float)rh[i] + (float)rl[i]);
+      acc[d][i] += bo[i];
       sum += acc[d][i];
     }
   }

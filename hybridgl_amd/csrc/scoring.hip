@@ -1174,6 +1174,42 @@ __global__ __launch_bounds__(256) void blur_q8_v_kernel(const uint16_t* __restri
   out[i] = (uint8_t)(v > 255u ? 255u : v);
 }
 
+// Both passes in one launch: a workgroup owns a 32 x 64 pixel tile, stages the tile and its halo (k / 2 rows and columns each
+// side, reflect-101 at the image border) in LDS as bytes, runs the row pass into 16-bit LDS sums and the column pass out of
+// them.  An image byte is fetched (32 + 2r)(64 + 2r) / (32 x 64) = 1.76 times for k = 15 (the two-launch form above: every tap
+// of every pixel through the cache, and a 16-bit intermediate image written and read back); same integer arithmetic, same bits.
+constexpr int BLUR_TH = 32, BLUR_TW = 64, BLUR_RMAX = 15, BLUR_CMAX = 4;
+__global__ __launch_bounds__(256) void blur_q8_tile_kernel(const uint8_t* __restrict__ img, int H, int W, int C, BlurTapsQ8 t,
+                                                           uint8_t* __restrict__ out) {
+  __shared__ uint8_t src[(BLUR_TH + 2 * BLUR_RMAX) * (BLUR_TW + 2 * BLUR_RMAX) * BLUR_CMAX];
+  __shared__ uint16_t rsum[(BLUR_TH + 2 * BLUR_RMAX) * BLUR_TW * BLUR_CMAX];
+  const int r = t.k / 2, x0 = blockIdx.x * BLUR_TW, y0 = blockIdx.y * BLUR_TH;
+  const int rows = BLUR_TH + 2 * r, cols = BLUR_TW + 2 * r, rowb = cols * C, outb = BLUR_TW * C;
+  for (int i = threadIdx.x; i < rows * rowb; i += 256) {
+    const int yy = i / rowb, rem = i - yy * rowb, xx = rem / C, c = rem - xx * C;
+    const int gy = reflect101(min(y0 - r + yy, H - 1 + r), H), gx = reflect101(min(x0 - r + xx, W - 1 + r), W);
+    src[i] = img[((long long)gy * W + gx) * C + c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < rows * outb; i += 256) {
+    const int yy = i / outb, rem = i - yy * outb;
+    const uint8_t* s0 = src + yy * rowb + rem;
+    unsigned a = 0;
+    for (int j = 0; j < t.k; ++j) a += (unsigned)t.x[j] * s0[j * C];
+    rsum[i] = (uint16_t)a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < BLUR_TH * outb; i += 256) {
+    const int yy = i / outb, rem = i - yy * outb, xx = rem / C;
+    if (y0 + yy >= H || x0 + xx >= W) continue;
+    const uint16_t* s0 = rsum + yy * outb + rem;
+    unsigned a = 0;
+    for (int j = 0; j < t.k; ++j) a += (unsigned)t.y[j] * s0[j * outb];
+    const unsigned v = (a + 32768u) >> 16;
+    out[((long long)(y0 + yy) * W + x0) * C + rem] = (uint8_t)(v > 255u ? 255u : v);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1645,6 +1681,11 @@ int hgl_gaussian_blur_u8_q8(const uint8_t* img, int H, int W, int C, const uint1
   const long long total = (long long)H * W * C;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
+  if (C <= BLUR_CMAX) {      // (the workspace stays part of the signature: wider pixels take the two-launch form)
+    hipLaunchKernelGGL(blur_q8_tile_kernel, dim3((unsigned)((W + BLUR_TW - 1) / BLUR_TW), (unsigned)((H + BLUR_TH - 1) / BLUR_TH)),
+                       dim3(256), 0, st, img, H, W, C, t, out);
+    return hgl_check_launch("gaussian_blur_u8_q8");
+  }
   hipLaunchKernelGGL(blur_q8_h_kernel, dim3(blocks), dim3(256), 0, st, img, H, W, C, t, (uint16_t*)workspace);
   hipLaunchKernelGGL(blur_q8_v_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)workspace, H, W, C, t, out);
   return hgl_check_launch("gaussian_blur_u8_q8");

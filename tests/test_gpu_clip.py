@@ -311,6 +311,18 @@ def test_cv2_fixed_point_blur_bit_exact_vs_oracle(cuda, H, W, k):
     assert np.array_equal(ops.gaussian_blur_u8(torch.from_numpy(flat).to(cuda), k).cpu().numpy(), flat)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [1, 4, 6])
+def test_cv2_fixed_point_blur_other_channel_counts(cuda, C):
+    """1 and 4 channels go through the one-launch tile kernel like RGB, 6 through the two-launch form (rows of 16-bit sums in
+    the workspace): both bit-exact against the oracle, on a size that is not a multiple of the 32 x 64 tile."""
+    from hybridgl_amd import ops
+    from oracle import cv_oracle as CV
+    img = np.random.default_rng(C).integers(0, 256, size=(75, 131, C), dtype=np.uint8)
+    for k in (15, 31):
+        assert np.array_equal(ops.gaussian_blur_u8(torch.from_numpy(img).to(cuda), k).cpu().numpy(), CV.gaussian_blur_u8(img, k))
+
+
 def test_forward_accepts_what_the_reference_accepts(cuda, tiny):
     """model/backbone.py:123,160 cast whatever comes in (`x.type(self.model.dtype)`, `pred_masks.type(torch.float32)`): image
     tensors of another float type, non-contiguous views, masks as bool / uint8 / int64 / float {0, 1} give the same features;
