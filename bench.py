@@ -812,7 +812,8 @@ def main():
         # layer (5 encoder passes, 128 decoder batches, per-crop + cross-crop NMS over 12288 + 4 x 3072 candidates), 8 phrases
         # per image scored against one hybrid forward; at most 256 proposals per image go on (random weights: noise masks)
         from hybridgl_amd.sam import SamAutomaticMaskGenerator
-        gen_pc = SamAutomaticMaskGenerator(sam, points_per_side=64, points_per_batch=512, pred_iou_thresh=-1e30, stability_score_thresh=0.0,
+        PC_PPB = 1024      # prompts per decoder launch (a memory knob: the candidates do not depend on it; 512 in rounds 4-5)
+        gen_pc = SamAutomaticMaskGenerator(sam, points_per_side=64, points_per_batch=PC_PPB, pred_iou_thresh=-1e30, stability_score_thresh=0.0,
                                            crop_n_layers=1, crop_n_points_downscale_factor=2, min_mask_region_area=100)
         pc_refs = [synthetic_ref(100 + j, dev, N=args.masks, H=480, W=640, n_sent=8, sam_img_size=1024, gem=use_gem,
                                  device_blur=True)[0] for j in range(2)]
@@ -820,7 +821,7 @@ def main():
         # the CLIP stage of group g, fill and drain inside the timed region
         t = timed(make_pipe(g=gen_pc, fusion="G2L&L2G"), n_steps=6, cap=256, pool=pc_refs, group=2)
         also["PhraseCut"] = entry(t, 6, "PhraseCut-shaped item, run() in groups of 2 images: 480x640 image, heavy AMG (64x64 points, 1 crop layer, downscale 2, min "
-                                        "area 100, thresholds open, 512 prompts per decoder launch: points_per_batch is a memory knob), <= 256 of SAM's masks into CLIP G2L&L2G, 8 phrases x (sentence + noun "
+                                        f"area 100, thresholds open, {PC_PPB} prompts per decoder launch: points_per_batch is a memory knob), <= 256 of SAM's masks into CLIP G2L&L2G, 8 phrases x (sentence + noun "
                                         "phrase + 1 other noun) + 8 GEM prompts")
         also["PhraseCut"]["unit"] = "images/s (8 phrases each)"
         # algorithmic work of one PhraseCut-shaped image: 5 encoder passes (image + 4 crops), 4096 + 4 x 1024 prompts
@@ -832,10 +833,10 @@ def main():
                  + 32 * 12 * (2.0 * text_S * g_["text_D"] * 12 * g_["text_D"]) + (gem_flops_per_image(g_["gem_S"], g_["D"], g_["layers"], 6, g_["patch_k"], g_["embed"]) if use_gem else 0.0))
         also["PhraseCut"]["whole_step_algorithmic_tflops"] = pc_fl / t / 1e12
         also["PhraseCut"]["algorithmic_flops_per_image"] = pc_fl
-        # the stage that carries this configuration: the mask decoder on 8192 prompts per image.  Timed alone here (512 prompts
-        # per call, HIP events); its HBM bytes per prompt come from the committed counter pass over the same call
+        # the stage that carries this configuration: the mask decoder on 8192 prompts per image.  Timed alone here (PC_PPB prompts
+        # per call, HIP events); its HBM bytes per prompt come from the committed counter pass (529 prompts per call)
         emb_ = torch.randn(4096, 256, device=dev)
-        p01_ = torch.rand(512, 2, device=dev)
+        p01_ = torch.rand(PC_PPB, 2, device=dev)
         for _ in range(2):
             sam.decode_points(emb_, p01_)
         e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -847,10 +848,10 @@ def main():
         dec_ms = e0_.elapsed_time(e1_) / 4
         dec = {"bound": "hbm / valu (see DESIGN.md section 5.4: dec_tail_kernel is bound by element-wise arithmetic, dec_i2t_kernel, the q "
                         "projection and the token -> image attention on the raw token planes by the bytes of the per-prompt image tokens)",
-               "ms_per_64_prompts": dec_ms / 8, "algorithmic_gflop_per_prompt": 3.62,
-               "achieved": 512 * 3.62e9 / (dec_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
-               "frac_of_fp16_mfma_peak": 512 * 3.62e9 / (dec_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
-               "ms_per_image_at_8192_prompts": dec_ms * 16}
+               "prompts_per_launch": PC_PPB, "ms_per_64_prompts": dec_ms * 64 / PC_PPB, "algorithmic_gflop_per_prompt": 3.62,
+               "achieved": PC_PPB * 3.62e9 / (dec_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+               "frac_of_fp16_mfma_peak": PC_PPB * 3.62e9 / (dec_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
+               "ms_per_image_at_8192_prompts": dec_ms * 8192 / PC_PPB}
         # HBM bytes per prompt: the newest tracked counter pass (profiles/r*_decoder_traffic.json, tools/decoder_traffic.py)
         import glob as _glob
         dpaths = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_decoder_traffic.json")), reverse=True)
@@ -860,7 +861,7 @@ def main():
             try:
                 dj = json.load(open(dpaths[0]))
                 dec["bytes_per_prompt"] = dj["bytes_per_prompt"]
-                dec["TBps"] = dj["bytes_per_prompt"] * 512 / (dec_ms * 1e-3) / 1e12
+                dec["TBps"] = dj["bytes_per_prompt"] * PC_PPB / (dec_ms * 1e-3) / 1e12
                 dec["frac_of_hbm_peak"] = dec["TBps"] / PEAK_HBM_TBPS
                 dec["bytes_source"] = (f"profiles/{os.path.basename(dpaths[0])} (" + dj.get("source", "") + "), replayed -- not measured in this run")
             except Exception as e:
@@ -879,7 +880,7 @@ def main():
             e1_.record()
             torch.cuda.synchronize()
             gms = e0_.elapsed_time(e1_) / 4
-            dec["iou_gate_at_median"] = {"ms_per_64_prompts": gms / 8, "ms_per_image_at_8192_prompts": gms * 16,
+            dec["iou_gate_at_median"] = {"ms_per_64_prompts": gms * 64 / PC_PPB, "ms_per_image_at_8192_prompts": gms * 8192 / PC_PPB,
                                          "prompts_skipping_the_upscaling": float((~(iou_ > thr_).any(dim=1)).float().mean()),
                                          "note": "candidates identical with the gate on and off (tests/test_gpu_sam.py::"
                                                  "test_decoder_iou_gate_leaves_the_candidates_unchanged)"}

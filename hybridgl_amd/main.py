@@ -246,7 +246,7 @@ AMG_DEFAULTS = {   # Hybridgl_main.py:67-73 / Hybridgl_main_PhraseCut.py:56-62
     "refer": dict(points_per_side=8, pred_iou_thresh=0.7, stability_score_thresh=0.7, min_mask_region_area=800, crop_n_layers=0,
                   crop_n_points_downscale_factor=1, points_per_batch=64, group=16),
     "phrasecut": dict(points_per_side=64, pred_iou_thresh=0.86, stability_score_thresh=0.92, min_mask_region_area=100,
-                      crop_n_layers=1, crop_n_points_downscale_factor=2, points_per_batch=512, group=4),
+                      crop_n_layers=1, crop_n_points_downscale_factor=2, points_per_batch=1024, group=4),
 }
 
 

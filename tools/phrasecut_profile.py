@@ -18,7 +18,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 dev = torch.device("cuda:0")
 model = CLIPViTFM("ViT-B/16", seed=0, device=dev)
 sam = sam_model_registry["default"](seed=0, device=dev)
-gen = SamAutomaticMaskGenerator(sam, points_per_side=64, points_per_batch=512, pred_iou_thresh=-1e30, stability_score_thresh=0.0,
+gen = SamAutomaticMaskGenerator(sam, points_per_side=64, points_per_batch=int(os.environ.get("PC_PPB", "1024")), pred_iou_thresh=-1e30, stability_score_thresh=0.0,
                                 crop_n_layers=1, crop_n_points_downscale_factor=2, min_mask_region_area=100)
 pipe = HybridGLPipeline(model, "G2L&L2G", 9, mask_generator=gen, use_sam_masks=True, gem_model=create_gem_model("ViT-B/16", clip=model))
 refs = [synthetic_ref(100 + j, dev, N=64, H=480, W=640, n_sent=8, sam_img_size=1024, gem=True, device_blur=True)[0] for j in range(2)]
