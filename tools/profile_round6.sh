@@ -8,6 +8,12 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+# FIRST the mask decoder, 529 prompts per call (3 warm-up + 5 timed calls): bytes per prompt -- the bench line below replays the
+# newest profiles/r*_decoder_traffic.json, which is then this one
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_dec_fetch -o p -- python3 $R/tools/decoder_bench.py 5 23 > $O/${tag}_dec_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_dec_write -o p -- python3 $R/tools/decoder_bench.py 5 23 > $O/${tag}_dec_write.log 2>&1
+python3 $R/tools/decoder_traffic.py $O/${tag}_dec_fetch $O/${tag}_dec_write 8 529 ${tag} > $O/${tag}_decoder_traffic.log 2>&1
+cp $R/profiles/${tag}_decoder_traffic.json $O/ 2>/dev/null
 python3 $R/bench.py > $O/${tag}_bench_default.json 2> $O/${tag}_bench_default.err
 tail -c 300 $O/${tag}_bench_default.json | head -c 200; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats_serial -o p -- python3 $R/tools/group_profile.py 3 16 > $O/${tag}_stats_serial.log 2>&1
@@ -27,12 +33,12 @@ bash $R/tools/pmc_run.sh ${tag}_attn_clip "attn_ps_kernel<64, 0, 2>" tools/attn_
 for s in group16 group10; do for b in 0 1; do echo "== $s balanced=$b"; X3_SHAPES=$s X3_BALANCED=$b python3 $R/tools/x3_bench.py 2>&1 | grep -v amdgpu.ids; done; done > $O/${tag}_x3_balanced_ab.log
 # the scoring tail: pooling kernel time per launch (tools/pool_prof.sh)
 bash $R/tools/pool_prof.sh ${tag} > /dev/null 2>&1
-# the mask decoder, 529 prompts per call (3 warm-up + 5 timed calls): bytes per prompt
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${tag}_dec_fetch -o p -- python3 $R/tools/decoder_bench.py 5 23 > $O/${tag}_dec_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${tag}_dec_write -o p -- python3 $R/tools/decoder_bench.py 5 23 > $O/${tag}_dec_write.log 2>&1
-python3 $R/tools/decoder_traffic.py $O/${tag}_dec_fetch $O/${tag}_dec_write 8 529 ${tag} > $O/${tag}_decoder_traffic.log 2>&1
-cp $R/profiles/${tag}_decoder_traffic.json $O/ 2>/dev/null
 python3 $R/tools/decoder_bench.py 10 23 > $O/${tag}_decoder_bench.log 2>&1
+# PhraseCut-shaped items, stages back to back on one stream: per-kernel table of the heavy-AMG path
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_pc -o p -- python3 $R/tools/phrasecut_profile.py 4 > $O/${tag}_phrasecut_profile.log 2>&1
+s=$(find $O/${tag}_pc -name "*kernel_stats.csv" | head -1); [ -n "$s" ] && cp $s $O/${tag}_phrasecut_kernel_stats.csv
+rm -rf $O/${tag}_pc
+python3 $R/tools/phrasecut_profile.py 4 >> $O/${tag}_phrasecut_profile.log 2>&1
 python3 $R/tools/tail_bench.py > $O/${tag}_tail_bench.log 2>&1
 python3 $R/tools/attn_ps_ab.py 16 > $O/${tag}_attn_ps_ab.log 2>&1
 # the evaluator fed from disk as 8 ranks on this one GPU (832 images: 104 per rank) and as 1 rank
