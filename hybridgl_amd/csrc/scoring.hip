@@ -1174,39 +1174,52 @@ __global__ __launch_bounds__(256) void blur_q8_v_kernel(const uint16_t* __restri
   out[i] = (uint8_t)(v > 255u ? 255u : v);
 }
 
-// Both passes in one launch: a workgroup owns a 32 x 64 pixel tile, stages the tile and its halo (k / 2 rows and columns each
-// side, reflect-101 at the image border) in LDS as bytes, runs the row pass into 16-bit LDS sums and the column pass out of
-// them.  An image byte is fetched (32 + 2r)(64 + 2r) / (32 x 64) = 1.76 times for k = 15 (the two-launch form above: every tap
-// of every pixel through the cache, and a 16-bit intermediate image written and read back); same integer arithmetic, same bits.
-constexpr int BLUR_TH = 32, BLUR_TW = 64, BLUR_RMAX = 15, BLUR_CMAX = 4;
-__global__ __launch_bounds__(256) void blur_q8_tile_kernel(const uint8_t* __restrict__ img, int H, int W, int C, BlurTapsQ8 t,
-                                                           uint8_t* __restrict__ out) {
+// Both passes in one launch: a workgroup owns a BLUR_TH x BLUR_TW pixel tile, stages the tile and its halo (k / 2 rows and
+// columns each side, reflect-101 at the image border) in LDS as bytes, runs the row pass into 16-bit LDS sums and the column pass
+// out of them: the image is fetched from HBM once (the halos of neighbouring tiles hit in L2) and no 16-bit intermediate image
+// is written and read back (the two-launch form above: every tap of every pixel through the cache, 5.6x the image fetched).
+// Same integer arithmetic, same bits.  A thread owns one byte column of the tile in every phase and walks the rows (no
+// division inside the loops; the loads of consecutive rows are independent); the taps sit in LDS (indexed from the kernel
+// arguments every tap of every row was a scalar load).  Small tiles on purpose: the work of an image is tiny and a thread's
+// chain of rows x taps is what the launch takes -- 8 x 32 tiles give 1200 workgroups for 480 x 640.
+constexpr int BLUR_TH = 8, BLUR_TW = 32, BLUR_RMAX = 15, BLUR_CMAX = 4, BLUR_NT = 128;
+__global__ __launch_bounds__(BLUR_NT) void blur_q8_tile_kernel(const uint8_t* __restrict__ img, int H, int W, int C, BlurTapsQ8 t,
+                                                               uint8_t* __restrict__ out) {
   __shared__ uint8_t src[(BLUR_TH + 2 * BLUR_RMAX) * (BLUR_TW + 2 * BLUR_RMAX) * BLUR_CMAX];
   __shared__ uint16_t rsum[(BLUR_TH + 2 * BLUR_RMAX) * BLUR_TW * BLUR_CMAX];
+  __shared__ unsigned tapx[32], tapy[32];
   const int r = t.k / 2, x0 = blockIdx.x * BLUR_TW, y0 = blockIdx.y * BLUR_TH;
   const int rows = BLUR_TH + 2 * r, cols = BLUR_TW + 2 * r, rowb = cols * C, outb = BLUR_TW * C;
-  for (int i = threadIdx.x; i < rows * rowb; i += 256) {
-    const int yy = i / rowb, rem = i - yy * rowb, xx = rem / C, c = rem - xx * C;
-    const int gy = reflect101(min(y0 - r + yy, H - 1 + r), H), gx = reflect101(min(x0 - r + xx, W - 1 + r), W);
-    src[i] = img[((long long)gy * W + gx) * C + c];
+  if (threadIdx.x < 31) { tapx[threadIdx.x] = t.x[threadIdx.x]; tapy[threadIdx.x] = t.y[threadIdx.x]; }
+  for (int cb = threadIdx.x; cb < rowb; cb += BLUR_NT) {
+    const int xx = cb / C, c = cb - xx * C;
+    const uint8_t* const col = img + (long long)reflect101(min(x0 - r + xx, W - 1 + r), W) * C + c;
+#pragma unroll 8
+    for (int yy = 0; yy < rows; ++yy)
+      src[yy * rowb + cb] = col[(long long)reflect101(min(y0 - r + yy, H - 1 + r), H) * W * C];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < rows * outb; i += 256) {
-    const int yy = i / outb, rem = i - yy * outb;
-    const uint8_t* s0 = src + yy * rowb + rem;
-    unsigned a = 0;
-    for (int j = 0; j < t.k; ++j) a += (unsigned)t.x[j] * s0[j * C];
-    rsum[i] = (uint16_t)a;
+  for (int ob = threadIdx.x; ob < outb; ob += BLUR_NT) {
+#pragma unroll 2
+    for (int yy = 0; yy < rows; ++yy) {
+      const uint8_t* s0 = src + yy * rowb + ob;
+      unsigned a = 0;
+      for (int j = 0; j < t.k; ++j) a += tapx[j] * s0[j * C];
+      rsum[yy * outb + ob] = (uint16_t)a;
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < BLUR_TH * outb; i += 256) {
-    const int yy = i / outb, rem = i - yy * outb, xx = rem / C;
-    if (y0 + yy >= H || x0 + xx >= W) continue;
-    const uint16_t* s0 = rsum + yy * outb + rem;
-    unsigned a = 0;
-    for (int j = 0; j < t.k; ++j) a += (unsigned)t.y[j] * s0[j * outb];
-    const unsigned v = (a + 32768u) >> 16;
-    out[((long long)(y0 + yy) * W + x0) * C + rem] = (uint8_t)(v > 255u ? 255u : v);
+  for (int ob = threadIdx.x; ob < outb; ob += BLUR_NT) {
+    if (x0 + ob / C >= W) continue;
+    const int ny = min(BLUR_TH, H - y0);
+#pragma unroll 2
+    for (int yy = 0; yy < ny; ++yy) {
+      const uint16_t* s0 = rsum + yy * outb + ob;
+      unsigned a = 0;
+      for (int j = 0; j < t.k; ++j) a += tapy[j] * s0[j * outb];
+      const unsigned v = (a + 32768u) >> 16;
+      out[((long long)(y0 + yy) * W + x0) * C + ob] = (uint8_t)(v > 255u ? 255u : v);
+    }
   }
 }
 
@@ -1683,7 +1696,7 @@ int hgl_gaussian_blur_u8_q8(const uint8_t* img, int H, int W, int C, const uint1
   hipStream_t st = (hipStream_t)stream;
   if (C <= BLUR_CMAX) {      // (the workspace stays part of the signature: wider pixels take the two-launch form)
     hipLaunchKernelGGL(blur_q8_tile_kernel, dim3((unsigned)((W + BLUR_TW - 1) / BLUR_TW), (unsigned)((H + BLUR_TH - 1) / BLUR_TH)),
-                       dim3(256), 0, st, img, H, W, C, t, out);
+                       dim3(BLUR_NT), 0, st, img, H, W, C, t, out);
     return hgl_check_launch("gaussian_blur_u8_q8");
   }
   hipLaunchKernelGGL(blur_q8_h_kernel, dim3(blocks), dim3(256), 0, st, img, H, W, C, t, (uint16_t*)workspace);

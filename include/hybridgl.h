@@ -531,8 +531,9 @@ int hgl_sam_embed_masks(const HglSamDecoderW* w, const float* mask_input, int P,
  * out-projection + residual + norm4 in one launch (needs bit 1); bit 4 = token -> image attention as key chunks of 256 with
  * all heads per workgroup + a combine pass (either precision mode); bit 5 = the token -> image attention of layer 1 and the
  * final one on the RAW image-token planes -- the 7 tokens are projected through W_k / W_v instead of the image tokens, no
- * k | v projection GEMM (needs bits 1 and 2; one foreground point per prompt).  Sets the mask (mask >= 0; default all
- * stages, or HGL_SAM_DEC_FUSED) and returns the previous one; mask < 0 only queries.  Fused and unfused stages agree to
+ * k | v projection GEMM -- and layer 1's image -> token step with W_q / W_o folded into the 7 tokens the same way, no q
+ * projection GEMM (needs bits 1 and 2; one foreground point per prompt; grid * grid a multiple of 128).  Sets the mask (mask >= 0; default all
+ * stages) and returns the previous one; mask < 0 only queries.  Fused and unfused stages agree to
  * fp32 rounding: the switch exists for timing and for that test. */
 int hgl_sam_decoder_fusion(int mask);
 
