@@ -426,19 +426,21 @@ def test_fused_decoder_stages_equal_the_unfused_launches(cuda, name, P):
     torch.cuda.empty_cache()
 
 
-def test_decoder_large_prompt_batches_equal_small_ones(cuda):
-    """points_per_batch is a memory knob (automatic_mask_generator.py:244-255): 576 prompts in one decoder launch (what the
-    PhraseCut configuration of bench.py uses: token-side GEMMs of 4032 rows on the small-tile kernel, 9 216 key-chunk workgroups)
-    give the rows of nine launches of 64, bit for bit, at the ViT-H decoder size"""
+@pytest.mark.parametrize("n", [576, 1100])
+def test_decoder_large_prompt_batches_equal_small_ones(cuda, n):
+    """points_per_batch is a memory knob (automatic_mask_generator.py:244-255): 576 / 1100 prompts in one decoder launch (the
+    PhraseCut configuration of bench.py uses 1024: token-side GEMMs of 7168 rows on the small-tile kernel, one workgroup per
+    prompt in the raw-token attention, a positional GEMM of 57k rows) give the rows of launches of 64, bit for bit, at the ViT-H
+    decoder size"""
     name = "vit_h_d2"
     cfg = weights.SAM_CONFIGS[name]
     m = hsam.Sam(weights.sam_state_dict(name, 0), cfg, cuda)
     g = cfg["img_size"] // cfg["patch_size"]
     rng = np.random.default_rng(5)
     emb = T(rng.standard_normal((g * g, 256)).astype(np.float32), cuda)
-    p01 = T(rng.random((576, 2)).astype(np.float32), cuda)
+    p01 = T(rng.random((n, 2)).astype(np.float32), cuda)
     low, iou = m.decode_points(emb, p01)
-    for s in (0, 64, 512):
+    for s in (0, 64, n - 64):
         l2, i2 = m.decode_points(emb, p01[s:s + 64].contiguous())
         assert torch.equal(l2, low[s:s + 64]) and torch.equal(i2, iou[s:s + 64]), s
     assert torch.isfinite(low).all()
