@@ -379,7 +379,7 @@ def hbm_kernel_specs(N=64, H=640, W=640, S=3, K=192, g=1):
         "ccl_count_kernel": (N * px // 8, "bit plane read once"),
         "ccl_stats_kernel": (N * px // 8, "bit plane read once"),
         "ccl_apply_kernel": (N * px // 8 + N * px, "bit plane read + cleaned mask bytes written (+ the per-row box words)"),
-        "blur_q8_tile_kernel": (3 * px + 3 * px, "u8 image read, u8 image written (both passes in LDS; halo re-reads 1.76x from L2)"),
+        "blur_q8_tile_kernel": (3 * px + 3 * px, "u8 image read, u8 image written (both passes in LDS; the tile halos -- 3.9x the image -- are re-reads inside an XCD's L2)"),
         "mask_resize_kernel": (N * 14 * 14 * 4 * 2, "4 taps per output of the 14 x 14 CLS keep maps (never the 26 MB of masks)"),
         # LayerNorm between the fp32 residual stream and the split GEMM operands: 8 B per element (fp32 row in, fp16 hi + lo row
         # out) is the floor of such a pass, and launches differ in rows -- the measured bytes ARE the algorithmic bytes here

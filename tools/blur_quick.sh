@@ -23,3 +23,12 @@ torch.cuda.synchronize()
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/blurq -o p -- python3 /tmp/blur_one.py > /dev/null 2>&1
 python tools/stats_top.py gpurun_out/blurq 1 4
+for c in FETCH_SIZE WRITE_SIZE; do
+rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/blurq_$c -o p -- python3 /tmp/blur_one.py > /dev/null 2>&1
+python3 - <<PY
+import csv, glob
+f = glob.glob("gpurun_out/blurq_$c/**/*counter_collection.csv", recursive=True)[0]
+v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "blur" in r["Kernel_Name"]]
+print("$c per launch (raw counter units):", sum(v) / 20)
+PY
+done
