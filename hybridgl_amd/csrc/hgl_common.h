@@ -280,15 +280,19 @@ int hgl_launch_pe_labeled(const float* coords01, const int32_t* labels, const fl
 // fused decoder stages (sam_decoder_fused.hip)
 // token -> image attention of the mask decoder on the raw image-token planes (sam_decoder_t2i.hip)
 int hgl_launch_t2i_fold_q(const float* q1, const float* Wk, float scale, float* Qk, int P, hipStream_t st);
+// ns = hgl_t2i_key_ranges(P, HW): 1 -> out = the attended rows [P*56, 256]; 8 (prompt batches of <= 128) -> out = key-range partials
+// of hgl_t2i_part_bytes(P, HW) bytes, which hgl_launch_t2i_unfold_v (same ns) puts together
+int hgl_t2i_key_ranges(int P, int HW);
+size_t hgl_t2i_part_bytes(int P, int HW);
 int hgl_launch_t2i_raw_attn(const void* Qh, const void* Ql, const float* bias, const void* Kh, const void* Kl, int P, int HW,
-                            float* out, hipStream_t st);
+                            float* out, int ns, hipStream_t st);
 int hgl_launch_i2t_prep(const float* k1, const float* v1, const float* Wq, const float* bq, const float* Wo, float scale, void* Kh,
                         void* Kl, float* cb, void* Uh, void* Ul, int P, hipStream_t st);
 unsigned long long hgl_split_overflow_decoder(int reset);
 int hgl_launch_dec_i2t_fold(const void* Xh, const void* Xl, const void* Kh, const void* Kl, const float* pek, const float* cb,
                             const void* Uh, const void* Ul, const float* bo, const float* ln_w, const float* ln_b, float eps, int P,
                             int HW, void* out_hi, void* out_lo, hipStream_t st);
-int hgl_launch_t2i_unfold_v(const float* A, const float* Wv, const float* bv, float* att, int P, hipStream_t st);
+int hgl_launch_t2i_unfold_v(const float* A, int ns, const float* Wv, const float* bv, float* att, int P, hipStream_t st);
 int hgl_launch_dec_tail(const void* src_hi, const void* src_lo, const float* up0_w, const float* up0_b, const float* ln_w,
                         const float* ln_b, const float* up3_w, const float* up3_b, const float* hyper, int row0, int P, int g,
                         float eps, float* low_res, const uint8_t* skip, hipStream_t st);

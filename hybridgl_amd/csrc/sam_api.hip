@@ -454,8 +454,11 @@ int dec_t2i_raw(const HglSamDecoderW* w, const HglSamAttnW& a, const float* qpe,
   // bias[p*56 + r, key] = Qk[p*56 + r, :] . pe[key, :]: pe is the "weight" [HW, C] of a split-fp16 GEMM
   HGL_TRY(hgl_launch_gemm_f16x3(Qh, Ql, C, w->dense_pe, nullptr, nullptr, 0, bias, nullptr, nullptr, HW, P * 56, HW, C,
                                 HGL_ACT_NONE, st));
-  HGL_TRY(hgl_launch_t2i_raw_attn(Qh, Ql, bias, keysS.hi, keysS.lo, P, HW, A, st));
-  HGL_TRY(hgl_launch_t2i_unfold_v(A, a.v.w, a.v.b, att, P, st));
+  // (prompt batches of <= 128: eight key ranges per prompt, their partial rows behind the folded queries; see the kernel)
+  const int ns = hgl_t2i_key_ranges(P, HW);
+  float* const rows = ns > 1 ? A + (size_t)P * 56 * C : A;
+  HGL_TRY(hgl_launch_t2i_raw_attn(Qh, Ql, bias, keysS.hi, keysS.lo, P, HW, rows, ns, st));
+  HGL_TRY(hgl_launch_t2i_unfold_v(rows, ns, a.v.w, a.v.b, att, P, st));
   return lin(att, I, a.out, queries, C, queries, C, P * T, C, I, HGL_ACT_NONE, st);
 }
 
@@ -647,7 +650,7 @@ static int decode_impl(const HglSamDecoderW* w, const float* emb, const float* p
   // through W_k / W_v instead of the HW image tokens: no k | v projection GEMM; layer 1 projects q alone for its step 4)
   const bool raw_t2i = merged && (dec_fusion_mask() & 32) && (dec_fusion_mask() & 4) && T == 7 && I1 == 128 && w->heads == 8 &&
                        C == 256 && HW % 128 == 0 && P <= 65535 && !perprompt && hgl_has_split_weight(w->dense_pe) &&
-                       (size_t)P * (56 * C * 8) <= atti_bytes &&                       // dec_t2i_raw: Q' planes + attended rows
+                       (size_t)P * (56 * C * 8) + hgl_t2i_part_bytes(P, HW) <= atti_bytes &&   // dec_t2i_raw: Q' planes + attended rows (+ partials)
                        (size_t)P * (56 * C * 4 + 16384 * 4 + 256) <= atti_bytes;      // step (4): K' and U planes + cb
   for (int li = 0; li < 2; ++li) {
     const auto& L = w->layer[li];

@@ -92,12 +92,46 @@ __global__ __launch_bounds__(256) void t2i_fold_q_kernel(const float* __restrict
 }
 
 // att[p, t, 16h + i] = A[p, h*7 + t, :] . Wv[16h + i, :] + bv[16h + i]
-__global__ __launch_bounds__(256) void t2i_unfold_v_kernel(const float* __restrict__ A, const float* __restrict__ Wv,
+// ns > 1: A is not the attended rows but ns partial results per prompt, one per key range (small prompt batches, see
+// t2i_raw_attn_kernel): part = [P][ns] x { O[56][256] un-normalised, ml[56][2] = (row maximum, row sum) }; the rows are put
+// together here, on the way into LDS: A[q, :] = sum_s O_s[q, :] 2^((m_s - M) log2 e) / sum_s l_s 2^((m_s - M) log2 e).
+constexpr int T2I_PART = T2I_ROWS * T2I_C + T2I_ROWS * 2;      // floats of one partial
+__global__ __launch_bounds__(256) void t2i_unfold_v_kernel(const float* __restrict__ A, int ns, const float* __restrict__ Wv,
                                                            const float* __restrict__ bv, float* __restrict__ att) {
   __shared__ float As[T2I_ROWS * T2I_C];      // 57 344 B
+  __shared__ float wgt[8 * T2I_ROWS];         // per (key range, row): 2^((m_s - M) log2 e) / L
   const int p = blockIdx.x;
-  for (int i = threadIdx.x; i < T2I_ROWS * T2I_C / 4; i += 256)
-    ((f32x4*)As)[i] = ((const f32x4*)(A + (long long)p * T2I_ROWS * T2I_C))[i];
+  if (ns > 1) {
+    const float* const part = A + (long long)p * ns * T2I_PART;
+    if (threadIdx.x < T2I_ROWS) {
+      const int q = threadIdx.x;
+      float M = -INFINITY;
+      for (int s = 0; s < ns; ++s) M = fmaxf(M, part[(long long)s * T2I_PART + T2I_ROWS * T2I_C + 2 * q]);
+      float L = 0.f;
+      for (int s = 0; s < ns; ++s) {
+        const float* ml = part + (long long)s * T2I_PART + T2I_ROWS * T2I_C + 2 * q;
+        const float e = exp2f((ml[0] - M) * T2I_LOG2E);
+        wgt[s * T2I_ROWS + q] = e;
+        L += ml[1] * e;
+      }
+      const float inv = 1.0f / L;
+      for (int s = 0; s < ns; ++s) wgt[s * T2I_ROWS + q] *= inv;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T2I_ROWS * T2I_C / 4; i += 256) {
+      const int q = i >> 6;      // 64 four-float pieces per row
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < ns; ++s) {
+        const f32x4 o = ((const f32x4*)(part + (long long)s * T2I_PART))[i];
+        const float w = wgt[s * T2I_ROWS + q];
+        acc[0] = fmaf(o[0], w, acc[0]); acc[1] = fmaf(o[1], w, acc[1]); acc[2] = fmaf(o[2], w, acc[2]); acc[3] = fmaf(o[3], w, acc[3]);
+      }
+      ((f32x4*)As)[i] = acc;
+    }
+  } else {
+    for (int i = threadIdx.x; i < T2I_ROWS * T2I_C / 4; i += 256)
+      ((f32x4*)As)[i] = ((const f32x4*)(A + (long long)p * T2I_ROWS * T2I_C))[i];
+  }
   __syncthreads();
   const int col = threadIdx.x & 127, h = col >> 4;
   const float* wrow = Wv + (long long)col * T2I_C;
@@ -117,8 +151,8 @@ struct T2IArgs {
   const _Float16 *Qh, *Ql;     // [P*56, 256] scaled folded queries
   const float* bias;           // [P*56, HW]  Qk . pe^T (scaled)
   const _Float16 *Kh, *Kl;     // [P*HW, 256] image-token planes
-  float* out;                  // [P*56, 256]
-  int HW;
+  float* out;                  // [P*56, 256]; with ns > 1: the partials [P][ns] x T2I_PART floats (see t2i_unfold_v_kernel)
+  int HW, ns;                  // ns key ranges per prompt, one workgroup each (grid.y)
 };
 
 __global__ __launch_bounds__(256, 2) void t2i_raw_attn_kernel(T2IArgs a) {
@@ -127,7 +161,11 @@ __global__ __launch_bounds__(256, 2) void t2i_raw_attn_kernel(T2IArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int p = blockIdx.x;
-  const int nchunks = a.HW / T2I_CHUNK;
+  // Small prompt batches (the RefCOCO configuration decodes 64 prompts per image): one workgroup per prompt leaves three
+  // quarters of the CUs without work and each of the others alone with its chunk loop (290 us per launch of 64 prompts, 63 us
+  // per 64 at 1024).  The key range is then cut into ns = 8 pieces, a workgroup each; the pieces leave their un-normalised
+  // rows with (maximum, sum) and t2i_unfold_v_kernel puts them together.
+  const int nchunks = a.HW / T2I_CHUNK / a.ns, chunk0 = (int)blockIdx.y * nchunks;
   const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)t2i_smem;
 
   // ---- this wave's DMA pieces: instruction i (0 .. 33) = plane i / 17, slots 64 (i % 17) .. +63 of that plane ----
@@ -152,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void t2i_raw_attn_kernel(T2IArgs a) {
       }
     }
   };
-  issue(0, 0);
+  issue(chunk0, 0);
 
   // ---- the wave's 16 query rows: second operand of S^T = K Q'^T, lane (query r, group g) holds channels 32 ks + 8 g .. +7 ----
   const int qrow = min(16 * wave + r, T2I_ROWS - 1);
@@ -163,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void t2i_raw_attn_kernel(T2IArgs a) {
     qh[ks] = *(const f16x8*)(a.Qh + qbase + 32 * ks);
     ql[ks] = *(const f16x8*)(a.Ql + qbase + 32 * ks);
   }
-  const float* const brow = a.bias + ((long long)p * T2I_ROWS + qrow) * a.HW + 4 * g;
+  const float* const brow = a.bias + ((long long)p * T2I_ROWS + qrow) * a.HW + chunk0 * T2I_CHUNK + 4 * g;
   f32x4 bnext[2];
   bnext[0] = *(const f32x4*)(brow);
   bnext[1] = *(const f32x4*)(brow + 16);
@@ -181,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void t2i_raw_attn_kernel(T2IArgs a) {
     const int stage = c & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk c has landed (and the bias vectors requested a chunk ago)
     __syncthreads();                                      // ... for every wave; and nobody reads the other stage any more
-    if (c + 1 < nchunks) issue(c + 1, stage ^ 1);
+    if (c + 1 < nchunks) issue(chunk0 + c + 1, stage ^ 1);
     const f32x4 b0 = bnext[0], b1 = bnext[1];
     if (c + 1 < nchunks) {
       bnext[0] = *(const f32x4*)(brow + (c + 1) * T2I_CHUNK);
@@ -247,6 +285,19 @@ __global__ __launch_bounds__(256, 2) void t2i_raw_attn_kernel(T2IArgs a) {
   // ---- normalise and store: lane (query r, group g) holds channels 16 d + 4 g .. +3 of its query ----
   lsum += __shfl_xor(lsum, 16);
   lsum += __shfl_xor(lsum, 32);
+  if (a.ns > 1) {      // this key range's share: un-normalised rows + (maximum, sum)
+    if (16 * wave + r < T2I_ROWS) {
+      float* const part = a.out + ((long long)p * a.ns + blockIdx.y) * T2I_PART;
+      float* const orow = part + (16 * wave + r) * T2I_C + 4 * g;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) *(f32x4*)(orow + 16 * d) = oacc[d];
+      if (g == 0) {
+        part[T2I_ROWS * T2I_C + 2 * (16 * wave + r)] = m;
+        part[T2I_ROWS * T2I_C + 2 * (16 * wave + r) + 1] = lsum;
+      }
+    }
+    return;
+  }
   const float inv = 1.0f / lsum;
   if (16 * wave + r < T2I_ROWS) {
     float* const orow = a.out + ((long long)p * T2I_ROWS + 16 * wave + r) * T2I_C + 4 * g;
@@ -556,22 +607,27 @@ int hgl_launch_t2i_fold_q(const float* q1, const float* Wk, float scale, float* 
   return hgl_check_launch("t2i_fold_q");
 }
 
+int hgl_t2i_key_ranges(int P, int HW) { return (P <= 128 && HW % (8 * T2I_CHUNK) == 0) ? 8 : 1; }
+size_t hgl_t2i_part_bytes(int P, int HW) { return (size_t)P * hgl_t2i_key_ranges(P, HW) * T2I_PART * sizeof(float); }
+
 int hgl_launch_t2i_raw_attn(const void* Qh, const void* Ql, const float* bias, const void* Kh, const void* Kl, int P, int HW,
-                            float* out, hipStream_t st) {
+                            float* out, int ns, hipStream_t st) {
   HGL_REQUIRE(HW % T2I_CHUNK == 0 && HW >= T2I_CHUNK && P > 0, "t2i_raw_attn: %d image tokens unsupported", HW);
+  HGL_REQUIRE(ns == 1 || (ns == 8 && HW % (8 * T2I_CHUNK) == 0), "t2i_raw_attn: %d key ranges over %d image tokens", ns, HW);
   HGL_REQUIRE((((uintptr_t)Qh | (uintptr_t)Ql | (uintptr_t)bias | (uintptr_t)Kh | (uintptr_t)Kl | (uintptr_t)out) & 15) == 0,
               "t2i_raw_attn: operands must be 16-byte aligned");
   T2IArgs a;
   a.Qh = (const _Float16*)Qh; a.Ql = (const _Float16*)Ql; a.bias = bias;
-  a.Kh = (const _Float16*)Kh; a.Kl = (const _Float16*)Kl; a.out = out; a.HW = HW;
+  a.Kh = (const _Float16*)Kh; a.Kl = (const _Float16*)Kl; a.out = out; a.HW = HW; a.ns = ns;
   HGL_RESERVE_LDS((t2i_raw_attn_kernel), T2I_LDS, "t2i_raw_attn");
   HglProfScope prof(HGL_PROF_ATTN, 4.0 * P * T2I_ROWS * (double)HW * T2I_C, 0.0, st);
-  hipLaunchKernelGGL(t2i_raw_attn_kernel, dim3((unsigned)P), dim3(256), T2I_LDS, st, a);
+  hipLaunchKernelGGL(t2i_raw_attn_kernel, dim3((unsigned)P, (unsigned)ns), dim3(256), T2I_LDS, st, a);
   return hgl_check_launch("t2i_raw_attn");
 }
 
-int hgl_launch_t2i_unfold_v(const float* A, const float* Wv, const float* bv, float* att, int P, hipStream_t st) {
-  hipLaunchKernelGGL(t2i_unfold_v_kernel, dim3((unsigned)P), dim3(256), 0, st, A, Wv, bv, att);
+int hgl_launch_t2i_unfold_v(const float* A, int ns, const float* Wv, const float* bv, float* att, int P, hipStream_t st) {
+  HGL_REQUIRE(ns >= 1 && ns <= 8, "t2i_unfold_v: %d key ranges", ns);
+  hipLaunchKernelGGL(t2i_unfold_v_kernel, dim3((unsigned)P), dim3(256), 0, st, A, ns, Wv, bv, att);
   return hgl_check_launch("t2i_unfold_v");
 }
 

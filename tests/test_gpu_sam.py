@@ -430,8 +430,10 @@ def test_fused_decoder_stages_equal_the_unfused_launches(cuda, name, P):
 def test_decoder_large_prompt_batches_equal_small_ones(cuda, n):
     """points_per_batch is a memory knob (automatic_mask_generator.py:244-255): 576 / 1100 prompts in one decoder launch (the
     PhraseCut configuration of bench.py uses 1024: token-side GEMMs of 7168 rows on the small-tile kernel, one workgroup per
-    prompt in the raw-token attention, a positional GEMM of 57k rows) give the rows of launches of 64, bit for bit, at the ViT-H
-    decoder size"""
+    prompt in the raw-token attention, a positional GEMM of 57k rows) give the rows of launches of 192, bit for bit, at the ViT-H
+    decoder size.  Launches of at most 128 prompts cut the key range of the token -> image attention into eight pieces per
+    prompt (one workgroup per prompt would leave most of the chip idle): their rows are the same sums in another order --
+    equal to fp32 rounding, and bit for bit among themselves (64 of 64 == 64 of 128)."""
     name = "vit_h_d2"
     cfg = weights.SAM_CONFIGS[name]
     m = hsam.Sam(weights.sam_state_dict(name, 0), cfg, cuda)
@@ -440,10 +442,15 @@ def test_decoder_large_prompt_batches_equal_small_ones(cuda, n):
     emb = T(rng.standard_normal((g * g, 256)).astype(np.float32), cuda)
     p01 = T(rng.random((n, 2)).astype(np.float32), cuda)
     low, iou = m.decode_points(emb, p01)
-    for s in (0, 64, n - 64):
-        l2, i2 = m.decode_points(emb, p01[s:s + 64].contiguous())
-        assert torch.equal(l2, low[s:s + 64]) and torch.equal(i2, iou[s:s + 64]), s
+    for s in (0, 192, n - 192):
+        l2, i2 = m.decode_points(emb, p01[s:s + 192].contiguous())
+        assert torch.equal(l2, low[s:s + 192]) and torch.equal(i2, iou[s:s + 192]), s
     assert torch.isfinite(low).all()
+    scale = float(low.abs().max())
+    l64, i64 = m.decode_points(emb, p01[64:128].contiguous())
+    assert float((l64 - low[64:128]).abs().max()) <= 2e-5 * max(1.0, scale) and float((i64 - iou[64:128]).abs().max()) <= 2e-5
+    l128, i128 = m.decode_points(emb, p01[:128].contiguous())
+    assert torch.equal(l128[64:], l64) and torch.equal(i128[64:], i64)
     del m, low
     torch.cuda.empty_cache()
 
