@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""SAM mask decoder at small prompt batches (64 = one RefCOCO image, 256): the raw-token path (fusion bit 5: key ranges cut into
+eight workgroups per prompt at <= 128 prompts) beside the projected path (bit 5 off).  usage: decoder_small_batch.py"""
 import sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
