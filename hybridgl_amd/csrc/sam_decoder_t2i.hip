@@ -17,7 +17,8 @@
 // of 12.6 MB per prompt and attention.  Exact in real arithmetic; in floating point every product is the split-fp16 triple
 // (hi*hi + hi*lo + lo*hi into fp32) as everywhere else: equal to the projected path to fp32 rounding (tests/test_gpu_sam.py).
 //
-// t2i_raw_attn_kernel.  One workgroup of four waves per prompt; wave w owns query rows 16w .. 16w+15 (of the 56) and ALL 256
+// t2i_raw_attn_kernel.  One workgroup of four waves per prompt (per eighth of a prompt's keys in launches of <= 128 prompts, the
+// pieces joined by t2i_unfold_v_kernel); wave w owns query rows 16w .. 16w+15 (of the 56) and ALL 256
 // channels: S^T = K Q'^T (v_mfma_f32_16x16x32_f16: first operand rows of the staged key chunk, second operand the wave's 16
 // query rows, register-resident for the whole prompt: 8 K steps x hi / lo = 64 VGPRs) -- the accumulator then holds, per lane,
 // query (lane & 15) and keys 4g .. 4g+3 (g = lane >> 4) of each 16-key tile, which is exactly the B operand of
@@ -26,6 +27,9 @@
 // no second copy of the chunk, no exchange between the waves.  Key chunks of 32 go global -> LDS by LDS-DMA into two stages, one
 // barrier per chunk; two workgroups per CU (68 KB of LDS each) cover each other's waits.  Online soft-max in base 2 with the
 // rescaling skipped while no row's maximum moves.
+//
+// The image -> token step of layer 1 with W_q / W_o folded into the same 7 tokens (i2t_prep_kernel, dec_i2t_fold_kernel) is
+// described at those kernels, further down.
 #include "hgl_common.h"
 
 bool hgl_get_split_weight(const float* W, const void** hi, const void** lo, int* scale_log2, int* N, int* K);
