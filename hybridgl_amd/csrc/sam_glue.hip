@@ -872,7 +872,9 @@ __global__ __launch_bounds__(256) void sam_postprocess_kernel(PostArgs a) {
 constexpr int PX1 = 112;            // max stage-1 columns of a tile (64 output columns at a 1.6 : 1 size ratio: 104).  Wider
                                     // tables (192 columns = 47 KB of LDS, for the 2.7 : 1 crops of a crop layer) measured SLOWER
                                     // than the per-pixel kernel there (3.1 against 2.0 ms per crop): three workgroups per CU
-                                    // do not hide the load -> build -> interpolate chain of a tile
+                                    // do not hide the load -> build -> interpolate chain of a tile.  Round 6: 32-column tiles
+                                    // (88 stage-1 columns: these tables, 128 threads) on the same crops: 3.1 ms again -- the
+                                    // table of a tile costs what its 2048 pixels save
 
 __global__ __launch_bounds__(256) void sam_postprocess_sep_kernel(PostArgs a) {
   __shared__ float patch[PR * PR];
